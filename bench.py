@@ -1,0 +1,186 @@
+#!/usr/bin/env python
+"""bench.py -- headline benchmark: beamformed subband frames/s, 64-mic 512-bin SubbandGSC.
+
+One "step" = one pass of the hot path over one batch of synthetic input resident in HBM:
+    S streams x 64 channels of PCM -> oversampled-DFT analysis (M=512, m=4, r=1)
+    -> SubbandGSC apply (wq - B wa, 257 bins) -> synthesis -> S output signals.
+`value` counts beamformed frames (S*T per step per GPU) per second, aggregated over all ranks.
+Multi-GPU: streams are sharded over ranks (independent utterances, no data-path collective);
+one process per GPU, launched by torch.distributed.run; scaling is weak.
+
+Prints ONE JSON line on rank 0 (see the driver contract in the task description), including
+  roofline     -- the dominant kernel (analysis bank) against the HBM roofline,
+  cpu_baseline -- the oracle (loop-faithful port of the reference's CPU path) on 1 host core.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK = 8.0e12          # B/s, MI355X spec (MI355X_MICROARCH.md)
+FS = 16000.0
+
+
+def synth_pcm_device(torch, dev, S, N, L, delays, seed):
+    """int16-scale synthetic PCM [S][N][L] generated on the device (SURVEY 8(d) distribution:
+    iid N(0,1000^2) noise + a common N(0,3000^2) target delayed per channel, rounded, clipped)."""
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    pcm = torch.empty((S, N, L), dtype=torch.float32, device=dev)
+    for s in range(S):
+        tgt = torch.randn(L + 64, generator=g, device=dev) * 3000.0
+        noise = torch.randn((N, L), generator=g, device=dev) * 1000.0
+        for c in range(N):
+            sh = int(round(delays[c] * FS))
+            noise[c] += tgt[32 + sh: 32 + sh + L]
+        pcm[s] = noise.round_().clamp_(-32767, 32767)
+    return pcm
+
+
+def cpu_baseline(N, M, m, r, dct, frames):
+    """Time the oracle's frame-by-frame pull graph (N analysis banks -> SubbandGSC -> synthesis)
+    on ONE host core, on a bounded sample of the same workload."""
+    from oracle import oracle as orc
+    from tests.util import design_prototype, synthetic_pcm
+    D = M >> r
+    h, g = design_prototype(M, m), design_prototype(M, m, "g")
+    pcm, delays = synthetic_pcm(1, N, frames * D, seed=20260927)
+    wq = orc.calc_mainlobe(M, N, FS, delays)
+    wl = np.zeros((M, N), np.complex128)
+    t0 = time.perf_counter()
+    _, nbf = orc.pipeline_gsc(h, g, M, m, r, dct, pcm[0], wq, wl)
+    dt = time.perf_counter() - t0
+    return {"value": nbf / dt, "unit": "frames/s", "cores": 1, "kind": "port",
+            "sample": "%d-mic %d-bin SubbandGSC chain, %d frames, 1 stream, oracle/btk_oracle.c -O3" % (N, M, nbf),
+            "xRT": nbf / dt / (FS / D)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--mics", type=int, default=64)
+    ap.add_argument("--bins", type=int, default=512)
+    ap.add_argument("--streams", type=int, default=16, help="utterance streams per GPU")
+    ap.add_argument("--frames", type=int, default=4096, help="frames per stream per step")
+    ap.add_argument("--cpu-frames", type=int, default=6000)
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    from distant_speech_recognition_amd import engine as eng
+    from tests.util import design_prototype, ula_positions, la_delays
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    N, M, m, r, dct = args.mics, args.bins, 4, 1, 2
+    D, K = M >> r, M // 2 + 1
+    S, T = args.streams, args.frames
+    h, g = design_prototype(M, m), design_prototype(M, m, "g")
+    afb = eng.FilterBank(h, M, m, r, dct)
+    sfb = eng.FilterBank(g, M, m, r, dct, synthesis=True)
+    L = (T - afb.processing_delay + afb.lookahead) * D          # so that num_frames(L) == T
+    assert afb.num_frames(L) == T
+    delays = la_delays(ula_positions(N), -1.306379)
+    pcm = synth_pcm_device(torch, dev, S, N, L, delays, seed=20260927 + 1000 * rank)
+
+    # SubbandGSC weights: quiescent + blocking matrix + a fixed (non-zero) active weight vector
+    wq = eng.weights_mainlobe(M, N, FS, delays)
+    rng = np.random.default_rng(0)
+    wl = np.zeros((M, N), np.complex128)
+    for k in range(1, K):
+        B = eng.weights_blocking_matrix(wq[k], 1)
+        wl[k] = eng.weights_sidelobe(B, (rng.normal(size=N - 1) + 1j * rng.normal(size=N - 1)) * 0.01)
+    W = torch.from_numpy(eng.weights_gsc_effective(wq, wl, M)).to(dev)
+
+    X = torch.empty((S, K, N, T), dtype=torch.complex64, device=dev)
+    Y = torch.empty((S, K, T), dtype=torch.complex64, device=dev)
+    nblk = sfb.num_blocks(T)
+    out = torch.empty((S, nblk * D), dtype=torch.float32, device=dev)
+
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(args.steps)]
+
+    def step(e=None):
+        if e: e[0].record()
+        afb.analysis(pcm, out=X)
+        if e: e[1].record()
+        eng.bf_apply(W, X, out=Y)
+        if e: e[2].record()
+        sfb.synthesize(Y, out=out)
+        if e: e[3].record()
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if dist: dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(ev[i])
+    torch.cuda.synchronize()
+    if dist: dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    t_ana = np.mean([e[0].elapsed_time(e[1]) for e in ev]) * 1e-3
+    t_bf = np.mean([e[1].elapsed_time(e[2]) for e in ev]) * 1e-3
+    t_syn = np.mean([e[2].elapsed_time(e[3]) for e in ev]) * 1e-3
+
+    if rank == 0:
+        frames_per_step = S * T * world
+        value = frames_per_step * args.steps / elapsed
+        b_ana = (4 * D + 8 * K) * N * S * T            # algorithmic bytes per analysis launch
+        b_bf = 8 * K * (N + 1) * S * T
+        b_syn = (8 * K + 4 * D) * S * T
+        res = {
+            "metric": "beamformed subband frames/sec, 64-mic 512-bin SubbandGSC",
+            "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "complex64 (f32)", "data": "synthetic",
+            "xRT": value / (FS / D),
+            "config": {"workload": "C0: %d-mic %d-bin SubbandGSC, analysis->GSC apply->synthesis, m=4 r=1 (D=%d), "
+                                   "%d streams/GPU x %d frames/step" % (N, M, D, S, T),
+                       "streams_per_gpu": S, "frames_per_stream": T, "parallelism": "stream-sharded x%d" % world},
+            "roofline": {"bound": "hbm", "kernel": "analysis_kernel", "achieved": b_ana / t_ana / 1e9, "peak": HBM_PEAK / 1e9,
+                         "unit": "GB/s", "frac": b_ana / t_ana / HBM_PEAK, "traffic": None,
+                         "bytes_per_launch": b_ana, "avg_launch_ms": t_ana * 1e3},
+            "stages": {
+                "analysis": {"ms": t_ana * 1e3, "GBps": b_ana / t_ana / 1e9, "frac": b_ana / t_ana / HBM_PEAK},
+                "gsc_apply": {"ms": t_bf * 1e3, "GBps": b_bf / t_bf / 1e9, "frac": b_bf / t_bf / HBM_PEAK,
+                              "frames_per_s": S * T / t_bf},
+                "synthesis": {"ms": t_syn * 1e3, "GBps": b_syn / t_syn / 1e9, "frac": b_syn / t_syn / HBM_PEAK},
+            },
+        }
+        if not args.no_cpu and world == 1:
+            res["cpu_baseline"] = cpu_baseline(N, M, m, r, dct, args.cpu_frames)
+        else:
+            res["cpu_baseline"] = None
+        print(json.dumps(res))
+    if dist:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,79 @@
+"""Loader of the C-ABI shared library (csrc/libbtkhip.so, declared in include/btkhip.h).
+
+The HIP extension is the product: there is NO CPU fallback.  If the library is missing the
+import of anything that needs it fails loudly (build it with `python -c "import
+__graft_entry__ as g; g.build()"` or `make -C distant_speech_recognition_amd/csrc`).
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libbtkhip.so")
+
+_lib = None
+
+
+class BtkError(RuntimeError):
+    """Raised for a non-zero status of a C-ABI call; .code holds the BTK_ERR_* value."""
+
+    def __init__(self, code, msg):
+        super().__init__(msg)
+        self.code = code
+
+
+BTK_OK = 0
+BTK_ERR_DIMENSION = -1
+BTK_ERR_CONSISTENCY = -2
+BTK_ERR_ALLOCATION = -3
+BTK_ERR_PARAMETER = -4
+BTK_ERR_HIP = -5
+BTK_ERR_NUMERIC = -6
+
+_vp, _i, _l, _f, _d = C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_double
+
+# name -> (restype, argtypes); mirrors include/btkhip.h one to one
+SIGNATURES = {
+    "btk_last_error": (C.c_char_p, []),
+    "btk_version": (_i, []),
+    "btk_device_count": (_i, []),
+    "btk_set_device": (_i, [_i]),
+    "btk_synchronize": (_i, [_vp]),
+    "btk_fb_create": (_i, [C.POINTER(_vp), _i, _i, _i, _i, _i, _vp]),
+    "btk_fb_destroy": (None, [_vp]),
+    "btk_fb_processing_delay": (_i, [_vp]),
+    "btk_fb_lookahead": (_i, [_vp]),
+    "btk_fb_analysis_num_frames": (_l, [_vp, _l]),
+    "btk_fb_synthesis_num_blocks": (_l, [_vp, _l]),
+    "btk_fb_analysis": (_i, [_vp, _vp, _l, _l, _i, _i, _vp, _l, _l, _l, _vp]),
+    "btk_fb_analysis_polyphase": (_i, [_vp, _vp, _l, _l, _i, _i, _vp, _l, _l, _vp]),
+    "btk_fb_synthesis": (_i, [_vp, _vp, _l, _l, _i, _vp, _l, _l, _l, _vp]),
+    "btk_bf_apply": (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _l, _l, _vp]),
+    "btk_weights_mainlobe": (_i, [_i, _i, _f, _vp, _vp]),
+    "btk_weights_blocking_matrix": (_i, [_vp, _i, _i, _vp]),
+    "btk_weights_sidelobe": (_i, [_vp, _vp, _i, _i, _vp]),
+    "btk_weights_gsc_effective": (_i, [_vp, _vp, _i, _i, _i, _vp]),
+}
+
+
+def lib():
+    """Return the loaded library; raise if the HIP extension has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                "distant_speech_recognition_amd: HIP extension %s is missing -- build it with "
+                "`make -C distant_speech_recognition_amd/csrc` (there is no CPU fallback)" % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)           # AttributeError here == header/library mismatch
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(code):
+    if code != BTK_OK:
+        msg = lib().btk_last_error()
+        raise BtkError(code, msg.decode() if msg else "btkhip error %d" % code)
+    return code

@@ -1,0 +1,215 @@
+// btk_api.hip -- C-ABI plumbing of libbtkhip: error state, device selection, filter-bank plans and
+// the host-side (float64) weight design that runs once per look direction.
+#include "btk_internal.h"
+#include <cmath>
+#include <complex>
+#include <cstring>
+#include <string>
+#include <vector>
+
+namespace {
+thread_local std::string g_last_error;
+using cd = std::complex<double>;
+}
+
+int btk_set_error(int code, const char* fmt, ...)
+{
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  g_last_error = buf;
+  return code;
+}
+
+extern "C" {
+
+const char* btk_last_error(void) { return g_last_error.c_str(); }
+int btk_version(void) { return 100; }
+
+int btk_device_count(void)
+{
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int btk_set_device(int device)
+{
+  BTK_HIP_CHECK(hipSetDevice(device));
+  return BTK_OK;
+}
+
+int btk_synchronize(void* stream)
+{
+  BTK_HIP_CHECK(hipStreamSynchronize(as_stream(stream)));
+  return BTK_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// OverSampledDFTFilterBank ctor (reference modulated/modulated.cc:232-268)
+int btk_fb_create(btk_fb_t** out, int M, int m, int r, int dct, int synthesis, const double* prototype)
+{
+  if (!out || !prototype) return btk_set_error(BTK_ERR_PARAMETER, "btk_fb_create: null argument");
+  if (M < 64 || M > 2048 || (M & (M - 1)))
+    return btk_set_error(BTK_ERR_PARAMETER, "M=%d must be a power of two in [64, 2048]", M);
+  if (m < 1 || m > 16) return btk_set_error(BTK_ERR_PARAMETER, "m=%d out of range [1,16]", m);
+  if (r < 0 || (M >> r) < 4) return btk_set_error(BTK_ERR_PARAMETER, "r=%d leaves a frame shift < 4", r);
+  btk_fb* fb = new btk_fb();
+  fb->M = M; fb->m = m; fb->r = r; fb->R = 1 << r; fb->D = M / fb->R; fb->K = M / 2 + 1;
+  fb->dct = dct; fb->synthesis = synthesis ? 1 : 0; fb->gain_factor = 1;
+  fb->laN = 0;
+  switch (dct) {                                    // modulated.cc:246-264
+    case 1: fb->pd = m * fb->R - 1; break;
+    case 2:
+      if (synthesis) fb->pd = m * fb->R / 2;
+      else { fb->pd = m * fb->R - 1; fb->laN = m * fb->R / 2 - 1; }
+      break;
+    default: fb->pd = 2 * m - 1; break;
+  }
+  std::vector<float> hp((size_t)m * M);
+  for (size_t i = 0; i < hp.size(); i++) hp[i] = (float)prototype[i];
+  std::vector<float2> tw(M);
+  for (int j = 0; j < M; j++) {
+    const double a = 2.0 * M_PI * (double)j / (double)M;
+    tw[j] = make_float2((float)std::cos(a), (float)std::sin(a));
+  }
+  fb->d_proto = nullptr; fb->d_tw = nullptr;
+  hipError_t e = hipMalloc(reinterpret_cast<void**>(&fb->d_proto), sizeof(float) * hp.size());
+  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&fb->d_tw), sizeof(float2) * M);
+  if (e == hipSuccess) e = hipMemcpy(fb->d_proto, hp.data(), sizeof(float) * hp.size(), hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(fb->d_tw, tw.data(), sizeof(float2) * M, hipMemcpyHostToDevice);
+  if (e != hipSuccess) {
+    if (fb->d_proto) (void)hipFree(fb->d_proto);
+    if (fb->d_tw) (void)hipFree(fb->d_tw);
+    delete fb;
+    return btk_set_error(e == hipErrorOutOfMemory ? BTK_ERR_ALLOCATION : BTK_ERR_HIP,
+                         "btk_fb_create: %s", hipGetErrorString(e));
+  }
+  *out = fb;
+  return BTK_OK;
+}
+
+void btk_fb_destroy(btk_fb_t* fb)
+{
+  if (!fb) return;
+  (void)hipFree(fb->d_proto);
+  (void)hipFree(fb->d_tw);
+  delete fb;
+}
+
+int btk_fb_processing_delay(const btk_fb_t* fb) { return fb ? fb->pd : -1; }
+int btk_fb_lookahead(const btk_fb_t* fb) { return fb ? fb->laN : -1; }
+
+// frames emitted before jiterator_error: the look-ahead consumes laN blocks (modulated.cc:425-439),
+// every remaining input block yields a frame, then processing_delay zero-padded frames (:440-466).
+long btk_fb_analysis_num_frames(const btk_fb_t* fb, long nsamples)
+{
+  if (!fb || nsamples < 0) return -1;
+  const long nblk = (nsamples + fb->D - 1) / fb->D;
+  const long body = nblk > fb->laN ? nblk - fb->laN : 0;
+  return body + fb->pd;
+}
+
+long btk_fb_synthesis_num_blocks(const btk_fb_t* fb, long nframes)
+{
+  if (!fb) return -1;
+  return nframes > fb->pd ? nframes - fb->pd : 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Host-side weight design (float64).  These are the engine's own implementations of the
+// reference's one-off weight computations; the streaming work stays on the GPU.
+
+// BeamformerWeights::calcMainlobe, halfBandShift == false (beamformer/beamformer.cc:527-553)
+int btk_weights_mainlobe(int M, int N, float samplerate, const double* delays, double* wq_out)
+{
+  if (M < 2 || N < 1 || !delays || !wq_out) return btk_set_error(BTK_ERR_PARAMETER, "btk_weights_mainlobe: bad argument");
+  cd* wq = reinterpret_cast<cd*>(wq_out);
+  const int half = M / 2;
+  const double invN = (double)N;
+  for (int c = 0; c < N; c++) wq[c] = cd(1.0, 0.0) / invN;
+  for (int k = 1; k < half; k++)
+    for (int c = 0; c < N; c++) {
+      const double ph = -2.0 * M_PI * k * delays[c] * samplerate / M;
+      wq[(size_t)k * N + c] = std::polar(1.0, ph) / invN;
+      wq[(size_t)(M - k) * N + c] = std::polar(1.0, -ph) / invN;
+    }
+  for (int c = 0; c < N; c++) {
+    const double ph = -M_PI * samplerate * delays[c];
+    wq[(size_t)half * N + c] = std::polar(1.0, ph) / invN;
+  }
+  return BTK_OK;
+}
+
+// calc_blocking_matrix_ (beamformer.cc:373-454): classical Gram-Schmidt over the first N-NC
+// columns of the projector I - conj(a) a^T / |a|^2.
+int btk_weights_blocking_matrix(const double* a_in, int N, int NC, double* B_out)
+{
+  const int bs = N - NC;
+  if (bs <= 0) return btk_set_error(BTK_ERR_DIMENSION, "The number of sensors %d > the number of constraints %d", N, NC);
+  const cd* a = reinterpret_cast<const cd*>(a_in);
+  cd* B = reinterpret_cast<cd*>(B_out);
+  double nrm2 = 0.0;
+  for (int i = 0; i < N; i++) nrm2 += std::norm(a[i]);
+  std::vector<cd> col(N);
+  for (int j = 0; j < bs; j++) {
+    const cd aj = a[j] / nrm2;
+    for (int i = 0; i < N; i++) col[i] = (i == j ? cd(1.0, 0.0) : cd(0.0, 0.0)) - std::conj(a[i]) * aj;
+    for (int q = 0; q < j; q++) {
+      cd ip(0.0, 0.0);
+      for (int i = 0; i < N; i++) ip += std::conj(B[(size_t)i * bs + q]) * col[i];
+      for (int i = 0; i < N; i++) col[i] -= ip * B[(size_t)i * bs + q];
+    }
+    double nn = 0.0;
+    for (int i = 0; i < N; i++) nn += std::norm(col[i]);
+    nn = std::sqrt(nn);
+    for (int i = 0; i < N; i++) B[(size_t)i * bs + j] = col[i] / nn;
+  }
+  return BTK_OK;
+}
+
+// calcSidelobeCancellerU_f (beamformer.cc:752-767)
+int btk_weights_sidelobe(const double* B_in, const double* wa_in, int N, int NC, double* wl_out)
+{
+  const int bs = N - NC;
+  if (bs <= 0) return btk_set_error(BTK_ERR_DIMENSION, "btk_weights_sidelobe: N=%d NC=%d", N, NC);
+  const cd* B = reinterpret_cast<const cd*>(B_in);
+  const cd* wa = reinterpret_cast<const cd*>(wa_in);
+  cd* wl = reinterpret_cast<cd*>(wl_out);
+  for (int i = 0; i < N; i++) {
+    cd acc(0.0, 0.0);
+    for (int j = 0; j < bs; j++) acc += B[(size_t)i * bs + j] * wa[j];
+    wl[i] = acc;
+  }
+  return BTK_OK;
+}
+
+// Effective weights of SubbandGSC::next: bin 0 uses wq alone (beamformer.cc:1288-1291), bins
+// 1..M/2 use wq - wl with the optional w/(|w| N) normalisation of calc_gsc_output (:1228-1237).
+int btk_weights_gsc_effective(const double* wq_in, const double* wl_in, int M, int N, int normalize, float* w_out)
+{
+  if (!wq_in || !w_out) return btk_set_error(BTK_ERR_PARAMETER, "btk_weights_gsc_effective: null argument");
+  const cd* wq = reinterpret_cast<const cd*>(wq_in);
+  const cd* wl = reinterpret_cast<const cd*>(wl_in);
+  const int K = M / 2 + 1;
+  std::vector<cd> w(N);
+  for (int k = 0; k < K; k++) {
+    for (int c = 0; c < N; c++)
+      w[c] = (k == 0 || !wl) ? wq[(size_t)k * N + c] : wq[(size_t)k * N + c] - wl[(size_t)k * N + c];
+    if (normalize && k > 0 && wl) {
+      double nn = 0.0;
+      for (int c = 0; c < N; c++) nn += std::norm(w[c]);
+      nn = std::sqrt(nn);
+      for (int c = 0; c < N; c++) w[c] /= (nn * N);
+    }
+    for (int c = 0; c < N; c++) {
+      w_out[2 * ((size_t)k * N + c)] = (float)w[c].real();
+      w_out[2 * ((size_t)k * N + c) + 1] = (float)w[c].imag();
+    }
+  }
+  return BTK_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,27 @@
+// btk_internal.h -- shared declarations of the HIP engine (not part of the public C-ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdarg>
+#include <cstdio>
+#include "btkhip.h"
+
+struct btk_fb {
+  int M, m, r, R, D, K;
+  int dct, synthesis;
+  int pd;            // processing_delay_  (modulated.cc:246-264)
+  int laN;           // laN_               (modulated.cc:246-264)
+  int gain_factor;   // gain_factor_ (int, default 1)
+  float* d_proto;    // [m*M] float32 prototype on device
+  float2* d_tw;      // [M] e^{+j 2 pi j / M}
+};
+
+int btk_set_error(int code, const char* fmt, ...);
+
+#define BTK_HIP_CHECK(expr)                                                              \
+  do {                                                                                   \
+    hipError_t e__ = (expr);                                                             \
+    if (e__ != hipSuccess)                                                               \
+      return btk_set_error(BTK_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e__)); \
+  } while (0)
+
+static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }

@@ -1,0 +1,368 @@
+// fb_kernels.hip -- oversampled modulated-DFT analysis / synthesis filter banks for gfx950.
+//
+// Replaces OverSampledDFTAnalysisBank::next and OverSampledDFTSynthesisBank::next
+// (reference modulated/modulated.cc:375-409, 553-612) with whole-tile kernels:
+//
+//   analysis : one workgroup = one (stream,channel) x TT consecutive frames.
+//              PCM span -> LDS (coalesced), polyphase FIR in registers (prototype taps held in
+//              VGPRs), real-input FFT as an M/2-point complex FFT in LDS, Hermitian post-pass,
+//              bins 0..M/2 written to X[S][K][N][T] as TT*8-byte contiguous runs.
+//   synthesis: one workgroup = one stream x TB output blocks; Hermitian pre-pass + M/2-point
+//              complex FFT (forward) gives the real sequence of modulated.cc:559-563, the
+//              polyphase/overlap-add of :594-606 runs out of an LDS ring of m*R frames.
+//
+// The closed forms used here (validated against the literal ring-buffer restatement in
+// oracle/btk_oracle.c):
+//   analysis frame t: newest sample index n_t = (t + laN + 1) D - 1,
+//       p[i] = sum_{k<m} h[i + M k] x[n_t - i - M k],  X_t[kappa] = sum_i p[i] e^{+j 2 pi kappa i / M}
+//   synthesis block b: newest input frame f = b + pd,
+//       v_f[i] = Re sum_kappa Y_f[kappa] e^{-j 2 pi kappa i / M}
+//       s_f[i] = sum_{k<m} g[M-1-i+M k] v_{f-Rk}[i],   out_b[D-1-d] = sum_{j<R} s_{f-(R-1-j)}[d + j D]
+#include "btk_internal.h"
+#include "fft_lds.h"
+
+namespace {
+
+constexpr int NT = 256;                       // threads per workgroup (4 wavefronts)
+
+template <int LOG2M> struct FbCfg {
+  static constexpr int M = 1 << LOG2M;
+  static constexpr int NF = M / 2;            // complex FFT length
+  static constexpr int LOG2NF = LOG2M - 1;
+  // frames per workgroup tile: FFT buffer stays at ~32 KB, capped at 32 frames
+  static constexpr int TT = (8192 / M) > 32 ? 32 : (8192 / M);
+  static constexpr int STRIDE = NF + 1;       // +1: slot for bin NF and bank de-phasing
+};
+
+// ------------------------------------------------------------------ analysis
+// MT > 0: compile-time prototype length factor m (taps in registers); MT == 0: runtime m.
+template <int LOG2M, int MT, bool POLYPHASE_ONLY>
+__global__ __launch_bounds__(NT)
+void analysis_kernel(const float* __restrict__ pcm, long nsamples, long pcm_stride,
+                     const float* __restrict__ proto, const float2* __restrict__ twg,
+                     int m_rt, int D, int laN, float gain,
+                     int N, int K, float2* __restrict__ X, float* __restrict__ P,
+                     long T_stride, long t0, long tcount, int ntiles, int nchan)
+{
+  using C = FbCfg<LOG2M>;
+  constexpr int M = C::M, NF = C::NF, TT = C::TT, STRIDE = C::STRIDE;
+  const int m = MT > 0 ? MT : m_rt;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float2* zbuf = reinterpret_cast<float2*>(smem);                 // [TT][STRIDE]
+  float2* tw = zbuf + TT * STRIDE;                                // [M]
+  float* xs = reinterpret_cast<float*>(tw + M);                   // [(TT-1) D + m M]
+
+  const int tid = threadIdx.x;
+  // XCD-aware mapping: consecutive tiles of one channel share an XCD's L2 (PCM halo reuse).
+  const int b = blockIdx.x;
+  const int xcd = b & 7, slot = b >> 3;
+  const int chan = (slot / ntiles) * 8 + xcd;
+  const int tile = slot % ntiles;
+  if (chan >= nchan) return;
+  const long tt0 = (long)tile * TT;                               // first frame of tile, relative to t0
+  const long tabs0 = t0 + tt0;                                    // absolute frame number
+
+  for (int j = tid; j < M; j += NT) tw[j] = twg[j];
+
+  // ---- PCM span -> LDS.  local index l <-> global sample g0 + l, g0 = (tabs0+laN+1) D - m M
+  const int span = (TT - 1) * D + m * M;
+  const long g0 = (tabs0 + laN + 1) * (long)D - (long)m * M;
+  const float* src = pcm + (long)chan * pcm_stride;
+  const bool vec_ok = ((pcm_stride & 3) == 0) && ((reinterpret_cast<uintptr_t>(pcm) & 15) == 0) && ((g0 & 3) == 0) && ((D & 3) == 0);
+  if (vec_ok && g0 >= 0 && g0 + span <= nsamples) {
+    for (int l = tid * 4; l < span; l += NT * 4)
+      *reinterpret_cast<float4*>(xs + l) = *reinterpret_cast<const float4*>(src + g0 + l);
+  } else {
+    for (int l = tid; l < span; l += NT) {
+      const long g = g0 + l;
+      xs[l] = (g >= 0 && g < nsamples) ? src[g] : 0.0f;
+    }
+  }
+  __syncthreads();
+
+  // ---- polyphase: z[f][n] = (p[2n], p[2n+1])
+  constexpr int NOWN = NF > NT ? NF / NT : 1;        // pair-indices n owned by a thread
+  constexpr int FPT = NF > NT ? TT : TT * NF / NT;   // frames handled per owned n
+  constexpr int FSTEP = NF > NT ? 1 : NT / NF;
+  constexpr int MTR = MT > 0 ? MT : 1;
+  const int f_first = NF > NT ? 0 : tid / NF;
+#pragma unroll
+  for (int q = 0; q < NOWN; q++) {
+    const int n = NF > NT ? tid + q * NT : tid % NF;
+    float2 hreg[MTR];
+    if (MT > 0) {
+#pragma unroll
+      for (int k = 0; k < MT; k++) hreg[k] = *reinterpret_cast<const float2*>(proto + 2 * n + M * k);
+    }
+#pragma unroll 4
+    for (int fi = 0; fi < FPT; fi++) {
+      const int f = f_first + fi * FSTEP;
+      // x[n_t - (2n+1) - M k] and x[n_t - 2n - M k] sit at xs[base - M k], xs[base - M k + 1]
+      const int base = f * D + m * M - 2 - 2 * n;
+      float p0 = 0.0f, p1 = 0.0f;
+      if (MT > 0) {
+#pragma unroll
+        for (int k = 0; k < MT; k++) {
+          const float2 x = *reinterpret_cast<const float2*>(xs + base - M * k);
+          p0 = fmaf(hreg[k].x, x.y, p0);
+          p1 = fmaf(hreg[k].y, x.x, p1);
+        }
+      } else {
+        for (int k = 0; k < m; k++) {
+          const float2 h = *reinterpret_cast<const float2*>(proto + 2 * n + M * k);
+          const float2 x = *reinterpret_cast<const float2*>(xs + base - M * k);
+          p0 = fmaf(h.x, x.y, p0);
+          p1 = fmaf(h.y, x.x, p1);
+        }
+      }
+      if (POLYPHASE_ONLY) {
+        if (tt0 + f < tcount)
+          *reinterpret_cast<float2*>(P + (((long)chan * tcount + tt0 + f) * M + 2 * n)) = make_float2(p0, p1);
+      } else {
+        zbuf[f * STRIDE + n] = make_float2(p0, p1);
+      }
+    }
+  }
+  if (POLYPHASE_ONLY) return;
+  __syncthreads();
+
+  // ---- M/2-point complex FFT, backward sign (e^{+j...}), gsl_fft_complex_radix2_backward
+  fft_lds<C::LOG2NF, TT, STRIDE, NT, +1>(zbuf, tw, tid);
+
+  // ---- Hermitian post-pass, in place: X[k] = E[k] + W^k O[k], X[NF-k] from the same pair
+  //      E = (Z[k] + conj Z[NF-k])/2,  O = -j (Z[k] - conj Z[NF-k])/2,  W = e^{+j 2 pi / M}
+  for (int idx = tid; idx < TT * (NF / 2 + 1); idx += NT) {
+    const int f = idx / (NF / 2 + 1), k = idx % (NF / 2 + 1);
+    float2* row = zbuf + f * STRIDE;
+    const float2 zk = row[k];
+    const float2 zc = cconjf(k == 0 ? row[0] : row[NF - k]);
+    const float2 e = make_float2(0.5f * (zk.x + zc.x), 0.5f * (zk.y + zc.y));
+    const float2 dd = make_float2(0.5f * (zk.x - zc.x), 0.5f * (zk.y - zc.y));
+    const float2 o = make_float2(dd.y, -dd.x);                    // -j * dd
+    const float2 wo = cmulf(tw[k], o);
+    const float2 xk = caddf(e, wo);
+    // X[NF-k] = conj(E[k]) + W^{NF-k} conj(O[k]),  W^{NF-k} = -conj(W^k)  => conj(E - W^k O)
+    const float2 xm = cconjf(csubf(e, wo));
+    row[k] = make_float2(xk.x * gain, xk.y * gain);
+    row[NF - k] = make_float2(xm.x * gain, xm.y * gain);          // k==0 writes bin NF; k==NF/2 rewrites itself
+  }
+  __syncthreads();
+
+  // ---- store bins 0..NF: for each k a run of TT frames (TT*8 B contiguous)
+  const int s = chan / N, nch = chan % N;
+  float2* xo = X + ((long)s * K * N + nch) * T_stride + tt0;
+  for (int idx = tid; idx < TT * (NF + 1); idx += NT) {
+    const int f = idx % TT, k = idx / TT;
+    if (tt0 + f < tcount) xo[(long)k * N * T_stride + f] = zbuf[f * STRIDE + k];
+  }
+}
+
+// ------------------------------------------------------------------ synthesis
+template <int LOG2M> struct SynCfg {
+  static constexpr int M = 1 << LOG2M;
+  static constexpr int NF = M / 2;
+  static constexpr int LOG2NF = LOG2M - 1;
+  static constexpr int FR = (4096 / M) > 32 ? 32 : (4096 / M);                    // frames per FFT round
+  static constexpr int STRIDE = NF + 1;
+};
+
+// One workgroup: stream s, output blocks [bt0, bt0+TB).  Needs v_f for f in [f_lo, f_hi],
+// f_lo = bt0 + pd - (R-1) - R (m-1), f_hi = bt0 + TB - 1 + pd.  v rows live in LDS as
+// vbuf[(f - f_lo)][M] floats.
+template <int LOG2M>
+__global__ __launch_bounds__(NT)
+void synthesis_kernel(const float2* __restrict__ Y, long nframes, long T_stride, int K,
+                      const float* __restrict__ proto, const float2* __restrict__ twg,
+                      int m, int R, int D, int pd, float gain, int TB,
+                      float* __restrict__ out, long out_stride, long b0, long bcount)
+{
+  using C = SynCfg<LOG2M>;
+  constexpr int M = C::M, NF = C::NF, FR = C::FR, STRIDE = C::STRIDE;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float2* zbuf = reinterpret_cast<float2*>(smem);                 // [FR][STRIDE]
+  float2* tw = zbuf + FR * STRIDE;                                // [M]
+  float* vbuf = reinterpret_cast<float*>(tw + M);                 // [NV][M]
+  const int NV = TB + R * m - 1;                                  // frames of v needed
+
+  const int tid = threadIdx.x;
+  const int s = blockIdx.y;
+  const long bt0 = b0 + (long)blockIdx.x * TB;
+  const long f_lo = bt0 + pd - (R - 1) - (long)R * (m - 1);
+  const float2* Ys = Y + (long)s * K * T_stride;
+
+  for (int j = tid; j < M; j += NT) tw[j] = twg[j];
+  __syncthreads();
+
+  for (int r0 = 0; r0 < NV; r0 += FR) {
+    // ---- Hermitian pre-pass: Zc[k] = (Y[k] + conj Y[NF-k]) + j W^{-k} (Y[k] - conj Y[NF-k]),
+    //      W = e^{+j 2 pi/M}; imaginary parts of Y[0], Y[NF] are ignored like the real part
+    //      taken at modulated.cc:562-563.
+    for (int idx = tid; idx < FR * NF; idx += NT) {
+      const int fr = idx % FR, k = idx / FR;                      // frames fastest: coalesced along t
+      const long f = f_lo + r0 + fr;
+      float2 z = make_float2(0.f, 0.f);
+      if (r0 + fr < NV && f >= 0 && f < nframes) {
+        float2 a = Ys[(long)k * T_stride + f];
+        float2 bq = Ys[(long)(NF - k) * T_stride + f];
+        if (k == 0) { a.y = 0.f; bq.y = 0.f; }
+        const float2 bc = cconjf(bq);
+        const float2 sm = caddf(a, bc), df = csubf(a, bc);
+        const float2 t = cmulf(cconjf(tw[k]), df);                // W^{-k} (Y[k] - conj Y[NF-k])
+        z = make_float2(sm.x - t.y, sm.y + t.x);                  // sm + j t
+      }
+      zbuf[fr * STRIDE + k] = z;
+    }
+    __syncthreads();
+    fft_lds<C::LOG2NF, FR, STRIDE, NT, -1>(zbuf, tw, tid);
+    // v[2n] = Re z[n], v[2n+1] = Im z[n]
+    for (int idx = tid; idx < FR * NF; idx += NT) {
+      const int fr = idx / NF, n = idx % NF;
+      if (r0 + fr < NV)
+        *reinterpret_cast<float2*>(vbuf + (long)(r0 + fr) * M + 2 * n) = zbuf[fr * STRIDE + n];
+    }
+    __syncthreads();
+  }
+
+  // ---- polyphase + overlap-add.  s_f[i] = sum_k g[M-1-i+M k] v_{f-Rk}[i]; block b (newest
+  //      frame f = b+pd) sums s_{f-(R-1-j)}[d + j D] over j in the reference's order with a
+  //      float32 running sum (modulated.cc:594-606).
+  float* os = out + (long)s * out_stride;
+  for (int idx = tid; idx < TB * D; idx += NT) {
+    const int bb = idx / D, d = idx % D;
+    const long bglob = bt0 + bb;
+    if (bglob - b0 >= bcount) continue;
+    float acc = 0.f;
+    for (int j = 0; j < R; j++) {
+      const int i = d + j * D;
+      const int vrow = bb + j + R * (m - 1);                      // row of v_{f-(R-1-j)} in vbuf
+      float sv = 0.f;
+      for (int k = 0; k < m; k++)
+        sv = fmaf(proto[(M - 1 - i) + M * k], vbuf[(long)(vrow - R * k) * M + i], sv);
+      acc += sv;
+    }
+    if (gain > 0.f) acc *= gain;
+    os[(bglob - b0) * D + (D - 1 - d)] = acc;
+  }
+}
+
+template <int LOG2M>
+int launch_analysis(const btk_fb* fb, const float* pcm, long nsamples, long pcm_stride, int S, int N,
+                    float2* X, float* P, long T_stride, long t0, long tcount, hipStream_t st)
+{
+  using C = FbCfg<LOG2M>;
+  const int nchan = S * N;
+  const int ntiles = (int)((tcount + C::TT - 1) / C::TT);
+  const int chan_groups = (nchan + 7) / 8;
+  const long nblocks = (long)chan_groups * ntiles * 8;
+  const size_t lds = sizeof(float2) * (C::TT * C::STRIDE + C::M) + sizeof(float) * ((C::TT - 1) * fb->D + fb->m * C::M);
+  if (lds > 160 * 1024) return btk_set_error(BTK_ERR_PARAMETER, "analysis tile needs %zu B of LDS (m too large)", lds);
+  const float gain = fb->gain_factor > 0 ? (float)fb->gain_factor : 1.0f;
+#define BTK_LAUNCH_ANA(MT, PO)                                                                          \
+  do {                                                                                                  \
+    auto kern = analysis_kernel<LOG2M, MT, PO>;                                                         \
+    if (lds > 64 * 1024)                                                                                \
+      BTK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                            \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));         \
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblocks), dim3(NT), lds, st, pcm, nsamples, pcm_stride,     \
+                       fb->d_proto, fb->d_tw, fb->m, fb->D, fb->laN, gain, N, fb->K, X, P, T_stride,    \
+                       t0, tcount, ntiles, nchan);                                                      \
+  } while (0)
+  if (P) {
+    if (fb->m == 4) BTK_LAUNCH_ANA(4, true); else BTK_LAUNCH_ANA(0, true);
+  } else {
+    if (fb->m == 4) BTK_LAUNCH_ANA(4, false);
+    else if (fb->m == 2) BTK_LAUNCH_ANA(2, false);
+    else BTK_LAUNCH_ANA(0, false);
+  }
+#undef BTK_LAUNCH_ANA
+  BTK_HIP_CHECK(hipGetLastError());
+  return BTK_OK;
+}
+
+template <int LOG2M>
+int launch_synthesis(const btk_fb* fb, const float2* Y, long nframes, long T_stride, int S,
+                     float* out, long out_stride, long b0, long bcount, hipStream_t st)
+{
+  using C = SynCfg<LOG2M>;
+  // TB output blocks per workgroup, bounded by LDS: (TB + R m - 1) rows of M floats
+  const int extra = fb->R * fb->m - 1;
+  const long lds_cap = (C::M <= 512 ? 96 : 150) * 1024;
+  long budget = (lds_cap - (long)sizeof(float2) * (C::FR * C::STRIDE + C::M)) / (long)(sizeof(float) * C::M);
+  int TB = (int)(budget - extra);
+  if (TB > 32) TB = 32;
+  if (TB < 1) return btk_set_error(BTK_ERR_PARAMETER, "synthesis tile does not fit LDS (M=%d m=%d r=%d)", fb->M, fb->m, fb->r);
+  const size_t lds = sizeof(float2) * (C::FR * C::STRIDE + C::M) + sizeof(float) * (size_t)C::M * (TB + extra);
+  auto kern = synthesis_kernel<LOG2M>;
+  if (lds > 64 * 1024)
+    BTK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  const unsigned gx = (unsigned)((bcount + TB - 1) / TB);
+  hipLaunchKernelGGL(kern, dim3(gx, (unsigned)S), dim3(NT), lds, st, Y, nframes, T_stride, fb->K,
+                     fb->d_proto, fb->d_tw, fb->m, fb->R, fb->D, fb->pd, (float)fb->gain_factor, TB,
+                     out, out_stride, b0, bcount);
+  BTK_HIP_CHECK(hipGetLastError());
+  return BTK_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int btk_fb_analysis(const btk_fb_t* fb, const float* pcm, long nsamples, long pcm_stride,
+                    int S, int N, void* X, long T_stride, long t0, long tcount, void* stream)
+{
+  if (!fb || fb->synthesis) return btk_set_error(BTK_ERR_PARAMETER, "btk_fb_analysis: not an analysis plan");
+  if (S <= 0 || N <= 0 || tcount < 0 || T_stride < tcount || pcm_stride < nsamples)
+    return btk_set_error(BTK_ERR_DIMENSION, "btk_fb_analysis: bad sizes S=%d N=%d tcount=%ld T_stride=%ld", S, N, tcount, T_stride);
+  if (tcount == 0) return BTK_OK;
+  hipStream_t st = as_stream(stream);
+  float2* Xp = static_cast<float2*>(X);
+  switch (fb->M) {
+    case 64:   return launch_analysis<6>(fb, pcm, nsamples, pcm_stride, S, N, Xp, nullptr, T_stride, t0, tcount, st);
+    case 128:  return launch_analysis<7>(fb, pcm, nsamples, pcm_stride, S, N, Xp, nullptr, T_stride, t0, tcount, st);
+    case 256:  return launch_analysis<8>(fb, pcm, nsamples, pcm_stride, S, N, Xp, nullptr, T_stride, t0, tcount, st);
+    case 512:  return launch_analysis<9>(fb, pcm, nsamples, pcm_stride, S, N, Xp, nullptr, T_stride, t0, tcount, st);
+    case 1024: return launch_analysis<10>(fb, pcm, nsamples, pcm_stride, S, N, Xp, nullptr, T_stride, t0, tcount, st);
+    case 2048: return launch_analysis<11>(fb, pcm, nsamples, pcm_stride, S, N, Xp, nullptr, T_stride, t0, tcount, st);
+  }
+  return btk_set_error(BTK_ERR_PARAMETER, "unsupported M=%d", fb->M);
+}
+
+int btk_fb_analysis_polyphase(const btk_fb_t* fb, const float* pcm, long nsamples, long pcm_stride,
+                              int S, int N, float* P, long t0, long tcount, void* stream)
+{
+  if (!fb || fb->synthesis) return btk_set_error(BTK_ERR_PARAMETER, "btk_fb_analysis_polyphase: not an analysis plan");
+  if (S <= 0 || N <= 0 || tcount < 0) return btk_set_error(BTK_ERR_DIMENSION, "btk_fb_analysis_polyphase: bad sizes");
+  if (tcount == 0) return BTK_OK;
+  hipStream_t st = as_stream(stream);
+  switch (fb->M) {
+    case 64:   return launch_analysis<6>(fb, pcm, nsamples, pcm_stride, S, N, nullptr, P, tcount, t0, tcount, st);
+    case 128:  return launch_analysis<7>(fb, pcm, nsamples, pcm_stride, S, N, nullptr, P, tcount, t0, tcount, st);
+    case 256:  return launch_analysis<8>(fb, pcm, nsamples, pcm_stride, S, N, nullptr, P, tcount, t0, tcount, st);
+    case 512:  return launch_analysis<9>(fb, pcm, nsamples, pcm_stride, S, N, nullptr, P, tcount, t0, tcount, st);
+    case 1024: return launch_analysis<10>(fb, pcm, nsamples, pcm_stride, S, N, nullptr, P, tcount, t0, tcount, st);
+    case 2048: return launch_analysis<11>(fb, pcm, nsamples, pcm_stride, S, N, nullptr, P, tcount, t0, tcount, st);
+  }
+  return btk_set_error(BTK_ERR_PARAMETER, "unsupported M=%d", fb->M);
+}
+
+int btk_fb_synthesis(const btk_fb_t* fb, const void* Y, long nframes, long T_stride, int S,
+                     float* out, long out_stride, long b0, long bcount, void* stream)
+{
+  if (!fb || !fb->synthesis) return btk_set_error(BTK_ERR_PARAMETER, "btk_fb_synthesis: not a synthesis plan");
+  if (S <= 0 || bcount < 0 || nframes > T_stride || out_stride < bcount * fb->D)
+    return btk_set_error(BTK_ERR_DIMENSION, "btk_fb_synthesis: bad sizes S=%d bcount=%ld nframes=%ld T_stride=%ld", S, bcount, nframes, T_stride);
+  if (bcount == 0) return BTK_OK;
+  hipStream_t st = as_stream(stream);
+  const float2* Yp = static_cast<const float2*>(Y);
+  switch (fb->M) {
+    case 64:   return launch_synthesis<6>(fb, Yp, nframes, T_stride, S, out, out_stride, b0, bcount, st);
+    case 128:  return launch_synthesis<7>(fb, Yp, nframes, T_stride, S, out, out_stride, b0, bcount, st);
+    case 256:  return launch_synthesis<8>(fb, Yp, nframes, T_stride, S, out, out_stride, b0, bcount, st);
+    case 512:  return launch_synthesis<9>(fb, Yp, nframes, T_stride, S, out, out_stride, b0, bcount, st);
+    case 1024: return launch_synthesis<10>(fb, Yp, nframes, T_stride, S, out, out_stride, b0, bcount, st);
+    case 2048: return launch_synthesis<11>(fb, Yp, nframes, T_stride, S, out, out_stride, b0, bcount, st);
+  }
+  return btk_set_error(BTK_ERR_PARAMETER, "unsupported M=%d", fb->M);
+}
+
+}  // extern "C"

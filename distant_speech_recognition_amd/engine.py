@@ -1,0 +1,167 @@
+"""Block-level Python front-end of the C-ABI (include/btkhip.h).
+
+PyTorch is used only for device memory and streams (tensor.data_ptr()); every computation is a
+hand-written HIP kernel in csrc/.  Tensor layouts:
+
+    pcm  float32   [S][N][L]       X  complex64 [S][K][N][T]
+    W    complex64 [S|1][K][N]     Y  complex64 [S][K][T]      out float32 [S][B*D]
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import check
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr())
+
+
+def _np_ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _need_cuda(t, name):
+    if not t.is_cuda:
+        raise ValueError("%s must live in HBM (cuda tensor); the engine has no CPU path" % name)
+    if not t.is_contiguous():
+        raise ValueError("%s must be contiguous" % name)
+
+
+class FilterBank:
+    """Plan of an oversampled modulated-DFT bank (OverSampledDFTFilterBank, modulated.cc:232-268)."""
+
+    def __init__(self, prototype, M, m, r, delay_compensation_type=0, synthesis=False):
+        proto = np.ascontiguousarray(prototype, np.float64)
+        if proto.shape != (m * M,):
+            raise _lib.BtkError(_lib.BTK_ERR_CONSISTENCY,
+                                "Prototype sizes do not match (%d vs. %d)." % (proto.size, m * M))
+        self.M, self.m, self.r = M, m, r
+        self.R = 1 << r
+        self.D = M // self.R
+        self.K = M // 2 + 1
+        self.synthesis = bool(synthesis)
+        self._h = C.c_void_p()
+        check(_lib.lib().btk_fb_create(C.byref(self._h), M, m, r, delay_compensation_type, int(synthesis), _np_ptr(proto)))
+        self.processing_delay = _lib.lib().btk_fb_processing_delay(self._h)
+        self.lookahead = _lib.lib().btk_fb_lookahead(self._h)
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            try:
+                _lib.lib().btk_fb_destroy(h)
+            except Exception:
+                pass
+            self._h = None
+
+    # ---- analysis
+    def num_frames(self, nsamples):
+        return _lib.lib().btk_fb_analysis_num_frames(self._h, nsamples)
+
+    def analysis(self, pcm, nsamples=None, t0=0, tcount=None, out=None):
+        """pcm float32 [S][N][L] (cuda) -> X complex64 [S][K][N][T]."""
+        _need_cuda(pcm, "pcm")
+        S, N, L = pcm.shape
+        nsamples = L if nsamples is None else nsamples
+        if tcount is None:
+            tcount = self.num_frames(nsamples) - t0
+        if out is None:
+            out = torch.empty((S, self.K, N, tcount), dtype=torch.complex64, device=pcm.device)
+        _need_cuda(out, "X")
+        check(_lib.lib().btk_fb_analysis(self._h, _ptr(pcm), nsamples, L, S, N, _ptr(out), out.shape[3], t0, tcount, _stream()))
+        return out
+
+    def analysis_polyphase(self, pcm, nsamples=None, t0=0, tcount=None):
+        """Polyphase sums before the FFT: float32 [S*N][T][M] (parity/debug entry)."""
+        _need_cuda(pcm, "pcm")
+        S, N, L = pcm.shape
+        nsamples = L if nsamples is None else nsamples
+        if tcount is None:
+            tcount = self.num_frames(nsamples) - t0
+        P = torch.empty((S * N, tcount, self.M), dtype=torch.float32, device=pcm.device)
+        check(_lib.lib().btk_fb_analysis_polyphase(self._h, _ptr(pcm), nsamples, L, S, N, _ptr(P), t0, tcount, _stream()))
+        return P
+
+    # ---- synthesis
+    def num_blocks(self, nframes):
+        return _lib.lib().btk_fb_synthesis_num_blocks(self._h, nframes)
+
+    def synthesize(self, Y, nframes=None, b0=0, bcount=None, out=None):
+        """Y complex64 [S][K][T] (cuda) -> float32 [S][bcount*D]."""
+        _need_cuda(Y, "Y")
+        S, K, T = Y.shape
+        if K != self.K:
+            raise _lib.BtkError(_lib.BTK_ERR_DIMENSION, "Y has %d bins, plan has %d" % (K, self.K))
+        nframes = T if nframes is None else nframes
+        if bcount is None:
+            bcount = self.num_blocks(nframes) - b0
+        if out is None:
+            out = torch.empty((S, bcount * self.D), dtype=torch.float32, device=Y.device)
+        check(_lib.lib().btk_fb_synthesis(self._h, _ptr(Y), nframes, T, S, _ptr(out), out.shape[1], b0, bcount, _stream()))
+        return out
+
+
+def bf_apply(W, X, out=None):
+    """y_k[t] = w_k^H x_k[t].  W complex64 [S|1][K][N], X complex64 [S][K][N][T] -> Y [S][K][T]."""
+    _need_cuda(W, "W")
+    _need_cuda(X, "X")
+    S, K, N, T = X.shape
+    if W.dim() == 2:
+        W = W.unsqueeze(0)
+    if W.shape[1:] != (K, N) or W.shape[0] not in (1, S):
+        raise _lib.BtkError(_lib.BTK_ERR_DIMENSION, "weights %s do not match X %s" % (tuple(W.shape), tuple(X.shape)))
+    if out is None:
+        out = torch.empty((S, K, T), dtype=torch.complex64, device=X.device)
+    check(_lib.lib().btk_bf_apply(_ptr(W), int(W.shape[0] == S and S > 1), _ptr(X), _ptr(out), S, K, N, T, T, _stream()))
+    return out
+
+
+# ---------------------------------------------------------------------------- host-side weight design
+def weights_mainlobe(M, N, samplerate, delays):
+    """BeamformerWeights::calcMainlobe -> wq complex128 [M][N]."""
+    delays = np.ascontiguousarray(delays, np.float64)
+    if delays.shape != (N,):
+        raise _lib.BtkError(_lib.BTK_ERR_DIMENSION,
+                            "Number of delays does not match number of channels (%d vs. %d)." % (delays.size, N))
+    wq = np.zeros((M, N), np.complex128)
+    check(_lib.lib().btk_weights_mainlobe(M, N, float(samplerate), _np_ptr(delays), _np_ptr(wq)))
+    return wq
+
+
+def weights_blocking_matrix(a, NC=1):
+    a = np.ascontiguousarray(a, np.complex128)
+    N = a.shape[0]
+    if N - NC <= 0:
+        raise _lib.BtkError(_lib.BTK_ERR_DIMENSION, "The number of sensors %d > the number of constraints %d" % (N, NC))
+    B = np.zeros((N, N - NC), np.complex128)
+    check(_lib.lib().btk_weights_blocking_matrix(_np_ptr(a), N, NC, _np_ptr(B)))
+    return B
+
+
+def weights_sidelobe(B, wa):
+    B = np.ascontiguousarray(B, np.complex128)
+    wa = np.ascontiguousarray(wa, np.complex128)
+    N, bs = B.shape
+    wl = np.zeros(N, np.complex128)
+    check(_lib.lib().btk_weights_sidelobe(_np_ptr(B), _np_ptr(wa), N, N - bs, _np_ptr(wl)))
+    return wl
+
+
+def weights_gsc_effective(wq, wl, M, normalize=False):
+    """complex64 [K][N] numpy array ready for bf_apply (wq - wl, bin 0 = wq_0)."""
+    wq = np.ascontiguousarray(wq, np.complex128)
+    N = wq.shape[1]
+    wlp = None
+    if wl is not None:
+        wl = np.ascontiguousarray(wl, np.complex128)
+        wlp = _np_ptr(wl)
+    out = np.zeros((M // 2 + 1, N), np.complex64)
+    check(_lib.lib().btk_weights_gsc_effective(_np_ptr(wq), wlp, M, N, int(normalize), _np_ptr(out)))
+    return out

@@ -1,0 +1,105 @@
+/*
+ * btkhip.h -- thin C-ABI of the MI355X (gfx950) subband-beamforming engine.
+ *
+ * This is the drop-in boundary: plain C, opaque handles, explicit sizes, int status codes.
+ * Bulk data pointers marked [dev] are DEVICE pointers (HBM) owned by the caller; pointers
+ * marked [host] are host memory read during the call only.  `stream` is a hipStream_t passed
+ * as void* (NULL = default stream).  Nothing here needs PyTorch.
+ *
+ * Each entry point cites the reference interface it replaces (paths relative to
+ * btk20_src/ of kkumatani/distant_speech_recognition).  The reference has no FFI of its own for
+ * this path (it is a single-process C++/SWIG library); INTEGRATION.md shows the binding a
+ * maintainer adds on the reference side.
+ *
+ * Data layout in HBM (K = M/2+1 computed bins):
+ *   pcm   float32   [S][N][pcm_stride]     stream, channel, sample (un-normalised int16 scale)
+ *   X     complex64 [S][K][N][T]           subband snapshots, FRAMES CONTIGUOUS
+ *   W     complex64 [S or 1][K][N]         beamformer weights,  y = w^H x
+ *   Y     complex64 [S][K][T]              beamformed subband frames
+ *   out   float32   [S][nblocks*D]         synthesised samples
+ *
+ * All functions return BTK_OK (0) or a negative error code; btk_last_error() returns the
+ * message of the calling thread's last failure (the C++ node layer turns codes into the
+ * reference's j_error subclasses, common/jexception.h:26-161).
+ */
+#ifndef BTKHIP_H
+#define BTKHIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BTK_OK              0
+#define BTK_ERR_DIMENSION  -1   /* jdimension_error   */
+#define BTK_ERR_CONSISTENCY -2  /* jconsistency_error */
+#define BTK_ERR_ALLOCATION -3   /* jallocation_error  */
+#define BTK_ERR_PARAMETER  -4   /* jparameter_error   */
+#define BTK_ERR_HIP        -5   /* j_error (device runtime failure) */
+#define BTK_ERR_NUMERIC    -6   /* jnumeric_error     */
+
+typedef struct btk_fb btk_fb_t;          /* filter-bank plan (analysis or synthesis) */
+
+const char* btk_last_error(void);
+int  btk_version(void);
+/* Number of HIP devices visible / select one for this thread (one process per GPU). */
+int  btk_device_count(void);
+int  btk_set_device(int device);
+int  btk_synchronize(void* stream);
+
+/* ---- Oversampled modulated-DFT filter bank --------------------------------------------
+ * Replaces OverSampledDFTAnalysisBank / OverSampledDFTSynthesisBank
+ * (modulated/modulated.h:268-340, modulated/modulated.cc:232-268 ctor delay logic).
+ * prototype: [host] m*M float64 coefficients, copied at creation (modulated.cc:243-244).
+ * M must be a power of two in [64, 2048]; r in [0, log2(M)]; delay_comp_type in {0,1,2}.   */
+int  btk_fb_create(btk_fb_t** fb, int M, int m, int r, int delay_comp_type, int synthesis,
+                   const double* prototype);
+void btk_fb_destroy(btk_fb_t* fb);
+int  btk_fb_processing_delay(const btk_fb_t* fb);   /* processing_delay_ */
+int  btk_fb_lookahead(const btk_fb_t* fb);          /* laN_ */
+/* frames an analysis bank emits for an nsamples-long channel before jiterator_error:
+ * ceil(nsamples/D) - laN + processing_delay   (modulated.cc:419-469).                       */
+long btk_fb_analysis_num_frames(const btk_fb_t* fb, long nsamples);
+/* blocks a synthesis bank emits when its source ends after nframes: nframes - pd (>= 0)
+ * (modulated.cc:569-612).                                                                   */
+long btk_fb_synthesis_num_blocks(const btk_fb_t* fb, long nframes);
+
+/* OverSampledDFTAnalysisBank::next for frames [t0, t0+tcount) of every (stream, channel):
+ * modulated.cc:375-409.  pcm [dev] [S*N][pcm_stride] with nsamples valid samples per channel
+ * (zero outside, like the zero-initialised ring and the end-of-stream padding).
+ * X [dev] [S][K][N][T_stride]; frame t is stored at column t - t0.                         */
+int  btk_fb_analysis(const btk_fb_t* fb, const float* pcm, long nsamples, long pcm_stride,
+                     int S, int N, void* X, long T_stride, long t0, long tcount, void* stream);
+/* Debug/parity entry: the M real polyphase sums of modulated.cc:384-391 (before the FFT),
+ * P [dev] float32 [S*N][tcount][M].  Used to pin the integer polyphase indexing bit-exactly. */
+int  btk_fb_analysis_polyphase(const btk_fb_t* fb, const float* pcm, long nsamples, long pcm_stride,
+                               int S, int N, float* P, long t0, long tcount, void* stream);
+/* OverSampledDFTSynthesisBank::next for blocks [b0, b0+bcount): modulated.cc:553-612.
+ * Y [dev] [S][K][T_stride] holding nframes valid frames (frame index < 0 reads as zero == the
+ * zeroed ring, modulated.cc:615-621); out [dev] [S][out_stride], block b at offset (b-b0)*D. */
+int  btk_fb_synthesis(const btk_fb_t* fb, const void* Y, long nframes, long T_stride, int S,
+                      float* out, long out_stride, long b0, long bcount, void* stream);
+
+/* ---- Fixed-weight beamformer apply ------------------------------------------------------
+ * SubbandDS::next (beamformer/beamformer.cc:1095-1157), SubbandGSC::next + calc_gsc_output
+ * (:1208-1316), SubbandMVDR::next (:2537-2587), SubbandMVDRGSC::next (:2720-2773):
+ *   y_k[t] = w_k^H x_k[t], k = 0..M/2 (mirror bins are conjugates, formed at synthesis).
+ * W [dev] complex64 [Sw][K][N] with Sw = S (per-stream weights) or 1 (shared).              */
+int  btk_bf_apply(const void* W, int per_stream_weights, const void* X, void* Y,
+                  int S, int K, int N, long T_stride, long T, void* stream);
+
+/* ---- Host-side weight design (double precision, one-off per look direction) -------------
+ * BeamformerWeights::calcMainlobe (beamformer.cc:502-565): wq [host] complex128 [M][N].     */
+int  btk_weights_mainlobe(int M, int N, float samplerate, const double* delays, double* wq);
+/* calc_blocking_matrix_ (beamformer.cc:373-454): a [host] complex128 [N]; B [host] [N][N-NC] */
+int  btk_weights_blocking_matrix(const double* a, int N, int NC, double* B);
+/* calcSidelobeCancellerU_f (beamformer.cc:752-767): wl = B wa                               */
+int  btk_weights_sidelobe(const double* B, const double* wa, int N, int NC, double* wl);
+/* Effective GSC weights (wq - wl, optional normalisation of calc_gsc_output :1228-1237) for
+ * bins 0..M/2 as complex64 [K][N] ready for btk_bf_apply; bin 0 is wq_0 alone (:1288-1291). */
+int  btk_weights_gsc_effective(const double* wq, const double* wl, int M, int N,
+                               int normalize, float* w_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BTKHIP_H */

@@ -1,0 +1,121 @@
+"""GPU parity: oversampled-DFT analysis/synthesis banks vs the oracle, through the C-ABI."""
+import numpy as np
+import pytest
+
+from tests.util import design_prototype, synthetic_pcm
+
+pytestmark = pytest.mark.gpu
+
+
+def _eng():
+    from distant_speech_recognition_amd import engine
+    return engine
+
+
+@pytest.mark.parametrize("M,m,r,dct", [(256, 4, 1, 2), (256, 4, 1, 0), (512, 4, 1, 2), (64, 4, 1, 1),
+                                       (128, 2, 1, 2), (1024, 4, 1, 2), (512, 3, 1, 0), (256, 4, 2, 2),
+                                       (2048, 4, 1, 2), (256, 4, 0, 0)])
+def test_analysis_matches_oracle(orc, dev, M, m, r, dct):
+    import torch
+    eng = _eng()
+    h = design_prototype(M, m)
+    D = M >> r
+    L = 23 * D + 17                       # ragged tail: exercises pad_zeros + end-of-stream padding
+    pcm, _ = synthetic_pcm(2, 3, L, seed=11)
+    fb = eng.FilterBank(h, M, m, r, dct)
+    T = fb.num_frames(L)
+    assert T == orc.analysis_num_frames(L, M, m, r, dct)
+    X = fb.analysis(torch.from_numpy(pcm).to(dev)).cpu().numpy()          # [S][K][N][T]
+    assert X.shape == (2, M // 2 + 1, 3, T)
+    for s in range(2):
+        for c in range(3):
+            ref = orc.analysis(h, M, m, r, dct, pcm[s, c])               # [T][M]
+            assert ref.shape[0] == T
+            got = X[s, :, c, :].T                                        # [T][K]
+            scale = np.max(np.abs(ref))
+            # tolerance: complex64 vs float64 oracle, <= 1e-5 * ||X||inf per SURVEY 8(c)
+            assert np.max(np.abs(got - ref[:, : M // 2 + 1])) <= 1e-5 * scale
+
+
+def test_polyphase_indexing_bit_exact(orc, dev):
+    """Integer-valued samples and taps make every float32 product/sum exact, so the GPU polyphase
+    stage must equal the literal ring-buffer oracle BIT FOR BIT (integer polyphase indexing)."""
+    import torch
+    eng = _eng()
+    for (M, m, r, dct) in [(256, 4, 1, 2), (64, 4, 1, 0), (512, 2, 2, 2), (128, 3, 0, 1)]:
+        rng = np.random.default_rng(M + m)
+        h = rng.integers(-8, 9, size=m * M).astype(np.float64)
+        D = M >> r
+        L = 19 * D + 5
+        pcm = rng.integers(-100, 101, size=(1, 2, L)).astype(np.float32)
+        fb = eng.FilterBank(h, M, m, r, dct)
+        P = fb.analysis_polyphase(torch.from_numpy(pcm).to(dev)).cpu().numpy()        # [2][T][M]
+        for c in range(2):
+            _, pp = orc.analysis(h, M, m, r, dct, pcm[0, c], want_polyphase=True)
+            assert P[c].shape == pp.shape
+            assert np.array_equal(P[c].astype(np.float64), pp)
+
+
+def test_analysis_reference_fixture(orc, dev, proto256, kinect_pcm):
+    import torch
+    eng = _eng()
+    h, _ = proto256
+    fb = eng.FilterBank(h, 256, 4, 1, 2)
+    pcm = kinect_pcm[None]                                               # [1][4][78064]
+    X = fb.analysis(torch.from_numpy(pcm).to(dev)).cpu().numpy()
+    assert X.shape[-1] == 614
+    ref = orc.analysis(h, 256, 4, 1, 2, kinect_pcm[3])
+    assert np.max(np.abs(X[0, :, 3, :].T - ref[:, :129])) <= 1e-5 * np.max(np.abs(ref))
+
+
+def test_analysis_chunked_equals_whole(dev):
+    """Frames are a closed form of the PCM: processing [t0, t0+n) chunks must equal one call."""
+    import torch
+    eng = _eng()
+    M, m, r = 256, 4, 1
+    fb = eng.FilterBank(design_prototype(M, m), M, m, r, 2)
+    pcm, _ = synthetic_pcm(1, 2, 40 * 128, seed=5)
+    p = torch.from_numpy(pcm).to(dev)
+    whole = fb.analysis(p)
+    T = whole.shape[-1]
+    parts = [fb.analysis(p, t0=a, tcount=min(13, T - a)) for a in range(0, T, 13)]
+    assert torch.equal(torch.cat(parts, dim=-1), whole)
+
+
+@pytest.mark.parametrize("M,m,r,dct", [(256, 4, 1, 2), (256, 4, 1, 0), (512, 4, 1, 2), (64, 4, 1, 1),
+                                       (128, 2, 2, 2), (1024, 4, 1, 2), (2048, 4, 1, 0)])
+def test_synthesis_matches_oracle(orc, dev, M, m, r, dct):
+    import torch
+    eng = _eng()
+    g = design_prototype(M, m, "g")
+    rng = np.random.default_rng(M)
+    T, S, K = 37, 2, M // 2 + 1
+    Yk = (rng.normal(size=(S, K, T)) + 1j * rng.normal(size=(S, K, T))) * 1000.0
+    fb = eng.FilterBank(g, M, m, r, dct, synthesis=True)
+    out = fb.synthesize(torch.from_numpy(Yk.astype(np.complex64)).to(dev)).cpu().numpy()
+    for s in range(S):
+        Yc = Yk[s].astype(np.complex64).astype(np.complex128)            # what the GPU saw
+        full = np.zeros((T, M), np.complex128)
+        full[:, :K] = Yc.T
+        full[:, K:] = np.conj(Yc.T[:, M // 2 - 1:0:-1])
+        ref = orc.synthesis(g, M, m, r, dct, full)
+        assert out[s].shape == ref.shape
+        # tolerance: float32 arithmetic on int16-scale output, well below 0.5 LSB
+        assert np.max(np.abs(out[s] - ref)) <= 2e-6 * np.max(np.abs(ref)) * np.sqrt(M)
+
+
+def test_round_trip_reference_prototypes(dev, proto256, kinect_pcm):
+    """analysis -> synthesis with the reference's shipped Nyquist(M) prototypes reproduces the input
+    at lag 0 (what tools/filterbank/test_oversampled_dft_filter.py measures): size-independent property."""
+    import torch
+    eng = _eng()
+    h, g = proto256
+    for dct in (2, 0):
+        afb = eng.FilterBank(h, 256, 4, 1, dct)
+        sfb = eng.FilterBank(g, 256, 4, 1, dct, synthesis=True)
+        X = afb.analysis(torch.from_numpy(kinect_pcm[None, :1]).to(dev))          # [1][129][1][T]
+        y = sfb.synthesize(X[:, :, 0, :].contiguous()).cpu().numpy()[0]
+        assert len(y) == 610 * 128
+        a, b = kinect_pcm[0][2000:70000], y[2000:70000]
+        snr = 10 * np.log10(np.sum(a * a) / np.sum((a - b) ** 2))
+        assert snr > 50.0, snr
