@@ -233,6 +233,9 @@ void synthesis_kernel(const float2* __restrict__ Y, long nframes, long T_stride,
     if (bglob - b0 >= bcount) continue;
     float acc = 0.f;
     for (int j = 0; j < R; j++) {
+      // gsi_ only holds s-frames computed by earlier next() calls: before block 0 the ring is
+      // still zero (nothing is pushed to gsi_ while priming, modulated.cc:574-578,600)
+      if (bglob - (R - 1 - j) < 0) continue;
       const int i = d + j * D;
       const int vrow = bb + j + R * (m - 1);                      // row of v_{f-(R-1-j)} in vbuf
       float sv = 0.f;
