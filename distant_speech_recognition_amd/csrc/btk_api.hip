@@ -212,4 +212,35 @@ int btk_weights_gsc_effective(const double* wq_in, const double* wl_in, int M, i
   return BTK_OK;
 }
 
+// u = wa^H B^T and back (B^T has orthonormal rows, so wa^H = u conj(B)); see nlms_kernels.hip
+int btk_nlms_wa_to_u(const double* waH_in, const double* B_in, int N, double* u_out)
+{
+  if (N < 2) return btk_set_error(BTK_ERR_DIMENSION, "btk_nlms_wa_to_u: N=%d", N);
+  const cd* wa = reinterpret_cast<const cd*>(waH_in);
+  const cd* B = reinterpret_cast<const cd*>(B_in);
+  cd* u = reinterpret_cast<cd*>(u_out);
+  const int bs = N - 1;
+  for (int n = 0; n < N; n++) {
+    cd acc(0.0, 0.0);
+    for (int i = 0; i < bs; i++) acc += wa[i] * B[(size_t)n * bs + i];
+    u[n] = acc;
+  }
+  return BTK_OK;
+}
+
+int btk_nlms_u_to_wa(const double* u_in, const double* B_in, int N, double* waH_out)
+{
+  if (N < 2) return btk_set_error(BTK_ERR_DIMENSION, "btk_nlms_u_to_wa: N=%d", N);
+  const cd* u = reinterpret_cast<const cd*>(u_in);
+  const cd* B = reinterpret_cast<const cd*>(B_in);
+  cd* wa = reinterpret_cast<cd*>(waH_out);
+  const int bs = N - 1;
+  for (int i = 0; i < bs; i++) {
+    cd acc(0.0, 0.0);
+    for (int n = 0; n < N; n++) acc += u[n] * std::conj(B[(size_t)n * bs + i]);
+    wa[i] = acc;
+  }
+  return BTK_OK;
+}
+
 }  // extern "C"

@@ -1,0 +1,287 @@
+// nlms_kernels.hip -- adaptive GSC canceller (leaky power-normalised NLMS) for gfx950.
+//
+// Replaces SubbandGSCLMSBeamformer.__iter__ (reference lib/pybeamformer.py:659-734), a per-frame,
+// per-bin numpy loop, with three kernels per block of T frames:
+//
+//   1. nlms_energy_kernel   energy[s][t] = |X_0^H X_0| / M over all M bins of channel 0
+//                           (update_snapshot_array(chan_no=0), pybeamformer.py:263-277,:665)
+//   2. nlms_control_kernel  the scalar recurrences of one stream: gamma halving (:668-670), the
+//                           silence gate energy > E_avg / sil_thresh (:672), E_avg update (:731)
+//   3. nlms_bin_kernel      one wavefront (or lane group) per (stream, bin): sequential in t,
+//                           channels across lanes, x_t staged through LDS in 16-frame tiles.
+//
+// Algebra used by kernel 3 (Nc = 1).  The reference keeps wa (N-1 values) and forms Z = B^T x
+// (an (N-1)xN matvec per frame and bin).  With u = wa^H B^T (N values) every quantity it needs is
+// O(N):   wa^H Z = u x,   |wa|^2 = |u|^2   (B^T has orthonormal rows),
+//         conj(Z)^T B^T = (Q x)^H  with  Q = conj(B B^H) = I - vs vs^H / |vs|^2,  Q x = x - vs Yc / |vs|^2
+// because B spans the complement of conj(vs) (calc_blocking_matrix, pybeamformer.py:309-341) and
+// vs^H x = Yc is the upper-branch output.  The update wa^H += a e conj(Z)^T - a l wa^H becomes
+//         u <- (1 - a l) u + a e (Q x)^H
+// which is the SAME recursion in another basis: outputs are identical up to rounding, the
+// blocking matrix never has to be read, and the kernel stays HBM-bound (8 K N bytes per frame).
+// wa is recovered on demand as wa^H = u conj(B) (host side, btk_nlms_u_to_wa).
+#include "btk_internal.h"
+
+namespace {
+
+constexpr int TB = 16;                 // frames per LDS tile (128-byte rows)
+constexpr int LDW = TB + 1;            // padded row length (float2 units): conflict-free column reads
+
+__global__ __launch_bounds__(256)
+void nlms_energy_kernel(const float2* __restrict__ X, int K, int N, int M, long T_stride, long T,
+                        float* __restrict__ energy /* [S][T] */)
+{
+  const int s = blockIdx.y;
+  const long t = (long)blockIdx.x * 256 + threadIdx.x;
+  if (t >= T) return;
+  const float2* x = X + (long)s * K * N * T_stride + t;        // channel 0
+  float acc = 0.f;
+  for (int k = 0; k < K; k++) {
+    const float2 v = x[(long)k * N * T_stride];
+    const float p = fmaf(v.x, v.x, v.y * v.y);
+    acc += (k == 0 || k == K - 1) ? p : 2.f * p;               // mirror bins M-k carry |X_k|^2 again
+  }
+  energy[(long)s * T + t] = acc / (float)M;
+}
+
+struct NlmsParams {
+  float beta, init_gamma, reg, energy_floor, sil_thresh, max_wa_l2norm;
+  int min_frames, slowdown_after;
+};
+
+// stream_state[s] = { E_avg, gamma, isamp, ttl_updates } (doubles, in/out)
+__global__ void nlms_control_kernel(const float* __restrict__ energy, long T, NlmsParams p,
+                                    double* __restrict__ stream_state, float* __restrict__ ctrl /* [S][T] */)
+{
+  const int s = blockIdx.x;
+  double* st = stream_state + 4 * (long)s;
+  double E = st[0], gamma = st[1];
+  long isamp = (long)st[2], ttl = (long)st[3];
+  const float* e = energy + (long)s * T;
+  float* c = ctrl + (long)s * T;
+  for (long t = 0; t < T; t++, isamp++) {
+    if (isamp > 0 && (isamp % p.slowdown_after) == 0) gamma *= 0.5;          // pybeamformer.py:668-670
+    const double en = e[t];
+    const bool adapt = en > E / (double)p.sil_thresh;                       // :672, :690
+    if (adapt) ttl++;
+    c[t] = adapt ? (float)gamma : 0.f;
+    E = E * (double)p.beta + (1.0 - (double)p.beta) * en;                   // :731
+  }
+  st[0] = E; st[1] = gamma; st[2] = (double)isamp; st[3] = (double)ttl;
+}
+
+template <int GROUP>
+__device__ __forceinline__ float group_sum(float v)
+{
+#pragma unroll
+  for (int d = GROUP / 2; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+  return v;
+}
+
+// GROUP lanes cooperate on one bin (GROUP = 64 covers N <= 64*CPL); a wavefront holds 64/GROUP bins.
+template <int GROUP, int CPL>
+__global__ __launch_bounds__(64)
+void nlms_bin_kernel(const float2* __restrict__ X, const float2* __restrict__ VS /* [K][N] */,
+                     float2* __restrict__ Y, int K, int N, long T_stride, long T,
+                     const float* __restrict__ ctrl,
+                     const double* __restrict__ stream_state_before /* isamp at block start, [S][4] */,
+                     NlmsParams p, float2* __restrict__ U /* [S][K][N] in/out */,
+                     float* __restrict__ sigma2 /* [S][K] in/out */)
+{
+  constexpr int BPW = 64 / GROUP;                       // bins per wavefront
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float2* tile = reinterpret_cast<float2*>(smem);      // [BPW*NR][LDW], NR = N rounded to GROUP*CPL
+  const int lane = threadIdx.x;
+  const int s = blockIdx.y;
+  const int kb = blockIdx.x * BPW;
+  const int gl = lane % GROUP, gi = lane / GROUP;       // lane in group, group (local bin) index
+  const int k = kb + gi;
+  const bool kvalid = k < K;
+  const int NR = GROUP * CPL;
+  const long isamp0 = (long)stream_state_before[4 * (long)s + 2];
+
+  // per-lane constants and state
+  float2 vs[CPL], u[CPL];
+  float vvp = 0.f;
+#pragma unroll
+  for (int c = 0; c < CPL; c++) {
+    const int n = gl + GROUP * c;
+    const bool ok = kvalid && n < N;
+    vs[c] = ok ? VS[(long)k * N + n] : make_float2(0.f, 0.f);
+    u[c] = ok ? U[((long)s * K + k) * N + n] : make_float2(0.f, 0.f);
+    vvp += vs[c].x * vs[c].x + vs[c].y * vs[c].y;
+  }
+  const float vv = group_sum<GROUP>(vvp);
+  const float inv_vv = vv > 0.f ? 1.f / vv : 0.f;
+  float sig = kvalid ? sigma2[(long)s * K + k] : 1.f;
+
+  // tile loader: rows = BPW*NR (row r -> local bin r / NR, channel r % NR), TB float2 per row;
+  // 16 consecutive lanes read one 128-byte row segment.
+  constexpr int ROWS_PER_PASS = 64 / TB;                // 4 rows per wave-load
+  constexpr int NPASS = CPL * 64 / ROWS_PER_PASS;       // BPW*NR rows / 4 rows per pass
+  float2 pre[NPASS];
+  float creg = 0.f;                                     // ctrl[t0 + lane%TB] of the staged tile
+  const int lrow = lane / TB, lcol = lane % TB;
+
+  auto prefetch = [&](long t0) {
+    const long t = t0 + lcol;
+#pragma unroll
+    for (int q = 0; q < NPASS; q++) {
+      const int r = q * ROWS_PER_PASS + lrow;
+      const int bl = r / NR, n = r % NR;
+      const int kk = kb + bl;
+      float2 v = make_float2(0.f, 0.f);
+      if (kk < K && n < N && t < T)
+        v = X[(((long)s * K + kk) * N + n) * T_stride + t];
+      pre[q] = v;
+    }
+    creg = t < T ? ctrl[(long)s * T + t] : 0.f;
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int q = 0; q < NPASS; q++) tile[(q * ROWS_PER_PASS + lrow) * LDW + lcol] = pre[q];
+  };
+
+  prefetch(0);
+  for (long t0 = 0; t0 < T; t0 += TB) {
+    __syncthreads();                                    // previous tile fully consumed
+    commit();
+    const float ctile = creg;
+    __syncthreads();
+    if (t0 + TB < T) prefetch(t0 + TB);                 // loads fly while this tile is processed
+    float2 yout = make_float2(0.f, 0.f);
+    const int nsteps = (T - t0) < TB ? (int)(T - t0) : TB;
+    for (int tt = 0; tt < nsteps; tt++) {
+      const long t = t0 + tt;
+      float2 x[CPL];
+      float ycr = 0.f, yci = 0.f, pr = 0.f, pi = 0.f, xx = 0.f, uu = 0.f;
+#pragma unroll
+      for (int c = 0; c < CPL; c++) {
+        x[c] = tile[(gi * NR + gl + GROUP * c) * LDW + tt];
+        // Yc = conj(vs) . x ; p = u . x
+        ycr = fmaf(vs[c].x, x[c].x, fmaf(vs[c].y, x[c].y, ycr));
+        yci = fmaf(vs[c].x, x[c].y, fmaf(-vs[c].y, x[c].x, yci));
+        pr = fmaf(u[c].x, x[c].x, fmaf(-u[c].y, x[c].y, pr));
+        pi = fmaf(u[c].x, x[c].y, fmaf(u[c].y, x[c].x, pi));
+        xx = fmaf(x[c].x, x[c].x, fmaf(x[c].y, x[c].y, xx));
+        uu = fmaf(u[c].x, u[c].x, fmaf(u[c].y, u[c].y, uu));
+      }
+      ycr = group_sum<GROUP>(ycr); yci = group_sum<GROUP>(yci);
+      pr = group_sum<GROUP>(pr);   pi = group_sum<GROUP>(pi);
+      xx = group_sum<GROUP>(xx);   uu = group_sum<GROUP>(uu);
+
+      const long isamp = isamp0 + t;
+      float se = (isamp > 0) ? fmaf(sig, p.beta, (1.f - p.beta) * xx) : xx;          // :682-685
+      if (se < p.energy_floor) se = p.energy_floor;                                  // :687-688
+      const float gam = __shfl(ctile, tt, 64);                                        // 0 => no adaptation
+      float pnr = pr, pni = pi;
+      if (gam > 0.f) {                                                               // :690-720
+        const float er = ycr - pr, ei = yci - pi;                                    // epa
+        const float a = gam / se;
+        const float c1 = p.reg > 0.f ? 1.f - a * p.reg : 1.f;
+        const float c2r = a * er, c2i = a * ei;
+        const float gg = xx - (ycr * ycr + yci * yci) * inv_vv;                      // |Q x|^2
+        const float nrm = c1 * c1 * uu + (c2r * c2r + c2i * c2i) * gg + 2.f * c1 * (c2r * pr + c2i * pi);
+        const float cK = nrm > p.max_wa_l2norm ? sqrtf(p.max_wa_l2norm / nrm) : 1.f;
+        const float sr = ycr * inv_vv, si = yci * inv_vv;                            // Yc / |vs|^2
+#pragma unroll
+        for (int c = 0; c < CPL; c++) {
+          // q = x - vs * (Yc/|vs|^2);  u <- cK (c1 u + c2 conj(q))
+          const float qr = x[c].x - (vs[c].x * sr - vs[c].y * si);
+          const float qi = x[c].y - (vs[c].x * si + vs[c].y * sr);
+          const float nr = c1 * u[c].x + (c2r * qr + c2i * qi);
+          const float ni = c1 * u[c].y + (c2i * qr - c2r * qi);
+          u[c] = make_float2(cK * nr, cK * ni);
+        }
+        sig = se;
+        pnr = cK * (c1 * pr + c2r * gg);
+        pni = cK * (c1 * pi + c2i * gg);
+      }
+      const bool active = isamp >= p.min_frames;                                     // :723-726
+      const float outr = active ? ycr - pnr : ycr, outi = active ? yci - pni : yci;
+      if (GROUP >= TB) {
+        if (gl == tt) yout = make_float2(outr, outi);     // lane tt of the group keeps frame tt
+      } else {
+        // small groups: 8 lanes cannot hold 16 frames, write the frame directly
+        if (gl == 0 && kvalid) Y[((long)s * K + k) * T_stride + t] = make_float2(outr, outi);
+      }
+    }
+    if (GROUP >= TB && kvalid && gl < nsteps)
+      Y[((long)s * K + k) * T_stride + t0 + gl] = yout;
+  }
+
+  // write the state back
+  if (kvalid) {
+#pragma unroll
+    for (int c = 0; c < CPL; c++) {
+      const int n = gl + GROUP * c;
+      if (n < N) U[((long)s * K + k) * N + n] = u[c];
+    }
+    if (gl == 0) sigma2[(long)s * K + k] = sig;
+  }
+}
+
+template <int GROUP, int CPL>
+int launch_bin(const float2* X, const float2* VS, float2* Y, int S, int K, int N, long T_stride, long T,
+               const float* ctrl, const double* state_before, NlmsParams p, float2* U, float* sigma2, hipStream_t st)
+{
+  constexpr int BPW = 64 / GROUP;
+  const int NR = GROUP * CPL;
+  const size_t lds = sizeof(float2) * (size_t)BPW * NR * LDW;
+  dim3 grid((unsigned)((K + BPW - 1) / BPW), (unsigned)S);
+  hipLaunchKernelGGL((nlms_bin_kernel<GROUP, CPL>), grid, dim3(64), lds, st, X, VS, Y, K, N, T_stride, T,
+                     ctrl, state_before, p, U, sigma2);
+  BTK_HIP_CHECK(hipGetLastError());
+  return BTK_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+long btk_nlms_workspace_bytes(int S, long T)
+{
+  // energy [S][T] + ctrl [S][T] floats + a copy of the stream state [S][4] doubles
+  return (long)sizeof(float) * 2 * S * T + (long)sizeof(double) * 4 * S + 64;
+}
+
+int btk_nlms_process(const float* params /* host, 8 floats */, const void* vs, const void* X, void* Y,
+                     int S, int M, int N, long T_stride, long T,
+                     void* u_state, float* sigma2, double* stream_state, void* workspace, void* stream)
+{
+  if (!params || !vs || !X || !Y || !u_state || !sigma2 || !stream_state || !workspace)
+    return btk_set_error(BTK_ERR_PARAMETER, "btk_nlms_process: null argument");
+  if (S <= 0 || N < 2 || M < 2 || T < 0 || T_stride < T)
+    return btk_set_error(BTK_ERR_DIMENSION, "btk_nlms_process: bad sizes S=%d N=%d M=%d T=%ld", S, N, M, T);
+  if (N > 256) return btk_set_error(BTK_ERR_DIMENSION, "btk_nlms_process: N=%d > 256 channels not supported", N);
+  if (T == 0) return BTK_OK;
+  const int K = M / 2 + 1;
+  NlmsParams p;
+  p.beta = params[0]; p.init_gamma = params[1]; p.reg = params[2]; p.energy_floor = params[3];
+  p.sil_thresh = params[4]; p.max_wa_l2norm = params[5];
+  p.min_frames = (int)params[6]; p.slowdown_after = (int)params[7];
+  if (p.slowdown_after < 1) return btk_set_error(BTK_ERR_PARAMETER, "slowdown_after must be >= 1");
+  hipStream_t st = as_stream(stream);
+  float* energy = static_cast<float*>(workspace);
+  float* ctrl = energy + (long)S * T;
+  double* state_before = reinterpret_cast<double*>((reinterpret_cast<uintptr_t>(ctrl + (long)S * T) + 63) & ~(uintptr_t)63);
+  const float2* Xp = static_cast<const float2*>(X);
+
+  hipLaunchKernelGGL(nlms_energy_kernel, dim3((unsigned)((T + 255) / 256), (unsigned)S), dim3(256), 0, st,
+                     Xp, K, N, M, T_stride, T, energy);
+  BTK_HIP_CHECK(hipMemcpyAsync(state_before, stream_state, sizeof(double) * 4 * S, hipMemcpyDeviceToDevice, st));
+  hipLaunchKernelGGL(nlms_control_kernel, dim3((unsigned)S), dim3(1), 0, st, energy, T, p, stream_state, ctrl);
+  BTK_HIP_CHECK(hipGetLastError());
+
+  const float2* VS = static_cast<const float2*>(vs);
+  float2* Yp = static_cast<float2*>(Y);
+  float2* U = static_cast<float2*>(u_state);
+  if (N <= 8)        return launch_bin<8, 1>(Xp, VS, Yp, S, K, N, T_stride, T, ctrl, state_before, p, U, sigma2, st);
+  else if (N <= 16)  return launch_bin<16, 1>(Xp, VS, Yp, S, K, N, T_stride, T, ctrl, state_before, p, U, sigma2, st);
+  else if (N <= 32)  return launch_bin<32, 1>(Xp, VS, Yp, S, K, N, T_stride, T, ctrl, state_before, p, U, sigma2, st);
+  else if (N <= 64)  return launch_bin<64, 1>(Xp, VS, Yp, S, K, N, T_stride, T, ctrl, state_before, p, U, sigma2, st);
+  else if (N <= 128) return launch_bin<64, 2>(Xp, VS, Yp, S, K, N, T_stride, T, ctrl, state_before, p, U, sigma2, st);
+  return launch_bin<64, 4>(Xp, VS, Yp, S, K, N, T_stride, T, ctrl, state_before, p, U, sigma2, st);
+}
+
+}  // extern "C"

@@ -165,3 +165,78 @@ def weights_gsc_effective(wq, wl, M, normalize=False):
     out = np.zeros((M // 2 + 1, N), np.complex64)
     check(_lib.lib().btk_weights_gsc_effective(_np_ptr(wq), wlp, M, N, int(normalize), _np_ptr(out)))
     return out
+
+
+# ---------------------------------------------------------------------------- adaptive canceller (NLMS)
+NLMS_DEFAULTS = dict(beta=0.97, gamma=0.01, init_diagonal_load=1.0e6, regularization_param=1.0e-4,
+                     energy_floor=90.0, sil_thresh=1.0e8, max_wa_l2norm=100.0, min_frames=128,
+                     slowdown_after=4096)      # lib/pybeamformer.py:597-607 == unit_test/confs/gsclms.json
+
+
+class NLMSState:
+    """Device-resident state of S independent SubbandGSCLMSBeamformer recursions
+    (reset_stats, lib/pybeamformer.py:745-758)."""
+
+    def __init__(self, S, M, N, device, **kw):
+        self.p = dict(NLMS_DEFAULTS)
+        self.p.update(kw)
+        self.S, self.M, self.N, self.K = S, M, N, M // 2 + 1
+        self.u = torch.zeros((S, self.K, N), dtype=torch.complex64, device=device)
+        self.sigma2 = torch.empty((S, self.K), dtype=torch.float32, device=device)
+        self.stream_state = torch.empty((S, 4), dtype=torch.float64, device=device)
+        self.reset_stats()
+        self._ws = None
+
+    def reset_stats(self):
+        self.u.zero_()
+        self.sigma2.fill_(self.p["init_diagonal_load"])
+        self.stream_state[:, 0] = self.p["init_diagonal_load"]
+        self.stream_state[:, 1] = self.p["gamma"]
+        self.stream_state[:, 2] = 0
+        self.stream_state[:, 3] = 0
+
+    def params_array(self):
+        p = self.p
+        return np.array([p["beta"], p["gamma"], p["regularization_param"], p["energy_floor"], p["sil_thresh"],
+                         p["max_wa_l2norm"], p["min_frames"], p["slowdown_after"]], np.float32)
+
+    def workspace(self, T):
+        need = _lib.lib().btk_nlms_workspace_bytes(self.S, T)
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=self.u.device)
+        return self._ws
+
+
+def nlms_process(vs, X, state, out=None):
+    """Adaptive GSC over a block: vs complex64 [K][N] (cuda), X [S][K][N][T] -> Y [S][K][T]; state updated in place."""
+    _need_cuda(vs, "vs")
+    _need_cuda(X, "X")
+    S, K, N, T = X.shape
+    if (S, K, N) != (state.S, state.K, state.N) or vs.shape != (K, N):
+        raise _lib.BtkError(_lib.BTK_ERR_DIMENSION, "nlms_process: shapes do not match the state")
+    if out is None:
+        out = torch.empty((S, K, T), dtype=torch.complex64, device=X.device)
+    params = state.params_array()
+    ws = state.workspace(T)
+    check(_lib.lib().btk_nlms_process(_np_ptr(params), _ptr(vs), _ptr(X), _ptr(out), S, state.M, N, T, T,
+                                      _ptr(state.u), _ptr(state.sigma2), _ptr(state.stream_state), _ptr(ws), _stream()))
+    return out
+
+
+def nlms_u_to_wa(u, B):
+    """wa^H (complex128 [N-1]) from the engine state u (complex [N]) and the bin's blocking matrix B."""
+    u = np.ascontiguousarray(u, np.complex128)
+    B = np.ascontiguousarray(B, np.complex128)
+    N = u.shape[0]
+    wa = np.zeros(N - 1, np.complex128)
+    check(_lib.lib().btk_nlms_u_to_wa(_np_ptr(u), _np_ptr(B), N, _np_ptr(wa)))
+    return wa
+
+
+def nlms_wa_to_u(waH, B):
+    waH = np.ascontiguousarray(waH, np.complex128)
+    B = np.ascontiguousarray(B, np.complex128)
+    N = B.shape[0]
+    u = np.zeros(N, np.complex128)
+    check(_lib.lib().btk_nlms_wa_to_u(_np_ptr(waH), _np_ptr(B), N, _np_ptr(u)))
+    return u

@@ -87,6 +87,27 @@ int  btk_fb_synthesis(const btk_fb_t* fb, const void* Y, long nframes, long T_st
 int  btk_bf_apply(const void* W, int per_stream_weights, const void* X, void* Y,
                   int S, int K, int N, long T_stride, long T, void* stream);
 
+/* ---- Adaptive GSC canceller: leaky power-normalised NLMS ----------------------------------
+ * Replaces SubbandGSCLMSBeamformer.__iter__ / reset_stats (lib/pybeamformer.py:659-762), Nc = 1.
+ * params [host] 8 floats: beta, gamma(init), regularization_param, energy_floor, sil_thresh,
+ *   max_wa_l2norm, min_frames, slowdown_after (pybeamformer.py:597-607).
+ * vs [dev] complex64 [K][N]: array manifold / N of bins 0..M/2 (calc_array_manifold_f :284-306;
+ *   the upper branch is Yc = vs^H x, the blocking matrix is implied by vs -- see DESIGN.md).
+ * State (all [dev], updated in place so consecutive blocks continue the recursion):
+ *   u_state complex64 [S][K][N]  = wa^H B^T  (zeros == reset_stats; convert with btk_nlms_*_wa)
+ *   sigma2  float32   [S][K]     = _subband_energy          (init_diagonal_load at reset)
+ *   stream_state float64 [S][4]  = {_energy, _gamma, _isamp, _ttl_updates}
+ * workspace [dev] btk_nlms_workspace_bytes(S,T) bytes.  Y [dev] complex64 [S][K][T_stride].    */
+long btk_nlms_workspace_bytes(int S, long T);
+int  btk_nlms_process(const float* params, const void* vs, const void* X, void* Y,
+                      int S, int M, int N, long T_stride, long T,
+                      void* u_state, float* sigma2, double* stream_state, void* workspace, void* stream);
+/* Host-side change of basis between the reference's active weights wa^H (complex128 [N-1], as
+ * kept in SubbandGSCLMSBeamformer._waH) and the engine state u = wa^H B^T (complex128 [N]);
+ * B [host] complex128 [N][N-1] from btk_weights_blocking_matrix.                               */
+int  btk_nlms_wa_to_u(const double* waH, const double* B, int N, double* u);
+int  btk_nlms_u_to_wa(const double* u, const double* B, int N, double* waH);
+
 /* ---- Host-side weight design (double precision, one-off per look direction) -------------
  * BeamformerWeights::calcMainlobe (beamformer.cc:502-565): wq [host] complex128 [M][N].     */
 int  btk_weights_mainlobe(int M, int N, float samplerate, const double* delays, double* wq);
