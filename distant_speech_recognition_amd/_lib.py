@@ -52,6 +52,15 @@ SIGNATURES = {
     "btk_nlms_process": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _l, _l, _vp, _vp, _vp, _vp, _vp]),
     "btk_nlms_wa_to_u": (_i, [_vp, _vp, _i, _vp]),
     "btk_nlms_u_to_wa": (_i, [_vp, _vp, _i, _vp]),
+    "btk_bf_apply_stats": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _l, _l, _vp]),
+    "btk_zelinski_process": (_i, [_vp, _vp, _vp, _i, _i, _i, _l, _l, _d, _i, _i, _l, _vp, _vp, _vp, _vp]),
+    "btk_frame_energy": (_i, [_vp, _i, _i, _i, _l, _l, _vp, _l, _vp]),
+    "btk_cov_frame_gate": (_i, [_vp, _vp, _i, _l, _l, _f, _vp, _vp, _vp]),
+    "btk_cov_accumulate": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _l, _l, _i, _vp]),
+    "btk_cov_finalize": (_i, [_vp, _vp, _i, _i, _i, _i, _f, _vp]),
+    "btk_mvdr_diffuse_model": (_i, [_vp, _i, _i, _f, _f, _vp, _vp]),
+    "btk_mvdr_diagonal_loading": (_i, [_vp, _i, _i, _f, _vp]),
+    "btk_mvdr_weights": (_i, [_vp, _vp, _vp, _i, _i, _f, _vp, _vp, _vp]),
     "btk_weights_mainlobe": (_i, [_i, _i, _f, _vp, _vp]),
     "btk_weights_blocking_matrix": (_i, [_vp, _i, _i, _vp]),
     "btk_weights_sidelobe": (_i, [_vp, _vp, _i, _i, _vp]),

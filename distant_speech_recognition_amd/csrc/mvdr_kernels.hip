@@ -1,0 +1,192 @@
+// mvdr_kernels.hip -- SubbandMVDR weight design on gfx950: diffuse-noise coherence model, diagonal
+// loading and a batched Hermitian solve for the MVDR weights.
+//
+// Replaces SubbandMVDR::set_diffuse_noise_model / set_all_diagonal_loading / calc_mvdr_weights
+// (reference beamformer/beamformer.cc:2442-2523, 2350-2402).  The reference inverts R_k with a
+// float32 LINPACK SVD pseudo-inverse (pseudoinverse(), :232-289) and substitutes the identity when a
+// singular value falls below dThreshold (:262-270, :2381-2383).  R_k is Hermitian; once it is
+// positive definite (diagonal loading) the pseudo-inverse IS the inverse, so the engine solves
+// R z = d by a complex Cholesky factorisation (one workgroup per bin, matrix resident in LDS) and
+// falls back to z = d (identity) when a pivot drops below the threshold -- the same observable rule.
+//     w_k = z / (N d^H z),  w_0 = all ones (:2369-2371),  d = wq_k (carries the 1/N factor, :542).
+#include "btk_internal.h"
+
+namespace {
+
+// Gamma_mn = sinc(2 fs k d_mn / (M c)), GSL sinc(x) = sin(pi x)/(pi x)  (beamformer.cc:2483-2502)
+__global__ __launch_bounds__(256)
+void diffuse_model_kernel(const float* __restrict__ mpos /* [N][3] */, int N, int M, float samplerate, float sspeed,
+                          float2* __restrict__ R /* [K][N][N] */)
+{
+  const int k = blockIdx.x;
+  const double omega_d_c = 2.0 * (double)samplerate * k / ((double)M * (double)sspeed);
+  float2* Rk = R + (long)k * N * N;
+  for (int idx = threadIdx.x; idx < N * N; idx += 256) {
+    const int a = idx / N, b = idx % N;
+    float v = 1.0f;
+    if (a != b) {
+      const double dx = (double)mpos[a * 3] - mpos[b * 3], dy = (double)mpos[a * 3 + 1] - mpos[b * 3 + 1],
+                   dz = (double)mpos[a * 3 + 2] - mpos[b * 3 + 2];
+      const double x = omega_d_c * sqrt(dx * dx + dy * dy + dz * dz);
+      v = (x == 0.0) ? 1.0f : (float)(sinpi(x) / (M_PI * x));
+    }
+    Rk[idx] = make_float2(v, 0.f);
+  }
+}
+
+__global__ void diag_load_kernel(float2* __restrict__ R, int N, float w)
+{
+  float2* Rk = R + (long)blockIdx.x * N * N;
+  for (int c = threadIdx.x; c < N; c += blockDim.x) Rk[(long)c * N + c].x += w;
+}
+
+// One workgroup per bin.  A (N x N, row-major, lower triangle used) lives in `mat` (LDS or global).
+// Right-looking Cholesky A = L L^H, then forward/back substitution for L y = d, L^H z = y.
+template <bool IN_LDS>
+__global__ __launch_bounds__(256)
+void mvdr_solve_kernel(const float2* __restrict__ R, const float2* __restrict__ Dq /* [K][N] d=wq */,
+                       float2* __restrict__ Wout /* [K][N] */, float2* __restrict__ scratch,
+                       int N, float threshold, int* __restrict__ fallback_count)
+{
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int k = blockIdx.x;
+  const int tid = threadIdx.x;
+  float2* rhs = reinterpret_cast<float2*>(smem);                   // [N]
+  float2* mat = IN_LDS ? rhs + N : scratch + (long)k * N * N;      // [N][N]
+  __shared__ int bad;
+  __shared__ float red_r[256], red_i[256];
+  const float2* Rk = R + (long)k * N * N;
+  if (k == 0) {                                                    // wmvdr_[0] = ones
+    for (int c = tid; c < N; c += 256) Wout[c] = make_float2(1.f, 0.f);
+    return;
+  }
+  for (int idx = tid; idx < N * N; idx += 256) mat[idx] = Rk[idx];
+  for (int c = tid; c < N; c += 256) rhs[c] = Dq[(long)k * N + c];
+  if (tid == 0) bad = 0;
+  __syncthreads();
+
+  for (int j = 0; j < N && !bad; j++) {
+    // pivot
+    if (tid == 0) {
+      const float piv = mat[(long)j * N + j].x;
+      if (!(piv > threshold)) bad = 1;
+      else mat[(long)j * N + j] = make_float2(sqrtf(piv), 0.f);
+    }
+    __syncthreads();
+    if (bad) break;
+    const float inv = 1.0f / mat[(long)j * N + j].x;
+    for (int i = j + 1 + tid; i < N; i += 256) {
+      float2 v = mat[(long)i * N + j];
+      mat[(long)i * N + j] = make_float2(v.x * inv, v.y * inv);
+    }
+    __syncthreads();
+    // trailing update of the lower triangle: A[i][c] -= L[i][j] conj(L[c][j]),  j < c <= i
+    const int rem = N - j - 1;
+    for (int idx = tid; idx < rem * rem; idx += 256) {
+      const int i = j + 1 + idx / rem, c = j + 1 + idx % rem;
+      if (c <= i) {
+        const float2 li = mat[(long)i * N + j], lc = mat[(long)c * N + j];
+        float2 v = mat[(long)i * N + c];
+        v.x -= li.x * lc.x + li.y * lc.y;
+        v.y -= li.y * lc.x - li.x * lc.y;
+        mat[(long)i * N + c] = v;
+      }
+    }
+    __syncthreads();
+  }
+  __syncthreads();
+  if (bad) {
+    // pseudoinverse() reported failure -> invR = identity -> tmpH = d  (beamformer.cc:2381-2383)
+    if (tid == 0) atomicAdd(fallback_count, 1);
+  } else {
+    // forward substitution L y = d (column sweep)
+    for (int j = 0; j < N; j++) {
+      if (tid == 0) { const float inv = 1.0f / mat[(long)j * N + j].x; rhs[j].x *= inv; rhs[j].y *= inv; }
+      __syncthreads();
+      const float2 yj = rhs[j];
+      for (int i = j + 1 + tid; i < N; i += 256) {
+        const float2 l = mat[(long)i * N + j];
+        rhs[i].x -= l.x * yj.x - l.y * yj.y;
+        rhs[i].y -= l.x * yj.y + l.y * yj.x;
+      }
+      __syncthreads();
+    }
+    // back substitution L^H z = y
+    for (int j = N - 1; j >= 0; j--) {
+      if (tid == 0) { const float inv = 1.0f / mat[(long)j * N + j].x; rhs[j].x *= inv; rhs[j].y *= inv; }
+      __syncthreads();
+      const float2 zj = rhs[j];
+      for (int i = tid; i < j; i += 256) {
+        const float2 l = mat[(long)j * N + i];                      // conj(L[j][i]) multiplies z_j
+        rhs[i].x -= l.x * zj.x + l.y * zj.y;
+        rhs[i].y -= l.x * zj.y - l.y * zj.x;
+      }
+      __syncthreads();
+    }
+  }
+  // Lambda = d^H z ; w = z / (N Lambda)
+  float pr = 0.f, pi = 0.f;
+  for (int c = tid; c < N; c += 256) {
+    const float2 d = Dq[(long)k * N + c], z = rhs[c];
+    pr += d.x * z.x + d.y * z.y;          // conj(z) d summed == zdotc(tmpH, d): real part
+    pi += z.x * d.y - z.y * d.x;
+  }
+  red_r[tid] = pr; red_i[tid] = pi;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (tid < o) { red_r[tid] += red_r[tid + o]; red_i[tid] += red_i[tid + o]; }
+    __syncthreads();
+  }
+  const float nr = red_r[0] * (float)N, ni = red_i[0] * (float)N;   // norm = Lambda * N (complex)
+  const float den = nr * nr + ni * ni;
+  for (int c = tid; c < N; c += 256) {
+    const float2 z = rhs[c];
+    Wout[(long)k * N + c] = make_float2((z.x * nr + z.y * ni) / den, (z.y * nr - z.x * ni) / den);
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int btk_mvdr_diffuse_model(const float* mpos, int N, int M, float samplerate, float sspeed, void* R, void* stream)
+{
+  if (!mpos || !R) return btk_set_error(BTK_ERR_PARAMETER, "btk_mvdr_diffuse_model: null argument");
+  if (N < 1 || M < 2) return btk_set_error(BTK_ERR_DIMENSION, "btk_mvdr_diffuse_model: bad sizes");
+  hipLaunchKernelGGL(diffuse_model_kernel, dim3((unsigned)(M / 2 + 1)), dim3(256), 0, as_stream(stream),
+                     mpos, N, M, samplerate, sspeed, static_cast<float2*>(R));
+  BTK_HIP_CHECK(hipGetLastError());
+  return BTK_OK;
+}
+
+int btk_mvdr_diagonal_loading(void* R, int nbins, int N, float weight, void* stream)
+{
+  if (!R) return btk_set_error(BTK_ERR_PARAMETER, "Construct first a noise covariance matrix");
+  hipLaunchKernelGGL(diag_load_kernel, dim3((unsigned)nbins), dim3(64), 0, as_stream(stream), static_cast<float2*>(R), N, weight);
+  BTK_HIP_CHECK(hipGetLastError());
+  return BTK_OK;
+}
+
+int btk_mvdr_weights(const void* R, const void* wq, void* W, int K, int N, float threshold,
+                     void* scratch, int* fallback_count, void* stream)
+{
+  if (!R || !wq || !W || !fallback_count) return btk_set_error(BTK_ERR_PARAMETER, "btk_mvdr_weights: null argument");
+  if (K < 1 || N < 1) return btk_set_error(BTK_ERR_DIMENSION, "btk_mvdr_weights: bad sizes");
+  const size_t lds_mat = sizeof(float2) * ((size_t)N * N + N);
+  if (lds_mat <= 150 * 1024) {
+    auto kern = mvdr_solve_kernel<true>;
+    if (lds_mat > 64 * 1024)
+      BTK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_mat));
+    hipLaunchKernelGGL(kern, dim3((unsigned)K), dim3(256), lds_mat, as_stream(stream), static_cast<const float2*>(R),
+                       static_cast<const float2*>(wq), static_cast<float2*>(W), nullptr, N, threshold, fallback_count);
+  } else {
+    if (!scratch) return btk_set_error(BTK_ERR_PARAMETER, "btk_mvdr_weights: N=%d needs a [K][N][N] complex64 scratch buffer", N);
+    hipLaunchKernelGGL(mvdr_solve_kernel<false>, dim3((unsigned)K), dim3(256), sizeof(float2) * N, as_stream(stream),
+                       static_cast<const float2*>(R), static_cast<const float2*>(wq), static_cast<float2*>(W),
+                       static_cast<float2*>(scratch), N, threshold, fallback_count);
+  }
+  BTK_HIP_CHECK(hipGetLastError());
+  return BTK_OK;
+}
+
+}  // extern "C"

@@ -29,7 +29,7 @@ constexpr int LDW = TB + 1;            // padded row length (float2 units): conf
 
 __global__ __launch_bounds__(256)
 void nlms_energy_kernel(const float2* __restrict__ X, int K, int N, int M, long T_stride, long T,
-                        float* __restrict__ energy /* [S][T] */)
+                        float* __restrict__ energy /* [S][e_stride] */, long e_stride)
 {
   const int s = blockIdx.y;
   const long t = (long)blockIdx.x * 256 + threadIdx.x;
@@ -41,7 +41,7 @@ void nlms_energy_kernel(const float2* __restrict__ X, int K, int N, int M, long 
     const float p = fmaf(v.x, v.x, v.y * v.y);
     acc += (k == 0 || k == K - 1) ? p : 2.f * p;               // mirror bins M-k carry |X_k|^2 again
   }
-  energy[(long)s * T + t] = acc / (float)M;
+  energy[(long)s * e_stride + t] = acc / (float)M;
 }
 
 struct NlmsParams {
@@ -239,6 +239,19 @@ int launch_bin(const float2* X, const float2* VS, float2* Y, int S, int K, int N
 
 extern "C" {
 
+// energy[s][t] = |X_0^H X_0| / M of channel 0 over all M bins: MultiChannelSource.update_snapshot_array
+// (pybeamformer.py:263-277) as used by the NLMS gate (:665) and the covariance gates (:978, :1080, :1131).
+int btk_frame_energy(const void* X, int S, int M, int N, long T_stride, long T, float* energy, long e_stride, void* stream)
+{
+  if (!X || !energy) return btk_set_error(BTK_ERR_PARAMETER, "btk_frame_energy: null argument");
+  if (S <= 0 || N <= 0 || T < 0 || T_stride < T || e_stride < T) return btk_set_error(BTK_ERR_DIMENSION, "btk_frame_energy: bad sizes");
+  if (T == 0) return BTK_OK;
+  hipLaunchKernelGGL(nlms_energy_kernel, dim3((unsigned)((T + 255) / 256), (unsigned)S), dim3(256), 0, as_stream(stream),
+                     static_cast<const float2*>(X), M / 2 + 1, N, M, T_stride, T, energy, e_stride);
+  BTK_HIP_CHECK(hipGetLastError());
+  return BTK_OK;
+}
+
 long btk_nlms_workspace_bytes(int S, long T)
 {
   // energy [S][T] + ctrl [S][T] floats + a copy of the stream state [S][4] doubles
@@ -268,7 +281,7 @@ int btk_nlms_process(const float* params /* host, 8 floats */, const void* vs, c
   const float2* Xp = static_cast<const float2*>(X);
 
   hipLaunchKernelGGL(nlms_energy_kernel, dim3((unsigned)((T + 255) / 256), (unsigned)S), dim3(256), 0, st,
-                     Xp, K, N, M, T_stride, T, energy);
+                     Xp, K, N, M, T_stride, T, energy, T);
   BTK_HIP_CHECK(hipMemcpyAsync(state_before, stream_state, sizeof(double) * 4 * S, hipMemcpyDeviceToDevice, st));
   hipLaunchKernelGGL(nlms_control_kernel, dim3((unsigned)S), dim3(1), 0, st, energy, T, p, stream_state, ctrl);
   BTK_HIP_CHECK(hipGetLastError());

@@ -240,3 +240,113 @@ def nlms_wa_to_u(waH, B):
     u = np.zeros(N, np.complex128)
     check(_lib.lib().btk_nlms_wa_to_u(_np_ptr(waH), _np_ptr(B), N, _np_ptr(u)))
     return u
+
+
+# ---------------------------------------------------------------------------- Zelinski post-filter
+class ZelinskiState:
+    """Summed CSD / PSD state of S post-filters (the part of BeamformerWeights::CSDs_/wp1_,
+    beamformer.cc:874-887, that the Zelinski gain depends on)."""
+
+    def __init__(self, S, K, device):
+        self.phi = torch.zeros((S, K), dtype=torch.complex64, device=device)
+        self.psi = torch.zeros((S, K), dtype=torch.float32, device=device)
+        self.w_last = torch.zeros((S, K), dtype=torch.float32, device=device)
+        self.frames_done = 0
+
+    def reset_csd(self):
+        """What alloc_bfweight_ does to the post-filter state when weights are recomputed
+        (beamformer.cc:1082-1092): CSD history restarts, the frame counter keeps counting."""
+        self.phi.zero_()
+        self.psi.zero_()
+        self.w_last.zero_()
+
+
+def bf_apply_zelinski(W, D, X, state, alpha=0.6, type_=2, min_frames=0, out=None):
+    """Beamform + Zelinski post-filter over a block (ZelinskiPostFilter over SubbandDS/GSC/MVDR).
+    W, D complex64 [S|1][K][N]; X [S][K][N][T] -> Y [S][K][T] (post-filtered)."""
+    _need_cuda(W, "W"); _need_cuda(D, "D"); _need_cuda(X, "X")
+    S, K, N, T = X.shape
+    if W.dim() == 2:
+        W, D = W.unsqueeze(0), D.unsqueeze(0)
+    if out is None:
+        out = torch.empty((S, K, T), dtype=torch.complex64, device=X.device)
+    Cc = torch.empty((S, K, T), dtype=torch.complex64, device=X.device)
+    Ee = torch.empty((S, K, T), dtype=torch.float32, device=X.device)
+    L = _lib.lib()
+    check(L.btk_bf_apply_stats(_ptr(W), _ptr(D), int(W.shape[0] == S and S > 1), _ptr(X), _ptr(out), _ptr(Cc), _ptr(Ee),
+                               S, K, N, T, T, _stream()))
+    check(L.btk_zelinski_process(_ptr(out), _ptr(Cc), _ptr(Ee), S, K, N, T, T, float(alpha), int(type_), int(min_frames),
+                                 state.frames_done, _ptr(state.phi), _ptr(state.psi), _ptr(state.w_last), _stream()))
+    state.frames_done += T
+    return out
+
+
+# ---------------------------------------------------------------------------- covariance accumulation
+def frame_energy(X, M):
+    _need_cuda(X, "X")
+    S, K, N, T = X.shape
+    e = torch.empty((S, T), dtype=torch.float32, device=X.device)
+    check(_lib.lib().btk_frame_energy(_ptr(X), S, M, N, T, T, _ptr(e), T, _stream()))
+    return e
+
+
+def cov_frame_gate(energy, label, threshold, count=None):
+    """w = (energy > threshold) * label; returns (w [S][T], count [S])."""
+    S, T = energy.shape
+    w = torch.empty_like(energy)
+    if count is None:
+        count = torch.zeros(S, dtype=torch.float32, device=energy.device)
+    check(_lib.lib().btk_cov_frame_gate(_ptr(energy), None if label is None else _ptr(label), S, T, T, float(threshold),
+                                        _ptr(w), _ptr(count), _stream()))
+    return w, count
+
+
+def cov_accumulate(X, R=None, tf_weights=None, frame_weights=None, use_mfma=True):
+    """R[s][k] += sum_t tf[s][k][t] fw[s][t] x x^H.  X [S][K][N][T] -> R complex64 [S][K][N][N]."""
+    _need_cuda(X, "X")
+    S, K, N, T = X.shape
+    if R is None:
+        R = torch.zeros((S, K, N, N), dtype=torch.complex64, device=X.device)
+    check(_lib.lib().btk_cov_accumulate(_ptr(X), None if tf_weights is None else _ptr(tf_weights),
+                                        None if frame_weights is None else _ptr(frame_weights), _ptr(R),
+                                        S, K, N, T, T, int(use_mfma), _stream()))
+    return R
+
+
+def cov_finalize(R, count, gamma=0.0):
+    S, K, N, _ = R.shape
+    per_bin = int(count.dim() == 2)
+    check(_lib.lib().btk_cov_finalize(_ptr(R), _ptr(count), per_bin, S, K, N, float(gamma), _stream()))
+    return R
+
+
+# ---------------------------------------------------------------------------- MVDR weight design
+def mvdr_diffuse_model(mpos, M, samplerate, sspeed=343740.0, device=None):
+    mp = torch.as_tensor(np.ascontiguousarray(mpos, np.float32)).to(device)
+    N = mp.shape[0]
+    if mp.shape[1] < 3:
+        raise _lib.BtkError(_lib.BTK_ERR_DIMENSION, "The microphone positions should be described in the three dimensions")
+    R = torch.empty((M // 2 + 1, N, N), dtype=torch.complex64, device=mp.device)
+    check(_lib.lib().btk_mvdr_diffuse_model(_ptr(mp), N, M, float(samplerate), float(sspeed), _ptr(R), _stream()))
+    return R
+
+
+def mvdr_diagonal_loading(R, weight):
+    nb, N = R.shape[-3], R.shape[-1]
+    nb = int(np.prod(R.shape[:-2]))
+    check(_lib.lib().btk_mvdr_diagonal_loading(_ptr(R), nb, N, float(weight), _stream()))
+    return R
+
+
+def mvdr_weights(R, wq, threshold=1.0e-8):
+    """R complex64 [K][N][N], wq complex64 [K][N] (cuda) -> (W [K][N], number of identity fall-backs)."""
+    _need_cuda(R, "R"); _need_cuda(wq, "wq")
+    K, N, _ = R.shape
+    W = torch.empty((K, N), dtype=torch.complex64, device=R.device)
+    fb = torch.zeros(1, dtype=torch.int32, device=R.device)
+    scratch = None
+    if 8 * (N * N + N) > 150 * 1024:
+        scratch = torch.empty((K, N, N), dtype=torch.complex64, device=R.device)
+    check(_lib.lib().btk_mvdr_weights(_ptr(R), _ptr(wq), _ptr(W), K, N, float(threshold),
+                                      None if scratch is None else _ptr(scratch), _ptr(fb), _stream()))
+    return W, int(fb.item())

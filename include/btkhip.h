@@ -108,6 +108,58 @@ int  btk_nlms_process(const float* params, const void* vs, const void* X, void* 
 int  btk_nlms_wa_to_u(const double* waH, const double* B, int N, double* u);
 int  btk_nlms_u_to_wa(const double* u, const double* B, int N, double* waH);
 
+/* ---- Zelinski post-filter -------------------------------------------------------------------
+ * Replaces ZelinskiFilter_f / ZelinskiFilter / ZelinskiPostFilter::next
+ * (postfilter/postfilter.cc:57-219, 424-491).  Two calls per block:
+ * btk_bf_apply_stats = btk_bf_apply plus, from the SAME pass over X, the per-frame statistics of
+ *   the time-aligned snapshot x' = conj(d) x:  C = sum_{i<j} x'_i conj(x'_j) (complex64
+ *   [S][K][T_stride]) and E = sum_i |x'_i|^2 (float32 [S][K][T_stride]).  D [dev] has W's layout
+ *   and holds wq (type & 8, TYPE_ZELINSKI2) or ta_ (postfilter.cc:452-457).
+ * btk_zelinski_process = the alpha-recursion on the summed cross/auto spectral densities
+ *   (alpha = 0 for the post-filter's first two frames, :460-463), the gain
+ *   clamp(f(Phi)/Psi * 2/(N-1), 1e-4, 1) with f = max(Re,0) (type & 1) or |.|, and y <- W y for
+ *   frames >= min_frames.  frames_done = frames this post-filter produced before this block.
+ *   State [dev]: phi complex64 [S][K], psi float32 [S][K], w_last float32 [S][K] (postfilter_weights()).
+ *   Zero the state where the reference re-allocates BeamformerWeights (beamformer.cc:1082-1092).  */
+int  btk_bf_apply_stats(const void* W, const void* D, int per_stream_weights, const void* X, void* Y,
+                        void* C, float* E, int S, int K, int N, long T_stride, long T, void* stream);
+int  btk_zelinski_process(void* Y, const void* C, const float* E, int S, int K, int N, long T_stride, long T,
+                          double alpha, int type, int min_frames, long frames_done,
+                          void* phi_state, float* psi_state, float* w_last, void* stream);
+
+/* ---- Spatial covariance accumulation ----------------------------------------------------------
+ * btk_frame_energy: |X_0^H X_0| / M of channel 0 over all M bins, per frame
+ *   (MultiChannelSource.update_snapshot_array, lib/pybeamformer.py:263-277); energy [dev] [S][e_stride].
+ * btk_cov_frame_gate: w[s][t] = (energy > threshold) * label[s][t] and count[s] += sum_t w
+ *   (accu_stats_from_label, pybeamformer.py:967-985; label==NULL means all frames eligible).
+ * btk_cov_accumulate: R[s][k] += sum_t tf[s][k][t] * fw[s][t] * x x^H  (either weight may be NULL;
+ *   pybeamformer.py:979-981, 1087-1093, 1136-1147).  R [dev] complex64 [S][K][N][N].
+ *   use_mfma != 0 selects the v_mfma_f32_32x32x2_f32 kernel, 0 the vector-ALU kernel.
+ * btk_cov_finalize: R <- R/count, then (gamma > 0) improve_matrix_condition
+ *   (pybeamformer.py:994-1000, 1200-1207, 1249-1263); count [dev] [S] or [S][K].                  */
+int  btk_frame_energy(const void* X, int S, int M, int N, long T_stride, long T, float* energy,
+                      long e_stride, void* stream);
+int  btk_cov_frame_gate(const float* energy, const float* label, int S, long T_stride, long T,
+                        float energy_threshold, float* frame_weights, float* frame_count, void* stream);
+int  btk_cov_accumulate(const void* X, const float* tf_weights, const float* frame_weights, void* R,
+                        int S, int K, int N, long T_stride, long T, int use_mfma, void* stream);
+int  btk_cov_finalize(void* R, const float* count, int count_per_bin, int S, int K, int N, float gamma,
+                      void* stream);
+
+/* ---- SubbandMVDR weight design ------------------------------------------------------------------
+ * btk_mvdr_diffuse_model: set_diffuse_noise_model (beamformer.cc:2442-2509); mpos [dev] float32 [N][3],
+ *   R [dev] complex64 [K][N][N].
+ * btk_mvdr_diagonal_loading: set_all_diagonal_loading (beamformer.cc:2511-2523) over nbins matrices.
+ * btk_mvdr_weights: calc_mvdr_weights (beamformer.cc:2350-2402): w_k = R_k^-1 d / (N d^H R_k^-1 d),
+ *   w_0 = ones; batched complex Cholesky, identity fall-back counted in *fallback_count [dev int]
+ *   when a pivot <= threshold (the reference's pseudoinverse() failure path, :262-270, :2381-2383).
+ *   wq [dev] complex64 [K][N] = d; W [dev] complex64 [K][N]; scratch [dev] [K][N][N] complex64 only
+ *   needed when N*N*8 bytes exceed the LDS budget (N > 136).                                        */
+int  btk_mvdr_diffuse_model(const float* mpos, int N, int M, float samplerate, float sspeed, void* R, void* stream);
+int  btk_mvdr_diagonal_loading(void* R, int nbins, int N, float weight, void* stream);
+int  btk_mvdr_weights(const void* R, const void* wq, void* W, int K, int N, float threshold,
+                      void* scratch, int* fallback_count, void* stream);
+
 /* ---- Host-side weight design (double precision, one-off per look direction) -------------
  * BeamformerWeights::calcMainlobe (beamformer.cc:502-565): wq [host] complex128 [M][N].     */
 int  btk_weights_mainlobe(int M, int N, float samplerate, const double* delays, double* wq);
