@@ -1,0 +1,15 @@
+"""btk20 -- host-side mirror of the reference's SWIG module surface for the beamforming hot path.
+
+Same class names, constructor kwargs, iterator protocol (`__iter__` = reset + self, `.next()`,
+`StopIteration` at end of stream) and error behaviour as the reference's
+btk20.{stream,feature,modulated,beamformer,postfilter} (btk20_src/*/*.i).  Every node computes on the
+MI355X through the C-ABI (include/btkhip.h): a node pulls its finite upstream once, runs the
+whole block through the HIP kernels and then serves frames from a host mirror, so `next()`
+keeps the reference's per-frame semantics (node-owned buffer, same-frame caching, end-of-stream).
+"""
+from .common import *      # noqa: F401,F403
+from .stream import *      # noqa: F401,F403
+from .feature import *     # noqa: F401,F403
+from .modulated import *   # noqa: F401,F403
+from .beamformer import *  # noqa: F401,F403
+from .postfilter import *  # noqa: F401,F403

@@ -1,0 +1,472 @@
+"""SnapShotArrayPtr, SubbandDSPtr, SubbandGSCPtr, SubbandMVDRPtr, SubbandMVDRGSCPtr
+(beamformer/beamformer.h:28-437, beamformer/beamformer.i): the reference's node API, computed on
+the MI355X.  A beamformer node gathers the PCM behind its analysis-bank channels, runs ONE batched
+analysis + beamform pass on the device and serves frames; weights are designed host-side in float64
+(one-off per look direction) exactly as the reference does."""
+import numpy as np
+
+from .. import _lib, engine
+from .common import j_error, jallocation_error, jdimension_error, jiterator_error, raise_from_code
+from .modulated import OverSampledDFTAnalysisBankPtr, _mirror, _pull_all
+from .stream import VectorComplexFeatureStream, _BlockServedStream, device
+
+__all__ = ["SSPEED", "SnapShotArrayPtr", "SubbandDSPtr", "SubbandGSCPtr", "SubbandMVDRPtr", "SubbandMVDRGSCPtr",
+           "SubbandDS", "SubbandGSC", "SubbandMVDR", "SubbandMVDRGSC", "calc_all_delays"]
+
+SSPEED = 343740.0     # beamformer/beamformer.h:26
+
+
+class SnapShotArrayPtr(object):
+    """SnapShotArray (beamformer/spectralinfoarray.h:6-36, beamformer.cc:18-93)."""
+
+    def __init__(self, fftlen, chan_num):
+        self._fftlen, self._chan_num = int(fftlen), int(chan_num)
+        self._samples = np.zeros((self._chan_num, self._fftlen), np.complex128)
+        self._snapshots = np.zeros((self._fftlen, self._chan_num), np.complex128)
+
+    def fftlen(self):
+        return self._fftlen
+
+    def chan_num(self):
+        return self._chan_num
+
+    fftLen, nChan = fftlen, chan_num
+
+    def set_samples(self, samp, chan_no):
+        self._samples[chan_no] = samp
+
+    def update(self):
+        self._snapshots = self._samples.T.copy()
+
+    def snapshot(self, fbin_no):
+        return self._snapshots[fbin_no]
+
+    def zero(self):
+        self._samples[:] = 0
+        self._snapshots[:] = 0
+
+
+class _SubbandBeamformer(_BlockServedStream, VectorComplexFeatureStream):
+    def __init__(self, fftlen, half_band_shift=False, nm="SubbandBeamformer"):
+        _BlockServedStream.__init__(self, fftlen, nm)
+        if half_band_shift:
+            raise jallocation_error("halfBandShift==true is not yet supported\n")
+        self._fftlen = int(fftlen)
+        self._K = self._fftlen // 2 + 1
+        self._channels = []
+        self._X = None            # device snapshots [1][K][N][T]
+        self._Xhost = None
+        self._Y = None            # device output [1][K][T]
+        self._snapshot_array = None
+
+    # ---- wiring (beamformer.h:89-125)
+    def set_channel(self, chan):
+        self._channels.append(chan)
+
+    def clear_channel(self):
+        self._channels = []
+        self._snapshot_array = None
+        self._X = self._Y = self._Xhost = None
+
+    def chan_num(self):
+        return len(self._channels)
+
+    def fftlen(self):
+        return self._fftlen
+
+    def dim(self):
+        return self._fftlen
+
+    def is_end(self):
+        return self._is_end
+
+    setChannel, clearChannel, chanN, fftLen = set_channel, clear_channel, chan_num, fftlen
+
+    def snapshot_array(self):
+        """Live host mirror of the current frame's snapshots (read by post-filters, postfilter.cc:439-442)."""
+        if self._snapshot_array is None:
+            self._snapshot_array = SnapShotArrayPtr(self._fftlen, self.chan_num())
+        if self._X is not None and self._frame_no >= 0:
+            if self._Xhost is None:
+                self._Xhost = self._X[0].cpu().numpy()
+            xk = self._Xhost[:, :, self._frame_no]                      # [K][N]
+            full = np.zeros((self._fftlen, self.chan_num()), np.complex128)
+            full[: self._K] = xk
+            full[self._K:] = np.conj(xk[self._fftlen // 2 - 1:0:-1])
+            self._snapshot_array._snapshots = full
+            self._snapshot_array._samples = full.T.copy()
+        return self._snapshot_array
+
+    def snapshot_array_f(self, fbin_no):
+        return self.snapshot_array().snapshot(fbin_no)
+
+    # ---- device block
+    def device_snapshots(self):
+        """X complex64 [1][K][N][T] on the device: one batched analysis over all channels."""
+        if self._X is None:
+            import torch
+            chans = self._channels
+            if not chans:
+                raise j_error("set channels first\n")
+            if all(isinstance(c, OverSampledDFTAnalysisBankPtr) for c in chans) and \
+                    len(set(c.plan_key()[:4] for c in chans)) == 1:
+                pcms = [c.pcm() for c in chans]
+                L = min(len(p) for p in pcms)            # is_end_ as soon as any channel ends (beamformer.cc:1269)
+                pcm = np.stack([p[:L] for p in pcms])[None]
+                plan = chans[0]._plan
+                self._X = plan.analysis(torch.from_numpy(np.ascontiguousarray(pcm)).to(device()))
+            else:
+                frames = [_pull_all(c) for c in chans]
+                T = min(len(f) for f in frames)
+                Xh = np.stack([np.stack(f[:T])[:, : self._K] for f in frames])         # [N][T][K]
+                self._X = torch.from_numpy(np.ascontiguousarray(np.transpose(Xh, (2, 0, 1))[None]).astype(np.complex64)).to(device())
+            self._Xhost = None
+        return self._X
+
+    def device_block(self):
+        """Y complex64 [1][K][T] on the device (used by downstream GPU nodes without a host round trip)."""
+        if self._Y is None:
+            self._compute_block()
+        return self._Y
+
+    def effective_weights(self):
+        raise NotImplementedError
+
+    def _compute_block(self):
+        import torch
+        X = self.device_snapshots()
+        W = torch.from_numpy(self.effective_weights()).to(device())
+        try:
+            self._Y = engine.bf_apply(W, X)
+        except _lib.BtkError as e:
+            raise_from_code(e)
+
+    def _prepare(self):
+        Y = self.device_block()
+        self._frames = _mirror(Y[0].cpu().numpy(), self._fftlen)
+
+    def _invalidate_output(self):
+        """Weights changed: frames not yet served are recomputed with the new weights."""
+        if self._Y is not None:
+            done = self._frame_no + 1
+            old = self._frames
+            self._Y = None
+            self._frames = None
+            if old is not None:
+                self._prepare()
+                self._frames[:done] = old[:done]
+
+    def reset(self):
+        for c in self._channels:
+            c.reset()
+        if self._snapshot_array is not None:
+            self._snapshot_array.zero()
+        self._X = self._Y = self._Xhost = None
+        _BlockServedStream.reset(self)
+
+
+class _BeamformerWeights(object):
+    """BeamformerWeights (beamformer.h:28-82, beamformer.cc:485-965): wq, B, wa, wl, ta host-side in float64."""
+
+    def __init__(self, fftlen, chan_num, NC=1):
+        self.fftlen, self.chan_num, self.NC = fftlen, chan_num, NC
+        self.wq = np.zeros((fftlen, chan_num), np.complex128)
+        self.wl = np.zeros((fftlen, chan_num), np.complex128)
+        self.ta = np.zeros((fftlen, chan_num), np.complex128)
+        self.B = None if chan_num == 1 or chan_num == NC else np.zeros((fftlen, chan_num, chan_num - NC), np.complex128)
+        self.wa = None if self.B is None else np.zeros((fftlen, chan_num - NC), np.complex128)
+
+    def calc_mainlobe(self, samplerate, delays, is_gsc):
+        delays = np.asarray(delays, np.float64)
+        if delays.size != self.chan_num:
+            raise jdimension_error("Number of delays does not match number of channels (%d vs. %d).\n" % (delays.size, self.chan_num))
+        if is_gsc and self.chan_num <= 1:
+            raise jdimension_error("The number of channels must be > 1 but it is %d\n" % self.chan_num)
+        self.wq = engine.weights_mainlobe(self.fftlen, self.chan_num, samplerate, delays)
+        self.ta = self.wq.copy()                                           # setTimeAlignment
+        if is_gsc:
+            for k in range(self.fftlen):                                   # all M bins (beamformer.cc:557-563)
+                self.B[k] = engine.weights_blocking_matrix(self.wq[k], 1)
+
+    def calc_sidelobe_canceller_f(self, fbin, wa):
+        self.wa[fbin] = wa
+        self.wl[fbin] = engine.weights_sidelobe(self.B[fbin], wa)
+
+
+class SubbandDSPtr(_SubbandBeamformer):
+    """SubbandDS (beamformer.h:130-165, beamformer.cc:1023-1170)."""
+
+    def __init__(self, fftlen, half_band_shift=False, nm="SubbandDS"):
+        _SubbandBeamformer.__init__(self, fftlen, half_band_shift, nm)
+        self._bfw = []
+
+    def clear_channel(self):
+        _SubbandBeamformer.clear_channel(self)
+        self._bfw = []
+
+    def _alloc_bfweight(self, NC):
+        # re-creates the BeamformerWeights object -> resets active weights and post-filter state (beamformer.cc:1082-1092)
+        self._bfw = [_BeamformerWeights(self._fftlen, self.chan_num(), NC)]
+        self._weights_version = getattr(self, "_weights_version", 0) + 1
+
+    def calc_array_manifold_vectors(self, samplerate, delays):
+        self._alloc_bfweight(1)
+        self._bfw[0].calc_mainlobe(samplerate, delays, False)
+        self._invalidate_output()
+
+    def get_weights(self, fbin_no):
+        return self._bfw[0].wq[fbin_no]
+
+    def beamformer_weight_object(self, srcX=0):
+        return self._bfw[srcX]
+
+    calcArrayManifoldVectors, getWeights = calc_array_manifold_vectors, get_weights
+
+    def _check_weights(self):
+        if not self._bfw:
+            raise j_error("call calc_array_manifold_vectorsX() once\n")
+
+    def effective_weights(self):
+        self._check_weights()
+        return engine.weights_gsc_effective(self._bfw[0].wq, None, self._fftlen)
+
+    def alignment_vector(self, use_wq):
+        self._check_weights()
+        src = self._bfw[0].wq if use_wq else self._bfw[0].ta
+        return src[: self._K].astype(np.complex64)
+
+    def next(self, frame_no=-5):
+        if not (frame_no == self._frame_no and self._vector is not None):
+            self._check_weights()
+        return _SubbandBeamformer.next(self, frame_no)
+
+
+class SubbandGSCPtr(SubbandDSPtr):
+    """SubbandGSC (beamformer.h:169-204, beamformer.cc:1245-1445)."""
+
+    def __init__(self, fftlen, half_band_shift=False, nm="SubbandGSC"):
+        SubbandDSPtr.__init__(self, fftlen, half_band_shift, nm)
+        self._normalize_weight = False
+
+    def normalize_weight(self, flag):
+        self._normalize_weight = bool(flag)
+        self._invalidate_output()
+
+    def _check_weights(self):
+        if not self._bfw:
+            raise j_error("call calc_gsc_weights_X() once\n")
+
+    def calc_gsc_weights(self, samplerate, delays_t):
+        self._alloc_bfweight(1)
+        self._bfw[0].calc_mainlobe(samplerate, delays_t, True)
+        self._invalidate_output()
+
+    def set_quiescent_weights_f(self, fbin_no, src_wq):
+        self._alloc_bfweight(1)
+        self._bfw[0].wq[fbin_no] = src_wq
+        self._bfw[0].B[fbin_no] = engine.weights_blocking_matrix(self._bfw[0].wq[fbin_no], 1)
+        self._invalidate_output()
+
+    def set_active_weights_f(self, fbin_no, packed_weight):
+        if not self._bfw:
+            raise j_error("call calc_gsc_weights_x() once\n")
+        bw = self._bfw[0]
+        packed_weight = np.asarray(packed_weight, np.float64)
+        if packed_weight.size != 2 * (bw.chan_num - bw.NC):
+            raise jdimension_error("the size of an active weight vector must be %d but it is %d\n"
+                                   % (2 * (bw.chan_num - bw.NC), packed_weight.size))
+        if fbin_no >= self._fftlen:
+            raise jdimension_error("Must be a frequency bin %d < the length of FFT %d\n" % (fbin_no, self._fftlen))
+        bw.calc_sidelobe_canceller_f(fbin_no, packed_weight[0::2] + 1j * packed_weight[1::2])
+        self._dirty = True
+
+    def zero_active_weights(self):
+        if not self._bfw:
+            raise j_error("call calc_gsc_weights_x() once\n")
+        self._bfw[0].wa[:] = 0
+        self._bfw[0].wl[:] = 0
+        self._invalidate_output()
+
+    def blocking_matrix(self, fbin_no):
+        return self._bfw[0].B[fbin_no]
+
+    calcGSCWeights, setActiveWeights_f, getBlockingMatrix = calc_gsc_weights, set_active_weights_f, blocking_matrix
+
+    def effective_weights(self):
+        self._check_weights()
+        self._dirty = False
+        return engine.weights_gsc_effective(self._bfw[0].wq, self._bfw[0].wl, self._fftlen, self._normalize_weight)
+
+    def next(self, frame_no=-5):
+        if getattr(self, "_dirty", False) and not (frame_no == self._frame_no and self._vector is not None):
+            self._invalidate_output()
+        return SubbandDSPtr.next(self, frame_no)
+
+
+class SubbandMVDRPtr(SubbandDSPtr):
+    """SubbandMVDR (beamformer.h:333-383, beamformer.cc:2280-2599)."""
+
+    def __init__(self, fftlen, half_band_shift=False, nm="SubbandMVDR"):
+        SubbandDSPtr.__init__(self, fftlen, half_band_shift, nm)
+        self._R = None            # device complex64 [K][N][N]
+        self._wmvdr = None        # host complex128 [K][N]
+        self._fallbacks = 0
+
+    def clear_channel(self):
+        SubbandDSPtr.clear_channel(self)
+        self._R = None
+        self._wmvdr = None
+
+    def _alloc_R(self):
+        import torch
+        if self._R is None:
+            N = self.chan_num()
+            self._R = torch.zeros((self._K, N, N), dtype=torch.complex64, device=device())
+
+    def set_noise_spatial_spectral_matrix(self, fbin_no, Rnn):
+        import torch
+        Rnn = np.asarray(Rnn)
+        N = self.chan_num()
+        if Rnn.shape[0] != N or Rnn.shape[1] != N:
+            print("The number of the rows/columns of the matrix must be %d" % N)
+            return False
+        self._alloc_R()
+        self._R[fbin_no] = torch.from_numpy(Rnn.astype(np.complex64)).to(device())
+        return True
+
+    def set_noise_spatial_spectral_matrices(self, R):
+        """All bins at once from a device tensor [K][N][N] (no host round trip)."""
+        self._R = R.clone()
+
+    def noise_spatial_spectral_matrix(self, fbin_no):
+        return self._R[fbin_no].cpu().numpy().astype(np.complex128)
+
+    def set_diffuse_noise_model(self, mic_positions, samplerate, sspeed=SSPEED):
+        mp = np.asarray(mic_positions, np.float64)
+        if mp.shape[0] != self.chan_num():
+            print("The number of microphones must be %d but it is %d" % (self.chan_num(), mp.shape[0]))
+            return False
+        if mp.shape[1] < 3:
+            print("The microphone positions should be described in the three dimensions")
+            return False
+        self._R = engine.mvdr_diffuse_model(mp, self._fftlen, samplerate, sspeed, device=device())
+        return True
+
+    def set_all_diagonal_loading(self, diagonal_weight):
+        if self._R is None:
+            raise j_error("Construct first a noise covariance matrix\n")
+        engine.mvdr_diagonal_loading(self._R, diagonal_weight)
+
+    def set_diagonal_looading(self, fbin_no, diagonal_weight):          # sic: the reference's spelling
+        if self._R is None:
+            raise j_error("Construct first a noise covariance matrix\n")
+        engine.mvdr_diagonal_loading(self._R[fbin_no], diagonal_weight)
+
+    def divide_nondiagonal_elements(self, fbin_no, mu):
+        import torch
+        N = self.chan_num()
+        eye = torch.eye(N, device=device(), dtype=torch.bool)
+        self._R[fbin_no] = torch.where(eye, self._R[fbin_no], self._R[fbin_no] / (1.0 + mu))
+
+    def divide_all_nondiagonal_elements(self, mu):
+        for k in range(self._K):
+            self.divide_nondiagonal_elements(k, mu)
+
+    def calc_mvdr_weights(self, samplerate, dthreshold=1.0e-8, calc_inverse_matrix=True):
+        import torch
+        if self._R is None:
+            raise jallocation_error("Set a spatial spectral matrix before calling calc_mvdr_weights()\n")
+        self._check_weights()
+        wq = torch.from_numpy(self._bfw[0].wq[: self._K].astype(np.complex64)).to(device())
+        try:
+            W, self._fallbacks = engine.mvdr_weights(self._R, wq, dthreshold)
+        except _lib.BtkError as e:
+            raise_from_code(e)
+        self._wmvdr = W.cpu().numpy().astype(np.complex128)
+        self._invalidate_output()
+        return True
+
+    def mvdr_weights(self, fbin_no):
+        return self._wmvdr[fbin_no]
+
+    setDiffuseNoiseModel, setAllLevelsOfDiagonalLoading, calcMVDRWeights, getMVDRWeights = \
+        set_diffuse_noise_model, set_all_diagonal_loading, calc_mvdr_weights, mvdr_weights
+
+    def effective_weights(self):
+        self._check_weights()
+        if self._wmvdr is None:
+            raise j_error("call calc_mvdr_weights() once\n")
+        return self._wmvdr.astype(np.complex64)
+
+    def next(self, frame_no=-5):
+        if not (frame_no == self._frame_no and self._vector is not None) and self._wmvdr is None:
+            self._check_weights()
+            raise j_error("call calc_mvdr_weights() once\n")
+        return SubbandDSPtr.next(self, frame_no)
+
+
+class SubbandMVDRGSCPtr(SubbandMVDRPtr):
+    """SubbandMVDRGSC (beamformer.h:385-437, beamformer.cc:2604-2773): MVDR quiescent + GSC lower branch."""
+
+    def __init__(self, fftlen, half_band_shift=False, nm="SubbandMVDRGSC"):
+        SubbandMVDRPtr.__init__(self, fftlen, half_band_shift, nm)
+        self._normalize_weight = False
+
+    def normalize_weight(self, flag):
+        self._normalize_weight = bool(flag)
+
+    def set_active_weights_f(self, fbin_no, packed_weight):
+        if not self._bfw:
+            raise j_error("set the quiescent vector once\n")
+        bw = self._bfw[0]
+        packed_weight = np.asarray(packed_weight, np.float64)
+        wa = packed_weight[0::2] + 1j * packed_weight[1::2]
+        bw.wa[fbin_no] = wa
+        # calcMainlobe(..., isGSC=false) never fills B (beamformer.cc:1045-1049): wl = B wa with B == 0
+        bw.wl[fbin_no] = engine.weights_sidelobe(bw.B[fbin_no], wa)
+        self._dirty = True
+
+    def zero_active_weights(self):
+        if not self._bfw:
+            raise j_error("call calc_gsc_weights_x() once\n")
+        self._bfw[0].wa[:] = 0
+        self._bfw[0].wl[:] = 0
+        self._invalidate_output()
+
+    def calc_blocking_matrix1(self, samplerate, delays_t):
+        self._alloc_bfweight(1)
+        self._bfw[0].calc_mainlobe(samplerate, delays_t, True)
+        return True
+
+    def calc_blocking_matrix2(self):
+        if self._wmvdr is None:
+            return False
+        self._alloc_bfweight(1)
+        for k in range(1, self._K):
+            self._bfw[0].wq[k] = self._wmvdr[k]
+            self._bfw[0].B[k] = engine.weights_blocking_matrix(self._wmvdr[k], 1)
+        return True
+
+    def effective_weights(self):
+        self._check_weights()
+        if self._wmvdr is None:
+            raise j_error("call calc_mvdr_weights() once\n")
+        self._dirty = False
+        full = np.zeros((self._fftlen, self.chan_num()), np.complex128)
+        full[: self._K] = self._wmvdr
+        return engine.weights_gsc_effective(full, self._bfw[0].wl, self._fftlen, self._normalize_weight)
+
+    def next(self, frame_no=-5):
+        if getattr(self, "_dirty", False) and not (frame_no == self._frame_no and self._vector is not None):
+            self._invalidate_output()
+        return SubbandMVDRPtr.next(self, frame_no)
+
+
+def calc_all_delays(x, y, z, mpos):
+    """calc_all_delays (beamformer.cc:1172-1189)."""
+    mpos = np.asarray(mpos, np.float64)
+    d = np.sqrt(np.sum(mpos[:, :3] ** 2, axis=1)) / SSPEED
+    return d - d[len(d) // 2]
+
+
+SubbandDS, SubbandGSC, SubbandMVDR, SubbandMVDRGSC = SubbandDSPtr, SubbandGSCPtr, SubbandMVDRPtr, SubbandMVDRGSCPtr

@@ -1,0 +1,159 @@
+"""FeatureStream protocol (stream/stream.h:16-54, stream/stream.i:145-154, stream/pyStream.h:25-168)."""
+import numpy as np
+
+from .common import jconsistency_error, jiterator_error
+
+__all__ = ["FeatureStream", "VectorFloatFeatureStream", "VectorComplexFeatureStream",
+           "PyVectorFloatFeatureStreamPtr", "PyVectorComplexFeatureStreamPtr", "device"]
+
+_DEVICE = None
+
+
+def device():
+    """The HIP device every node of this process uses (one process per GPU)."""
+    global _DEVICE
+    if _DEVICE is None:
+        import torch
+        if not torch.cuda.is_available():
+            raise RuntimeError("btk20 nodes compute on an MI355X: no HIP device visible (there is no CPU fallback)")
+        _DEVICE = torch.device("cuda", torch.cuda.current_device())
+    return _DEVICE
+
+
+class FeatureStream(object):
+    """next(frame_no=-5) returns the node-owned buffer of the next frame; asking again for the
+    current frame number returns the same buffer; StopIteration (jiterator_error) at the end."""
+
+    def __init__(self, size, name=""):
+        self._size = int(size)
+        self._name = name
+        self._frame_reset_no = -1
+        self._frame_no = -1
+        self._is_end = False
+        self._vector = None
+
+    def name(self):
+        return self._name
+
+    def size(self):
+        return self._size
+
+    def frame_no(self):
+        return self._frame_no
+
+    def is_end(self):
+        return self._is_end
+
+    def current(self):
+        if self._frame_no < 0:
+            raise jconsistency_error("Frame index (%d) < 0." % self._frame_no)
+        return self.next(self._frame_no)
+
+    def reset(self):
+        self._frame_no = self._frame_reset_no
+        self._is_end = False
+
+    def next(self, frame_no=-5):
+        raise NotImplementedError
+
+    # SWIG: __iter__ = reset(); return self  (stream.i:145-154).  Python 3 adds __next__.
+    def __iter__(self):
+        self.reset()
+        return self
+
+    def __next__(self):
+        return self.next()
+
+
+class VectorFloatFeatureStream(FeatureStream):
+    pass
+
+
+class VectorComplexFeatureStream(FeatureStream):
+    pass
+
+
+class _BlockServedStream(FeatureStream):
+    """A node whose frames are computed block-wise on the GPU and served from a host array
+    self._frames [T][size]."""
+
+    def __init__(self, size, name=""):
+        FeatureStream.__init__(self, size, name)
+        self._frames = None
+
+    def _prepare(self):
+        raise NotImplementedError
+
+    def _num_frames(self):
+        if self._frames is None:
+            self._prepare()
+        return self._frames.shape[0]
+
+    def next(self, frame_no=-5):
+        if frame_no == self._frame_no and self._vector is not None:
+            return self._vector
+        if self._frames is None:
+            self._prepare()
+        idx = self._frame_no + 1
+        if idx >= self._frames.shape[0]:
+            self._is_end = True
+            raise jiterator_error("end of samples!")
+        self._vector = self._frames[idx]
+        self._frame_no = idx
+        return self._vector
+
+    def reset(self):
+        FeatureStream.reset(self)
+        self._frames = None
+        self._vector = None
+
+
+class _PyFeatureStream(FeatureStream):
+    """PyFeatureStream (stream/pyStream.h:25-168): any Python object with size()/reset()/__iter__()
+    whose iterator yields arrays becomes a source node."""
+
+    def __init__(self, obj, dtype, name="PyFeatureStream"):
+        FeatureStream.__init__(self, obj.size(), name)
+        self._obj = obj
+        self._dtype = dtype
+        self._iter = None
+
+    def python_object(self):
+        return self._obj
+
+    def device_block(self):
+        """Device-resident output block of a GPU-backed Python beamformer (None for plain iterators)."""
+        f = getattr(self._obj, "device_block", None)
+        return f() if f is not None else None
+
+    def next(self, frame_no=-5):
+        if frame_no == self._frame_no and self._vector is not None:
+            return self._vector
+        if self._iter is None:
+            self._iter = iter(self._obj)
+        try:
+            v = next(self._iter)
+        except (StopIteration, RuntimeError):
+            self._is_end = True
+            raise jiterator_error("end of samples!")
+        v = np.asarray(v, self._dtype)
+        if v.shape != (self._size,):
+            raise jconsistency_error("Feature size mismatch (%d vs. %d)" % (v.size, self._size))
+        self._vector = v
+        self._frame_no += 1
+        return self._vector
+
+    def reset(self):
+        self._obj.reset()
+        self._iter = None
+        FeatureStream.reset(self)
+
+
+class PyVectorFloatFeatureStreamPtr(_PyFeatureStream, VectorFloatFeatureStream):
+    def __init__(self, obj, name="PyVectorFloatFeatureStream"):
+        _PyFeatureStream.__init__(self, obj, np.float32, name)
+
+
+class PyVectorComplexFeatureStreamPtr(_PyFeatureStream, VectorComplexFeatureStream):
+    def __init__(self, obj, name="PyVectorComplexFeatureStream"):
+        _PyFeatureStream.__init__(self, obj, np.complex128, name)

@@ -1,0 +1,314 @@
+"""Host-side mirror of the reference's Python algorithm library for the beamforming hot path
+(btk20_src/lib/pybeamformer.py): same function and class names, constructor arguments and
+iterator behaviour; the per-frame / per-bin numpy loops are replaced by HIP kernels.
+
+    calc_delays family            lib/pybeamformer.py:41-153   (host, float64, unchanged arithmetic)
+    calc_array_manifold_f         :284-306
+    calc_blocking_matrix          :309-341                     (host float64 through the C-ABI)
+    SubbandGSCBeamformer          :478-537   D&S / LCMV-ready GSC with static active weights
+    SubbandMVDRBeamformer         :540-585   super-directive (diffuse-noise MVDR)
+    SubbandGSCLMSBeamformer       :588-762   adaptive NLMS canceller   -> btk_nlms_process
+    SubbandSMIMVDRBeamformer      :930-1019  sample-matrix-inversion MVDR -> btk_cov_* + btk_mvdr_weights
+"""
+import numpy as np
+
+from . import engine
+from .btk20.beamformer import SSPEED, SubbandGSCPtr, SubbandMVDRGSCPtr
+from .btk20.modulated import _mirror
+from .btk20.stream import device
+
+
+# ------------------------------------------------------------------ delays (pybeamformer.py:41-153)
+def calc_la_delays(mpos, azimuth, sspeed=SSPEED, ref_micx=None):
+    chanN = len(mpos)
+    if ref_micx is None:
+        ref_micx = chanN // 2
+    delays = np.zeros(chanN, float)
+    for i in range(chanN):
+        delays[i] = -mpos[i][0] * np.cos(azimuth) / sspeed
+    return delays - delays[ref_micx]
+
+
+def calc_pa_delays(mpos, azimuth, polar_angle, sspeed=SSPEED, ref_micx=None):
+    chanN = len(mpos)
+    if ref_micx is None:
+        ref_micx = chanN // 2
+    delays = np.zeros(chanN, float)
+    for i in range(chanN):
+        dx = mpos[i][0] - mpos[ref_micx][0]
+        dy = mpos[i][1] - mpos[ref_micx][1]
+        delays[i] = -(dx * np.cos(azimuth) * np.sin(polar_angle) + dy * np.sin(azimuth) * np.sin(polar_angle)) / sspeed
+    return delays
+
+
+def calc_ca_delays(mpos, azimuth, polar_angle, sspeed=SSPEED):
+    c_x = -np.sin(polar_angle) * np.cos(azimuth)
+    c_y = -np.sin(polar_angle) * np.sin(azimuth)
+    c_z = -np.cos(polar_angle)
+    return np.array([(c_x * p[0] + c_y * p[1] + c_z * p[2]) / sspeed for p in mpos], float)
+
+
+def calc_nf_delays(mpos, x, y, z, sspeed=SSPEED, ref_micx=None):
+    chanN = len(mpos)
+    if ref_micx is None:
+        ref_micx = chanN // 2
+    delays = np.array([np.sqrt((x - p[0]) ** 2 + (y - p[1]) ** 2 + (z - p[2]) ** 2) / sspeed for p in mpos], float)
+    return delays - delays[ref_micx]
+
+
+def calc_delays(array_type, mpos, position, sspeed=SSPEED, ref_micx=None):
+    if array_type == 'linear':
+        return calc_la_delays(mpos, position[0], sspeed=sspeed, ref_micx=ref_micx)
+    elif array_type == 'planar':
+        return calc_pa_delays(mpos, position[0], position[1], sspeed=sspeed, ref_micx=ref_micx)
+    elif array_type == 'circular':
+        return calc_ca_delays(mpos, position[0], position[1], sspeed=sspeed)
+    return calc_nf_delays(mpos, position[0], position[1], position[2], sspeed=sspeed, ref_micx=ref_micx)
+
+
+def calc_array_manifold_f(fbinX, fftlen, samplerate, delays, half_band_shift):
+    """pybeamformer.py:284-306."""
+    chan_num = len(delays)
+    Delta_f = samplerate / float(fftlen)
+    fftlen2 = fftlen / 2
+    delays = np.asarray(delays, float)
+    if half_band_shift:
+        if fbinX < fftlen2:
+            vs = np.exp(-1j * 2.0 * np.pi * (0.5 + fbinX) * Delta_f * delays)
+        else:
+            vs = np.exp(-1j * 2.0 * np.pi * (0.5 - fftlen + fbinX) * Delta_f * delays)
+    else:
+        if fbinX <= fftlen2:
+            vs = np.exp(-1j * 2.0 * np.pi * fbinX * Delta_f * delays)
+        else:
+            vs = np.conjugate(np.exp(-1j * 2.0 * np.pi * fbinX * Delta_f * delays))
+    return vs / chan_num
+
+
+def calc_blocking_matrix(vs, Nc=1):
+    """pybeamformer.py:309-341."""
+    return engine.weights_blocking_matrix(np.asarray(vs, complex), Nc)
+
+
+# ------------------------------------------------------------------ beamformer wrappers
+class SubbandBeamformer(object):
+    """pybeamformer.py:376-475."""
+
+    def __init__(self, spec_sources):
+        self._spec_sources = spec_sources
+        self._chan_num = len(spec_sources)
+        self._shiftlen = spec_sources[0].shiftlen()
+        self._fftlen = spec_sources[0].size()
+        self._fftlen2 = self._fftlen // 2
+        for c in range(1, self._chan_num):
+            assert self._shiftlen == spec_sources[c].shiftlen(), "%d-th channel: inconsistent shift length" % c
+            assert self._fftlen == spec_sources[c].size(), "%d-th channel: inconsistent FFT length" % c
+        self._beamformer = None
+        self._wqH = None
+        self._BmH = None
+        self._waH = None
+        self._iter_pos = 0
+
+    def beamformer(self):
+        return self._beamformer
+
+    def spec_sources(self):
+        return self._spec_sources
+
+    def device_block(self):
+        return self._beamformer.device_block()
+
+    def __iter__(self):
+        if self._beamformer is None:
+            raise NotImplementedError("Undefined beamformer object")
+        while True:
+            try:
+                yield np.array(self._beamformer.next())
+            except StopIteration:
+                return
+
+    def reset(self):
+        if self._beamformer is None:
+            raise NotImplementedError("Undefined beamformer object")
+        self._beamformer.reset()
+
+    def next_speaker(self):
+        pass
+
+    def chan_num(self):
+        return self._chan_num
+
+    def size(self):
+        return self._fftlen
+
+    def shiftlen(self):
+        return self._shiftlen
+
+    def set_active_weights(self):
+        if self._beamformer is None:
+            raise NotImplementedError("Undefined beamformer object")
+        assert self._waH is not None, "The active weight vectors have to be set"
+        for fbinX in range(self._fftlen2 + 1):
+            packed_wa = np.zeros(2 * (self._chan_num - self._Nc), float)
+            packed_wa[0::2] = np.real(self._waH[fbinX])
+            packed_wa[1::2] = np.imag(self._waH[fbinX])
+            self._beamformer.set_active_weights_f(fbinX, packed_wa)
+
+
+class SubbandGSCBeamformer(SubbandBeamformer):
+    """pybeamformer.py:478-537."""
+
+    def __init__(self, spec_sources, Nc=1):
+        SubbandBeamformer.__init__(self, spec_sources)
+        self._beamformer = SubbandGSCPtr(fftlen=self._fftlen, half_band_shift=False)
+        for source in self._spec_sources:
+            self._beamformer.set_channel(source)
+        self._Nc = Nc
+        self._waH = np.zeros((self._fftlen, self._chan_num - self._Nc), complex)
+
+    def calc_beamformer_weights(self, samplerate, delays, update_active_weights=True):
+        self._beamformer.calc_gsc_weights(samplerate, delays)
+        if update_active_weights:
+            self.set_active_weights()
+        self._wq = np.array([self._beamformer.get_weights(m) for m in range(self._fftlen2 + 1)], complex)
+
+
+class SubbandMVDRBeamformer(SubbandBeamformer):
+    """pybeamformer.py:540-585 (super-directive beamformer = diffuse-noise MVDR)."""
+
+    def __init__(self, spec_sources, Nc=1):
+        SubbandBeamformer.__init__(self, spec_sources)
+        self._beamformer = SubbandMVDRGSCPtr(fftlen=self._fftlen, half_band_shift=False)
+        for source in self._spec_sources:
+            self._beamformer.set_channel(source)
+        self._Nc = Nc
+        self._waH = np.zeros((self._fftlen, self._chan_num - self._Nc), complex)
+
+    def calc_sd_beamformer_weights(self, samplerate, delays, mpos, sspeed=SSPEED, mu=0.01, update_active_weights=True):
+        self._beamformer.calc_array_manifold_vectors(samplerate, delays)
+        self._beamformer.set_diffuse_noise_model(mpos, samplerate, sspeed)
+        self._beamformer.set_all_diagonal_loading(mu)
+        self._beamformer.calc_mvdr_weights(samplerate, dthreshold=1.0E-8, calc_inverse_matrix=True)
+        if update_active_weights:
+            self.set_active_weights()
+        self._wqH = np.conjugate(np.array([self._beamformer.mvdr_weights(m) for m in range(self._fftlen2 + 1)], complex))
+
+
+class SubbandGSCLMSBeamformer(SubbandBeamformer):
+    """pybeamformer.py:588-762: leaky power-normalised NLMS in GSC configuration.  The recursion runs
+    on the GPU (btk_nlms_process); this class keeps the reference's state names as read-only views."""
+
+    def __init__(self, spec_sources, beta=0.97, gamma=0.01, init_diagonal_load=1.0E+6, regularization_param=1.0E-4,
+                 energy_floor=90, sil_thresh=1.0E+8, max_wa_l2norm=100.0, min_frames=128, slowdown_after=4096, Nc=1):
+        SubbandBeamformer.__init__(self, spec_sources)
+        if Nc != 1:
+            raise NotImplementedError("the GPU canceller supports Nc = 1 (see DESIGN.md)")
+        self._Nc = Nc
+        self._front = SubbandGSCPtr(fftlen=self._fftlen, half_band_shift=False)   # owns channels + device snapshots
+        for source in self._spec_sources:
+            self._front.set_channel(source)
+        self._beamformer = self._front
+        self._params = dict(beta=beta, gamma=gamma, init_diagonal_load=init_diagonal_load,
+                            regularization_param=regularization_param, energy_floor=float(energy_floor),
+                            sil_thresh=sil_thresh, max_wa_l2norm=max_wa_l2norm, min_frames=min_frames,
+                            slowdown_after=slowdown_after)
+        self._state = None
+        self._vs = None
+        self._Y = None
+        self._frames = None
+
+    def calc_beamformer_weights(self, samplerate, delays):
+        """pybeamformer.py:736-743."""
+        K = self._fftlen2 + 1
+        self._vs = np.stack([calc_array_manifold_f(m, self._fftlen, samplerate, delays, False) for m in range(K)])
+        self._wqH = np.conjugate(self._vs)
+        self._BmH = None                               # formed lazily (only needed to export wa)
+        self._Y = None
+        self._frames = None
+
+    def _blocking(self, m):
+        return calc_blocking_matrix(self._vs[m], self._Nc)
+
+    def reset_stats(self):
+        if self._state is not None:
+            self._state.reset_stats()
+
+    def device_block(self):
+        import torch
+        if self._Y is None:
+            assert self._vs is not None, "call calc_beamformer_weights() first"
+            X = self._front.device_snapshots()
+            if self._state is None:
+                self._state = engine.NLMSState(1, self._fftlen, self._chan_num, device(), **self._params)
+            self._Y = engine.nlms_process(torch.from_numpy(self._vs.astype(np.complex64)).to(device()), X, self._state)
+        return self._Y
+
+    def __iter__(self):
+        Y = self.device_block()
+        if self._frames is None:
+            self._frames = _mirror(Y[0].cpu().numpy(), self._fftlen)
+        for t in range(self._frames.shape[0]):
+            yield self._frames[t]
+
+    @property
+    def _waH(self):
+        """Active weights in the reference's basis, wa^H = u conj(B) per bin."""
+        if self._state is None or self._vs is None:
+            return np.zeros((self._fftlen2 + 1, self._chan_num - 1), complex)
+        u = self._state.u[0].cpu().numpy().astype(np.complex128)
+        return np.stack([engine.nlms_u_to_wa(u[m], self._blocking(m)) for m in range(self._fftlen2 + 1)])
+
+    @_waH.setter
+    def _waH(self, v):
+        pass
+
+    def reset(self):
+        self._front.reset()
+        self.reset_stats()
+        self._Y = None
+        self._frames = None
+
+
+class SubbandSMIMVDRBeamformer(SubbandMVDRBeamformer):
+    """pybeamformer.py:930-1019: MVDR by sample matrix inversion."""
+
+    def __init__(self, spec_sources, Nc=1):
+        SubbandMVDRBeamformer.__init__(self, spec_sources, Nc)
+        self._noise_covariance_matrices = None      # device complex64 [1][K][N][N]
+        self._noise_frame_num = None                # device float32 [1]
+
+    def accu_stats_from_label(self, samplerate, target_labs=[(0.1, -1)], energy_threshold=10):
+        import torch
+        X = self._beamformer.device_snapshots()
+        T = X.shape[-1]
+        # noise-frame label exactly as the loop of pybeamformer.py:967-985 walks the VAD segments
+        elapsed_time, time_delta, labx = 0.0, self.shiftlen() / float(samplerate), 0
+        label = np.zeros(T, np.float32)
+        for t in range(T):
+            is_target = False
+            if labx < len(target_labs):
+                if elapsed_time >= target_labs[labx][0] and (elapsed_time <= target_labs[labx][1] or target_labs[labx][1] < 0):
+                    is_target = True
+                elif elapsed_time > target_labs[labx][1]:
+                    labx += 1
+            label[t] = 0.0 if is_target else 1.0
+            elapsed_time += time_delta
+        en = engine.frame_energy(X, self._fftlen)
+        w, self._noise_frame_num = engine.cov_frame_gate(en, torch.from_numpy(label[None]).to(device()), energy_threshold,
+                                                         count=self._noise_frame_num)
+        self._noise_covariance_matrices = engine.cov_accumulate(X, R=self._noise_covariance_matrices, frame_weights=w)
+        self._beamformer.reset()          # the reference drained its sources here; they are re-read afterwards
+
+    def finalize_stats(self):
+        assert self._noise_frame_num is not None and float(self._noise_frame_num.item()) > 0, \
+            "No noise stats accumulated; Use self.accu_stats_from_label()"
+        engine.cov_finalize(self._noise_covariance_matrices, self._noise_frame_num)
+
+    def calc_beamformer_weights(self, samplerate, delays, mu=1e-4, update_active_weights=True):
+        self._beamformer.calc_array_manifold_vectors(samplerate, delays)
+        self._beamformer.set_noise_spatial_spectral_matrices(self._noise_covariance_matrices[0])
+        self._beamformer.set_all_diagonal_loading(mu)
+        self._beamformer.calc_mvdr_weights(samplerate, dthreshold=1.0E-8, calc_inverse_matrix=True)
+        if update_active_weights:
+            self.set_active_weights()
+        self._wqH = np.conjugate(np.array([self._beamformer.mvdr_weights(m) for m in range(self._fftlen2 + 1)], complex))

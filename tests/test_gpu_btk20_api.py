@@ -1,0 +1,174 @@
+"""GPU: the reference's own integration flows (unit_test/test_online_beamforming.py:51-228,
+unit_test/test_sos_batch_beamforming.py:95-233) written against the btk20 mirror, checked against
+the oracle pull graph.  Geometry / parameters from unit_test/confs/{ds,ds_and_zelinski,sd,gsclms,smimvdr}.json."""
+import wave
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+MPOS = [[-113.0, 0.0, 2.0], [36.0, 0.0, 2.0], [76.0, 0.0, 2.0], [113.0, 0.0, 2.0]]      # confs/ds.json:2-5
+AZIMUTH = -1.306379                                                                      # confs/ds.json:6
+M, m, r, D, FS = 256, 4, 1, 128, 16000
+
+
+@pytest.fixture(scope="module")
+def wavs(tmp_path_factory, kinect_pcm):
+    d = tmp_path_factory.mktemp("wav")
+    paths = []
+    for c in range(4):
+        p = str(d / ("c%d.wav" % (c + 1)))
+        w = wave.open(p, "wb")
+        w.setnchannels(1); w.setsampwidth(2); w.setframerate(FS)
+        w.writeframes(kinect_pcm[c][:40000].astype(np.int16).tobytes())
+        w.close()
+        paths.append(p)
+    return paths
+
+
+def _build(wavs, h):
+    from distant_speech_recognition_amd.btk20 import SampleFeaturePtr, OverSampledDFTAnalysisBankPtr
+    sample_feats, afbs = [], []
+    for p in wavs:
+        sf = SampleFeaturePtr(block_len=D, shift_len=D, pad_zeros=True)
+        sf.read(p, FS)
+        afbs.append(OverSampledDFTAnalysisBankPtr(sf, prototype=h, M=M, m=m, r=r, delay_compensation_type=2))
+        sample_feats.append(sf)
+    return sample_feats, afbs
+
+
+def _oracle_X(orc, h, kinect_pcm):
+    return np.stack([orc.analysis(h, M, m, r, 2, kinect_pcm[c][:40000]) for c in range(4)], axis=1)      # [T][N][M]
+
+
+def test_delay_and_sum_with_zelinski_flow(orc, dev, proto256, kinect_pcm, wavs):
+    from distant_speech_recognition_amd.btk20 import (PyVectorComplexFeatureStreamPtr, ZelinskiPostFilterPtr,
+                                                      OverSampledDFTSynthesisBankPtr)
+    from distant_speech_recognition_amd.pybeamformer import SubbandGSCBeamformer, calc_delays
+    h, g = proto256
+    _, afbs = _build(wavs, h)
+    beamformer = SubbandGSCBeamformer(afbs, Nc=1)
+    pybf = PyVectorComplexFeatureStreamPtr(beamformer)
+    spatial_filter = ZelinskiPostFilterPtr(pybf, M, 0.7, 2)                       # confs/ds_and_zelinski.json
+    sfb = OverSampledDFTSynthesisBankPtr(spatial_filter, prototype=g, M=M, m=m, r=r, delay_compensation_type=2)
+    delays = calc_delays("linear", MPOS, [AZIMUTH, None, None])
+    beamformer.calc_beamformer_weights(FS, delays)
+    spatial_filter.set_beamformer(beamformer.beamformer())
+    out = np.concatenate([np.array(buf) for buf in sfb])
+    # oracle: same graph frame by frame
+    X = _oracle_X(orc, h, kinect_pcm)
+    wq = orc.calc_mainlobe(M, 4, FS, delays)
+    Yf, _ = orc.zelinski_frames(X, orc.gsc_frames(X, wq, np.zeros_like(wq)), wq, 0.7, 2)
+    ref = orc.synthesis(g, M, m, r, 2, Yf)
+    assert out.shape == ref.shape == (313 * D,)
+    assert np.max(np.abs(out - ref)) < 0.5                     # <= 0.5 LSB at int16 scale
+    # iterator protocol: exhausted stream raises StopIteration, same-frame caching
+    with pytest.raises(StopIteration):
+        sfb.next()
+
+
+def test_node_semantics(dev, proto256, wavs):
+    from distant_speech_recognition_amd.btk20 import SubbandGSCPtr, j_error, jdimension_error, jconsistency_error, \
+        OverSampledDFTAnalysisBankPtr, SampleFeaturePtr
+    h, _ = proto256
+    _, afbs = _build(wavs, h)
+    a0 = afbs[0]
+    f0 = np.array(a0.next())
+    assert a0.frame_no() == 0 and np.array_equal(np.array(a0.next(0)), f0)       # frame_no == frame_no_ -> cached
+    f1 = np.array(a0.next())
+    assert a0.frame_no() == 1 and not np.array_equal(f0, f1)
+    assert np.array_equal(np.array(a0.current()), f1)
+    bf = SubbandGSCPtr(fftlen=M, half_band_shift=False)
+    for a in afbs:
+        bf.set_channel(a)
+    with pytest.raises(j_error):
+        bf.next()                                                                # "call calc_gsc_weights_X() once"
+    with pytest.raises(jdimension_error):
+        bf.calc_gsc_weights(FS, np.zeros(3))
+    with pytest.raises(jconsistency_error):
+        OverSampledDFTAnalysisBankPtr(SampleFeaturePtr(block_len=D, shift_len=D, pad_zeros=True), prototype=h[:-1], M=M, m=m, r=r)
+    with pytest.raises(jdimension_error):
+        OverSampledDFTAnalysisBankPtr(SampleFeaturePtr(block_len=64, shift_len=64, pad_zeros=True), prototype=h, M=M, m=m, r=r)
+    # __iter__ = reset + self; frame count of the fixture slice: ceil(40000/128)=313 blocks -> 317 frames
+    _, afbs2 = _build(wavs[:1], h)
+    assert sum(1 for _ in afbs2[0]) == 317
+
+
+def test_super_directive_flow(orc, dev, proto256, kinect_pcm, wavs):
+    from distant_speech_recognition_amd.btk20 import PyVectorComplexFeatureStreamPtr, OverSampledDFTSynthesisBankPtr
+    from distant_speech_recognition_amd.pybeamformer import SubbandMVDRBeamformer, calc_delays
+    h, g = proto256
+    _, afbs = _build(wavs, h)
+    beamformer = SubbandMVDRBeamformer(afbs)
+    sfb = OverSampledDFTSynthesisBankPtr(PyVectorComplexFeatureStreamPtr(beamformer), prototype=g, M=M, m=m, r=r,
+                                         delay_compensation_type=2)
+    delays = calc_delays("linear", MPOS, [AZIMUTH, None, None])
+    beamformer.calc_sd_beamformer_weights(FS, delays, MPOS, mu=0.01)              # confs/sd.json
+    out = np.concatenate([np.array(buf) for buf in sfb])
+    X = _oracle_X(orc, h, kinect_pcm)
+    wq = orc.calc_mainlobe(M, 4, FS, delays)
+    R = orc.diagonal_loading(orc.diffuse_noise_model(np.array(MPOS), M, FS), M, 0.01)
+    w = orc.mvdr_weights(R, wq, M)
+    ref = orc.synthesis(g, M, m, r, 2, orc.mvdr_frames(X, w))
+    assert out.shape == ref.shape
+    # MVDR weights agree to ~1e-3 (float32 SVD in the reference vs float32 Cholesky): scale the PCM tolerance
+    assert np.max(np.abs(out - ref)) < 2e-3 * np.max(np.abs(ref)) + 0.5
+
+
+def test_gsclms_flow(orc, dev, proto256, kinect_pcm, wavs):
+    from distant_speech_recognition_amd.btk20 import PyVectorComplexFeatureStreamPtr, OverSampledDFTSynthesisBankPtr
+    from distant_speech_recognition_amd.pybeamformer import SubbandGSCLMSBeamformer, calc_delays
+    h, g = proto256
+    _, afbs = _build(wavs, h)
+    beamformer = SubbandGSCLMSBeamformer(afbs, min_frames=32)                      # other values = confs/gsclms.json
+    sfb = OverSampledDFTSynthesisBankPtr(PyVectorComplexFeatureStreamPtr(beamformer), prototype=g, M=M, m=m, r=r,
+                                         delay_compensation_type=2)
+    delays = calc_delays("linear", MPOS, [AZIMUTH, None, None])
+    beamformer.calc_beamformer_weights(FS, delays)
+    out = np.concatenate([np.array(buf) for buf in sfb])
+    X = _oracle_X(orc, h, kinect_pcm)
+    o = orc.NLMS(M, 4, min_frames=32)
+    o.calc_beamformer_weights(FS, delays)
+    ref = orc.synthesis(g, M, m, r, 2, o.run(X))
+    assert out.shape == ref.shape
+    assert np.max(np.abs(out - ref)) < 1e-4 * np.max(np.abs(ref)) + 0.5
+    assert np.max(np.abs(beamformer._waH - o.wa())) < 2e-4
+
+
+def test_smimvdr_batch_flow(orc, dev, proto256, kinect_pcm, wavs):
+    from distant_speech_recognition_amd.btk20 import PyVectorComplexFeatureStreamPtr, OverSampledDFTSynthesisBankPtr
+    from distant_speech_recognition_amd.pybeamformer import SubbandSMIMVDRBeamformer, calc_delays
+    h, g = proto256
+    sample_feats, afbs = _build(wavs, h)
+    beamformer = SubbandSMIMVDRBeamformer(afbs, Nc=1)
+    sfb = OverSampledDFTSynthesisBankPtr(PyVectorComplexFeatureStreamPtr(beamformer), prototype=g, M=M, m=m, r=r,
+                                         delay_compensation_type=2)
+    delays = calc_delays("linear", MPOS, [AZIMUTH, None, None])
+    labs = [(1.0, 2.0)]
+    beamformer.accu_stats_from_label(FS, target_labs=labs, energy_threshold=10)
+    beamformer.finalize_stats()
+    beamformer.calc_beamformer_weights(FS, delays, mu=1e-4)                        # confs/smimvdr.json
+    for c, p in enumerate(wavs):                                                   # reload (test_sos_batch_beamforming.py:221-222)
+        sample_feats[c].read(p, FS)
+    out = np.concatenate([np.array(buf) for buf in sfb])
+    # oracle
+    X = _oracle_X(orc, h, kinect_pcm)
+    T = X.shape[0]
+    en = np.array([orc.frame_energy(X[t, 0]) for t in range(T)])
+    el, labx, fw = 0.0, 0, []
+    for t in range(T):
+        tgt = False
+        if labx < len(labs):
+            if el >= labs[labx][0] and (el <= labs[labx][1] or labs[labx][1] < 0):
+                tgt = True
+            elif el > labs[labx][1]:
+                labx += 1
+        fw.append((not tgt) and en[t] > 10)
+        el += D / float(FS)
+    R = orc.cov_accumulate(X, frame_weights=fw) / sum(fw)
+    wq = orc.calc_mainlobe(M, 4, FS, delays)
+    w = orc.mvdr_weights(orc.diagonal_loading(R, M, 1e-4), wq, M)
+    ref = orc.synthesis(g, M, m, r, 2, orc.mvdr_frames(X, w))
+    assert out.shape == ref.shape
+    assert np.max(np.abs(out - ref)) < 5e-3 * np.max(np.abs(ref)) + 0.5
