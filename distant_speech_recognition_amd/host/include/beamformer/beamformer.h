@@ -1,0 +1,142 @@
+// beamformer/beamformer.h -- SnapShotArray, BeamformerWeights, SubbandBeamformer, SubbandDS, SubbandGSC,
+// SubbandMVDR with the reference's method names (reference beamformer/beamformer.h:28-383,
+// beamformer/spectralinfoarray.h:6-36), computed through libbtkhip.
+#pragma once
+#include <complex>
+#include <list>
+#include <vector>
+#include "stream/stream.h"
+#include "modulated/modulated.h"
+
+#define SSPEED 343740.0
+
+class SnapShotArray : public Countable {
+ public:
+  SnapShotArray(unsigned fftLn, unsigned nChn);
+  virtual ~SnapShotArray();
+  const gsl_vector_complex* snapshot(unsigned fbinX) const { return snapshots_[fbinX]; }
+  void set_samples(const gsl_vector_complex* samp, unsigned chanX);
+  virtual void update();
+  virtual void zero();
+  unsigned fftLen() const { return fftLen_; }
+  unsigned nChan() const { return nChan_; }
+  gsl_vector_complex** raw_snapshots() { return snapshots_; }
+ protected:
+  const unsigned fftLen_, nChan_;
+  gsl_vector_complex** samples_;
+  gsl_vector_complex** snapshots_;
+};
+typedef refcountable_ptr<SnapShotArray> SnapShotArrayPtr;
+
+// Host-side weights (float64): wq, B, wa, wl, ta  (reference beamformer.h:28-82)
+class BeamformerWeights {
+ public:
+  BeamformerWeights(unsigned fftLen, unsigned chanN, bool halfBandShift, unsigned NC = 1);
+  void calcMainlobe(float samplerate, const gsl_vector* delays, bool isGSC);
+  void calcSidelobeCancellerP_f(unsigned fbinX, const gsl_vector* packedWeight);
+  void calcSidelobeCancellerU_f(unsigned fbinX, const std::complex<double>* wa);
+  void calcBlockingMatrix(unsigned fbinX);
+  unsigned fftLen() const { return fftLen_; }
+  unsigned chanN() const { return chanN_; }
+  unsigned NC() const { return NC_; }
+  bool isHalfBandShift() const { return false; }
+  std::vector<std::complex<double> > wq, wl, ta, wa, B;   // [M][N], [M][N], [M][N], [M][N-NC], [M][N][N-NC]
+ private:
+  unsigned fftLen_, chanN_, NC_;
+};
+
+class SubbandBeamformer : public VectorComplexFeatureStream {
+ public:
+  SubbandBeamformer(unsigned fftLen, bool halfBandShift = false, const String& nm = "SubbandBeamformer");
+  ~SubbandBeamformer();
+  bool is_end() { return is_end_; }
+  unsigned fftLen() const { return fftLen_; }
+  unsigned chanN() const { return (unsigned)channelList_.size(); }
+  virtual void reset();
+  unsigned dim() const { return fftLen_; }
+  void set_channel(VectorComplexFeatureStreamPtr& chan);
+  virtual void clear_channel();
+  const gsl_vector_complex* snapshot_array_f(unsigned fbinX) { return snapshot_array()->snapshot(fbinX); }
+  virtual SnapShotArrayPtr snapshot_array();
+  void setChannel(VectorComplexFeatureStreamPtr& chan) { set_channel(chan); }       // legacy API
+  void clearChannel() { clear_channel(); }
+  // device hooks
+  void* device_snapshots();       // complex64 [1][K][N][T] on the device
+  long num_frames() { device_snapshots(); return T_; }
+ protected:
+  void free_device_();
+  typedef std::list<VectorComplexFeatureStreamPtr> ChannelList_;
+  ChannelList_ channelList_;
+  SnapShotArrayPtr snapshot_array_;
+  unsigned fftLen_, fftLen2_;
+  void* dX_;                      // device snapshots
+  long T_;
+  std::vector<float> Xhost_;      // lazily fetched host copy for snapshot_array()
+};
+
+class SubbandDS : public SubbandBeamformer {
+ public:
+  SubbandDS(unsigned fftLen, bool halfBandShift = false, const String& nm = "SubbandDS");
+  ~SubbandDS();
+  virtual const gsl_vector_complex* next(int frame_no = -5);
+  virtual void reset();
+  virtual void clear_channel();
+  virtual const gsl_vector_complex* get_weights(unsigned fbinX);
+  virtual BeamformerWeights* beamformer_weight_object(unsigned srcX = 0) const { return bfweight_; }
+  virtual void calc_array_manifold_vectors(float samplerate, const gsl_vector* delays);
+  void calcArrayManifoldVectors(float samplerate, const gsl_vector* delays) { calc_array_manifold_vectors(samplerate, delays); }
+  // engine hooks for downstream GPU nodes (post-filter, synthesis)
+  virtual void effective_weights(std::vector<float>& w);   // complex64 [K][N]
+  void alignment_vector(bool use_wq, std::vector<float>& d);
+  unsigned long weights_version() const { return weights_version_; }
+ protected:
+  void alloc_bfweight_(int NC);
+  void compute_output_(long from_frame);
+  virtual const char* need_weights_msg_() const { return "call calc_array_manifold_vectorsX() once\n"; }
+  BeamformerWeights* bfweight_;
+  unsigned long weights_version_, output_version_;
+  std::vector<float> Yhost_;      // [K][T] complex64
+  gsl_vector_complex* wq_view_;
+};
+typedef Inherit<SubbandDS, VectorComplexFeatureStreamPtr> SubbandDSPtr;
+
+class SubbandGSC : public SubbandDS {
+ public:
+  SubbandGSC(unsigned fftLen, bool halfBandShift = false, const String& nm = "SubbandGSC")
+      : SubbandDS(fftLen, halfBandShift, nm), normalize_weight_(false) {}
+  void normalize_weight(bool flag) { normalize_weight_ = flag; weights_version_++; }
+  void set_quiescent_weights_f(unsigned fbinX, const gsl_vector_complex* srcWq);
+  void set_active_weights_f(unsigned fbinX, const gsl_vector* packedWeight);
+  void zero_active_weights();
+  void calc_gsc_weights(float samplerate, const gsl_vector* delaysT);
+  void calcGSCWeights(float samplerate, const gsl_vector* delaysT) { calc_gsc_weights(samplerate, delaysT); }
+  void setActiveWeights_f(unsigned fbinX, const gsl_vector* packedWeight) { set_active_weights_f(fbinX, packedWeight); }
+  virtual void effective_weights(std::vector<float>& w);
+ protected:
+  virtual const char* need_weights_msg_() const { return "call calc_gsc_weights_X() once\n"; }
+  bool normalize_weight_;
+};
+typedef Inherit<SubbandGSC, SubbandDSPtr> SubbandGSCPtr;
+
+class SubbandMVDR : public SubbandDS {
+ public:
+  SubbandMVDR(unsigned fftLen, bool halfBandShift = false, const String& nm = "SubbandMVDR");
+  ~SubbandMVDR();
+  virtual void clear_channel();
+  bool calc_mvdr_weights(float samplerate, float dThreshold = 1.0E-8, bool calcInverseMatrix = true);
+  const gsl_vector_complex* mvdr_weights(unsigned fbinX);
+  bool set_noise_spatial_spectral_matrix(unsigned fbinX, gsl_matrix_complex* Rnn);
+  bool set_diffuse_noise_model(const gsl_matrix* micPositions, float samplerate, float sspeed = 343740.0);
+  void set_all_diagonal_loading(float diagonalWeight);
+  void set_diagonal_looading(unsigned fbinX, float diagonalWeight);          // sic (reference spelling)
+  virtual void effective_weights(std::vector<float>& w);
+  int identity_fallbacks() const { return fallbacks_; }
+ protected:
+  void alloc_R_();
+  void* dR_;                        // device complex64 [K][N][N]
+  std::vector<float> wmvdr_;        // complex64 [K][N]
+  bool have_mvdr_;
+  int fallbacks_;
+  gsl_vector_complex* wm_view_;
+};
+typedef Inherit<SubbandMVDR, SubbandDSPtr> SubbandMVDRPtr;

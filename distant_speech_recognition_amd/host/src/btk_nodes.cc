@@ -1,0 +1,782 @@
+// btk_nodes.cc -- C++ node layer: the reference's FeatureStream nodes for the beamforming hot path,
+// implemented over the C-ABI of libbtkhip (include/btkhip.h).
+//
+// A node drains its finite upstream once, runs the whole utterance through the HIP kernels and serves
+// frames from a host mirror, so next() keeps the reference's per-frame contract: node-owned buffer,
+// same-frame caching, consecutive frame numbers, jiterator_error("end of samples!") at the end.
+// Weight changes between frames recompute only the frames not yet served (analysis is
+// weight-independent and stays resident on the device).
+#include <hip/hip_runtime_api.h>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+
+#include "feature/feature.h"
+#include "modulated/modulated.h"
+#include "beamformer/beamformer.h"
+#include "postfilter/postfilter.h"
+
+namespace {
+
+typedef std::complex<double> cd;
+
+void check_abi(int rc)
+{
+  if (rc == BTK_OK) return;
+  const char* msg = btk_last_error();
+  switch (rc) {
+    case BTK_ERR_DIMENSION: throw jdimension_error("%s", msg);
+    case BTK_ERR_CONSISTENCY: throw jconsistency_error("%s", msg);
+    case BTK_ERR_ALLOCATION: throw jallocation_error("%s", msg);
+    case BTK_ERR_PARAMETER: throw jparameter_error("%s", msg);
+    case BTK_ERR_NUMERIC: throw jnumeric_error("%s", msg);
+    default: throw j_error("%s", msg);
+  }
+}
+
+void check_hip(hipError_t e, const char* what)
+{
+  if (e == hipSuccess) return;
+  if (e == hipErrorOutOfMemory) throw jallocation_error("%s: %s", what, hipGetErrorString(e));
+  throw j_error("%s: %s", what, hipGetErrorString(e));
+}
+
+void* dev_alloc(size_t bytes)
+{
+  void* p = NULL;
+  check_hip(hipMalloc(&p, bytes ? bytes : 16), "hipMalloc");
+  return p;
+}
+void dev_free(void* p) { if (p) (void)hipFree(p); }
+void h2d(void* d, const void* h, size_t n) { check_hip(hipMemcpy(d, h, n, hipMemcpyHostToDevice), "hipMemcpy H2D"); }
+void d2h(void* h, const void* d, size_t n) { check_hip(hipMemcpy(h, d, n, hipMemcpyDeviceToHost), "hipMemcpy D2H"); }
+
+// [K][T] complex64 -> frame t as gsl_vector_complex of M bins with conjugate mirror
+void serve_frame(const std::vector<float>& Y, long T, unsigned M, long t, gsl_vector_complex* out)
+{
+  const unsigned K = M / 2 + 1;
+  for (unsigned k = 0; k < K; k++) {
+    const double re = Y[2 * ((size_t)k * T + t)], im = Y[2 * ((size_t)k * T + t) + 1];
+    out->data[2 * k] = re; out->data[2 * k + 1] = im;
+    if (k > 0 && k < M / 2) { out->data[2 * (M - k)] = re; out->data[2 * (M - k) + 1] = -im; }
+  }
+}
+
+// drain a complex node: frames [T][K] complex64 (bins 0..M/2)
+long drain_complex(VectorComplexFeatureStreamPtr& src, unsigned M, std::vector<float>& frames)
+{
+  const unsigned K = M / 2 + 1;
+  long T = 0;
+  for (;;) {
+    const gsl_vector_complex* v;
+    try { v = src->next(); } catch (jiterator_error&) { break; }
+    frames.resize((size_t)(T + 1) * K * 2);
+    for (unsigned k = 0; k < K; k++) {
+      frames[2 * ((size_t)T * K + k)] = (float)v->data[2 * k];
+      frames[2 * ((size_t)T * K + k) + 1] = (float)v->data[2 * k + 1];
+    }
+    T++;
+  }
+  return T;
+}
+
+}  // namespace
+
+// ================================================================================ SampleFeature
+SampleFeature::SampleFeature(const String& fn, unsigned blockLen, unsigned shiftLen, bool padZeros, const String& nm)
+    : VectorFloatFeatureStream(blockLen, nm), have_samples_(false), shiftLen_(shiftLen), cur_(0), pad_zeros_(padZeros),
+      samplerate_(0)
+{
+  if (fn != "") read(fn);
+  is_end_ = false;
+}
+
+unsigned SampleFeature::read(const String& fn, int, int, int chX, int, int cfrom, int to, int, float norm)
+{
+  FILE* fp = fopen(fn.c_str(), "rb");
+  if (!fp) throw jio_error("Could not open file %s.", fn.c_str());
+  unsigned char hdr[12];
+  if (fread(hdr, 1, 12, fp) != 12 || memcmp(hdr, "RIFF", 4) || memcmp(hdr + 8, "WAVE", 4)) {
+    fclose(fp);
+    throw jio_error("%s is not a RIFF/WAVE file", fn.c_str());
+  }
+  int channels = 1, bits = 16, fmt = 1;
+  std::vector<short> raw;
+  for (;;) {
+    unsigned char ck[8];
+    if (fread(ck, 1, 8, fp) != 8) break;
+    const unsigned len = ck[4] | (ck[5] << 8) | (ck[6] << 16) | ((unsigned)ck[7] << 24);
+    if (!memcmp(ck, "fmt ", 4)) {
+      std::vector<unsigned char> f(len);
+      if (fread(f.data(), 1, len, fp) != len) break;
+      fmt = f[0] | (f[1] << 8); channels = f[2] | (f[3] << 8);
+      samplerate_ = f[4] | (f[5] << 8) | (f[6] << 16) | (f[7] << 24);
+      bits = f[14] | (f[15] << 8);
+      if (len & 1) fseek(fp, 1, SEEK_CUR);
+    } else if (!memcmp(ck, "data", 4)) {
+      raw.resize(len / 2);
+      size_t got = fread(raw.data(), 2, raw.size(), fp);
+      raw.resize(got);
+      break;
+    } else {
+      fseek(fp, len + (len & 1), SEEK_CUR);
+    }
+  }
+  fclose(fp);
+  if (fmt != 1 || bits != 16) throw jio_error("Only 16-bit PCM WAV is supported (%s)", fn.c_str());
+  if (chX > channels || chX < 1) {
+    if (chX == 0) throw jconsistency_error("Multi-channel read is not yet supported.");
+    throw jconsistency_error("Selected channel out of range of available channels.");
+  }
+  const size_t nfr = raw.size() / channels;
+  size_t first = cfrom > 0 ? (size_t)cfrom : 0, last = (to > 0 && (size_t)to < nfr) ? (size_t)to + 1 : nfr;
+  std::vector<float> s;
+  for (size_t i = first; i < last; i++) s.push_back((float)raw[i * channels + (chX - 1)]);   // un-normalised
+  if (norm != 1.0f && norm != 0.0f) for (size_t i = 0; i < s.size(); i++) s[i] *= norm;
+  set_samples(s.data(), s.size());
+  return (unsigned)samples_.size();
+}
+
+void SampleFeature::set_samples(const float* samples, size_t n)
+{
+  samples_.assign(samples, samples + n);
+  have_samples_ = true;
+  cur_ = 0;
+  reset();
+  is_end_ = false;
+}
+
+const gsl_vector_float* SampleFeature::next(int frame_no)
+{
+  if (is_end_) throw jiterator_error("end of samples!");
+  if (frame_no == frame_no_) return vector_;
+  if (frame_no >= 0 && frame_no - 1 != frame_no_)
+    throw jindex_error("Problem in Feature %s: %d != %d\n", name().c_str(), frame_no - 1, frame_no_);
+  const size_t ttl = samples_.size();
+  if (!have_samples_ || cur_ >= ttl) {
+    is_end_ = true; have_samples_ = false; samples_.clear();
+    throw jiterator_error("end of samples!");
+  }
+  if (cur_ + size() >= ttl) {
+    if (pad_zeros_) {
+      gsl_vector_float_set_zero(vector_);
+      for (size_t i = 0; i < ttl - cur_; i++) vector_->data[i] = samples_[cur_ + i];
+    } else {
+      is_end_ = true; have_samples_ = false; samples_.clear();
+      throw jiterator_error("end of samples!");
+    }
+  } else {
+    for (unsigned i = 0; i < size(); i++) vector_->data[i] = samples_[cur_ + i];
+  }
+  cur_ += shiftLen_;
+  increment_();
+  return vector_;
+}
+
+// ================================================================================ analysis bank
+OverSampledDFTAnalysisBank::OverSampledDFTAnalysisBank(VectorFloatFeatureStreamPtr& samp, gsl_vector* prototype, unsigned M,
+                                                       unsigned m, unsigned r, unsigned delayCompensationType, const String& nm)
+    : VectorComplexFeatureStream(M, nm), samp_(samp), M_(M), m_(m), r_(r), D_(M >> r), dct_(delayCompensationType),
+      plan_(NULL), drained_(false), nframes_(0), prepared_(false)
+{
+  if (prototype->size != (size_t)M * m)
+    throw jconsistency_error("Prototype sizes do not match (%d vs. %d).", (int)prototype->size, (int)(M * m));
+  if (samp_->size() != D_) throw jdimension_error("Input block length (%d) != D_ (%d)\n", samp_->size(), D_);
+  std::vector<double> h(prototype->size);
+  for (size_t i = 0; i < h.size(); i++) h[i] = gsl_vector_get(prototype, i);
+  check_abi(btk_fb_create(&plan_, (int)M, (int)m, (int)r, (int)delayCompensationType, 0, h.data()));
+}
+
+OverSampledDFTAnalysisBank::~OverSampledDFTAnalysisBank() { btk_fb_destroy(plan_); }
+
+const std::vector<float>& OverSampledDFTAnalysisBank::pcm()
+{
+  if (!drained_) {
+    pcm_.clear();
+    for (;;) {
+      const gsl_vector_float* b;
+      try { b = samp_->next(); } catch (jiterator_error&) { break; }
+      pcm_.insert(pcm_.end(), b->data, b->data + b->size);
+    }
+    drained_ = true;
+  }
+  return pcm_;
+}
+
+void OverSampledDFTAnalysisBank::prepare_()
+{
+  const std::vector<float>& x = pcm();
+  const long L = (long)x.size();
+  nframes_ = btk_fb_analysis_num_frames(plan_, L);
+  const unsigned K = M_ / 2 + 1;
+  void* dp = dev_alloc(sizeof(float) * (L ? L : 1));
+  void* dX = dev_alloc(sizeof(float) * 2 * K * (nframes_ ? nframes_ : 1));
+  if (L) h2d(dp, x.data(), sizeof(float) * L);
+  check_abi(btk_fb_analysis(plan_, (const float*)dp, L, L ? L : 1, 1, 1, dX, nframes_, 0, nframes_, NULL));
+  check_abi(btk_synchronize(NULL));
+  std::vector<float> Xh((size_t)2 * K * nframes_);
+  if (nframes_) d2h(Xh.data(), dX, sizeof(float) * Xh.size());
+  dev_free(dp); dev_free(dX);
+  frames_.assign((size_t)nframes_ * 2 * M_, 0.0);
+  gsl_vector_complex tmp; tmp.size = M_; tmp.stride = 1;
+  for (long t = 0; t < nframes_; t++) {
+    tmp.data = frames_.data() + (size_t)t * 2 * M_;
+    serve_frame(Xh, nframes_, M_, t, &tmp);
+  }
+  prepared_ = true;
+}
+
+const gsl_vector_complex* OverSampledDFTAnalysisBank::next(int frame_no)
+{
+  if (frame_no == frame_no_) return vector_;
+  if (!prepared_) prepare_();
+  const long idx = frame_no_ + 1;
+  if (idx >= nframes_) { is_end_ = true; throw jiterator_error("end of samples!"); }
+  memcpy(vector_->data, frames_.data() + (size_t)idx * 2 * M_, sizeof(double) * 2 * M_);
+  increment_();
+  return vector_;
+}
+
+void OverSampledDFTAnalysisBank::reset()
+{
+  samp_->reset();
+  VectorComplexFeatureStream::reset();
+  drained_ = false; prepared_ = false; pcm_.clear(); frames_.clear(); nframes_ = 0;
+}
+
+// ================================================================================ synthesis bank
+OverSampledDFTSynthesisBank::OverSampledDFTSynthesisBank(VectorComplexFeatureStreamPtr& samp, gsl_vector* prototype, unsigned M,
+                                                         unsigned m, unsigned r, unsigned delayCompensationType, int gainFactor,
+                                                         const String& nm)
+    : VectorFloatFeatureStream(M >> r, nm), samp_(samp), M_(M), m_(m), r_(r), D_(M >> r), gain_(gainFactor), plan_(NULL),
+      nblocks_(0), prepared_(false)
+{
+  if (prototype->size != (size_t)M * m)
+    throw jconsistency_error("Prototype sizes do not match (%d vs. %d).", (int)prototype->size, (int)(M * m));
+  std::vector<double> g(prototype->size);
+  for (size_t i = 0; i < g.size(); i++) g[i] = gsl_vector_get(prototype, i);
+  check_abi(btk_fb_create(&plan_, (int)M, (int)m, (int)r, (int)delayCompensationType, 1, g.data()));
+}
+
+OverSampledDFTSynthesisBank::~OverSampledDFTSynthesisBank() { btk_fb_destroy(plan_); }
+
+void OverSampledDFTSynthesisBank::prepare_()
+{
+  const unsigned K = M_ / 2 + 1;
+  std::vector<float> fr;                       // [T][K]
+  const long T = drain_complex(samp_, M_, fr);
+  nblocks_ = btk_fb_synthesis_num_blocks(plan_, T);
+  blocks_.assign((size_t)nblocks_ * D_, 0.f);
+  if (nblocks_ > 0) {
+    std::vector<float> Yk((size_t)2 * K * T);  // [K][T]
+    for (long t = 0; t < T; t++)
+      for (unsigned k = 0; k < K; k++) {
+        Yk[2 * ((size_t)k * T + t)] = fr[2 * ((size_t)t * K + k)];
+        Yk[2 * ((size_t)k * T + t) + 1] = fr[2 * ((size_t)t * K + k) + 1];
+      }
+    void* dY = dev_alloc(sizeof(float) * Yk.size());
+    void* dO = dev_alloc(sizeof(float) * blocks_.size());
+    h2d(dY, Yk.data(), sizeof(float) * Yk.size());
+    check_abi(btk_fb_synthesis(plan_, dY, T, T, 1, (float*)dO, nblocks_ * D_, 0, nblocks_, NULL));
+    check_abi(btk_synchronize(NULL));
+    d2h(blocks_.data(), dO, sizeof(float) * blocks_.size());
+    dev_free(dY); dev_free(dO);
+    if (gain_ > 1) for (size_t i = 0; i < blocks_.size(); i++) blocks_[i] *= (float)gain_;
+  }
+  prepared_ = true;
+}
+
+const gsl_vector_float* OverSampledDFTSynthesisBank::next(int frame_no)
+{
+  if (!prepared_) prepare_();
+  const long idx = frame_no_ + 1;
+  if (idx >= nblocks_) { is_end_ = true; throw jiterator_error("end of samples!"); }
+  memcpy(vector_->data, blocks_.data() + (size_t)idx * D_, sizeof(float) * D_);
+  increment_();
+  return vector_;
+}
+
+void OverSampledDFTSynthesisBank::reset()
+{
+  samp_->reset();
+  VectorFloatFeatureStream::reset();
+  prepared_ = false; blocks_.clear(); nblocks_ = 0;
+}
+
+// ================================================================================ SnapShotArray
+SnapShotArray::SnapShotArray(unsigned fftLn, unsigned nChn) : fftLen_(fftLn), nChan_(nChn)
+{
+  samples_ = new gsl_vector_complex*[nChan_];
+  for (unsigned i = 0; i < nChan_; i++) samples_[i] = gsl_vector_complex_calloc(fftLen_);
+  snapshots_ = new gsl_vector_complex*[fftLen_];
+  for (unsigned i = 0; i < fftLen_; i++) snapshots_[i] = gsl_vector_complex_calloc(nChan_);
+}
+SnapShotArray::~SnapShotArray()
+{
+  for (unsigned i = 0; i < nChan_; i++) gsl_vector_complex_free(samples_[i]);
+  delete[] samples_;
+  for (unsigned i = 0; i < fftLen_; i++) gsl_vector_complex_free(snapshots_[i]);
+  delete[] snapshots_;
+}
+void SnapShotArray::zero()
+{
+  for (unsigned i = 0; i < nChan_; i++) gsl_vector_complex_set_zero(samples_[i]);
+  for (unsigned i = 0; i < fftLen_; i++) gsl_vector_complex_set_zero(snapshots_[i]);
+}
+void SnapShotArray::set_samples(const gsl_vector_complex* samp, unsigned chanX)
+{
+  memcpy(samples_[chanX]->data, samp->data, sizeof(double) * 2 * fftLen_);
+}
+void SnapShotArray::update()
+{
+  for (unsigned k = 0; k < fftLen_; k++)
+    for (unsigned c = 0; c < nChan_; c++) {
+      snapshots_[k]->data[2 * c] = samples_[c]->data[2 * k];
+      snapshots_[k]->data[2 * c + 1] = samples_[c]->data[2 * k + 1];
+    }
+}
+
+// ================================================================================ BeamformerWeights
+BeamformerWeights::BeamformerWeights(unsigned fftLen, unsigned chanN, bool, unsigned NC)
+    : wq((size_t)fftLen * chanN), wl((size_t)fftLen * chanN), ta((size_t)fftLen * chanN),
+      wa(chanN > NC ? (size_t)fftLen * (chanN - NC) : 0), B(chanN > NC ? (size_t)fftLen * chanN * (chanN - NC) : 0),
+      fftLen_(fftLen), chanN_(chanN), NC_(NC) {}
+
+void BeamformerWeights::calcMainlobe(float samplerate, const gsl_vector* delays, bool isGSC)
+{
+  if (delays->size != chanN_)
+    throw jdimension_error("Number of delays does not match number of channels (%d vs. %d).\n", (int)delays->size, chanN_);
+  if (isGSC && chanN_ <= 1) throw jdimension_error("The number of channels must be > 1 but it is %d\n", chanN_);
+  std::vector<double> d(chanN_);
+  for (unsigned c = 0; c < chanN_; c++) d[c] = gsl_vector_get(delays, c);
+  check_abi(btk_weights_mainlobe((int)fftLen_, (int)chanN_, samplerate, d.data(), reinterpret_cast<double*>(wq.data())));
+  ta = wq;                                                   // setTimeAlignment
+  if (isGSC)
+    for (unsigned k = 0; k < fftLen_; k++) calcBlockingMatrix(k);
+}
+
+void BeamformerWeights::calcBlockingMatrix(unsigned fbinX)
+{
+  const unsigned bs = chanN_ - NC_;
+  check_abi(btk_weights_blocking_matrix(reinterpret_cast<const double*>(&wq[(size_t)fbinX * chanN_]), (int)chanN_, (int)NC_,
+                                        reinterpret_cast<double*>(&B[(size_t)fbinX * chanN_ * bs])));
+}
+
+void BeamformerWeights::calcSidelobeCancellerU_f(unsigned fbinX, const cd* w)
+{
+  if (fbinX >= fftLen_) throw jdimension_error("Must be a frequency bin %d < the length of FFT %d\n", fbinX, fftLen_);
+  const unsigned bs = chanN_ - NC_;
+  for (unsigned i = 0; i < bs; i++) wa[(size_t)fbinX * bs + i] = w[i];
+  check_abi(btk_weights_sidelobe(reinterpret_cast<const double*>(&B[(size_t)fbinX * chanN_ * bs]),
+                                 reinterpret_cast<const double*>(&wa[(size_t)fbinX * bs]), (int)chanN_, (int)NC_,
+                                 reinterpret_cast<double*>(&wl[(size_t)fbinX * chanN_])));
+}
+
+void BeamformerWeights::calcSidelobeCancellerP_f(unsigned fbinX, const gsl_vector* packedWeight)
+{
+  const unsigned bs = chanN_ - NC_;
+  if (packedWeight->size != 2 * bs)
+    throw jdimension_error("the size of an active weight vector must be %d but it is %d\n", 2 * bs, (int)packedWeight->size);
+  std::vector<cd> w(bs);
+  for (unsigned i = 0; i < bs; i++) w[i] = cd(gsl_vector_get(packedWeight, 2 * i), gsl_vector_get(packedWeight, 2 * i + 1));
+  calcSidelobeCancellerU_f(fbinX, w.data());
+}
+
+// ================================================================================ SubbandBeamformer
+SubbandBeamformer::SubbandBeamformer(unsigned fftLen, bool halfBandShift, const String& nm)
+    : VectorComplexFeatureStream(fftLen, nm), snapshot_array_(NULL), fftLen_(fftLen), fftLen2_(fftLen / 2), dX_(NULL), T_(0)
+{
+  if (halfBandShift) throw jallocation_error("halfBandShift==true is not yet supported\n");
+}
+SubbandBeamformer::~SubbandBeamformer() { free_device_(); }
+void SubbandBeamformer::free_device_() { dev_free(dX_); dX_ = NULL; T_ = 0; Xhost_.clear(); }
+void SubbandBeamformer::set_channel(VectorComplexFeatureStreamPtr& chan) { channelList_.push_back(chan); }
+void SubbandBeamformer::clear_channel() { channelList_.clear(); snapshot_array_ = NULL; free_device_(); }
+
+void SubbandBeamformer::reset()
+{
+  for (ChannelList_::iterator it = channelList_.begin(); it != channelList_.end(); ++it) (*it)->reset();
+  if (!snapshot_array_.is_null()) snapshot_array_->zero();
+  VectorComplexFeatureStream::reset();
+  is_end_ = false;
+  free_device_();
+}
+
+void* SubbandBeamformer::device_snapshots()
+{
+  if (dX_) return dX_;
+  const unsigned N = chanN(), K = fftLen2_ + 1;
+  if (N == 0) throw j_error("set channels first\n");
+  // fast path: every channel is an analysis bank with the same plan -> one batched analysis launch
+  bool all_banks = true;
+  std::vector<OverSampledDFTAnalysisBank*> banks;
+  for (ChannelList_::iterator it = channelList_.begin(); it != channelList_.end(); ++it) {
+    OverSampledDFTAnalysisBank* b = dynamic_cast<OverSampledDFTAnalysisBank*>(it->operator->());
+    if (!b || (!banks.empty() && (b->fftlen() != banks[0]->fftlen() || b->m() != banks[0]->m() || b->r() != banks[0]->r() ||
+                                  b->delay_compensation_type() != banks[0]->delay_compensation_type()))) { all_banks = false; break; }
+    banks.push_back(b);
+  }
+  if (all_banks) {
+    long L = -1;
+    for (size_t c = 0; c < banks.size(); c++) { const long l = (long)banks[c]->pcm().size(); if (L < 0 || l < L) L = l; }
+    T_ = btk_fb_analysis_num_frames(banks[0]->plan(), L);
+    void* dp = dev_alloc(sizeof(float) * N * (L ? L : 1));
+    for (unsigned c = 0; c < N; c++)
+      if (L) h2d(static_cast<float*>(dp) + (size_t)c * L, banks[c]->pcm().data(), sizeof(float) * L);
+    dX_ = dev_alloc(sizeof(float) * 2 * K * N * (T_ ? T_ : 1));
+    check_abi(btk_fb_analysis(banks[0]->plan(), (const float*)dp, L, L ? L : 1, 1, (int)N, dX_, T_, 0, T_, NULL));
+    check_abi(btk_synchronize(NULL));
+    dev_free(dp);
+  } else {
+    std::vector<std::vector<float> > fr(N);
+    long T = -1; unsigned c = 0;
+    for (ChannelList_::iterator it = channelList_.begin(); it != channelList_.end(); ++it, ++c) {
+      const long t = drain_complex(*it, fftLen_, fr[c]);
+      if (T < 0 || t < T) T = t;
+    }
+    T_ = T;
+    std::vector<float> Xh((size_t)2 * K * N * T_);
+    for (unsigned k = 0; k < K; k++)
+      for (unsigned n = 0; n < N; n++)
+        for (long t = 0; t < T_; t++) {
+          Xh[2 * (((size_t)k * N + n) * T_ + t)] = fr[n][2 * ((size_t)t * K + k)];
+          Xh[2 * (((size_t)k * N + n) * T_ + t) + 1] = fr[n][2 * ((size_t)t * K + k) + 1];
+        }
+    dX_ = dev_alloc(sizeof(float) * Xh.size());
+    if (!Xh.empty()) h2d(dX_, Xh.data(), sizeof(float) * Xh.size());
+  }
+  return dX_;
+}
+
+SnapShotArrayPtr SubbandBeamformer::snapshot_array()
+{
+  const unsigned N = chanN(), K = fftLen2_ + 1;
+  if (snapshot_array_.is_null()) snapshot_array_ = new SnapShotArray(fftLen_, N);
+  if (dX_ && frame_no_ >= 0 && frame_no_ < T_) {
+    if (Xhost_.empty()) { Xhost_.resize((size_t)2 * K * N * T_); d2h(Xhost_.data(), dX_, sizeof(float) * Xhost_.size()); }
+    gsl_vector_complex** snaps = snapshot_array_->raw_snapshots();
+    for (unsigned k = 0; k < K; k++)
+      for (unsigned n = 0; n < N; n++) {
+        const double re = Xhost_[2 * (((size_t)k * N + n) * T_ + frame_no_)], im = Xhost_[2 * (((size_t)k * N + n) * T_ + frame_no_) + 1];
+        snaps[k]->data[2 * n] = re; snaps[k]->data[2 * n + 1] = im;
+        if (k > 0 && k < fftLen2_) { snaps[fftLen_ - k]->data[2 * n] = re; snaps[fftLen_ - k]->data[2 * n + 1] = -im; }
+      }
+  }
+  return snapshot_array_;
+}
+
+// ================================================================================ SubbandDS
+SubbandDS::SubbandDS(unsigned fftLen, bool halfBandShift, const String& nm)
+    : SubbandBeamformer(fftLen, halfBandShift, nm), bfweight_(NULL), weights_version_(0), output_version_(0),
+      wq_view_(gsl_vector_complex_calloc(1)) {}
+SubbandDS::~SubbandDS() { delete bfweight_; gsl_vector_complex_free(wq_view_); }
+
+void SubbandDS::clear_channel() { SubbandBeamformer::clear_channel(); delete bfweight_; bfweight_ = NULL; }
+
+void SubbandDS::alloc_bfweight_(int NC)
+{
+  // re-creates the weight object: active weights and post-filter state start over (reference beamformer.cc:1082-1092)
+  delete bfweight_;
+  bfweight_ = new BeamformerWeights(fftLen_, chanN(), false, (unsigned)NC);
+  weights_version_++;
+}
+
+void SubbandDS::calc_array_manifold_vectors(float samplerate, const gsl_vector* delays)
+{
+  alloc_bfweight_(1);
+  bfweight_->calcMainlobe(samplerate, delays, false);
+}
+
+const gsl_vector_complex* SubbandDS::get_weights(unsigned fbinX)
+{
+  const unsigned N = chanN();
+  gsl_vector_complex_free(wq_view_);
+  wq_view_ = gsl_vector_complex_calloc(N);
+  memcpy(wq_view_->data, &bfweight_->wq[(size_t)fbinX * N], sizeof(double) * 2 * N);
+  return wq_view_;
+}
+
+void SubbandDS::effective_weights(std::vector<float>& w)
+{
+  if (!bfweight_) throw j_error("%s", need_weights_msg_());
+  w.resize((size_t)2 * (fftLen2_ + 1) * chanN());
+  check_abi(btk_weights_gsc_effective(reinterpret_cast<const double*>(bfweight_->wq.data()), NULL, (int)fftLen_, (int)chanN(), 0, w.data()));
+}
+
+void SubbandDS::alignment_vector(bool use_wq, std::vector<float>& d)
+{
+  if (!bfweight_) throw j_error("%s", need_weights_msg_());
+  const unsigned N = chanN(), K = fftLen2_ + 1;
+  const std::vector<cd>& src = use_wq ? bfweight_->wq : bfweight_->ta;
+  d.resize((size_t)2 * K * N);
+  for (size_t i = 0; i < (size_t)K * N; i++) { d[2 * i] = (float)src[i].real(); d[2 * i + 1] = (float)src[i].imag(); }
+}
+
+void SubbandDS::compute_output_(long from_frame)
+{
+  const unsigned N = chanN(), K = fftLen2_ + 1;
+  void* dX = device_snapshots();
+  std::vector<float> w;
+  effective_weights(w);
+  void* dW = dev_alloc(sizeof(float) * w.size());
+  void* dY = dev_alloc(sizeof(float) * 2 * K * (T_ ? T_ : 1));
+  h2d(dW, w.data(), sizeof(float) * w.size());
+  check_abi(btk_bf_apply(dW, 0, dX, dY, 1, (int)K, (int)N, T_, T_, NULL));
+  check_abi(btk_synchronize(NULL));
+  std::vector<float> Ynew((size_t)2 * K * T_);
+  if (T_) d2h(Ynew.data(), dY, sizeof(float) * Ynew.size());
+  dev_free(dW); dev_free(dY);
+  if (Yhost_.size() == Ynew.size() && from_frame > 0) {
+    for (unsigned k = 0; k < K; k++)                        // frames already served keep their values
+      memcpy(&Ynew[2 * ((size_t)k * T_)], &Yhost_[2 * ((size_t)k * T_)], sizeof(float) * 2 * (size_t)from_frame);
+  }
+  Yhost_.swap(Ynew);
+  output_version_ = weights_version_;
+}
+
+const gsl_vector_complex* SubbandDS::next(int frame_no)
+{
+  if (frame_no == frame_no_) return vector_;
+  if (!bfweight_) throw j_error("%s", need_weights_msg_());
+  if (Yhost_.empty() || output_version_ != weights_version_) compute_output_(frame_no_ + 1);
+  const long idx = frame_no_ + 1;
+  if (idx >= T_) { is_end_ = true; throw jiterator_error("end of samples!"); }
+  serve_frame(Yhost_, T_, fftLen_, idx, vector_);
+  increment_();
+  return vector_;
+}
+
+void SubbandDS::reset() { SubbandBeamformer::reset(); Yhost_.clear(); }
+
+// ================================================================================ SubbandGSC
+void SubbandGSC::calc_gsc_weights(float samplerate, const gsl_vector* delaysT)
+{
+  alloc_bfweight_(1);
+  bfweight_->calcMainlobe(samplerate, delaysT, true);
+}
+
+void SubbandGSC::set_quiescent_weights_f(unsigned fbinX, const gsl_vector_complex* srcWq)
+{
+  alloc_bfweight_(1);
+  memcpy(&bfweight_->wq[(size_t)fbinX * chanN()], srcWq->data, sizeof(double) * 2 * chanN());
+  bfweight_->calcBlockingMatrix(fbinX);
+}
+
+void SubbandGSC::set_active_weights_f(unsigned fbinX, const gsl_vector* packedWeight)
+{
+  if (!bfweight_) throw j_error("call calc_gsc_weights_x() once\n");
+  bfweight_->calcSidelobeCancellerP_f(fbinX, packedWeight);
+  weights_version_++;
+}
+
+void SubbandGSC::zero_active_weights()
+{
+  if (!bfweight_) throw j_error("call calc_gsc_weights_x() once\n");
+  std::vector<cd> z(chanN() - bfweight_->NC(), cd(0.0, 0.0));
+  for (unsigned k = 0; k < fftLen_; k++) bfweight_->calcSidelobeCancellerU_f(k, z.data());
+  weights_version_++;
+}
+
+void SubbandGSC::effective_weights(std::vector<float>& w)
+{
+  if (!bfweight_) throw j_error("%s", need_weights_msg_());
+  w.resize((size_t)2 * (fftLen2_ + 1) * chanN());
+  check_abi(btk_weights_gsc_effective(reinterpret_cast<const double*>(bfweight_->wq.data()),
+                                      reinterpret_cast<const double*>(bfweight_->wl.data()), (int)fftLen_, (int)chanN(),
+                                      normalize_weight_ ? 1 : 0, w.data()));
+}
+
+// ================================================================================ SubbandMVDR
+SubbandMVDR::SubbandMVDR(unsigned fftLen, bool halfBandShift, const String& nm)
+    : SubbandDS(fftLen, halfBandShift, nm), dR_(NULL), have_mvdr_(false), fallbacks_(0), wm_view_(gsl_vector_complex_calloc(1)) {}
+SubbandMVDR::~SubbandMVDR() { dev_free(dR_); gsl_vector_complex_free(wm_view_); }
+void SubbandMVDR::clear_channel() { SubbandDS::clear_channel(); dev_free(dR_); dR_ = NULL; have_mvdr_ = false; }
+
+void SubbandMVDR::alloc_R_()
+{
+  if (dR_) return;
+  const size_t n = (size_t)2 * (fftLen2_ + 1) * chanN() * chanN();
+  dR_ = dev_alloc(sizeof(float) * n);
+  check_hip(hipMemset(dR_, 0, sizeof(float) * n), "hipMemset");
+}
+
+bool SubbandMVDR::set_noise_spatial_spectral_matrix(unsigned fbinX, gsl_matrix_complex* Rnn)
+{
+  const unsigned N = chanN();
+  if (Rnn->size1 != N) { fprintf(stderr, "The number of the rows of the matrix must be %d but it is %lu\n", N, (unsigned long)Rnn->size1); return false; }
+  if (Rnn->size2 != N) { fprintf(stderr, "The number of the columns of the matrix must be %d but it is %lu\n", N, (unsigned long)Rnn->size2); return false; }
+  alloc_R_();
+  std::vector<float> r((size_t)2 * N * N);
+  for (unsigned a = 0; a < N; a++)
+    for (unsigned b = 0; b < N; b++) {
+      const gsl_complex z = gsl_matrix_complex_get(Rnn, a, b);
+      r[2 * ((size_t)a * N + b)] = (float)GSL_REAL(z); r[2 * ((size_t)a * N + b) + 1] = (float)GSL_IMAG(z);
+    }
+  h2d(static_cast<float*>(dR_) + (size_t)fbinX * 2 * N * N, r.data(), sizeof(float) * r.size());
+  return true;
+}
+
+bool SubbandMVDR::set_diffuse_noise_model(const gsl_matrix* micPositions, float samplerate, float sspeed)
+{
+  const unsigned N = chanN();
+  if (micPositions->size1 != N) { fprintf(stderr, "The number of microphones must be %d but it is %lu\n", N, (unsigned long)micPositions->size1); return false; }
+  if (micPositions->size2 < 3) { fprintf(stderr, "The microphone positions should be described in the three dimensions\n"); return false; }
+  alloc_R_();
+  std::vector<float> mp((size_t)3 * N);
+  for (unsigned a = 0; a < N; a++) for (int j = 0; j < 3; j++) mp[3 * a + j] = (float)gsl_matrix_get(micPositions, a, j);
+  void* dmp = dev_alloc(sizeof(float) * mp.size());
+  h2d(dmp, mp.data(), sizeof(float) * mp.size());
+  check_abi(btk_mvdr_diffuse_model((const float*)dmp, (int)N, (int)fftLen_, samplerate, sspeed, dR_, NULL));
+  check_abi(btk_synchronize(NULL));
+  dev_free(dmp);
+  return true;
+}
+
+void SubbandMVDR::set_all_diagonal_loading(float diagonalWeight)
+{
+  if (!dR_) throw j_error("Construct first a noise covariance matrix\n");
+  check_abi(btk_mvdr_diagonal_loading(dR_, (int)(fftLen2_ + 1), (int)chanN(), diagonalWeight, NULL));
+}
+
+void SubbandMVDR::set_diagonal_looading(unsigned fbinX, float diagonalWeight)
+{
+  if (!dR_) throw j_error("Construct first a noise covariance matrix\n");
+  const unsigned N = chanN();
+  check_abi(btk_mvdr_diagonal_loading(static_cast<float*>(dR_) + (size_t)fbinX * 2 * N * N, 1, (int)N, diagonalWeight, NULL));
+}
+
+bool SubbandMVDR::calc_mvdr_weights(float, float dThreshold, bool)
+{
+  if (!dR_) throw jallocation_error("Set a spatial spectral matrix before calling calc_mvdr_weights()\n");
+  if (!bfweight_) throw j_error("call calc_array_manifold_vectorsX() once\n");
+  const unsigned N = chanN(), K = fftLen2_ + 1;
+  std::vector<float> d;
+  alignment_vector(true, d);
+  void* dD = dev_alloc(sizeof(float) * d.size());
+  void* dW = dev_alloc(sizeof(float) * d.size());
+  void* dfb = dev_alloc(sizeof(int));
+  void* scratch = NULL;
+  if (8 * ((size_t)N * N + N) > 150 * 1024) scratch = dev_alloc(sizeof(float) * 2 * K * N * N);
+  h2d(dD, d.data(), sizeof(float) * d.size());
+  check_hip(hipMemset(dfb, 0, sizeof(int)), "hipMemset");
+  check_abi(btk_mvdr_weights(dR_, dD, dW, (int)K, (int)N, dThreshold, scratch, (int*)dfb, NULL));
+  check_abi(btk_synchronize(NULL));
+  wmvdr_.resize(d.size());
+  d2h(wmvdr_.data(), dW, sizeof(float) * wmvdr_.size());
+  d2h(&fallbacks_, dfb, sizeof(int));
+  dev_free(dD); dev_free(dW); dev_free(dfb); dev_free(scratch);
+  have_mvdr_ = true;
+  weights_version_++;
+  return true;
+}
+
+const gsl_vector_complex* SubbandMVDR::mvdr_weights(unsigned fbinX)
+{
+  const unsigned N = chanN();
+  gsl_vector_complex_free(wm_view_);
+  wm_view_ = gsl_vector_complex_calloc(N);
+  for (unsigned c = 0; c < N; c++) {
+    wm_view_->data[2 * c] = wmvdr_[2 * ((size_t)fbinX * N + c)];
+    wm_view_->data[2 * c + 1] = wmvdr_[2 * ((size_t)fbinX * N + c) + 1];
+  }
+  return wm_view_;
+}
+
+void SubbandMVDR::effective_weights(std::vector<float>& w)
+{
+  if (!bfweight_) throw j_error("call calc_array_manifold_vectorsX() once\n");
+  if (!have_mvdr_) throw j_error("call calc_mvdr_weights() once\n");
+  w = wmvdr_;
+}
+
+// ================================================================================ ZelinskiPostFilter
+ZelinskiPostFilter::ZelinskiPostFilter(VectorComplexFeatureStreamPtr& output, unsigned fftLen, double alpha, int type,
+                                       int minFrames, const String& nm)
+    : VectorComplexFeatureStream(fftLen, nm), fftLen_(fftLen), samp_(output), type_((PostfilterType)type), alpha_(alpha),
+      min_frames_(minFrames), has_bf_ptr_(false), T_(0), prepared_(false), bf_version_(0), dPhi_(NULL), dPsi_(NULL), dWl_(NULL),
+      wp1_(gsl_vector_complex_calloc(fftLen))
+{
+  if (output->size() != fftLen) throw jdimension_error("Input block length (%d) != fftLen (%d)\n", output->size(), fftLen);
+}
+
+ZelinskiPostFilter::~ZelinskiPostFilter() { dev_free(dPhi_); dev_free(dPsi_); dev_free(dWl_); gsl_vector_complex_free(wp1_); }
+
+void ZelinskiPostFilter::set_beamformer(SubbandDSPtr& bfptr) { has_bf_ptr_ = true; bf_ptr_ = bfptr; }
+
+void ZelinskiPostFilter::compute_(long from_frame)
+{
+  if (!has_bf_ptr_) throw j_error("set beamformer's weights \n");
+  SubbandDS* bf = bf_ptr_.operator->();
+  const unsigned N = bf->chanN(), K = fftLen_ / 2 + 1;
+  void* dX = bf->device_snapshots();
+  T_ = bf->num_frames();
+  std::vector<float> w, d;
+  bf->effective_weights(w);
+  bf->alignment_vector((type_ & TYPE_ZELINSKI2) != 0, d);
+  const long Tn = T_ - from_frame;
+  if (!dPhi_) { dPhi_ = dev_alloc(sizeof(float) * 2 * K); dPsi_ = dev_alloc(sizeof(float) * K); dWl_ = dev_alloc(sizeof(float) * K); }
+  // weights (re)computed: the CSD history restarts, the frame counter keeps counting
+  check_hip(hipMemset(dPhi_, 0, sizeof(float) * 2 * K), "hipMemset");
+  check_hip(hipMemset(dPsi_, 0, sizeof(float) * K), "hipMemset");
+  check_hip(hipMemset(dWl_, 0, sizeof(float) * K), "hipMemset");
+  std::vector<float> Ynew((size_t)2 * K * T_);
+  if (Tn > 0) {
+    void* dW = dev_alloc(sizeof(float) * w.size());
+    void* dD = dev_alloc(sizeof(float) * d.size());
+    void* dY = dev_alloc(sizeof(float) * 2 * K * T_);
+    void* dC = dev_alloc(sizeof(float) * 2 * K * T_);
+    void* dE = dev_alloc(sizeof(float) * K * T_);
+    h2d(dW, w.data(), sizeof(float) * w.size());
+    h2d(dD, d.data(), sizeof(float) * d.size());
+    // process frames [from_frame, T): offset the frame axis by pointer arithmetic, strides stay T_
+    const float* Xo = static_cast<const float*>(dX) + 2 * from_frame;
+    float* Yo = static_cast<float*>(dY) + 2 * from_frame;
+    float* Co = static_cast<float*>(dC) + 2 * from_frame;
+    float* Eo = static_cast<float*>(dE) + from_frame;
+    check_abi(btk_bf_apply_stats(dW, dD, 0, Xo, Yo, Co, Eo, 1, (int)K, (int)N, T_, Tn, NULL));
+    check_abi(btk_zelinski_process(Yo, Co, Eo, 1, (int)K, (int)N, T_, Tn, alpha_, (int)type_, min_frames_, from_frame,
+                                   dPhi_, (float*)dPsi_, (float*)dWl_, NULL));
+    check_abi(btk_synchronize(NULL));
+    d2h(Ynew.data(), dY, sizeof(float) * Ynew.size());
+    dev_free(dW); dev_free(dD); dev_free(dY); dev_free(dC); dev_free(dE);
+  }
+  if (Yhost_.size() == Ynew.size() && from_frame > 0)
+    for (unsigned k = 0; k < K; k++)
+      memcpy(&Ynew[2 * ((size_t)k * T_)], &Yhost_[2 * ((size_t)k * T_)], sizeof(float) * 2 * (size_t)from_frame);
+  Yhost_.swap(Ynew);
+  bf_version_ = bf->weights_version();
+  prepared_ = true;
+}
+
+const gsl_vector_complex* ZelinskiPostFilter::next(int frame_no)
+{
+  if (frame_no == frame_no_) return vector_;
+  if (!has_bf_ptr_) throw j_error("set beamformer's weights \n");
+  if (!prepared_ || bf_version_ != bf_ptr_->weights_version()) compute_(frame_no_ + 1);
+  const long idx = frame_no_ + 1;
+  if (idx >= T_) { is_end_ = true; throw jiterator_error("end of samples!"); }
+  serve_frame(Yhost_, T_, fftLen_, idx, vector_);
+  increment_();
+  return vector_;
+}
+
+const gsl_vector_complex* ZelinskiPostFilter::postfilter_weights()
+{
+  if (!dWl_) return NULL;
+  const unsigned K = fftLen_ / 2 + 1;
+  std::vector<float> wl(K);
+  d2h(wl.data(), dWl_, sizeof(float) * K);
+  for (unsigned k = 0; k < K; k++) {
+    wp1_->data[2 * k] = wl[k]; wp1_->data[2 * k + 1] = 0.0;
+    if (k > 0 && k < fftLen_ / 2) { wp1_->data[2 * (fftLen_ - k)] = wl[k]; wp1_->data[2 * (fftLen_ - k) + 1] = 0.0; }
+  }
+  return wp1_;
+}
+
+void ZelinskiPostFilter::reset()
+{
+  samp_->reset();
+  VectorComplexFeatureStream::reset();
+  is_end_ = false;
+  prepared_ = false; Yhost_.clear();
+}
