@@ -1,0 +1,265 @@
+// fb_analysis512.hip -- analysis bank specialised for the headline geometry M = 512, m = 4 (gfx950).
+//
+// Same arithmetic contract as analysis_kernel<9,4> in fb_kernels.hip (reference
+// modulated/modulated.cc:375-409) with a schedule built around the LDS, which bounds the generic
+// kernel:
+//   * polyphase FIR with a register sliding window: a thread owns one sample pair index n for all
+//     16 frames of the tile; the 16+3R distinct sample pairs it needs are read from LDS once
+//     (22 ds_read_b64 instead of 64), the 8 prototype taps stay in VGPRs;
+//   * the 256-point complex FFT is two radix-16 passes held in registers (16x16 Cooley-Tukey,
+//     inter-pass twiddles W_256^{j k} precomputed per lane); each wavefront owns 4 frames, so the
+//     FFT needs NO workgroup barrier -- LDS ops of one wave execute in order;
+//   * every LDS exchange uses a 17-column padded 16x16 layout: reads and writes are conflict-free;
+//   * the Hermitian post-pass is fused into the final store (X[k] from Z[k], Z[256-k]); bins 0..256
+//     leave as 128-byte runs of 16 frames.
+//   * a workgroup walks through 16 consecutive tiles of its channel; the PCM span of tile i+1 is
+//     fetched into registers while tile i is computed, so HBM latency hides under LDS/VALU work.
+// LDS: the PCM span and the 16 FFT frames share one 35 KB region (the polyphase window is pulled
+// into registers before the frames overwrite the span) + 4 KB of twiddles -> four workgroups per CU.
+#include "btk_internal.h"
+#include "fft_lds.h"
+#include <cstdlib>
+
+namespace {
+
+constexpr int A_M = 512, A_NF = 256, A_MT = 4, A_TT = 16, A_NT = 256;
+constexpr int FRS = 273;               // float2 per FFT frame buffer: 16 rows x 17 (+1: frame stride = 34 banks mod 64)
+
+__device__ __forceinline__ void dft4p(float2& a0, float2& a1, float2& a2, float2& a3)
+{
+  const float2 s02 = caddf(a0, a2), d02 = csubf(a0, a2);
+  const float2 s13 = caddf(a1, a3), d13 = cmul_i<+1>(csubf(a1, a3));
+  a0 = caddf(s02, s13); a1 = caddf(d02, d13); a2 = csubf(s02, s13); a3 = csubf(d02, d13);
+}
+
+// in-register 16-point DFT, positive exponent: v[k] <- sum_r v[r] e^{+j 2 pi r k / 16}
+__device__ __forceinline__ void dft16p(float2 (&v)[16])
+{
+  constexpr float C1 = 0.92387953251128674f, S1 = 0.38268343236508977f, H = 0.70710678118654752f;
+  // r = 4a + b: DFT4 over a for each b -> T[b][c] in v[4c' ...]; keep as t[b][c]
+  float2 t[4][4];
+#pragma unroll
+  for (int b = 0; b < 4; b++) {
+    float2 x0 = v[b], x1 = v[4 + b], x2 = v[8 + b], x3 = v[12 + b];
+    dft4p(x0, x1, x2, x3);
+    t[b][0] = x0; t[b][1] = x1; t[b][2] = x2; t[b][3] = x3;
+  }
+  // twiddle W16^{b c}
+  t[1][1] = cmulf(t[1][1], make_float2(C1, S1));
+  t[1][2] = cmulf(t[1][2], make_float2(H, H));
+  t[1][3] = cmulf(t[1][3], make_float2(S1, C1));
+  t[2][1] = cmulf(t[2][1], make_float2(H, H));
+  t[2][2] = cmul_i<+1>(t[2][2]);
+  t[2][3] = cmulf(t[2][3], make_float2(-H, H));
+  t[3][1] = cmulf(t[3][1], make_float2(S1, C1));
+  t[3][2] = cmulf(t[3][2], make_float2(-H, H));
+  t[3][3] = cmulf(t[3][3], make_float2(-C1, -S1));     // W16^9
+#pragma unroll
+  for (int c = 0; c < 4; c++) {
+    float2 y0 = t[0][c], y1 = t[1][c], y2 = t[2][c], y3 = t[3][c];
+    dft4p(y0, y1, y2, y3);
+    v[c] = y0; v[c + 4] = y1; v[c + 8] = y2; v[c + 12] = y3;   // k = c + 4 d
+  }
+}
+
+constexpr int A_RUN = 16;             // consecutive tiles (16 frames each) one workgroup walks through
+
+template <int R>     // R = M / D in {1, 2, 4}
+__global__ __launch_bounds__(A_NT, 3)
+void analysis512_kernel(const float* __restrict__ pcm, long nsamples, long pcm_stride,
+                        const float* __restrict__ proto, const float2* __restrict__ twg,
+                        int laN, float gain, int N, int K, float2* __restrict__ X,
+                        long T_stride, long t0, long tcount, int ntiles, int nruns, int nchan, int ablate)
+{
+  constexpr int D = A_M / R;
+  constexpr int SPAN = (A_TT - 1) * D + A_MT * A_M;
+  constexpr int FB_BYTES = A_TT * FRS * 8;
+  constexpr int REG_U = (SPAN * 4 > FB_BYTES) ? SPAN * 4 : FB_BYTES;          // PCM span and FFT frames share one region
+  constexpr int NV4 = (SPAN / 4 + A_NT - 1) / A_NT;                          // float4 per thread covering the span
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* xs = reinterpret_cast<float*>(smem);
+  float2* fbuf = reinterpret_cast<float2*>(smem);                             // [16 frames][FRS], aliases xs
+  float2* tw = reinterpret_cast<float2*>(smem + REG_U);                       // [257] e^{+j 2 pi k / 512}
+  float2* twj = tw + (A_NF + 1);                                              // [16 k1][16 j] W_256^{j k1}
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // XCD-aware mapping: the runs of one channel stay on one XCD (its L2 serves the PCM halo re-reads)
+  const int b = blockIdx.x;
+  const int xcd = b & 7, slot = b >> 3;
+  const int chan = (slot / nruns) * 8 + xcd;
+  const int run = slot % nruns;
+  if (chan >= nchan) return;
+  const int tile_first = run * A_RUN;
+  const int tile_end = (tile_first + A_RUN < ntiles) ? tile_first + A_RUN : ntiles;
+
+  for (int j = tid; j <= A_NF; j += A_NT) tw[j] = twg[j];
+  twj[tid] = twg[(2 * (tid & 15) * (tid >> 4)) & 511];                        // tid = k1*16 + j
+
+  const float* src = pcm + (long)chan * pcm_stride;
+  const bool vec_ok = ((pcm_stride & 3) == 0) && ((reinterpret_cast<uintptr_t>(pcm) & 15) == 0);
+  float4 pre[NV4];
+  // PCM span of a tile -> registers (global loads stay in flight while the previous tile is computed)
+  auto fetch = [&](int tile) {
+    const long g0 = (t0 + (long)tile * A_TT + laN + 1) * (long)D - (long)A_MT * A_M;
+    if (vec_ok && g0 >= 0 && g0 + SPAN <= nsamples) {
+#pragma unroll
+      for (int q = 0; q < NV4; q++) {
+        const int l = (tid + q * A_NT) * 4;
+        if (l < SPAN) pre[q] = *reinterpret_cast<const float4*>(src + g0 + l);
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < NV4; q++) {
+        const int l = (tid + q * A_NT) * 4;
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+          const long g = g0 + l + e;
+          v[e] = (l + e < SPAN && g >= 0 && g < nsamples) ? src[g] : 0.0f;
+        }
+        pre[q] = make_float4(v[0], v[1], v[2], v[3]);
+      }
+    }
+  };
+
+  float2 h[A_MT];                                                             // prototype taps of pair index n = tid
+#pragma unroll
+  for (int k = 0; k < A_MT; k++) h[k] = *reinterpret_cast<const float2*>(proto + 2 * tid + A_M * k);
+  const int s = chan / N, nch = chan % N;
+  const long kstride = (long)N * T_stride;
+  const float hg = 0.5f * gain;
+
+  fetch(tile_first);
+  for (int tile = tile_first; tile < tile_end; tile++) {
+    const long tt0 = (long)tile * A_TT;
+    // ---- phase 1: registers -> LDS span, then start fetching the next tile
+#pragma unroll
+    for (int q = 0; q < NV4; q++) {
+      const int l = (tid + q * A_NT) * 4;
+      if (l < SPAN) *reinterpret_cast<float4*>(xs + l) = pre[q];
+    }
+    __syncthreads();
+    if (tile + 1 < tile_end) fetch(tile + 1);
+
+    // ---- phase 2: polyphase with a sliding register window; thread owns pair index n = tid.
+    //      The window is pulled into registers first: after the barrier the span is dead and the
+    //      FFT frames may overwrite it.
+    {
+      const int n = tid;
+      constexpr int NW = A_TT + (A_MT - 1) * R;
+      float2 win[NW];
+      const float* wbase = xs + (A_M - 2 - 2 * n);
+#pragma unroll
+      for (int i = 0; i < NW; i++) win[i] = *reinterpret_cast<const float2*>(wbase + i * D);
+      __syncthreads();
+      const int zoff = (n >> 4) * 17 + (n & 15);
+      if (ablate != 2) {
+#pragma unroll
+        for (int f = 0; f < A_TT; f++) {
+          float p0 = 0.f, p1 = 0.f;
+#pragma unroll
+          for (int k = 0; k < A_MT; k++) {
+            const float2 x = win[f + R * (A_MT - 1 - k)];      // xs[f D + m M - 2 - 2n - M k]
+            p0 = fmaf(h[k].x, x.y, p0);
+            p1 = fmaf(h[k].y, x.x, p1);
+          }
+          fbuf[f * FRS + zoff] = make_float2(p0, p1);          // frame f -> wave f/4, slot f%4
+        }
+      }
+    }
+    __syncthreads();
+
+    // ---- phase 3: wave-private 256-point FFT of 4 frames (no workgroup barrier inside)
+    if (ablate != 2) {
+      const int fl = lane >> 4, j = lane & 15;
+      float2* fb = fbuf + (wave * 4 + fl) * FRS;
+      float2 v[16];
+#pragma unroll
+      for (int r = 0; r < 16; r++) v[r] = fb[r * 17 + j];              // x[16 r + j]
+      dft16p(v);                                                      // A[j][k1]
+#pragma unroll
+      for (int k1 = 1; k1 < 16; k1++) v[k1] = cmulf(v[k1], twj[k1 * 16 + j]);
+#pragma unroll
+      for (int k1 = 0; k1 < 16; k1++) fb[j * 17 + k1] = v[k1];         // row j
+      // lane now plays k1 = j: column k1 over rows j'
+#pragma unroll
+      for (int jp = 0; jp < 16; jp++) v[jp] = fb[jp * 17 + j];
+      dft16p(v);                                                      // Z[k1 + 16 k2]
+#pragma unroll
+      for (int k2 = 0; k2 < 16; k2++) fb[k2 * 17 + j] = v[k2];         // natural order: idx(k) = (k>>4)*17 + (k&15)
+    }
+    __syncthreads();
+
+    // ---- phase 4: Hermitian post-pass fused into the store: X[k] = E + W^k O
+    //      thread (kq = tid>>4, f = tid&15) walks k = kq, kq+16, ..., kq+240; bin 256 is handled by tid < 16
+    {
+      const int f = tid & 15, kq = tid >> 4;
+      const bool live = tt0 + f < tcount;
+      const float2* zf = fbuf + f * FRS;
+      float2* xo = X + ((long)s * K * N + nch) * T_stride + tt0 + f + (long)kq * kstride;
+#pragma unroll 4
+      for (int it = 0; it < 16; it++) {
+        const int k = kq + 16 * it;
+        const int kp = (A_NF - k) & 255;
+        const float2 zk = zf[it * 17 + kq];
+        const float2 zq = zf[(kp >> 4) * 17 + (kp & 15)];                  // Z[256-k], conjugated below
+        const float2 e = make_float2(hg * (zk.x + zq.x), hg * (zk.y - zq.y));
+        const float2 o = make_float2(hg * (zk.y + zq.y), -hg * (zk.x - zq.x));   // -j (Z[k] - conj Z[256-k]) / 2
+        const float2 w = tw[k];
+        const float2 xv = make_float2(e.x + (w.x * o.x - w.y * o.y), e.y + (w.x * o.y + w.y * o.x));
+        if (ablate == 1) { if (xv.x == 1.2345e33f) xo[0] = xv; }
+        else if (live) xo[(long)(16 * it) * kstride] = xv;
+      }
+      if (tid < 16 && live && ablate != 1) {                           // k = 256: W^256 = -1, partner Z[0]
+        const float2 z0 = zf[0];
+        X[((long)s * K * N + nch) * T_stride + tt0 + f + (long)A_NF * kstride] = make_float2(gain * (z0.x - z0.y), 0.f);
+      }
+    }
+    __syncthreads();                                         // frames consumed before the next span overwrites them
+  }
+}
+
+template <int R>
+int launch512(const btk_fb* fb, const float* pcm, long nsamples, long pcm_stride, int S, int N, float2* X,
+              long T_stride, long t0, long tcount, hipStream_t st)
+{
+  constexpr int D = A_M / R;
+  constexpr int SPAN = (A_TT - 1) * D + A_MT * A_M;
+  constexpr int FB_BYTES = A_TT * FRS * 8;
+  constexpr int REG_U = (SPAN * 4 > FB_BYTES) ? SPAN * 4 : FB_BYTES;
+  const size_t lds = REG_U + sizeof(float2) * (A_NF + 1 + 256);
+  const int nchan = S * N;
+  const int ntiles = (int)((tcount + A_TT - 1) / A_TT);
+  const int nruns = (ntiles + A_RUN - 1) / A_RUN;
+  const long nblocks = (long)((nchan + 7) / 8) * nruns * 8;
+  auto kern = analysis512_kernel<R>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    BTK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
+  }
+  const float gain = fb->gain_factor > 0 ? (float)fb->gain_factor : 1.0f;
+  static const int ablate = getenv("BTK_ANALYSIS512_ABLATE") ? atoi(getenv("BTK_ANALYSIS512_ABLATE")) : 0;   // diagnostics only
+  hipLaunchKernelGGL(kern, dim3((unsigned)nblocks), dim3(A_NT), lds, st, pcm, nsamples, pcm_stride, fb->d_proto, fb->d_tw,
+                     fb->laN, gain, N, fb->K, X, T_stride, t0, tcount, ntiles, nruns, nchan, ablate);
+  BTK_HIP_CHECK(hipGetLastError());
+  return BTK_OK;
+}
+
+}  // namespace
+
+// returns 1 if handled, 0 if the geometry is not covered (caller falls back to the generic kernel), <0 on error
+int btk_analysis512_try(const btk_fb* fb, const float* pcm, long nsamples, long pcm_stride, int S, int N, void* X,
+                        long T_stride, long t0, long tcount, hipStream_t st)
+{
+  if (fb->M != A_M || fb->m != A_MT) return 0;
+  float2* Xp = static_cast<float2*>(X);
+  int rc;
+  switch (fb->R) {
+    case 1: rc = launch512<1>(fb, pcm, nsamples, pcm_stride, S, N, Xp, T_stride, t0, tcount, st); break;
+    case 2: rc = launch512<2>(fb, pcm, nsamples, pcm_stride, S, N, Xp, T_stride, t0, tcount, st); break;
+    case 4: rc = launch512<4>(fb, pcm, nsamples, pcm_stride, S, N, Xp, T_stride, t0, tcount, st); break;
+    default: return 0;
+  }
+  return rc == BTK_OK ? 1 : rc;
+}

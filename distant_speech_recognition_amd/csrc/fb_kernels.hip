@@ -20,6 +20,7 @@
 //       s_f[i] = sum_{k<m} g[M-1-i+M k] v_{f-Rk}[i],   out_b[D-1-d] = sum_{j<R} s_{f-(R-1-j)}[d + j D]
 #include "btk_internal.h"
 #include "fft_lds.h"
+#include <cstdlib>
 
 namespace {
 
@@ -319,6 +320,11 @@ int btk_fb_analysis(const btk_fb_t* fb, const float* pcm, long nsamples, long pc
   if (tcount == 0) return BTK_OK;
   hipStream_t st = as_stream(stream);
   float2* Xp = static_cast<float2*>(X);
+  static const bool no512 = getenv("BTK_DISABLE_ANALYSIS512") != nullptr;       // A/B switch for benchmarking
+  if (!no512) {
+    const int rc = btk_analysis512_try(fb, pcm, nsamples, pcm_stride, S, N, X, T_stride, t0, tcount, st);
+    if (rc != 0) return rc > 0 ? BTK_OK : rc;
+  }
   switch (fb->M) {
     case 64:   return launch_analysis<6>(fb, pcm, nsamples, pcm_stride, S, N, Xp, nullptr, T_stride, t0, tcount, st);
     case 128:  return launch_analysis<7>(fb, pcm, nsamples, pcm_stride, S, N, Xp, nullptr, T_stride, t0, tcount, st);

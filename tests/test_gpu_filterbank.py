@@ -14,7 +14,7 @@ def _eng():
 
 @pytest.mark.parametrize("M,m,r,dct", [(256, 4, 1, 2), (256, 4, 1, 0), (512, 4, 1, 2), (64, 4, 1, 1),
                                        (128, 2, 1, 2), (1024, 4, 1, 2), (512, 3, 1, 0), (256, 4, 2, 2),
-                                       (2048, 4, 1, 2), (256, 4, 0, 0)])
+                                       (2048, 4, 1, 2), (256, 4, 0, 0), (512, 4, 0, 2), (512, 4, 2, 1)])
 def test_analysis_matches_oracle(orc, dev, M, m, r, dct):
     import torch
     eng = _eng()
