@@ -62,6 +62,7 @@ SIGNATURES = {
     "btk_mvdr_diagonal_loading": (_i, [_vp, _i, _i, _f, _vp]),
     "btk_mvdr_weights": (_i, [_vp, _vp, _vp, _i, _i, _f, _vp, _vp, _vp]),
     "btk_weights_mainlobe": (_i, [_i, _i, _f, _vp, _vp]),
+    "btk_weights_mainlobe_2": (_i, [_i, _i, _f, _vp, _vp, _vp]),
     "btk_weights_blocking_matrix": (_i, [_vp, _i, _i, _vp]),
     "btk_weights_sidelobe": (_i, [_vp, _vp, _i, _i, _vp]),
     "btk_weights_gsc_effective": (_i, [_vp, _vp, _i, _i, _i, _vp]),

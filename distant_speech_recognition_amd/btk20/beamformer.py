@@ -188,6 +188,24 @@ class _BeamformerWeights(object):
             for k in range(self.fftlen):                                   # all M bins (beamformer.cc:557-563)
                 self.B[k] = engine.weights_blocking_matrix(self.wq[k], 1)
 
+    def calc_mainlobe_2(self, samplerate, delays_t, delays_i, is_gsc):
+        """calcMainlobe2 / calcMainlobeN with NC = 2 (beamformer.cc:572-721)."""
+        delays_t, delays_i = np.asarray(delays_t, np.float64), np.asarray(delays_i, np.float64)
+        if delays_i.size != self.chan_num:
+            raise jdimension_error("The number of delays for an interference signal does not match number of channels (%d vs. %d).\n"
+                                   % (delays_i.size, self.chan_num))
+        if delays_t.size != self.chan_num:
+            raise jdimension_error("The number of delays does not match number of channels (%d vs. %d).\n" % (delays_t.size, self.chan_num))
+        try:
+            self.wq = engine.weights_mainlobe_2(self.fftlen, self.chan_num, samplerate, delays_t, delays_i)
+        except _lib.BtkError as e:
+            raise_from_code(e)
+        # calcMainlobeN calls calcMainlobe(.., false) first, which sets ta_ to the plain D&S weights (:638, :555)
+        self.ta = engine.weights_mainlobe(self.fftlen, self.chan_num, samplerate, delays_t)
+        if is_gsc:
+            for k in range(self.fftlen):
+                self.B[k] = engine.weights_blocking_matrix(self.wq[k], self.NC)
+
     def calc_sidelobe_canceller_f(self, fbin, wa):
         self.wa[fbin] = wa
         self.wl[fbin] = engine.weights_sidelobe(self.B[fbin], wa)
@@ -213,6 +231,16 @@ class SubbandDSPtr(_SubbandBeamformer):
         self._alloc_bfweight(1)
         self._bfw[0].calc_mainlobe(samplerate, delays, False)
         self._invalidate_output()
+
+    def calc_array_manifold_vectors_2(self, samplerate, delays_t, delays_j):
+        self._alloc_bfweight(2)
+        self._bfw[0].calc_mainlobe_2(samplerate, delays_t, delays_j, False)
+        self._invalidate_output()
+
+    def calc_array_manifold_vectors_n(self, samplerate, delays_t, delays_js, NC=2):
+        if NC != 2:
+            raise jdimension_error("the GPU engine designs LCMV weights for NC = 2 constraints (got %d)\n" % NC)
+        self.calc_array_manifold_vectors_2(samplerate, delays_t, np.asarray(delays_js, np.float64).reshape(-1, self.chan_num())[0])
 
     def get_weights(self, fbin_no):
         return self._bfw[0].wq[fbin_no]
@@ -260,6 +288,16 @@ class SubbandGSCPtr(SubbandDSPtr):
         self._alloc_bfweight(1)
         self._bfw[0].calc_mainlobe(samplerate, delays_t, True)
         self._invalidate_output()
+
+    def calc_gsc_weights_2(self, samplerate, delays_t, delays_i):
+        self._alloc_bfweight(2)
+        self._bfw[0].calc_mainlobe_2(samplerate, delays_t, delays_i, True)
+        self._invalidate_output()
+
+    def calc_gsc_weights_n(self, samplerate, delays_t, delays_is, NC=2):
+        if NC != 2:
+            raise jdimension_error("the GPU engine designs LCMV weights for NC = 2 constraints (got %d)\n" % NC)
+        self.calc_gsc_weights_2(samplerate, delays_t, np.asarray(delays_is, np.float64).reshape(-1, self.chan_num())[0])
 
     def set_quiescent_weights_f(self, fbin_no, src_wq):
         self._alloc_bfweight(1)

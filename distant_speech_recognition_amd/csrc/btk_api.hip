@@ -244,3 +244,47 @@ int btk_nlms_u_to_wa(const double* u_in, const double* B_in, int N, double* waH_
 }
 
 }  // extern "C"
+
+// LCMV quiescent weights with NC = 2 constraints (look direction + one null):
+// BeamformerWeights::calcMainlobe2 / calcMainlobeN (reference beamformer/beamformer.cc:572-721) with
+// calc_null_beamformer_ (:299-363) and the thresholded closed-form 2x2 inverse calc_inverse_22mat_ (:181-221).
+// The reference's treatment of bin M/2 (:692-703) is reproduced as written, see the comment there.
+namespace {
+void lcmv_solve2(cd* wt, const cd* wj, int N)
+{
+  cd g00(0, 0), g01(0, 0), g10(0, 0), g11(0, 0);
+  for (int i = 0; i < N; i++) {
+    g00 += std::conj(wt[i]) * wt[i]; g01 += std::conj(wt[i]) * wj[i];
+    g10 += std::conj(wj[i]) * wt[i]; g11 += std::conj(wj[i]) * wj[i];
+  }
+  cd det = g00 * g11 - g01 * g10;
+  if (std::abs(det) < 1.0e-7) { g00 += 0.01; g11 += 0.01; det = g00 * g11 - g01 * g10; }
+  const cd v0 = g11 / det, v1 = -(g10 / det);                // first column of the inverse
+  for (int i = 0; i < N; i++) wt[i] = wt[i] * v0 + wj[i] * v1;
+}
+}  // namespace
+
+extern "C" int btk_weights_mainlobe_2(int M, int N, float samplerate, const double* delaysT, const double* delaysI, double* wq_out)
+{
+  if (N < 2) return btk_set_error(BTK_ERR_DIMENSION, "The number of channels must be > 2 but it is %d\n", N);
+  int rc = btk_weights_mainlobe(M, N, samplerate, delaysT, wq_out);
+  if (rc) return rc;
+  cd* wq = reinterpret_cast<cd*>(wq_out);
+  const int half = M / 2;
+  std::vector<cd> wj(N);
+  for (int c = 0; c < N; c++) wq[c] = cd(1.0 / N, 0.0);
+  for (int k = 1; k < half; k++) {
+    cd* vec = wq + (size_t)k * N;
+    for (int c = 0; c < N; c++) {
+      vec[c] *= (double)N;
+      wj[c] = std::polar(1.0, -2.0 * M_PI * k * samplerate * delaysI[c] / M);
+    }
+    lcmv_solve2(vec, wj.data(), N);
+  }
+  cd* vec = wq + (size_t)half * N;                          // bin M/2: literal reference behaviour (:692-703)
+  for (int c = 0; c < N; c++) {
+    vec[c] = std::polar(1.0, -M_PI * samplerate * delaysI[c]) / (double)N;
+    lcmv_solve2(vec, wj.data(), N);                         // wj still holds bin M/2-1
+  }
+  return BTK_OK;
+}

@@ -135,6 +135,17 @@ def weights_mainlobe(M, N, samplerate, delays):
     return wq
 
 
+def weights_mainlobe_2(M, N, samplerate, delays_t, delays_i):
+    """LCMV quiescent weights (target + one null): calcMainlobe2 -> wq complex128 [M][N]."""
+    dt = np.ascontiguousarray(delays_t, np.float64)
+    di = np.ascontiguousarray(delays_i, np.float64)
+    if dt.shape != (N,) or di.shape != (N,):
+        raise _lib.BtkError(_lib.BTK_ERR_DIMENSION, "The number of delays does not match number of channels (%d)" % N)
+    wq = np.zeros((M, N), np.complex128)
+    check(_lib.lib().btk_weights_mainlobe_2(M, N, float(samplerate), _np_ptr(dt), _np_ptr(di), _np_ptr(wq)))
+    return wq
+
+
 def weights_blocking_matrix(a, NC=1):
     a = np.ascontiguousarray(a, np.complex128)
     N = a.shape[0]

@@ -173,6 +173,15 @@ class SubbandGSCBeamformer(SubbandBeamformer):
         self._wq = np.array([self._beamformer.get_weights(m) for m in range(self._fftlen2 + 1)], complex)
 
 
+    def calc_beamformer_weights_n(self, samplerate, delays_t, delays_js, update_active_weights=True):
+        """pybeamformer.py:517-537 (LCMV: look direction + nulls)."""
+        assert (self._Nc - 1) == len(delays_js), 'Mismatch between no. constraints and no. jammers'
+        self._beamformer.calc_gsc_weights_n(samplerate, delays_t, delays_js, self._Nc)
+        if update_active_weights:
+            self.set_active_weights()
+        self._wqH = np.conjugate(np.array([self._beamformer.get_weights(m) for m in range(self._fftlen2 + 1)], complex))
+
+
 class SubbandMVDRBeamformer(SubbandBeamformer):
     """pybeamformer.py:540-585 (super-directive beamformer = diffuse-noise MVDR)."""
 

@@ -163,6 +163,9 @@ int  btk_mvdr_weights(const void* R, const void* wq, void* W, int K, int N, floa
 /* ---- Host-side weight design (double precision, one-off per look direction) -------------
  * BeamformerWeights::calcMainlobe (beamformer.cc:502-565): wq [host] complex128 [M][N].     */
 int  btk_weights_mainlobe(int M, int N, float samplerate, const double* delays, double* wq);
+/* LCMV quiescent weights with two constraints (target + one null): calcMainlobe2 / calcMainlobeN +
+ * calc_null_beamformer_ + calc_inverse_22mat_ (beamformer.cc:181-221, 299-363, 572-721); wq [M][N].   */
+int  btk_weights_mainlobe_2(int M, int N, float samplerate, const double* delaysT, const double* delaysI, double* wq);
 /* calc_blocking_matrix_ (beamformer.cc:373-454): a [host] complex128 [N]; B [host] [N][N-NC] */
 int  btk_weights_blocking_matrix(const double* a, int N, int NC, double* B);
 /* calcSidelobeCancellerU_f (beamformer.cc:752-767): wl = B wa                               */

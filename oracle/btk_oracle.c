@@ -415,6 +415,70 @@ void orc_calc_mainlobe(unsigned M, unsigned N, float samplerate, const double* d
   }
 }
 
+
+/* ------------------------------------------------------------------------
+ * LCMV quiescent weights: calc_inverse_22mat_ (beamformer.cc:181-221),
+ * calc_null_beamformer_ (:299-363) and BeamformerWeights::calcMainlobeN (:600-721),
+ * halfBandShift == false, NC == 2 (the closed-form 2x2 inverse; NC > 2 takes the
+ * float32 SVD pseudo-inverse in the reference and is handled by the Python side of the oracle).
+ * ---------------------------------------------------------------------- */
+static void inverse_22(cplx m[4], double beta)
+{                                                                   /* beamformer.cc:181-221 */
+  cplx m00 = m[0], m01 = m[1], m10 = m[2], m11 = m[3];
+  cplx det = c_sub(c_mul(m00, m11), c_mul(m01, m10));
+  if (c_abs(det) < 1.0E-07) {                                       /* MINDET_THRESHOLD */
+    m00.re += beta; m11.re += beta;
+    det = c_sub(c_mul(m00, m11), c_mul(m01, m10));
+  }
+  m[0] = c_div(m11, det);
+  m[3] = c_div(m00, det);
+  m[1] = c_scale(c_div(m01, det), -1.0);
+  m[2] = c_scale(c_div(m10, det), -1.0);
+}
+
+/* wt (in/out, target manifold), wj interference manifold; wt <- C (C^H C)^-1 g, g = (1,0) */
+static void null_beamformer2(cplx* wt, const cplx* wj, unsigned N)
+{                                                                   /* beamformer.cc:299-363 with NC = 2 */
+  cplx G[4] = { {0,0}, {0,0}, {0,0}, {0,0} };
+  for (unsigned i = 0; i < N; i++) {                                /* C^H C */
+    G[0] = c_add(G[0], c_mul(c_conj(wt[i]), wt[i]));
+    G[1] = c_add(G[1], c_mul(c_conj(wt[i]), wj[i]));
+    G[2] = c_add(G[2], c_mul(c_conj(wj[i]), wt[i]));
+    G[3] = c_add(G[3], c_mul(c_conj(wj[i]), wj[i]));
+  }
+  inverse_22(G, 0.01);
+  cplx v0 = G[0], v1 = G[2];                                        /* inv * (1,0)^T */
+  for (unsigned i = 0; i < N; i++) wt[i] = c_add(c_mul(wt[i], v0), c_mul(wj[i], v1));
+}
+
+void orc_calc_mainlobe_2(unsigned M, unsigned N, float samplerate, const double* delaysT, const double* delaysI, cplx* wq)
+{
+  unsigned M2 = M / 2;
+  cplx* pWj = (cplx*)calloc(N, sizeof(cplx));
+  orc_calc_mainlobe(M, N, samplerate, delaysT, wq);                 /* :638 */
+  for (unsigned c = 0; c < N; c++) wq[c] = c_make(1.0 / N, 0.0);    /* :665-667 */
+  for (unsigned k = 1; k < M2; k++) {                               /* :670-689 */
+    cplx* vec = wq + (size_t)k * N;
+    for (unsigned c = 0; c < N; c++) {
+      vec[c] = c_scale(vec[c], (double)N);
+      double valJ = -2.0 * M_PI * k * samplerate * delaysI[c] / M;
+      pWj[c] = c_polar(1.0, valJ);
+    }
+    null_beamformer2(vec, pWj, N);
+  }
+  {                                                                 /* :692-703, bin M/2, reproduced literally: */
+    cplx* vec = wq + (size_t)M2 * N;                                /* the interferer's manifold is written into */
+    for (unsigned c = 0; c < N; c++) {                              /* vec and the solve runs inside the channel */
+      vec[c] = c_scale(vec[c], (double)N);                          /* loop with pWj left over from bin M/2-1    */
+      double val = -M_PI * samplerate * delaysI[c];
+      cplx p = c_polar(1.0, val);
+      vec[c] = c_make(p.re / N, p.im / N);
+      null_beamformer2(vec, pWj, N);
+    }
+  }
+  free(pWj);
+}
+
 /* BLAS level-1 helpers written as the loops GSL's CBLAS performs. */
 static double dznrm2(const cplx* x, unsigned n)
 {

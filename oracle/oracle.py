@@ -38,6 +38,7 @@ def lib():
         L.orc_synthesis_run.restype = C.c_long
         L.orc_synthesis_run.argtypes = [vp, C.c_uint, C.c_uint, C.c_uint, C.c_uint, C.c_int, vp, C.c_long, vp, C.c_long]
         L.orc_calc_mainlobe.argtypes = [C.c_uint, C.c_uint, C.c_float, vp, vp]
+        L.orc_calc_mainlobe_2.argtypes = [C.c_uint, C.c_uint, C.c_float, vp, vp, vp]
         L.orc_blocking_matrix.restype = C.c_int
         L.orc_blocking_matrix.argtypes = [vp, C.c_uint, C.c_uint, vp]
         L.orc_sidelobe_canceller.argtypes = [vp, vp, C.c_uint, C.c_uint, vp]
@@ -140,6 +141,15 @@ def calc_mainlobe(M, N, samplerate, delays):
     delays = np.ascontiguousarray(delays, np.float64)
     wq = np.zeros((M, N), np.complex128)
     lib().orc_calc_mainlobe(M, N, float(samplerate), _p(delays), _p(wq))
+    return wq
+
+
+def calc_mainlobe_2(M, N, samplerate, delays_t, delays_i):
+    """calcMainlobe2 / calcMainlobeN with NC = 2 (beamformer.cc:572-721): LCMV quiescent weights."""
+    dt = np.ascontiguousarray(delays_t, np.float64)
+    di = np.ascontiguousarray(delays_i, np.float64)
+    wq = np.zeros((M, N), np.complex128)
+    lib().orc_calc_mainlobe_2(M, N, float(samplerate), _p(dt), _p(di), _p(wq))
     return wq
 
 

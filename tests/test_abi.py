@@ -58,3 +58,20 @@ def test_error_reporting_no_gpu():
     rc = L.btk_fb_create(ctypes.byref(h), 100, 4, 1, 0, 0, proto.ctypes.data_as(ctypes.c_void_p))
     assert rc == _lib.BTK_ERR_PARAMETER
     assert b"power of two" in L.btk_last_error()
+
+
+def test_lcmv_weights_host(orc):
+    """calcMainlobe2 (LCMV, NC=2): product vs oracle, distortionless + null known answers."""
+    import numpy as np
+    from distant_speech_recognition_amd import engine
+    from tests.util import ula_positions, la_delays
+    M, N = 128, 8
+    dt, di = la_delays(ula_positions(N), 0.4), la_delays(ula_positions(N), 1.9)
+    wq = engine.weights_mainlobe_2(M, N, 16000, dt, di)
+    assert np.max(np.abs(wq - orc.calc_mainlobe_2(M, N, 16000, dt, di))) < 1e-14
+    for k in (1, 9, 63):
+        vt = np.exp(-2j * np.pi * k * dt * 16000 / M)
+        vj = np.exp(-2j * np.pi * k * di * 16000 / M)
+        assert abs(np.vdot(wq[k], vt) - 1.0) < 1e-12 and abs(np.vdot(wq[k], vj)) < 1e-12
+    B = engine.weights_blocking_matrix(wq[9], 2)
+    assert B.shape == (N, N - 2) and np.max(np.abs(wq[9] @ B)) < 1e-12
