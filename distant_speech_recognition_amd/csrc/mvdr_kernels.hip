@@ -51,10 +51,12 @@ void mvdr_solve_kernel(const float2* __restrict__ R, const float2* __restrict__ 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int k = blockIdx.x;
   const int tid = threadIdx.x;
-  float2* rhs = reinterpret_cast<float2*>(smem);                   // [N]
+  // all LDS carved from the dynamic region (16-B aligned base, guide G17)
+  float* red_r = reinterpret_cast<float*>(smem);                   // [256]
+  float* red_i = red_r + 256;                                      // [256]
+  volatile int& bad = *reinterpret_cast<volatile int*>(red_i + 256);
+  float2* rhs = reinterpret_cast<float2*>(smem + 2064);            // [N]
   float2* mat = IN_LDS ? rhs + N : scratch + (long)k * N * N;      // [N][N]
-  __shared__ int bad;
-  __shared__ float red_r[256], red_i[256];
   const float2* Rk = R + (long)k * N * N;
   if (k == 0) {                                                    // wmvdr_[0] = ones
     for (int c = tid; c < N; c += 256) Wout[c] = make_float2(1.f, 0.f);
@@ -172,7 +174,7 @@ int btk_mvdr_weights(const void* R, const void* wq, void* W, int K, int N, float
 {
   if (!R || !wq || !W || !fallback_count) return btk_set_error(BTK_ERR_PARAMETER, "btk_mvdr_weights: null argument");
   if (K < 1 || N < 1) return btk_set_error(BTK_ERR_DIMENSION, "btk_mvdr_weights: bad sizes");
-  const size_t lds_mat = sizeof(float2) * ((size_t)N * N + N);
+  const size_t lds_mat = 2064 + sizeof(float2) * ((size_t)N * N + N);
   if (lds_mat <= 150 * 1024) {
     auto kern = mvdr_solve_kernel<true>;
     if (lds_mat > 64 * 1024)
@@ -181,7 +183,7 @@ int btk_mvdr_weights(const void* R, const void* wq, void* W, int K, int N, float
                        static_cast<const float2*>(wq), static_cast<float2*>(W), nullptr, N, threshold, fallback_count);
   } else {
     if (!scratch) return btk_set_error(BTK_ERR_PARAMETER, "btk_mvdr_weights: N=%d needs a [K][N][N] complex64 scratch buffer", N);
-    hipLaunchKernelGGL(mvdr_solve_kernel<false>, dim3((unsigned)K), dim3(256), sizeof(float2) * N, as_stream(stream),
+    hipLaunchKernelGGL(mvdr_solve_kernel<false>, dim3((unsigned)K), dim3(256), 2064 + sizeof(float2) * N, as_stream(stream),
                        static_cast<const float2*>(R), static_cast<const float2*>(wq), static_cast<float2*>(W),
                        static_cast<float2*>(scratch), N, threshold, fallback_count);
   }

@@ -1,0 +1,319 @@
+// wpe_kernels.hip -- multi-channel WPE dereverberation (weighted prediction error) for gfx950.
+//
+// Replaces MultiChannelWPEDereverberation::{estimate_filter, calc_every_channel_output}
+// (reference dereverberation/dereverberation.cc:312-698).  Per stream s, bin k and target channel c:
+//   lag vector   ybar(t) = [ y_{c'}(t - lowerN - l) ],  c' < C channel-major, l < L = upperN-lowerN+1   (:540-555)
+//   theta_c(t)   = max(|y_c(t) - g_c^H ybar(t)|, 1e-3)^2                                                (:619-646)
+//   R_c = sum_{t>=lowerN} ybar ybar^H / theta_c + bias I,   r_c = sum conj(y_c) ybar / theta_c          (:557-615)
+//   R_ii <- |R_ii| + max_i |R_ii| 10^{load_db/10}                                                       (:648-663)
+//   g_c = R_c^{-1} r_c by complex Cholesky                                                              (:665-690)
+//   output   y_c(t) - g_c^H ybar(t)   for t >= lowerN                                                   (:444-501)
+// The lag matrix A [C*L][T] is never materialised: every kernel reads the snapshot rows
+// X[s][k][c'][.] (frames contiguous) with a per-row shift.
+//   wpe_predict_kernel : lanes own frames, (c',l) loop in registers, filter taps wave-uniform -> theta^-1 or output
+//   wpe_herk_kernel    : the normal equations are a weighted HERK A diag(1/theta) A^H -> fp32 MFMA
+//                        (v_mfma_f32_32x32x2_f32), 64x64 tiles of the lower triangle only
+//   wpe_rvec_kernel    : r_c
+//   wpe_solve_kernel   : diagonal bias + loading + in-place Cholesky (matrix in global memory / L2) + solves
+#include "btk_internal.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr int WT_ = 32;                // frames per LDS tile
+constexpr int WLD = WT_ + 1;
+
+struct WpeGeom { int K, C, L, lowerN, lower_bw, upper_bw; long T_stride, T; };
+
+__device__ __forceinline__ bool bin_active(const WpeGeom& g, int k) { return !(k > g.lower_bw && k < g.upper_bw); }
+
+// mode 0: Winv[sc][k][t] = 1 / max(|y - pred|, 1e-3)^2 (0 for t < lowerN is handled by the consumers)
+// mode 1: OUT[s][k][c][t] = y - pred for t >= lowerN (apply-time ring rule), y otherwise
+__global__ __launch_bounds__(256)
+void wpe_predict_kernel(const float2* __restrict__ X, const float2* __restrict__ G, WpeGeom g, int mode,
+                        float* __restrict__ Winv, float2* __restrict__ OUT)
+{
+  const int k = blockIdx.y, sc = blockIdx.z;
+  const int s = sc / g.C, c = sc % g.C;
+  const long t = (long)blockIdx.x * 256 + threadIdx.x;
+  if (t >= g.T) return;
+  const float2* Xk = X + ((long)s * g.K + k) * g.C * g.T_stride;
+  const float2 y = Xk[(long)c * g.T_stride + t];
+  float pr = 0.f, pi = 0.f;
+  const bool active = bin_active(g, k) && t >= g.lowerN;
+  if (active) {
+    const float2* gk = G + (((long)s * g.C + c) * g.K + k) * (long)(g.C * g.L);
+    const long newest = t - g.lowerN;
+    // apply-time ring holds the last L frames only (dereverberation.cc:471-480); estimation sees all history
+    const long first = (mode == 1) ? ((t + 1 > g.L) ? t + 1 - g.L : 0) : 0;
+    for (int cc = 0; cc < g.C; cc++) {
+      const float2* xr = Xk + (long)cc * g.T_stride;
+      for (int l = 0; l < g.L; l++) {
+        const long idx = newest - l;
+        if (idx < first) break;
+        const float2 gv = gk[cc * g.L + l];
+        const float2 v = xr[idx];
+        pr = fmaf(gv.x, v.x, fmaf(gv.y, v.y, pr));              // conj(g) * x
+        pi = fmaf(gv.x, v.y, fmaf(-gv.y, v.x, pi));
+      }
+    }
+  }
+  const float dr = y.x - pr, di = y.y - pi;
+  if (mode == 0) {
+    float th = sqrtf(dr * dr + di * di);
+    if (th < 1.0e-3f) th = 1.0e-3f;                               // subband_floor_
+    Winv[((long)sc * g.K + k) * g.T_stride + t] = 1.0f / (th * th);
+  } else {
+    OUT[(((long)s * g.K + k) * g.C + c) * g.T_stride + t] = make_float2(dr, di);
+  }
+}
+
+// rows [row0,row0+64) of the lag matrix for frames [t0,t0+WT_): A[(c',l)][t] = X[c'][t-lowerN-l], t >= lowerN
+__device__ __forceinline__ void stage_lags(const float2* __restrict__ Xk, const WpeGeom& g, int P, int row0, long t0,
+                                           float2* __restrict__ dst, int tid)
+{
+  for (int idx = tid; idx < 64 * WT_; idx += 256) {
+    const int r = idx / WT_, tt = idx % WT_;
+    const int p = row0 + r;
+    const long t = t0 + tt;
+    float2 v = make_float2(0.f, 0.f);
+    if (p < P && t < g.T && t >= g.lowerN) {
+      const int cc = p / g.L, l = p % g.L;
+      const long i = t - g.lowerN - l;
+      if (i >= 0) v = Xk[(long)cc * g.T_stride + i];
+    }
+    dst[r * WLD + tt] = v;
+  }
+}
+
+// grid: (lower-triangle tile pairs, K, S*C)
+__global__ __launch_bounds__(256)
+void wpe_herk_kernel(const float2* __restrict__ X, const float* __restrict__ Winv, WpeGeom g, int ntile,
+                     float2* __restrict__ R)
+{
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float2* Ai = reinterpret_cast<float2*>(smem);
+  float2* Aj = Ai + 64 * WLD;
+  float* wrow = reinterpret_cast<float*>(Aj + 64 * WLD);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int k = blockIdx.y, sc = blockIdx.z;
+  if (!bin_active(g, k)) return;
+  const int s = sc / g.C;
+  const int P = g.C * g.L;
+  // blockIdx.x -> (ti >= tj)
+  int ti = 0, rem = blockIdx.x;
+  while (rem > ti) { rem -= ti + 1; ti++; }
+  const int tj = rem;
+  const float2* Xk = X + ((long)s * g.K + k) * g.C * g.T_stride;
+  const float* w = Winv + ((long)sc * g.K + k) * g.T_stride;
+  const int qi = wave >> 1, qj = wave & 1;
+  f32x16 rr = {0}, ri = {0};
+  const int li = lane & 31, lk = lane >> 5;
+  for (long t0 = 0; t0 < g.T; t0 += WT_) {
+    __syncthreads();
+    stage_lags(Xk, g, P, ti * 64, t0, Ai, tid);
+    stage_lags(Xk, g, P, tj * 64, t0, Aj, tid);
+    if (tid < WT_) { const long t = t0 + tid; wrow[tid] = (t < g.T && t >= g.lowerN) ? w[t] : 0.f; }
+    __syncthreads();
+#pragma unroll 4
+    for (int kk = 0; kk < WT_; kk += 2) {
+      const float2 a = Ai[(qi * 32 + li) * WLD + kk + lk];
+      float2 b = Aj[(qj * 32 + li) * WLD + kk + lk];
+      const float wv = wrow[kk + lk];
+      b.x *= wv; b.y *= wv;
+      rr = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, rr, 0, 0, 0);
+      rr = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, rr, 0, 0, 0);
+      ri = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.x, ri, 0, 0, 0);
+      ri = __builtin_amdgcn_mfma_f32_32x32x2f32(-a.x, b.y, ri, 0, 0, 0);
+    }
+  }
+  float2* Rk = R + ((long)sc * g.K + k) * (long)P * P;
+#pragma unroll
+  for (int reg = 0; reg < 16; reg++) {
+    const int row = ti * 64 + qi * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+    const int col = tj * 64 + qj * 32 + (lane & 31);
+    if (row < P && col < P) Rk[(long)row * P + col] = make_float2(rr[reg], ri[reg]);
+  }
+}
+
+// r_c[p] = sum_t conj(y_c(t)) ybar_p(t) / theta_c(t)
+__global__ __launch_bounds__(256)
+void wpe_rvec_kernel(const float2* __restrict__ X, const float* __restrict__ Winv, WpeGeom g, float2* __restrict__ rvec)
+{
+  const int k = blockIdx.x, sc = blockIdx.y;
+  if (!bin_active(g, k)) return;
+  const int s = sc / g.C, c = sc % g.C;
+  const int P = g.C * g.L;
+  const float2* Xk = X + ((long)s * g.K + k) * g.C * g.T_stride;
+  const float2* yc = Xk + (long)c * g.T_stride;
+  const float* w = Winv + ((long)sc * g.K + k) * g.T_stride;
+  for (int p = threadIdx.x; p < P; p += 256) {
+    const int cc = p / g.L, l = p % g.L;
+    const float2* xr = Xk + (long)cc * g.T_stride;
+    float ar = 0.f, ai = 0.f;
+    for (long t = g.lowerN + l; t < g.T; t++) {
+      const float2 y = yc[t];
+      const float2 v = xr[t - g.lowerN - l];
+      const float wv = w[t];
+      ar = fmaf(wv, y.x * v.x + y.y * v.y, ar);                   // conj(y) * v
+      ai = fmaf(wv, y.x * v.y - y.y * v.x, ai);
+    }
+    rvec[((long)sc * g.K + k) * P + p] = make_float2(ar, ai);
+  }
+}
+
+// One workgroup per (sc,k): R in global memory (in place), rhs -> solution written to G.
+__global__ __launch_bounds__(256)
+void wpe_solve_kernel(float2* __restrict__ R, const float2* __restrict__ rvec, WpeGeom g, float load_factor,
+                      float diagonal_bias, float2* __restrict__ G, int* __restrict__ fail_count)
+{
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int k = blockIdx.x, sc = blockIdx.y;
+  if (!bin_active(g, k)) return;
+  const int P = g.C * g.L;
+  const int tid = threadIdx.x;
+  float2* rhs = reinterpret_cast<float2*>(smem);                   // [P]  (all LDS carved from the dynamic region, 16-B aligned)
+  float* red = reinterpret_cast<float*>(rhs + ((P + 1) & ~1));     // [256]
+  volatile int& bad = *reinterpret_cast<volatile int*>(red + 256);
+  float2* mat = R + ((long)sc * g.K + k) * (long)P * P;
+  const int s = sc / g.C, c = sc % g.C;
+  float2* gout = G + (((long)s * g.C + c) * g.K + k) * (long)P;
+  for (int p = tid; p < P; p += 256) rhs[p] = rvec[((long)sc * g.K + k) * P + p];
+  // diagonal bias (dereverberation.cc:574-577) then load_R_ (:648-663)
+  float mx = 0.f;
+  for (int p = tid; p < P; p += 256) {
+    float2 d = mat[(long)p * P + p];
+    d.x += diagonal_bias;
+    const float a = sqrtf(d.x * d.x + d.y * d.y);
+    mat[(long)p * P + p] = make_float2(a, 0.f);
+    mx = fmaxf(mx, a);
+  }
+  red[tid] = mx;
+  if (tid == 0) bad = 0;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) { if (tid < o) red[tid] = fmaxf(red[tid], red[tid + o]); __syncthreads(); }
+  const float load = red[0] * load_factor;
+  for (int p = tid; p < P; p += 256) mat[(long)p * P + p].x += load;
+  __syncthreads();
+
+  for (int j = 0; j < P; j++) {
+    if (tid == 0) {
+      const float piv = mat[(long)j * P + j].x;
+      if (!(piv > 0.f)) bad = 1; else mat[(long)j * P + j] = make_float2(sqrtf(piv), 0.f);
+    }
+    __syncthreads();
+    if (bad) break;
+    const float inv = 1.0f / mat[(long)j * P + j].x;
+    for (int i = j + 1 + tid; i < P; i += 256) {
+      float2 v = mat[(long)i * P + j];
+      mat[(long)i * P + j] = make_float2(v.x * inv, v.y * inv);
+    }
+    __syncthreads();
+    const int rem = P - j - 1;
+    for (int idx = tid; idx < rem * rem; idx += 256) {
+      const int i = j + 1 + idx / rem, cc = j + 1 + idx % rem;
+      if (cc <= i) {
+        const float2 a = mat[(long)i * P + j], b = mat[(long)cc * P + j];
+        float2 v = mat[(long)i * P + cc];
+        v.x -= a.x * b.x + a.y * b.y;
+        v.y -= a.y * b.x - a.x * b.y;
+        mat[(long)i * P + cc] = v;
+      }
+    }
+    __syncthreads();
+  }
+  __syncthreads();
+  if (bad) { if (tid == 0) atomicAdd(fail_count, 1); return; }
+  for (int j = 0; j < P; j++) {                                   // L y = r
+    if (tid == 0) { const float inv = 1.0f / mat[(long)j * P + j].x; rhs[j].x *= inv; rhs[j].y *= inv; }
+    __syncthreads();
+    const float2 yj = rhs[j];
+    for (int i = j + 1 + tid; i < P; i += 256) {
+      const float2 l = mat[(long)i * P + j];
+      rhs[i].x -= l.x * yj.x - l.y * yj.y;
+      rhs[i].y -= l.x * yj.y + l.y * yj.x;
+    }
+    __syncthreads();
+  }
+  for (int j = P - 1; j >= 0; j--) {                              // L^H g = y
+    if (tid == 0) { const float inv = 1.0f / mat[(long)j * P + j].x; rhs[j].x *= inv; rhs[j].y *= inv; }
+    __syncthreads();
+    const float2 zj = rhs[j];
+    for (int i = tid; i < j; i += 256) {
+      const float2 l = mat[(long)j * P + i];
+      rhs[i].x -= l.x * zj.x + l.y * zj.y;
+      rhs[i].y -= l.x * zj.y - l.y * zj.x;
+    }
+    __syncthreads();
+  }
+  for (int p = tid; p < P; p += 256) gout[p] = rhs[p];
+}
+
+WpeGeom make_geom(int K, int C, int lowerN, int upperN, int lower_bw, int upper_bw, long T_stride, long T)
+{
+  WpeGeom g;
+  g.K = K; g.C = C; g.L = upperN - lowerN + 1; g.lowerN = lowerN; g.lower_bw = lower_bw; g.upper_bw = upper_bw;
+  g.T_stride = T_stride; g.T = T;
+  return g;
+}
+
+}  // namespace
+
+extern "C" {
+
+long btk_wpe_workspace_bytes(int S, int K, int C, int lowerN, int upperN, long T_stride)
+{
+  const long P = (long)C * (upperN - lowerN + 1);
+  const long nb = (long)S * C * K;
+  return nb * P * P * 8 + nb * P * 8 + nb * T_stride * 4 + 256;
+}
+
+int btk_wpe_estimate(const void* X, int S, int K, int C, long T_stride, long T, int lowerN, int upperN, int iterations,
+                     double load_db, double diagonal_bias, int lower_bw, int upper_bw, void* G, void* workspace,
+                     int* fail_count, void* stream)
+{
+  if (!X || !G || !workspace || !fail_count) return btk_set_error(BTK_ERR_PARAMETER, "btk_wpe_estimate: null argument");
+  if (S <= 0 || K <= 0 || C <= 0 || T < 0 || T_stride < T || upperN < lowerN || lowerN < 0)
+    return btk_set_error(BTK_ERR_DIMENSION, "btk_wpe_estimate: bad sizes S=%d K=%d C=%d T=%ld lags %d..%d", S, K, C, T, lowerN, upperN);
+  if (T == 0) return BTK_OK;
+  const WpeGeom g = make_geom(K, C, lowerN, upperN, lower_bw, upper_bw, T_stride, T);
+  const long P = (long)C * g.L;
+  const long nb = (long)S * C * K;
+  hipStream_t st = as_stream(stream);
+  float2* R = static_cast<float2*>(workspace);
+  float2* rvec = R + nb * P * P;
+  float* Winv = reinterpret_cast<float*>(rvec + nb * P);
+  const float2* Xp = static_cast<const float2*>(X);
+  float2* Gp = static_cast<float2*>(G);
+  const int ntile = (int)((P + 63) / 64);
+  const size_t lds_herk = sizeof(float2) * 2 * 64 * WLD + sizeof(float) * WT_;
+  const float load_factor = (float)pow(10.0, load_db / 10.0);
+  for (int it = 0; it < iterations; it++) {
+    hipLaunchKernelGGL(wpe_predict_kernel, dim3((unsigned)((T + 255) / 256), (unsigned)K, (unsigned)(S * C)), dim3(256), 0, st,
+                       Xp, Gp, g, 0, Winv, static_cast<float2*>(nullptr));
+    hipLaunchKernelGGL(wpe_herk_kernel, dim3((unsigned)(ntile * (ntile + 1) / 2), (unsigned)K, (unsigned)(S * C)), dim3(256),
+                       lds_herk, st, Xp, Winv, g, ntile, R);
+    hipLaunchKernelGGL(wpe_rvec_kernel, dim3((unsigned)K, (unsigned)(S * C)), dim3(256), 0, st, Xp, Winv, g, rvec);
+    hipLaunchKernelGGL(wpe_solve_kernel, dim3((unsigned)K, (unsigned)(S * C)), dim3(256), sizeof(float2) * ((P + 1) & ~1L) + sizeof(float) * 260, st,
+                       R, rvec, g, load_factor, (float)diagonal_bias, Gp, fail_count);
+    BTK_HIP_CHECK(hipGetLastError());
+  }
+  return BTK_OK;
+}
+
+int btk_wpe_apply(const void* X, const void* G, void* OUT, int S, int K, int C, long T_stride, long T,
+                  int lowerN, int upperN, int lower_bw, int upper_bw, void* stream)
+{
+  if (!X || !G || !OUT) return btk_set_error(BTK_ERR_PARAMETER, "btk_wpe_apply: null argument");
+  if (S <= 0 || K <= 0 || C <= 0 || T < 0 || T_stride < T || upperN < lowerN)
+    return btk_set_error(BTK_ERR_DIMENSION, "btk_wpe_apply: bad sizes");
+  if (T == 0) return BTK_OK;
+  const WpeGeom g = make_geom(K, C, lowerN, upperN, lower_bw, upper_bw, T_stride, T);
+  hipLaunchKernelGGL(wpe_predict_kernel, dim3((unsigned)((T + 255) / 256), (unsigned)K, (unsigned)(S * C)), dim3(256), 0,
+                     as_stream(stream), static_cast<const float2*>(X), static_cast<const float2*>(G), g, 1,
+                     static_cast<float*>(nullptr), static_cast<float2*>(OUT));
+  BTK_HIP_CHECK(hipGetLastError());
+  return BTK_OK;
+}
+
+}  // extern "C"

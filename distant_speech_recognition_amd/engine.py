@@ -356,8 +356,50 @@ def mvdr_weights(R, wq, threshold=1.0e-8):
     W = torch.empty((K, N), dtype=torch.complex64, device=R.device)
     fb = torch.zeros(1, dtype=torch.int32, device=R.device)
     scratch = None
-    if 8 * (N * N + N) > 150 * 1024:
+    if 2064 + 8 * (N * N + N) > 150 * 1024:
         scratch = torch.empty((K, N, N), dtype=torch.complex64, device=R.device)
     check(_lib.lib().btk_mvdr_weights(_ptr(R), _ptr(wq), _ptr(W), K, N, float(threshold),
                                       None if scratch is None else _ptr(scratch), _ptr(fb), _stream()))
     return W, int(fb.item())
+
+
+# ---------------------------------------------------------------------------- WPE dereverberation
+def wpe_band(M, band_width, samplerate):
+    """set_band_width_ (dereverberation.cc:361-369): (lower_bandWidthN_, upper_bandWidthN_)."""
+    if band_width == 0.0:
+        lower = M // 2
+    else:
+        if band_width > samplerate / 2.0:
+            raise _lib.BtkError(_lib.BTK_ERR_DIMENSION, "Bandwidth is greater than the Nyquist rate.")
+        lower = int((band_width / (samplerate / 2.0)) * (M // 2))
+    return lower, M - lower
+
+
+def wpe_estimate(X, M, lower_num=0, upper_num=32, iterations_num=2, load_db=-18.0, band_width=0.0,
+                 diagonal_bias=1.0e-4, samplerate=16000.0, G=None):
+    """MultiChannelWPEDereverberation::estimate_filter.  X complex64 [S][K][C][T] -> G complex64 [S][C][K][C*L]."""
+    _need_cuda(X, "X")
+    S, K, Cn, T = X.shape
+    L = upper_num - lower_num + 1
+    if G is None:
+        G = torch.zeros((S, Cn, K, Cn * L), dtype=torch.complex64, device=X.device)
+    lo, up = wpe_band(M, band_width, samplerate)
+    ws = torch.empty(_lib.lib().btk_wpe_workspace_bytes(S, K, Cn, lower_num, upper_num, T), dtype=torch.uint8, device=X.device)
+    fail = torch.zeros(1, dtype=torch.int32, device=X.device)
+    check(_lib.lib().btk_wpe_estimate(_ptr(X), S, K, Cn, T, T, lower_num, upper_num, iterations_num, float(load_db),
+                                      float(diagonal_bias), lo, up, _ptr(G), _ptr(ws), _ptr(fail), _stream()))
+    if int(fail.item()) > 0:
+        raise _lib.BtkError(_lib.BTK_ERR_NUMERIC, "MultiChannelWPEDereverberation: Cholesky decomposition failed (%d systems).\n"
+                            "Some channels may be too similar. Try to increase 'diagonal_bias'" % int(fail.item()))
+    return G
+
+
+def wpe_apply(X, G, M, lower_num=0, upper_num=32, band_width=0.0, samplerate=16000.0, out=None):
+    """calc_every_channel_output for every frame and channel: X [S][K][C][T] -> dereverberated [S][K][C][T]."""
+    _need_cuda(X, "X"); _need_cuda(G, "G")
+    S, K, Cn, T = X.shape
+    if out is None:
+        out = torch.empty_like(X)
+    lo, up = wpe_band(M, band_width, samplerate)
+    check(_lib.lib().btk_wpe_apply(_ptr(X), _ptr(G), _ptr(out), S, K, Cn, T, T, lower_num, upper_num, lo, up, _stream()))
+    return out

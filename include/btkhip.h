@@ -160,6 +160,26 @@ int  btk_mvdr_diagonal_loading(void* R, int nbins, int N, float weight, void* st
 int  btk_mvdr_weights(const void* R, const void* wq, void* W, int K, int N, float threshold,
                       void* scratch, int* fallback_count, void* stream);
 
+/* ---- Multi-channel WPE dereverberation ---------------------------------------------------------
+ * Replaces MultiChannelWPEDereverberation::estimate_filter / calc_every_channel_output
+ * (dereverberation/dereverberation.cc:312-698).  X [dev] complex64 [S][K][C][T_stride] (the snapshot
+ * layout with C channels); L = upperN-lowerN+1 lags, prediction order P = C*L, lag vector ordered
+ * channel-major then lag (:540-555).  lower_bw/upper_bw = lower_bandWidthN_/upper_bandWidthN_ (:361-369):
+ * bins with lower_bw < k < upper_bw are left untouched.
+ * btk_wpe_estimate: `iterations` rounds of { theta = max(|y - g^H ybar|,1e-3)^2 ; R = A diag(1/theta) A^H
+ *   + bias I (fp32 MFMA HERK) ; r ; diagonal loading |R_ii| + max|R_ii| 10^(load_db/10) ; Cholesky solve }.
+ *   G [dev] complex64 [S][C][K][P] in/out (zeros == a fresh object / next_speaker()).
+ *   workspace [dev] btk_wpe_workspace_bytes(...) bytes; *fail_count [dev int] counts failed factorisations
+ *   (the reference throws jnumeric_error, :676-680).
+ * btk_wpe_apply: OUT[s][k][c][t] = y_c(t) - g_c^H ybar(t) for t >= lowerN using the L-frame ring rule of
+ *   :471-480; other frames/bins are copied.                                                          */
+long btk_wpe_workspace_bytes(int S, int K, int C, int lowerN, int upperN, long T_stride);
+int  btk_wpe_estimate(const void* X, int S, int K, int C, long T_stride, long T, int lowerN, int upperN,
+                      int iterations, double load_db, double diagonal_bias, int lower_bw, int upper_bw,
+                      void* G, void* workspace, int* fail_count, void* stream);
+int  btk_wpe_apply(const void* X, const void* G, void* OUT, int S, int K, int C, long T_stride, long T,
+                   int lowerN, int upperN, int lower_bw, int upper_bw, void* stream);
+
 /* ---- Host-side weight design (double precision, one-off per look direction) -------------
  * BeamformerWeights::calcMainlobe (beamformer.cc:502-565): wq [host] complex128 [M][N].     */
 int  btk_weights_mainlobe(int M, int N, float samplerate, const double* delays, double* wq);
