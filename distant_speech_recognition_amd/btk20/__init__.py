@@ -13,3 +13,4 @@ from .feature import *     # noqa: F401,F403
 from .modulated import *   # noqa: F401,F403
 from .beamformer import *  # noqa: F401,F403
 from .postfilter import *  # noqa: F401,F403
+from .dereverberation import *  # noqa: F401,F403

@@ -115,6 +115,10 @@ class _SubbandBeamformer(_BlockServedStream, VectorComplexFeatureStream):
                 pcm = np.stack([p[:L] for p in pcms])[None]
                 plan = chans[0]._plan
                 self._X = plan.analysis(torch.from_numpy(np.ascontiguousarray(pcm)).to(device()))
+            elif all(hasattr(c, "wpe_source") for c in chans) and len(set(id(c.wpe_source()) for c in chans)) == 1 \
+                    and [c.channel_no() for c in chans] == list(range(chans[0].wpe_source()._C)):
+                # config C4: the channels are the WPE outputs of one estimator -> stay on the device
+                self._X = chans[0].wpe_source().device_output()
             else:
                 frames = [_pull_all(c) for c in chans]
                 T = min(len(f) for f in frames)
