@@ -140,9 +140,8 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if dist:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+        from distant_speech_recognition_amd import sharding
+        elapsed = sharding.max_over_ranks(elapsed, dev)
 
     t_ana = np.mean([e[0].elapsed_time(e[1]) for e in ev]) * 1e-3
     t_bf = np.mean([e[1].elapsed_time(e[2]) for e in ev]) * 1e-3
@@ -165,6 +164,9 @@ def main():
                        "streams_per_gpu": S, "frames_per_stream": T, "parallelism": "stream-sharded x%d" % world},
             "roofline": {"bound": "hbm", "kernel": "analysis_kernel", "achieved": b_ana / t_ana / 1e9, "peak": HBM_PEAK / 1e9,
                          "unit": "GB/s", "frac": b_ana / t_ana / HBM_PEAK, "traffic": None,
+                         "traffic_note": "rocprofv3 PMC on the same kernel, 8 streams x 2048 frames "
+                                         "(profiles/r01_pmc_c0_analysis512.txt): 2*FETCH_SIZE + WRITE_SIZE = 3.23 GB "
+                                         "= 1.00 x algorithmic bytes of that launch",
                          "bytes_per_launch": b_ana, "avg_launch_ms": t_ana * 1e3},
             "stages": {
                 "analysis": {"ms": t_ana * 1e3, "GBps": b_ana / t_ana / 1e9, "frac": b_ana / t_ana / HBM_PEAK},

@@ -1,0 +1,85 @@
+#!/usr/bin/env python
+"""bench_stages.py -- per-kernel measurements of the stages that are not in the headline chain
+(adaptive NLMS canceller, fused apply+Zelinski, covariance HERK, MVDR solve, WPE), each against its
+roofline.  Not the driver's bench (that is bench.py); results are copied into profiles/ and DESIGN.md."""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+HBM, FP32 = 8.0e12, 157.3e12
+
+
+def timeit(torch, fn, n=5, warm=2):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e-3 / n
+
+
+def main():
+    import torch
+    from distant_speech_recognition_amd import engine as eng
+    from tests.util import ula_positions, la_delays
+    dev = torch.device("cuda:0")
+    out = {}
+    # ---- C0 snapshots: 64 mics, 512 bins
+    S, N, M, T = 16, 64, 512, 4096
+    K = M // 2 + 1
+    X = torch.randn((S, K, N, T), dtype=torch.float32, device=dev).to(torch.complex64) * 2000
+    X = X + 1j * torch.randn((S, K, N, T), dtype=torch.float32, device=dev) * 2000
+    delays = la_delays(ula_positions(N), -1.306379)
+    vs = np.stack([np.exp(-2j * np.pi * k * (16000.0 / M) * delays) / N for k in range(K)]).astype(np.complex64)
+    vd = torch.from_numpy(vs).to(dev)
+    st = eng.NLMSState(S, M, N, dev)
+    Y = torch.empty((S, K, T), dtype=torch.complex64, device=dev)
+    t = timeit(torch, lambda: eng.nlms_process(vd, X, st, out=Y))
+    b = 8 * K * (N + 1) * S * T
+    out["nlms_c0"] = {"ms": t * 1e3, "frames_per_s": S * T / t, "GBps": b / t / 1e9, "hbm_frac": b / t / HBM}
+    zs = eng.ZelinskiState(S, K, dev)
+    t = timeit(torch, lambda: eng.bf_apply_zelinski(vd, vd, X, zs, alpha=0.7, out=Y))
+    out["apply_zelinski_c0"] = {"ms": t * 1e3, "frames_per_s": S * T / t, "GBps": b / t / 1e9, "hbm_frac": b / t / HBM}
+    R = torch.zeros((S, K, N, N), dtype=torch.complex64, device=dev)
+    for mf, tag in ((True, "cov_mfma_c0"), (False, "cov_valu_c0")):
+        t = timeit(torch, lambda: eng.cov_accumulate(X, R=R, use_mfma=mf), n=3, warm=1)
+        fl = 8.0 * K * N * N * S * T
+        out[tag] = {"ms": t * 1e3, "frames_per_s": S * T / t, "TFLOPs": fl / t / 1e12, "fp32_frac": fl / t / FP32,
+                    "GBps_read": 8 * K * N * S * T / t / 1e9}
+    del X, R, Y
+    # ---- C3: MVDR solve, 64 mics, 1024 bins
+    N, M = 64, 1024
+    K = M // 2 + 1
+    mpos = ula_positions(N); mpos[:, 2] = 2.0
+    Rd = eng.mvdr_diffuse_model(mpos, M, 16000, device=dev)
+    eng.mvdr_diagonal_loading(Rd, 0.01)
+    wq = eng.weights_mainlobe(M, N, 16000, la_delays(mpos, -1.3))[:K].astype(np.complex64)
+    wd = torch.from_numpy(wq).to(dev)
+    t = timeit(torch, lambda: eng.mvdr_weights(Rd, wd), n=3, warm=1)
+    out["mvdr_solve_c3"] = {"ms": t * 1e3, "bins": K, "N": N, "GFLOPs": (32.0 / 3) * K * N ** 3 / t / 1e9}
+    # ---- C4-style WPE: 8 mics, 512 bins, lags 0..32, one stream of 1000 frames
+    C, M, T = 8, 512, 1000
+    K = M // 2 + 1
+    Xw = (torch.randn((1, K, C, T), device=dev) + 1j * torch.randn((1, K, C, T), device=dev)).to(torch.complex64) * 500
+    t0 = time.perf_counter()
+    G = eng.wpe_estimate(Xw, M, 0, 32, 2, -18.0, 0.0, 1e-4)
+    torch.cuda.synchronize()
+    t = time.perf_counter() - t0
+    P = C * 33
+    out["wpe_estimate_c4"] = {"ms": t * 1e3, "iterations": 2, "P": P, "herk_TFLOPs": 2 * 8.0 * K * C * T * P * P / 2 / t / 1e12}
+    t = timeit(torch, lambda: eng.wpe_apply(Xw, G, M, 0, 32), n=3, warm=1)
+    out["wpe_apply_c4"] = {"ms": t * 1e3, "frames_per_s": T / t}
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,62 @@
+"""Multi-GPU sharding of the hot path: one process per GPU, torch.distributed (backend "nccl" == RCCL
+over xGMI on ROCm, "gloo" in CPU tests).
+
+The path shards two ways:
+  * by utterance STREAM -- streams are independent graphs (unit_test/test_online_beamforming.py:80-88
+    builds one per utterance): stream s runs on rank s mod G, no data-path collective at all;
+  * by frequency BIN -- every stage between the analysis FFT and the synthesis FFT is independent per
+    bin (`for fbinX` loops, beamformer.cc:1298, postfilter.cc:184, pybeamformer.py:674): rank g owns a
+    contiguous bin range, and ONE all-gather of the beamformed block Y[K_g][T] precedes synthesis.
+"""
+import numpy as np
+
+
+def streams_for_rank(num_streams, rank, world):
+    """Indices of the utterance streams rank `rank` processes (round-robin: s mod world == rank)."""
+    return list(range(rank, num_streams, world))
+
+
+def bin_range_for_rank(K, rank, world):
+    """Contiguous bin range [k0, k1) of rank `rank`: ceil(K/world) bins per rank, last ranks may be short/empty."""
+    per = -(-K // world)
+    k0 = min(rank * per, K)
+    return k0, min(k0 + per, K)
+
+
+def allgather_bins(Y_local, K, group=None):
+    """All-gather the beamformed block before synthesis.  Y_local complex [S][K_g][T] on this rank
+    (K_g = its bin range, possibly shorter on the last ranks) -> Y complex [S][K][T] on every rank.
+    One collective per block; payload 8*K*T*S bytes in total (33.6 MB at C5 with T=4096), i.e. a few
+    MB per xGMI link -- the reason a plain ring all-gather is enough here."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    per = -(-K // world)
+    S, Kg, T = Y_local.shape
+    k0, k1 = bin_range_for_rank(K, rank, world)
+    assert Kg == k1 - k0, "local block does not match this rank's bin range"
+    pad = torch.zeros((S, per, T), dtype=Y_local.dtype, device=Y_local.device)
+    pad[:, :Kg] = Y_local
+    buf = torch.view_as_real(pad).contiguous()
+    out = [torch.empty_like(buf) for _ in range(world)]
+    dist.all_gather(out, buf, group=group)
+    full = torch.cat([torch.view_as_complex(o) for o in out], dim=1)[:, :K]
+    return full.contiguous()
+
+
+def max_over_ranks(value, device, group=None):
+    """MAX-reduce a host scalar (step time) over ranks."""
+    import torch
+    import torch.distributed as dist
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    return float(t.item())
+
+
+def bf_apply_bin_sharded(W_local, X_local, K, group=None):
+    """Beamform this rank's bin range on its GPU and all-gather the result.
+    W_local complex64 [K_g][N], X_local complex64 [S][K_g][N][T] -> Y complex64 [S][K][T]."""
+    from . import engine
+    Y_local = engine.bf_apply(W_local, X_local)
+    return allgather_bins(Y_local, K, group)
