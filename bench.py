@@ -73,6 +73,8 @@ def main():
     ap.add_argument("--frames", type=int, default=4096, help="frames per stream per step")
     ap.add_argument("--cpu-frames", type=int, default=6000)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--staged", action="store_true",
+                    help="time the staged chain (analysis -> HBM snapshots -> apply) instead of the fused kernel")
     args = ap.parse_args()
 
     import torch
@@ -117,13 +119,18 @@ def main():
     out = torch.empty((S, nblk * D), dtype=torch.float32, device=dev)
 
     ev = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(args.steps)]
+    fused = not args.staged
 
     def step(e=None):
         if e: e[0].record()
-        afb.analysis(pcm, out=X)
-        if e: e[1].record()
-        eng.bf_apply(W, X, out=Y)
-        if e: e[2].record()
+        if fused:
+            afb.analysis_beamform(pcm, W, out=Y)          # analysis + SubbandGSC apply, snapshots stay on chip
+            if e: e[1].record(); e[2].record()
+        else:
+            afb.analysis(pcm, out=X)
+            if e: e[1].record()
+            eng.bf_apply(W, X, out=Y)
+            if e: e[2].record()
         sfb.synthesize(Y, out=out)
         if e: e[3].record()
 
@@ -143,32 +150,59 @@ def main():
         from distant_speech_recognition_amd import sharding
         elapsed = sharding.max_over_ranks(elapsed, dev)
 
-    t_ana = np.mean([e[0].elapsed_time(e[1]) for e in ev]) * 1e-3
-    t_bf = np.mean([e[1].elapsed_time(e[2]) for e in ev]) * 1e-3
+    t_a = np.mean([e[0].elapsed_time(e[1]) for e in ev]) * 1e-3          # fused: analysis+apply kernel
+    t_b = np.mean([e[1].elapsed_time(e[2]) for e in ev]) * 1e-3
     t_syn = np.mean([e[2].elapsed_time(e[3]) for e in ev]) * 1e-3
+
+    # per-stage reference measurements of the staged kernels (outside the timed region)
+    def _time(fn, n=3):
+        fn(); torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(n): fn()
+        b.record(); torch.cuda.synchronize()
+        return a.elapsed_time(b) * 1e-3 / n
+    if fused:
+        t_ana = _time(lambda: afb.analysis(pcm, out=X))
+        t_bf = _time(lambda: eng.bf_apply(W, X, out=Y))
+    else:
+        t_ana, t_bf = t_a, t_b
 
     if rank == 0:
         frames_per_step = S * T * world
         value = frames_per_step * args.steps / elapsed
-        b_ana = (4 * D + 8 * K) * N * S * T            # algorithmic bytes per analysis launch
-        b_bf = 8 * K * (N + 1) * S * T
+        b_ana = (4 * D + 8 * K) * N * S * T            # algorithmic bytes: analysis, per launch
+        b_bf = 8 * K * (N + 1) * S * T                 # beamformer apply
         b_syn = (8 * K + 4 * D) * S * T
+        b_fused_hbm = (4 * D * N + 8 * K) * S * T      # what the fused kernel actually has to move
+        if fused:
+            roof = {"bound": "hbm", "kernel": "analysis512_bf_kernel (fused analysis bank + SubbandGSC apply)",
+                    "achieved": (b_ana + b_bf) / t_a / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                    "frac": (b_ana + b_bf) / t_a / HBM_PEAK, "traffic": None,
+                    "bytes_per_launch": b_ana + b_bf, "avg_launch_ms": t_a * 1e3,
+                    "note": "algorithmic bytes = SURVEY 8(d) staged figures N(4D+8K)+8K(N+1) per frame; the fused kernel keeps "
+                            "the N x K snapshots on chip, so the HBM traffic it needs is 4DN+8K per frame = %.2f GB per launch "
+                            "(%.0f GB/s actual) and it is bounded by LDS/VALU work, not by HBM; see stages.analysis for the "
+                            "staged analysis kernel against the HBM roofline" % (b_fused_hbm / 1e9, b_fused_hbm / t_a / 1e9)}
+        else:
+            roof = {"bound": "hbm", "kernel": "analysis512_kernel", "achieved": b_ana / t_ana / 1e9, "peak": HBM_PEAK / 1e9,
+                    "unit": "GB/s", "frac": b_ana / t_ana / HBM_PEAK, "traffic": None,
+                    "traffic_note": "rocprofv3 PMC, same kernel, 8 streams x 2048 frames (profiles/r01_pmc_c0_analysis512.txt): "
+                                    "2*FETCH_SIZE + WRITE_SIZE = 3.23 GB = 1.00 x algorithmic bytes of that launch",
+                    "bytes_per_launch": b_ana, "avg_launch_ms": t_ana * 1e3}
         res = {
             "metric": "beamformed subband frames/sec, 64-mic 512-bin SubbandGSC",
             "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "complex64 (f32)", "data": "synthetic",
             "xRT": value / (FS / D),
-            "config": {"workload": "C0: %d-mic %d-bin SubbandGSC, analysis->GSC apply->synthesis, m=4 r=1 (D=%d), "
-                                   "%d streams/GPU x %d frames/step" % (N, M, D, S, T),
+            "config": {"workload": "C0: %d-mic %d-bin SubbandGSC, analysis->GSC apply->synthesis (%s), m=4 r=1 (D=%d), "
+                                   "%d streams/GPU x %d frames/step" % (N, M, "fused analysis+apply" if fused else "staged", D, S, T),
                        "streams_per_gpu": S, "frames_per_stream": T, "parallelism": "stream-sharded x%d" % world},
-            "roofline": {"bound": "hbm", "kernel": "analysis_kernel", "achieved": b_ana / t_ana / 1e9, "peak": HBM_PEAK / 1e9,
-                         "unit": "GB/s", "frac": b_ana / t_ana / HBM_PEAK, "traffic": None,
-                         "traffic_note": "rocprofv3 PMC on the same kernel, 8 streams x 2048 frames "
-                                         "(profiles/r01_pmc_c0_analysis512.txt): 2*FETCH_SIZE + WRITE_SIZE = 3.23 GB "
-                                         "= 1.00 x algorithmic bytes of that launch",
-                         "bytes_per_launch": b_ana, "avg_launch_ms": t_ana * 1e3},
+            "roofline": roof,
             "stages": {
+                "fused_analysis_apply": ({"ms": t_a * 1e3, "frames_per_s": S * T / t_a,
+                                          "hbm_GBps_actual": b_fused_hbm / t_a / 1e9} if fused else None),
                 "analysis": {"ms": t_ana * 1e3, "GBps": b_ana / t_ana / 1e9, "frac": b_ana / t_ana / HBM_PEAK},
                 "gsc_apply": {"ms": t_bf * 1e3, "GBps": b_bf / t_bf / 1e9, "frac": b_bf / t_bf / HBM_PEAK,
                               "frames_per_s": S * T / t_bf},

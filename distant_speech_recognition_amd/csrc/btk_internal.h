@@ -29,3 +29,5 @@ static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream
 // fb_analysis512.hip: specialised analysis kernel (M=512, m=4); returns 1 handled / 0 not covered / <0 error
 int btk_analysis512_try(const btk_fb* fb, const float* pcm, long nsamples, long pcm_stride, int S, int N, void* X,
                         long T_stride, long t0, long tcount, hipStream_t st);
+int btk_analysis512_bf_try(const btk_fb* fb, const float* pcm, long nsamples, long pcm_stride, int S, int N, const void* W,
+                           int per_stream, void* Wt_scratch, void* Y, long T_stride, long t0, long tcount, hipStream_t st);

@@ -246,6 +246,225 @@ int launch512(const btk_fb* fb, const float* pcm, long nsamples, long pcm_stride
   return BTK_OK;
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Fused analysis -> fixed-weight beamformer (SubbandDS/GSC/MVDR::next over OverSampledDFTAnalysisBank
+// channels, reference beamformer.cc:1267-1311 + modulated.cc:375-409) for static weights.
+// One workgroup = one (stream, 16-frame tile); it walks over the N channels, computes each channel's
+// spectrum exactly as analysis512_kernel does and accumulates y_k[t] += conj(w_k[n]) X_n[k][t] in
+// registers.  The N x K snapshot block never goes to HBM: traffic drops from N(4D+8K)+8K(N+1) to
+// 4 D N + 8 K bytes per frame.  Wt is the weight matrix transposed to [Sw][N][K] (one contiguous
+// column of 257 weights per channel).
+template <int R>
+__global__ __launch_bounds__(A_NT, 2)
+void analysis512_bf_kernel(const float* __restrict__ pcm, long nsamples, long pcm_stride,
+                           const float* __restrict__ proto, const float2* __restrict__ twg,
+                           int laN, float gain, int N, int K, const float2* __restrict__ Wt, long w_stream_stride,
+                           float2* __restrict__ Y, long T_stride, long t0, long tcount, int ntiles, int tiles_per_xcd, int S)
+{
+  constexpr int D = A_M / R;
+  constexpr int SPAN = (A_TT - 1) * D + A_MT * A_M;
+  constexpr int FB_BYTES = A_TT * FRS * 8;
+  constexpr int REG_U = (SPAN * 4 > FB_BYTES) ? SPAN * 4 : FB_BYTES;
+  constexpr int NV4 = (SPAN / 4 + A_NT - 1) / A_NT;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* xs = reinterpret_cast<float*>(smem);
+  float2* fbuf = reinterpret_cast<float2*>(smem);
+  float2* tw = reinterpret_cast<float2*>(smem + REG_U);                       // [257]
+  float2* twj = tw + (A_NF + 1);                                              // [256]
+  float2* wcol = twj + 256;                                                   // [257] weights of the current channel
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // XCD-aware mapping: each XCD owns a contiguous range of tiles of every stream, so neighbouring tiles
+  // (which share m M - D samples of PCM per channel) hit the same L2
+  const int b = blockIdx.x;
+  const int xcd = b & 7, j0 = b >> 3;
+  const int s = j0 / tiles_per_xcd;
+  const int tile = xcd * tiles_per_xcd + j0 % tiles_per_xcd;
+  if (s >= S || tile >= ntiles) return;
+  const long tt0 = (long)tile * A_TT;
+
+  for (int j = tid; j <= A_NF; j += A_NT) tw[j] = twg[j];
+  twj[tid] = twg[(2 * (tid & 15) * (tid >> 4)) & 511];
+
+  const bool vec_ok = ((pcm_stride & 3) == 0) && ((reinterpret_cast<uintptr_t>(pcm) & 15) == 0);
+  const long g0 = (t0 + tt0 + laN + 1) * (long)D - (long)A_MT * A_M;
+  const bool inb = vec_ok && g0 >= 0 && g0 + SPAN <= nsamples;
+  const float2* wts = Wt + (long)s * w_stream_stride;
+  float4 pre[NV4];
+  float2 wpre0, wpre1;
+  auto fetch = [&](int n) {
+    const float* src = pcm + ((long)s * N + n) * pcm_stride;
+    if (inb) {
+#pragma unroll
+      for (int q = 0; q < NV4; q++) {
+        const int l = (tid + q * A_NT) * 4;
+        if (l < SPAN) pre[q] = *reinterpret_cast<const float4*>(src + g0 + l);
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < NV4; q++) {
+        const int l = (tid + q * A_NT) * 4;
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+          const long g = g0 + l + e;
+          v[e] = (l + e < SPAN && g >= 0 && g < nsamples) ? src[g] : 0.0f;
+        }
+        pre[q] = make_float4(v[0], v[1], v[2], v[3]);
+      }
+    }
+    wpre0 = wts[(long)n * K + tid];
+    wpre1 = (tid == 0) ? wts[(long)n * K + A_NF] : make_float2(0.f, 0.f);
+  };
+
+  float2 h[A_MT];
+#pragma unroll
+  for (int k = 0; k < A_MT; k++) h[k] = *reinterpret_cast<const float2*>(proto + 2 * tid + A_M * k);
+  const float hg = 0.5f * gain;
+  float2 acc[16];
+#pragma unroll
+  for (int it = 0; it < 16; it++) acc[it] = make_float2(0.f, 0.f);
+  float2 acc256 = make_float2(0.f, 0.f);
+
+  fetch(0);
+  for (int n = 0; n < N; n++) {
+    // ---- phase 1: registers -> LDS (PCM span + weight column), then prefetch the next channel
+#pragma unroll
+    for (int q = 0; q < NV4; q++) {
+      const int l = (tid + q * A_NT) * 4;
+      if (l < SPAN) *reinterpret_cast<float4*>(xs + l) = pre[q];
+    }
+    wcol[tid] = wpre0;
+    if (tid == 0) wcol[A_NF] = wpre1;
+    __syncthreads();
+
+    // ---- phase 2: polyphase (sliding register window), frames overwrite the span after the barrier
+    {
+      constexpr int NW = A_TT + (A_MT - 1) * R;
+      float2 win[NW];
+      const float* wbase = xs + (A_M - 2 - 2 * tid);
+#pragma unroll
+      for (int i = 0; i < NW; i++) win[i] = *reinterpret_cast<const float2*>(wbase + i * D);
+      __syncthreads();
+      const int zoff = (tid >> 4) * 17 + (tid & 15);
+#pragma unroll
+      for (int f = 0; f < A_TT; f++) {
+        float p0 = 0.f, p1 = 0.f;
+#pragma unroll
+        for (int k = 0; k < A_MT; k++) {
+          const float2 x = win[f + R * (A_MT - 1 - k)];
+          p0 = fmaf(h[k].x, x.y, p0);
+          p1 = fmaf(h[k].y, x.x, p1);
+        }
+        fbuf[f * FRS + zoff] = make_float2(p0, p1);
+      }
+    }
+    __syncthreads();
+    if (n + 1 < N) fetch(n + 1);          // issued once the window registers are dead; lands under phases 3-4
+
+    // ---- phase 3: wave-private 256-point FFT of 4 frames
+    {
+      const int fl = lane >> 4, j = lane & 15;
+      float2* fb = fbuf + (wave * 4 + fl) * FRS;
+      float2 v[16];
+#pragma unroll
+      for (int r = 0; r < 16; r++) v[r] = fb[r * 17 + j];
+      dft16p(v);
+#pragma unroll
+      for (int k1 = 1; k1 < 16; k1++) v[k1] = cmulf(v[k1], twj[k1 * 16 + j]);
+#pragma unroll
+      for (int k1 = 0; k1 < 16; k1++) fb[j * 17 + k1] = v[k1];
+#pragma unroll
+      for (int jp = 0; jp < 16; jp++) v[jp] = fb[jp * 17 + j];
+      dft16p(v);
+#pragma unroll
+      for (int k2 = 0; k2 < 16; k2++) fb[k2 * 17 + j] = v[k2];
+    }
+    __syncthreads();
+
+    // ---- phase 4: Hermitian post-pass + beamformer accumulation  y += conj(w) X
+    {
+      const int f = tid & 15, kq = tid >> 4;
+      const float2* zf = fbuf + f * FRS;
+#pragma unroll
+      for (int it = 0; it < 16; it++) {
+        const int k = kq + 16 * it;
+        const int kp = (A_NF - k) & 255;
+        const float2 zk = zf[it * 17 + kq];
+        const float2 zq = zf[(kp >> 4) * 17 + (kp & 15)];
+        const float2 e = make_float2(hg * (zk.x + zq.x), hg * (zk.y - zq.y));
+        const float2 o = make_float2(hg * (zk.y + zq.y), -hg * (zk.x - zq.x));
+        const float2 w = tw[k];
+        const float xr = e.x + (w.x * o.x - w.y * o.y), xi = e.y + (w.x * o.y + w.y * o.x);
+        const float2 wn = wcol[k];
+        acc[it].x = fmaf(wn.x, xr, fmaf(wn.y, xi, acc[it].x));
+        acc[it].y = fmaf(wn.x, xi, fmaf(-wn.y, xr, acc[it].y));
+        if ((it & 3) == 3) __builtin_amdgcn_sched_barrier(0);          // keep the live set small: 4 bins at a time
+      }
+      if (tid < 16) {                                                  // k = 256: X = gain (Re Z0 - Im Z0), real
+        const float2 z0 = zf[0];
+        const float xr = gain * (z0.x - z0.y);
+        const float2 wn = wcol[A_NF];
+        acc256.x = fmaf(wn.x, xr, acc256.x);
+        acc256.y = fmaf(-wn.y, xr, acc256.y);
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---- store Y[s][k][tt0 .. tt0+15]
+  {
+    const int f = tid & 15, kq = tid >> 4;
+    if (tt0 + f < tcount) {
+      float2* yo = Y + ((long)s * K + kq) * T_stride + tt0 + f;
+#pragma unroll
+      for (int it = 0; it < 16; it++) yo[(long)(16 * it) * T_stride] = acc[it];
+      if (tid < 16) Y[((long)s * K + A_NF) * T_stride + tt0 + f] = acc256;
+    }
+  }
+}
+
+// W [Sw][K][N] -> Wt [Sw][N][K]
+__global__ void transpose_weights_kernel(const float2* __restrict__ W, float2* __restrict__ Wt, int K, int N, int Sw)
+{
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)Sw * K * N) return;
+  const int n = (int)(i % N);
+  const int k = (int)((i / N) % K);
+  const long s = i / ((long)N * K);
+  Wt[(s * N + n) * K + k] = W[i];
+}
+
+template <int R>
+int launch512_bf(const btk_fb* fb, const float* pcm, long nsamples, long pcm_stride, int S, int N, const float2* W,
+                 int per_stream, float2* Wt, float2* Y, long T_stride, long t0, long tcount, hipStream_t st)
+{
+  constexpr int D = A_M / R;
+  constexpr int SPAN = (A_TT - 1) * D + A_MT * A_M;
+  constexpr int FB_BYTES = A_TT * FRS * 8;
+  constexpr int REG_U = (SPAN * 4 > FB_BYTES) ? SPAN * 4 : FB_BYTES;
+  const size_t lds = REG_U + sizeof(float2) * (A_NF + 1 + 256 + A_NF + 1);
+  const int K = fb->K;
+  const int Sw = per_stream ? S : 1;
+  const long nw = (long)Sw * K * N;
+  hipLaunchKernelGGL(transpose_weights_kernel, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, st, W, Wt, K, N, Sw);
+  const int ntiles = (int)((tcount + A_TT - 1) / A_TT);
+  const int tiles_per_xcd = (ntiles + 7) / 8;
+  const long nblocks = (long)8 * tiles_per_xcd * S;
+  auto kern = analysis512_bf_kernel<R>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    BTK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
+  }
+  const float gain = fb->gain_factor > 0 ? (float)fb->gain_factor : 1.0f;
+  hipLaunchKernelGGL(kern, dim3((unsigned)nblocks), dim3(A_NT), lds, st, pcm, nsamples, pcm_stride, fb->d_proto, fb->d_tw,
+                     fb->laN, gain, N, K, Wt, per_stream ? (long)N * K : 0L, Y, T_stride, t0, tcount, ntiles, tiles_per_xcd, S);
+  BTK_HIP_CHECK(hipGetLastError());
+  return BTK_OK;
+}
+
 }  // namespace
 
 // returns 1 if handled, 0 if the geometry is not covered (caller falls back to the generic kernel), <0 on error
@@ -259,6 +478,24 @@ int btk_analysis512_try(const btk_fb* fb, const float* pcm, long nsamples, long 
     case 1: rc = launch512<1>(fb, pcm, nsamples, pcm_stride, S, N, Xp, T_stride, t0, tcount, st); break;
     case 2: rc = launch512<2>(fb, pcm, nsamples, pcm_stride, S, N, Xp, T_stride, t0, tcount, st); break;
     case 4: rc = launch512<4>(fb, pcm, nsamples, pcm_stride, S, N, Xp, T_stride, t0, tcount, st); break;
+    default: return 0;
+  }
+  return rc == BTK_OK ? 1 : rc;
+}
+
+// Fused analysis + fixed-weight beamformer; returns 1 if handled, 0 if the geometry is not covered, <0 on error
+int btk_analysis512_bf_try(const btk_fb* fb, const float* pcm, long nsamples, long pcm_stride, int S, int N, const void* W,
+                           int per_stream, void* Wt_scratch, void* Y, long T_stride, long t0, long tcount, hipStream_t st)
+{
+  if (fb->M != A_M || fb->m != A_MT) return 0;
+  const float2* Wp = static_cast<const float2*>(W);
+  float2* Wt = static_cast<float2*>(Wt_scratch);
+  float2* Yp = static_cast<float2*>(Y);
+  int rc;
+  switch (fb->R) {
+    case 1: rc = launch512_bf<1>(fb, pcm, nsamples, pcm_stride, S, N, Wp, per_stream, Wt, Yp, T_stride, t0, tcount, st); break;
+    case 2: rc = launch512_bf<2>(fb, pcm, nsamples, pcm_stride, S, N, Wp, per_stream, Wt, Yp, T_stride, t0, tcount, st); break;
+    case 4: rc = launch512_bf<4>(fb, pcm, nsamples, pcm_stride, S, N, Wp, per_stream, Wt, Yp, T_stride, t0, tcount, st); break;
     default: return 0;
   }
   return rc == BTK_OK ? 1 : rc;

@@ -374,4 +374,41 @@ int btk_fb_synthesis(const btk_fb_t* fb, const void* Y, long nframes, long T_str
   return btk_set_error(BTK_ERR_PARAMETER, "unsupported M=%d", fb->M);
 }
 
+// Fused OverSampledDFTAnalysisBank xN -> SubbandDS/GSC/MVDR::next for static weights.  Falls back to the staged
+// pair (btk_fb_analysis into `scratch` + btk_bf_apply) for geometries the fused kernel does not cover.
+int btk_fb_analysis_bf(const btk_fb_t* fb, const float* pcm, long nsamples, long pcm_stride, int S, int N,
+                       const void* W, int per_stream_weights, void* Y, long T_stride, long t0, long tcount,
+                       void* scratch, long scratch_bytes, void* stream)
+{
+  if (!fb || fb->synthesis) return btk_set_error(BTK_ERR_PARAMETER, "btk_fb_analysis_bf: not an analysis plan");
+  if (!pcm || !W || !Y || !scratch) return btk_set_error(BTK_ERR_PARAMETER, "btk_fb_analysis_bf: null argument");
+  if (S <= 0 || N <= 0 || tcount < 0 || T_stride < tcount || pcm_stride < nsamples)
+    return btk_set_error(BTK_ERR_DIMENSION, "btk_fb_analysis_bf: bad sizes S=%d N=%d tcount=%ld T_stride=%ld", S, N, tcount, T_stride);
+  if (tcount == 0) return BTK_OK;
+  const long wt_bytes = (long)sizeof(float2) * (per_stream_weights ? S : 1) * fb->K * N;
+  if (scratch_bytes < wt_bytes) return btk_set_error(BTK_ERR_PARAMETER, "btk_fb_analysis_bf: scratch too small (%ld < %ld)", scratch_bytes, wt_bytes);
+  hipStream_t st = as_stream(stream);
+  static const bool nofuse = getenv("BTK_DISABLE_FUSED") != nullptr;
+  if (!nofuse) {
+    const int rc = btk_analysis512_bf_try(fb, pcm, nsamples, pcm_stride, S, N, W, per_stream_weights, scratch, Y, T_stride, t0, tcount, st);
+    if (rc != 0) return rc > 0 ? BTK_OK : rc;
+  }
+  const long x_bytes = (long)sizeof(float2) * S * fb->K * N * tcount;
+  if (scratch_bytes < x_bytes)
+    return btk_set_error(BTK_ERR_PARAMETER, "btk_fb_analysis_bf: staged fall-back needs %ld bytes of scratch for the snapshots", x_bytes);
+  int rc = btk_fb_analysis(fb, pcm, nsamples, pcm_stride, S, N, scratch, tcount, t0, tcount, stream);
+  if (rc) return rc;
+  // staged layout has T_stride == tcount for X; Y keeps the caller's stride only when they agree
+  if (T_stride != tcount) return btk_set_error(BTK_ERR_PARAMETER, "btk_fb_analysis_bf: staged fall-back needs T_stride == tcount");
+  return btk_bf_apply(W, per_stream_weights, scratch, Y, S, fb->K, N, tcount, tcount, stream);
+}
+
+long btk_fb_analysis_bf_scratch_bytes(const btk_fb_t* fb, int S, int N, int per_stream_weights, long tcount)
+{
+  if (!fb) return -1;
+  const bool fused = fb->M == 512 && fb->m == 4 && (fb->R == 1 || fb->R == 2 || fb->R == 4) && getenv("BTK_DISABLE_FUSED") == nullptr;
+  if (fused) return (long)sizeof(float2) * (per_stream_weights ? S : 1) * fb->K * N;
+  return (long)sizeof(float2) * S * fb->K * N * tcount;
+}
+
 }  // extern "C"

@@ -89,6 +89,26 @@ class FilterBank:
         check(_lib.lib().btk_fb_analysis_polyphase(self._h, _ptr(pcm), nsamples, L, S, N, _ptr(P), t0, tcount, _stream()))
         return P
 
+    def analysis_beamform(self, pcm, W, nsamples=None, t0=0, tcount=None, out=None):
+        """Fused analysis -> fixed-weight beamformer: pcm [S][N][L], W complex64 [S|1][K][N] -> Y [S][K][T]
+        (the N x K snapshots are not written to HBM)."""
+        _need_cuda(pcm, "pcm"); _need_cuda(W, "W")
+        S, N, L = pcm.shape
+        nsamples = L if nsamples is None else nsamples
+        if tcount is None:
+            tcount = self.num_frames(nsamples) - t0
+        if W.dim() == 2:
+            W = W.unsqueeze(0)
+        per_stream = int(W.shape[0] == S and S > 1)
+        if out is None:
+            out = torch.empty((S, self.K, tcount), dtype=torch.complex64, device=pcm.device)
+        nb = _lib.lib().btk_fb_analysis_bf_scratch_bytes(self._h, S, N, per_stream, tcount)
+        if getattr(self, "_bf_scratch", None) is None or self._bf_scratch.numel() < nb:
+            self._bf_scratch = torch.empty(nb, dtype=torch.uint8, device=pcm.device)
+        check(_lib.lib().btk_fb_analysis_bf(self._h, _ptr(pcm), nsamples, L, S, N, _ptr(W), per_stream, _ptr(out), out.shape[2],
+                                            t0, tcount, _ptr(self._bf_scratch), self._bf_scratch.numel(), _stream()))
+        return out
+
     # ---- synthesis
     def num_blocks(self, nframes):
         return _lib.lib().btk_fb_synthesis_num_blocks(self._h, nframes)

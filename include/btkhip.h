@@ -87,6 +87,16 @@ int  btk_fb_synthesis(const btk_fb_t* fb, const void* Y, long nframes, long T_st
 int  btk_bf_apply(const void* W, int per_stream_weights, const void* X, void* Y,
                   int S, int K, int N, long T_stride, long T, void* stream);
 
+/* Fused OverSampledDFTAnalysisBank x N -> fixed-weight beamformer (the chain SubbandGSC::next pulls per frame,
+ * beamformer.cc:1267-1311): Y[s][k][t] = sum_n conj(W[k][n]) X_n[k][t] without materialising the snapshots in HBM
+ * (M = 512, m = 4 today; other geometries run btk_fb_analysis + btk_bf_apply through `scratch`).
+ * scratch [dev] of btk_fb_analysis_bf_scratch_bytes(...) bytes.  Use the staged calls when a post-filter, the
+ * adaptive canceller or covariance accumulation needs the snapshots.                                          */
+long btk_fb_analysis_bf_scratch_bytes(const btk_fb_t* fb, int S, int N, int per_stream_weights, long tcount);
+int  btk_fb_analysis_bf(const btk_fb_t* fb, const float* pcm, long nsamples, long pcm_stride, int S, int N,
+                        const void* W, int per_stream_weights, void* Y, long T_stride, long t0, long tcount,
+                        void* scratch, long scratch_bytes, void* stream);
+
 /* ---- Adaptive GSC canceller: leaky power-normalised NLMS ----------------------------------
  * Replaces SubbandGSCLMSBeamformer.__iter__ / reset_stats (lib/pybeamformer.py:659-762), Nc = 1.
  * params [host] 8 floats: beta, gamma(init), regularization_param, energy_floor, sil_thresh,

@@ -101,3 +101,25 @@ def test_full_chain_vs_oracle_c2(orc, dev):
     assert out.shape == ref.shape
     # synthesis PCM tolerance: <= 0.5 LSB at int16 scale
     assert np.max(np.abs(out - ref)) < 0.5
+
+
+@pytest.mark.parametrize("N,r,S,L", [(8, 1, 2, 40 * 256 + 31), (64, 1, 1, 20 * 256), (5, 0, 2, 9 * 512 + 100), (3, 2, 1, 70 * 128)])
+def test_fused_analysis_beamform_equals_staged(dev, N, r, S, L):
+    """btk_fb_analysis_bf (snapshots never written to HBM) == btk_fb_analysis + btk_bf_apply, incl. ragged tails,
+    per-stream weights and every supported decimation."""
+    import torch
+    from distant_speech_recognition_amd import engine as eng
+    M, m = 512, 4
+    rng = np.random.default_rng(N + r)
+    fb = eng.FilterBank(design_prototype(M, m), M, m, r, 2)
+    pcm, _ = synthetic_pcm(S, N, L, seed=N)
+    p = torch.from_numpy(pcm).to(dev)
+    K = M // 2 + 1
+    Wn = ((rng.normal(size=(S, K, N)) + 1j * rng.normal(size=(S, K, N))) / N).astype(np.complex64)
+    for W in (torch.from_numpy(Wn).to(dev), torch.from_numpy(Wn[0]).to(dev)):
+        X = fb.analysis(p)
+        ref = eng.bf_apply(W, X)
+        got = fb.analysis_beamform(p, W)
+        assert got.shape == ref.shape
+        scale = float(ref.abs().max())
+        assert float((got - ref).abs().max()) <= 2e-6 * np.sqrt(N) * scale + 1e-6 * scale
