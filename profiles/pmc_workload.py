@@ -20,5 +20,6 @@ for _ in range(2):
     afb.analysis(pcm, out=X)
     eng.bf_apply(W, X, out=Y)
     sfb.synthesize(Y)
+    afb.analysis_beamform(pcm, W, out=Y)
 torch.cuda.synchronize()
 print("pmc workload done: algorithmic bytes analysis=%d apply=%d" % ((4 * 256 + 8 * 257) * N * S * T, 8 * 257 * (N + 1) * S * T))
