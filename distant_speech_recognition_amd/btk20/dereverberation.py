@@ -7,7 +7,8 @@ from .common import jallocation_error, jindex_error, jinitialization_error, jnum
 from .modulated import OverSampledDFTAnalysisBankPtr, _mirror, _pull_all
 from .stream import VectorComplexFeatureStream, _BlockServedStream, device
 
-__all__ = ["MultiChannelWPEDereverberationPtr", "MultiChannelWPEDereverberationFeaturePtr"]
+__all__ = ["MultiChannelWPEDereverberationPtr", "MultiChannelWPEDereverberationFeaturePtr",
+           "SingleChannelWPEDereverberationFeaturePtr"]
 
 
 class MultiChannelWPEDereverberationPtr(object):
@@ -116,4 +117,37 @@ class MultiChannelWPEDereverberationFeaturePtr(_BlockServedStream, VectorComplex
 
     def reset(self):
         self._source.reset()
+        _BlockServedStream.reset(self)
+
+
+class SingleChannelWPEDereverberationFeaturePtr(_BlockServedStream, VectorComplexFeatureStream):
+    """SingleChannelWPEDereverberationFeature (dereverberation/dereverberation.cc:40-307,
+    dereverberation.i:73-81): the C = 1 case of the same estimator, without a diagonal bias."""
+
+    def __init__(self, samples, lower_num, upper_num, iterations_num=2, load_db=-20.0, band_width=0.0,
+                 samplerate=16000.0, nm="SingleChannelWPEDereverberationFeature"):
+        _BlockServedStream.__init__(self, samples.size(), nm)
+        self._core = MultiChannelWPEDereverberationPtr(samples.size(), 1, lower_num, upper_num, iterations_num, load_db,
+                                                       band_width, 0.0, samplerate)
+        self._core.set_input(samples)
+
+    def estimate_filter(self, start_frame_no=0, frame_num=-1):
+        end = -1 if frame_num < 0 else start_frame_no + frame_num
+        return self._core.estimate_filter(start_frame_no, end)
+
+    def print_objective_func(self, subband_no):
+        pass
+
+    def next_speaker(self):
+        self._core.next_speaker()
+        _BlockServedStream.reset(self)
+
+    nextSpeaker = next_speaker
+
+    def _prepare(self):
+        out = self._core.device_output()
+        self._frames = _mirror(out[0, :, 0, :].cpu().numpy(), self._size)
+
+    def reset(self):
+        self._core.reset()
         _BlockServedStream.reset(self)

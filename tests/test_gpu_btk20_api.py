@@ -223,3 +223,20 @@ def test_wpe_chain_flow(orc, dev, proto256, kinect_pcm, wavs):
     wq = orc.calc_mainlobe(M, 2, FS, delays)
     ref = orc.synthesis(g, M, m, r, 2, orc.gsc_frames(Yd, wq, None))
     assert out.shape == ref.shape and np.max(np.abs(out - ref)) < 1e-3 * np.max(np.abs(ref)) + 0.5
+
+
+def test_single_channel_wpe_flow(orc, dev, proto256, kinect_pcm, wavs):
+    """unit_test/test_subband_dereverberator.py single-channel branch: estimate on the utterance, re-read, dereverberate."""
+    from distant_speech_recognition_amd.btk20 import SingleChannelWPEDereverberationFeaturePtr, OverSampledDFTSynthesisBankPtr
+    h, g = proto256
+    sample_feats, afbs = _build(wavs[:1], h)
+    dereverb = SingleChannelWPEDereverberationFeaturePtr(afbs[0], lower_num=1, upper_num=12, iterations_num=2, load_db=-18.0,
+                                                        band_width=0.0, samplerate=FS)
+    assert dereverb.estimate_filter() == 317
+    sample_feats[0].read(wavs[0], FS)
+    sfb = OverSampledDFTSynthesisBankPtr(dereverb, prototype=g, M=M, m=m, r=r, delay_compensation_type=2)
+    out = np.concatenate([np.array(b) for b in sfb])
+    X = _oracle_X(orc, h, kinect_pcm)[:, :1]
+    G = orc.wpe_estimate(X, 1, 12, 2, -18.0, 0.0, 0.0)
+    ref = orc.synthesis(g, M, m, r, 2, orc.wpe_apply(X, G, 1, 12)[:, 0])
+    assert out.shape == ref.shape and np.max(np.abs(out - ref)) < 1e-3 * np.max(np.abs(ref)) + 0.5
