@@ -21,6 +21,7 @@
 // blocking matrix never has to be read, and the kernel stays HBM-bound (8 K N bytes per frame).
 // wa is recovered on demand as wa^H = u conj(B) (host side, btk_nlms_u_to_wa).
 #include "btk_internal.h"
+#include <cstdlib>
 
 namespace {
 
@@ -221,6 +222,182 @@ void nlms_bin_kernel(const float2* __restrict__ X, const float2* __restrict__ VS
   }
 }
 
+// ---- v2: row-DPP reductions, several bins per wavefront, float4 tile loads --------------------------------
+template <int CTRL> __device__ __forceinline__ float dpp_f(float v)
+{
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+// sum over aligned groups of GROUP lanes, result in every lane of the group
+template <int GROUP> __device__ __forceinline__ float group_sum2(float v)
+{
+  v += dpp_f<0xB1>(v);                                  // quad_perm [1,0,3,2]
+  v += dpp_f<0x4E>(v);                                  // quad_perm [2,3,0,1]
+  if (GROUP >= 8) v += dpp_f<0x141>(v);                 // row_half_mirror
+  if (GROUP >= 16) v += dpp_f<0x140>(v);                // row_mirror
+  if (GROUP >= 32) v += __shfl_xor(v, 16, 64);
+  if (GROUP >= 64) v += __shfl_xor(v, 32, 64);
+  return v;
+}
+
+// GROUP lanes x CPL channels per lane cooperate on one bin; a wavefront carries 64/GROUP bins, so the
+// per-step scalar arithmetic of the recursion is shared by 64/GROUP bins and the reductions stay inside
+// DPP rows.  TBF frames per LDS tile (rows of TBF*8 bytes read as float4 pairs).  Requires even T_stride.
+template <int GROUP, int CPL, int TBF>
+__global__ __launch_bounds__(64)
+void nlms_bin2_kernel(const float2* __restrict__ X, const float2* __restrict__ VS, float2* __restrict__ Y,
+                      int K, int N, long T_stride, long T, const float* __restrict__ ctrl,
+                      const double* __restrict__ stream_state_before, NlmsParams p,
+                      float2* __restrict__ U, float* __restrict__ sigma2)
+{
+  constexpr int BPW = 64 / GROUP;
+  constexpr int NR = GROUP * CPL;
+  constexpr int LDWv = TBF + 1;
+  constexpr int LPR = TBF / 2;                          // lanes per row (float4 = 2 frames)
+  constexpr int RPP = 64 / LPR;                         // rows per wave-load
+  constexpr int NPASS = 64 * CPL / RPP;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float2* tile = reinterpret_cast<float2*>(smem);      // [64*CPL rows][LDWv]
+  const int lane = threadIdx.x;
+  const int s = blockIdx.y;
+  const int kb = blockIdx.x * BPW;
+  const int gl = lane % GROUP, gi = lane / GROUP;
+  const int k = kb + gi;
+  const bool kvalid = k < K;
+  const long isamp0 = (long)stream_state_before[4 * (long)s + 2];
+
+  float2 vs[CPL], u[CPL];
+  float vvp = 0.f;
+#pragma unroll
+  for (int c = 0; c < CPL; c++) {
+    const int n = gl + GROUP * c;
+    const bool ok = kvalid && n < N;
+    vs[c] = ok ? VS[(long)k * N + n] : make_float2(0.f, 0.f);
+    u[c] = ok ? U[((long)s * K + k) * N + n] : make_float2(0.f, 0.f);
+    vvp += vs[c].x * vs[c].x + vs[c].y * vs[c].y;
+  }
+  const float vv = group_sum2<GROUP>(vvp);
+  const float inv_vv = vv > 0.f ? 1.f / vv : 0.f;
+  float sig = kvalid ? sigma2[(long)s * K + k] : 1.f;
+
+  float4 pre[NPASS];
+  float creg = 0.f;
+  const int lrow = lane / LPR, lc4 = lane % LPR;
+  auto prefetch = [&](long t0) {
+    const long t = t0 + 2 * lc4;
+#pragma unroll
+    for (int q = 0; q < NPASS; q++) {
+      const int r = q * RPP + lrow;
+      const int bl = r / NR, n = r % NR;
+      const int kk = kb + bl;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (kk < K && n < N && t < T) {
+        const float2* src = X + (((long)s * K + kk) * N + n) * T_stride + t;
+        if (t + 1 < T) v = *reinterpret_cast<const float4*>(src);
+        else { const float2 a = src[0]; v = make_float4(a.x, a.y, 0.f, 0.f); }
+      }
+      pre[q] = v;
+    }
+    const long tc = t0 + (lane % TBF);
+    creg = tc < T ? ctrl[(long)s * T + tc] : 0.f;
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int q = 0; q < NPASS; q++) {
+      float2* d = tile + (q * RPP + lrow) * LDWv + 2 * lc4;
+      d[0] = make_float2(pre[q].x, pre[q].y);
+      d[1] = make_float2(pre[q].z, pre[q].w);
+    }
+  };
+
+  prefetch(0);
+  for (long t0 = 0; t0 < T; t0 += TBF) {
+    __syncthreads();
+    commit();
+    const float ctile = creg;
+    __syncthreads();
+    if (t0 + TBF < T) prefetch(t0 + TBF);
+    float2 yout = make_float2(0.f, 0.f);
+    const int nsteps = (T - t0) < TBF ? (int)(T - t0) : TBF;
+#pragma unroll
+    for (int tt = 0; tt < TBF; tt++) {
+      if (tt < nsteps) {
+        float2 x[CPL];
+        float ycr = 0.f, yci = 0.f, pr = 0.f, pi = 0.f, xx = 0.f, uu = 0.f;
+#pragma unroll
+        for (int c = 0; c < CPL; c++) {
+          x[c] = tile[(gi * NR + gl + GROUP * c) * LDWv + tt];
+          ycr = fmaf(vs[c].x, x[c].x, fmaf(vs[c].y, x[c].y, ycr));
+          yci = fmaf(vs[c].x, x[c].y, fmaf(-vs[c].y, x[c].x, yci));
+          pr = fmaf(u[c].x, x[c].x, fmaf(-u[c].y, x[c].y, pr));
+          pi = fmaf(u[c].x, x[c].y, fmaf(u[c].y, x[c].x, pi));
+          xx = fmaf(x[c].x, x[c].x, fmaf(x[c].y, x[c].y, xx));
+          uu = fmaf(u[c].x, u[c].x, fmaf(u[c].y, u[c].y, uu));
+        }
+        ycr = group_sum2<GROUP>(ycr); yci = group_sum2<GROUP>(yci);
+        pr = group_sum2<GROUP>(pr);   pi = group_sum2<GROUP>(pi);
+        xx = group_sum2<GROUP>(xx);   uu = group_sum2<GROUP>(uu);
+
+        const long isamp = isamp0 + t0 + tt;
+        float se = (isamp > 0) ? fmaf(sig, p.beta, (1.f - p.beta) * xx) : xx;
+        if (se < p.energy_floor) se = p.energy_floor;
+        const float gam = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ctile), tt));
+        float pnr = pr, pni = pi;
+        if (gam > 0.f) {
+          const float er = ycr - pr, ei = yci - pi;
+          const float a = gam / se;
+          const float c1 = p.reg > 0.f ? 1.f - a * p.reg : 1.f;
+          const float c2r = a * er, c2i = a * ei;
+          const float gg = xx - (ycr * ycr + yci * yci) * inv_vv;
+          const float nrm = c1 * c1 * uu + (c2r * c2r + c2i * c2i) * gg + 2.f * c1 * (c2r * pr + c2i * pi);
+          const float cK = nrm > p.max_wa_l2norm ? sqrtf(p.max_wa_l2norm / nrm) : 1.f;
+          const float sr = ycr * inv_vv, si = yci * inv_vv;
+#pragma unroll
+          for (int c = 0; c < CPL; c++) {
+            const float qr = x[c].x - (vs[c].x * sr - vs[c].y * si);
+            const float qi = x[c].y - (vs[c].x * si + vs[c].y * sr);
+            const float nr = c1 * u[c].x + (c2r * qr + c2i * qi);
+            const float ni = c1 * u[c].y + (c2i * qr - c2r * qi);
+            u[c] = make_float2(cK * nr, cK * ni);
+          }
+          sig = se;
+          pnr = cK * (c1 * pr + c2r * gg);
+          pni = cK * (c1 * pi + c2i * gg);
+        }
+        const bool active = isamp >= p.min_frames;
+        const float outr = active ? ycr - pnr : ycr, outi = active ? yci - pni : yci;
+        if (GROUP >= TBF) {
+          if (gl == tt) yout = make_float2(outr, outi);
+        } else {
+          if (gl == 0 && kvalid) Y[((long)s * K + k) * T_stride + t0 + tt] = make_float2(outr, outi);
+        }
+      }
+    }
+    if (GROUP >= TBF && kvalid && gl < nsteps)
+      Y[((long)s * K + k) * T_stride + t0 + gl] = yout;
+  }
+  if (kvalid) {
+#pragma unroll
+    for (int c = 0; c < CPL; c++) {
+      const int n = gl + GROUP * c;
+      if (n < N) U[((long)s * K + k) * N + n] = u[c];
+    }
+    if (gl == 0) sigma2[(long)s * K + k] = sig;
+  }
+}
+
+template <int GROUP, int CPL, int TBF>
+int launch_bin2(const float2* X, const float2* VS, float2* Y, int S, int K, int N, long T_stride, long T,
+                const float* ctrl, const double* state_before, NlmsParams p, float2* U, float* sigma2, hipStream_t st)
+{
+  constexpr int BPW = 64 / GROUP;
+  const size_t lds = sizeof(float2) * (size_t)64 * CPL * (TBF + 1);
+  dim3 grid((unsigned)((K + BPW - 1) / BPW), (unsigned)S);
+  hipLaunchKernelGGL((nlms_bin2_kernel<GROUP, CPL, TBF>), grid, dim3(64), lds, st, X, VS, Y, K, N, T_stride, T,
+                     ctrl, state_before, p, U, sigma2);
+  BTK_HIP_CHECK(hipGetLastError());
+  return BTK_OK;
+}
+
 template <int GROUP, int CPL>
 int launch_bin(const float2* X, const float2* VS, float2* Y, int S, int K, int N, long T_stride, long T,
                const float* ctrl, const double* state_before, NlmsParams p, float2* U, float* sigma2, hipStream_t st)
@@ -289,6 +466,21 @@ int btk_nlms_process(const float* params /* host, 8 floats */, const void* vs, c
   const float2* VS = static_cast<const float2*>(vs);
   float2* Yp = static_cast<float2*>(Y);
   float2* U = static_cast<float2*>(u_state);
+  static const bool v1 = getenv("BTK_NLMS_V1") != nullptr;                       // A/B switches (benchmarking only)
+  static const int alt = getenv("BTK_NLMS_ALT") ? atoi(getenv("BTK_NLMS_ALT")) : 0;
+  const bool vec_ok = (T_stride % 2 == 0) && ((reinterpret_cast<uintptr_t>(X) & 15) == 0);
+  if (vec_ok && !v1) {
+    if (N <= 8)        return launch_bin2<8, 1, 16>(Xp, VS, Yp, S, K, N, T_stride, T, ctrl, state_before, p, U, sigma2, st);
+    else if (N <= 16)  return launch_bin2<16, 1, 16>(Xp, VS, Yp, S, K, N, T_stride, T, ctrl, state_before, p, U, sigma2, st);
+    else if (N <= 32)  return launch_bin2<16, 2, 16>(Xp, VS, Yp, S, K, N, T_stride, T, ctrl, state_before, p, U, sigma2, st);
+    else if (N <= 64) {
+      if (alt == 1) return launch_bin2<32, 2, 16>(Xp, VS, Yp, S, K, N, T_stride, T, ctrl, state_before, p, U, sigma2, st);
+      if (alt == 2) return launch_bin2<8, 8, 8>(Xp, VS, Yp, S, K, N, T_stride, T, ctrl, state_before, p, U, sigma2, st);
+      return launch_bin2<16, 4, 8>(Xp, VS, Yp, S, K, N, T_stride, T, ctrl, state_before, p, U, sigma2, st);
+    }
+    else if (N <= 128) return launch_bin2<32, 4, 8>(Xp, VS, Yp, S, K, N, T_stride, T, ctrl, state_before, p, U, sigma2, st);
+    return launch_bin2<64, 4, 8>(Xp, VS, Yp, S, K, N, T_stride, T, ctrl, state_before, p, U, sigma2, st);
+  }
   if (N <= 8)        return launch_bin<8, 1>(Xp, VS, Yp, S, K, N, T_stride, T, ctrl, state_before, p, U, sigma2, st);
   else if (N <= 16)  return launch_bin<16, 1>(Xp, VS, Yp, S, K, N, T_stride, T, ctrl, state_before, p, U, sigma2, st);
   else if (N <= 32)  return launch_bin<32, 1>(Xp, VS, Yp, S, K, N, T_stride, T, ctrl, state_before, p, U, sigma2, st);
