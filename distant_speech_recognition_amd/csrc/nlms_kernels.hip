@@ -344,12 +344,12 @@ void nlms_bin2_kernel(const float2* __restrict__ X, const float2* __restrict__ V
         float pnr = pr, pni = pi;
         if (gam > 0.f) {
           const float er = ycr - pr, ei = yci - pi;
-          const float a = gam / se;
+          const float a = gam * __builtin_amdgcn_rcpf(se);            // 1-ulp reciprocal: tolerance is 1e-4
           const float c1 = p.reg > 0.f ? 1.f - a * p.reg : 1.f;
           const float c2r = a * er, c2i = a * ei;
           const float gg = xx - (ycr * ycr + yci * yci) * inv_vv;
           const float nrm = c1 * c1 * uu + (c2r * c2r + c2i * c2i) * gg + 2.f * c1 * (c2r * pr + c2i * pi);
-          const float cK = nrm > p.max_wa_l2norm ? sqrtf(p.max_wa_l2norm / nrm) : 1.f;
+          const float cK = nrm > p.max_wa_l2norm ? __builtin_amdgcn_sqrtf(p.max_wa_l2norm * __builtin_amdgcn_rcpf(nrm)) : 1.f;
           const float sr = ycr * inv_vv, si = yci * inv_vv;
 #pragma unroll
           for (int c = 0; c < CPL; c++) {
