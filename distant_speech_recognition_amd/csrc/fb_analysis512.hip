@@ -465,6 +465,170 @@ int launch512_bf(const btk_fb* fb, const float* pcm, long nsamples, long pcm_str
   return BTK_OK;
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Synthesis bank specialised for M = 512, m = 4 (reference modulated/modulated.cc:553-612).
+// One workgroup walks through S_RUN consecutive output blocks of one stream.  The real sequences
+// v_f = Re FFT_fwd(Y_f) live in a ring of 16 + m R - 1 frame buffers in LDS (the m R - 1 frames of
+// history are computed once per run, not once per tile); every iteration adds 16 frames:
+//   A. Hermitian pre-pass straight from Y[s][k][t] (128-byte runs of 16 frames per bin),
+//   B. wave-private 256-point FFT (two in-register radix-16 passes; forward sign through conjugation),
+//   C. polyphase + overlap-add with a register window: thread d reads each of the 16 + m R - 1 frames
+//      once at i = d and i = d + jD and produces 16 output samples; float32 running sum in the reference's order.
+constexpr int S_RUN = 128;
+
+template <int R>
+__global__ __launch_bounds__(A_NT, 2)
+void synthesis512_kernel(const float2* __restrict__ Y, long nframes, long T_stride, int K,
+                         const float* __restrict__ proto, const float2* __restrict__ twg,
+                         int pd, float gain, float* __restrict__ out, long out_stride, long b0, long bcount)
+{
+  constexpr int D = A_M / R;
+  constexpr int HALO = A_MT * R - 1;
+  constexpr int NRING = 16 + HALO + 1;
+  constexpr int DPT = (D + A_NT - 1) / A_NT;                  // output samples (d) per thread
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float2* ring = reinterpret_cast<float2*>(smem);             // [NRING][FRS]
+  float2* tw = ring + NRING * FRS;                            // [257]
+  float2* twj = tw + (A_NF + 1);                              // [256]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int s = blockIdx.y;
+  const long bt0 = b0 + (long)blockIdx.x * S_RUN;             // first block of this run
+  const long bend = (bt0 + S_RUN < b0 + bcount) ? bt0 + S_RUN : b0 + bcount;
+  const float2* Ys = Y + (long)s * K * T_stride;
+  float* os = out + (long)s * out_stride;
+
+  for (int j = tid; j <= A_NF; j += A_NT) tw[j] = twg[j];
+  twj[tid] = twg[(2 * (tid & 15) * (tid >> 4)) & 511];
+
+  // synthesis taps of this thread: g[M-1-(d+jD)+M k]
+  float gco[DPT][R][A_MT];
+#pragma unroll
+  for (int q = 0; q < DPT; q++) {
+    const int d = tid + q * A_NT;
+#pragma unroll
+    for (int j = 0; j < R; j++)
+#pragma unroll
+      for (int k = 0; k < A_MT; k++)
+        gco[q][j][k] = (d < D) ? proto[(A_M - 1 - (d + j * D)) + A_M * k] : 0.f;
+  }
+  __syncthreads();
+
+  const long f_lo = bt0 + pd - HALO;                          // oldest frame the run needs
+  // chunk c covers frames fc0 .. fc0+15; chunk -1 is the history (only its last HALO frames matter)
+  for (long fc0 = f_lo + HALO - 16; fc0 < bend + pd; fc0 += 16) {
+    // ---- A. Hermitian pre-pass: Zc[k] = (Y[k] + conj Y[256-k]) + j W^-k (Y[k] - conj Y[256-k])
+    {
+      const int fi = tid & 15, kq = tid >> 4;
+      const long f = fc0 + fi;
+      const bool fok = f >= f_lo && f >= 0 && f < nframes;
+      const int slot = (int)(((f - f_lo) % NRING + NRING) % NRING);
+      float2* zf = ring + slot * FRS;
+      if (f >= f_lo) {
+#pragma unroll 4
+        for (int it = 0; it < 16; it++) {
+          const int k = kq + 16 * it;
+          float2 z = make_float2(0.f, 0.f);
+          if (fok) {
+            float2 a = Ys[(long)k * T_stride + f];
+            float2 bq = Ys[(long)(A_NF - k) * T_stride + f];
+            if (k == 0) { a.y = 0.f; bq.y = 0.f; }               // imaginary parts of bins 0 and M/2 are ignored
+            const float2 sm = make_float2(a.x + bq.x, a.y - bq.y), df = make_float2(a.x - bq.x, a.y + bq.y);
+            const float2 w = tw[k];
+            const float2 t = make_float2(w.x * df.x + w.y * df.y, w.x * df.y - w.y * df.x);   // conj(W^k) * df
+            z = make_float2(sm.x - t.y, sm.y + t.x);
+          }
+          zf[it * 17 + kq] = z;
+        }
+      }
+    }
+    __syncthreads();
+    // ---- B. forward FFT of the 16 new frames (4 per wavefront): conj -> positive-exponent passes -> conj
+    {
+      const int fl = lane >> 4, j = lane & 15;
+      const long f = fc0 + wave * 4 + fl;
+      if (f >= f_lo) {
+        const int slot = (int)(((f - f_lo) % NRING + NRING) % NRING);
+        float2* fb = ring + slot * FRS;
+        float2 v[16];
+#pragma unroll
+        for (int r = 0; r < 16; r++) v[r] = cconjf(fb[r * 17 + j]);
+        dft16p(v);
+#pragma unroll
+        for (int k1 = 1; k1 < 16; k1++) v[k1] = cmulf(v[k1], twj[k1 * 16 + j]);
+#pragma unroll
+        for (int k1 = 0; k1 < 16; k1++) fb[j * 17 + k1] = v[k1];
+#pragma unroll
+        for (int jp = 0; jp < 16; jp++) v[jp] = fb[jp * 17 + j];
+        dft16p(v);
+#pragma unroll
+        for (int k2 = 0; k2 < 16; k2++) fb[k2 * 17 + j] = cconjf(v[k2]);     // z[n]: v[2n] = Re, v[2n+1] = Im
+      }
+    }
+    __syncthreads();
+    // ---- C. polyphase + overlap-add for the 16 blocks whose newest frame is in this chunk
+    if (fc0 >= f_lo + HALO) {
+#pragma unroll
+      for (int q = 0; q < DPT; q++) {
+        const int d = tid + q * A_NT;
+        if (d < D) {
+          // window: frames fc0-HALO .. fc0+15 at i = d + jD
+          float win[R][16 + HALO];
+#pragma unroll
+          for (int j = 0; j < R; j++) {
+            const int i = d + j * D;
+            const int zi = ((i >> 1) >> 4) * 17 + ((i >> 1) & 15);
+#pragma unroll
+            for (int wdx = 0; wdx < 16 + HALO; wdx++) {
+              const long f = fc0 - HALO + wdx;
+              const int slot = (int)((f - f_lo) % NRING);
+              const float2 zz = ring[slot * FRS + zi];
+              win[j][wdx] = (i & 1) ? zz.y : zz.x;
+            }
+          }
+#pragma unroll
+          for (int bb = 0; bb < 16; bb++) {
+            const long bglob = fc0 + bb - pd;
+            float acc = 0.f;
+#pragma unroll
+            for (int j = 0; j < R; j++) {
+              // s_{f-(R-1-j)}[d + jD] = sum_k g[...] v_{f-(R-1-j)-Rk}[d + jD];  window index of frame f' is f' - fc0 + HALO
+              float sv = 0.f;
+#pragma unroll
+              for (int k = 0; k < A_MT; k++)
+                sv = fmaf(gco[q][j][k], win[j][bb + HALO - (R - 1 - j) - R * k], sv);
+              if (bglob - (R - 1 - j) >= 0) acc += sv;       // gsi_ is still zero before block 0 (modulated.cc:574-578,600)
+            }
+            if (gain > 0.f) acc *= gain;
+            if (bglob >= bt0 && bglob < bend) os[(bglob - b0) * D + (D - 1 - d)] = acc;
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
+template <int R>
+int launch_syn512(const btk_fb* fb, const float2* Y, long nframes, long T_stride, int S, float* out, long out_stride,
+                  long b0, long bcount, hipStream_t st)
+{
+  constexpr int HALO = A_MT * R - 1;
+  constexpr int NRING = 16 + HALO + 1;
+  const size_t lds = sizeof(float2) * ((size_t)NRING * FRS + A_NF + 1 + 256);
+  auto kern = synthesis512_kernel<R>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    BTK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
+  }
+  const unsigned gx = (unsigned)((bcount + S_RUN - 1) / S_RUN);
+  hipLaunchKernelGGL(kern, dim3(gx, (unsigned)S), dim3(A_NT), lds, st, Y, nframes, T_stride, fb->K, fb->d_proto, fb->d_tw,
+                     fb->pd, (float)fb->gain_factor, out, out_stride, b0, bcount);
+  BTK_HIP_CHECK(hipGetLastError());
+  return BTK_OK;
+}
+
 }  // namespace
 
 // returns 1 if handled, 0 if the geometry is not covered (caller falls back to the generic kernel), <0 on error
@@ -496,6 +660,22 @@ int btk_analysis512_bf_try(const btk_fb* fb, const float* pcm, long nsamples, lo
     case 1: rc = launch512_bf<1>(fb, pcm, nsamples, pcm_stride, S, N, Wp, per_stream, Wt, Yp, T_stride, t0, tcount, st); break;
     case 2: rc = launch512_bf<2>(fb, pcm, nsamples, pcm_stride, S, N, Wp, per_stream, Wt, Yp, T_stride, t0, tcount, st); break;
     case 4: rc = launch512_bf<4>(fb, pcm, nsamples, pcm_stride, S, N, Wp, per_stream, Wt, Yp, T_stride, t0, tcount, st); break;
+    default: return 0;
+  }
+  return rc == BTK_OK ? 1 : rc;
+}
+
+// Specialised synthesis (M = 512, m = 4); returns 1 if handled, 0 if the geometry is not covered, <0 on error
+int btk_synthesis512_try(const btk_fb* fb, const void* Y, long nframes, long T_stride, int S, float* out, long out_stride,
+                         long b0, long bcount, hipStream_t st)
+{
+  if (fb->M != A_M || fb->m != A_MT) return 0;
+  const float2* Yp = static_cast<const float2*>(Y);
+  int rc;
+  switch (fb->R) {
+    case 1: rc = launch_syn512<1>(fb, Yp, nframes, T_stride, S, out, out_stride, b0, bcount, st); break;
+    case 2: rc = launch_syn512<2>(fb, Yp, nframes, T_stride, S, out, out_stride, b0, bcount, st); break;
+    case 4: rc = launch_syn512<4>(fb, Yp, nframes, T_stride, S, out, out_stride, b0, bcount, st); break;
     default: return 0;
   }
   return rc == BTK_OK ? 1 : rc;

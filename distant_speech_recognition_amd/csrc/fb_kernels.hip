@@ -363,6 +363,11 @@ int btk_fb_synthesis(const btk_fb_t* fb, const void* Y, long nframes, long T_str
   if (bcount == 0) return BTK_OK;
   hipStream_t st = as_stream(stream);
   const float2* Yp = static_cast<const float2*>(Y);
+  static const bool no512 = getenv("BTK_DISABLE_SYNTHESIS512") != nullptr;      // A/B switch for benchmarking
+  if (!no512) {
+    const int rc = btk_synthesis512_try(fb, Y, nframes, T_stride, S, out, out_stride, b0, bcount, st);
+    if (rc != 0) return rc > 0 ? BTK_OK : rc;
+  }
   switch (fb->M) {
     case 64:   return launch_synthesis<6>(fb, Yp, nframes, T_stride, S, out, out_stride, b0, bcount, st);
     case 128:  return launch_synthesis<7>(fb, Yp, nframes, T_stride, S, out, out_stride, b0, bcount, st);
