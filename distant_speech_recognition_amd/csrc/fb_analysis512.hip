@@ -322,10 +322,12 @@ void analysis512_bf_kernel(const float* __restrict__ pcm, long nsamples, long pc
 #pragma unroll
   for (int k = 0; k < A_MT; k++) h[k] = *reinterpret_cast<const float2*>(proto + 2 * tid + A_M * k);
   const float hg = 0.5f * gain;
-  float2 acc[16];
+  // thread (kq = tid>>4, f = tid&15) owns the bin pairs (k, 256-k), k = kq + 16 it, it < 8, of frame f;
+  // the pair shares Z[k], Z[256-k], E and W^k O.  Bin 128 (its own partner) goes to the kq == 0 threads.
+  float2 accA[8], accB[8];
 #pragma unroll
-  for (int it = 0; it < 16; it++) acc[it] = make_float2(0.f, 0.f);
-  float2 acc256 = make_float2(0.f, 0.f);
+  for (int it = 0; it < 8; it++) { accA[it] = make_float2(0.f, 0.f); accB[it] = make_float2(0.f, 0.f); }
+  float2 acc128 = make_float2(0.f, 0.f);
 
   fetch(0);
   for (int n = 0; n < N; n++) {
@@ -383,12 +385,13 @@ void analysis512_bf_kernel(const float* __restrict__ pcm, long nsamples, long pc
     }
     __syncthreads();
 
-    // ---- phase 4: Hermitian post-pass + beamformer accumulation  y += conj(w) X
+    // ---- phase 4: Hermitian post-pass + beamformer accumulation  y += conj(w) X, two bins per pass:
+    //      X[k] = E + W^k O,  X[256-k] = conj(E - W^k O)
     {
       const int f = tid & 15, kq = tid >> 4;
       const float2* zf = fbuf + f * FRS;
 #pragma unroll
-      for (int it = 0; it < 16; it++) {
+      for (int it = 0; it < 8; it++) {
         const int k = kq + 16 * it;
         const int kp = (A_NF - k) & 255;
         const float2 zk = zf[it * 17 + kq];
@@ -396,18 +399,24 @@ void analysis512_bf_kernel(const float* __restrict__ pcm, long nsamples, long pc
         const float2 e = make_float2(hg * (zk.x + zq.x), hg * (zk.y - zq.y));
         const float2 o = make_float2(hg * (zk.y + zq.y), -hg * (zk.x - zq.x));
         const float2 w = tw[k];
-        const float xr = e.x + (w.x * o.x - w.y * o.y), xi = e.y + (w.x * o.y + w.y * o.x);
-        const float2 wn = wcol[k];
-        acc[it].x = fmaf(wn.x, xr, fmaf(wn.y, xi, acc[it].x));
-        acc[it].y = fmaf(wn.x, xi, fmaf(-wn.y, xr, acc[it].y));
-        if ((it & 3) == 3) __builtin_amdgcn_sched_barrier(0);          // keep the live set small: 4 bins at a time
+        const float2 wo = make_float2(w.x * o.x - w.y * o.y, w.x * o.y + w.y * o.x);
+        const float xr = e.x + wo.x, xi = e.y + wo.y;                  // X[k]
+        const float yr = e.x - wo.x, yi = -(e.y - wo.y);               // X[256-k]
+        const float2 wa = wcol[k], wb = wcol[A_NF - k];
+        accA[it].x = fmaf(wa.x, xr, fmaf(wa.y, xi, accA[it].x));
+        accA[it].y = fmaf(wa.x, xi, fmaf(-wa.y, xr, accA[it].y));
+        accB[it].x = fmaf(wb.x, yr, fmaf(wb.y, yi, accB[it].x));
+        accB[it].y = fmaf(wb.x, yi, fmaf(-wb.y, yr, accB[it].y));
       }
-      if (tid < 16) {                                                  // k = 256: X = gain (Re Z0 - Im Z0), real
-        const float2 z0 = zf[0];
-        const float xr = gain * (z0.x - z0.y);
-        const float2 wn = wcol[A_NF];
-        acc256.x = fmaf(wn.x, xr, acc256.x);
-        acc256.y = fmaf(-wn.y, xr, acc256.y);
+      if (kq == 0) {                                                   // k = 128 pairs with itself
+        const float2 zk = zf[8 * 17];
+        const float2 e = make_float2(hg * (zk.x + zk.x), 0.f);
+        const float2 o = make_float2(hg * (zk.y + zk.y), 0.f);
+        const float2 w = tw[128];
+        const float xr = e.x + w.x * o.x, xi = w.y * o.x;
+        const float2 wn = wcol[128];
+        acc128.x = fmaf(wn.x, xr, fmaf(wn.y, xi, acc128.x));
+        acc128.y = fmaf(wn.x, xi, fmaf(-wn.y, xr, acc128.y));
       }
     }
     __syncthreads();
@@ -417,10 +426,14 @@ void analysis512_bf_kernel(const float* __restrict__ pcm, long nsamples, long pc
   {
     const int f = tid & 15, kq = tid >> 4;
     if (tt0 + f < tcount) {
-      float2* yo = Y + ((long)s * K + kq) * T_stride + tt0 + f;
+      float2* yo = Y + (long)s * K * T_stride + tt0 + f;
 #pragma unroll
-      for (int it = 0; it < 16; it++) yo[(long)(16 * it) * T_stride] = acc[it];
-      if (tid < 16) Y[((long)s * K + A_NF) * T_stride + tt0 + f] = acc256;
+      for (int it = 0; it < 8; it++) {
+        const int k = kq + 16 * it;
+        yo[(long)k * T_stride] = accA[it];
+        yo[(long)(A_NF - k) * T_stride] = accB[it];
+      }
+      if (kq == 0) yo[(long)128 * T_stride] = acc128;
     }
   }
 }
