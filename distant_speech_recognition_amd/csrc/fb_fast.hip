@@ -1,0 +1,353 @@
+// fb_fast.hip -- register-FFT filter-bank kernels for every power-of-two M in {256, 512, 1024, 2048}, m = 4.
+//
+// Generalisation of the schedule tuned in fb_analysis512.hip (reference modulated/modulated.cc:375-409,
+// 553-612): persistent tiles with register prefetch, sliding-window polyphase, the M/2-point complex FFT as
+// two in-register passes NF = P1 x P2 (P in {8,16,32}) with padded conflict-free LDS exchanges, wavefront-
+// private frames (no workgroup barrier inside the FFT), Hermitian pass fused into the store.
+//
+//   n = P2 r + j   (r < P1, j < P2)            kappa = k1 + P1 k2   (k1 < P1, k2 < P2)
+//   pass 1: lane j   : A[j][k1]  = sum_r z[P2 r + j] W_P1^{r k1};   A'[j][k1] = A[j][k1] W_NF^{j k1}
+//   pass 2: lane k1  : Z[k1 + P1 k2] = sum_j A'[j][k1] W_P2^{j k2}
+// LDS frame layout: input z[n] at r (P2+1) + j; A' and Z at j (P1+1) + k1 == (kappa / P1)(P1+1) + kappa % P1.
+#include "btk_internal.h"
+#include "fft_lds.h"
+#include <cstdlib>
+
+namespace {
+
+constexpr int F_NT = 256, F_MT = 4;
+
+__device__ __forceinline__ void f_dft4p(float2& a0, float2& a1, float2& a2, float2& a3)
+{
+  const float2 s02 = caddf(a0, a2), d02 = csubf(a0, a2);
+  const float2 s13 = caddf(a1, a3), d13 = cmul_i<+1>(csubf(a1, a3));
+  a0 = caddf(s02, s13); a1 = caddf(d02, d13); a2 = csubf(s02, s13); a3 = csubf(d02, d13);
+}
+
+// positive-exponent DFTs on register arrays: v[k] <- sum_r v[r] e^{+j 2 pi r k / P}
+__device__ __forceinline__ void f_dft8p(float2 (&v)[8])
+{
+  constexpr float H = 0.70710678118654752f;
+  float2 e0 = v[0], e1 = v[2], e2 = v[4], e3 = v[6];
+  float2 o0 = v[1], o1 = v[3], o2 = v[5], o3 = v[7];
+  f_dft4p(e0, e1, e2, e3);
+  f_dft4p(o0, o1, o2, o3);
+  o1 = cmulf(o1, make_float2(H, H));
+  o2 = cmul_i<+1>(o2);
+  o3 = cmulf(o3, make_float2(-H, H));
+  v[0] = caddf(e0, o0); v[4] = csubf(e0, o0);
+  v[1] = caddf(e1, o1); v[5] = csubf(e1, o1);
+  v[2] = caddf(e2, o2); v[6] = csubf(e2, o2);
+  v[3] = caddf(e3, o3); v[7] = csubf(e3, o3);
+}
+
+__device__ __forceinline__ void f_dft16p(float2 (&v)[16])
+{
+  constexpr float C1 = 0.92387953251128674f, S1 = 0.38268343236508977f, H = 0.70710678118654752f;
+  float2 t[4][4];
+#pragma unroll
+  for (int b = 0; b < 4; b++) {
+    float2 x0 = v[b], x1 = v[4 + b], x2 = v[8 + b], x3 = v[12 + b];
+    f_dft4p(x0, x1, x2, x3);
+    t[b][0] = x0; t[b][1] = x1; t[b][2] = x2; t[b][3] = x3;
+  }
+  t[1][1] = cmulf(t[1][1], make_float2(C1, S1));
+  t[1][2] = cmulf(t[1][2], make_float2(H, H));
+  t[1][3] = cmulf(t[1][3], make_float2(S1, C1));
+  t[2][1] = cmulf(t[2][1], make_float2(H, H));
+  t[2][2] = cmul_i<+1>(t[2][2]);
+  t[2][3] = cmulf(t[2][3], make_float2(-H, H));
+  t[3][1] = cmulf(t[3][1], make_float2(S1, C1));
+  t[3][2] = cmulf(t[3][2], make_float2(-H, H));
+  t[3][3] = cmulf(t[3][3], make_float2(-C1, -S1));
+#pragma unroll
+  for (int c = 0; c < 4; c++) {
+    float2 y0 = t[0][c], y1 = t[1][c], y2 = t[2][c], y3 = t[3][c];
+    f_dft4p(y0, y1, y2, y3);
+    v[c] = y0; v[c + 4] = y1; v[c + 8] = y2; v[c + 12] = y3;
+  }
+}
+
+__device__ __forceinline__ void f_dft32p(float2 (&v)[32])
+{
+  // r = 2a + b: two 16-point DFTs (even/odd), odd half times W32^c, radix-2 combine
+  constexpr float CW[16] = {1.0f, 0.98078528040323043f, 0.92387953251128674f, 0.83146961230254524f,
+                            0.70710678118654752f, 0.55557023301960218f, 0.38268343236508977f, 0.19509032201612825f,
+                            0.0f, -0.19509032201612825f, -0.38268343236508977f, -0.55557023301960218f,
+                            -0.70710678118654752f, -0.83146961230254524f, -0.92387953251128674f, -0.98078528040323043f};
+  constexpr float SW[16] = {0.0f, 0.19509032201612825f, 0.38268343236508977f, 0.55557023301960218f,
+                            0.70710678118654752f, 0.83146961230254524f, 0.92387953251128674f, 0.98078528040323043f,
+                            1.0f, 0.98078528040323043f, 0.92387953251128674f, 0.83146961230254524f,
+                            0.70710678118654752f, 0.55557023301960218f, 0.38268343236508977f, 0.19509032201612825f};
+  float2 e[16], o[16];
+#pragma unroll
+  for (int a = 0; a < 16; a++) { e[a] = v[2 * a]; o[a] = v[2 * a + 1]; }
+  f_dft16p(e);
+  f_dft16p(o);
+#pragma unroll
+  for (int c = 0; c < 16; c++) {
+    const float2 t = (c == 0) ? o[0] : cmulf(o[c], make_float2(CW[c], SW[c]));
+    v[c] = caddf(e[c], t);
+    v[c + 16] = csubf(e[c], t);
+  }
+}
+
+template <int P> __device__ __forceinline__ void f_dftp(float2 (&v)[P]);
+template <> __device__ __forceinline__ void f_dftp<8>(float2 (&v)[8]) { f_dft8p(v); }
+template <> __device__ __forceinline__ void f_dftp<16>(float2 (&v)[16]) { f_dft16p(v); }
+template <> __device__ __forceinline__ void f_dftp<32>(float2 (&v)[32]) { f_dft32p(v); }
+
+template <int LOG2M> struct FG {
+  static constexpr int M = 1 << LOG2M, NF = M / 2;
+  static constexpr int P1 = (LOG2M >= 10) ? 32 : 16;
+  static constexpr int P2 = NF / P1;                          // 8, 16, 16, 32
+  static constexpr int LOG2P1 = (LOG2M >= 10) ? 5 : 4;
+  static constexpr int FP1 = 64 / P2, FP2 = 64 / P1;          // frames per wave per pass round
+  static constexpr int FPW = FP1 > FP2 ? FP1 : FP2;           // frames per wave: 8, 4, 4, 2
+  static constexpr int TT = 4 * FPW;                          // frames per workgroup tile: 32, 16, 16, 8
+  static constexpr int LA = P2 + 1, LB = P1 + 1;
+  static constexpr int FRS0 = (P1 * LA > P2 * LB) ? P1 * LA : P2 * LB;
+  static constexpr int FRS = FRS0 | 1;                        // odd float2 stride: frames land on different banks
+  static constexpr int NSPLIT = NF < F_NT ? F_NT / NF : 1;    // frame groups when a tile has fewer pair indices than threads
+  static constexpr int NOWN = NF > F_NT ? NF / F_NT : 1;      // pair indices per thread
+  static constexpr int FPT = TT / NSPLIT;                     // frames per (thread, pair index)
+  static constexpr int KQ = F_NT / TT;                        // bin lanes in the store pass
+};
+
+// wave-private FFT of this wave's FPW frames (positive exponent); CONJ: forward transform through conjugation
+template <int LOG2M, bool CONJ>
+__device__ __forceinline__ void wave_fft(float2* __restrict__ frames /* this wave's first frame */, const float2* __restrict__ twj, int lane)
+{
+  using G = FG<LOG2M>;
+  constexpr int P1 = G::P1, P2 = G::P2, LA = G::LA, LB = G::LB, FRS = G::FRS;
+#pragma unroll
+  for (int rd = 0; rd < G::FPW / G::FP1; rd++) {               // pass 1: lane = (frame, j)
+    const int fl = lane / P2, j = lane % P2;
+    float2* fb = frames + (rd * G::FP1 + fl) * FRS;
+    float2 v[P1];
+#pragma unroll
+    for (int r = 0; r < P1; r++) { const float2 z = fb[r * LA + j]; v[r] = CONJ ? cconjf(z) : z; }
+    f_dftp<P1>(v);
+#pragma unroll
+    for (int k1 = 1; k1 < P1; k1++) v[k1] = cmulf(v[k1], twj[k1 * P2 + j]);
+#pragma unroll
+    for (int k1 = 0; k1 < P1; k1++) fb[j * LB + k1] = v[k1];
+  }
+#pragma unroll
+  for (int rd = 0; rd < G::FPW / G::FP2; rd++) {               // pass 2: lane = (frame, k1)
+    const int fl = lane / P1, k1 = lane % P1;
+    float2* fb = frames + (rd * G::FP2 + fl) * FRS;
+    float2 v[P2];
+#pragma unroll
+    for (int jp = 0; jp < P2; jp++) v[jp] = fb[jp * LB + k1];
+    f_dftp<P2>(v);
+#pragma unroll
+    for (int k2 = 0; k2 < P2; k2++) fb[k2 * LB + k1] = CONJ ? cconjf(v[k2]) : v[k2];
+  }
+}
+
+template <int LOG2M> __device__ __forceinline__ int zidx(int kappa)
+{
+  using G = FG<LOG2M>;
+  return (kappa >> G::LOG2P1) * G::LB + (kappa & (G::P1 - 1));
+}
+
+constexpr int F_RUN = 8;       // consecutive tiles a workgroup walks through
+
+// ------------------------------------------------------------------------------------------------ analysis
+template <int LOG2M, int R>
+__global__ __launch_bounds__(F_NT, 2)
+void fast_analysis_kernel(const float* __restrict__ pcm, long nsamples, long pcm_stride,
+                          const float* __restrict__ proto, const float2* __restrict__ twg,
+                          int laN, float gain, int N, int K, float2* __restrict__ X,
+                          long T_stride, long t0, long tcount, int ntiles, int nruns, int nchan)
+{
+  using G = FG<LOG2M>;
+  constexpr int M = G::M, NF = G::NF, TT = G::TT, FRS = G::FRS, P2 = G::P2, LA = G::LA;
+  constexpr int D = M / R;
+  constexpr int SPAN = (TT - 1) * D + F_MT * M;
+  constexpr int FB_BYTES = TT * FRS * 8;
+  constexpr int REG_U = ((SPAN * 4 > FB_BYTES) ? SPAN * 4 : FB_BYTES + 15) & ~15;
+  constexpr int NV4 = (SPAN / 4 + F_NT - 1) / F_NT;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* xs = reinterpret_cast<float*>(smem);
+  float2* fbuf = reinterpret_cast<float2*>(smem);
+  float2* twj = reinterpret_cast<float2*>(smem + REG_U);        // [P1][P2] W_NF^{j k1}
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.x;
+  const int xcd = b & 7, slot = b >> 3;
+  const int chan = (slot / nruns) * 8 + xcd;
+  const int run = slot % nruns;
+  if (chan >= nchan) return;
+  const int tile_first = run * F_RUN;
+  const int tile_end = (tile_first + F_RUN < ntiles) ? tile_first + F_RUN : ntiles;
+
+  for (int i = tid; i < NF; i += F_NT) twj[i] = twg[(2 * (i % P2) * (i / P2)) & (M - 1)];     // i = k1*P2 + j
+
+  const float* src = pcm + (long)chan * pcm_stride;
+  const bool vec_ok = ((pcm_stride & 3) == 0) && ((reinterpret_cast<uintptr_t>(pcm) & 15) == 0);
+  float4 pre[NV4];
+  auto fetch = [&](int tile) {
+    const long g0 = (t0 + (long)tile * TT + laN + 1) * (long)D - (long)F_MT * M;
+    if (vec_ok && g0 >= 0 && g0 + SPAN <= nsamples) {
+#pragma unroll
+      for (int q = 0; q < NV4; q++) {
+        const int l = (tid + q * F_NT) * 4;
+        if (l < SPAN) pre[q] = *reinterpret_cast<const float4*>(src + g0 + l);
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < NV4; q++) {
+        const int l = (tid + q * F_NT) * 4;
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+          const long g = g0 + l + e;
+          v[e] = (l + e < SPAN && g >= 0 && g < nsamples) ? src[g] : 0.0f;
+        }
+        pre[q] = make_float4(v[0], v[1], v[2], v[3]);
+      }
+    }
+  };
+
+  // pair indices owned by this thread and their taps
+  constexpr int NOWN = G::NOWN, FPT = G::FPT;
+  const int nbase = (NF >= F_NT) ? tid : (tid % NF);
+  const int f0 = (NF >= F_NT) ? 0 : (tid / NF) * FPT;
+  float2 h[NOWN][F_MT];
+#pragma unroll
+  for (int q = 0; q < NOWN; q++)
+#pragma unroll
+    for (int k = 0; k < F_MT; k++) h[q][k] = *reinterpret_cast<const float2*>(proto + 2 * (nbase + q * F_NT) + M * k);
+  const int s = chan / N, nch = chan % N;
+  const long kstride = (long)N * T_stride;
+  const float hg = 0.5f * gain;
+
+  fetch(tile_first);
+  for (int tile = tile_first; tile < tile_end; tile++) {
+    const long tt0 = (long)tile * TT;
+#pragma unroll
+    for (int q = 0; q < NV4; q++) {
+      const int l = (tid + q * F_NT) * 4;
+      if (l < SPAN) *reinterpret_cast<float4*>(xs + l) = pre[q];
+    }
+    __syncthreads();
+    if (tile + 1 < tile_end) fetch(tile + 1);
+
+    // ---- polyphase with register windows (all windows are pulled before the frames overwrite the span)
+    {
+      constexpr int NW = FPT + (F_MT - 1) * R;
+      float2 win[NOWN][NW];
+#pragma unroll
+      for (int q = 0; q < NOWN; q++) {
+        const float* wbase = xs + (M - 2 - 2 * (nbase + q * F_NT)) + f0 * D;
+#pragma unroll
+        for (int i = 0; i < NW; i++) win[q][i] = *reinterpret_cast<const float2*>(wbase + i * D);
+      }
+      __syncthreads();
+#pragma unroll
+      for (int q = 0; q < NOWN; q++) {
+        const int n = nbase + q * F_NT;
+        const int zoff = (n / P2) * LA + (n % P2);
+#pragma unroll
+        for (int f = 0; f < FPT; f++) {
+          float p0 = 0.f, p1 = 0.f;
+#pragma unroll
+          for (int k = 0; k < F_MT; k++) {
+            const float2 x = win[q][f + R * (F_MT - 1 - k)];
+            p0 = fmaf(h[q][k].x, x.y, p0);
+            p1 = fmaf(h[q][k].y, x.x, p1);
+          }
+          fbuf[(f0 + f) * FRS + zoff] = make_float2(p0, p1);
+        }
+      }
+    }
+    __syncthreads();
+
+    wave_fft<LOG2M, false>(fbuf + wave * G::FPW * FRS, twj, lane);
+    __syncthreads();
+
+    // ---- Hermitian post-pass fused into the store
+    {
+      constexpr int KQ = G::KQ;
+      const int f = tid % TT, kq = tid / TT;
+      const bool live = tt0 + f < tcount;
+      const float2* zf = fbuf + f * FRS;
+      float2* xo = X + ((long)s * K * N + nch) * T_stride + tt0 + f;
+#pragma unroll 4
+      for (int it = 0; it < NF / KQ; it++) {
+        const int k = kq + KQ * it;
+        const int kp = (NF - k) & (NF - 1);
+        const float2 zk = zf[zidx<LOG2M>(k)];
+        const float2 zq = zf[zidx<LOG2M>(kp)];
+        const float2 e = make_float2(hg * (zk.x + zq.x), hg * (zk.y - zq.y));
+        const float2 o = make_float2(hg * (zk.y + zq.y), -hg * (zk.x - zq.x));
+        const float2 w = twg[k];                                  // e^{+j 2 pi k / M}, L1-resident
+        if (live) xo[(long)k * kstride] = make_float2(e.x + (w.x * o.x - w.y * o.y), e.y + (w.x * o.y + w.y * o.x));
+      }
+      if (kq == 0 && live) {
+        const float2 z0 = zf[0];
+        xo[(long)NF * kstride] = make_float2(gain * (z0.x - z0.y), 0.f);
+      }
+    }
+    __syncthreads();
+  }
+}
+
+template <int LOG2M, int R>
+int launch_fast_analysis(const btk_fb* fb, const float* pcm, long nsamples, long pcm_stride, int S, int N, float2* X,
+                         long T_stride, long t0, long tcount, hipStream_t st)
+{
+  using G = FG<LOG2M>;
+  constexpr int D = G::M / R;
+  constexpr int SPAN = (G::TT - 1) * D + F_MT * G::M;
+  constexpr int FB_BYTES = G::TT * G::FRS * 8;
+  constexpr int REG_U = ((SPAN * 4 > FB_BYTES) ? SPAN * 4 : FB_BYTES + 15) & ~15;
+  const size_t lds = REG_U + sizeof(float2) * G::NF;
+  if (lds > 160 * 1024) return 0;
+  const int nchan = S * N;
+  const int ntiles = (int)((tcount + G::TT - 1) / G::TT);
+  const int nruns = (ntiles + F_RUN - 1) / F_RUN;
+  const long nblocks = (long)((nchan + 7) / 8) * nruns * 8;
+  auto kern = fast_analysis_kernel<LOG2M, R>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    BTK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
+  }
+  const float gain = fb->gain_factor > 0 ? (float)fb->gain_factor : 1.0f;
+  hipLaunchKernelGGL(kern, dim3((unsigned)nblocks), dim3(F_NT), lds, st, pcm, nsamples, pcm_stride, fb->d_proto, fb->d_tw,
+                     fb->laN, gain, N, fb->K, X, T_stride, t0, tcount, ntiles, nruns, nchan);
+  BTK_HIP_CHECK(hipGetLastError());
+  return 1;
+}
+
+template <int LOG2M>
+int fast_analysis_r(const btk_fb* fb, const float* pcm, long nsamples, long pcm_stride, int S, int N, float2* X,
+                    long T_stride, long t0, long tcount, hipStream_t st)
+{
+  switch (fb->R) {
+    case 1: return launch_fast_analysis<LOG2M, 1>(fb, pcm, nsamples, pcm_stride, S, N, X, T_stride, t0, tcount, st);
+    case 2: return launch_fast_analysis<LOG2M, 2>(fb, pcm, nsamples, pcm_stride, S, N, X, T_stride, t0, tcount, st);
+    case 4: return launch_fast_analysis<LOG2M, 4>(fb, pcm, nsamples, pcm_stride, S, N, X, T_stride, t0, tcount, st);
+  }
+  return 0;
+}
+
+}  // namespace
+
+// returns 1 handled / 0 geometry not covered / <0 error
+int btk_fast_analysis_try(const btk_fb* fb, const float* pcm, long nsamples, long pcm_stride, int S, int N, void* X,
+                          long T_stride, long t0, long tcount, hipStream_t st)
+{
+  if (fb->m != F_MT) return 0;
+  float2* Xp = static_cast<float2*>(X);
+  switch (fb->M) {
+    case 256:  return fast_analysis_r<8>(fb, pcm, nsamples, pcm_stride, S, N, Xp, T_stride, t0, tcount, st);
+    case 512:  return fast_analysis_r<9>(fb, pcm, nsamples, pcm_stride, S, N, Xp, T_stride, t0, tcount, st);
+    case 1024: return fast_analysis_r<10>(fb, pcm, nsamples, pcm_stride, S, N, Xp, T_stride, t0, tcount, st);
+    case 2048: return fast_analysis_r<11>(fb, pcm, nsamples, pcm_stride, S, N, Xp, T_stride, t0, tcount, st);
+  }
+  return 0;
+}

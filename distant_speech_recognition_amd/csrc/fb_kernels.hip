@@ -325,6 +325,11 @@ int btk_fb_analysis(const btk_fb_t* fb, const float* pcm, long nsamples, long pc
     const int rc = btk_analysis512_try(fb, pcm, nsamples, pcm_stride, S, N, X, T_stride, t0, tcount, st);
     if (rc != 0) return rc > 0 ? BTK_OK : rc;
   }
+  static const bool nofast = getenv("BTK_DISABLE_FAST") != nullptr;
+  if (!nofast) {
+    const int rc = btk_fast_analysis_try(fb, pcm, nsamples, pcm_stride, S, N, X, T_stride, t0, tcount, st);
+    if (rc != 0) return rc > 0 ? BTK_OK : rc;
+  }
   switch (fb->M) {
     case 64:   return launch_analysis<6>(fb, pcm, nsamples, pcm_stride, S, N, Xp, nullptr, T_stride, t0, tcount, st);
     case 128:  return launch_analysis<7>(fb, pcm, nsamples, pcm_stride, S, N, Xp, nullptr, T_stride, t0, tcount, st);
