@@ -335,6 +335,190 @@ int fast_analysis_r(const btk_fb* fb, const float* pcm, long nsamples, long pcm_
   return 0;
 }
 
+
+// ------------------------------------------------------------------------------------------------ synthesis
+// Same schedule as synthesis512_kernel (fb_analysis512.hip) for any M: a workgroup walks through F_SRUN output
+// blocks of one stream; the real sequences v_f live in a ring of TT + m R frame buffers; every iteration adds
+// TT frames (Hermitian pre-pass from Y, wave-private forward FFT through conjugation) and emits TT blocks
+// (register-window polyphase + overlap-add, float32 running sum in the reference's order).
+constexpr int F_SRUN = 128;
+
+template <int LOG2M, int R>
+__global__ __launch_bounds__(F_NT, 1)
+void fast_synthesis_kernel(const float2* __restrict__ Y, long nframes, long T_stride, int K,
+                           const float* __restrict__ proto, const float2* __restrict__ twg,
+                           int pd, float gain, float* __restrict__ out, long out_stride, long b0, long bcount)
+{
+  using G = FG<LOG2M>;
+  constexpr int M = G::M, NF = G::NF, TT = G::TT, FRS = G::FRS, P2 = G::P2, KQ = G::KQ;
+  constexpr int D = M / R;
+  constexpr int HALO = F_MT * R - 1;
+  constexpr int NRING = TT + HALO + 1;
+  constexpr int DSPL = D < F_NT ? F_NT / D : 1;               // block groups when D < 256
+  constexpr int DPT = D > F_NT ? D / F_NT : 1;                // output samples per thread
+  constexpr int BPT = TT / DSPL;                              // blocks per thread
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float2* ring = reinterpret_cast<float2*>(smem);             // [NRING][FRS]
+  float2* twj = ring + NRING * FRS;                           // [NF]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int s = blockIdx.y;
+  const long bt0 = b0 + (long)blockIdx.x * F_SRUN;
+  const long bend = (bt0 + F_SRUN < b0 + bcount) ? bt0 + F_SRUN : b0 + bcount;
+  const float2* Ys = Y + (long)s * K * T_stride;
+  float* os = out + (long)s * out_stride;
+
+  for (int i = tid; i < NF; i += F_NT) twj[i] = twg[(2 * (i % P2) * (i / P2)) & (M - 1)];
+  __syncthreads();
+
+  const long f_lo = bt0 + pd - HALO;
+  for (long fc0 = f_lo + HALO - TT; fc0 < bend + pd; fc0 += TT) {
+    // ---- A. Hermitian pre-pass
+    {
+      const int fi = tid % TT, kq = tid / TT;
+      const long f = fc0 + fi;
+      const bool fok = f >= 0 && f < nframes;
+      if (f >= f_lo) {
+        float2* zf = ring + (int)((f - f_lo) % NRING) * FRS;
+#pragma unroll 4
+        for (int it = 0; it < NF / KQ; it++) {
+          const int k = kq + KQ * it;
+          float2 z = make_float2(0.f, 0.f);
+          if (fok) {
+            float2 a = Ys[(long)k * T_stride + f];
+            float2 bq = Ys[(long)(NF - k) * T_stride + f];
+            if (k == 0) { a.y = 0.f; bq.y = 0.f; }
+            const float2 sm = make_float2(a.x + bq.x, a.y - bq.y), df = make_float2(a.x - bq.x, a.y + bq.y);
+            const float2 w = twg[k];
+            const float2 t = make_float2(w.x * df.x + w.y * df.y, w.x * df.y - w.y * df.x);
+            z = make_float2(sm.x - t.y, sm.y + t.x);
+          }
+          zf[(k / P2) * G::LA + (k % P2)] = z;                  // input layout of pass 1: n = P2 r + j
+        }
+      }
+    }
+    __syncthreads();
+    // ---- B. forward FFT of this wave's FPW new frames
+    {
+      // frames of a wave are consecutive ring slots only when they do not wrap; handle frame by frame groups
+      const long fw0 = fc0 + (long)wave * G::FPW;
+      if (fw0 + G::FPW - 1 >= f_lo) {
+        // ring slots of consecutive frames are consecutive modulo NRING; wave_fft needs a contiguous block,
+        // so the ring is laid out such that a wave's FPW frames never straddle the wrap (NRING % FPW == 0 is
+        // not guaranteed) -> process through a per-frame slot table
+        using GG = G;
+        constexpr int P1 = GG::P1, LA = GG::LA, LB = GG::LB;
+#pragma unroll
+        for (int rd = 0; rd < GG::FPW / GG::FP1; rd++) {
+          const int fl = lane / P2, j = lane % P2;
+          const long f = fw0 + rd * GG::FP1 + fl;
+          if (f >= f_lo) {
+            float2* fb = ring + (int)((f - f_lo) % NRING) * FRS;
+            float2 v[P1];
+#pragma unroll
+            for (int r = 0; r < P1; r++) v[r] = cconjf(fb[r * LA + j]);
+            f_dftp<P1>(v);
+#pragma unroll
+            for (int k1 = 1; k1 < P1; k1++) v[k1] = cmulf(v[k1], twj[k1 * P2 + j]);
+#pragma unroll
+            for (int k1 = 0; k1 < P1; k1++) fb[j * LB + k1] = v[k1];
+          }
+        }
+#pragma unroll
+        for (int rd = 0; rd < GG::FPW / GG::FP2; rd++) {
+          const int fl = lane / P1, k1 = lane % P1;
+          const long f = fw0 + rd * GG::FP2 + fl;
+          if (f >= f_lo) {
+            float2* fb = ring + (int)((f - f_lo) % NRING) * FRS;
+            float2 v[P2];
+#pragma unroll
+            for (int jp = 0; jp < P2; jp++) v[jp] = fb[jp * LB + k1];
+            f_dftp<P2>(v);
+#pragma unroll
+            for (int k2 = 0; k2 < P2; k2++) fb[k2 * LB + k1] = cconjf(v[k2]);
+          }
+        }
+      }
+    }
+    __syncthreads();
+    // ---- C. polyphase + overlap-add: thread owns sample(s) d and BPT of the TT blocks
+    if (fc0 >= f_lo + HALO) {
+      const int dbase = (D >= F_NT) ? tid : tid % D;
+      const int bb0 = (D >= F_NT) ? 0 : (tid / D) * BPT;
+#pragma unroll
+      for (int q = 0; q < DPT; q++) {
+        const int d = dbase + q * F_NT;
+        float gco[R][F_MT];
+#pragma unroll
+        for (int j = 0; j < R; j++)
+#pragma unroll
+          for (int k = 0; k < F_MT; k++) gco[j][k] = proto[(M - 1 - (d + j * D)) + M * k];
+        float win[R][BPT + HALO];
+#pragma unroll
+        for (int j = 0; j < R; j++) {
+          const int i = d + j * D;
+          const int zi = zidx<LOG2M>(i >> 1);
+#pragma unroll
+          for (int wdx = 0; wdx < BPT + HALO; wdx++) {
+            const long f = fc0 + bb0 - HALO + wdx;
+            const float2 zz = ring[(int)((f - f_lo) % NRING) * FRS + zi];
+            win[j][wdx] = (i & 1) ? zz.y : zz.x;
+          }
+        }
+#pragma unroll
+        for (int bb = 0; bb < BPT; bb++) {
+          const long bglob = fc0 + bb0 + bb - pd;
+          float acc = 0.f;
+#pragma unroll
+          for (int j = 0; j < R; j++) {
+            float sv = 0.f;
+#pragma unroll
+            for (int k = 0; k < F_MT; k++)
+              sv = fmaf(gco[j][k], win[j][bb + HALO - (R - 1 - j) - R * k], sv);
+            if (bglob - (R - 1 - j) >= 0) acc += sv;
+          }
+          if (gain > 0.f) acc *= gain;
+          if (bglob >= bt0 && bglob < bend) os[(bglob - b0) * D + (D - 1 - d)] = acc;
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
+template <int LOG2M, int R>
+int launch_fast_synthesis(const btk_fb* fb, const float2* Y, long nframes, long T_stride, int S, float* out, long out_stride,
+                          long b0, long bcount, hipStream_t st)
+{
+  using G = FG<LOG2M>;
+  constexpr int HALO = F_MT * R - 1;
+  constexpr int NRING = G::TT + HALO + 1;
+  const size_t lds = sizeof(float2) * ((size_t)NRING * G::FRS + G::NF);
+  if (lds > 160 * 1024) return 0;
+  auto kern = fast_synthesis_kernel<LOG2M, R>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    BTK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
+  }
+  const unsigned gx = (unsigned)((bcount + F_SRUN - 1) / F_SRUN);
+  hipLaunchKernelGGL(kern, dim3(gx, (unsigned)S), dim3(F_NT), lds, st, Y, nframes, T_stride, fb->K, fb->d_proto, fb->d_tw,
+                     fb->pd, (float)fb->gain_factor, out, out_stride, b0, bcount);
+  BTK_HIP_CHECK(hipGetLastError());
+  return 1;
+}
+
+template <int LOG2M>
+int fast_synthesis_r(const btk_fb* fb, const float2* Y, long nframes, long T_stride, int S, float* out, long out_stride,
+                     long b0, long bcount, hipStream_t st)
+{
+  switch (fb->R) {
+    case 1: return launch_fast_synthesis<LOG2M, 1>(fb, Y, nframes, T_stride, S, out, out_stride, b0, bcount, st);
+    case 2: return launch_fast_synthesis<LOG2M, 2>(fb, Y, nframes, T_stride, S, out, out_stride, b0, bcount, st);
+    case 4: return launch_fast_synthesis<LOG2M, 4>(fb, Y, nframes, T_stride, S, out, out_stride, b0, bcount, st);
+  }
+  return 0;
+}
+
 }  // namespace
 
 // returns 1 handled / 0 geometry not covered / <0 error
@@ -348,6 +532,20 @@ int btk_fast_analysis_try(const btk_fb* fb, const float* pcm, long nsamples, lon
     case 512:  return fast_analysis_r<9>(fb, pcm, nsamples, pcm_stride, S, N, Xp, T_stride, t0, tcount, st);
     case 1024: return fast_analysis_r<10>(fb, pcm, nsamples, pcm_stride, S, N, Xp, T_stride, t0, tcount, st);
     case 2048: return fast_analysis_r<11>(fb, pcm, nsamples, pcm_stride, S, N, Xp, T_stride, t0, tcount, st);
+  }
+  return 0;
+}
+
+int btk_fast_synthesis_try(const btk_fb* fb, const void* Y, long nframes, long T_stride, int S, float* out, long out_stride,
+                           long b0, long bcount, hipStream_t st)
+{
+  if (fb->m != F_MT) return 0;
+  const float2* Yp = static_cast<const float2*>(Y);
+  switch (fb->M) {
+    case 256:  return fast_synthesis_r<8>(fb, Yp, nframes, T_stride, S, out, out_stride, b0, bcount, st);
+    case 512:  return fast_synthesis_r<9>(fb, Yp, nframes, T_stride, S, out, out_stride, b0, bcount, st);
+    case 1024: return fast_synthesis_r<10>(fb, Yp, nframes, T_stride, S, out, out_stride, b0, bcount, st);
+    case 2048: return fast_synthesis_r<11>(fb, Yp, nframes, T_stride, S, out, out_stride, b0, bcount, st);
   }
   return 0;
 }

@@ -373,6 +373,11 @@ int btk_fb_synthesis(const btk_fb_t* fb, const void* Y, long nframes, long T_str
     const int rc = btk_synthesis512_try(fb, Y, nframes, T_stride, S, out, out_stride, b0, bcount, st);
     if (rc != 0) return rc > 0 ? BTK_OK : rc;
   }
+  static const bool nofast = getenv("BTK_DISABLE_FAST") != nullptr;
+  if (!nofast) {
+    const int rc = btk_fast_synthesis_try(fb, Y, nframes, T_stride, S, out, out_stride, b0, bcount, st);
+    if (rc != 0) return rc > 0 ? BTK_OK : rc;
+  }
   switch (fb->M) {
     case 64:   return launch_synthesis<6>(fb, Yp, nframes, T_stride, S, out, out_stride, b0, bcount, st);
     case 128:  return launch_synthesis<7>(fb, Yp, nframes, T_stride, S, out, out_stride, b0, bcount, st);
