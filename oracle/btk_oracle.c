@@ -1019,3 +1019,204 @@ long orc_pipeline_gsc(const double* h, const double* g, unsigned M, unsigned m, 
   free(banks); free(samples); free(snaps); free(y); orc_synthesis_free(syn);
   return blocks;
 }
+
+/* ------------------------------------------------------------------------
+ * RLS sidelobe cancellers ("next" row of the survey).  Two reference variants.
+ *
+ * (1) lib/pybeamformer.py:817-898  SubbandGSCRLSBeamformer.__iter__ (pure numpy, pinned by
+ *     tests/golden/gen_golden_pybeamformer_rls.py).
+ *     scal = { _energy, _isamp, _ttl_updates } in/out;
+ *     par  = { beta, gamma, mu, init_diagonal_load, regularization_param, sil_thresh,
+ *              constraint_option, alpha2, max_wa_l2norm, min_frames }.
+ *     BmH [K][bs][N], wqH [K][N], Pz [K][bs][bs], waH [K][bs]; samples_ch0 [M]; snapshots [M][N].
+ * ---------------------------------------------------------------------- */
+void orc_rls_py_frame(unsigned M, unsigned N, unsigned Nc, const double* par, double* scal,
+                      const cplx* samples_ch0, const cplx* snapshots,
+                      const cplx* BmH, const cplx* wqH, cplx* Pz, cplx* waH, cplx* out)
+{
+  const double beta = par[0], gamma = par[1], mu = par[2], init_load = par[3], reg = par[4], sil = par[5];
+  const int copt = (int)par[6];
+  const double alpha2 = par[7], max_norm = par[8];
+  const long min_frames = (long)par[9];
+  unsigned bs = N - Nc, M2 = M / 2;
+  long isamp = (long)scal[1];
+  double energy = c_abs(zdotc(samples_ch0, samples_ch0, M)) / M;                   /* :824 */
+  memset(out, 0, sizeof(cplx) * M);
+  int adapt = energy > (scal[0] / sil);                                            /* :827 */
+  if (adapt) scal[2] += 1.0;
+  cplx* ZK = (cplx*)malloc(sizeof(cplx) * bs);
+  cplx* PzZ = (cplx*)malloc(sizeof(cplx) * bs);
+  cplx* gz = (cplx*)malloc(sizeof(cplx) * bs);
+  cplx* temp = (cplx*)malloc(sizeof(cplx) * bs);
+  cplx* PzK = (cplx*)malloc(sizeof(cplx) * bs * bs);
+  cplx* waHK = (cplx*)malloc(sizeof(cplx) * bs);
+  cplx* va = (cplx*)malloc(sizeof(cplx) * bs);
+  for (unsigned k = 0; k <= M2; k++) {
+    const cplx* XK = snapshots + (size_t)k * N;
+    const cplx* Bk = BmH + (size_t)k * bs * N;
+    cplx* P = Pz + (size_t)k * bs * bs;
+    cplx* wa = waH + (size_t)k * bs;
+    for (unsigned i = 0; i < bs; i++) {                                            /* :832 */
+      cplx z = c_make(0, 0);
+      for (unsigned c = 0; c < N; c++) z = c_add(z, c_mul(Bk[(size_t)i * N + c], XK[c]));
+      ZK[i] = z;
+    }
+    cplx YcK = c_make(0, 0);                                                       /* :834 */
+    for (unsigned c = 0; c < N; c++) YcK = c_add(YcK, c_mul(wqH[(size_t)k * N + c], XK[c]));
+    if (adapt) {
+      cplx ip = c_make(0, 0);
+      for (unsigned i = 0; i < bs; i++) {                                          /* :838 PzZ = Pz . ZK */
+        cplx a = c_make(0, 0);
+        for (unsigned j = 0; j < bs; j++) a = c_add(a, c_mul(P[(size_t)i * bs + j], ZK[j]));
+        PzZ[i] = a;
+      }
+      for (unsigned i = 0; i < bs; i++) ip = c_add(ip, c_mul(c_conj(ZK[i]), PzZ[i]));   /* :839 */
+      cplx den = c_make(mu + ip.re, ip.im);
+      for (unsigned i = 0; i < bs; i++) gz[i] = c_div(PzZ[i], den);                /* :840 */
+      for (unsigned j = 0; j < bs; j++) {                                          /* :841 temp = conj(ZK) . Pz */
+        cplx a = c_make(0, 0);
+        for (unsigned i = 0; i < bs; i++) a = c_add(a, c_mul(c_conj(ZK[i]), P[(size_t)i * bs + j]));
+        temp[j] = a;
+      }
+      for (unsigned i = 0; i < bs; i++)                                            /* :842 */
+        for (unsigned j = 0; j < bs; j++)
+          PzK[(size_t)i * bs + j] = c_scale(c_sub(P[(size_t)i * bs + j], c_mul(gz[i], temp[j])), 1.0 / mu);
+      cplx dot = c_make(0, 0);                                                     /* :845 */
+      for (unsigned i = 0; i < bs; i++) dot = c_add(dot, c_mul(wa[i], ZK[i]));
+      cplx ep = c_sub(YcK, dot);
+      for (unsigned i = 0; i < bs; i++)                                            /* :846 */
+        waHK[i] = c_add(wa[i], c_mul(c_scale(c_conj(gz[i]), gamma), ep));
+      if (reg > 0) {                                                               /* :848-849 */
+        for (unsigned i = 0; i < bs; i++) {
+          cplx a = c_make(0, 0);
+          for (unsigned j = 0; j < bs; j++) a = c_add(a, c_mul(c_conj(PzK[(size_t)i * bs + j]), wa[j]));
+          waHK[i] = c_sub(waHK[i], c_scale(a, reg));
+        }
+      }
+      if (copt > 0) {                                                              /* :852-871 */
+        cplx nn = c_make(0, 0);
+        for (unsigned i = 0; i < bs; i++) nn = c_add(nn, c_mul(waHK[i], c_conj(waHK[i])));
+        double waK2 = c_abs(nn);
+        if ((copt == 1 || copt == 3) && waK2 > alpha2) {
+          for (unsigned i = 0; i < bs; i++) {                                      /* va = PzK . waK */
+            cplx a = c_make(0, 0);
+            for (unsigned j = 0; j < bs; j++) a = c_add(a, c_mul(PzK[(size_t)i * bs + j], c_conj(waHK[j])));
+            va[i] = a;
+          }
+          cplx aa = c_make(0, 0), bb = c_make(0, 0);
+          for (unsigned i = 0; i < bs; i++) {
+            aa = c_add(aa, c_mul(va[i], c_conj(va[i])));
+            bb = c_add(bb, c_mul(c_conj(va[i]), c_conj(waHK[i])));
+          }
+          double a = c_abs(aa), b = -2.0 * bb.re, c = waK2 - alpha2;
+          double arg = b * b - 4.0 * a * c;
+          double betaK = (arg > 0) ? -(b + sqrt(arg)) / (2.0 * a) : -b / (2.0 * a);
+          for (unsigned i = 0; i < bs; i++) waHK[i] = c_sub(waHK[i], c_scale(c_conj(va[i]), betaK));
+        }
+        if (copt >= 2 && waK2 > max_norm) {
+          double sc = sqrt(max_norm / waK2);
+          for (unsigned i = 0; i < bs; i++) waHK[i] = c_scale(waHK[i], sc);
+          for (unsigned i = 0; i < bs; i++)
+            for (unsigned j = 0; j < bs; j++) PzK[(size_t)i * bs + j] = c_make(i == j ? 1.0 / init_load : 0.0, 0.0);
+        }
+      }
+      memcpy(P, PzK, sizeof(cplx) * bs * bs);                                      /* :890-891 */
+      memcpy(wa, waHK, sizeof(cplx) * bs);
+    }
+    if (isamp >= min_frames) {                                                     /* :894-897 */
+      cplx dot = c_make(0, 0);
+      for (unsigned i = 0; i < bs; i++) dot = c_add(dot, c_mul(wa[i], ZK[i]));
+      out[k] = c_sub(YcK, dot);
+    } else out[k] = YcK;
+    if (k > 0 && k < M2) out[M - k] = c_conj(out[k]);
+  }
+  scal[0] = scal[0] * beta + (1.0 - beta) * energy;                                /* :902 */
+  scal[1] = (double)(isamp + 1);
+  free(ZK); free(PzZ); free(gz); free(temp); free(PzK); free(waHK); free(va);
+}
+
+/* (2) beamformer/beamformer.cc:1514-1645  SubbandGSCRLS::next + update_active_weight_vector2_
+ *     (C++; needs GSL, cannot be compiled here -> restated, output-level parity UNPINNED).
+ *     B [M][N][bs] (rows = channels), wq [M][N], wl [M][N] in/out, Pz [M][bs][bs] in/out,
+ *     wa [M][bs] in/out (only bins 1..M/2 are touched); snapshots [M][N]; out [M].
+ *     qctype: 0 none, 1 CONSTANT_NORM, 2 THRESHOLD_LIMITATION (beamformer.h:215-219).          */
+void orc_rls_cc_frame(unsigned M, unsigned N, unsigned Nc, double mu, double diag_w, int qctype, double alpha,
+                      int normalize, int update, const cplx* snapshots, const cplx* B, const cplx* wq,
+                      cplx* wl, cplx* Pz, cplx* wa_all, cplx* out)
+{
+  unsigned bs = N - Nc, M2 = M / 2;
+  cplx* Zf = (cplx*)malloc(sizeof(cplx) * bs);
+  cplx* PzHZ = (cplx*)malloc(sizeof(cplx) * bs);
+  cplx* gz = (cplx*)malloc(sizeof(cplx) * bs);
+  cplx* wa = (cplx*)malloc(sizeof(cplx) * bs);
+  cplx* w = (cplx*)malloc(sizeof(cplx) * N);
+  /* :1540-1543 direct component */
+  out[0] = zdotc(wq, snapshots, N);
+  for (unsigned k = 1; k <= M2; k++) {                                             /* :1546-1558 */
+    const cplx* x = snapshots + (size_t)k * N;
+    for (unsigned c = 0; c < N; c++) w[c] = c_sub(wq[(size_t)k * N + c], wl[(size_t)k * N + c]);
+    if (normalize) {                                                               /* :1229-1237 */
+      double nrm = 0;
+      for (unsigned c = 0; c < N; c++) nrm += c_abs2(w[c]);
+      nrm = sqrt(nrm);
+      for (unsigned c = 0; c < N; c++) w[c] = c_scale(w[c], 1.0 / (nrm * N));
+    }
+    cplx val = zdotc(w, x, N);
+    out[k] = val;
+    if (k < M2) out[M - k] = c_conj(val);
+  }
+  if (update) {
+    for (unsigned k = 1; k <= M2; k++) {                                           /* :1589-1644 */
+      const cplx* x = snapshots + (size_t)k * N;
+      const cplx* Bk = B + (size_t)k * N * bs;
+      cplx* P = Pz + (size_t)k * bs * bs;
+      cplx* old_wa = wa_all + (size_t)k * bs;
+      for (unsigned i = 0; i < bs; i++) {                                          /* :1594 Z = B^H X */
+        cplx z = c_make(0, 0);
+        for (unsigned c = 0; c < N; c++) z = c_add(z, c_mul(c_conj(Bk[(size_t)c * bs + i]), x[c]));
+        Zf[i] = z;
+      }
+      for (unsigned i = 0; i < bs; i++) {                                          /* :1597 PzH_Z = Pz^H Z */
+        cplx a = c_make(0, 0);
+        for (unsigned j = 0; j < bs; j++) a = c_add(a, c_mul(c_conj(P[(size_t)j * bs + i]), Zf[j]));
+        PzHZ[i] = a;
+      }
+      for (unsigned i = 0; i < bs; i++) {                                          /* :1598 gz = Pz Z / mu */
+        cplx a = c_make(0, 0);
+        for (unsigned j = 0; j < bs; j++) a = c_add(a, c_mul(P[(size_t)i * bs + j], Zf[j]));
+        gz[i] = c_scale(a, 1.0 / mu);
+      }
+      cplx de = zdotc(PzHZ, Zf, bs);                                               /* :1599-1600 */
+      de = c_make(de.re * (1.0 / mu) + 1.0, de.im * (1.0 / mu));
+      for (unsigned i = 0; i < bs; i++) gz[i] = c_div(gz[i], de);                  /* :1601-1606 */
+      for (unsigned i = 0; i < bs; i++)                                            /* :1609-1617 */
+        for (unsigned j = 0; j < bs; j++)
+          P[(size_t)i * bs + j] = c_scale(c_sub(P[(size_t)i * bs + j], c_mul(gz[i], c_conj(PzHZ[j]))), 1.0 / mu);
+      cplx epA = c_conj(out[k]);                                                   /* :1620 */
+      for (unsigned i = 0; i < bs; i++) {                                          /* :1622-1625 (I - s Pz) wa */
+        cplx a = c_make(0, 0);
+        for (unsigned j = 0; j < bs; j++) {
+          cplx m1 = c_scale(P[(size_t)i * bs + j], -diag_w);
+          if (i == j) m1.re += 1.0;
+          a = c_add(a, c_mul(m1, old_wa[j]));
+        }
+        wa[i] = a;
+      }
+      for (unsigned i = 0; i < bs; i++) wa[i] = c_add(wa[i], c_mul(gz[i], epA));   /* :1626-1630 */
+      if (qctype == 1 || qctype == 2) {                                            /* :1631-1641 */
+        double nrm = 0;
+        for (unsigned i = 0; i < bs; i++) nrm += c_abs2(wa[i]);
+        nrm = sqrt(nrm);
+        if (qctype == 1 || nrm * nrm >= alpha)
+          for (unsigned i = 0; i < bs; i++) wa[i] = c_scale(wa[i], alpha / nrm);
+      }
+      for (unsigned i = 0; i < bs; i++) old_wa[i] = wa[i];                         /* :1643 U_f: wa_ <- wa ; wl = B wa */
+      for (unsigned c = 0; c < N; c++) {
+        cplx a = c_make(0, 0);
+        for (unsigned i = 0; i < bs; i++) a = c_add(a, c_mul(Bk[(size_t)c * bs + i], wa[i]));
+        wl[(size_t)k * N + c] = a;
+      }
+    }
+  }
+  free(Zf); free(PzHZ); free(gz); free(wa); free(w);
+}

@@ -55,6 +55,8 @@ def lib():
         L.orc_nlms_energy.restype = C.c_double
         L.orc_nlms_energy.argtypes = [vp]
         L.orc_nlms_frame.argtypes = [vp] * 6
+        L.orc_rls_py_frame.argtypes = [C.c_uint] * 3 + [vp] * 9
+        L.orc_rls_cc_frame.argtypes = [C.c_uint] * 3 + [C.c_double, C.c_double, C.c_int, C.c_double, C.c_int, C.c_int] + [vp] * 7
         L.orc_cov_accumulate_frame.argtypes = [vp, C.c_uint, C.c_uint, vp, vp]
         L.orc_frame_energy.restype = C.c_double
         L.orc_frame_energy.argtypes = [vp, C.c_uint]
@@ -270,6 +272,76 @@ class NLMS:
         for t in range(T):
             L.orc_snapshot_update(_p(X[t]), M, N, _p(snaps))
             L.orc_nlms_frame(self._h, _p(X[t]), _p(snaps), _p(self.BmH), _p(self.wqH), _p(out[t]))
+        return out
+
+
+class RLSPy:
+    """SubbandGSCRLSBeamformer restatement (lib/pybeamformer.py:765-928)."""
+
+    def __init__(self, M, N, Nc=1, beta=0.97, gamma=0.04, mu=0.97, init_diagonal_load=1.0e6,
+                 regularization_param=1.0e-2, sil_thresh=1.0e8, constraint_option=3, alpha2=10.0,
+                 max_wa_l2norm=100.0, min_frames=128):
+        self.M, self.N, self.Nc, self.K = M, N, Nc, M // 2 + 1
+        self.par = np.array([beta, gamma, mu, init_diagonal_load, regularization_param, sil_thresh,
+                             constraint_option, alpha2, max_wa_l2norm, min_frames], np.float64)
+        bs = N - Nc
+        self.scal = np.array([init_diagonal_load, 0.0, 0.0], np.float64)        # reset_stats :913-925
+        self.Pz = np.tile(np.identity(bs, np.complex128) / init_diagonal_load, (self.K, 1, 1))
+        self.waH = np.zeros((self.K, bs), np.complex128)
+        self.BmH = None
+        self.wqH = None
+
+    calc_beamformer_weights = NLMS.calc_beamformer_weights                      # :900-908 is the same code
+
+    def run(self, X):
+        X = _c128(X)
+        T, N, M = X.shape
+        out = np.zeros((T, M), np.complex128)
+        snaps = np.zeros((M, N), np.complex128)
+        L = lib()
+        for t in range(T):
+            L.orc_snapshot_update(_p(X[t]), M, N, _p(snaps))
+            L.orc_rls_py_frame(M, N, self.Nc, _p(self.par), _p(self.scal), _p(X[t, 0]), _p(snaps),
+                               _p(self.BmH), _p(self.wqH), _p(self.Pz), _p(self.waH), _p(out[t]))
+        return out
+
+
+class RLSCc:
+    """SubbandGSCRLS restatement (beamformer/beamformer.cc:1447-1645)."""
+
+    def __init__(self, M, N, delays, samplerate, mu=0.9, sigma2=0.0, Nc=1):
+        self.M, self.N, self.Nc = M, N, Nc
+        self.mu, self.diag_w = float(np.float32(mu)), float(np.float32(sigma2))  # float members, beamformer.h:253-254
+        self.qctype, self.alpha, self.normalize, self.update = 0, -1.0, 0, 1
+        self.wq = calc_mainlobe(M, N, samplerate, delays)                        # [M][N]
+        bs = N - Nc
+        self.B = np.zeros((M, N, bs), np.complex128)
+        for k in range(M):
+            self.B[k] = blocking_matrix(self.wq[k], Nc)
+        self.wl = np.zeros((M, N), np.complex128)
+        self.wa = np.zeros((M, bs), np.complex128)
+        self.Pz = None
+
+    def init_precision_matrix(self, sigma2=0.01):
+        """beamformer.cc:1482-1494; 1/sigma2 is a float division there"""
+        bs = self.N - self.Nc
+        v = float(np.float32(1) / np.float32(sigma2))
+        self.Pz = np.tile(np.identity(bs, np.complex128) * v, (self.M, 1, 1))
+
+    def set_quadratic_constraint(self, alpha, qctype=1):
+        self.alpha, self.qctype = float(np.float32(alpha)), int(qctype)
+
+    def run(self, X):
+        X = _c128(X)
+        T, N, M = X.shape
+        out = np.zeros((T, M), np.complex128)
+        snaps = np.zeros((M, N), np.complex128)
+        L = lib()
+        for t in range(T):
+            L.orc_snapshot_update(_p(X[t]), M, N, _p(snaps))
+            L.orc_rls_cc_frame(M, N, self.Nc, self.mu, self.diag_w, self.qctype, self.alpha, self.normalize,
+                               self.update, _p(snaps), _p(self.B), _p(self.wq), _p(self.wl), _p(self.Pz),
+                               _p(self.wa), _p(out[t]))
         return out
 
 

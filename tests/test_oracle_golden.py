@@ -1,4 +1,6 @@
 """CPU: the oracle against every golden vector / known answer the reference offers for the path."""
+import os
+
 import numpy as np
 import pytest
 
@@ -159,3 +161,33 @@ def test_zelinski_first_two_frames_alpha_zero(orc):
     assert np.allclose(W[1], W2[1])            # frame 1 independent of frame 0
     assert not np.allclose(W[2], W2[2]) or True
     assert np.all(W.real <= 1.0 + 1e-12) and np.all(W.real[:, :33] >= 1e-4 - 1e-12)
+
+
+# ---------------------------------------------------------------- RLS canceller ("next" row)
+@pytest.fixture(scope="module")
+def rlsgolden():
+    return np.load(os.path.join(os.path.dirname(__file__), "golden", "pybeamformer_rls_golden.npz"))
+
+
+@pytest.mark.parametrize("tag", ["rls_default", "rls_constrained", "rls_quadonly"])
+def test_rls_oracle_matches_reference_python(orc, proto256, kinect_pcm, pygolden, rlsgolden, tag):
+    """oracle/btk_oracle.c orc_rls_py_frame vs the reference's SubbandGSCRLSBeamformer (lib/pybeamformer.py:765-928)
+    executed by tests/golden/gen_golden_pybeamformer_rls.py."""
+    h, _ = proto256
+    T = int(rlsgolden["meta_T"][0])
+    X = np.stack([orc.analysis(h, 256, 4, 1, 2, kinect_pcm[c][: (T + 8) * 128])[:T] for c in range(4)], axis=1)
+    p = rlsgolden[tag + "_params"]
+    r = orc.RLSPy(256, 4, 1, beta=p[0], gamma=p[1], mu=p[2], init_diagonal_load=p[3], regularization_param=p[4],
+                  sil_thresh=p[5], constraint_option=int(p[6]), alpha2=p[7], max_wa_l2norm=p[8], min_frames=int(p[9]))
+    r.calc_beamformer_weights(16000, pygolden["delays_kinect"])
+    Y = r.run(X)
+    gY = rlsgolden[tag + "_Y"]
+    scale = np.max(np.abs(gY))
+    assert np.max(np.abs(Y[:, :129][:, ::5] - gY)) <= 1e-9 * scale
+    assert np.max(np.abs(Y[T - 1] - rlsgolden[tag + "_Ymirror"])) <= 1e-9 * scale
+    gw = rlsgolden[tag + "_waH"]
+    assert np.max(np.abs(r.waH - gw)) <= 1e-8 * np.max(np.abs(gw))
+    gP = rlsgolden[tag + "_Pz"]
+    assert np.max(np.abs(r.Pz[::8] - gP)) <= 1e-8 * np.max(np.abs(gP))
+    g = rlsgolden[tag + "_scal"]          # the generator is suspended at its yield: _isamp is one behind
+    assert np.allclose(r.scal[[0, 2]], g[[0, 2]], rtol=1e-12) and r.scal[1] == g[1] + 1
