@@ -54,6 +54,9 @@ SIGNATURES = {
     "btk_nlms_process": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _l, _l, _vp, _vp, _vp, _vp, _vp]),
     "btk_nlms_wa_to_u": (_i, [_vp, _vp, _i, _vp]),
     "btk_nlms_u_to_wa": (_i, [_vp, _vp, _i, _vp]),
+    "btk_rls_workspace_bytes": (_l, [_i, _l]),
+    "btk_rls_init": (_i, [_i, _vp, _i, _d, _i, _i, _i, _vp, _vp, _vp]),
+    "btk_rls_process": (_i, [_i, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _l, _l, _vp, _vp, _vp, _vp, _vp]),
     "btk_bf_apply_stats": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _l, _l, _vp]),
     "btk_zelinski_process": (_i, [_vp, _vp, _vp, _i, _i, _i, _l, _l, _d, _i, _i, _l, _vp, _vp, _vp, _vp]),
     "btk_frame_energy": (_i, [_vp, _i, _i, _i, _l, _l, _vp, _l, _vp]),

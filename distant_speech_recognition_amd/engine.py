@@ -273,6 +273,95 @@ def nlms_wa_to_u(waH, B):
     return u
 
 
+# ---------------------------------------------------------------------------- RLS canceller
+RLS_PY_DEFAULTS = dict(beta=0.97, gamma=0.04, mu=0.97, init_diagonal_load=1.0e6, regularization_param=1.0e-2,
+                       sil_thresh=1.0e8, constraint_option=3, alpha2=10.0, max_wa_l2norm=100.0, min_frames=128)
+RLS_CC_DEFAULTS = dict(mu=0.9, diagonal_weight=0.0, qctype=0, alpha=-1.0, normalize_weight=False, update=True)
+
+
+class RLSState:
+    """Device-resident state of S independent RLS sidelobe cancellers.
+    mode 1: SubbandGSCRLSBeamformer (lib/pybeamformer.py:765-928); mode 0: SubbandGSCRLS (beamformer.cc:1447-1645).
+    v complex128 [K][N] or [S][K][N] (cuda): vs resp. wq of bins 0..M/2."""
+
+    def __init__(self, mode, S, M, N, v, **kw):
+        if mode not in (0, 1):
+            raise _lib.BtkError(_lib.BTK_ERR_PARAMETER, "RLSState: mode must be 0 or 1")
+        self.mode = mode
+        self.p = dict(RLS_PY_DEFAULTS if mode == 1 else RLS_CC_DEFAULTS)
+        unknown = set(kw) - set(self.p)
+        if unknown:
+            raise _lib.BtkError(_lib.BTK_ERR_PARAMETER, "RLSState: unknown parameters %s" % sorted(unknown))
+        self.p.update(kw)
+        _need_cuda(v, "v")
+        self.S, self.M, self.N, self.K = S, M, N, M // 2 + 1
+        if v.dtype != torch.complex128 or v.shape[-2:] != (self.K, N) or v.dim() not in (2, 3):
+            raise _lib.BtkError(_lib.BTK_ERR_DIMENSION, "RLSState: v must be complex128 [K][N] or [S][K][N]")
+        self.v = v.contiguous()
+        self.per_stream = 1 if v.dim() == 3 else 0
+        dev = v.device
+        self.P = torch.empty((S, self.K, N, N), dtype=torch.complex128, device=dev)
+        self.w = torch.empty((S, self.K, N), dtype=torch.complex128, device=dev)
+        self.stream_state = torch.zeros((S, 4), dtype=torch.float64, device=dev)
+        self._ws = None
+        if mode == 1:
+            self.reset_stats()
+
+    def init_precision_matrix(self, p0):
+        """P = p0 B B^H (mode 0) / p0 conj(B) B^T (mode 1), w = 0 (init_precision_matrix with p0 = 1/sigma2,
+        beamformer.cc:1482-1494)"""
+        check(_lib.lib().btk_rls_init(self.mode, _ptr(self.v), self.per_stream, float(p0), self.S, self.K, self.N,
+                                      _ptr(self.P), _ptr(self.w), _stream()))
+
+    def reset_stats(self):
+        """pybeamformer.py:913-925"""
+        self.init_precision_matrix(1.0 / self.p["init_diagonal_load"])
+        self.stream_state.zero_()
+        self.stream_state[:, 0] = self.p["init_diagonal_load"]
+
+    def params_array(self):
+        p = self.p
+        if self.mode == 1:
+            return np.array([p["beta"], p["gamma"], p["mu"], p["init_diagonal_load"], p["regularization_param"],
+                             p["sil_thresh"], p["constraint_option"], p["alpha2"], p["max_wa_l2norm"], p["min_frames"]],
+                            np.float64)
+        return np.array([p["mu"], p["diagonal_weight"], p["qctype"], p["alpha"], float(bool(p["normalize_weight"])),
+                         float(bool(p["update"]))], np.float64)
+
+    def workspace(self, T):
+        need = _lib.lib().btk_rls_workspace_bytes(self.S, T)
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=self.P.device)
+        return self._ws
+
+
+def rls_process(X, state, out=None):
+    """RLS canceller over a block: X complex64 [S][K][N][T] -> Y [S][K][T]; state updated in place."""
+    _need_cuda(X, "X")
+    S, K, N, T = X.shape
+    if (S, K, N) != (state.S, state.K, state.N):
+        raise _lib.BtkError(_lib.BTK_ERR_DIMENSION, "rls_process: shapes do not match the state")
+    if out is None:
+        out = torch.empty((S, K, T), dtype=torch.complex64, device=X.device)
+    params = state.params_array()
+    ws = state.workspace(T)
+    check(_lib.lib().btk_rls_process(state.mode, _np_ptr(params), _ptr(state.v), state.per_stream, _ptr(X), _ptr(out),
+                                     S, state.M, N, T, T, _ptr(state.P), _ptr(state.w), _ptr(state.stream_state),
+                                     _ptr(ws), _stream()))
+    return out
+
+
+def rls_state_to_reference(mode, P, w, B):
+    """Host change of basis for one bin: engine (P [N][N], w [N]) -> reference (Pz [N-1][N-1], wa resp. waH [N-1])
+    with the bin's blocking matrix B [N][N-1] (orthonormal columns)."""
+    P = np.asarray(P, np.complex128)
+    w = np.asarray(w, np.complex128)
+    B = np.asarray(B, np.complex128)
+    if mode == 1:      # P = conj(B) Pz B^T, u = waH B^T
+        return B.T @ P @ np.conj(B), w @ np.conj(B)
+    return np.conj(B.T) @ P @ B, np.conj(B.T) @ w      # P = B Pz B^H, wl = B wa
+
+
 # ---------------------------------------------------------------------------- Zelinski post-filter
 class ZelinskiState:
     """Summed CSD / PSD state of S post-filters (the part of BeamformerWeights::CSDs_/wp1_,

@@ -118,6 +118,29 @@ int  btk_nlms_process(const float* params, const void* vs, const void* X, void* 
 int  btk_nlms_wa_to_u(const double* waH, const double* B, int N, double* u);
 int  btk_nlms_u_to_wa(const double* u, const double* B, int N, double* waH);
 
+/* ---- Adaptive GSC canceller: recursive least squares (float64 recursion) ---------------------
+ * mode 0 replaces SubbandGSCRLS::next + update_active_weight_vector2_ (beamformer/beamformer.cc:1514-1645):
+ *   params [host] 6 doubles: mu, diagonal_weight (sigma2 of the ctor, :1447-1467), qctype (0 none,
+ *   1 CONSTANT_NORM, 2 THRESHOLD_LIMITATION, beamformer.h:215-219), alpha, normalize_weight, update flag
+ *   (update_active_weight_vecotrs, beamformer.h:234);  v = wq (calcMainlobe), bins 1..M/2 adapt.
+ * mode 1 replaces SubbandGSCRLSBeamformer.__iter__ / reset_stats (lib/pybeamformer.py:817-925), Nc = 1:
+ *   params [host] 10 doubles: beta, gamma, mu, init_diagonal_load, regularization_param, sil_thresh,
+ *   constraint_option, alpha2, max_wa_l2norm, min_frames (:776-787);  v = vs (calc_array_manifold_f :284-306).
+ * v [dev] complex128 [Sv][K][N] (Sv = S if per_stream_v else 1); the upper branch is v^H x and the blocking
+ * matrix is implied by v.  State [dev], updated in place so consecutive blocks continue:
+ *   P_state complex128 [S][K][N][N] = B Pz B^H (mode 0) / conj(B) Pz B^T (mode 1)
+ *   w_state complex128 [S][K][N]    = wl = B wa (mode 0) / u = wa^H B^T (mode 1)
+ *   stream_state float64 [S][4]     = {_energy, -, _isamp, _ttl_updates} (mode 1; untouched in mode 0)
+ * btk_rls_init writes P = p0 B B^H resp. p0 conj(B) B^T (closed form from v), w = 0  == init_precision_matrix (p0 = 1/sigma2,
+ * beamformer.cc:1482-1494) resp. reset_stats (p0 = 1/init_diagonal_load, pybeamformer.py:921-925).
+ * N <= 64.  workspace [dev] btk_rls_workspace_bytes(S,T) bytes.  Y [dev] complex64 [S][K][T_stride].     */
+long btk_rls_workspace_bytes(int S, long T);
+int  btk_rls_init(int mode, const void* v, int per_stream_v, double p0, int S, int K, int N,
+                  void* P_state, void* w_state, void* stream);
+int  btk_rls_process(int mode, const double* params, const void* v, int per_stream_v,
+                     const void* X, void* Y, int S, int M, int N, long T_stride, long T,
+                     void* P_state, void* w_state, double* stream_state, void* workspace, void* stream);
+
 /* ---- Zelinski post-filter -------------------------------------------------------------------
  * Replaces ZelinskiFilter_f / ZelinskiFilter / ZelinskiPostFilter::next
  * (postfilter/postfilter.cc:57-219, 424-491).  Two calls per block:
