@@ -10,8 +10,9 @@ from .common import j_error, jallocation_error, jdimension_error, jiterator_erro
 from .modulated import OverSampledDFTAnalysisBankPtr, _mirror, _pull_all
 from .stream import VectorComplexFeatureStream, _BlockServedStream, device
 
-__all__ = ["SSPEED", "SnapShotArrayPtr", "SubbandDSPtr", "SubbandGSCPtr", "SubbandMVDRPtr", "SubbandMVDRGSCPtr",
-           "SubbandDS", "SubbandGSC", "SubbandMVDR", "SubbandMVDRGSC", "calc_all_delays"]
+__all__ = ["SSPEED", "SnapShotArrayPtr", "SubbandDSPtr", "SubbandGSCPtr", "SubbandGSCRLSPtr", "SubbandMVDRPtr",
+           "SubbandMVDRGSCPtr", "SubbandDS", "SubbandGSC", "SubbandGSCRLS", "SubbandMVDR", "SubbandMVDRGSC",
+           "calc_all_delays"]
 
 SSPEED = 343740.0     # beamformer/beamformer.h:26
 
@@ -345,6 +346,94 @@ class SubbandGSCPtr(SubbandDSPtr):
         return SubbandDSPtr.next(self, frame_no)
 
 
+class SubbandGSCRLSPtr(SubbandGSCPtr):
+    """SubbandGSCRLS (beamformer.h:207-263, beamformer.cc:1447-1699): GSC whose active weights are adapted by a
+    recursive-least-squares recursion per frame (Van Trees pp. 766-767).  The whole utterance runs in one
+    btk_rls_process launch (mode 0); the active weights after the last served block are exported to the weight
+    object like calcSidelobeCancellerU_f does (:1643)."""
+
+    def __init__(self, fftlen=512, half_band_shift=False, mu=0.9, sigma2=0.0, nm="SubbandGSCRLS"):
+        SubbandGSCPtr.__init__(self, fftlen, half_band_shift, nm)
+        self._mu = float(np.float32(mu))                       # float members (beamformer.h:253-256)
+        self._diagonal_weight = float(np.float32(sigma2))
+        self._alpha = -1.0
+        self._qctype = 0
+        self._is_wa_updated = True
+        self._p0 = None
+        self._Pz_user = {}
+        self._rls = None
+
+    def init_precision_matrix(self, sigma2=0.01):
+        if not self._bfw:
+            raise j_error("call calc_gsc_weights_x() once\n")
+        self._p0 = float(np.float32(1) / np.float32(sigma2))   # float division, beamformer.cc:1491
+        self._Pz_user = {}
+        self._rls = None
+        self._invalidate_output()
+
+    def set_precision_matrix(self, fbin_no, Pz):
+        if not self._bfw:
+            raise j_error("call calc_gsc_weights_x() once\n")
+        if self._p0 is None:
+            self._p0 = 0.0
+        self._Pz_user[int(fbin_no)] = np.array(Pz, np.complex128)
+        self._rls = None
+        self._invalidate_output()
+
+    def update_active_weight_vecotrs(self, flag):              # sic: the reference's spelling
+        self._is_wa_updated = bool(flag)
+
+    def set_quadratic_constraint(self, alpha, qctype=1):
+        self._alpha, self._qctype = float(np.float32(alpha)), int(qctype)
+
+    initPrecisionMatrix, setPrecisionMatrix = init_precision_matrix, set_precision_matrix
+    updateActiveWeightVecotrs, setQuadraticConstraint = update_active_weight_vecotrs, set_quadratic_constraint
+
+    def _compute_block(self):
+        import torch
+        self._check_weights()
+        if self._p0 is None:
+            raise j_error("set the precision matrix with init_precision_matrix() or set_precision_matrix()\n")
+        X = self.device_snapshots()
+        bw = self._bfw[0]
+        K, N = self._K, self.chan_num()
+        if bw.NC != 1:
+            raise jdimension_error("the GPU RLS canceller supports NC = 1 constraint (got %d)\n" % bw.NC)
+        try:
+            if self._rls is None:
+                wq = torch.from_numpy(np.ascontiguousarray(bw.wq[:K]).astype(np.complex128)).to(device())
+                self._rls = engine.RLSState(0, 1, self._fftlen, N, wq)
+                self._rls.init_precision_matrix(self._p0)
+                if self._Pz_user or np.any(bw.wl[:K] != 0):
+                    P = self._rls.P.cpu().numpy()
+                    for k, Pz in self._Pz_user.items():
+                        if k < K:
+                            n = N - bw.NC
+                            P[0, k] = bw.B[k] @ Pz[:n, :n] @ np.conj(bw.B[k].T)
+                    self._rls.P.copy_(torch.from_numpy(P))
+                    self._rls.w.copy_(torch.from_numpy(np.ascontiguousarray(bw.wl[:K])[None]))
+            self._rls.p.update(mu=self._mu, diagonal_weight=self._diagonal_weight, qctype=self._qctype,
+                               alpha=self._alpha, normalize_weight=self._normalize_weight, update=self._is_wa_updated)
+            self._Y = engine.rls_process(X, self._rls)
+        except _lib.BtkError as e:
+            raise_from_code(e)
+        # export wl / wa of the bins that adapt (1..M/2), as calcSidelobeCancellerU_f leaves them (:1643)
+        wl = self._rls.w[0].cpu().numpy()
+        for k in range(1, K):
+            bw.wl[k] = wl[k]
+            bw.wa[k] = np.conj(bw.B[k].T) @ wl[k]
+
+    def _invalidate_output(self):
+        # the recursion cannot be re-run from the middle of a block: changes apply from the next reset()
+        if self._Y is None:
+            return
+        self._dirty = False
+
+    def reset(self):
+        # beamformer.cc:1565-1575: sources and snapshots are reset, Pz_ and wa are KEPT
+        SubbandGSCPtr.reset(self)
+
+
 class SubbandMVDRPtr(SubbandDSPtr):
     """SubbandMVDR (beamformer.h:333-383, beamformer.cc:2280-2599)."""
 
@@ -512,3 +601,4 @@ def calc_all_delays(x, y, z, mpos):
 
 
 SubbandDS, SubbandGSC, SubbandMVDR, SubbandMVDRGSC = SubbandDSPtr, SubbandGSCPtr, SubbandMVDRPtr, SubbandMVDRGSCPtr
+SubbandGSCRLS = SubbandGSCRLSPtr

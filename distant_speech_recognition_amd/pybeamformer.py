@@ -278,6 +278,95 @@ class SubbandGSCLMSBeamformer(SubbandBeamformer):
         self._frames = None
 
 
+class SubbandGSCRLSBeamformer(SubbandBeamformer):
+    """pybeamformer.py:765-928: RLS beamformer in GSC configuration with a regularisation term.  The recursion runs
+    on the GPU (btk_rls_process mode 1, float64); _waH / _Pz are exported in the reference's basis on demand."""
+
+    def __init__(self, spec_sources, beta=0.97, gamma=0.04, mu=0.97, init_diagonal_load=1.0E+6,
+                 regularization_param=1.0E-2, sil_thresh=1.0E+8, constraint_option=3, alpha2=10.0,
+                 max_wa_l2norm=100.0, min_frames=128, slowdown_after=4096, Nc=1):
+        SubbandBeamformer.__init__(self, spec_sources)
+        if Nc != 1:
+            raise NotImplementedError("the GPU canceller supports Nc = 1 (see DESIGN.md)")
+        self._Nc = Nc
+        self._front = SubbandGSCPtr(fftlen=self._fftlen, half_band_shift=False)   # owns channels + device snapshots
+        for source in self._spec_sources:
+            self._front.set_channel(source)
+        self._beamformer = self._front
+        # slowdown_after is accepted and, as in the reference (:777-811), never used
+        self._params = dict(beta=beta, gamma=gamma, mu=mu, init_diagonal_load=init_diagonal_load,
+                            regularization_param=regularization_param, sil_thresh=sil_thresh,
+                            constraint_option=constraint_option, alpha2=alpha2, max_wa_l2norm=max_wa_l2norm,
+                            min_frames=min_frames)
+        self._state = None
+        self._vs = None
+        self._Y = None
+        self._frames = None
+
+    def calc_beamformer_weights(self, samplerate, delays):
+        """pybeamformer.py:900-908."""
+        K = self._fftlen2 + 1
+        self._vs = np.stack([calc_array_manifold_f(m, self._fftlen, samplerate, delays, False) for m in range(K)])
+        self._wqH = np.conjugate(self._vs)
+        self._state = None
+        self._Y = None
+        self._frames = None
+
+    def _blocking(self, m):
+        return calc_blocking_matrix(self._vs[m], self._Nc)
+
+    def reset_stats(self):
+        if self._state is not None:
+            self._state.reset_stats()
+
+    def device_block(self):
+        import torch
+        if self._Y is None:
+            assert self._vs is not None, "call calc_beamformer_weights() first"
+            X = self._front.device_snapshots()
+            if self._state is None:
+                self._state = engine.RLSState(1, 1, self._fftlen, self._chan_num,
+                                              torch.from_numpy(np.ascontiguousarray(self._vs)).to(device()), **self._params)
+            self._Y = engine.rls_process(X, self._state)
+        return self._Y
+
+    def __iter__(self):
+        Y = self.device_block()
+        if self._frames is None:
+            self._frames = _mirror(Y[0].cpu().numpy(), self._fftlen)
+        for t in range(self._frames.shape[0]):
+            yield self._frames[t]
+
+    def _export(self):
+        K = self._fftlen2 + 1
+        P = self._state.P[0].cpu().numpy()
+        w = self._state.w[0].cpu().numpy()
+        return [engine.rls_state_to_reference(1, P[m], w[m], self._blocking(m)) for m in range(K)]
+
+    @property
+    def _waH(self):
+        if self._state is None or self._vs is None:
+            return np.zeros((self._fftlen2 + 1, self._chan_num - 1), complex)
+        return np.stack([e[1] for e in self._export()])
+
+    @_waH.setter
+    def _waH(self, v):
+        pass
+
+    @property
+    def _Pz(self):
+        if self._state is None or self._vs is None:
+            n = self._chan_num - 1
+            return [np.identity(n) / self._params["init_diagonal_load"] for _ in range(self._fftlen2 + 1)]
+        return [e[0] for e in self._export()]
+
+    def reset(self):
+        self._front.reset()
+        self.reset_stats()
+        self._Y = None
+        self._frames = None
+
+
 class SubbandSMIMVDRBeamformer(SubbandMVDRBeamformer):
     """pybeamformer.py:930-1019: MVDR by sample matrix inversion."""
 

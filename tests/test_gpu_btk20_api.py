@@ -136,6 +136,55 @@ def test_gsclms_flow(orc, dev, proto256, kinect_pcm, wavs):
     assert np.max(np.abs(beamformer._waH - o.wa())) < 2e-4
 
 
+def test_gscrls_flow(orc, dev, proto256, kinect_pcm, wavs):
+    """unit_test/test_online_beamforming.py with confs/gscrls.json (beamformer type "gscrls"): same script shape"""
+    from distant_speech_recognition_amd.btk20 import PyVectorComplexFeatureStreamPtr, OverSampledDFTSynthesisBankPtr
+    from distant_speech_recognition_amd.pybeamformer import SubbandGSCRLSBeamformer, calc_delays
+    h, g = proto256
+    _, afbs = _build(wavs, h)
+    beamformer = SubbandGSCRLSBeamformer(afbs, min_frames=32)
+    sfb = OverSampledDFTSynthesisBankPtr(PyVectorComplexFeatureStreamPtr(beamformer), prototype=g, M=M, m=m, r=r,
+                                         delay_compensation_type=2)
+    delays = calc_delays("linear", MPOS, [AZIMUTH, None, None])
+    beamformer.calc_beamformer_weights(FS, delays)
+    out = np.concatenate([np.array(buf) for buf in sfb])
+    X = _oracle_X(orc, h, kinect_pcm)
+    o = orc.RLSPy(M, 4, 1, min_frames=32)
+    o.calc_beamformer_weights(FS, delays)
+    ref = orc.synthesis(g, M, m, r, 2, o.run(X))
+    assert out.shape == ref.shape
+    assert np.max(np.abs(out - ref)) < 1e-4 * np.max(np.abs(ref)) + 0.5
+    assert np.max(np.abs(beamformer._waH - o.waH)) < 2e-4 * max(1.0, np.max(np.abs(o.waH)))
+
+
+def test_subband_gscrls_node(orc, dev, proto256, kinect_pcm, wavs):
+    """C++-style node SubbandGSCRLS (beamformer.h:224-263): calc_gsc_weights -> init_precision_matrix -> next()"""
+    from distant_speech_recognition_amd.btk20 import SubbandGSCRLSPtr, j_error
+    h, g = proto256
+    _, afbs = _build(wavs, h)
+    bf = SubbandGSCRLSPtr(fftlen=M, half_band_shift=False, mu=0.97, sigma2=0.001)
+    for a in afbs:
+        bf.set_channel(a)
+    from distant_speech_recognition_amd.pybeamformer import calc_delays
+    delays = calc_delays("linear", MPOS, [AZIMUTH, None, None])
+    with pytest.raises(j_error):
+        bf.init_precision_matrix(1.0e6)                 # "call calc_gsc_weights_x() once"
+    bf.calc_gsc_weights(FS, delays)
+    with pytest.raises(j_error):
+        bf.next()                                       # precision matrix not set
+    bf.init_precision_matrix(1.0e6)
+    bf.set_quadratic_constraint(0.1, 2)
+    frames = np.stack([np.array(f) for f in bf])
+    X = _oracle_X(orc, h, kinect_pcm)
+    o = orc.RLSCc(M, 4, delays, FS, mu=0.97, sigma2=0.001)
+    o.init_precision_matrix(1.0e6)
+    o.set_quadratic_constraint(0.1, 2)
+    ref = o.run(X)
+    assert frames.shape == ref.shape
+    assert np.max(np.abs(frames - ref)) <= 1e-4 * np.max(np.abs(ref))
+    assert np.max(np.abs(bf._bfw[0].wl[: M // 2 + 1] - o.wl[: M // 2 + 1])) <= 1e-4 * max(np.max(np.abs(o.wl)), 1e-30)
+
+
 def test_smimvdr_batch_flow(orc, dev, proto256, kinect_pcm, wavs):
     from distant_speech_recognition_amd.btk20 import PyVectorComplexFeatureStreamPtr, OverSampledDFTSynthesisBankPtr
     from distant_speech_recognition_amd.pybeamformer import SubbandSMIMVDRBeamformer, calc_delays
