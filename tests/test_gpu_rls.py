@@ -79,6 +79,7 @@ def test_rls_vs_reference_python_golden(orc, dev, proto256, kinect_pcm, pygolden
     (7, 64, 60, 3, dict(min_frames=10, constraint_option=1, alpha2=1e-5, regularization_param=0.0)),
     (16, 64, 50, 1, dict(min_frames=2, constraint_option=2, max_wa_l2norm=1e-4)),
     (33, 32, 40, 1, dict(min_frames=2)),
+    (8, 32, 2500, 1, dict(min_frames=64)),                       # long run: the per-tile re-projection must not drift
     (64, 32, 100, 1, dict(min_frames=2, gamma=0.2, constraint_option=2, max_wa_l2norm=0.05)),
 ])
 def test_rls_py_matches_oracle_synthetic(orc, dev, N, M, T, S, kw):
