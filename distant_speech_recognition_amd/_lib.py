@@ -59,6 +59,10 @@ SIGNATURES = {
     "btk_rls_process": (_i, [_i, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _l, _l, _vp, _vp, _vp, _vp, _vp]),
     "btk_bf_apply_stats": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _l, _l, _vp]),
     "btk_zelinski_process": (_i, [_vp, _vp, _vp, _i, _i, _i, _l, _l, _d, _i, _i, _l, _vp, _vp, _vp, _vp]),
+    "btk_pf_coherence_coeffs": (_i, [_vp, _f, _i, _i, _vp, _vp, _vp]),
+    "btk_bf_apply_stats2": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _l, _l, _vp]),
+    "btk_lefkimmiatis_process": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _l, _l, _d, _i, _i, _l, _vp, _vp, _vp, _vp]),
+    "btk_mvdr_lambda": (_i, [_vp, _vp, _vp, _i, _i, _f, _vp, _vp, _vp]),
     "btk_frame_energy": (_i, [_vp, _i, _i, _i, _l, _l, _vp, _l, _vp]),
     "btk_cov_frame_gate": (_i, [_vp, _vp, _i, _l, _l, _f, _vp, _vp, _vp]),
     "btk_cov_accumulate": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _l, _l, _i, _vp]),

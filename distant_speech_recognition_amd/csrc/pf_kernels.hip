@@ -114,6 +114,191 @@ void zelinski_iir_kernel(float2* __restrict__ Y, const float2* __restrict__ Cc, 
   if (lane == 0) { Phi[row] = phi_c; Psi[row] = psi_c; Wlast[row] = wlast; }
 }
 
+// ------------------------------------------------------------------------------------------------
+// McCowan / Lefkimmiatis post-filters (postfilter/postfilter.cc:496-1190).
+//
+// Their gains need per-pair weights: clean PSD  sum_{i<j} (phi_ij - R_ij (phi_ii + phi_jj)/2) / (1 - R_ij)   (:798-829)
+//                                    noise PSD  sum_{i<j} ((phi_ii + phi_jj)/2 - phi_ij) / (1 - R_ij)         (:1041-1077)
+// with the coherence R_ij clipped at threshold_of_Rij_.  Every phi obeys the same first-order recursion, and the
+// sums are LINEAR in the phi, so -- as for Zelinski -- only the recursively averaged sums are state:
+//     U_t = a_t U_{t-1} + b_t u_t,   u_t = sum_{i<=j} Cs[j][i] x'_i conj(x'_j)
+//     V_t = a_t V_{t-1} + b_t v_t,   v_t = sum_{i<=j} Cv[j][i] x'_i conj(x'_j)
+// with per-bin coefficient matrices built once from R (pf_coherence_coeff_kernel): off-diagonal 1/(1-R_ij) resp.
+// -1/(1-R_ij), diagonal = the collected (phi_ii + phi_jj)/2 terms.  McCowan: W = g(U) / Psi * 2/(N-1) -- the
+// Zelinski formula with Phi replaced by U, so btk_zelinski_process is reused.  Lefkimmiatis: W = g(U)/(g(U) + g(V)/L).
+//
+//   3. pf_coherence_coeff_kernel : R [K][N][N] -> Cs, Cv [K][N][N] (row j holds i <= j), float64 arithmetic
+//   4. bf_apply_stats2_kernel    : y_t, e_t and the quadratic forms u_t (v_t); lanes own frames, 16 rows of C at a
+//                                  time in registers, C entries are wave-uniform (scalar loads), outer sums in float64
+//   5. lefkimmiatis_iir_kernel   : the same chunked linear-recurrence scan as zelinski_iir_kernel on (U, V)
+__global__ __launch_bounds__(64)
+void pf_coherence_coeff_kernel(const float2* __restrict__ R, float threshold, int N,
+                               float2* __restrict__ Cs, float2* __restrict__ Cv /* nullable */)
+{
+  const int k = blockIdx.x;
+  const float2* Rk = R + (long)k * N * N;
+  const double thr = (double)threshold;
+  for (int j = threadIdx.x; j < N; j += 64) {
+    double dsr = 0.0, dsi = 0.0, dvr = 0.0, dvi = 0.0;
+    for (int i = 0; i < N; i++) {
+      if (i == j) continue;
+      const int a = i < j ? i : j, b = i < j ? j : i;              // only the upper triangle R[a][b], a < b, is read
+      const float2 rf = Rk[(long)a * N + b];
+      // clean PSD rule (:813-815)
+      double rr = rf.x, ri = rf.y;
+      if (rr > thr && ri <= 0.0) { rr = thr; ri = 0.0; }
+      double dr = 1.0 - rr, di = -ri, dn = dr * dr + di * di;
+      const double csr = dr / dn, csi = -di / dn;                  // 1 / (1 - R)
+      // - 0.5 R / (1 - R) goes to both diagonal entries of the pair
+      dsr -= 0.5 * (csr * rr - csi * ri); dsi -= 0.5 * (csr * ri + csi * rr);
+      if (i < j) Cs[((long)k * N + j) * N + i] = make_float2((float)csr, (float)csi);
+      else Cs[((long)k * N + j) * N + i] = make_float2(0.f, 0.f);
+      if (Cv) {
+        // noise PSD rule (:1057-1062)
+        double qr = rf.x, qi = rf.y;
+        if (qr > thr) { qr = thr; qi = 0.0; }
+        else if (qr == 1.0) { qr = 0.99; qi = 0.0; }
+        dr = 1.0 - qr; di = -qi; dn = dr * dr + di * di;
+        const double cvr = dr / dn, cvi = -di / dn;
+        dvr += 0.5 * cvr; dvi += 0.5 * cvi;
+        if (i < j) Cv[((long)k * N + j) * N + i] = make_float2((float)-cvr, (float)-cvi);
+        else Cv[((long)k * N + j) * N + i] = make_float2(0.f, 0.f);
+      }
+    }
+    Cs[((long)k * N + j) * N + j] = make_float2((float)dsr, (float)dsi);
+    if (Cv) Cv[((long)k * N + j) * N + j] = make_float2((float)dvr, (float)dvi);
+  }
+}
+
+constexpr int PF_JB = 16;
+
+template <int NQ>
+__global__ __launch_bounds__(PF_NT)
+void bf_apply_stats2_kernel(const float2* __restrict__ W, long w_stream_stride, const float2* __restrict__ Dv,
+                            const float2* __restrict__ X, float2* __restrict__ Y,
+                            const float2* __restrict__ Cs, const float2* __restrict__ Cv,
+                            float2* __restrict__ U, float2* __restrict__ V, float* __restrict__ Ee,
+                            int K, int N, long T_stride, long T)
+{
+  const int k = blockIdx.y, s = blockIdx.z;
+  const long t = (long)blockIdx.x * PF_NT + threadIdx.x;
+  if (t >= T) return;
+  const float2* w = W + s * w_stream_stride + (long)k * N;
+  const float2* d = Dv + s * w_stream_stride + (long)k * N;
+  const float2* x = X + ((long)s * K + k) * N * T_stride + t;
+  const float2* cs = Cs + (long)k * N * N;
+  const float2* cv = (NQ == 2) ? Cv + (long)k * N * N : nullptr;
+  float yr = 0.f, yi = 0.f, e = 0.f;
+#pragma unroll 8
+  for (int n = 0; n < N; n++) {
+    const float2 v = x[(long)n * T_stride];
+    const float2 wn = w[n], dn = d[n];
+    yr = fmaf(wn.x, v.x, fmaf(wn.y, v.y, yr));
+    yi = fmaf(wn.x, v.y, fmaf(-wn.y, v.x, yi));
+    const float ar = fmaf(dn.x, v.x, dn.y * v.y), ai = fmaf(dn.x, v.y, -dn.y * v.x);
+    e = fmaf(ar, ar, fmaf(ai, ai, e));
+  }
+  double ur = 0.0, ui = 0.0, vr = 0.0, vi = 0.0;
+  for (int jb = 0; jb < N; jb += PF_JB) {
+    float ar[PF_JB], ai[PF_JB], br[PF_JB], bi[PF_JB];
+#pragma unroll
+    for (int jj = 0; jj < PF_JB; jj++) { ar[jj] = ai[jj] = 0.f; br[jj] = bi[jj] = 0.f; }
+    const int iend = (jb + PF_JB < N) ? jb + PF_JB : N;
+    for (int i = 0; i < iend; i++) {
+      const float2 xv = x[(long)i * T_stride];
+      const float2 dn = d[i];
+      const float xr = fmaf(dn.x, xv.x, dn.y * xv.y), xi = fmaf(dn.x, xv.y, -dn.y * xv.x);   // x'_i = conj(d_i) x_i
+#pragma unroll
+      for (int jj = 0; jj < PF_JB; jj++) {
+        const int j = (jb + jj < N) ? jb + jj : N - 1;            // clamped rows are never used
+        const float2 c = cs[(long)j * N + i];                     // wave-uniform
+        ar[jj] = fmaf(c.x, xr, fmaf(-c.y, xi, ar[jj]));
+        ai[jj] = fmaf(c.x, xi, fmaf(c.y, xr, ai[jj]));
+        if (NQ == 2) {
+          const float2 c2 = cv[(long)j * N + i];
+          br[jj] = fmaf(c2.x, xr, fmaf(-c2.y, xi, br[jj]));
+          bi[jj] = fmaf(c2.x, xi, fmaf(c2.y, xr, bi[jj]));
+        }
+      }
+    }
+#pragma unroll
+    for (int jj = 0; jj < PF_JB; jj++) {
+      const int j = jb + jj;
+      if (j < N) {
+        const float2 xv = x[(long)j * T_stride];
+        const float2 dn = d[j];
+        const double xr = fmaf(dn.x, xv.x, dn.y * xv.y), xi = fmaf(dn.x, xv.y, -dn.y * xv.x);
+        ur += xr * (double)ar[jj] + xi * (double)ai[jj];          // conj(x'_j) a_j
+        ui += xr * (double)ai[jj] - xi * (double)ar[jj];
+        if (NQ == 2) {
+          vr += xr * (double)br[jj] + xi * (double)bi[jj];
+          vi += xr * (double)bi[jj] - xi * (double)br[jj];
+        }
+      }
+    }
+  }
+  const long o = ((long)s * K + k) * T_stride + t;
+  Y[o] = make_float2(yr, yi);
+  U[o] = make_float2((float)ur, (float)ui);
+  if (NQ == 2) V[o] = make_float2((float)vr, (float)vi);
+  Ee[o] = e;
+}
+
+// One wavefront per (s,k): W = g(U) / (g(U) + g(V) / Lambda_k), Lambda_k = 1 for k < fbinX1 (postfilter.cc:1122-1135)
+__global__ __launch_bounds__(64)
+void lefkimmiatis_iir_kernel(float2* __restrict__ Y, const float2* __restrict__ Uc, const float2* __restrict__ Vc,
+                             const float2* __restrict__ Lambda /* [K] */, int fbinX1,
+                             int K, long T_stride, long T, float alpha, int type, int min_frames, long frame_base,
+                             float2* __restrict__ Us /* [S][K] */, float2* __restrict__ Vs /* [S][K] */,
+                             float* __restrict__ Wlast)
+{
+  const int k = blockIdx.x, s = blockIdx.y;
+  const int lane = threadIdx.x;
+  const long row = ((long)s * K + k);
+  float2 u_c = Us[row], v_c = Vs[row];
+  float wlast = Wlast[row];
+  float lam = 1.f;
+  if (k >= fbinX1) { const float2 L = Lambda[k]; lam = (type & 1) ? L.x : sqrtf(L.x * L.x + L.y * L.y); }
+  for (long t0 = 0; t0 < T; t0 += 64) {
+    const long t = t0 + lane;
+    const bool ok = t < T;
+    const long g = frame_base + t;
+    float a = ok ? ((g >= 2) ? alpha : 0.f) : 1.f;
+    const float bsc = (g >= 2 && alpha > 0.f) ? 1.f - alpha : 1.f;
+    if (alpha <= 0.f) a = ok ? 0.f : 1.f;
+    const float2 cu = ok ? Uc[row * T_stride + t] : make_float2(0.f, 0.f);
+    const float2 cvv = ok ? Vc[row * T_stride + t] : make_float2(0.f, 0.f);
+    float b0 = ok ? bsc * cu.x : 0.f, b1 = ok ? bsc * cu.y : 0.f, b2 = ok ? bsc * cvv.x : 0.f, b3 = ok ? bsc * cvv.y : 0.f;
+#pragma unroll
+    for (int dlt = 1; dlt < 64; dlt <<= 1) {
+      const float a2 = __shfl_up(a, dlt, 64);
+      const float p0 = __shfl_up(b0, dlt, 64), p1 = __shfl_up(b1, dlt, 64), p2 = __shfl_up(b2, dlt, 64), p3 = __shfl_up(b3, dlt, 64);
+      if (lane >= dlt) {
+        b0 = fmaf(a, p0, b0); b1 = fmaf(a, p1, b1); b2 = fmaf(a, p2, b2); b3 = fmaf(a, p3, b3);
+        a *= a2;
+      }
+    }
+    const float u0 = fmaf(a, u_c.x, b0), u1 = fmaf(a, u_c.y, b1), v0 = fmaf(a, v_c.x, b2), v1 = fmaf(a, v_c.y, b3);
+    if (ok) {
+      const float gs = (type & 1) ? u0 : sqrtf(u0 * u0 + u1 * u1);
+      const float gv = (type & 1) ? v0 : sqrtf(v0 * v0 + v1 * v1);
+      float Wf = gs / (gs + gv / lam);
+      if (Wf > 1.0f) Wf = 1.0f;
+      if (Wf < 1.0e-4f) Wf = 1.0e-4f;
+      if ((g - 1) >= (long)min_frames) {
+        const float2 y = Y[row * T_stride + t];
+        Y[row * T_stride + t] = make_float2(Wf * y.x, Wf * y.y);
+      }
+      wlast = Wf;
+    }
+    const int last = (T - t0) >= 64 ? 63 : (int)(T - t0) - 1;
+    u_c = make_float2(__shfl(u0, last, 64), __shfl(u1, last, 64));
+    v_c = make_float2(__shfl(v0, last, 64), __shfl(v1, last, 64));
+    wlast = __shfl(wlast, last, 64);
+  }
+  if (lane == 0) { Us[row] = u_c; Vs[row] = v_c; Wlast[row] = wlast; }
+}
+
 }  // namespace
 
 extern "C" {
@@ -148,6 +333,59 @@ int btk_zelinski_process(void* Y, const void* C, const float* E, int S, int K, i
   hipLaunchKernelGGL(zelinski_iir_kernel, dim3((unsigned)K, (unsigned)S), dim3(64), 0, as_stream(stream),
                      static_cast<float2*>(Y), static_cast<const float2*>(C), E, K, N, T_stride, T,
                      (float)alpha, type, min_frames, frames_done, static_cast<float2*>(phi_state), psi_state, w_last);
+  BTK_HIP_CHECK(hipGetLastError());
+  return BTK_OK;
+}
+
+int btk_pf_coherence_coeffs(const void* R, float threshold, int K, int N, void* Cs, void* Cv, void* stream)
+{
+  if (!R || !Cs) return btk_set_error(BTK_ERR_PARAMETER, "construct/set a noise coherence matrix");
+  if (K <= 0 || N <= 1) return btk_set_error(BTK_ERR_DIMENSION, "btk_pf_coherence_coeffs: bad sizes K=%d N=%d", K, N);
+  hipLaunchKernelGGL(pf_coherence_coeff_kernel, dim3((unsigned)K), dim3(64), 0, as_stream(stream),
+                     static_cast<const float2*>(R), threshold, N, static_cast<float2*>(Cs), static_cast<float2*>(Cv));
+  BTK_HIP_CHECK(hipGetLastError());
+  return BTK_OK;
+}
+
+int btk_bf_apply_stats2(const void* W, const void* D, int per_stream_weights, const void* X, void* Y,
+                        const void* Cs, const void* Cv, void* U, void* V, float* E,
+                        int S, int K, int N, long T_stride, long T, void* stream)
+{
+  if (!W || !D || !X || !Y || !Cs || !U || !E) return btk_set_error(BTK_ERR_PARAMETER, "btk_bf_apply_stats2: null argument");
+  if ((Cv == nullptr) != (V == nullptr)) return btk_set_error(BTK_ERR_PARAMETER, "btk_bf_apply_stats2: Cv and V go together");
+  if (S <= 0 || K <= 0 || N <= 1 || T < 0 || T_stride < T)
+    return btk_set_error(BTK_ERR_DIMENSION, "btk_bf_apply_stats2: bad sizes S=%d K=%d N=%d T=%ld", S, K, N, T);
+  if (T == 0) return BTK_OK;
+  const long wss = per_stream_weights ? (long)K * N : 0;
+  dim3 grid((unsigned)((T + PF_NT - 1) / PF_NT), (unsigned)K, (unsigned)S);
+  if (Cv)
+    hipLaunchKernelGGL(bf_apply_stats2_kernel<2>, grid, dim3(PF_NT), 0, as_stream(stream),
+                       static_cast<const float2*>(W), wss, static_cast<const float2*>(D), static_cast<const float2*>(X),
+                       static_cast<float2*>(Y), static_cast<const float2*>(Cs), static_cast<const float2*>(Cv),
+                       static_cast<float2*>(U), static_cast<float2*>(V), E, K, N, T_stride, T);
+  else
+    hipLaunchKernelGGL(bf_apply_stats2_kernel<1>, grid, dim3(PF_NT), 0, as_stream(stream),
+                       static_cast<const float2*>(W), wss, static_cast<const float2*>(D), static_cast<const float2*>(X),
+                       static_cast<float2*>(Y), static_cast<const float2*>(Cs), static_cast<const float2*>(nullptr),
+                       static_cast<float2*>(U), static_cast<float2*>(nullptr), E, K, N, T_stride, T);
+  BTK_HIP_CHECK(hipGetLastError());
+  return BTK_OK;
+}
+
+int btk_lefkimmiatis_process(void* Y, const void* U, const void* V, const void* lambda, int fbinX1,
+                             int S, int K, int N, long T_stride, long T, double alpha, int type, int min_frames,
+                             long frames_done, void* u_state, void* v_state, float* w_last, void* stream)
+{
+  if (!Y || !U || !V || !lambda || !u_state || !v_state || !w_last)
+    return btk_set_error(BTK_ERR_PARAMETER, "btk_lefkimmiatis_process: null argument");
+  if (N <= 1) return btk_set_error(BTK_ERR_DIMENSION, "The number of channels %d is <= 1 ", N);
+  if (S <= 0 || K <= 0 || T < 0 || T_stride < T || fbinX1 < 0)
+    return btk_set_error(BTK_ERR_DIMENSION, "btk_lefkimmiatis_process: bad sizes S=%d K=%d T=%ld", S, K, T);
+  if (T == 0) return BTK_OK;
+  hipLaunchKernelGGL(lefkimmiatis_iir_kernel, dim3((unsigned)K, (unsigned)S), dim3(64), 0, as_stream(stream),
+                     static_cast<float2*>(Y), static_cast<const float2*>(U), static_cast<const float2*>(V),
+                     static_cast<const float2*>(lambda), fbinX1, K, T_stride, T, (float)alpha, type, min_frames,
+                     frames_done, static_cast<float2*>(u_state), static_cast<float2*>(v_state), w_last);
   BTK_HIP_CHECK(hipGetLastError());
   return BTK_OK;
 }

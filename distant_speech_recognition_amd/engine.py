@@ -401,6 +401,91 @@ def bf_apply_zelinski(W, D, X, state, alpha=0.6, type_=2, min_frames=0, out=None
     return out
 
 
+class CoherencePostFilterState:
+    """State of S McCowan / Lefkimmiatis post-filters: the recursively averaged weighted CSD sums (see
+    csrc/pf_kernels.hip) plus the per-bin pair-weight matrices built from the noise coherence matrix R_."""
+
+    def __init__(self, S, K, N, device, lefkimmiatis=False):
+        self.S, self.K, self.N = S, K, N
+        self.lefkimmiatis = bool(lefkimmiatis)
+        self.u = torch.zeros((S, K), dtype=torch.complex64, device=device)
+        self.v = torch.zeros((S, K), dtype=torch.complex64, device=device)     # Lefkimmiatis only
+        self.psi = torch.zeros((S, K), dtype=torch.float32, device=device)     # McCowan only
+        self.w_last = torch.zeros((S, K), dtype=torch.float32, device=device)
+        self.Cs = self.Cv = self.lam = None
+        self.frames_done = 0
+
+    def set_coherence(self, R, threshold=0.99):
+        """R complex64 [K][N][N] (cuda): R_ after set_diffuse_noise_model / set_noise_spatial_spectral_matrix /
+        diagonal loading (postfilter.cc:536-660); threshold = threshold_of_Rij_."""
+        _need_cuda(R, "R")
+        K, N = self.K, self.N
+        if tuple(R.shape) != (K, N, N):
+            raise _lib.BtkError(_lib.BTK_ERR_DIMENSION, "set_coherence: R must be [K][N][N]")
+        self.Cs = torch.empty((K, N, N), dtype=torch.complex64, device=R.device)
+        self.Cv = torch.empty((K, N, N), dtype=torch.complex64, device=R.device) if self.lefkimmiatis else None
+        check(_lib.lib().btk_pf_coherence_coeffs(_ptr(R.contiguous()), float(np.float32(threshold)), K, N, _ptr(self.Cs),
+                                                 None if self.Cv is None else _ptr(self.Cv), _stream()))
+
+    def set_lambda(self, R, d, min_sv=1.0e-8):
+        """Lambda_k = d^H pinv(R_k) d (calcLambda, postfilter.cc:982-995) for all bins; returns the number of bins
+        that fell back to the identity (:975-977)."""
+        _need_cuda(R, "R"); _need_cuda(d, "d")
+        K, N = self.K, self.N
+        self.lam = torch.empty((K,), dtype=torch.complex64, device=R.device)
+        fb = torch.zeros(1, dtype=torch.int32, device=R.device)
+        scratch = None
+        if 2064 + 8 * (N * N + N) > 150 * 1024:
+            scratch = torch.empty((K, N, N), dtype=torch.complex64, device=R.device)
+        check(_lib.lib().btk_mvdr_lambda(_ptr(R.contiguous()), _ptr(d.contiguous()), _ptr(self.lam), K, N, float(min_sv),
+                                         None if scratch is None else _ptr(scratch), _ptr(fb), _stream()))
+        return int(fb.item())
+
+
+def bf_apply_mccowan(W, D, X, state, alpha=0.6, type_=2, min_frames=0, out=None):
+    """Beamform + McCowan post-filter over a block.  W, D complex64 [S|1][K][N]; X [S][K][N][T] -> Y [S][K][T]."""
+    _need_cuda(W, "W"); _need_cuda(D, "D"); _need_cuda(X, "X")
+    S, K, N, T = X.shape
+    if state.Cs is None:
+        raise _lib.BtkError(_lib.BTK_ERR_PARAMETER, "McCowanPostFilter:  construct/set a noise coherence matrix")
+    if W.dim() == 2:
+        W, D = W.unsqueeze(0), D.unsqueeze(0)
+    if out is None:
+        out = torch.empty((S, K, T), dtype=torch.complex64, device=X.device)
+    U = torch.empty((S, K, T), dtype=torch.complex64, device=X.device)
+    Ee = torch.empty((S, K, T), dtype=torch.float32, device=X.device)
+    L = _lib.lib()
+    check(L.btk_bf_apply_stats2(_ptr(W), _ptr(D), int(W.shape[0] == S and S > 1), _ptr(X), _ptr(out), _ptr(state.Cs), None,
+                                _ptr(U), None, _ptr(Ee), S, K, N, T, T, _stream()))
+    check(L.btk_zelinski_process(_ptr(out), _ptr(U), _ptr(Ee), S, K, N, T, T, float(alpha), int(type_) & 3, int(min_frames),
+                                 state.frames_done, _ptr(state.u), _ptr(state.psi), _ptr(state.w_last), _stream()))
+    state.frames_done += T
+    return out
+
+
+def bf_apply_lefkimmiatis(W, D, X, state, fbin_x1=0, alpha=0.6, type_=2, min_frames=0, out=None):
+    """Beamform + Lefkimmiatis post-filter over a block (D = array manifold)."""
+    _need_cuda(W, "W"); _need_cuda(D, "D"); _need_cuda(X, "X")
+    S, K, N, T = X.shape
+    if state.Cs is None or state.Cv is None or state.lam is None:
+        raise _lib.BtkError(_lib.BTK_ERR_PARAMETER, "LefkimmiatisPostFilter:  construct/set a noise coherence matrix")
+    if W.dim() == 2:
+        W, D = W.unsqueeze(0), D.unsqueeze(0)
+    if out is None:
+        out = torch.empty((S, K, T), dtype=torch.complex64, device=X.device)
+    U = torch.empty((S, K, T), dtype=torch.complex64, device=X.device)
+    V = torch.empty((S, K, T), dtype=torch.complex64, device=X.device)
+    Ee = torch.empty((S, K, T), dtype=torch.float32, device=X.device)
+    L = _lib.lib()
+    check(L.btk_bf_apply_stats2(_ptr(W), _ptr(D), int(W.shape[0] == S and S > 1), _ptr(X), _ptr(out), _ptr(state.Cs),
+                                _ptr(state.Cv), _ptr(U), _ptr(V), _ptr(Ee), S, K, N, T, T, _stream()))
+    check(L.btk_lefkimmiatis_process(_ptr(out), _ptr(U), _ptr(V), _ptr(state.lam), int(fbin_x1), S, K, N, T, T, float(alpha),
+                                     int(type_), int(min_frames), state.frames_done, _ptr(state.u), _ptr(state.v),
+                                     _ptr(state.w_last), _stream()))
+    state.frames_done += T
+    return out
+
+
 # ---------------------------------------------------------------------------- covariance accumulation
 def frame_energy(X, M):
     _need_cuda(X, "X")

@@ -160,6 +160,27 @@ int  btk_zelinski_process(void* Y, const void* C, const float* E, int S, int K, 
                           double alpha, int type, int min_frames, long frames_done,
                           void* phi_state, float* psi_state, float* w_last, void* stream);
 
+/* ---- McCowan / Lefkimmiatis post-filters ----------------------------------------------------------
+ * Replace McCowanPostFilter::{estimate_average_clean_PSD_, post_filtering_, next} (postfilter/postfilter.cc:798-935)
+ * and LefkimmiatisPostFilter::{calc_inverse_noise_spatial_spectral_matrix, calcLambda, estimate_average_noise_PSD_,
+ * post_filtering_, next} (:967-1190).  R [dev] complex64 [K][N][N] is the noise coherence matrix R_ (build it with
+ * btk_mvdr_diffuse_model == set_diffuse_noise_model :560-618, btk_mvdr_diagonal_loading == set_all_diagonal_loading
+ * :620-632).  btk_pf_coherence_coeffs turns it (with threshold_of_Rij_) into the pair-weight matrices Cs (clean PSD)
+ * and Cv (noise PSD, may be NULL for McCowan), complex64 [K][N][N].  btk_bf_apply_stats2 = btk_bf_apply plus, from
+ * the same snapshots, the per-frame quadratic forms U (and V) complex64 [S][K][T_stride] and E (as btk_bf_apply_stats).
+ *   McCowan:      btk_zelinski_process(Y, U, E, ...) -- the gain formula is Zelinski's with the weighted sum.
+ *   Lefkimmiatis: btk_lefkimmiatis_process(Y, U, V, lambda, fbinX1, ...), lambda [dev] complex64 [K] = d^H pinv(R) d
+ *                 from btk_mvdr_lambda (Cholesky with the identity fallback of :975-977), state u/v complex64 [S][K]. */
+int  btk_pf_coherence_coeffs(const void* R, float threshold, int K, int N, void* Cs, void* Cv, void* stream);
+int  btk_bf_apply_stats2(const void* W, const void* D, int per_stream_weights, const void* X, void* Y,
+                         const void* Cs, const void* Cv, void* U, void* V, float* E,
+                         int S, int K, int N, long T_stride, long T, void* stream);
+int  btk_lefkimmiatis_process(void* Y, const void* U, const void* V, const void* lambda, int fbinX1,
+                              int S, int K, int N, long T_stride, long T, double alpha, int type, int min_frames,
+                              long frames_done, void* u_state, void* v_state, float* w_last, void* stream);
+int  btk_mvdr_lambda(const void* R, const void* d, void* lambda, int K, int N, float threshold,
+                     void* scratch, int* fallback_count, void* stream);
+
 /* ---- Spatial covariance accumulation ----------------------------------------------------------
  * btk_frame_energy: |X_0^H X_0| / M of channel 0 over all M bins, per frame
  *   (MultiChannelSource.update_snapshot_array, lib/pybeamformer.py:263-277); energy [dev] [S][e_stride].

@@ -1220,3 +1220,142 @@ void orc_rls_cc_frame(unsigned M, unsigned N, unsigned Nc, double mu, double dia
   }
   free(Zf); free(PzHZ); free(gz); free(wa); free(w);
 }
+
+/* ------------------------------------------------------------------------
+ * McCowan / Lefkimmiatis post-filters ("next" row of the survey), postfilter/postfilter.cc.
+ * C++ only (needs GSL) -> restated, output-level parity UNPINNED.
+ * ---------------------------------------------------------------------- */
+/* calculateSpectralDensities_f: postfilter.cc:692-736.  csd [N*N] in/out; returns sumOfPSD / N */
+static double spectral_densities_f(const cplx* ta, unsigned N, cplx* csd, double alpha)
+{
+  double sum_psd = 0.0;
+  for (unsigned i = 0; i + 1 < N; i++)
+    for (unsigned j = i + 1; j < N; j++) {
+      unsigned idx = i * N + j;
+      cplx xx = c_mul(ta[i], c_conj(ta[j]));                                       /* calc_CSD_ :8-21 */
+      csd[idx] = (alpha > 0.0) ? c_add(c_scale(csd[idx], alpha), c_scale(xx, 1.0 - alpha)) : xx;
+    }
+  for (unsigned i = 0; i < N; i++) {
+    unsigned idx = i * N + i;
+    double est = (alpha > 0.0) ? alpha * csd[idx].re + (1.0 - alpha) * c_abs2(ta[i]) : c_abs2(ta[i]);
+    sum_psd += est;
+    csd[idx] = c_make(est, 0.0);
+  }
+  return sum_psd / N;
+}
+
+/* McCowanPostFilter::estimate_average_clean_PSD_ (non-ORIGINAL_IAIN_PAPER branch): postfilter.cc:798-829 */
+static double mccowan_clean_psd(const cplx* R, const cplx* csd, unsigned N, double thr, int type)
+{
+  cplx sum = c_make(0, 0);
+  for (unsigned i = 0; i + 1 < N; i++) {
+    double phi_ii = csd[i * N + i].re;
+    for (unsigned j = i + 1; j < N; j++) {
+      cplx phi_ij = csd[i * N + j];
+      double phi_jj = csd[j * N + j].re;
+      cplx R_ij = R[i * N + j];
+      if (R_ij.re > thr && R_ij.im <= 0.0) R_ij = c_make(thr, 0);
+      cplx nu = c_sub(phi_ij, c_scale(R_ij, 0.5 * (phi_ii + phi_jj)));
+      cplx de = c_make(1.0 - R_ij.re, -R_ij.im);
+      sum = c_add(sum, c_div(nu, de));
+    }
+  }
+  double avg = (type & 1) ? sum.re : c_abs(sum);
+  return 2.0 * avg / (N * (N - 1.0));
+}
+
+/* LefkimmiatisPostFilter::estimate_average_noise_PSD_ (non-ORIGINAL branch): postfilter.cc:1041-1077 */
+static double lefkimmiatis_noise_psd(const cplx* R, const cplx* csd, unsigned N, double thr, int type)
+{
+  cplx sum = c_make(0, 0);
+  for (unsigned i = 0; i + 1 < N; i++) {
+    cplx phi_ii = csd[i * N + i];
+    for (unsigned j = i + 1; j < N; j++) {
+      cplx phi_ij = csd[i * N + j];
+      cplx phi_jj = csd[j * N + j];
+      cplx R_ij = R[i * N + j];
+      if (R_ij.re > thr) R_ij = c_make(thr, 0);
+      else if (R_ij.re == 1) R_ij = c_make(0.99, 0);
+      cplx nu = c_sub(c_scale(c_add(phi_ii, phi_jj), 0.5), phi_ij);
+      cplx de = c_make(1.0 - R_ij.re, -R_ij.im);
+      sum = c_add(sum, c_div(nu, de));
+    }
+  }
+  double avg = (type & 1) ? sum.re : c_abs(sum);
+  return 2.0 * avg / (N * (N - 1.0));
+}
+
+/* McCowanPostFilter::post_filtering_ for one frame: postfilter.cc:843-898.
+ * d [K..][N] = wq if (type & 8) else the array manifold (callers pass the right array); R [K][N][N];
+ * csds [K][N*N] in/out; wp [M] out; y [M] in/out; frame_no_pre = frame_no_ before increment_. */
+void orc_mccowan_frame(const cplx* d, const cplx* snapshots, const cplx* R, unsigned M, unsigned N,
+                       cplx* csds, cplx* wp, double alpha_cfg, int type, int min_frames, double thr,
+                       int frame_no_pre, cplx* y)
+{
+  unsigned M2 = M / 2;
+  double alpha = (frame_no_pre > 0) ? alpha_cfg : 0.0;                             /* :866-869 */
+  cplx* ta = (cplx*)malloc(sizeof(cplx) * N);
+  for (unsigned k = 0; k <= M2; k++) {
+    const cplx* dk = d + (size_t)k * N;
+    const cplx* x = snapshots + (size_t)k * N;
+    cplx* csd = csds + (size_t)k * N * N;
+    for (unsigned i = 0; i < N; i++) ta[i] = c_mul(c_conj(dk[i]), x[i]);            /* time_alignment_ :30-43 */
+    double de = spectral_densities_f(ta, N, csd, alpha);
+    double nu = mccowan_clean_psd(R + (size_t)k * N * N, csd, N, thr, type);
+    double weight = nu / de;
+    if (weight > 1.0) weight = 1.0;
+    if (weight < ORC_SPECTRAL_FLOOR) weight = ORC_SPECTRAL_FLOOR;
+    wp[k] = c_make(weight, 0);
+    if (k > 0 && k < M2) wp[M - k] = c_make(weight, 0);
+    if (frame_no_pre >= min_frames) {                                              /* :889-894 */
+      cplx o = c_scale(y[k], weight);
+      y[k] = o;
+      if (k > 0 && k < M2) y[M - k] = c_conj(o);
+    }
+  }
+  free(ta);
+}
+
+/* LefkimmiatisPostFilter::post_filtering_ for one frame: postfilter.cc:1081-1157 with calcLambda :982-995.
+ * d [K][N] = array manifold; invR [K][N][N] (pseudoinverse or identity, :967-980); fbinX1. */
+void orc_lefkimmiatis_frame(const cplx* d, const cplx* snapshots, const cplx* R, const cplx* invR, unsigned M,
+                            unsigned N, cplx* csds, cplx* wp, double alpha_cfg, int type, int min_frames,
+                            double thr, unsigned fbinX1, int frame_no_pre, cplx* y)
+{
+  unsigned M2 = M / 2;
+  double alpha = (frame_no_pre > 0) ? alpha_cfg : 0.0;                             /* :1104-1107 */
+  cplx* ta = (cplx*)malloc(sizeof(cplx) * N);
+  cplx* tmpH = (cplx*)malloc(sizeof(cplx) * N);
+  for (unsigned k = 0; k <= M2; k++) {
+    const cplx* dk = d + (size_t)k * N;
+    const cplx* x = snapshots + (size_t)k * N;
+    cplx* csd = csds + (size_t)k * N * N;
+    for (unsigned i = 0; i < N; i++) ta[i] = c_mul(c_conj(dk[i]), x[i]);
+    spectral_densities_f(ta, N, csd, alpha);
+    double phi_ss = mccowan_clean_psd(R + (size_t)k * N * N, csd, N, thr, type);
+    double phi_vv = lefkimmiatis_noise_psd(R + (size_t)k * N * N, csd, N, thr, type);
+    double weight;
+    if (k < fbinX1) weight = phi_ss / (phi_ss + phi_vv);
+    else {
+      const cplx* iR = invR + (size_t)k * N * N;
+      for (unsigned i = 0; i < N; i++) {                                           /* tmpH = invR^H d */
+        cplx a = c_make(0, 0);
+        for (unsigned j = 0; j < N; j++) a = c_add(a, c_mul(c_conj(iR[(size_t)j * N + i]), dk[j]));
+        tmpH[i] = a;
+      }
+      cplx Lambda = zdotc(tmpH, dk, N);
+      double phi_nn = phi_vv / ((type & 1) ? Lambda.re : c_abs(Lambda));
+      weight = phi_ss / (phi_ss + phi_nn);
+    }
+    if (weight > 1.0) weight = 1.0;
+    if (weight < ORC_SPECTRAL_FLOOR) weight = ORC_SPECTRAL_FLOOR;
+    wp[k] = c_make(weight, 0);
+    if (k > 0 && k < M2) wp[M - k] = c_make(weight, 0);
+    if (frame_no_pre >= min_frames) {
+      cplx o = c_scale(y[k], weight);
+      y[k] = o;
+      if (k > 0 && k < M2) y[M - k] = c_conj(o);
+    }
+  }
+  free(ta); free(tmpH);
+}

@@ -45,6 +45,10 @@ def lib():
         L.orc_snapshot_update.argtypes = [vp, C.c_uint, C.c_uint, vp]
         L.orc_gsc_frame.argtypes = [vp, vp, vp, C.c_uint, C.c_uint, C.c_int, vp]
         L.orc_zelinski_frame.argtypes = [vp, vp, C.c_uint, C.c_uint, vp, vp, C.c_double, C.c_int, C.c_int, C.c_int, vp]
+        L.orc_mccowan_frame.argtypes = [vp, vp, vp, C.c_uint, C.c_uint, vp, vp, C.c_double, C.c_int, C.c_int, C.c_double,
+                                        C.c_int, vp]
+        L.orc_lefkimmiatis_frame.argtypes = [vp, vp, vp, vp, C.c_uint, C.c_uint, vp, vp, C.c_double, C.c_int, C.c_int,
+                                             C.c_double, C.c_uint, C.c_int, vp]
         L.orc_nlms_new.restype = vp
         L.orc_nlms_new.argtypes = [C.c_uint] * 3 + [C.c_double] * 7 + [C.c_int, C.c_int]
         L.orc_nlms_free.argtypes = [vp]
@@ -223,6 +227,48 @@ def zelinski_frames(X, Y, d, alpha, type_=2, min_frames=0):
         L.orc_zelinski_frame(_p(d), _p(snaps), M, N, _p(csd), _p(wp1), float(alpha), int(type_),
                              int(min_frames), t - 1, _p(Y[t]))
         W[t] = wp1
+    return Y, W
+
+
+def mccowan_frames(X, Y, d, R, alpha=0.6, type_=2, min_frames=0, threshold=0.99):
+    """McCowanPostFilter over a whole utterance (postfilter.cc:843-935). X [T][N][M], Y [T][M] beamformer output,
+    d [K..][N] (wq if type & 8 else the array manifold), R [K][N][N] noise coherence.  Returns filtered Y and weights."""
+    X, Y, d, R = _c128(X), _c128(Y).copy(), _c128(d), _c128(R)
+    T, N, M = X.shape
+    csd = np.zeros((M, N * N), np.complex128)
+    wp = np.zeros(M, np.complex128)
+    W = np.zeros((T, M), np.complex128)
+    snaps = np.zeros((M, N), np.complex128)
+    L = lib()
+    thr = float(np.float32(threshold))                     # float member threshold_of_Rij_ (postfilter.h:157)
+    for t in range(T):
+        L.orc_snapshot_update(_p(X[t]), M, N, _p(snaps))
+        L.orc_mccowan_frame(_p(d), _p(snaps), _p(R), M, N, _p(csd), _p(wp), float(alpha), int(type_), int(min_frames),
+                            thr, t - 1, _p(Y[t]))
+        W[t] = wp
+    return Y, W
+
+
+def lefkimmiatis_frames(X, Y, d, R, min_sv=1.0e-8, fbin_x1=0, alpha=0.6, type_=2, min_frames=0, threshold=0.99):
+    """LefkimmiatisPostFilter over a whole utterance (postfilter.cc:967-1190)."""
+    X, Y, d, R = _c128(X), _c128(Y).copy(), _c128(d), _c128(R)
+    T, N, M = X.shape
+    K = M // 2 + 1
+    invR = np.zeros((K, N, N), np.complex128)
+    for k in range(K):                                      # calc_inverse_noise_spatial_spectral_matrix :967-980
+        inv, ok = pseudoinverse(R[k], min_sv)
+        invR[k] = inv if ok else np.eye(N)
+    csd = np.zeros((M, N * N), np.complex128)
+    wp = np.zeros(M, np.complex128)
+    W = np.zeros((T, M), np.complex128)
+    snaps = np.zeros((M, N), np.complex128)
+    L = lib()
+    thr = float(np.float32(threshold))
+    for t in range(T):
+        L.orc_snapshot_update(_p(X[t]), M, N, _p(snaps))
+        L.orc_lefkimmiatis_frame(_p(d), _p(snaps), _p(R), _p(invR), M, N, _p(csd), _p(wp), float(alpha), int(type_),
+                                 int(min_frames), thr, int(fbin_x1), t - 1, _p(Y[t]))
+        W[t] = wp
     return Y, W
 
 

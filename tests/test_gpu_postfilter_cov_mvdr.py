@@ -159,3 +159,86 @@ def test_mvdr_identity_fallback(dev):
     assert nfb == K - 1
     # invR = I: w = d / (N d^H d) = 0.25 / (4 * 0.25) = 0.25
     assert torch.allclose(W[1:], torch.full((K - 1, N), 0.25 + 0.0j, dtype=torch.complex64, device=dev), atol=1e-6)
+
+
+def _coherent_snapshots(rng, S, K, N, T):
+    X = _rand_snapshots(rng, S, K, N, T)
+    X += (rng.normal(size=(S, K, 1, T)) + 1j * rng.normal(size=(S, K, 1, T))).astype(np.complex64) * 2500.0
+    return X
+
+
+@pytest.mark.parametrize("N,M,T,type_,minf,load", [(4, 256, 120, 2, 0, 0.01), (8, 64, 70, 1, 0, 0.01), (64, 64, 40, 2, 5, 0.0),
+                                                  (5, 128, 90, 10, 0, 0.05), (20, 64, 50, 2, 0, 0.01)])
+def test_mccowan_matches_oracle(orc, dev, N, M, T, type_, minf, load):
+    """McCowanPostFilter (postfilter.cc:798-935) over a delay-and-sum beamformer, diffuse-noise coherence
+    (confs/sd_and_mccowan.json shape), two consecutive blocks."""
+    import torch
+    from distant_speech_recognition_amd import engine as eng
+    rng = np.random.default_rng(N + M + T)
+    K, S = M // 2 + 1, 2
+    X = _coherent_snapshots(rng, S, K, N, T)
+    mpos = ula_positions(N, 40.0)
+    delays = la_delays(mpos, 0.4)
+    wq = orc.calc_mainlobe(M, N, 16000, delays)
+    w = eng.weights_gsc_effective(wq, None, M)
+    d = wq[:K].astype(np.complex64)
+    R = eng.mvdr_diffuse_model(mpos, M, 16000.0, device=dev)
+    if load > 0:
+        eng.mvdr_diagonal_loading(R, load)
+    st = eng.CoherencePostFilterState(S, K, N, dev)
+    st.set_coherence(R, 0.99)
+    Xd = torch.from_numpy(X).to(dev)
+    Wd, Dd = torch.from_numpy(w).to(dev), torch.from_numpy(d).to(dev)
+    T1 = T // 3
+    Y = torch.cat([eng.bf_apply_mccowan(Wd, Dd, Xd[..., :T1].contiguous(), st, alpha=0.7, type_=type_, min_frames=minf),
+                   eng.bf_apply_mccowan(Wd, Dd, Xd[..., T1:].contiguous(), st, alpha=0.7, type_=type_, min_frames=minf)],
+                  dim=-1).cpu().numpy()
+    Ro = orc.diffuse_noise_model(mpos, M, 16000.0)
+    if load > 0:
+        Ro = orc.diagonal_loading(Ro, M, load)
+    for s in range(S):
+        Xo = _full(X[s], M)
+        ref, Wref = orc.mccowan_frames(Xo, orc.gsc_frames(Xo, wq), wq, Ro, alpha=0.7, type_=type_, min_frames=minf)
+        # stated tolerance: post-filter recurrences <= 1e-4 relative (SURVEY 8(c))
+        assert np.max(np.abs(Y[s].T - ref[:, :K])) <= 1e-4 * np.max(np.abs(ref))
+        wl = st.w_last.cpu().numpy()[s]
+        assert np.max(np.abs(wl - Wref[-1, :K].real)) <= 1e-4
+    assert 1e-3 < np.mean(Wref.real[:, :K]) < 0.999
+
+
+@pytest.mark.parametrize("N,M,T,type_,minf,x1", [(4, 256, 120, 2, 0, 100), (8, 64, 70, 1, 0, 10), (33, 64, 40, 2, 3, 0),
+                                                (6, 128, 90, 2, 0, 200)])
+def test_lefkimmiatis_matches_oracle(orc, dev, N, M, T, type_, minf, x1):
+    """LefkimmiatisPostFilter (postfilter.cc:967-1190), confs/sd_and_lefkimmiatis.json shape (alpha 0.8, min_sv 1e-4)."""
+    import torch
+    from distant_speech_recognition_amd import engine as eng
+    rng = np.random.default_rng(N * 5 + M + T)
+    K, S = M // 2 + 1, 2
+    X = _coherent_snapshots(rng, S, K, N, T)
+    mpos = ula_positions(N, 40.0)
+    delays = la_delays(mpos, -0.8)
+    wq = orc.calc_mainlobe(M, N, 16000, delays)
+    w = eng.weights_gsc_effective(wq, None, M)
+    d = wq[:K].astype(np.complex64)
+    R = eng.mvdr_diffuse_model(mpos, M, 16000.0, device=dev)
+    eng.mvdr_diagonal_loading(R, 0.1)
+    st = eng.CoherencePostFilterState(S, K, N, dev, lefkimmiatis=True)
+    st.set_coherence(R, 0.99)
+    Dd = torch.from_numpy(d).to(dev)
+    assert st.set_lambda(R, Dd, 1.0e-4) == 0
+    Xd = torch.from_numpy(X).to(dev)
+    Wd = torch.from_numpy(w).to(dev)
+    T1 = T // 2
+    kw = dict(fbin_x1=x1, alpha=0.8, type_=type_, min_frames=minf)
+    Y = torch.cat([eng.bf_apply_lefkimmiatis(Wd, Dd, Xd[..., :T1].contiguous(), st, **kw),
+                   eng.bf_apply_lefkimmiatis(Wd, Dd, Xd[..., T1:].contiguous(), st, **kw)], dim=-1).cpu().numpy()
+    Ro = orc.diagonal_loading(orc.diffuse_noise_model(mpos, M, 16000.0), M, 0.1)
+    for s in range(S):
+        Xo = _full(X[s], M)
+        ref, Wref = orc.lefkimmiatis_frames(Xo, orc.gsc_frames(Xo, wq), wq, Ro, min_sv=1.0e-4, fbin_x1=x1, alpha=0.8,
+                                            type_=type_, min_frames=minf)
+        # Lambda goes through the reference's float32 SVD vs a float32 Cholesky here: gains agree to ~1e-3 like MVDR weights
+        assert np.max(np.abs(Y[s].T - ref[:, :K])) <= 1e-3 * np.max(np.abs(ref))
+        wl = st.w_last.cpu().numpy()[s]
+        assert np.max(np.abs(wl - Wref[-1, :K].real)) <= 1e-3
+    assert 1.5e-4 < np.mean(Wref.real[:, :K]) < 0.999          # neither clamped to the floor nor to 1 everywhere
