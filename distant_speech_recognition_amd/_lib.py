@@ -67,6 +67,11 @@ SIGNATURES = {
     "btk_cov_frame_gate": (_i, [_vp, _vp, _i, _l, _l, _f, _vp, _vp, _vp]),
     "btk_cov_accumulate": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _l, _l, _i, _vp]),
     "btk_cov_finalize": (_i, [_vp, _vp, _i, _i, _i, _i, _f, _vp]),
+    "btk_cov_mask_count": (_i, [_vp, _vp, _i, _i, _l, _l, _vp, _vp]),
+    "btk_cov_trace_normalize": (_i, [_vp, _i, _i, _vp]),
+    "btk_sos_scratch_bytes": (_l, [_i, _i]),
+    "btk_bmvdr_weights": (_i, [_vp, _vp, _i, _i, _i, _d, _vp, _vp, _vp, _vp]),
+    "btk_gev_weights": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp]),
     "btk_mvdr_diffuse_model": (_i, [_vp, _i, _i, _f, _f, _vp, _vp]),
     "btk_mvdr_diagonal_loading": (_i, [_vp, _i, _i, _f, _vp]),
     "btk_mvdr_weights": (_i, [_vp, _vp, _vp, _i, _i, _f, _vp, _vp, _vp]),

@@ -525,6 +525,51 @@ def cov_finalize(R, count, gamma=0.0):
     return R
 
 
+def cov_mask_count(tf_weights, frame_weights=None, count=None):
+    """count[s][k] += sum_t trunc(tf[s][k][t]) fw[s][t]  (integer per-bin counters of accu_stats_from_tfmask)."""
+    _need_cuda(tf_weights, "tf_weights")
+    S, K, T = tf_weights.shape
+    if count is None:
+        count = torch.zeros((S, K), dtype=torch.float32, device=tf_weights.device)
+    check(_lib.lib().btk_cov_mask_count(_ptr(tf_weights), None if frame_weights is None else _ptr(frame_weights), S, K, T, T,
+                                        _ptr(count), _stream()))
+    return count
+
+
+def cov_trace_normalize(R):
+    N = R.shape[-1]
+    check(_lib.lib().btk_cov_trace_normalize(_ptr(R), int(np.prod(R.shape[:-2])), N, _stream()))
+    return R
+
+
+def _sos_weights(which, Rt, Rn, *args):
+    _need_cuda(Rt, "Rt"); _need_cuda(Rn, "Rn")
+    K, N, _ = Rt.shape
+    if Rn.shape != Rt.shape or Rt.dtype != torch.complex64 or Rn.dtype != torch.complex64:
+        raise _lib.BtkError(_lib.BTK_ERR_DIMENSION, "covariance matrices must both be complex64 [K][N][N]")
+    L = _lib.lib()
+    W = torch.empty((K, N), dtype=torch.complex64, device=Rt.device)
+    scratch = torch.empty(L.btk_sos_scratch_bytes(K, N), dtype=torch.uint8, device=Rt.device)
+    fail = torch.zeros(1, dtype=torch.int32, device=Rt.device)
+    Rt, Rn = Rt.contiguous(), Rn.contiguous()
+    if which == "bmvdr":
+        check(L.btk_bmvdr_weights(_ptr(Rt), _ptr(Rn), K, N, int(args[0]), float(args[1]), _ptr(W), _ptr(scratch), _ptr(fail),
+                                  _stream()))
+    else:
+        check(L.btk_gev_weights(_ptr(Rt), _ptr(Rn), K, N, _ptr(W), _ptr(scratch), _ptr(fail), _stream()))
+    return W, int(fail.item())
+
+
+def bmvdr_weights(Rt, Rn, ref_micx=0, offset=0.0):
+    """Blind MVDR: wqH [K][N] complex64 (cuda) and the number of bins whose noise covariance is not positive definite."""
+    return _sos_weights("bmvdr", Rt, Rn, ref_micx, offset)
+
+
+def gev_weights(Rt, Rn):
+    """GEV: wqH [K][N] complex64 (cuda), equal to the reference's up to one global sign; and the failure count."""
+    return _sos_weights("gev", Rt, Rn)
+
+
 # ---------------------------------------------------------------------------- MVDR weight design
 def mvdr_diffuse_model(mpos, M, samplerate, sspeed=343740.0, device=None):
     mp = torch.as_tensor(np.ascontiguousarray(mpos, np.float32)).to(device)

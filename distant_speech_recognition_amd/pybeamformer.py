@@ -13,7 +13,7 @@ iterator behaviour; the per-frame / per-bin numpy loops are replaced by HIP kern
 import numpy as np
 
 from . import engine
-from .btk20.beamformer import SSPEED, SubbandGSCPtr, SubbandMVDRGSCPtr
+from .btk20.beamformer import SSPEED, SubbandDSPtr, SubbandGSCPtr, SubbandMVDRGSCPtr
 from .btk20.modulated import _mirror
 from .btk20.stream import device
 
@@ -410,3 +410,153 @@ class SubbandSMIMVDRBeamformer(SubbandMVDRBeamformer):
         if update_active_weights:
             self.set_active_weights()
         self._wqH = np.conjugate(np.array([self._beamformer.mvdr_weights(m) for m in range(self._fftlen2 + 1)], complex))
+
+
+def _vad_noise_label(T, time_delta, target_labs):
+    """Per-frame target indicator exactly as the loops of pybeamformer.py:967-985 / :1071-1080 walk the VAD segments."""
+    elapsed_time, labx = 0.0, 0
+    is_target = np.zeros(T, np.float32)
+    for t in range(T):
+        tgt = False
+        if labx < len(target_labs):
+            if elapsed_time >= target_labs[labx][0] and (elapsed_time <= target_labs[labx][1] or target_labs[labx][1] < 0):
+                tgt = True
+            elif elapsed_time > target_labs[labx][1]:
+                labx += 1
+        is_target[t] = 1.0 if tgt else 0.0
+        elapsed_time += time_delta
+    return is_target
+
+
+class SubbandSOSBatchBeamformer(SubbandBeamformer):
+    """pybeamformer.py:1022-1197: batch beamformer driven by target / noise spatial covariance matrices.
+    Statistics are accumulated on the GPU (btk_cov_accumulate); _target/_noise_covariance_matrices are device
+    complex64 [1][K][N][N], the frame counters device float32 [1][K]."""
+
+    def __init__(self, spec_sources):
+        SubbandBeamformer.__init__(self, spec_sources)
+        self._isamp = 0
+        self._front = SubbandDSPtr(fftlen=self._fftlen, half_band_shift=False)    # owns channels + device snapshots
+        for source in self._spec_sources:
+            self._front.set_channel(source)
+        self._beamformer = self._front
+        self._wqH = np.ones((self._fftlen2 + 1, self._chan_num), complex)
+        self._Y = None
+        self._frames = None
+        self.reset_stats()
+
+    def reset_stats(self):
+        self._target_covariance_matrices = None
+        self._noise_covariance_matrices = None
+        self._target_frame_counts = None
+        self._noise_frame_counts = None
+
+    def _accumulate(self, X, tf_t, tf_j, fw_t, fw_j, cnt_t, cnt_j):
+        self._target_covariance_matrices = engine.cov_accumulate(X, R=self._target_covariance_matrices,
+                                                                 tf_weights=tf_t, frame_weights=fw_t)
+        self._noise_covariance_matrices = engine.cov_accumulate(X, R=self._noise_covariance_matrices,
+                                                                tf_weights=tf_j, frame_weights=fw_j)
+        self._target_frame_counts = cnt_t if self._target_frame_counts is None else self._target_frame_counts + cnt_t
+        self._noise_frame_counts = cnt_j if self._noise_frame_counts is None else self._noise_frame_counts + cnt_j
+        self._front.reset()          # the reference drained its sources here; they are re-read afterwards
+
+    def accu_stats_from_label(self, samplerate, target_labs=[(0.1, -1)], energy_threshold=10):
+        import torch
+        X = self._front.device_snapshots()
+        T, K = X.shape[-1], self._fftlen2 + 1
+        tgt = _vad_noise_label(T, self.shiftlen() / float(samplerate), target_labs)
+        en = engine.frame_energy(X, self._fftlen)
+        fw_t, ct = engine.cov_frame_gate(en, torch.from_numpy(tgt[None]).to(device()), energy_threshold)
+        fw_j, cj = engine.cov_frame_gate(en, torch.from_numpy((1.0 - tgt)[None]).to(device()), energy_threshold)
+        self._accumulate(X, None, None, fw_t, fw_j, ct[:, None].expand(1, K).contiguous(), cj[:, None].expand(1, K).contiguous())
+
+    def accu_stats_from_tfmask(self, samplerate, mask_t, mask_j, energy_threshold=10):
+        import torch
+        X = self._front.device_snapshots()
+        T, K = X.shape[-1], self._fftlen2 + 1
+        mt = np.zeros((K, T), np.float32)
+        mj = np.zeros((K, T), np.float32)
+        n = min(T, len(mask_t))
+        mt[:, :n] = np.asarray(mask_t, np.float32)[:n, :K].T
+        mj[:, :n] = np.asarray(mask_j, np.float32)[:n, :K].T
+        mt, mj = np.maximum(mt, 0.0), np.maximum(mj, 0.0)           # only mask > 0 contributes (:1137-1146)
+        tf_t, tf_j = torch.from_numpy(mt[None]).to(device()), torch.from_numpy(mj[None]).to(device())
+        en = engine.frame_energy(X, self._fftlen)
+        fw, _ = engine.cov_frame_gate(en, None, energy_threshold)
+        self._accumulate(X, tf_t, tf_j, fw, fw, engine.cov_mask_count(tf_t, fw), engine.cov_mask_count(tf_j, fw))
+
+    def finalize_stats(self):
+        pass
+
+    def device_block(self):
+        import torch
+        if self._Y is None:
+            X = self._front.device_snapshots()
+            W = torch.from_numpy(np.conjugate(np.asarray(self._wqH)).astype(np.complex64)).to(device())
+            self._Y = engine.bf_apply(W, X)
+        return self._Y
+
+    def __iter__(self):
+        Y = self.device_block()
+        if self._frames is None:
+            self._frames = _mirror(Y[0].cpu().numpy(), self._fftlen)
+        for t in range(self._frames.shape[0]):
+            self._isamp += 1
+            yield self._frames[t]
+
+    def reset(self):
+        self._front.reset()
+        self._isamp = 0
+        self._Y = None
+        self._frames = None
+
+
+class SubbandBlindMVDRBeamformer(SubbandSOSBatchBeamformer):
+    """pybeamformer.py:1210-1263: MVDR without the look direction (MMSE beamforming)."""
+
+    def _check_stats(self):
+        if self._target_covariance_matrices is None:
+            raise RuntimeError('No target signal SOS')
+        if self._noise_covariance_matrices is None:
+            raise RuntimeError('No noise signal SOS')
+
+    def calc_beamformer_weights(self, ref_micx=0, offset=0.0):
+        self._check_stats()
+        assert offset >= 0 and offset <= 1, "The offset value %f is out of [0, 1]" % (offset)
+        W, failed = engine.bmvdr_weights(self._target_covariance_matrices[0], self._noise_covariance_matrices[0],
+                                         ref_micx, offset)
+        if failed:
+            raise ArithmeticError('Matrix inversion failed\nAdd a small value to the diagonal component of the covariance matrix')
+        self._wqH = W.cpu().numpy().astype(complex)
+        self._Y = None
+        self._frames = None
+
+    def finalize_stats(self, gamma=1e-6):
+        assert self._target_frame_counts is not None and float(self._target_frame_counts.min().item()) > 0, \
+            "No target signal stats accumulated; Use self.accu_stats_from_label() or accu_stats_from_tfmask()"
+        assert self._noise_frame_counts is not None and float(self._noise_frame_counts.min().item()) > 0, \
+            "No noise stats accumulated; Use self.accu_stats_from_label() or accu_stats_from_tfmask()"
+        engine.cov_finalize(self._target_covariance_matrices, self._target_frame_counts)
+        engine.cov_finalize(self._noise_covariance_matrices, self._noise_frame_counts, gamma=max(gamma, 0.0))
+
+
+class SubbandGEVBeamformer(SubbandBlindMVDRBeamformer):
+    """pybeamformer.py:1266-1328: generalised eigenvector beamformer."""
+
+    def calc_beamformer_weights(self):
+        self._check_stats()
+        W, failed = engine.gev_weights(self._target_covariance_matrices[0], self._noise_covariance_matrices[0])
+        if failed:
+            raise ArithmeticError('GEV failed\nAdd a small value to the diagonal component of the covariance matrix')
+        self._wqH = W.cpu().numpy().astype(complex)
+        self._Y = None
+        self._frames = None
+
+    def finalize_stats(self, gamma=1e-6):
+        assert self._target_frame_counts is not None and float(self._target_frame_counts.min().item()) > 0, \
+            "No target signal stats accumulated; Use self.accu_stats_from_label() or accu_stats_from_tfmask()"
+        assert self._noise_frame_counts is not None and float(self._noise_frame_counts.min().item()) > 0, \
+            "No noise stats accumulated; Use self.accu_stats_from_label() or accu_stats_from_tfmask()"
+        # the target covariance stays un-normalised: no impact on the GEV solution (:1317-1318)
+        engine.cov_finalize(self._noise_covariance_matrices, self._noise_frame_counts, gamma=max(gamma, 0.0))
+        engine.cov_trace_normalize(self._noise_covariance_matrices)

@@ -200,6 +200,29 @@ int  btk_cov_accumulate(const void* X, const float* tf_weights, const float* fra
 int  btk_cov_finalize(void* R, const float* count, int count_per_bin, int S, int K, int N, float gamma,
                       void* stream);
 
+/* ---- Batch second-order-statistics beamformers: weight design from accumulated covariances -------
+ * btk_cov_mask_count: count[s][k] += sum_t trunc(tf[s][k][t]) * fw[s][t] -- the per-bin integer frame counters of
+ *   accu_stats_from_tfmask (lib/pybeamformer.py:1127-1147; the reference's counters are integer arrays, so fractional
+ *   mask values weight the covariance but do not count).  count [dev] float32 [S][K].
+ * btk_cov_trace_normalize: R <- R / (tr(R)/N) over nbins matrices (SubbandGEVBeamformer.finalize_stats :1326).
+ * btk_bmvdr_weights: wqH_k = conj( inv(Rn_k) Rt_k u / (offset + tr(inv(Rn_k) Rt_k)) ), u = e_ref_mic
+ *   (SubbandBlindMVDRBeamformer.calc_beamformer_weights :1225-1247).
+ * btk_gev_weights: wqH_k = conj of the principal generalised eigenvector of (Rt_k, Rn_k), v^H Rn v = 1, phase of bin
+ *   k aligned to bin k-1 (SubbandGEVBeamformer.calc_beamformer_weights :1280-1303).  scipy.linalg.eigh leaves the
+ *   phase of each eigenvector to LAPACK; bin 0 is rotated so that its largest component is real positive, i.e. the
+ *   result equals the reference's up to one global sign.
+ * Rt, Rn [dev] complex64 [nbins][N][N]; WqH [dev] complex64 [nbins][N] (the beamformer output is wqH . x);
+ * scratch [dev] btk_sos_scratch_bytes(nbins, N) bytes; *fail_count [dev] += bins whose Rn is not positive definite
+ * (the reference raises ArithmeticError there).                                                               */
+int  btk_cov_mask_count(const float* tf_weights, const float* frame_weights, int S, int K, long T_stride, long T,
+                        float* count, void* stream);
+int  btk_cov_trace_normalize(void* R, int nbins, int N, void* stream);
+long btk_sos_scratch_bytes(int nbins, int N);
+int  btk_bmvdr_weights(const void* Rt, const void* Rn, int nbins, int N, int ref_mic, double offset, void* WqH,
+                       void* scratch, int* fail_count, void* stream);
+int  btk_gev_weights(const void* Rt, const void* Rn, int K, int N, void* WqH, void* scratch, int* fail_count,
+                     void* stream);
+
 /* ---- SubbandMVDR weight design ------------------------------------------------------------------
  * btk_mvdr_diffuse_model: set_diffuse_noise_model (beamformer.cc:2442-2509); mpos [dev] float32 [N][3],
  *   R [dev] complex64 [K][N][N].

@@ -417,6 +417,68 @@ def cov_accumulate(X, frame_weights=None, masks=None):
 
 
 # --------------------------------------------------------------------------- MVDR
+def improve_matrix_condition(x, gamma):
+    """lib/pybeamformer.py:1200-1207"""
+    x = _c128(x)
+    scale = gamma * np.trace(x) / x.shape[-1]
+    return (x + np.eye(x.shape[-1]) * scale) / (1 + gamma)
+
+
+def sos_finalize(cov_t, cov_j, cnt_t, cnt_j, gamma=1e-6, gev=False):
+    """SubbandBlindMVDRBeamformer.finalize_stats (:1249-1263) / SubbandGEVBeamformer.finalize_stats (:1305-1328).
+    cov_* [K][N][N] raw sums, cnt_* [K].  Returns (target, noise)."""
+    ct, cj = _c128(cov_t).copy(), _c128(cov_j).copy()
+    K, N = ct.shape[0], ct.shape[1]
+    for m in range(K):
+        if not gev:
+            ct[m] /= cnt_t[m]
+        cj[m] /= cnt_j[m]
+        if gamma > 0:
+            cj[m] = improve_matrix_condition(cj[m], gamma)
+        if gev:
+            cj[m] /= (np.trace(cj[m]) / N)
+    return ct, cj
+
+
+def blind_mvdr_weights(cov_t, cov_j, ref_micx=0, offset=0.0):
+    """SubbandBlindMVDRBeamformer.calc_beamformer_weights (:1225-1247): wqH [K][N]"""
+    ct, cj = _c128(cov_t), _c128(cov_j)
+    K, N = ct.shape[0], ct.shape[1]
+    u = np.zeros(N)
+    u[ref_micx] = 1.0
+    wqH = np.zeros((K, N), np.complex128)
+    for m in range(K):
+        no = np.dot(np.linalg.inv(cj[m]), ct[m])
+        wqH[m] = np.conjugate(np.dot(no, u) / (offset + np.trace(no)))
+    return wqH
+
+
+def gev_weights(cov_t, cov_j):
+    """SubbandGEVBeamformer.calc_beamformer_weights (:1280-1303): scipy.linalg.eigh(target, noise), principal
+    eigenvector, phase aligned to the previous bin, conjugated.  wqH [K][N]"""
+    import scipy.linalg
+    ct, cj = _c128(cov_t), _c128(cov_j)
+    K, N = ct.shape[0], ct.shape[1]
+    wqH = np.zeros((K, N), np.complex128)
+    for m in range(K):
+        _, vecs = scipy.linalg.eigh(ct[m], cj[m])
+        wqH[m] = vecs[:, -1]
+        if m > 0:
+            wqH[m] *= np.exp(-1j * np.angle(np.inner(wqH[m], np.conjugate(wqH[m - 1]))))
+    return np.conjugate(wqH)
+
+
+def sos_frames(X, wqH):
+    """SubbandSOSBatchBeamformer.__iter__ (:1171-1186): X [T][N][M], wqH [K][N] -> [T][M]"""
+    X, wqH = _c128(X), _c128(wqH)
+    T, N, M = X.shape
+    K = M // 2 + 1
+    out = np.zeros((T, M), np.complex128)
+    out[:, :K] = np.einsum("kn,tnk->tk", wqH, X[:, :, :K])
+    out[:, K:] = np.conj(out[:, M // 2 - 1:0:-1])
+    return out
+
+
 def diffuse_noise_model(mpos, M, samplerate, sspeed=343740.0):
     mpos = np.ascontiguousarray(mpos, np.float64)
     N = mpos.shape[0]

@@ -191,3 +191,38 @@ def test_rls_oracle_matches_reference_python(orc, proto256, kinect_pcm, pygolden
     assert np.max(np.abs(r.Pz[::8] - gP)) <= 1e-8 * np.max(np.abs(gP))
     g = rlsgolden[tag + "_scal"]          # the generator is suspended at its yield: _isamp is one behind
     assert np.allclose(r.scal[[0, 2]], g[[0, 2]], rtol=1e-12) and r.scal[1] == g[1] + 1
+
+
+# ---------------------------------------------------------------- batch SOS beamformers ("next" row)
+@pytest.fixture(scope="module")
+def sosgolden():
+    return np.load(os.path.join(os.path.dirname(__file__), "golden", "pybeamformer_sos_golden.npz"))
+
+
+def test_sos_batch_oracle_matches_reference_python(orc, proto256, kinect_pcm, sosgolden):
+    """TF-mask / label accumulation, finalize_stats, blind-MVDR and GEV weights (lib/pybeamformer.py:1043-1328) vs the
+    reference's own numpy/scipy arithmetic (tests/golden/gen_golden_pybeamformer_sos.py)."""
+    G = sosgolden
+    h, _ = proto256
+    T = int(G["meta_T"][0])
+    X = np.stack([orc.analysis(h, 256, 4, 1, 2, kinect_pcm[c][: (T + 8) * 128])[:T] for c in range(4)], axis=1)
+    en = np.array([orc.frame_energy(X[t, 0]) for t in range(T)])
+    gate = (en > 10).astype(np.float64)
+    mt, mj = G["mask_t"].astype(np.float64), G["mask_j"].astype(np.float64)
+    Rt = orc.cov_accumulate(X, masks=mt * gate[:, None])
+    Rj = orc.cov_accumulate(X, masks=mj * gate[:, None])
+    assert np.allclose(Rt, G["bm_cov_t_raw"], rtol=1e-10, atol=1e-6) and np.allclose(Rj, G["bm_cov_j_raw"], rtol=1e-10, atol=1e-6)
+    ct = (np.floor(mt) * gate[:, None]).sum(axis=0)
+    cj = (np.floor(mj) * gate[:, None]).sum(axis=0)
+    assert np.array_equal(ct, G["bm_cnt_t"]) and np.array_equal(cj, G["bm_cnt_j"])
+    ft, fj = orc.sos_finalize(Rt, Rj, ct, cj, 1e-6)
+    assert np.allclose(ft, G["bm_cov_t"], rtol=1e-10) and np.allclose(fj, G["bm_cov_j"], rtol=1e-10)
+    w = orc.blind_mvdr_weights(ft, fj, ref_micx=1, offset=0.0)
+    assert np.max(np.abs(w - G["bm_wqH"])) <= 1e-9 * np.max(np.abs(G["bm_wqH"]))
+    Y = orc.sos_frames(X, w)
+    assert np.max(np.abs(Y[:, ::7] - G["bm_Y"])) <= 1e-9 * np.max(np.abs(G["bm_Y"]))
+    # GEV (scipy.linalg.eigh fixes each eigenvector only up to a phase; bin 0 is real -> a global sign)
+    gt, gj = G["gev_cov_t"], G["gev_cov_j"]
+    wg = orc.gev_weights(gt, gj)
+    sgn = np.sign(np.real(np.vdot(G["gev_wqH"][0], wg[0])))
+    assert np.max(np.abs(sgn * wg - G["gev_wqH"])) <= 1e-8 * np.max(np.abs(G["gev_wqH"]))
