@@ -175,20 +175,35 @@ def main():
         b_bf = 8 * K * (N + 1) * S * T                 # beamformer apply
         b_syn = (8 * K + 4 * D) * S * T
         b_fused_hbm = (4 * D * N + 8 * K) * S * T      # what the fused kernel actually has to move
+        def pmc_traffic(kernel_substr):
+            """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/make_traffic_json.py), only if
+            they were taken at this launch size"""
+            try:
+                j = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")))
+                if (j["S"], j["T"], j["N"], j["M"]) != (S, T, N, M):
+                    return None
+                for kname, e in j["kernels"].items():
+                    if kernel_substr in kname and "traffic_bytes" in e:
+                        return e["traffic_bytes"]
+            except (OSError, ValueError, KeyError):
+                pass
+            return None
         if fused:
             roof = {"bound": "hbm", "kernel": "analysis512_bf_kernel (fused analysis bank + SubbandGSC apply)",
                     "achieved": (b_ana + b_bf) / t_a / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                    "frac": (b_ana + b_bf) / t_a / HBM_PEAK, "traffic": None,
+                    "frac": (b_ana + b_bf) / t_a / HBM_PEAK, "traffic": pmc_traffic("analysis512_bf_kernel"),
+                    "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of profiles/pmc_workload.py at this launch "
+                                      "size (profiles/r01_pmc_traffic.json; gfx950 correction 2 x FETCH_SIZE)",
                     "bytes_per_launch": b_ana + b_bf, "avg_launch_ms": t_a * 1e3,
+                    "frac_of_peak_on_min_traffic": b_fused_hbm / t_a / HBM_PEAK,
                     "note": "algorithmic bytes = SURVEY 8(d) staged figures N(4D+8K)+8K(N+1) per frame; the fused kernel keeps "
                             "the N x K snapshots on chip, so the HBM traffic it needs is 4DN+8K per frame = %.2f GB per launch "
                             "(%.0f GB/s actual) and it is bounded by LDS/VALU work, not by HBM; see stages.analysis for the "
                             "staged analysis kernel against the HBM roofline" % (b_fused_hbm / 1e9, b_fused_hbm / t_a / 1e9)}
         else:
             roof = {"bound": "hbm", "kernel": "analysis512_kernel", "achieved": b_ana / t_ana / 1e9, "peak": HBM_PEAK / 1e9,
-                    "unit": "GB/s", "frac": b_ana / t_ana / HBM_PEAK, "traffic": None,
-                    "traffic_note": "rocprofv3 PMC, same kernel, 8 streams x 2048 frames (profiles/r01_pmc_c0_analysis512.txt): "
-                                    "2*FETCH_SIZE + WRITE_SIZE = 3.23 GB = 1.00 x algorithmic bytes of that launch",
+                    "unit": "GB/s", "frac": b_ana / t_ana / HBM_PEAK, "traffic": pmc_traffic("analysis512_kernel"),
+                    "traffic_source": "rocprofv3 --pmc passes, profiles/r01_pmc_traffic.json (2 x FETCH_SIZE + WRITE_SIZE)",
                     "bytes_per_launch": b_ana, "avg_launch_ms": t_ana * 1e3}
         res = {
             "metric": "beamformed subband frames/sec, 64-mic 512-bin SubbandGSC",

@@ -1,13 +1,14 @@
 #!/usr/bin/env python
-"""Small fixed workload for rocprofv3 --pmc passes: 2 launches each of the C0 analysis, GSC apply and
-synthesis kernels (8 streams x 64 mics x 2048 frames, M=512) -- same kernels/geometry as bench.py."""
+"""Fixed workload for rocprofv3 --pmc passes: 2 launches each of the C0 analysis, GSC apply, synthesis and fused
+analysis+apply kernels at bench.py's default launch size (16 streams x 64 mics x 4096 frames, M=512), so the
+per-launch counter values compare directly with bench.py's roofline.bytes_per_launch.  PMC_S / PMC_T override."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from distant_speech_recognition_amd import engine as eng
 from tests.util import design_prototype
 
-S, N, M, T = 8, 64, 512, 2048
+S, N, M, T = int(os.environ.get("PMC_S", 16)), 64, 512, int(os.environ.get("PMC_T", 4096))
 dev = torch.device("cuda:0")
 afb = eng.FilterBank(design_prototype(M, 4), M, 4, 1, 2)
 sfb = eng.FilterBank(design_prototype(M, 4, "g"), M, 4, 1, 2, synthesis=True)
@@ -22,4 +23,5 @@ for _ in range(2):
     sfb.synthesize(Y)
     afb.analysis_beamform(pcm, W, out=Y)
 torch.cuda.synchronize()
-print("pmc workload done: algorithmic bytes analysis=%d apply=%d" % ((4 * 256 + 8 * 257) * N * S * T, 8 * 257 * (N + 1) * S * T))
+print("pmc workload done: S=%d T=%d algorithmic bytes analysis=%d apply=%d fused(min traffic)=%d"
+      % (S, T, (4 * 256 + 8 * 257) * N * S * T, 8 * 257 * (N + 1) * S * T, (4 * 256 * N + 8 * 257) * S * T))
