@@ -49,6 +49,21 @@ def main():
     zs = eng.ZelinskiState(S, K, dev)
     t = timeit(torch, lambda: eng.bf_apply_zelinski(vd, vd, X, zs, alpha=0.7, out=Y))
     out["apply_zelinski_c0"] = {"ms": t * 1e3, "frames_per_s": S * T / t, "GBps": b / t / 1e9, "hbm_frac": b / t / HBM}
+    # McCowan / Lefkimmiatis: apply + the per-pair weighted quadratic forms (O(N^2) flops per bin-frame)
+    mpos0 = ula_positions(N); mpos0[:, 2] = 2.0
+    Rc = eng.mvdr_diffuse_model(mpos0, M, 16000, device=dev)
+    eng.mvdr_diagonal_loading(Rc, 0.01)
+    for lef, tag in ((False, "apply_mccowan_c0"), (True, "apply_lefkimmiatis_c0")):
+        cs = eng.CoherencePostFilterState(S, K, N, dev, lefkimmiatis=lef)
+        cs.set_coherence(Rc, 0.99)
+        if lef:
+            cs.set_lambda(Rc, vd, 1e-4)
+            fn = lambda: eng.bf_apply_lefkimmiatis(vd, vd, X, cs, fbin_x1=100, alpha=0.8, out=Y)
+        else:
+            fn = lambda: eng.bf_apply_mccowan(vd, vd, X, cs, alpha=0.7, out=Y)
+        t = timeit(torch, fn, n=3, warm=1)
+        fl = 8.0 * (N * (N + 1) / 2) * (2 if lef else 1) * K * S * T
+        out[tag] = {"ms": t * 1e3, "frames_per_s": S * T / t, "TFLOPs_quadratic_forms": fl / t / 1e12, "GBps": b / t / 1e9}
     R = torch.zeros((S, K, N, N), dtype=torch.complex64, device=dev)
     for mf, tag in ((True, "cov_mfma_c0"), (False, "cov_valu_c0")):
         t = timeit(torch, lambda: eng.cov_accumulate(X, R=R, use_mfma=mf), n=3, warm=1)
@@ -56,6 +71,32 @@ def main():
         out[tag] = {"ms": t * 1e3, "frames_per_s": S * T / t, "TFLOPs": fl / t / 1e12, "fp32_frac": fl / t / FP32,
                     "GBps_read": 8 * K * N * S * T / t / 1e9}
     del X, R, Y
+    # ---- C1-style RLS canceller: 8 mics, 512 bins, 16 streams (float64 recursion, O(N^2) per bin-frame)
+    N8 = 8
+    X8 = (torch.randn((S, K, N8, T), device=dev) + 1j * torch.randn((S, K, N8, T), device=dev)).to(torch.complex64) * 2000
+    d8 = la_delays(ula_positions(N8), -1.306379)
+    vs8 = torch.from_numpy(np.stack([np.exp(-2j * np.pi * k * (16000.0 / M) * d8) / N8 for k in range(K)])).to(dev)
+    rs = eng.RLSState(1, S, M, N8, vs8, min_frames=0)
+    Y8 = torch.empty((S, K, T), dtype=torch.complex64, device=dev)
+    t = timeit(torch, lambda: eng.rls_process(X8, rs, out=Y8), n=3, warm=1)
+    out["rls_8mic"] = {"ms": t * 1e3, "frames_per_s": S * T / t, "bin_frames_per_s": S * K * T / t,
+                       "GFLOPs_f64": 8.0 * 5 * N8 * N8 * S * K * T / t / 1e9}
+    st8 = eng.NLMSState(S, M, N8, dev)
+    v8c = vs8.to(torch.complex64)
+    t = timeit(torch, lambda: eng.nlms_process(v8c, X8, st8, out=Y8))
+    b8 = 8 * K * (N8 + 1) * S * T
+    out["nlms_8mic"] = {"ms": t * 1e3, "frames_per_s": S * T / t, "GBps": b8 / t / 1e9, "hbm_frac": b8 / t / HBM}
+    del X8, Y8
+    # ---- blind MVDR / GEV weight design from covariances: 64 mics, 257 bins
+    A = torch.randn((K, N, 2 * N), device=dev) + 1j * torch.randn((K, N, 2 * N), device=dev)
+    Rn = (A @ A.conj().transpose(1, 2) / (2 * N) + 0.05 * torch.eye(N, device=dev)).to(torch.complex64)
+    A = torch.randn((K, N, 2), device=dev) + 1j * torch.randn((K, N, 2), device=dev)
+    Rt = (A @ A.conj().transpose(1, 2)).to(torch.complex64)
+    t = timeit(torch, lambda: eng.bmvdr_weights(Rt, Rn), n=2, warm=1)
+    out["bmvdr_weights_64mic"] = {"ms": t * 1e3, "bins": K}
+    t = timeit(torch, lambda: eng.gev_weights(Rt, Rn), n=2, warm=1)
+    out["gev_weights_64mic"] = {"ms": t * 1e3, "bins": K, "squarings": 32}
+    del Rn, Rt, A
     # ---- C3: MVDR solve, 64 mics, 1024 bins
     N, M = 64, 1024
     K = M // 2 + 1
