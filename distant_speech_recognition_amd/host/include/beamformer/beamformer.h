@@ -118,6 +118,34 @@ class SubbandGSC : public SubbandDS {
 };
 typedef Inherit<SubbandGSC, SubbandDSPtr> SubbandGSCPtr;
 
+// RLS sidelobe canceller (reference beamformer.h:207-263, beamformer.cc:1447-1699): the recursion of the whole
+// utterance runs in one btk_rls_process launch (mode 0); Pz_ and the active weights survive reset() as in the reference.
+typedef enum { CONSTANT_NORM = 0x01, THRESHOLD_LIMITATION = 0x02, NO_QUADRATIC_CONSTRAINT = 0x00 } QuadraticConstraintType;
+
+class SubbandGSCRLS : public SubbandGSC {
+ public:
+  SubbandGSCRLS(unsigned fftLen = 512, bool halfBandShift = false, float mu = 0.9, float sigma2 = 0.0,
+                const String& nm = "SubbandGSCRLS");
+  ~SubbandGSCRLS();
+  virtual const gsl_vector_complex* next(int frame_no = -5);
+  void init_precision_matrix(float sigma2 = 0.01);
+  void set_precision_matrix(unsigned fbinX, gsl_matrix_complex* Pz);
+  void update_active_weight_vecotrs(bool flag) { is_wa_updated_ = flag; }   // sic (reference spelling)
+  void set_quadratic_constraint(float alpha, int qctype = 1) { alpha_ = alpha; qctype_ = (QuadraticConstraintType)qctype; }
+  void initPrecisionMatrix(float sigma2 = 0.01) { init_precision_matrix(sigma2); }
+  void setPrecisionMatrix(unsigned fbinX, gsl_matrix_complex* Pz) { set_precision_matrix(fbinX, Pz); }
+  void updateActiveWeightVecotrs(bool flag) { update_active_weight_vecotrs(flag); }
+  void setQuadraticConstraint(float alpha, int qctype = 1) { set_quadratic_constraint(alpha, qctype); }
+ private:
+  void alloc_state_();
+  void run_block_();
+  float mu_, diagonal_weight_, alpha_;
+  QuadraticConstraintType qctype_;
+  bool is_wa_updated_, have_P_;
+  void *dP_, *dW_, *dV_, *dSS_;     // device: P complex128 [K][N][N], w complex128 [K][N], wq complex128 [K][N], stream state
+};
+typedef Inherit<SubbandGSCRLS, SubbandGSCPtr> SubbandGSCRLSPtr;
+
 class SubbandMVDR : public SubbandDS {
  public:
   SubbandMVDR(unsigned fftLen, bool halfBandShift = false, const String& nm = "SubbandMVDR");

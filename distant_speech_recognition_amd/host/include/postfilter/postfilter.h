@@ -1,4 +1,5 @@
-// postfilter/postfilter.h -- ZelinskiPostFilter (reference postfilter/postfilter.h:74-108).
+// postfilter/postfilter.h -- ZelinskiPostFilter, McCowanPostFilter, LefkimmiatisPostFilter
+// (reference postfilter/postfilter.h:74-108, 123-162, 174-203).
 #pragma once
 #include "beamformer/beamformer.h"
 
@@ -15,8 +16,9 @@ class ZelinskiPostFilter : public VectorComplexFeatureStream {
   void set_beamformer(SubbandDSPtr& beamformer);
   void setBeamformer(SubbandDSPtr& beamformer) { set_beamformer(beamformer); }
   const gsl_vector_complex* postfilter_weights();
- private:
-  void compute_(long from_frame);
+ protected:
+  virtual void compute_(long from_frame);
+  void merge_output_(std::vector<float>& Ynew, long from_frame);
   unsigned fftLen_;
   VectorComplexFeatureStreamPtr samp_;
   PostfilterType type_;
@@ -32,3 +34,51 @@ class ZelinskiPostFilter : public VectorComplexFeatureStream {
   gsl_vector_complex* wp1_;
 };
 typedef Inherit<ZelinskiPostFilter, VectorComplexFeatureStreamPtr> ZelinskiPostFilterPtr;
+
+// McCowan post-filter: Zelinski's estimator with the microphone-pair terms weighted by a noise coherence matrix.
+class McCowanPostFilter : public ZelinskiPostFilter {
+ public:
+  McCowanPostFilter(VectorComplexFeatureStreamPtr& output, unsigned fftLen, double alpha = 0.6, int type = 2,
+                    int minFrames = 0, float threshold = 0.99, const String& nm = "McCowanPostFilter");
+  ~McCowanPostFilter();
+  const gsl_matrix_complex* noise_spatial_spectral_matrix(unsigned fbinX);
+  bool set_noise_spatial_spectral_matrix(unsigned fbinX, gsl_matrix_complex* Rnn);
+  bool set_diffuse_noise_model(const gsl_matrix* micPositions, double sampleRate, double sspeed = 343740.0);
+  void set_all_diagonal_loading(float diagonalWeight);
+  void set_diagonal_looading(unsigned fbinX, float diagonalWeight);          // sic (reference spelling)
+  void divide_all_nondiagonal_elements(float mu);
+  void divide_nondiagonal_elements(unsigned fbinX, float mu);
+  // legacy API
+  bool setDiffuseNoiseModel(const gsl_matrix* mp, double fs, double c = 343740.0) { return set_diffuse_noise_model(mp, fs, c); }
+  void setAllLevelsOfDiagonalLoading(float w) { set_all_diagonal_loading(w); }
+ protected:
+  virtual void compute_(long from_frame);
+  virtual bool lefkimmiatis_() const { return false; }
+  virtual const char* no_R_msg_() const { return "McCowanPostFilter:  construct/set a noise coherence matrix\n"; }
+  void fetch_R_();
+  void push_R_();
+  float threshold_of_Rij_;
+  unsigned nChanR_;
+  void* dR_;                        // device complex64 [K][N][N]
+  std::vector<float> Rhost_;        // host mirror, complex64 [K][N][N]
+  gsl_matrix_complex* Rview_;
+  bool invR_computed_;
+  double minSV_;
+  unsigned fbinX1_;
+  void *dU_, *dV_;
+};
+typedef Inherit<McCowanPostFilter, ZelinskiPostFilterPtr> McCowanPostFilterPtr;
+
+// Lefkimmiatis post-filter: Wiener gain under the diffuse-noise-field assumption.
+class LefkimmiatisPostFilter : public McCowanPostFilter {
+ public:
+  LefkimmiatisPostFilter(VectorComplexFeatureStreamPtr& output, unsigned fftLen, double minSV = 1.0E-8, unsigned fbinX1 = 0,
+                         double alpha = 0.6, int type = 2, int minFrames = 0, float threshold = 0.99,
+                         const String& nm = "LefkimmiatisPostFilter");
+  void calc_inverse_noise_spatial_spectral_matrix();
+  void calcInverseNoiseSpatialSpectralMatrix() { calc_inverse_noise_spatial_spectral_matrix(); }
+ protected:
+  virtual bool lefkimmiatis_() const { return true; }
+  virtual const char* no_R_msg_() const { return "LefkimmiatisPostFilter:  construct/set a noise coherence matrix\n"; }
+};
+typedef Inherit<LefkimmiatisPostFilter, McCowanPostFilterPtr> LefkimmiatisPostFilterPtr;

@@ -740,12 +740,18 @@ void ZelinskiPostFilter::compute_(long from_frame)
     d2h(Ynew.data(), dY, sizeof(float) * Ynew.size());
     dev_free(dW); dev_free(dD); dev_free(dY); dev_free(dC); dev_free(dE);
   }
-  if (Yhost_.size() == Ynew.size() && from_frame > 0)
-    for (unsigned k = 0; k < K; k++)
-      memcpy(&Ynew[2 * ((size_t)k * T_)], &Yhost_[2 * ((size_t)k * T_)], sizeof(float) * 2 * (size_t)from_frame);
-  Yhost_.swap(Ynew);
+  merge_output_(Ynew, from_frame);
   bf_version_ = bf->weights_version();
   prepared_ = true;
+}
+
+void ZelinskiPostFilter::merge_output_(std::vector<float>& Ynew, long from_frame)
+{
+  const unsigned K = fftLen_ / 2 + 1;
+  if (Yhost_.size() == Ynew.size() && from_frame > 0)
+    for (unsigned k = 0; k < K; k++)                          // frames already served keep their values
+      memcpy(&Ynew[2 * ((size_t)k * T_)], &Yhost_[2 * ((size_t)k * T_)], sizeof(float) * 2 * (size_t)from_frame);
+  Yhost_.swap(Ynew);
 }
 
 const gsl_vector_complex* ZelinskiPostFilter::next(int frame_no)
@@ -779,4 +785,303 @@ void ZelinskiPostFilter::reset()
   VectorComplexFeatureStream::reset();
   is_end_ = false;
   prepared_ = false; Yhost_.clear();
+}
+
+// ================================================================================ McCowan / Lefkimmiatis
+McCowanPostFilter::McCowanPostFilter(VectorComplexFeatureStreamPtr& output, unsigned fftLen, double alpha, int type,
+                                     int minFrames, float threshold, const String& nm)
+    : ZelinskiPostFilter(output, fftLen, alpha, type, minFrames, nm), threshold_of_Rij_(threshold), nChanR_(0), dR_(NULL),
+      Rview_(NULL), invR_computed_(false), minSV_(1.0e-8), fbinX1_(0), dU_(NULL), dV_(NULL) {}
+
+McCowanPostFilter::~McCowanPostFilter()
+{
+  dev_free(dR_); dev_free(dU_); dev_free(dV_);
+  if (Rview_) gsl_matrix_complex_free(Rview_);
+}
+
+void McCowanPostFilter::fetch_R_()
+{
+  const unsigned K = fftLen_ / 2 + 1;
+  Rhost_.resize((size_t)2 * K * nChanR_ * nChanR_);
+  if (dR_) d2h(Rhost_.data(), dR_, sizeof(float) * Rhost_.size());
+}
+void McCowanPostFilter::push_R_()
+{
+  h2d(dR_, Rhost_.data(), sizeof(float) * Rhost_.size());
+  invR_computed_ = false;
+  prepared_ = false;
+}
+
+const gsl_matrix_complex* McCowanPostFilter::noise_spatial_spectral_matrix(unsigned fbinX)
+{
+  if (!dR_) return NULL;
+  fetch_R_();
+  const unsigned N = nChanR_;
+  if (Rview_ && Rview_->size1 != N) { gsl_matrix_complex_free(Rview_); Rview_ = NULL; }
+  if (!Rview_) Rview_ = gsl_matrix_complex_alloc(N, N);
+  for (size_t e = 0; e < (size_t)2 * N * N; e++) Rview_->data[e] = Rhost_[(size_t)2 * fbinX * N * N + e];
+  return Rview_;
+}
+
+bool McCowanPostFilter::set_noise_spatial_spectral_matrix(unsigned fbinX, gsl_matrix_complex* Rnn)
+{
+  if (Rnn->size1 != Rnn->size2) { fprintf(stderr, "The noise coherence matrix should be the square matrix\n"); return false; }
+  const unsigned K = fftLen_ / 2 + 1, N = (unsigned)Rnn->size1;
+  if (!dR_ || nChanR_ != N) {
+    dev_free(dR_);
+    nChanR_ = N;
+    dR_ = dev_alloc(sizeof(float) * 2 * K * N * N);
+    check_hip(hipMemset(dR_, 0, sizeof(float) * 2 * K * N * N), "hipMemset");
+  }
+  fetch_R_();
+  for (unsigned a = 0; a < N; a++)
+    for (unsigned b = 0; b < N; b++) {
+      const gsl_complex z = gsl_matrix_complex_get(Rnn, a, b);
+      Rhost_[2 * (((size_t)fbinX * N + a) * N + b)] = (float)GSL_REAL(z);
+      Rhost_[2 * (((size_t)fbinX * N + a) * N + b) + 1] = (float)GSL_IMAG(z);
+    }
+  push_R_();
+  return true;
+}
+
+bool McCowanPostFilter::set_diffuse_noise_model(const gsl_matrix* micPositions, double sampleRate, double sspeed)
+{
+  const unsigned K = fftLen_ / 2 + 1, N = (unsigned)micPositions->size1;
+  if (micPositions->size2 < 3) { fprintf(stderr, "The microphone positions should be described in the three dimensions\n"); return false; }
+  if (!dR_ || nChanR_ != N) { dev_free(dR_); nChanR_ = N; dR_ = dev_alloc(sizeof(float) * 2 * K * N * N); }
+  std::vector<float> mp((size_t)3 * N);
+  for (unsigned a = 0; a < N; a++) for (int j = 0; j < 3; j++) mp[3 * a + j] = (float)gsl_matrix_get(micPositions, a, j);
+  void* dmp = dev_alloc(sizeof(float) * mp.size());
+  h2d(dmp, mp.data(), sizeof(float) * mp.size());
+  check_abi(btk_mvdr_diffuse_model((const float*)dmp, (int)N, (int)fftLen_, (float)sampleRate, (float)sspeed, dR_, NULL));
+  check_abi(btk_synchronize(NULL));
+  dev_free(dmp);
+  invR_computed_ = false;
+  prepared_ = false;
+  return true;
+}
+
+void McCowanPostFilter::set_all_diagonal_loading(float diagonalWeight)
+{
+  if (!dR_) throw j_error("Construct/set first a noise coherence matrix\n");
+  check_abi(btk_mvdr_diagonal_loading(dR_, (int)(fftLen_ / 2 + 1), (int)nChanR_, diagonalWeight, NULL));
+  invR_computed_ = false;
+  prepared_ = false;
+}
+
+void McCowanPostFilter::set_diagonal_looading(unsigned fbinX, float diagonalWeight)
+{
+  if (!dR_) throw j_error("Construct/set first a noise coherence matrix\n");
+  check_abi(btk_mvdr_diagonal_loading(static_cast<float*>(dR_) + (size_t)2 * fbinX * nChanR_ * nChanR_, 1, (int)nChanR_,
+                                      diagonalWeight, NULL));
+  invR_computed_ = false;
+  prepared_ = false;
+}
+
+void McCowanPostFilter::divide_nondiagonal_elements(unsigned fbinX, float mu)
+{
+  if (!dR_) throw j_error("Construct/set first a noise coherence matrix\n");
+  fetch_R_();
+  const unsigned N = nChanR_;
+  for (unsigned a = 0; a < N; a++)
+    for (unsigned b = 0; b < N; b++)
+      if (a != b) {
+        float* z = &Rhost_[2 * (((size_t)fbinX * N + a) * N + b)];
+        z[0] = (float)((double)z[0] / (1.0 + mu));
+        z[1] = (float)((double)z[1] / (1.0 + mu));
+      }
+  push_R_();
+}
+
+void McCowanPostFilter::divide_all_nondiagonal_elements(float mu)
+{
+  for (unsigned k = 0; k <= fftLen_ / 2; k++) divide_nondiagonal_elements(k, mu);
+}
+
+void McCowanPostFilter::compute_(long from_frame)
+{
+  if (!has_bf_ptr_) throw j_error("set beamformer's weights \n");
+  if (!dR_) throw j_error("%s", no_R_msg_());
+  SubbandDS* bf = bf_ptr_.operator->();
+  const unsigned N = bf->chanN(), K = fftLen_ / 2 + 1;
+  if (N != nChanR_) throw jdimension_error("The noise coherence matrix is %dx%d but there are %d channels\n", nChanR_, nChanR_, N);
+  const bool lef = lefkimmiatis_();
+  void* dX = bf->device_snapshots();
+  T_ = bf->num_frames();
+  std::vector<float> w, d;
+  bf->effective_weights(w);
+  bf->alignment_vector(!lef && (type_ & TYPE_ZELINSKI2) != 0, d);              // postfilter.cc:858-863 vs :1098
+  const long Tn = T_ - from_frame;
+  if (!dPhi_) { dPhi_ = dev_alloc(sizeof(float) * 2 * K); dPsi_ = dev_alloc(sizeof(float) * K); dWl_ = dev_alloc(sizeof(float) * K); }
+  if (!dU_) { dU_ = dev_alloc(sizeof(float) * 2 * K); dV_ = dev_alloc(sizeof(float) * 2 * K); }
+  check_hip(hipMemset(dPhi_, 0, sizeof(float) * 2 * K), "hipMemset");
+  check_hip(hipMemset(dPsi_, 0, sizeof(float) * K), "hipMemset");
+  check_hip(hipMemset(dWl_, 0, sizeof(float) * K), "hipMemset");
+  check_hip(hipMemset(dV_, 0, sizeof(float) * 2 * K), "hipMemset");
+  std::vector<float> Ynew((size_t)2 * K * T_);
+  if (Tn > 0) {
+    void* dW = dev_alloc(sizeof(float) * w.size());
+    void* dD = dev_alloc(sizeof(float) * d.size());
+    void* dY = dev_alloc(sizeof(float) * 2 * K * T_);
+    void* dUs = dev_alloc(sizeof(float) * 2 * K * T_);
+    void* dVs = lef ? dev_alloc(sizeof(float) * 2 * K * T_) : NULL;
+    void* dE = dev_alloc(sizeof(float) * K * T_);
+    void* dCs = dev_alloc(sizeof(float) * 2 * K * N * N);
+    void* dCv = lef ? dev_alloc(sizeof(float) * 2 * K * N * N) : NULL;
+    h2d(dW, w.data(), sizeof(float) * w.size());
+    h2d(dD, d.data(), sizeof(float) * d.size());
+    check_abi(btk_pf_coherence_coeffs(dR_, threshold_of_Rij_, (int)K, (int)N, dCs, dCv, NULL));
+    const float* Xo = static_cast<const float*>(dX) + 2 * from_frame;
+    float* Yo = static_cast<float*>(dY) + 2 * from_frame;
+    float* Uo = static_cast<float*>(dUs) + 2 * from_frame;
+    float* Vo = lef ? static_cast<float*>(dVs) + 2 * from_frame : NULL;
+    float* Eo = static_cast<float*>(dE) + from_frame;
+    check_abi(btk_bf_apply_stats2(dW, dD, 0, Xo, Yo, dCs, dCv, Uo, Vo, Eo, 1, (int)K, (int)N, T_, Tn, NULL));
+    if (lef) {
+      void* dLam = dev_alloc(sizeof(float) * 2 * K);
+      void* dFb = dev_alloc(sizeof(int));
+      check_hip(hipMemset(dFb, 0, sizeof(int)), "hipMemset");
+      void* scratch = (2064 + 8 * ((size_t)N * N + N) > 150 * 1024) ? dev_alloc(sizeof(float) * 2 * K * N * N) : NULL;
+      check_abi(btk_mvdr_lambda(dR_, dD, dLam, (int)K, (int)N, (float)minSV_, scratch, (int*)dFb, NULL));   // :967-995
+      invR_computed_ = true;
+      check_abi(btk_lefkimmiatis_process(Yo, Uo, Vo, dLam, (int)fbinX1_, 1, (int)K, (int)N, T_, Tn, alpha_, (int)type_,
+                                         min_frames_, from_frame, dPhi_, dV_, (float*)dWl_, NULL));
+      check_abi(btk_synchronize(NULL));
+      dev_free(dLam); dev_free(dFb); dev_free(scratch);
+    } else {
+      check_abi(btk_zelinski_process(Yo, Uo, Eo, 1, (int)K, (int)N, T_, Tn, alpha_, (int)type_ & 3, min_frames_, from_frame,
+                                     dPhi_, (float*)dPsi_, (float*)dWl_, NULL));
+      check_abi(btk_synchronize(NULL));
+    }
+    d2h(Ynew.data(), dY, sizeof(float) * Ynew.size());
+    dev_free(dW); dev_free(dD); dev_free(dY); dev_free(dUs); dev_free(dVs); dev_free(dE); dev_free(dCs); dev_free(dCv);
+  }
+  merge_output_(Ynew, from_frame);
+  bf_version_ = bf->weights_version();
+  prepared_ = true;
+}
+
+LefkimmiatisPostFilter::LefkimmiatisPostFilter(VectorComplexFeatureStreamPtr& output, unsigned fftLen, double minSV,
+                                               unsigned fbinX1, double alpha, int type, int minFrames, float threshold,
+                                               const String& nm)
+    : McCowanPostFilter(output, fftLen, alpha, type, minFrames, threshold, nm)
+{
+  minSV_ = minSV;
+  fbinX1_ = fbinX1;
+}
+
+void LefkimmiatisPostFilter::calc_inverse_noise_spatial_spectral_matrix()
+{
+  // calcLambda only needs d^H pinv(R) d, formed with the look direction when the block is computed
+  if (!dR_) throw j_error("%s", no_R_msg_());
+  prepared_ = false;
+}
+
+// ================================================================================ SubbandGSCRLS
+SubbandGSCRLS::SubbandGSCRLS(unsigned fftLen, bool halfBandShift, float mu, float sigma2, const String& nm)
+    : SubbandGSC(fftLen, halfBandShift, nm), mu_(mu), diagonal_weight_(sigma2), alpha_(-1.0f), qctype_(NO_QUADRATIC_CONSTRAINT),
+      is_wa_updated_(true), have_P_(false), dP_(NULL), dW_(NULL), dV_(NULL), dSS_(NULL) {}
+
+SubbandGSCRLS::~SubbandGSCRLS() { dev_free(dP_); dev_free(dW_); dev_free(dV_); dev_free(dSS_); }
+
+void SubbandGSCRLS::alloc_state_()
+{
+  if (!bfweight_) throw j_error("call calc_gsc_weights_x() once\n");
+  if (bfweight_->NC() != 1) throw jdimension_error("the GPU RLS canceller supports NC = 1 constraint (got %d)\n", bfweight_->NC());
+  const unsigned N = chanN(), K = fftLen2_ + 1;
+  dev_free(dP_); dev_free(dW_); dev_free(dV_); dev_free(dSS_);
+  dP_ = dev_alloc(sizeof(double) * 2 * K * N * N);
+  dW_ = dev_alloc(sizeof(double) * 2 * K * N);
+  dV_ = dev_alloc(sizeof(double) * 2 * K * N);
+  dSS_ = dev_alloc(sizeof(double) * 4);
+  check_hip(hipMemset(dSS_, 0, sizeof(double) * 4), "hipMemset");
+  h2d(dV_, bfweight_->wq.data(), sizeof(double) * 2 * K * N);                 // bins 0..M/2 of wq [M][N]
+}
+
+void SubbandGSCRLS::init_precision_matrix(float sigma2)
+{
+  alloc_state_();
+  const unsigned N = chanN(), K = fftLen2_ + 1;
+  const float p0 = 1 / sigma2;                                                // float division, beamformer.cc:1491
+  check_abi(btk_rls_init(0, dV_, 0, (double)p0, 1, (int)K, (int)N, dP_, dW_, NULL));
+  // the active weights kept in the weight object are the starting point (zeros after calc_gsc_weights)
+  h2d(dW_, bfweight_->wl.data(), sizeof(double) * 2 * K * N);
+  have_P_ = true;
+  Yhost_.clear();
+}
+
+void SubbandGSCRLS::set_precision_matrix(unsigned fbinX, gsl_matrix_complex* Pz)
+{
+  if (!have_P_) {
+    alloc_state_();
+    const unsigned N = chanN(), K = fftLen2_ + 1;
+    check_hip(hipMemset(dP_, 0, sizeof(double) * 2 * K * N * N), "hipMemset");
+    h2d(dW_, bfweight_->wl.data(), sizeof(double) * 2 * K * N);
+    have_P_ = true;
+  }
+  const unsigned N = chanN(), bs = N - 1;
+  if (fbinX > fftLen2_) return;                                               // only bins 1..M/2 are ever used
+  if (Pz->size1 < bs || Pz->size2 < bs) throw jdimension_error("the precision matrix must be at least %dx%d\n", bs, bs);
+  // engine basis: P = B Pz B^H
+  const cd* B = &bfweight_->B[(size_t)fbinX * N * bs];
+  std::vector<cd> T((size_t)N * bs), P((size_t)N * N);
+  for (unsigned a = 0; a < N; a++)
+    for (unsigned j = 0; j < bs; j++) {
+      cd acc(0, 0);
+      for (unsigned i = 0; i < bs; i++) {
+        const gsl_complex z = gsl_matrix_complex_get(Pz, i, j);
+        acc += B[(size_t)a * bs + i] * cd(GSL_REAL(z), GSL_IMAG(z));
+      }
+      T[(size_t)a * bs + j] = acc;
+    }
+  for (unsigned a = 0; a < N; a++)
+    for (unsigned b = 0; b < N; b++) {
+      cd acc(0, 0);
+      for (unsigned j = 0; j < bs; j++) acc += T[(size_t)a * bs + j] * std::conj(B[(size_t)b * bs + j]);
+      P[(size_t)a * N + b] = acc;
+    }
+  h2d(static_cast<double*>(dP_) + (size_t)2 * fbinX * N * N, P.data(), sizeof(double) * 2 * N * N);
+  Yhost_.clear();
+}
+
+void SubbandGSCRLS::run_block_()
+{
+  const unsigned N = chanN(), K = fftLen2_ + 1;
+  void* dX = device_snapshots();
+  void* dY = dev_alloc(sizeof(float) * 2 * K * (T_ ? T_ : 1));
+  const double params[6] = { (double)mu_, (double)diagonal_weight_, (double)(int)qctype_, (double)alpha_,
+                             normalize_weight_ ? 1.0 : 0.0, is_wa_updated_ ? 1.0 : 0.0 };
+  void* ws = dev_alloc((size_t)btk_rls_workspace_bytes(1, T_ ? T_ : 1));
+  check_abi(btk_rls_process(0, params, dV_, 0, dX, dY, 1, (int)fftLen_, (int)N, T_, T_, dP_, dW_, (double*)dSS_, ws, NULL));
+  check_abi(btk_synchronize(NULL));
+  Yhost_.assign((size_t)2 * K * T_, 0.f);
+  if (T_) d2h(Yhost_.data(), dY, sizeof(float) * Yhost_.size());
+  dev_free(dY); dev_free(ws);
+  // export wl / wa of bins 1..M/2 as calcSidelobeCancellerU_f leaves them (beamformer.cc:1643)
+  std::vector<cd> wl((size_t)K * N);
+  d2h(wl.data(), dW_, sizeof(double) * 2 * K * N);
+  const unsigned bs = N - 1;
+  for (unsigned k = 1; k < K; k++) {
+    const cd* B = &bfweight_->B[(size_t)k * N * bs];
+    for (unsigned c = 0; c < N; c++) bfweight_->wl[(size_t)k * N + c] = wl[(size_t)k * N + c];
+    for (unsigned i = 0; i < bs; i++) {
+      cd acc(0, 0);
+      for (unsigned c = 0; c < N; c++) acc += std::conj(B[(size_t)c * bs + i]) * wl[(size_t)k * N + c];
+      bfweight_->wa[(size_t)k * bs + i] = acc;
+    }
+  }
+  output_version_ = weights_version_;
+}
+
+const gsl_vector_complex* SubbandGSCRLS::next(int frame_no)
+{
+  if (frame_no == frame_no_) return vector_;
+  if (!bfweight_) throw j_error("call calc_gsc_weights_x() once\n");
+  if (!have_P_) throw j_error("set the precision matrix with init_precision_matrix() or set_precision_matrix()\n");
+  if (Yhost_.empty()) run_block_();
+  const long idx = frame_no_ + 1;
+  if (idx >= T_) { is_end_ = true; throw jiterator_error("end of samples!"); }
+  serve_frame(Yhost_, T_, fftLen_, idx, vector_);
+  increment_();
+  return vector_;
 }
