@@ -18,6 +18,7 @@
 //   2. zelinski_iir_kernel   : one wavefront per (stream, bin) row; 64-frame chunks scanned with a
 //                              Hillis-Steele linear-recurrence scan; gain applied to Y in place.
 #include "btk_internal.h"
+#include <cstdlib>
 
 namespace {
 
@@ -170,9 +171,7 @@ void pf_coherence_coeff_kernel(const float2* __restrict__ R, float threshold, in
   }
 }
 
-constexpr int PF_JB = 16;
-
-template <int NQ>
+template <int NQ, int PF_JB>
 __global__ __launch_bounds__(PF_NT)
 void bf_apply_stats2_kernel(const float2* __restrict__ W, long w_stream_stride, const float2* __restrict__ Dv,
                             const float2* __restrict__ X, float2* __restrict__ Y,
@@ -358,13 +357,27 @@ int btk_bf_apply_stats2(const void* W, const void* D, int per_stream_weights, co
   if (T == 0) return BTK_OK;
   const long wss = per_stream_weights ? (long)K * N : 0;
   dim3 grid((unsigned)((T + PF_NT - 1) / PF_NT), (unsigned)K, (unsigned)S);
-  if (Cv)
-    hipLaunchKernelGGL(bf_apply_stats2_kernel<2>, grid, dim3(PF_NT), 0, as_stream(stream),
+  // rows of C per register block: 16 rows x two forms overflow the SGPR file (the C entries are scalar loads) and
+  // N <= 8 wastes half of a 16-row block; measured in profiles/pf_ab.py.  BTK_PF_JB overrides (benchmarking only).
+  static const int jb_env = getenv("BTK_PF_JB") ? atoi(getenv("BTK_PF_JB")) : 0;
+  const int jb = jb_env ? jb_env : (Cv ? 8 : (N <= 8 ? 8 : 16));
+  if (Cv && jb == 16)
+    hipLaunchKernelGGL((bf_apply_stats2_kernel<2, 16>), grid, dim3(PF_NT), 0, as_stream(stream),
                        static_cast<const float2*>(W), wss, static_cast<const float2*>(D), static_cast<const float2*>(X),
                        static_cast<float2*>(Y), static_cast<const float2*>(Cs), static_cast<const float2*>(Cv),
                        static_cast<float2*>(U), static_cast<float2*>(V), E, K, N, T_stride, T);
+  else if (Cv)
+    hipLaunchKernelGGL((bf_apply_stats2_kernel<2, 8>), grid, dim3(PF_NT), 0, as_stream(stream),
+                       static_cast<const float2*>(W), wss, static_cast<const float2*>(D), static_cast<const float2*>(X),
+                       static_cast<float2*>(Y), static_cast<const float2*>(Cs), static_cast<const float2*>(Cv),
+                       static_cast<float2*>(U), static_cast<float2*>(V), E, K, N, T_stride, T);
+  else if (jb == 8)
+    hipLaunchKernelGGL((bf_apply_stats2_kernel<1, 8>), grid, dim3(PF_NT), 0, as_stream(stream),
+                       static_cast<const float2*>(W), wss, static_cast<const float2*>(D), static_cast<const float2*>(X),
+                       static_cast<float2*>(Y), static_cast<const float2*>(Cs), static_cast<const float2*>(nullptr),
+                       static_cast<float2*>(U), static_cast<float2*>(nullptr), E, K, N, T_stride, T);
   else
-    hipLaunchKernelGGL(bf_apply_stats2_kernel<1>, grid, dim3(PF_NT), 0, as_stream(stream),
+    hipLaunchKernelGGL((bf_apply_stats2_kernel<1, 16>), grid, dim3(PF_NT), 0, as_stream(stream),
                        static_cast<const float2*>(W), wss, static_cast<const float2*>(D), static_cast<const float2*>(X),
                        static_cast<float2*>(Y), static_cast<const float2*>(Cs), static_cast<const float2*>(nullptr),
                        static_cast<float2*>(U), static_cast<float2*>(nullptr), E, K, N, T_stride, T);
