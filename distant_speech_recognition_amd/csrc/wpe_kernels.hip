@@ -162,7 +162,16 @@ void wpe_rvec_kernel(const float2* __restrict__ X, const float* __restrict__ Win
   }
 }
 
-// One workgroup per (sc,k): R in global memory (in place), rhs -> solution written to G.
+// One workgroup per (sc,k): blocked left-looking Cholesky, 16-column panels factored in LDS.
+// The unblocked version swept the trailing matrix in global memory once per column (P = 264: ~100 MB of traffic per
+// matrix, 2056 matrices -> 51 ms, bandwidth-bound); here every panel is read once, updated from the already
+// factored columns staged through LDS in 16-column chunks, factored in LDS and written back once (< 1 MB per matrix).
+// Forward substitution rides along with the panels; back substitution re-reads them in reverse order.
+constexpr int CH_NB = 16;              // panel width
+constexpr int CH_LD = CH_NB + 1;       // padded row (float2): conflict-free row-per-lane access
+
+__device__ __forceinline__ float2 cmul_conj_b(float2 a, float2 b) { return make_float2(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y); }
+
 __global__ __launch_bounds__(256)
 void wpe_solve_kernel(float2* __restrict__ R, const float2* __restrict__ rvec, WpeGeom g, float load_factor,
                       float diagonal_bias, float2* __restrict__ G, int* __restrict__ fail_count)
@@ -172,9 +181,11 @@ void wpe_solve_kernel(float2* __restrict__ R, const float2* __restrict__ rvec, W
   if (!bin_active(g, k)) return;
   const int P = g.C * g.L;
   const int tid = threadIdx.x;
-  float2* rhs = reinterpret_cast<float2*>(smem);                   // [P]  (all LDS carved from the dynamic region, 16-B aligned)
-  float* red = reinterpret_cast<float*>(rhs + ((P + 1) & ~1));     // [256]
-  volatile int& bad = *reinterpret_cast<volatile int*>(red + 256);
+  const int Ppad = (P + 1) & ~1;
+  float2* rhs = reinterpret_cast<float2*>(smem);                   // [Ppad]
+  float* red = reinterpret_cast<float*>(rhs + Ppad);               // [512]
+  float2* panel = reinterpret_cast<float2*>(red + 512);            // [P][CH_LD]
+  float2* chunk = panel + (long)P * CH_LD;                         // [P][CH_LD]
   float2* mat = R + ((long)sc * g.K + k) * (long)P * P;
   const int s = sc / g.C, c = sc % g.C;
   float2* gout = G + (((long)s * g.C + c) * g.K + k) * (long)P;
@@ -189,60 +200,159 @@ void wpe_solve_kernel(float2* __restrict__ R, const float2* __restrict__ rvec, W
     mx = fmaxf(mx, a);
   }
   red[tid] = mx;
-  if (tid == 0) bad = 0;
   __syncthreads();
   for (int o = 128; o > 0; o >>= 1) { if (tid < o) red[tid] = fmaxf(red[tid], red[tid + o]); __syncthreads(); }
   const float load = red[0] * load_factor;
+  __syncthreads();
   for (int p = tid; p < P; p += 256) mat[(long)p * P + p].x += load;
   __syncthreads();
 
-  for (int j = 0; j < P; j++) {
-    if (tid == 0) {
-      const float piv = mat[(long)j * P + j].x;
-      if (!(piv > 0.f)) bad = 1; else mat[(long)j * P + j] = make_float2(sqrtf(piv), 0.f);
+  bool bad = false;
+  for (int jb = 0; jb < P && !bad; jb += CH_NB) {
+    const int nb = (P - jb < CH_NB) ? P - jb : CH_NB;
+    const int rows = P - jb;
+    // ---- panel <- A[jb.., jb..jb+nb)
+    for (int idx = tid; idx < rows * CH_NB; idx += 256) {
+      const int r = idx / CH_NB, cc = idx % CH_NB;
+      panel[r * CH_LD + cc] = (cc < nb) ? mat[(long)(jb + r) * P + jb + cc] : make_float2(0.f, 0.f);
     }
-    __syncthreads();
-    if (bad) break;
-    const float inv = 1.0f / mat[(long)j * P + j].x;
-    for (int i = j + 1 + tid; i < P; i += 256) {
-      float2 v = mat[(long)i * P + j];
-      mat[(long)i * P + j] = make_float2(v.x * inv, v.y * inv);
-    }
-    __syncthreads();
-    const int rem = P - j - 1;
-    for (int idx = tid; idx < rem * rem; idx += 256) {
-      const int i = j + 1 + idx / rem, cc = j + 1 + idx % rem;
-      if (cc <= i) {
-        const float2 a = mat[(long)i * P + j], b = mat[(long)cc * P + j];
-        float2 v = mat[(long)i * P + cc];
-        v.x -= a.x * b.x + a.y * b.y;
-        v.y -= a.y * b.x - a.x * b.y;
-        mat[(long)i * P + cc] = v;
+    // ---- left-looking update: panel[r][cc] -= sum_{q<jb} L[jb+r][q] conj(L[jb+cc][q]), chunks of CH_NB previous columns
+    for (int r0 = 0; r0 < rows; r0 += 256) {
+      const int r = r0 + tid;
+      float2 acc[CH_NB];
+#pragma unroll
+      for (int cc = 0; cc < CH_NB; cc++) acc[cc] = make_float2(0.f, 0.f);
+      for (int q0 = 0; q0 < jb; q0 += CH_NB) {
+        __syncthreads();
+        for (int idx = tid; idx < rows * CH_NB; idx += 256) {     // chunk <- L[jb.., q0..q0+CH_NB)  (64-byte row pieces)
+          const int rr = idx / CH_NB, qq = idx % CH_NB;
+          chunk[rr * CH_LD + qq] = mat[(long)(jb + rr) * P + q0 + qq];
+        }
+        __syncthreads();
+        if (r < rows) {
+#pragma unroll 4
+          for (int qq = 0; qq < CH_NB; qq++) {
+            const float2 a = chunk[r * CH_LD + qq];
+#pragma unroll
+            for (int cc = 0; cc < CH_NB; cc++) {
+              const float2 b = chunk[cc * CH_LD + qq];              // rows jb..jb+nb of the same chunk (broadcast)
+              acc[cc].x = fmaf(a.x, b.x, fmaf(a.y, b.y, acc[cc].x));
+              acc[cc].y = fmaf(a.y, b.x, fmaf(-a.x, b.y, acc[cc].y));
+            }
+          }
+        }
+      }
+      __syncthreads();
+      if (r < rows) {
+#pragma unroll
+        for (int cc = 0; cc < CH_NB; cc++) {
+          float2 v = panel[r * CH_LD + cc];
+          panel[r * CH_LD + cc] = make_float2(v.x - acc[cc].x, v.y - acc[cc].y);
+        }
       }
     }
     __syncthreads();
-  }
-  __syncthreads();
-  if (bad) { if (tid == 0) atomicAdd(fail_count, 1); return; }
-  for (int j = 0; j < P; j++) {                                   // L y = r
-    if (tid == 0) { const float inv = 1.0f / mat[(long)j * P + j].x; rhs[j].x *= inv; rhs[j].y *= inv; }
+    // ---- factor the panel in LDS
+    for (int cc = 0; cc < nb; cc++) {
+      const float piv = panel[cc * CH_LD + cc].x;                  // final value: same for every thread
+      if (!(piv > 0.f)) { bad = true; break; }
+      const float d = sqrtf(piv), inv = 1.0f / d;
+      __syncthreads();
+      for (int r = tid; r < rows; r += 256) {
+        if (r == cc) panel[r * CH_LD + cc] = make_float2(d, 0.f);
+        else if (r > cc) { const float2 v = panel[r * CH_LD + cc]; panel[r * CH_LD + cc] = make_float2(v.x * inv, v.y * inv); }
+      }
+      __syncthreads();
+      for (int r = tid; r < rows; r += 256) {
+        if (r > cc) {
+          const float2 a = panel[r * CH_LD + cc];
+          for (int c2 = cc + 1; c2 < nb; c2++) {
+            if (c2 <= r) {
+              const float2 t = cmul_conj_b(a, panel[c2 * CH_LD + cc]);
+              float2 v = panel[r * CH_LD + c2];
+              panel[r * CH_LD + c2] = make_float2(v.x - t.x, v.y - t.y);
+            }
+          }
+        }
+      }
+      __syncthreads();
+    }
+    if (bad) break;
+    // ---- write the factored panel back, forward substitution for its columns: L y = r
+    for (int idx = tid; idx < rows * CH_NB; idx += 256) {
+      const int r = idx / CH_NB, cc = idx % CH_NB;
+      if (cc < nb && cc <= r) mat[(long)(jb + r) * P + jb + cc] = panel[r * CH_LD + cc];
+    }
+    if (tid == 0) {
+      for (int cc = 0; cc < nb; cc++) {
+        float2 y = rhs[jb + cc];
+        for (int c2 = 0; c2 < cc; c2++) {
+          const float2 l = panel[cc * CH_LD + c2], yy = rhs[jb + c2];
+          y.x -= l.x * yy.x - l.y * yy.y;
+          y.y -= l.x * yy.y + l.y * yy.x;
+        }
+        const float inv = 1.0f / panel[cc * CH_LD + cc].x;
+        rhs[jb + cc] = make_float2(y.x * inv, y.y * inv);
+      }
+    }
     __syncthreads();
-    const float2 yj = rhs[j];
-    for (int i = j + 1 + tid; i < P; i += 256) {
-      const float2 l = mat[(long)i * P + j];
-      rhs[i].x -= l.x * yj.x - l.y * yj.y;
-      rhs[i].y -= l.x * yj.y + l.y * yj.x;
+    for (int r = nb + tid; r < rows; r += 256) {
+      float2 y = rhs[jb + r];
+      for (int cc = 0; cc < nb; cc++) {
+        const float2 l = panel[r * CH_LD + cc], yy = rhs[jb + cc];
+        y.x -= l.x * yy.x - l.y * yy.y;
+        y.y -= l.x * yy.y + l.y * yy.x;
+      }
+      rhs[jb + r] = y;
     }
     __syncthreads();
   }
-  for (int j = P - 1; j >= 0; j--) {                              // L^H g = y
-    if (tid == 0) { const float inv = 1.0f / mat[(long)j * P + j].x; rhs[j].x *= inv; rhs[j].y *= inv; }
+  if (bad) { if (tid == 0) atomicAdd(fail_count, 1); return; }
+  // ---- back substitution L^H g = y, panels in reverse order
+  const int npan = (P + CH_NB - 1) / CH_NB;
+  for (int pb = npan - 1; pb >= 0; pb--) {
+    const int jb = pb * CH_NB;
+    const int nb = (P - jb < CH_NB) ? P - jb : CH_NB;
+    const int rows = P - jb;
     __syncthreads();
-    const float2 zj = rhs[j];
-    for (int i = tid; i < j; i += 256) {
-      const float2 l = mat[(long)j * P + i];
-      rhs[i].x -= l.x * zj.x + l.y * zj.y;
-      rhs[i].y -= l.x * zj.y - l.y * zj.x;
+    for (int idx = tid; idx < rows * CH_NB; idx += 256) {
+      const int r = idx / CH_NB, cc = idx % CH_NB;
+      panel[r * CH_LD + cc] = (cc < nb && cc <= r) ? mat[(long)(jb + r) * P + jb + cc] : make_float2(0.f, 0.f);
+    }
+    __syncthreads();
+    // contributions of the rows below the diagonal block: sum_r conj(L[r][cc]) g[r], r >= nb
+    float2 part[CH_NB];
+#pragma unroll
+    for (int cc = 0; cc < CH_NB; cc++) part[cc] = make_float2(0.f, 0.f);
+    for (int r = nb + tid; r < rows; r += 256) {
+      const float2 gr = rhs[jb + r];
+#pragma unroll
+      for (int cc = 0; cc < CH_NB; cc++) {
+        const float2 l = panel[r * CH_LD + cc];
+        part[cc].x += l.x * gr.x + l.y * gr.y;                     // conj(l) * g
+        part[cc].y += l.x * gr.y - l.y * gr.x;
+      }
+    }
+    // reduce the 16 partial sums over the workgroup: wave shuffles, then 4 waves through LDS
+#pragma unroll
+    for (int cc = 0; cc < CH_NB; cc++) {
+      float px = part[cc].x, py = part[cc].y;
+      for (int o = 32; o > 0; o >>= 1) { px += __shfl_xor(px, o, 64); py += __shfl_xor(py, o, 64); }
+      if ((tid & 63) == 0) { red[((tid >> 6) * CH_NB + cc) * 2] = px; red[((tid >> 6) * CH_NB + cc) * 2 + 1] = py; }
+    }
+    __syncthreads();
+    if (tid == 0) {
+      for (int cc = nb - 1; cc >= 0; cc--) {
+        float2 z = rhs[jb + cc];
+        for (int wv = 0; wv < 4; wv++) { z.x -= red[(wv * CH_NB + cc) * 2]; z.y -= red[(wv * CH_NB + cc) * 2 + 1]; }
+        for (int c2 = cc + 1; c2 < nb; c2++) {
+          const float2 l = panel[c2 * CH_LD + cc], gg = rhs[jb + c2];
+          z.x -= l.x * gg.x + l.y * gg.y;
+          z.y -= l.x * gg.y - l.y * gg.x;
+        }
+        const float inv = 1.0f / panel[cc * CH_LD + cc].x;
+        rhs[jb + cc] = make_float2(z.x * inv, z.y * inv);
+      }
     }
     __syncthreads();
   }
@@ -288,13 +398,18 @@ int btk_wpe_estimate(const void* X, int S, int K, int C, long T_stride, long T, 
   const int ntile = (int)((P + 63) / 64);
   const size_t lds_herk = sizeof(float2) * 2 * 64 * WLD + sizeof(float) * WT_;
   const float load_factor = (float)pow(10.0, load_db / 10.0);
+  const size_t lds_solve = sizeof(float2) * ((P + 1) & ~1L) + sizeof(float) * 512 + sizeof(float2) * 2 * (size_t)P * CH_LD;
+  if (lds_solve > 160 * 1024)
+    return btk_set_error(BTK_ERR_DIMENSION, "btk_wpe_estimate: C*(upperN-lowerN+1) = %ld taps exceed the LDS-resident solver (max ~560)", P);
+  if (lds_solve > 64 * 1024)
+    BTK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(wpe_solve_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_solve));
   for (int it = 0; it < iterations; it++) {
     hipLaunchKernelGGL(wpe_predict_kernel, dim3((unsigned)((T + 255) / 256), (unsigned)K, (unsigned)(S * C)), dim3(256), 0, st,
                        Xp, Gp, g, 0, Winv, static_cast<float2*>(nullptr));
     hipLaunchKernelGGL(wpe_herk_kernel, dim3((unsigned)(ntile * (ntile + 1) / 2), (unsigned)K, (unsigned)(S * C)), dim3(256),
                        lds_herk, st, Xp, Winv, g, ntile, R);
     hipLaunchKernelGGL(wpe_rvec_kernel, dim3((unsigned)K, (unsigned)(S * C)), dim3(256), 0, st, Xp, Winv, g, rvec);
-    hipLaunchKernelGGL(wpe_solve_kernel, dim3((unsigned)K, (unsigned)(S * C)), dim3(256), sizeof(float2) * ((P + 1) & ~1L) + sizeof(float) * 260, st,
+    hipLaunchKernelGGL(wpe_solve_kernel, dim3((unsigned)K, (unsigned)(S * C)), dim3(256), lds_solve, st,
                        R, rvec, g, load_factor, (float)diagonal_bias, Gp, fail_count);
     BTK_HIP_CHECK(hipGetLastError());
   }
