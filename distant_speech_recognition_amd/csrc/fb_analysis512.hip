@@ -494,7 +494,7 @@ template <int R>
 __global__ __launch_bounds__(A_NT, 2)
 void synthesis512_kernel(const float2* __restrict__ Y, long nframes, long T_stride, int K,
                          const float* __restrict__ proto, const float2* __restrict__ twg,
-                         int pd, float gain, float* __restrict__ out, long out_stride, long b0, long bcount)
+                         int pd, float gain, float* __restrict__ out, long out_stride, long b0, long bcount, int srun)
 {
   constexpr int D = A_M / R;
   constexpr int HALO = A_MT * R - 1;
@@ -506,8 +506,8 @@ void synthesis512_kernel(const float2* __restrict__ Y, long nframes, long T_stri
   float2* twj = tw + (A_NF + 1);                              // [256]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int s = blockIdx.y;
-  const long bt0 = b0 + (long)blockIdx.x * S_RUN;             // first block of this run
-  const long bend = (bt0 + S_RUN < b0 + bcount) ? bt0 + S_RUN : b0 + bcount;
+  const long bt0 = b0 + (long)blockIdx.x * srun;              // first block of this run
+  const long bend = (bt0 + srun < b0 + bcount) ? bt0 + srun : b0 + bcount;
   const float2* Ys = Y + (long)s * K * T_stride;
   float* os = out + (long)s * out_stride;
 
@@ -635,9 +635,13 @@ int launch_syn512(const btk_fb* fb, const float2* Y, long nframes, long T_stride
     BTK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;
   }
-  const unsigned gx = (unsigned)((bcount + S_RUN - 1) / S_RUN);
+  // run length: S_RUN blocks amortise the m R - 1 frame ring priming best, but few streams need shorter runs to fill
+  // the chip (a single stream of 4096 blocks would be 32 workgroups); multiples of the 16-frame chunk, >= 512 runs
+  long srun = ((bcount * S / 512 + 15) / 16) * 16;
+  srun = srun < 16 ? 16 : (srun > S_RUN ? S_RUN : srun);
+  const unsigned gx = (unsigned)((bcount + srun - 1) / srun);
   hipLaunchKernelGGL(kern, dim3(gx, (unsigned)S), dim3(A_NT), lds, st, Y, nframes, T_stride, fb->K, fb->d_proto, fb->d_tw,
-                     fb->pd, (float)fb->gain_factor, out, out_stride, b0, bcount);
+                     fb->pd, (float)fb->gain_factor, out, out_stride, b0, bcount, (int)srun);
   BTK_HIP_CHECK(hipGetLastError());
   return BTK_OK;
 }

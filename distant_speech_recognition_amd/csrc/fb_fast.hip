@@ -347,7 +347,7 @@ template <int LOG2M, int R>
 __global__ __launch_bounds__(F_NT, 1)
 void fast_synthesis_kernel(const float2* __restrict__ Y, long nframes, long T_stride, int K,
                            const float* __restrict__ proto, const float2* __restrict__ twg,
-                           int pd, float gain, float* __restrict__ out, long out_stride, long b0, long bcount)
+                           int pd, float gain, float* __restrict__ out, long out_stride, long b0, long bcount, int srun)
 {
   using G = FG<LOG2M>;
   constexpr int M = G::M, NF = G::NF, TT = G::TT, FRS = G::FRS, P2 = G::P2, KQ = G::KQ;
@@ -362,8 +362,8 @@ void fast_synthesis_kernel(const float2* __restrict__ Y, long nframes, long T_st
   float2* twj = ring + NRING * FRS;                           // [NF]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int s = blockIdx.y;
-  const long bt0 = b0 + (long)blockIdx.x * F_SRUN;
-  const long bend = (bt0 + F_SRUN < b0 + bcount) ? bt0 + F_SRUN : b0 + bcount;
+  const long bt0 = b0 + (long)blockIdx.x * srun;
+  const long bend = (bt0 + srun < b0 + bcount) ? bt0 + srun : b0 + bcount;
   const float2* Ys = Y + (long)s * K * T_stride;
   float* os = out + (long)s * out_stride;
 
@@ -500,9 +500,12 @@ int launch_fast_synthesis(const btk_fb* fb, const float2* Y, long nframes, long 
     BTK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;
   }
-  const unsigned gx = (unsigned)((bcount + F_SRUN - 1) / F_SRUN);
+  // shorter runs when few streams would leave the chip empty (see synthesis512): multiples of TT, aiming at >= 512 runs
+  long srun = ((bcount * S / 512 + G::TT - 1) / G::TT) * G::TT;
+  srun = srun < 2 * G::TT ? 2 * G::TT : (srun > F_SRUN ? F_SRUN : srun);
+  const unsigned gx = (unsigned)((bcount + srun - 1) / srun);
   hipLaunchKernelGGL(kern, dim3(gx, (unsigned)S), dim3(F_NT), lds, st, Y, nframes, T_stride, fb->K, fb->d_proto, fb->d_tw,
-                     fb->pd, (float)fb->gain_factor, out, out_stride, b0, bcount);
+                     fb->pd, (float)fb->gain_factor, out, out_stride, b0, bcount, (int)srun);
   BTK_HIP_CHECK(hipGetLastError());
   return 1;
 }

@@ -16,12 +16,12 @@
 //   wpe_rvec_kernel    : r_c
 //   wpe_solve_kernel   : diagonal bias + loading + in-place Cholesky (matrix in global memory / L2) + solves
 #include "btk_internal.h"
+#include <cstdlib>
 
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int WT_ = 32;                // frames per LDS tile
-constexpr int WLD = WT_ + 1;
 
 struct WpeGeom { int K, C, L, lowerN, lower_bw, upper_bw; long T_stride, T; };
 
@@ -68,71 +68,95 @@ void wpe_predict_kernel(const float2* __restrict__ X, const float2* __restrict__
   }
 }
 
-// rows [row0,row0+64) of the lag matrix for frames [t0,t0+WT_): A[(c',l)][t] = X[c'][t-lowerN-l], t >= lowerN
-__device__ __forceinline__ void stage_lags(const float2* __restrict__ Xk, const WpeGeom& g, int P, int row0, long t0,
-                                           float2* __restrict__ dst, int tid)
-{
-  for (int idx = tid; idx < 64 * WT_; idx += 256) {
-    const int r = idx / WT_, tt = idx % WT_;
-    const int p = row0 + r;
-    const long t = t0 + tt;
-    float2 v = make_float2(0.f, 0.f);
-    if (p < P && t < g.T && t >= g.lowerN) {
-      const int cc = p / g.L, l = p % g.L;
-      const long i = t - g.lowerN - l;
-      if (i >= 0) v = Xk[(long)cc * g.T_stride + i];
-    }
-    dst[r * WLD + tt] = v;
-  }
-}
 
-// grid: (lower-triangle tile pairs, K, S*C)
+// grid: (lower-triangle tile pairs, K, S*C/CB).  The lag matrix is the same for all target channels -- only the weights
+// 1/theta_c differ -- so one workgroup accumulates the tiles of CB channels from ONE staging of the lag rows.
+// Staging: row (c', l) of the lag matrix is the snapshot row of channel c' shifted by l, so a 64-row tile x WT_ frames
+// only touches a (WT_ + L - 1)-sample span of at most 64/L + 2 channels.  The spans go to LDS (a few hundred
+// elements instead of 64 x WT_ per tile) and every lane reads its row through its own shift -- consecutive lags
+// are consecutive addresses, i.e. conflict-free.
+template <int CB>
 __global__ __launch_bounds__(256)
 void wpe_herk_kernel(const float2* __restrict__ X, const float* __restrict__ Winv, WpeGeom g, int ntile,
-                     float2* __restrict__ R)
+                     float2* __restrict__ R, int skip_unused, int nspan)
 {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  float2* Ai = reinterpret_cast<float2*>(smem);
-  float2* Aj = Ai + 64 * WLD;
-  float* wrow = reinterpret_cast<float*>(Aj + 64 * WLD);
+  const int SPW = WT_ + g.L - 1;                                   // samples per channel span
+  float2* spanI = reinterpret_cast<float2*>(smem);                 // [nspan][SPW]
+  float2* spanJ = spanI + nspan * SPW;
+  float* wrow = reinterpret_cast<float*>(spanJ + nspan * SPW);     // [CB][WT_]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int k = blockIdx.y, sc = blockIdx.z;
+  const int k = blockIdx.y;
   if (!bin_active(g, k)) return;
-  const int s = sc / g.C;
+  const int ncg = g.C / CB;
+  const int s = blockIdx.z / ncg, c0 = (blockIdx.z % ncg) * CB;
   const int P = g.C * g.L;
   // blockIdx.x -> (ti >= tj)
   int ti = 0, rem = blockIdx.x;
   while (rem > ti) { rem -= ti + 1; ti++; }
   const int tj = rem;
   const float2* Xk = X + ((long)s * g.K + k) * g.C * g.T_stride;
-  const float* w = Winv + ((long)sc * g.K + k) * g.T_stride;
   const int qi = wave >> 1, qj = wave & 1;
-  f32x16 rr = {0}, ri = {0};
+  f32x16 rr[CB], ri[CB];
+#pragma unroll
+  for (int cb = 0; cb < CB; cb++) { rr[cb] = f32x16{0}; ri[cb] = f32x16{0}; }
   const int li = lane & 31, lk = lane >> 5;
+  // a wavefront owns one 32x32 quadrant; quadrants strictly above the diagonal or beyond P are never read by the
+  // solver -> their MFMAs are skipped (P = 160: 15 of 24 quadrants remain, P = 264: 45 of 60)
+  const int bi = ti * 2 + qi, bj = tj * 2 + qj;
+  const bool quad_active = !skip_unused || (bi >= bj && bi * 32 < P && bj * 32 < P);
+  // this lane's rows of the two tiles -> (channel, lag) -> offset into the spans
+  const int chI0 = (ti * 64) / g.L, chJ0 = (tj * 64) / g.L;
+  const int pI = ti * 64 + qi * 32 + li, pJ = tj * 64 + qj * 32 + li;
+  const bool vI = pI < P, vJ = pJ < P;
+  const int offI = vI ? (pI / g.L - chI0) * SPW + (g.L - 1 - pI % g.L) : 0;
+  const int offJ = vJ ? (pJ / g.L - chJ0) * SPW + (g.L - 1 - pJ % g.L) : 0;
   for (long t0 = 0; t0 < g.T; t0 += WT_) {
     __syncthreads();
-    stage_lags(Xk, g, P, ti * 64, t0, Ai, tid);
-    stage_lags(Xk, g, P, tj * 64, t0, Aj, tid);
-    if (tid < WT_) { const long t = t0 + tid; wrow[tid] = (t < g.T && t >= g.lowerN) ? w[t] : 0.f; }
+    // span element j of channel ch holds sample i = t0 - lowerN - (L-1) + j (zero outside [0, T))
+    for (int idx = tid; idx < 2 * nspan * SPW; idx += 256) {
+      const int which = idx / (nspan * SPW), e = idx % (nspan * SPW);
+      const int ch = (which ? chJ0 : chI0) + e / SPW;
+      const long i = t0 - g.lowerN - (g.L - 1) + e % SPW;
+      float2 v = make_float2(0.f, 0.f);
+      if (ch < g.C && i >= 0 && i < g.T) v = Xk[(long)ch * g.T_stride + i];
+      (which ? spanJ : spanI)[e] = v;
+    }
+    if (tid < CB * WT_) {
+      const int cb = tid / WT_, tt = tid % WT_;
+      const long t = t0 + tt;
+      const float* w = Winv + (((long)s * g.C + c0 + cb) * g.K + k) * g.T_stride;
+      wrow[cb * WT_ + tt] = (t < g.T && t >= g.lowerN) ? w[t] : 0.f;
+    }
     __syncthreads();
-#pragma unroll 4
+    if (!quad_active) continue;
+#pragma unroll 2
     for (int kk = 0; kk < WT_; kk += 2) {
-      const float2 a = Ai[(qi * 32 + li) * WLD + kk + lk];
-      float2 b = Aj[(qj * 32 + li) * WLD + kk + lk];
-      const float wv = wrow[kk + lk];
-      b.x *= wv; b.y *= wv;
-      rr = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, rr, 0, 0, 0);
-      rr = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, rr, 0, 0, 0);
-      ri = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.x, ri, 0, 0, 0);
-      ri = __builtin_amdgcn_mfma_f32_32x32x2f32(-a.x, b.y, ri, 0, 0, 0);
+      float2 a = spanI[offI + kk + lk];
+      float2 b = spanJ[offJ + kk + lk];
+      if (!vI) a = make_float2(0.f, 0.f);
+      if (!vJ) b = make_float2(0.f, 0.f);
+#pragma unroll
+      for (int cb = 0; cb < CB; cb++) {
+        const float wv = wrow[cb * WT_ + kk + lk];
+        const float bx = b.x * wv, by = b.y * wv;
+        rr[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, bx, rr[cb], 0, 0, 0);
+        rr[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, by, rr[cb], 0, 0, 0);
+        ri[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, bx, ri[cb], 0, 0, 0);
+        ri[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(-a.x, by, ri[cb], 0, 0, 0);
+      }
     }
   }
-  float2* Rk = R + ((long)sc * g.K + k) * (long)P * P;
+  if (!quad_active) return;
 #pragma unroll
-  for (int reg = 0; reg < 16; reg++) {
-    const int row = ti * 64 + qi * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
-    const int col = tj * 64 + qj * 32 + (lane & 31);
-    if (row < P && col < P) Rk[(long)row * P + col] = make_float2(rr[reg], ri[reg]);
+  for (int cb = 0; cb < CB; cb++) {
+    float2* Rk = R + (((long)s * g.C + c0 + cb) * g.K + k) * (long)P * P;
+#pragma unroll
+    for (int reg = 0; reg < 16; reg++) {
+      const int row = ti * 64 + qi * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+      const int col = tj * 64 + qj * 32 + (lane & 31);
+      if (row < P && col < P) Rk[(long)row * P + col] = make_float2(rr[cb][reg], ri[cb][reg]);
+    }
   }
 }
 
@@ -396,7 +420,8 @@ int btk_wpe_estimate(const void* X, int S, int K, int C, long T_stride, long T, 
   const float2* Xp = static_cast<const float2*>(X);
   float2* Gp = static_cast<float2*>(G);
   const int ntile = (int)((P + 63) / 64);
-  const size_t lds_herk = sizeof(float2) * 2 * 64 * WLD + sizeof(float) * WT_;
+  const int nspan = 63 / g.L + 2;                                  // channels a 64-row tile can touch
+  const size_t lds_herk = sizeof(float2) * 2 * (size_t)nspan * (WT_ + g.L - 1) + sizeof(float) * 4 * WT_;
   const float load_factor = (float)pow(10.0, load_db / 10.0);
   const size_t lds_solve = sizeof(float2) * ((P + 1) & ~1L) + sizeof(float) * 512 + sizeof(float2) * 2 * (size_t)P * CH_LD;
   if (lds_solve > 160 * 1024)
@@ -406,8 +431,14 @@ int btk_wpe_estimate(const void* X, int S, int K, int C, long T_stride, long T, 
   for (int it = 0; it < iterations; it++) {
     hipLaunchKernelGGL(wpe_predict_kernel, dim3((unsigned)((T + 255) / 256), (unsigned)K, (unsigned)(S * C)), dim3(256), 0, st,
                        Xp, Gp, g, 0, Winv, static_cast<float2*>(nullptr));
-    hipLaunchKernelGGL(wpe_herk_kernel, dim3((unsigned)(ntile * (ntile + 1) / 2), (unsigned)K, (unsigned)(S * C)), dim3(256),
-                       lds_herk, st, Xp, Winv, g, ntile, R);
+    static const int skip = getenv("BTK_WPE_NOSKIP") ? 0 : 1;      // A/B switch (benchmarking only)
+    const dim3 hgrid1((unsigned)(ntile * (ntile + 1) / 2), (unsigned)K, (unsigned)(S * C));
+    if (C % 4 == 0)
+      hipLaunchKernelGGL(wpe_herk_kernel<4>, dim3(hgrid1.x, hgrid1.y, (unsigned)(S * C / 4)), dim3(256), lds_herk, st, Xp, Winv, g, ntile, R, skip, nspan);
+    else if (C % 2 == 0)
+      hipLaunchKernelGGL(wpe_herk_kernel<2>, dim3(hgrid1.x, hgrid1.y, (unsigned)(S * C / 2)), dim3(256), lds_herk, st, Xp, Winv, g, ntile, R, skip, nspan);
+    else
+      hipLaunchKernelGGL(wpe_herk_kernel<1>, hgrid1, dim3(256), lds_herk, st, Xp, Winv, g, ntile, R, skip, nspan);
     hipLaunchKernelGGL(wpe_rvec_kernel, dim3((unsigned)K, (unsigned)(S * C)), dim3(256), 0, st, Xp, Winv, g, rvec);
     hipLaunchKernelGGL(wpe_solve_kernel, dim3((unsigned)K, (unsigned)(S * C)), dim3(256), lds_solve, st,
                        R, rvec, g, load_factor, (float)diagonal_bias, Gp, fail_count);
