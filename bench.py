@@ -71,7 +71,7 @@ def main():
     ap.add_argument("--bins", type=int, default=512)
     ap.add_argument("--streams", type=int, default=16, help="utterance streams per GPU")
     ap.add_argument("--frames", type=int, default=4096, help="frames per stream per step")
-    ap.add_argument("--cpu-frames", type=int, default=6000)
+    ap.add_argument("--cpu-frames", type=int, default=16000, help="frames of the CPU-baseline sample (~12 s of one core)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--staged", action="store_true",
                     help="time the staged chain (analysis -> HBM snapshots -> apply) instead of the fused kernel")
@@ -209,7 +209,7 @@ def main():
             "metric": "beamformed subband frames/sec, 64-mic 512-bin SubbandGSC",
             "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "complex64 (f32)", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f32", "element": "complex64", "data": "synthetic",
             "xRT": value / (FS / D),
             "config": {"workload": "C0: %d-mic %d-bin SubbandGSC, analysis->GSC apply->synthesis (%s), m=4 r=1 (D=%d), "
                                    "%d streams/GPU x %d frames/step" % (N, M, "fused analysis+apply" if fused else "staged", D, S, T),

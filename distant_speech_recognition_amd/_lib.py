@@ -80,6 +80,7 @@ SIGNATURES = {
     "btk_wpe_apply": (_i, [_vp, _vp, _vp, _i, _i, _i, _l, _l, _i, _i, _i, _i, _vp]),
     "btk_weights_mainlobe": (_i, [_i, _i, _f, _vp, _vp]),
     "btk_weights_mainlobe_2": (_i, [_i, _i, _f, _vp, _vp, _vp]),
+    "btk_weights_mainlobe_n": (_i, [_i, _i, _f, _vp, _vp, _i, _vp]),
     "btk_weights_blocking_matrix": (_i, [_vp, _i, _i, _vp]),
     "btk_weights_sidelobe": (_i, [_vp, _vp, _i, _i, _vp]),
     "btk_weights_gsc_effective": (_i, [_vp, _vp, _i, _i, _i, _vp]),

@@ -211,6 +211,23 @@ class _BeamformerWeights(object):
             for k in range(self.fftlen):
                 self.B[k] = engine.weights_blocking_matrix(self.wq[k], self.NC)
 
+    def calc_mainlobe_n(self, samplerate, delays_t, delays_is, NC, is_gsc):
+        """calcMainlobeN (beamformer.cc:600-721), NC >= 2."""
+        if NC < 2 or NC > self.chan_num:
+            raise jdimension_error("1 < the number of constraints %d <= the number of sensors %d.\n" % (NC, self.chan_num))
+        delays_t = np.asarray(delays_t, np.float64)
+        delays_is = np.asarray(delays_is, np.float64).reshape(-1, self.chan_num)
+        if delays_t.size != self.chan_num:
+            raise jdimension_error("The number of delays does not match number of channels (%d vs. %d).\n" % (delays_t.size, self.chan_num))
+        try:
+            self.wq = engine.weights_mainlobe_n(self.fftlen, self.chan_num, samplerate, delays_t, delays_is, NC)
+        except _lib.BtkError as e:
+            raise_from_code(e)
+        self.ta = engine.weights_mainlobe(self.fftlen, self.chan_num, samplerate, delays_t)
+        if is_gsc:
+            for k in range(self.fftlen):
+                self.B[k] = engine.weights_blocking_matrix(self.wq[k], self.NC)
+
     def calc_sidelobe_canceller_f(self, fbin, wa):
         self.wa[fbin] = wa
         self.wl[fbin] = engine.weights_sidelobe(self.B[fbin], wa)
@@ -243,9 +260,9 @@ class SubbandDSPtr(_SubbandBeamformer):
         self._invalidate_output()
 
     def calc_array_manifold_vectors_n(self, samplerate, delays_t, delays_js, NC=2):
-        if NC != 2:
-            raise jdimension_error("the GPU engine designs LCMV weights for NC = 2 constraints (got %d)\n" % NC)
-        self.calc_array_manifold_vectors_2(samplerate, delays_t, np.asarray(delays_js, np.float64).reshape(-1, self.chan_num())[0])
+        self._alloc_bfweight(NC)
+        self._bfw[0].calc_mainlobe_n(samplerate, delays_t, delays_js, NC, False)
+        self._invalidate_output()
 
     def get_weights(self, fbin_no):
         return self._bfw[0].wq[fbin_no]
@@ -300,9 +317,9 @@ class SubbandGSCPtr(SubbandDSPtr):
         self._invalidate_output()
 
     def calc_gsc_weights_n(self, samplerate, delays_t, delays_is, NC=2):
-        if NC != 2:
-            raise jdimension_error("the GPU engine designs LCMV weights for NC = 2 constraints (got %d)\n" % NC)
-        self.calc_gsc_weights_2(samplerate, delays_t, np.asarray(delays_is, np.float64).reshape(-1, self.chan_num())[0])
+        self._alloc_bfweight(NC)
+        self._bfw[0].calc_mainlobe_n(samplerate, delays_t, delays_is, NC, True)
+        self._invalidate_output()
 
     def set_quiescent_weights_f(self, fbin_no, src_wq):
         self._alloc_bfweight(1)

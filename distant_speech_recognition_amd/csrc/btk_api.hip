@@ -288,3 +288,75 @@ extern "C" int btk_weights_mainlobe_2(int M, int N, float samplerate, const doub
   }
   return BTK_OK;
 }
+
+// LCMV quiescent weights with NC >= 2 constraints (look direction + NC-1 nulls): BeamformerWeights::calcMainlobeN
+// (reference beamformer/beamformer.cc:600-721).  NC = 2 is btk_weights_mainlobe_2 (closed-form 2x2 inverse); for
+// NC > 2 the reference inverts the NC x NC Gram matrix C^H C with its float32 SVD pseudoinverse (:352-355) -- here a
+// float64 Gauss-Jordan inverse with partial pivoting (same result to float32 precision for the well-conditioned
+// Gram matrices of distinct directions; a singular Gram matrix is reported as BTK_ERR_NUMERIC).
+namespace {
+bool lcmv_solve_n(cd* wt, const std::vector<std::vector<cd> >& wj, int N, int NC)
+{
+  std::vector<cd> G((size_t)NC * NC), inv((size_t)NC * NC, cd(0, 0));
+  auto col = [&](int j, int i) -> cd { return j == 0 ? wt[i] : wj[j - 1][i]; };
+  for (int a = 0; a < NC; a++)
+    for (int b = 0; b < NC; b++) {
+      cd acc(0, 0);
+      for (int i = 0; i < N; i++) acc += std::conj(col(a, i)) * col(b, i);
+      G[(size_t)a * NC + b] = acc;
+    }
+  for (int a = 0; a < NC; a++) inv[(size_t)a * NC + a] = cd(1, 0);
+  for (int c = 0; c < NC; c++) {
+    int piv = c;
+    for (int r = c + 1; r < NC; r++) if (std::abs(G[(size_t)r * NC + c]) > std::abs(G[(size_t)piv * NC + c])) piv = r;
+    if (!(std::abs(G[(size_t)piv * NC + c]) > 1.0e-12)) return false;
+    if (piv != c)
+      for (int b = 0; b < NC; b++) { std::swap(G[(size_t)c * NC + b], G[(size_t)piv * NC + b]); std::swap(inv[(size_t)c * NC + b], inv[(size_t)piv * NC + b]); }
+    const cd d = G[(size_t)c * NC + c];
+    for (int b = 0; b < NC; b++) { G[(size_t)c * NC + b] /= d; inv[(size_t)c * NC + b] /= d; }
+    for (int r = 0; r < NC; r++) {
+      if (r == c) continue;
+      const cd f = G[(size_t)r * NC + c];
+      for (int b = 0; b < NC; b++) { G[(size_t)r * NC + b] -= f * G[(size_t)c * NC + b]; inv[(size_t)r * NC + b] -= f * inv[(size_t)c * NC + b]; }
+    }
+  }
+  // wt <- C inv g, g = e_0
+  std::vector<cd> out(N);
+  for (int i = 0; i < N; i++) {
+    cd acc(0, 0);
+    for (int j = 0; j < NC; j++) acc += col(j, i) * inv[(size_t)j * NC + 0];
+    out[i] = acc;
+  }
+  for (int i = 0; i < N; i++) wt[i] = out[i];
+  return true;
+}
+}  // namespace
+
+extern "C" int btk_weights_mainlobe_n(int M, int N, float samplerate, const double* delaysT, const double* delaysIs, int NC,
+                                      double* wq_out)
+{
+  if (NC < 2 || NC > N)
+    return btk_set_error(BTK_ERR_DIMENSION, "1 < the number of constraints %d <= the number of sensors %d.\n", NC, N);
+  if (NC == 2) return btk_weights_mainlobe_2(M, N, samplerate, delaysT, delaysIs, wq_out);
+  int rc = btk_weights_mainlobe(M, N, samplerate, delaysT, wq_out);
+  if (rc) return rc;
+  cd* wq = reinterpret_cast<cd*>(wq_out);
+  const int half = M / 2;
+  std::vector<std::vector<cd> > wj(NC - 1, std::vector<cd>(N));
+  for (int c = 0; c < N; c++) wq[c] = cd(1.0 / N, 0.0);
+  for (int k = 1; k < half; k++) {
+    cd* vec = wq + (size_t)k * N;
+    for (int c = 0; c < N; c++) {
+      vec[c] *= (double)N;
+      for (int n = 0; n < NC - 1; n++) wj[n][c] = std::polar(1.0, -2.0 * M_PI * k * samplerate * delaysIs[(size_t)n * N + c] / M);
+    }
+    if (!lcmv_solve_n(vec, wj, N, NC)) return btk_set_error(BTK_ERR_NUMERIC, "calc_null_beamformer_() failed\n");
+  }
+  cd* vec = wq + (size_t)half * N;                          // bin M/2: literal reference behaviour (:692-703)
+  for (int c = 0; c < N; c++) {
+    vec[c] = std::polar(1.0, -M_PI * samplerate * delaysIs[(size_t)(NC - 2) * N + c]) / (double)N;   // the last n wins
+    if (!lcmv_solve_n(vec, wj, N, NC)) return btk_set_error(BTK_ERR_NUMERIC, "calc_null_beamformer_() failed\n");
+  }
+  return BTK_OK;
+}
+

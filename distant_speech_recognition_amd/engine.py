@@ -166,6 +166,17 @@ def weights_mainlobe_2(M, N, samplerate, delays_t, delays_i):
     return wq
 
 
+def weights_mainlobe_n(M, N, samplerate, delays_t, delays_is, NC):
+    """LCMV quiescent weights (target + NC-1 nulls): calcMainlobeN -> wq complex128 [M][N]; delays_is [NC-1][N]."""
+    dt = np.ascontiguousarray(delays_t, np.float64)
+    di = np.ascontiguousarray(delays_is, np.float64).reshape(-1, N)
+    if dt.shape != (N,) or di.shape != (NC - 1, N):
+        raise _lib.BtkError(_lib.BTK_ERR_DIMENSION, "The number of delays does not match number of channels (%d)" % N)
+    wq = np.zeros((M, N), np.complex128)
+    check(_lib.lib().btk_weights_mainlobe_n(M, N, float(samplerate), _np_ptr(dt), _np_ptr(di), int(NC), _np_ptr(wq)))
+    return wq
+
+
 def weights_blocking_matrix(a, NC=1):
     a = np.ascontiguousarray(a, np.complex128)
     N = a.shape[0]

@@ -263,6 +263,11 @@ int  btk_weights_mainlobe(int M, int N, float samplerate, const double* delays, 
 /* LCMV quiescent weights with two constraints (target + one null): calcMainlobe2 / calcMainlobeN +
  * calc_null_beamformer_ + calc_inverse_22mat_ (beamformer.cc:181-221, 299-363, 572-721); wq [M][N].   */
 int  btk_weights_mainlobe_2(int M, int N, float samplerate, const double* delaysT, const double* delaysI, double* wq);
+/* BeamformerWeights::calcMainlobeN (beamformer/beamformer.cc:600-721) with NC >= 2 constraints: delaysIs [host]
+ * float64 [NC-1][N].  NC = 2 takes the closed-form path above; NC > 2 inverts the NC x NC Gram matrix in float64
+ * (the reference: float32 SVD pseudoinverse, :352-355).                                                        */
+int  btk_weights_mainlobe_n(int M, int N, float samplerate, const double* delaysT, const double* delaysIs, int NC,
+                            double* wq);
 /* calc_blocking_matrix_ (beamformer.cc:373-454): a [host] complex128 [N]; B [host] [N][N-NC] */
 int  btk_weights_blocking_matrix(const double* a, int N, int NC, double* B);
 /* calcSidelobeCancellerU_f (beamformer.cc:752-767): wl = B wa                               */

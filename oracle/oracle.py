@@ -159,6 +159,41 @@ def calc_mainlobe_2(M, N, samplerate, delays_t, delays_i):
     return wq
 
 
+def calc_mainlobe_n(M, N, samplerate, delays_t, delays_is, NC):
+    """calcMainlobeN (beamformer.cc:600-721) for NC >= 2 with calc_null_beamformer_ (:299-363): the NC x NC Gram matrix
+    is inverted by calc_inverse_22mat_ for NC = 2 and by pseudoinverse() (float32 csvdc, oracle/_ref) otherwise."""
+    dt = np.ascontiguousarray(delays_t, np.float64)
+    dis = np.ascontiguousarray(delays_is, np.float64).reshape(NC - 1, N)
+    if NC == 2:
+        return calc_mainlobe_2(M, N, samplerate, dt, dis[0])
+    wq = calc_mainlobe(M, N, samplerate, dt)                       # :638
+    M2 = M // 2
+    g = np.zeros(NC, np.complex128)
+    g[0] = 1.0
+
+    def null_beamformer(wt, pWj):
+        Cm = np.stack([wt] + list(pWj), axis=1)                      # [N][NC]
+        G = np.conj(Cm.T) @ Cm
+        inv, _ = pseudoinverse(G)                                    # :352-355 (return value ignored there)
+        return Cm @ (inv @ g)
+
+    wq[0] = 1.0 / N
+    pWj = [np.zeros(N, np.complex128) for _ in range(NC - 1)]
+    for k in range(1, M2):                                           # :670-689
+        vec = wq[k] * N
+        for n in range(NC - 1):
+            pWj[n] = np.exp(1j * (-2.0 * np.pi * k * float(np.float32(samplerate)) * dis[n] / M))
+        wq[k] = null_beamformer(vec, pWj)
+    vec = wq[M2].copy()                                              # :692-703, reproduced literally
+    for c in range(N):
+        vec[c] = vec[c] * N
+        for n in range(NC - 1):
+            vec[c] = np.exp(1j * (-np.pi * float(np.float32(samplerate)) * dis[n][c])) / N
+        vec = null_beamformer(vec, pWj)
+    wq[M2] = vec
+    return wq
+
+
 def blocking_matrix(a, NC=1):
     a = _c128(a)
     N = a.shape[0]

@@ -75,3 +75,37 @@ def test_lcmv_weights_host(orc):
         assert abs(np.vdot(wq[k], vt) - 1.0) < 1e-12 and abs(np.vdot(wq[k], vj)) < 1e-12
     B = engine.weights_blocking_matrix(wq[9], 2)
     assert B.shape == (N, N - 2) and np.max(np.abs(wq[9] @ B)) < 1e-12
+
+
+def test_lcmv_weights_n_constraints_host(orc):
+    """calcMainlobeN with NC = 3, 4 (beamformer.cc:600-721): product (float64 inverse of the Gram matrix) vs the oracle
+    (the reference's float32 csvdc pseudoinverse, compiled into oracle/_ref when /root/reference is present, numpy
+    float32 SVD otherwise) + distortionless / null known answers; NC = 2 falls through to calcMainlobe2."""
+    import numpy as np
+    from distant_speech_recognition_amd import engine, _lib
+    from tests.util import ula_positions, la_delays
+    M, N = 64, 8
+    mp = ula_positions(N, 40.0)
+    dt = la_delays(mp, 0.3)
+    nulls = np.stack([la_delays(mp, a) for a in (1.2, 2.0, 2.6)])
+    for NC in (3, 4):
+        wq = engine.weights_mainlobe_n(M, N, 16000, dt, nulls[: NC - 1], NC)
+        ref = orc.calc_mainlobe_n(M, N, 16000, dt, nulls[: NC - 1], NC)
+        K = M // 2 + 1
+        # the reference inverts the Gram matrix with a float32 SVD: error ~ 1e-6 x cond(C^H C) per bin
+        # (bins above M/2 keep calcMainlobe's mirror in both)
+        for k in range(1, M // 2):
+            Cm = np.stack([np.exp(-2j * np.pi * k * d * 16000 / M) for d in [dt] + list(nulls[: NC - 1])], axis=1)
+            cond = np.linalg.cond(np.conj(Cm.T) @ Cm)
+            assert np.max(np.abs(wq[k] - ref[k])) <= 2e-6 * cond * np.max(np.abs(ref[k])), (NC, k, cond)
+        assert np.array_equal(wq[0], ref[0]) and np.array_equal(wq[K:], ref[K:])
+        for k in (1, 9, 31):
+            vt = np.exp(-2j * np.pi * k * dt * 16000 / M)
+            assert abs(np.vdot(wq[k], vt) - 1.0) < 1e-10
+            for n in range(NC - 1):
+                assert abs(np.vdot(wq[k], np.exp(-2j * np.pi * k * nulls[n] * 16000 / M))) < 1e-10
+        B = engine.weights_blocking_matrix(wq[9], NC)
+        assert B.shape == (N, N - NC) and np.max(np.abs(wq[9] @ B)) < 1e-12
+    assert np.array_equal(engine.weights_mainlobe_n(M, N, 16000, dt, nulls[:1], 2), engine.weights_mainlobe_2(M, N, 16000, dt, nulls[0]))
+    with pytest.raises(_lib.BtkError):
+        engine.weights_mainlobe_n(M, N, 16000, dt, nulls[:1], 9)
