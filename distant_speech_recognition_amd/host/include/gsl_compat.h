@@ -46,13 +46,13 @@ typedef struct { size_t size1, size2, tda; double* data; void* block; int owner;
 typedef struct { size_t size1, size2, tda; double* data; void* block; int owner; } gsl_matrix_complex;
 static inline gsl_matrix* gsl_matrix_alloc(size_t n1, size_t n2) {
   gsl_matrix* m = (gsl_matrix*)malloc(sizeof(gsl_matrix)); m->size1 = n1; m->size2 = n2; m->tda = n2;
-  m->data = (double*)calloc(n1 * n2 ? n1 * n2 : 1, sizeof(double)); m->block = NULL; m->owner = 1; return m; }
+  m->data = (double*)calloc((n1 * n2) != 0 ? n1 * n2 : 1, sizeof(double)); m->block = NULL; m->owner = 1; return m; }
 static inline void gsl_matrix_free(gsl_matrix* m) { if (m) { free(m->data); free(m); } }
 static inline double gsl_matrix_get(const gsl_matrix* m, size_t i, size_t j) { return m->data[i * m->tda + j]; }
 static inline void gsl_matrix_set(gsl_matrix* m, size_t i, size_t j, double x) { m->data[i * m->tda + j] = x; }
 static inline gsl_matrix_complex* gsl_matrix_complex_alloc(size_t n1, size_t n2) {
   gsl_matrix_complex* m = (gsl_matrix_complex*)malloc(sizeof(gsl_matrix_complex)); m->size1 = n1; m->size2 = n2; m->tda = n2;
-  m->data = (double*)calloc(n1 * n2 ? 2 * n1 * n2 : 1, sizeof(double)); m->block = NULL; m->owner = 1; return m; }
+  m->data = (double*)calloc((n1 * n2) != 0 ? 2 * n1 * n2 : 1, sizeof(double)); m->block = NULL; m->owner = 1; return m; }
 static inline void gsl_matrix_complex_free(gsl_matrix_complex* m) { if (m) { free(m->data); free(m); } }
 static inline gsl_complex gsl_matrix_complex_get(const gsl_matrix_complex* m, size_t i, size_t j) {
   return gsl_complex_rect(m->data[2 * (i * m->tda + j)], m->data[2 * (i * m->tda + j) + 1]); }
