@@ -59,6 +59,7 @@ class _SubbandBeamformer(_BlockServedStream, VectorComplexFeatureStream):
         self._Xhost = None
         self._Y = None            # device output [1][K][T]
         self._snapshot_array = None
+        self._wversion = 0        # bumped whenever the weights (hence the future output) change
 
     # ---- wiring (beamformer.h:89-125)
     def set_channel(self, chan):
@@ -150,13 +151,21 @@ class _SubbandBeamformer(_BlockServedStream, VectorComplexFeatureStream):
         Y = self.device_block()
         self._frames = _mirror(Y[0].cpu().numpy(), self._fftlen)
 
+    def _output_version(self):
+        return self._wversion
+
     def _invalidate_output(self):
-        """Weights changed: frames not yet served are recomputed with the new weights."""
+        """Weights changed: frames not yet served are recomputed with the new weights (host mirror and device block)."""
+        self._wversion += 1
         if self._Y is not None:
             done = self._frame_no + 1
-            old = self._frames
+            old, oldY = self._frames, self._Y
             self._Y = None
             self._frames = None
+            if done > 0:
+                self._compute_block()
+                if self._Y is not None and oldY.shape == self._Y.shape:
+                    self._Y[..., :done] = oldY[..., :done]
             if old is not None:
                 self._prepare()
                 self._frames[:done] = old[:done]

@@ -119,6 +119,32 @@ class OverSampledDFTSynthesisBankPtr(_BlockServedStream, VectorFloatFeatureStrea
             out = out * np.float32(self._gain)
         self._frames = out.reshape(nb, self._size)
 
+    def _prepare_versioned(self):
+        self._src_version = self._samp._output_version() if hasattr(self._samp, "_output_version") else 0
+        self._prepare()
+
+    def next(self, frame_no=-5):
+        if frame_no == self._frame_no and self._vector is not None:
+            return self._vector
+        src = self._samp
+        if self._frames is None:
+            self._prepare_versioned()
+        elif hasattr(src, "_output_version") and src._output_version() != self._src_version:
+            # the source's weights changed between two blocks (moving look direction): blocks already served stay,
+            # the rest is re-synthesised from the source's updated frames (frames it had already handed over keep
+            # their old values -- see _advance_to below)
+            done = self._frame_no + 1
+            old = self._frames
+            self._prepare_versioned()
+            n = min(done, self._frames.shape[0])
+            self._frames[:n] = old[:n]
+        out = _BlockServedStream.next(self, frame_no)
+        # a per-frame pull graph would by now have pulled pd + 1 frames for the first block and one more per block
+        # (modulated.cc:574-578): tell the source, so that a later weight change only touches frames after those
+        if hasattr(src, "_advance_to"):
+            src._advance_to(self._plan.processing_delay + self._frame_no)
+        return out
+
     def reset(self):
         self._samp.reset()
         _BlockServedStream.reset(self)

@@ -42,33 +42,92 @@ class ZelinskiPostFilterPtr(_BlockServedStream, VectorComplexFeatureStream):
 
     getPostFilterWeights = postfilter_weights
 
-    def device_block(self):
-        if self._Y is None:
-            self._compute()
-        return self._Y
-
-    def _compute(self):
-        import torch
+    def _find_beamformer(self):
         bf = self._bf
         if bf is None:
             src = self._samp
             bf = src.python_object().beamformer() if hasattr(src, "python_object") and hasattr(src.python_object(), "beamformer") else None
         if bf is None:
             raise j_error("set beamformer's weights \n")
-        X = bf.device_snapshots()
-        W = torch.from_numpy(bf.effective_weights()).to(device())
-        D = torch.from_numpy(bf.alignment_vector(bool(self._type & TYPE_ZELINSKI2))).to(device())
+        return bf
+
+    def _bf_or_none(self):
+        try:
+            return self._find_beamformer()
+        except j_error:
+            return None
+
+    def _output_version(self):
+        bf = self._bf_or_none()
+        return 0 if bf is None else bf._output_version()
+
+    def _advance_to(self, idx):
+        if idx > self._frame_no:
+            self._frame_no = idx
+        bf = self._bf_or_none()
+        if bf is not None:
+            bf._advance_to(idx)
+
+    def device_block(self):
+        bf = self._find_beamformer()
+        if self._Y is None:
+            self._bf_version = bf._output_version()
+            self._compute(0)
+        elif bf._output_version() != self._bf_version:
+            # weights recomputed between two frames: frames already handed over keep their values, the CSD history
+            # restarts while the frame counter keeps counting (alloc_bfweight_, beamformer.cc:1082-1092)
+            self._bf_version = bf._output_version()
+            self._compute(self._frame_no + 1)
+            self._frames = None
+        return self._Y
+
+    def _run_filter(self, W, D, X, from_frame):
+        """returns (Y [S][K][T'], w_last [K]) for the frames from_frame.. of X"""
         S, K, N, T = X.shape
         st = engine.ZelinskiState(S, K, device())
+        st.frames_done = from_frame
+        Y = engine.bf_apply_zelinski(W, D, X[..., from_frame:].contiguous(), st, alpha=self._alpha, type_=self._type,
+                                     min_frames=self._min_frames)
+        return Y, st.w_last[0].cpu().numpy()
+
+    def _compute(self, from_frame=0):
+        import torch
+        bf = self._find_beamformer()
+        X = bf.device_snapshots()
+        W = torch.from_numpy(bf.effective_weights()).to(device())
+        D = torch.from_numpy(bf.alignment_vector(self._use_wq())).to(device())
+        T = X.shape[-1]
+        from_frame = max(0, min(int(from_frame), T))
+        old = self._Y
         try:
-            self._Y = engine.bf_apply_zelinski(W, D, X, st, alpha=self._alpha, type_=self._type, min_frames=self._min_frames)
+            if from_frame < T:
+                Ynew, self._w_last = self._run_filter(W, D, X, from_frame)
+            else:
+                Ynew = None
         except _lib.BtkError as e:
             raise_from_code(e)
-        self._w_last = st.w_last[0].cpu().numpy()
+        if from_frame == 0 or old is None:
+            self._Y = Ynew
+        else:
+            self._Y = old.clone()
+            if Ynew is not None:
+                self._Y[..., from_frame:] = Ynew
+
+    def _use_wq(self):
+        return bool(self._type & TYPE_ZELINSKI2)
 
     def _prepare(self):
         Y = self.device_block()
         self._frames = _mirror(Y[0].cpu().numpy(), self._size)
+
+    def next(self, frame_no=-5):
+        bf = self._bf_or_none()
+        if self._frames is not None and bf is not None and bf._output_version() != getattr(self, "_bf_version", None):
+            done = self._frame_no + 1
+            old = self._frames
+            self._prepare()
+            self._frames[:done] = old[:done]
+        return _BlockServedStream.next(self, frame_no)
 
     def reset(self):
         self._samp.reset()
@@ -146,45 +205,31 @@ class McCowanPostFilterPtr(ZelinskiPostFilterPtr):
     setLevelOfDiagonalLoading = set_diagonal_looading
     divideAllNonDiagonalElements, divideNonDiagonalElements = divide_all_nondiagonal_elements, divide_nondiagonal_elements
 
-    def _beamformer(self):
-        bf = self._bf
-        if bf is None:
-            src = self._samp
-            bf = src.python_object().beamformer() if hasattr(src, "python_object") and hasattr(src.python_object(), "beamformer") else None
-        if bf is None:
-            raise j_error("set beamformer's weights \n")
-        return bf
-
     _lefkimmiatis = False
     _no_R_message = "McCowanPostFilter:  construct/set a noise coherence matrix\n"
 
-    def _compute(self):
-        import torch
-        bf = self._beamformer()
+    def _use_wq(self):
+        return bool(self._type & TYPE_ZELINSKI2) and not self._lefkimmiatis         # :858-863 vs :1098
+
+    def _run_filter(self, W, D, X, from_frame):
         if self._R is None:
             raise j_error(self._no_R_message)
-        X = bf.device_snapshots()
-        W = torch.from_numpy(bf.effective_weights()).to(device())
-        use_wq = bool(self._type & TYPE_ZELINSKI2) and not self._lefkimmiatis      # :858-863 vs :1098
-        D = torch.from_numpy(bf.alignment_vector(use_wq)).to(device())
         S, K, N, T = X.shape
         if self._R.shape[-1] != N:
             raise jdimension_error("The noise coherence matrix is %dx%d but there are %d channels\n"
                                    % (self._R.shape[-1], self._R.shape[-1], N))
         st = engine.CoherencePostFilterState(S, K, N, device(), lefkimmiatis=self._lefkimmiatis)
-        try:
-            st.set_coherence(self._R, self._threshold)
-            if self._lefkimmiatis:
-                st.set_lambda(self._R, D, self._min_sv)                               # :967-995
-                self._invR_computed = True
-                self._Y = engine.bf_apply_lefkimmiatis(W, D, X, st, fbin_x1=self._fbin_no1, alpha=self._alpha,
-                                                       type_=self._type, min_frames=self._min_frames)
-            else:
-                self._Y = engine.bf_apply_mccowan(W, D, X, st, alpha=self._alpha, type_=self._type,
-                                                  min_frames=self._min_frames)
-        except _lib.BtkError as e:
-            raise_from_code(e)
-        self._w_last = st.w_last[0].cpu().numpy()
+        st.frames_done = from_frame
+        st.set_coherence(self._R, self._threshold)
+        Xs = X[..., from_frame:].contiguous()
+        if self._lefkimmiatis:
+            st.set_lambda(self._R, D, self._min_sv)                               # :967-995
+            self._invR_computed = True
+            Y = engine.bf_apply_lefkimmiatis(W, D, Xs, st, fbin_x1=self._fbin_no1, alpha=self._alpha, type_=self._type,
+                                             min_frames=self._min_frames)
+        else:
+            Y = engine.bf_apply_mccowan(W, D, Xs, st, alpha=self._alpha, type_=self._type, min_frames=self._min_frames)
+        return Y, st.w_last[0].cpu().numpy()
 
 
 class LefkimmiatisPostFilterPtr(McCowanPostFilterPtr):

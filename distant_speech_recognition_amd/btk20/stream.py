@@ -56,6 +56,17 @@ class FeatureStream(object):
     def next(self, frame_no=-5):
         raise NotImplementedError
 
+    # ---- block-served graphs: what a per-frame pull graph does implicitly.
+    # A downstream node that computed its whole block at once tells its source how far the reference's frame-by-frame
+    # pulling would have advanced (_advance_to), and notices when the source's future output changed (_output_version,
+    # e.g. new look direction between two frames): frames already consumed keep their values, later ones are recomputed.
+    def _advance_to(self, idx):
+        if idx > self._frame_no:
+            self._frame_no = idx
+
+    def _output_version(self):
+        return 0
+
     # SWIG: __iter__ = reset(); return self  (stream.i:145-154).  Python 3 adds __next__.
     def __iter__(self):
         self.reset()
@@ -125,6 +136,15 @@ class _PyFeatureStream(FeatureStream):
         """Device-resident output block of a GPU-backed Python beamformer (None for plain iterators)."""
         f = getattr(self._obj, "device_block", None)
         return f() if f is not None else None
+
+    def _advance_to(self, idx):
+        f = getattr(self._obj, "_advance_to", None)
+        if f is not None:
+            f(idx)
+
+    def _output_version(self):
+        f = getattr(self._obj, "_output_version", None)
+        return f() if f is not None else 0
 
     def next(self, frame_no=-5):
         if frame_no == self._frame_no and self._vector is not None:

@@ -118,6 +118,13 @@ class SubbandBeamformer(object):
     def device_block(self):
         return self._beamformer.device_block()
 
+    def _advance_to(self, idx):
+        if self._beamformer is not None:
+            self._beamformer._advance_to(idx)
+
+    def _output_version(self):
+        return 0 if self._beamformer is None else self._beamformer._output_version()
+
     def __iter__(self):
         if self._beamformer is None:
             raise NotImplementedError("Undefined beamformer object")
