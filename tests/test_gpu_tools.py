@@ -105,3 +105,61 @@ def test_tool_moving_look_direction(orc, dev, proto256, kinect_pcm, wavs, tmp_pa
     out_s = _run(tmp_path, wavs, _conf({"type": "delay_and_sum"}, {"type": "zelinski", "subtype": 2, "alpha": 0.7}), "statz")
     nb = (b_switch + 1) * D
     assert out_z.shape == out_s.shape and np.array_equal(out_z[:nb], out_s[:nb]) and np.max(np.abs(out_z[nb:] - out_s[nb:])) > 5.0
+
+
+def test_tool_sos_batch_and_dereverberator(orc, dev, proto256, kinect_pcm, wavs, tmp_path):
+    """tools/sos_batch_beamforming.py (confs/gev_vad.json, bmvdr_tfmask.json shapes) and tools/subband_dereverberator.py
+    (confs/wpe.json shape): outputs against the oracle graph."""
+    import scipy.linalg  # noqa: F401
+    h, g = proto256
+    X = np.stack([orc.analysis(h, M, m, r, 2, kinect_pcm[c][:L]) for c in range(4)], axis=1)
+    T = X.shape[0]
+    en = np.array([orc.frame_energy(X[t, 0]) for t in range(T)])
+    gate = (en > 10).astype(np.float64)
+    # ---- GEV from a VAD label
+    conf = {"target": {"vad_label": [[0.4, 1.1]]}, "beamformer": {"type": "gev", "energy_threshold": 10}}
+    cpath, opath = str(tmp_path / "gev.json"), str(tmp_path / "gev.wav")
+    json.dump(conf, open(cpath, "w"))
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "sos_batch_beamforming.py"), "-q", "-c", cpath, "-o", opath,
+                          "-i"] + wavs, capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stderr[-2000:]
+    w = wave.open(opath, "rb"); out = np.frombuffer(w.readframes(w.getnframes()), np.int16).astype(np.float64); w.close()
+    from distant_speech_recognition_amd.pybeamformer import _vad_noise_label
+    tgt = _vad_noise_label(T, D / FS, [(0.4, 1.1)]).astype(np.float64)
+    Rt, Rj = orc.cov_accumulate(X, frame_weights=tgt * gate), orc.cov_accumulate(X, frame_weights=(1 - tgt) * gate)
+    ft, fj = orc.sos_finalize(Rt, Rj, np.full(129, (tgt * gate).sum()), np.full(129, ((1 - tgt) * gate).sum()), 1e-6, gev=True)
+    wg = orc.gev_weights(ft, fj)
+    ref = orc.synthesis(g, M, m, r, 2, orc.sos_frames(X, wg))
+    err = min(np.max(np.abs(out - np.trunc(ref))), np.max(np.abs(out - np.trunc(-ref))))      # global sign of the eigenvector
+    assert out.shape == ref.shape and err <= 2e-3 * np.max(np.abs(ref)) + 1.0
+    # ---- blind MVDR from TF masks (.npy files)
+    rng = np.random.default_rng(3)
+    mt = (rng.random((T, 129)) > 0.5).astype(np.float64)
+    mj = (rng.random((T, 129)) > 0.5).astype(np.float64)
+    np.save(str(tmp_path / "mt.npy"), mt); np.save(str(tmp_path / "mj.npy"), mj)
+    conf = {"target": {"tfmask_path": str(tmp_path / "mt.npy")}, "noises": [{"tfmask_path": str(tmp_path / "mj.npy")}],
+            "beamformer": {"type": "bmvdr", "energy_threshold": 10, "ref_micx": 2, "offset": 0.0}}
+    cpath, opath = str(tmp_path / "bm.json"), str(tmp_path / "bm.wav")
+    json.dump(conf, open(cpath, "w"))
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "sos_batch_beamforming.py"), "-q", "-c", cpath, "-o", opath,
+                          "-i"] + wavs, capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stderr[-2000:]
+    w = wave.open(opath, "rb"); out = np.frombuffer(w.readframes(w.getnframes()), np.int16).astype(np.float64); w.close()
+    Rt, Rj = orc.cov_accumulate(X, masks=mt * gate[:, None]), orc.cov_accumulate(X, masks=mj * gate[:, None])
+    ft, fj = orc.sos_finalize(Rt, Rj, (mt * gate[:, None]).sum(0), (mj * gate[:, None]).sum(0), 1e-6)
+    ref = orc.synthesis(g, M, m, r, 2, orc.sos_frames(X, orc.blind_mvdr_weights(ft, fj, ref_micx=2)))
+    assert out.shape == ref.shape and np.max(np.abs(out - np.trunc(ref))) <= 1e-3 * np.max(np.abs(ref)) + 1.0
+    # ---- multi-channel WPE on two channels
+    conf = {"lower_num": 0, "upper_num": 7, "iterations_num": 2, "load_db": -18.0, "band_width": 0.0, "diagonal_bias": 0.0001}
+    cpath = str(tmp_path / "wpe.json")
+    json.dump(conf, open(cpath, "w"))
+    outs = [str(tmp_path / "d0.wav"), str(tmp_path / "d1.wav")]
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "subband_dereverberator.py"), "-q", "-c", cpath, "-i"] + wavs[:2]
+                         + ["-o"] + outs, capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stderr[-2000:]
+    G = orc.wpe_estimate(X[:, :2], 0, 7, 2, -18.0, 0.0, 1e-4)
+    Yd = orc.wpe_apply(X[:, :2], G, 0, 7)
+    for c in range(2):
+        w = wave.open(outs[c], "rb"); o = np.frombuffer(w.readframes(w.getnframes()), np.int16).astype(np.float64); w.close()
+        ref = orc.synthesis(g, M, m, r, 2, Yd[:, c])
+        assert o.shape == ref.shape and np.max(np.abs(o - np.trunc(ref))) <= 1e-3 * np.max(np.abs(ref)) + 1.0
