@@ -108,8 +108,10 @@ long btk_fb_analysis_num_frames(const btk_fb_t* fb, long nsamples)
 {
   if (!fb || nsamples < 0) return -1;
   const long nblk = (nsamples + fb->D - 1) / fb->D;
-  const long body = nblk > fb->laN ? nblk - fb->laN : 0;
-  return body + fb->pd;
+  // a source that ends while the look-ahead blocks are being skipped sets is_end_ before the first frame
+  // (update_buffer_, modulated.cc:423-438): no frame at all, not even the zero-padded ones
+  if (nblk < fb->laN) return 0;
+  return nblk - fb->laN + fb->pd;
 }
 
 long btk_fb_synthesis_num_blocks(const btk_fb_t* fb, long nframes)

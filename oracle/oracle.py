@@ -111,11 +111,12 @@ def fb_delays(m, r, synthesis, dct):
 
 
 def analysis_num_frames(nsamples, M, m, r, dct):
-    """ceil(len/D) - laN + pd  (modulated.cc:419-469 bookkeeping)."""
+    """ceil(len/D) - laN + pd  (modulated.cc:419-469 bookkeeping); 0 when the source ends inside the look-ahead skip
+    (is_end_ is set before the first frame, :423-438)."""
     D = M >> r
     pd, la = fb_delays(m, r, False, dct)
     nblk = -(-nsamples // D)
-    return max(nblk - la, 0) + pd if nblk > la else pd
+    return 0 if nblk < la else nblk - la + pd
 
 
 def analysis(proto, M, m, r, dct, pcm, want_polyphase=False):

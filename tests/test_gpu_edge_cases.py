@@ -1,0 +1,106 @@
+"""GPU parity on the edges of the domain: empty / one-sample / ragged inputs, single frames, single channel, odd strides,
+every decimation, streams of different content in one launch."""
+import numpy as np
+import pytest
+
+from tests.util import design_prototype, la_delays, ula_positions
+
+pytestmark = pytest.mark.gpu
+
+
+def _eng():
+    from distant_speech_recognition_amd import engine
+    return engine
+
+
+@pytest.mark.parametrize("M,m,r,dct", [(256, 4, 1, 2), (512, 4, 1, 0), (64, 2, 2, 2), (512, 4, 2, 2)])
+@pytest.mark.parametrize("L", [0, 1, 127, 128, 129, 1000])
+def test_analysis_tiny_inputs(orc, dev, M, m, r, dct, L):
+    """ceil(L/D) - laN + pd frames even for an empty signal (the bank drains its delay line, modulated.cc:419-469)"""
+    import torch
+    eng = _eng()
+    h = design_prototype(M, m)
+    rng = np.random.default_rng(L + M)
+    pcm = np.rint(rng.normal(0, 1000, (2, 3, L))).astype(np.float32)
+    fb = eng.FilterBank(h, M, m, r, dct)
+    nfr = orc.analysis_num_frames(L, M, m, r, dct)
+    assert fb.num_frames(L) == nfr
+    if nfr <= 0:
+        return
+    X = fb.analysis(torch.from_numpy(pcm).to(dev)).cpu().numpy()          # [S][K][N][T]
+    assert X.shape == (2, M // 2 + 1, 3, nfr)
+    for s in range(2):
+        for c in range(3):
+            ref = orc.analysis(h, M, m, r, dct, pcm[s, c])
+            assert ref.shape[0] == nfr
+            scale = max(np.max(np.abs(ref)), 1.0)
+            assert np.max(np.abs(X[s, :, c, :].T - ref[:, : M // 2 + 1])) <= 1e-5 * scale
+
+
+@pytest.mark.parametrize("T", [1, 2, 5, 9])
+def test_synthesis_few_frames(orc, dev, T):
+    """fewer frames than the processing delay -> no output block at all; just above it -> the priming rule"""
+    import torch
+    eng = _eng()
+    M, m, r = 256, 4, 1
+    g = design_prototype(M, m, "g")
+    K = M // 2 + 1
+    rng = np.random.default_rng(T)
+    Y = (rng.normal(size=(1, K, T)) + 1j * rng.normal(size=(1, K, T))) * 100
+    fb = eng.FilterBank(g, M, m, r, 2, synthesis=True)
+    full = np.zeros((T, M), np.complex128)
+    Yc = Y[0].astype(np.complex64).astype(np.complex128)
+    full[:, :K] = Yc.T
+    full[:, K:] = np.conj(Yc.T[:, M // 2 - 1:0:-1])
+    ref = orc.synthesis(g, M, m, r, 2, full)
+    nb = fb.num_blocks(T)
+    assert nb * (M >> r) == ref.shape[0]
+    if nb > 0:
+        out = fb.synthesize(torch.from_numpy(Y.astype(np.complex64)).to(dev)).cpu().numpy()[0]
+        assert np.max(np.abs(out - ref)) <= 2e-6 * np.sqrt(M) * max(np.max(np.abs(ref)), 1.0)
+
+
+def test_single_channel_and_odd_sizes(orc, dev):
+    """N = 1 delay-and-sum, odd frame counts (no 16-byte alignment of the rows), three streams with different content"""
+    import torch
+    eng = _eng()
+    M, K, S, T = 128, 65, 3, 77
+    rng = np.random.default_rng(0)
+    for N in (1, 3, 7):
+        X = ((rng.normal(size=(S, K, N, T)) + 1j * rng.normal(size=(S, K, N, T))) * 500).astype(np.complex64)
+        W = ((rng.normal(size=(S, K, N)) + 1j * rng.normal(size=(S, K, N))) / N).astype(np.complex64)
+        Y = eng.bf_apply(torch.from_numpy(W).to(dev), torch.from_numpy(X).to(dev)).cpu().numpy()
+        ref = np.einsum("skn,sknt->skt", np.conj(W.astype(np.complex128)), X.astype(np.complex128))
+        assert np.max(np.abs(Y - ref)) <= 2e-6 * np.sqrt(N) * np.max(np.abs(ref))
+    # adaptive cancellers with an odd row stride take the scalar-load path
+    N = 5
+    delays = la_delays(ula_positions(N), 0.3)
+    X = ((rng.normal(size=(1, K, N, T)) + 1j * rng.normal(size=(1, K, N, T))) * 2000).astype(np.complex64)
+    vs = np.stack([np.exp(-2j * np.pi * k * (16000.0 / M) * delays) / N for k in range(K)])
+    st = eng.NLMSState(1, M, N, dev, min_frames=4)
+    Yn = eng.nlms_process(torch.from_numpy(vs.astype(np.complex64)).to(dev), torch.from_numpy(X).to(dev), st).cpu().numpy()[0]
+    o = orc.NLMS(M, N, min_frames=4)
+    o.calc_beamformer_weights(16000, delays)
+    full = np.zeros((T, N, M), np.complex128)
+    full[:, :, :K] = np.transpose(X[0].astype(np.complex128), (2, 1, 0))
+    full[:, :, K:] = np.conj(full[:, :, M // 2 - 1:0:-1])
+    ref = o.run(full)
+    assert np.max(np.abs(Yn.T - ref[:, :K])) <= 2e-4 * np.max(np.abs(ref))
+
+
+def test_errors_are_loud(dev):
+    """bad arguments come back as BtkError with the reference's wording, never as silent garbage"""
+    import torch
+    eng = _eng()
+    from distant_speech_recognition_amd import _lib
+    h = design_prototype(256, 4)
+    with pytest.raises(_lib.BtkError):
+        eng.FilterBank(h[:-1], 256, 4, 1, 2)                               # "Prototype sizes do not match"
+    fb7 = eng.FilterBank(h, 256, 4, 1, 7)                                  # unknown type = the `default:` branch (modulated.cc:260-263)
+    assert (fb7.processing_delay, fb7.lookahead) == (2 * 4 - 1, 0)
+    fb = eng.FilterBank(h, 256, 4, 1, 2)
+    with pytest.raises(ValueError):
+        fb.analysis(torch.zeros((1, 2, 100), dtype=torch.float32))         # host tensor: no CPU fallback
+    X = torch.zeros((1, 129, 4, 8), dtype=torch.complex64, device=dev)
+    with pytest.raises(_lib.BtkError):
+        eng.bf_apply(torch.zeros((129, 3), dtype=torch.complex64, device=dev), X)      # channel mismatch

@@ -226,3 +226,14 @@ def test_sos_batch_oracle_matches_reference_python(orc, proto256, kinect_pcm, so
     wg = orc.gev_weights(gt, gj)
     sgn = np.sign(np.real(np.vdot(G["gev_wqH"][0], wg[0])))
     assert np.max(np.abs(sgn * wg - G["gev_wqH"])) <= 1e-8 * np.max(np.abs(G["gev_wqH"]))
+
+
+@pytest.mark.parametrize("M,m,r,dct", [(64, 2, 1, 2), (64, 4, 1, 2), (64, 4, 2, 2), (64, 4, 0, 0), (64, 3, 1, 1), (64, 2, 2, 0)])
+def test_frame_count_formula_equals_literal_loop(orc, M, m, r, dct):
+    """btk_fb_analysis_num_frames' closed form (also used by the GPU launch sizes) against the loop-faithful restatement of
+    update_buffer_ (modulated.cc:419-469), including sources that end inside the look-ahead skip (0 frames)."""
+    from tests.util import design_prototype
+    h = design_prototype(M, m)
+    D = M >> r
+    for L in list(range(0, 3 * D + 2)) + [7 * D - 1, 7 * D, 7 * D + 1, 20 * D + 3]:
+        assert orc.analysis(h, M, m, r, dct, np.ones(L, np.float32)).shape[0] == orc.analysis_num_frames(L, M, m, r, dct), L
