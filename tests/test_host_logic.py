@@ -1,0 +1,132 @@
+"""CPU: host-side logic of the mirror that needs no GPU -- SampleFeature block reader semantics, delay calculators
+against the reference-python goldens, VAD labelling, the tools' configuration handling."""
+import json
+import os
+import pickle
+import sys
+import wave
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _wav(path, x, fs=16000):
+    w = wave.open(str(path), "wb")
+    w.setnchannels(1); w.setsampwidth(2); w.setframerate(fs)
+    w.writeframes(np.asarray(x, np.int16).tobytes())
+    w.close()
+
+
+def test_sample_feature_block_reader(tmp_path):
+    """SampleFeature::next (feature/feature.cc:605-649): un-normalised int16 -> float, pad_zeros, the `cur + size >= total`
+    end rule (a last block that fits exactly is treated as the padded tail), explicit frame numbers, end of samples."""
+    from distant_speech_recognition_amd.btk20 import SampleFeaturePtr
+    from distant_speech_recognition_amd.btk20.common import jindex_error
+    x = (np.arange(1000) - 500).astype(np.int16)
+    p = tmp_path / "a.wav"
+    _wav(p, x)
+    sf = SampleFeaturePtr(block_len=128, shift_len=128, pad_zeros=True)
+    assert sf.read(str(p), 16000) == 1000
+    blocks = [np.array(b) for b in sf]
+    assert len(blocks) == 8                                            # ceil(1000/128)
+    cat = np.concatenate(blocks)
+    assert np.array_equal(cat[:1000], x.astype(np.float32)) and np.all(cat[1000:] == 0)
+    with pytest.raises(StopIteration):
+        sf.next()
+    # without padding the tail (and an exactly fitting last block) is dropped
+    sf = SampleFeaturePtr(block_len=128, shift_len=128, pad_zeros=False)
+    sf.read(str(p), 16000)
+    assert len([1 for _ in sf]) == 7
+    _wav(tmp_path / "b.wav", x[:1024])
+    sf.read(str(tmp_path / "b.wav"), 16000)
+    assert len([1 for _ in sf]) == 7                                   # 8 * 128 == 1024: cur + size >= total on the 8th
+    # overlapping blocks, same-frame caching, out-of-order frame numbers
+    sf = SampleFeaturePtr(block_len=320, shift_len=160, pad_zeros=True)
+    sf.read(str(p), 16000)
+    b0 = np.array(sf.next())
+    assert np.array_equal(np.array(sf.next(0)), b0)
+    b1 = np.array(sf.next(1))
+    assert np.array_equal(b1[:160], b0[160:])
+    with pytest.raises(jindex_error):
+        sf.next(5)
+
+
+def test_delay_calculators_match_reference_python(pygolden):
+    """calc_la_delays and friends (lib/pybeamformer.py:41-153) against values produced by the reference's own module"""
+    from distant_speech_recognition_amd import pybeamformer as pb
+    mpos = np.array([[-113.0, 0.0, 2.0], [36.0, 0.0, 2.0], [76.0, 0.0, 2.0], [113.0, 0.0, 2.0]])
+    assert np.allclose(pb.calc_delays("linear", mpos, [-1.306379, None, None]), pygolden["delays_kinect"], rtol=0, atol=1e-18)
+    d8 = pb.calc_la_delays(np.array([[20.0 * (i - 3.5), 0, 0] for i in range(8)]), 0.7)
+    assert np.allclose(d8, pygolden["delays_ula8"], rtol=0, atol=1e-18)
+    vs = pb.calc_array_manifold_f(5, 256, 16000, pygolden["delays_kinect"], False)
+    assert np.allclose(vs, pygolden["manifold_k5"], rtol=1e-15)
+    B = pb.calc_blocking_matrix(vs, 1)
+    assert np.allclose(B, pygolden["blockmat_k5_nc1"], atol=1e-14)
+    B2 = pb.calc_blocking_matrix(pb.calc_array_manifold_f(77, 256, 16000, pygolden["delays_kinect"], False), 2)
+    assert np.allclose(B2, pygolden["blockmat_k77_nc2"], atol=1e-14)
+
+
+def test_vad_labelling_walks_segments_like_the_reference():
+    """the target/noise decision of accu_stats_from_label (pybeamformer.py:967-985) restated literally: inclusive bounds;
+    labx advances as soon as `elapsed > end` -- which is also true for an open end (-1) that has not started yet, so an
+    open-ended segment is only honoured if it is active from the first frame it is looked at"""
+    from distant_speech_recognition_amd.pybeamformer import _vad_noise_label
+    dt = 0.008
+
+    def literal(T, labs):
+        el, labx, out = 0.0, 0, []
+        for _ in range(T):
+            tgt = False
+            if labx < len(labs):
+                if el >= labs[labx][0] and (el <= labs[labx][1] or labs[labx][1] < 0):
+                    tgt = True
+                elif el > labs[labx][1]:
+                    labx += 1
+            out.append(1.0 if tgt else 0.0)
+            el += dt
+        return np.array(out, np.float32)
+
+    for labs in ([(0.5, 1.0), (1.6, 2.0)], [(0.5, 1.0), (1.6, -1)], [(0.0, -1)], [(0.1, -1)], [], [(0.2, 0.4), (0.3, 0.9)]):
+        assert np.array_equal(_vad_noise_label(300, dt, labs), literal(300, labs)), labs
+    lab = _vad_noise_label(300, dt, [(0.5, 1.0), (1.6, 2.0)])
+    assert lab[0] == 0 and lab[80] == 1 and lab[150] == 0 and lab[220] == 1 and lab[299] == 0
+    assert np.all(_vad_noise_label(300, dt, [(0.0, -1)]) == 1)
+    assert np.all(_vad_noise_label(300, dt, [(0.1, -1)]) == 0)          # the quirk: skipped before it starts
+
+
+def test_tools_configuration_handling(tmp_path):
+    sys.path.insert(0, ROOT)
+    from tools import online_beamforming as ob
+    from tools import sos_batch_beamforming as sb
+    conf = {"array_type": "linear", "microphone_positions": [[0, 0, 0], [1, 0, 0]],
+            "target": {"positions": [[0.0, [0.1, None, None]], [1.0, [0.2, None, None]]]},
+            "noises": [{"positions": [[0.0, [1.0, None, None]], [1.0, [1.1, None, None]]]}], "beamformer": {"type": "lcmv"}}
+    ob.check_position_data_format(conf)
+    bad = json.loads(json.dumps(conf))
+    bad["noises"][0]["positions"][1][0] = 2.0
+    with pytest.raises(AssertionError):
+        ob.check_position_data_format(bad)
+    bad = json.loads(json.dumps(conf))
+    bad["array_type"] = "planar"
+    bad["target"]["positions"][0][1] = [0.1]
+    with pytest.raises(AssertionError):
+        ob.check_position_data_format(bad)
+    # prototypes: the reference's pickles (numpy arrays) and this repo's npz
+    h = np.arange(8, dtype=np.float64)
+    with open(tmp_path / "h.pickle", "wb") as fp:
+        pickle.dump(h, fp, protocol=2)
+    assert np.array_equal(ob.load_prototype(str(tmp_path / "h.pickle"), "h"), h)
+    np.savez(tmp_path / "p.npz", h=h, g=2 * h)
+    assert np.array_equal(ob.load_prototype(str(tmp_path / "p.npz"), "g"), 2 * h)
+    # TF masks: a stream of pickled rows (the reference's format) or npy
+    rows = (np.random.default_rng(0).random((5, 9)) > 0.5).astype(float)
+    with open(tmp_path / "m.pickle", "wb") as fp:
+        for r in rows:
+            pickle.dump(r, fp, protocol=2)
+    assert np.array_equal(sb.load_tfmask(str(tmp_path / "m.pickle")), rows)
+    np.save(tmp_path / "m.npy", rows)
+    mt, mj = sb.load_tfmasks({"target": {"tfmask_path": str(tmp_path / "m.npy")},
+                              "noises": [{"tfmask_path": str(tmp_path / "m.pickle")}, {"tfmask_path": str(tmp_path / "m.npy")}]})
+    assert np.array_equal(mt, rows) and np.allclose(mj, rows)
