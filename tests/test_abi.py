@@ -109,3 +109,28 @@ def test_lcmv_weights_n_constraints_host(orc):
     assert np.array_equal(engine.weights_mainlobe_n(M, N, 16000, dt, nulls[:1], 2), engine.weights_mainlobe_2(M, N, 16000, dt, nulls[0]))
     with pytest.raises(_lib.BtkError):
         engine.weights_mainlobe_n(M, N, 16000, dt, nulls[:1], 9)
+
+
+def test_missing_extension_fails_loudly(monkeypatch):
+    """no CPU fallback: without libbtkhip.so every entry of the product raises instead of computing somewhere else"""
+    from distant_speech_recognition_amd import _lib, engine
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", os.path.join(ROOT, "does", "not", "exist", "libbtkhip.so"))
+    with pytest.raises(ImportError, match="no CPU fallback"):
+        _lib.lib()
+    import numpy as np
+    with pytest.raises(ImportError):
+        engine.weights_mainlobe(64, 4, 16000, np.zeros(4))
+    # and the product never imports the oracle
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r); import distant_speech_recognition_amd.engine, distant_speech_recognition_amd.btk20, "
+            "distant_speech_recognition_amd.pybeamformer, distant_speech_recognition_amd.sharding; "
+            "assert not any(m == 'oracle' or m.startswith('oracle.') for m in sys.modules), 'product imports the oracle'" % ROOT)
+    assert subprocess.run([sys.executable, "-c", code], capture_output=True, text=True).returncode == 0
+    src = ""
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "distant_speech_recognition_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cc")):
+                src += open(os.path.join(dirpath, f), errors="ignore").read()
+    assert "import oracle" not in src and "from oracle" not in src and "liborc" not in src
