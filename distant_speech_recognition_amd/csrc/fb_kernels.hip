@@ -170,7 +170,7 @@ template <int LOG2M> struct SynCfg {
 // One workgroup: stream s, output blocks [bt0, bt0+TB).  Needs v_f for f in [f_lo, f_hi],
 // f_lo = bt0 + pd - (R-1) - R (m-1), f_hi = bt0 + TB - 1 + pd.  v rows live in LDS as
 // vbuf[(f - f_lo)][M] floats.
-template <int LOG2M>
+template <int LOG2M, int FR>
 __global__ __launch_bounds__(NT)
 void synthesis_kernel(const float2* __restrict__ Y, long nframes, long T_stride, int K,
                       const float* __restrict__ proto, const float2* __restrict__ twg,
@@ -178,7 +178,7 @@ void synthesis_kernel(const float2* __restrict__ Y, long nframes, long T_stride,
                       float* __restrict__ out, long out_stride, long b0, long bcount)
 {
   using C = SynCfg<LOG2M>;
-  constexpr int M = C::M, NF = C::NF, FR = C::FR, STRIDE = C::STRIDE;
+  constexpr int M = C::M, NF = C::NF, STRIDE = C::STRIDE;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float2* zbuf = reinterpret_cast<float2*>(smem);                 // [FR][STRIDE]
   float2* tw = zbuf + FR * STRIDE;                                // [M]
@@ -283,20 +283,20 @@ int launch_analysis(const btk_fb* fb, const float* pcm, long nsamples, long pcm_
   return BTK_OK;
 }
 
-template <int LOG2M>
-int launch_synthesis(const btk_fb* fb, const float2* Y, long nframes, long T_stride, int S,
-                     float* out, long out_stride, long b0, long bcount, hipStream_t st)
+template <int LOG2M, int FR>
+int launch_synthesis_fr(const btk_fb* fb, const float2* Y, long nframes, long T_stride, int S,
+                        float* out, long out_stride, long b0, long bcount, hipStream_t st)
 {
   using C = SynCfg<LOG2M>;
   // TB output blocks per workgroup, bounded by LDS: (TB + R m - 1) rows of M floats
   const int extra = fb->R * fb->m - 1;
-  const long lds_cap = (C::M <= 512 ? 96 : 150) * 1024;
-  long budget = (lds_cap - (long)sizeof(float2) * (C::FR * C::STRIDE + C::M)) / (long)(sizeof(float) * C::M);
+  const long lds_cap = (C::M <= 512 ? 96 : (FR == C::FR ? 150 : 160)) * 1024;
+  long budget = (lds_cap - (long)sizeof(float2) * (FR * C::STRIDE + C::M)) / (long)(sizeof(float) * C::M);
   int TB = (int)(budget - extra);
   if (TB > 32) TB = 32;
-  if (TB < 1) return btk_set_error(BTK_ERR_PARAMETER, "synthesis tile does not fit LDS (M=%d m=%d r=%d)", fb->M, fb->m, fb->r);
-  const size_t lds = sizeof(float2) * (C::FR * C::STRIDE + C::M) + sizeof(float) * (size_t)C::M * (TB + extra);
-  auto kern = synthesis_kernel<LOG2M>;
+  if (TB < 1) return 0;
+  const size_t lds = sizeof(float2) * (FR * C::STRIDE + C::M) + sizeof(float) * (size_t)C::M * (TB + extra);
+  auto kern = synthesis_kernel<LOG2M, FR>;
   if (lds > 64 * 1024)
     BTK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const unsigned gx = (unsigned)((bcount + TB - 1) / TB);
@@ -304,7 +304,21 @@ int launch_synthesis(const btk_fb* fb, const float2* Y, long nframes, long T_str
                      fb->d_proto, fb->d_tw, fb->m, fb->R, fb->D, fb->pd, (float)fb->gain_factor, TB,
                      out, out_stride, b0, bcount);
   BTK_HIP_CHECK(hipGetLastError());
-  return BTK_OK;
+  return 1;
+}
+
+template <int LOG2M>
+int launch_synthesis(const btk_fb* fb, const float2* Y, long nframes, long T_stride, int S,
+                     float* out, long out_stride, long b0, long bcount, hipStream_t st)
+{
+  using C = SynCfg<LOG2M>;
+  int rc = launch_synthesis_fr<LOG2M, C::FR>(fb, Y, nframes, T_stride, S, out, out_stride, b0, bcount, st);
+  // the largest geometry (M = 2048, m R = 16 history rows) only fits with one frame per FFT round
+  if constexpr (LOG2M == 11) {
+    if (rc == 0) rc = launch_synthesis_fr<LOG2M, 1>(fb, Y, nframes, T_stride, S, out, out_stride, b0, bcount, st);
+  }
+  if (rc == 0) return btk_set_error(BTK_ERR_PARAMETER, "synthesis tile does not fit LDS (M=%d m=%d r=%d)", fb->M, fb->m, fb->r);
+  return rc > 0 ? BTK_OK : rc;
 }
 
 }  // namespace
