@@ -123,3 +123,84 @@ def test_per_bin_kernels_random_shapes(orc, dev, N, M, T, S):
         Yz = eng.bf_apply_zelinski(Wd, Wd, Xd, st, alpha=0.6, type_=2).cpu().numpy()[0]
         refz, _ = orc.zelinski_frames(full, orc.gsc_frames(full, Wf, None), Wf, 0.6, 2)
         assert np.max(np.abs(Yz.T - refz[:, :K])) <= 1e-4 * np.max(np.abs(refz))
+
+
+_ADAPT_CASES = []
+for _ in range(14):
+    N = int(_RNG.choice([2, 3, 4, 6, 8, 9, 13, 16, 17, 24, 32, 33, 48, 64]))
+    T = int(_RNG.choice([1, 7, 8, 9, 15, 16, 17, 31, 33, 50, 64, 65]))
+    _ADAPT_CASES.append((N, int(_RNG.choice([16, 32])), T, int(_RNG.integers(1, 3)), int(_RNG.integers(0, 1000))))
+
+
+def _frames_full(Xe, M):
+    K, N, T = Xe.shape
+    full = np.zeros((T, N, M), np.complex128)
+    full[:, :, :K] = np.transpose(Xe.astype(np.complex128), (2, 1, 0))
+    full[:, :, K:] = np.conj(full[:, :, M // 2 - 1:0:-1])
+    return full
+
+
+@pytest.mark.parametrize("N,M,T,S,seed", _ADAPT_CASES)
+def test_adaptive_cancellers_random_shapes(orc, dev, N, M, T, S, seed):
+    """NLMS and RLS (both variants) at random channel counts and block lengths around the 8/16-frame tiles,
+    processed as two consecutive blocks"""
+    import torch
+    from distant_speech_recognition_amd import engine as eng
+    from tests.util import ula_positions, la_delays
+    rng = np.random.default_rng(seed)
+    K = M // 2 + 1
+    delays = la_delays(ula_positions(N), float(rng.uniform(-1.4, 1.4)))
+    X = ((rng.normal(size=(S, K, N, T)) + 1j * rng.normal(size=(S, K, N, T))) * 1500).astype(np.complex64)
+    X += ((rng.normal(size=(S, K, 1, T)) + 1j * rng.normal(size=(S, K, 1, T))) * 3000).astype(np.complex64)
+    X[:, 0] = X[:, 0].real
+    X[:, K - 1] = X[:, K - 1].real
+    Xd = torch.from_numpy(X).to(dev)
+    vs = np.stack([np.exp(-2j * np.pi * k * (16000.0 / M) * delays) / N for k in range(K)])
+    T1 = int(rng.integers(0, T + 1))
+
+    def two_blocks(fn):
+        parts = [fn(Xd[..., a:b].contiguous()) for a, b in ((0, T1), (T1, T)) if b > a]
+        return torch.cat(parts, dim=-1).cpu().numpy()
+
+    kw = dict(min_frames=int(rng.integers(0, 6)), gamma=0.05, slowdown_after=int(rng.integers(3, 40)), max_wa_l2norm=0.5)
+    st = eng.NLMSState(S, M, N, dev, **kw)
+    vd = torch.from_numpy(vs.astype(np.complex64)).to(dev)
+    Y = two_blocks(lambda x: eng.nlms_process(vd, x, st))
+    for s in range(S):
+        o = orc.NLMS(M, N, **kw)
+        o.calc_beamformer_weights(16000, delays)
+        ref = o.run(_frames_full(X[s], M))
+        assert np.max(np.abs(Y[s].T - ref[:, :K])) <= 2e-4 * np.max(np.abs(ref))
+    if N <= 64:
+        kwr = dict(min_frames=int(rng.integers(0, 6)), gamma=float(rng.choice([0.04, 0.2])),
+                   constraint_option=int(rng.choice([0, 2, 3])), max_wa_l2norm=float(rng.choice([100.0, 1e-3])))
+        rs = eng.RLSState(1, S, M, N, torch.from_numpy(vs).to(dev), **kwr)
+        Yr = two_blocks(lambda x: eng.rls_process(x, rs))
+        for s in range(S):
+            o = orc.RLSPy(M, N, 1, **kwr)
+            o.calc_beamformer_weights(16000, delays)
+            ref = o.run(_frames_full(X[s], M))
+            assert np.max(np.abs(Yr[s].T - ref[:, :K])) <= 1e-4 * np.max(np.abs(ref))
+
+
+@pytest.mark.parametrize("C,L0,L1,T,K,seed", [(1, 0, 3, 40, 9, 1), (2, 1, 6, 70, 5, 2), (3, 0, 20, 90, 3, 3), (4, 2, 17, 120, 3, 4),
+                                              (8, 0, 7, 64, 2, 5), (5, 1, 33, 200, 2, 6), (2, 0, 0, 30, 4, 7)])
+def test_wpe_random_shapes(orc, dev, C, L0, L1, T, K, seed):
+    """multi-channel WPE with tap counts around the 16-column panels / 64-row tiles of the solver and the HERK"""
+    import torch
+    from distant_speech_recognition_amd import engine as eng
+    rng = np.random.default_rng(seed)
+    M = 2 * (K - 1)
+    X = ((rng.normal(size=(1, K, C, T)) + 1j * rng.normal(size=(1, K, C, T))) * 300).astype(np.complex64)
+    for t in range(3, T):                                        # some reverberation to predict
+        X[..., t] += 0.5 * X[..., t - 2] + 0.25 * X[..., t - 3]
+    X[:, 0] = X[:, 0].real
+    X[:, K - 1] = X[:, K - 1].real
+    Xd = torch.from_numpy(X).to(dev)
+    G = eng.wpe_estimate(Xd, M, L0, L1, 2, -18.0, 0.0, 1e-4)
+    Yd = eng.wpe_apply(Xd, G, M, L0, L1).cpu().numpy()[0]       # [K][C][T]
+    full = _frames_full(np.transpose(X[0], (0, 1, 2)), M)       # [T][C][M]
+    Go = orc.wpe_estimate(full, L0, L1, 2, -18.0, 0.0, 1e-4)
+    Yo = orc.wpe_apply(full, Go, L0, L1)                         # [T][C][M]
+    ref = np.transpose(Yo[:, :, :K], (2, 1, 0))
+    assert np.max(np.abs(Yd - ref)) <= 2e-3 * np.max(np.abs(ref))
