@@ -67,3 +67,31 @@ def test_beamformer_ds_binary_matches_oracle(orc, dev, tmp_path, proto256, kinec
     ref = orc.synthesis(g, M, m, r, 0, Y)
     assert out.shape == ref.shape
     assert np.max(np.abs(out - ref)) < tol
+
+
+@pytest.mark.parametrize("M_,m_,r_", [(512, 4, 2), (128, 2, 0), (1024, 4, 1)])
+def test_beamformer_ds_binary_other_geometries(orc, dev, tmp_path, kinect_pcm, M_, m_, r_):
+    """the C++ nodes are geometry-agnostic: other FFT lengths / decimations through the same example binary"""
+    from tests.util import la_delays, design_prototype
+    h, g = design_prototype(M_, m_), design_prototype(M_, m_, "g")
+    coeffs = str(tmp_path / "coeffs.f64")
+    np.concatenate([h, g]).astype(np.float64).tofile(coeffs)
+    delays = la_delays(MPOS, 0.5)
+    L = 20000
+    args = [EXE, coeffs, str(M_), str(m_), str(r_), "2", "0.7", str(tmp_path / "out.f32")]
+    for c in range(4):
+        p = str(tmp_path / ("c%d.wav" % c))
+        w = wave.open(p, "wb")
+        w.setnchannels(1); w.setsampwidth(2); w.setframerate(FS)
+        w.writeframes(kinect_pcm[c][:L].astype(np.int16).tobytes())
+        w.close()
+        args += [repr(float(delays[c])), p]
+    res = subprocess.run(args, capture_output=True, text=True, timeout=120)
+    assert res.returncode == 0, res.stderr
+    out = np.fromfile(str(tmp_path / "out.f32"), np.float32)
+    X = np.stack([orc.analysis(h, M_, m_, r_, 0, kinect_pcm[c][:L]) for c in range(4)], axis=1)
+    wq, B, wl = orc.gsc_weights(M_, 4, FS, delays)
+    Y, _ = orc.zelinski_frames(X, orc.gsc_frames(X, wq, wl), wq, 0.7, 2)
+    ref = orc.synthesis(g, M_, m_, r_, 0, Y)
+    assert out.shape == ref.shape
+    assert np.max(np.abs(out - ref)) < 1e-4 * np.max(np.abs(ref)) + 0.5
