@@ -167,6 +167,11 @@ def main():
         t_bf = _time(lambda: eng.bf_apply(W, X, out=Y))
     else:
         t_ana, t_bf = t_a, t_b
+    # the adaptive variant of the same beamformer (SubbandGSCLMSBeamformer: NLMS canceller on the snapshots), reported
+    # next to the static-weight chain; the recursion is sequential in t, so its rate depends on the number of streams
+    vs = torch.from_numpy(np.stack([np.exp(-2j * np.pi * k * (FS / M) * delays) / N for k in range(K)]).astype(np.complex64)).to(dev)
+    nst = eng.NLMSState(S, M, N, dev)
+    t_nlms = _time(lambda: eng.nlms_process(vs, X, nst, out=Y))
 
     if rank == 0:
         frames_per_step = S * T * world
@@ -222,6 +227,10 @@ def main():
                 "gsc_apply": {"ms": t_bf * 1e3, "GBps": b_bf / t_bf / 1e9, "frac": b_bf / t_bf / HBM_PEAK,
                               "frames_per_s": S * T / t_bf},
                 "synthesis": {"ms": t_syn * 1e3, "GBps": b_syn / t_syn / 1e9, "frac": b_syn / t_syn / HBM_PEAK},
+                "adaptive_nlms_canceller": {"ms": t_nlms * 1e3, "GBps": b_bf / t_nlms / 1e9, "frac": b_bf / t_nlms / HBM_PEAK,
+                                            "frames_per_s": S * T / t_nlms,
+                                            "note": "sequential recursion per (stream, bin): %d streams fill one wavefront per SIMD; "
+                                                    "see profiles/r01_bench_stages.json for 128 streams" % S},
             },
         }
         if not args.no_cpu and world == 1:
