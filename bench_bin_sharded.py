@@ -1,0 +1,94 @@
+#!/usr/bin/env python
+"""bench_bin_sharded.py -- BASELINE config C5 (256-mic super-directive array, 2048 bins) sharded by frequency-bin range:
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node G --master-addr 127.0.0.1 bench_bin_sharded.py --gpus G`.
+Every rank designs the MVDR weights of ITS bins (the O(K N^3) part), analyses the replicated PCM, beamforms its bin range;
+one RCCL all-gather of Y (8 K T S bytes) precedes the synthesis on rank 0.  Strong scaling: the total work is fixed.
+Prints one JSON line on rank 0.  (Not the driver's bench: bench.py measures the stream-sharded headline.)"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--mics", type=int, default=256)
+    ap.add_argument("--bins", type=int, default=2048)
+    ap.add_argument("--frames", type=int, default=512)
+    args = ap.parse_args()
+    import torch
+    from distant_speech_recognition_amd import engine as eng, sharding
+    from tests.util import design_prototype, ula_positions, la_delays
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+    N, M, T, S = args.mics, args.bins, args.frames, 1
+    D, K = M // 2, M // 2 + 1
+    afb = eng.FilterBank(design_prototype(M, 4), M, 4, 1, 2)
+    sfb = eng.FilterBank(design_prototype(M, 4, "g"), M, 4, 1, 2, synthesis=True)
+    L = (T - afb.processing_delay + afb.lookahead) * D
+    g = torch.Generator(device=dev).manual_seed(4)                     # the same PCM on every rank (replicated input)
+    pcm = (torch.randn((S, N, L), device=dev, generator=g) * 1000.0).round_()
+    mpos = ula_positions(N, 10.0)
+    k0, k1 = sharding.bin_range_for_rank(K, rank, world)
+    wq = torch.from_numpy(eng.weights_mainlobe(M, N, 16000.0, la_delays(mpos, 0.8))[:K].astype(np.complex64)).to(dev)
+
+    def design():
+        Rd = eng.mvdr_diffuse_model(mpos, M, 16000.0, device=dev)[k0:k1].contiguous()
+        eng.mvdr_diagonal_loading(Rd, 0.01)
+        Wl, _ = eng.mvdr_weights(Rd, wq[k0:k1].contiguous(), first_bin=k0)
+        return Wl
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    W_local = design()
+    torch.cuda.synchronize()
+    t_design = time.perf_counter() - t0
+
+    def step():
+        return sharding.pipeline_bin_sharded(afb, sfb, pcm, W_local, K, rank, world, synth_rank=0)
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if dist: dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out, Y = step()
+    torch.cuda.synchronize()
+    if dist: dist.barrier()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    if dist:
+        el = sharding.max_over_ranks(el, dev)
+        td = sharding.max_over_ranks(t_design, dev)
+    else:
+        td = t_design
+    if rank == 0:
+        print(json.dumps({"metric": "beamformed subband frames/sec, %d-mic %d-bin super-directive, bin-sharded" % (N, M),
+                          "value": S * T * args.steps / el, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+                          "warmup": args.warmup, "ms_per_step": el / args.steps * 1e3, "higher_is_better": True,
+                          "scaling": "strong", "dtype": "f32", "data": "synthetic",
+                          "config": {"workload": "C5: %d mics, %d bins, %d frames, bins [%d,%d) on rank 0 of %d" % (N, M, T, k0, k1, world),
+                                     "parallelism": "bin-sharded x%d, 1 all-gather of %d bytes per step" % (world, 8 * K * T * S)},
+                          "weight_design_ms": td * 1e3, "pcm_checksum": float(out.double().abs().sum())}))
+    if dist:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -75,6 +75,7 @@ SIGNATURES = {
     "btk_mvdr_diffuse_model": (_i, [_vp, _i, _i, _f, _f, _vp, _vp]),
     "btk_mvdr_diagonal_loading": (_i, [_vp, _i, _i, _f, _vp]),
     "btk_mvdr_weights": (_i, [_vp, _vp, _vp, _i, _i, _f, _vp, _vp, _vp]),
+    "btk_mvdr_weights_shard": (_i, [_vp, _vp, _vp, _i, _i, _i, _f, _vp, _vp, _vp]),
     "btk_wpe_workspace_bytes": (_l, [_i, _i, _i, _i, _i, _l]),
     "btk_wpe_estimate": (_i, [_vp, _i, _i, _i, _l, _l, _i, _i, _i, _d, _d, _i, _i, _vp, _vp, _vp, _vp]),
     "btk_wpe_apply": (_i, [_vp, _vp, _vp, _i, _i, _i, _l, _l, _i, _i, _i, _i, _vp]),

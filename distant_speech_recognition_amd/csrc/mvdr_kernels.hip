@@ -47,7 +47,7 @@ __global__ __launch_bounds__(256)
 void mvdr_solve_kernel(const float2* __restrict__ R, const float2* __restrict__ Dq /* [K][N] d=wq */,
                        float2* __restrict__ Wout /* [K][N] or null */, float2* __restrict__ scratch,
                        int N, float threshold, int* __restrict__ fallback_count,
-                       float2* __restrict__ lambda_out /* [K] or null: d^H invR d */)
+                       float2* __restrict__ lambda_out /* [K] or null: d^H invR d */, int k_offset /* global index of bin 0 */)
 {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int k = blockIdx.x;
@@ -59,8 +59,9 @@ void mvdr_solve_kernel(const float2* __restrict__ R, const float2* __restrict__ 
   float2* rhs = reinterpret_cast<float2*>(smem + 2064);            // [N]
   float2* mat = IN_LDS ? rhs + N : scratch + (long)k * N * N;      // [N][N]
   const float2* Rk = R + (long)k * N * N;
-  if (k == 0 && Wout) {                                            // wmvdr_[0] = ones (calc_mvdr_weights starts at bin 1)
-    for (int c = tid; c < N; c += 256) Wout[c] = make_float2(1.f, 0.f);
+  const bool dc_bin = (k + k_offset) == 0;
+  if (dc_bin && Wout) {                                            // wmvdr_[0] = ones (calc_mvdr_weights starts at bin 1)
+    for (int c = tid; c < N; c += 256) Wout[(long)k * N + c] = make_float2(1.f, 0.f);
     if (!lambda_out) return;
   }
   for (int idx = tid; idx < N * N; idx += 256) mat[idx] = Rk[idx];
@@ -141,7 +142,7 @@ void mvdr_solve_kernel(const float2* __restrict__ R, const float2* __restrict__ 
     __syncthreads();
   }
   if (lambda_out && tid == 0) lambda_out[k] = make_float2(red_r[0], red_i[0]);
-  if (!Wout || k == 0) return;
+  if (!Wout || dc_bin) return;
   const float nr = red_r[0] * (float)N, ni = red_i[0] * (float)N;   // norm = Lambda * N (complex)
   const float den = nr * nr + ni * ni;
   for (int c = tid; c < N; c += 256) {
@@ -173,7 +174,7 @@ int btk_mvdr_diagonal_loading(void* R, int nbins, int N, float weight, void* str
 }
 
 static int mvdr_solve(const void* R, const void* wq, void* W, void* lambda_out, int K, int N, float threshold,
-                      void* scratch, int* fallback_count, void* stream)
+                      void* scratch, int* fallback_count, void* stream, int k_offset = 0)
 {
   if (!R || !wq || !fallback_count) return btk_set_error(BTK_ERR_PARAMETER, "btk_mvdr_weights: null argument");
   if (K < 1 || N < 1) return btk_set_error(BTK_ERR_DIMENSION, "btk_mvdr_weights: bad sizes");
@@ -184,12 +185,12 @@ static int mvdr_solve(const void* R, const void* wq, void* W, void* lambda_out, 
       BTK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_mat));
     hipLaunchKernelGGL(kern, dim3((unsigned)K), dim3(256), lds_mat, as_stream(stream), static_cast<const float2*>(R),
                        static_cast<const float2*>(wq), static_cast<float2*>(W), nullptr, N, threshold, fallback_count,
-                       static_cast<float2*>(lambda_out));
+                       static_cast<float2*>(lambda_out), k_offset);
   } else {
     if (!scratch) return btk_set_error(BTK_ERR_PARAMETER, "btk_mvdr_weights: N=%d needs a [K][N][N] complex64 scratch buffer", N);
     hipLaunchKernelGGL(mvdr_solve_kernel<false>, dim3((unsigned)K), dim3(256), 2064 + sizeof(float2) * N, as_stream(stream),
                        static_cast<const float2*>(R), static_cast<const float2*>(wq), static_cast<float2*>(W),
-                       static_cast<float2*>(scratch), N, threshold, fallback_count, static_cast<float2*>(lambda_out));
+                       static_cast<float2*>(scratch), N, threshold, fallback_count, static_cast<float2*>(lambda_out), k_offset);
   }
   BTK_HIP_CHECK(hipGetLastError());
   return BTK_OK;
@@ -200,6 +201,14 @@ int btk_mvdr_weights(const void* R, const void* wq, void* W, int K, int N, float
 {
   if (!W) return btk_set_error(BTK_ERR_PARAMETER, "btk_mvdr_weights: null argument");
   return mvdr_solve(R, wq, W, nullptr, K, N, threshold, scratch, fallback_count, stream);
+}
+
+int btk_mvdr_weights_shard(const void* R, const void* wq, void* W, int K, int N, int first_bin, float threshold,
+                           void* scratch, int* fallback_count, void* stream)
+{
+  if (!W) return btk_set_error(BTK_ERR_PARAMETER, "btk_mvdr_weights_shard: null argument");
+  if (first_bin < 0) return btk_set_error(BTK_ERR_DIMENSION, "btk_mvdr_weights_shard: first_bin = %d", first_bin);
+  return mvdr_solve(R, wq, W, nullptr, K, N, threshold, scratch, fallback_count, stream, first_bin);
 }
 
 int btk_mvdr_lambda(const void* R, const void* d, void* lambda, int K, int N, float threshold,

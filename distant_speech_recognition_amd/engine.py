@@ -599,8 +599,9 @@ def mvdr_diagonal_loading(R, weight):
     return R
 
 
-def mvdr_weights(R, wq, threshold=1.0e-8):
-    """R complex64 [K][N][N], wq complex64 [K][N] (cuda) -> (W [K][N], number of identity fall-backs)."""
+def mvdr_weights(R, wq, threshold=1.0e-8, first_bin=0):
+    """R complex64 [K][N][N], wq complex64 [K][N] (cuda) -> (W [K][N], number of identity fall-backs).
+    first_bin: global index of row 0 when R / wq are one rank's bin range (only global bin 0 gets the all-ones weight)."""
     _need_cuda(R, "R"); _need_cuda(wq, "wq")
     K, N, _ = R.shape
     W = torch.empty((K, N), dtype=torch.complex64, device=R.device)
@@ -608,8 +609,9 @@ def mvdr_weights(R, wq, threshold=1.0e-8):
     scratch = None
     if 2064 + 8 * (N * N + N) > 150 * 1024:
         scratch = torch.empty((K, N, N), dtype=torch.complex64, device=R.device)
-    check(_lib.lib().btk_mvdr_weights(_ptr(R), _ptr(wq), _ptr(W), K, N, float(threshold),
-                                      None if scratch is None else _ptr(scratch), _ptr(fb), _stream()))
+    if K > 0:
+        check(_lib.lib().btk_mvdr_weights_shard(_ptr(R), _ptr(wq), _ptr(W), K, N, int(first_bin), float(threshold),
+                                                None if scratch is None else _ptr(scratch), _ptr(fb), _stream()))
     return W, int(fb.item())
 
 

@@ -60,3 +60,19 @@ def bf_apply_bin_sharded(W_local, X_local, K, group=None):
     from . import engine
     Y_local = engine.bf_apply(W_local, X_local)
     return allgather_bins(Y_local, K, group)
+
+
+def pipeline_bin_sharded(afb, sfb, pcm, W_local, K, rank, world, group=None, synth_rank=None):
+    """BASELINE config C5 end to end on `world` GPUs: every rank analyses the SAME multichannel PCM (the analysis FFT
+    yields all bins of a channel, so the PCM -- N*D*4 bytes per frame -- is what is replicated), keeps its bin range of
+    the snapshots, beamforms it, ONE all-gather assembles Y [S][K][T], and the synthesis bank runs on `synth_rank`
+    (every rank if None).  afb / sfb: engine.FilterBank analysis / synthesis plans; W_local complex64 [K_g][N].
+    Returns (pcm_out or None, Y)."""
+    k0, k1 = bin_range_for_rank(K, rank, world)
+    X = afb.analysis(pcm)                                   # [S][K][N][T]
+    X_local = X[:, k0:k1].contiguous()
+    del X
+    from . import engine
+    Y = bf_apply_bin_sharded(W_local, X_local, K, group) if world > 1 else engine.bf_apply(W_local, X_local)
+    out = sfb.synthesize(Y) if (synth_rank is None or synth_rank == rank) else None
+    return out, Y

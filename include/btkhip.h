@@ -236,6 +236,10 @@ int  btk_mvdr_diffuse_model(const float* mpos, int N, int M, float samplerate, f
 int  btk_mvdr_diagonal_loading(void* R, int nbins, int N, float weight, void* stream);
 int  btk_mvdr_weights(const void* R, const void* wq, void* W, int K, int N, float threshold,
                       void* scratch, int* fallback_count, void* stream);
+/* The same solve for a bin SHARD [first_bin, first_bin + K) of a bin-sharded run: only global bin 0 gets the
+ * all-ones weight of calc_mvdr_weights (beamformer.cc:2369-2371).                                                    */
+int  btk_mvdr_weights_shard(const void* R, const void* wq, void* W, int K, int N, int first_bin, float threshold,
+                            void* scratch, int* fallback_count, void* stream);
 
 /* ---- Multi-channel WPE dereverberation ---------------------------------------------------------
  * Replaces MultiChannelWPEDereverberation::estimate_filter / calc_every_channel_output

@@ -87,6 +87,14 @@ def test_c5_superdirective_256mic_2048bins_bin_sharded(orc, dev):
     finally:
         dist.destroy_process_group()
     assert torch.equal(Y, ref)
+    # weight design per bin shard: the shards of an 8-rank run tile the single-rank result, only global bin 0 is all ones
+    shards = []
+    for rk in range(8):
+        a, b = sharding.bin_range_for_rank(K, rk, 8)
+        Ws, nf = eng.mvdr_weights(Rd[a:b].contiguous(), torch.from_numpy(wq[a:b].astype(np.complex64)).to(dev), first_bin=a)
+        assert nf == 0
+        shards.append(Ws)
+    assert torch.equal(torch.cat(shards), W)
     g = design_prototype(M, 4, "g")
     out = eng.FilterBank(g, M, 4, 1, 2, synthesis=True).synthesize(Y).cpu().numpy()[0]
     full = np.zeros((T, M), np.complex128)
