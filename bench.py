@@ -85,13 +85,17 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
+    # one rank per GPU; BTK_DIST_BACKEND=gloo lets a test run several ranks on one device (RCCL refuses that)
+    backend = os.environ.get("BTK_DIST_BACKEND", "nccl")
+    dev = torch.device("cuda", local_rank % max(torch.cuda.device_count(), 1))
+    torch.cuda.set_device(dev)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    dev = torch.device("cuda", local_rank)
-    torch.cuda.set_device(dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     N, M, m, r, dct = args.mics, args.bins, 4, 1, 2
     D, K = M >> r, M // 2 + 1

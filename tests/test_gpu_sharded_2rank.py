@@ -67,3 +67,25 @@ def test_two_ranks_one_gpu(dev):
     ret = mgr.dict()
     mp.spawn(_worker, args=(world, port, ret), nprocs=world, join=True)
     assert dict(ret) == {0: 1, 1: 1}
+
+
+def test_bench_two_ranks_contract(dev):
+    """bench.py launched the way the driver launches it for N = 2 (torch.distributed.run, one JSON line from rank 0,
+    whole-job value); both ranks share this box's GPU, so gloo carries the barrier / max-over-ranks"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, BTK_DIST_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+           "--streams", "4", "--frames", "1024"]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, res.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["warmup"] == 1 and d["scaling"] == "weak" and d["higher_is_better"] is True
+    assert d["unit"] == "frames/s" and d["cpu_baseline"] is None and "roofline" in d and d["config"]["parallelism"].endswith("x2")
+    # whole-job aggregate: 2 ranks x 4 streams x 1024 frames per step
+    assert abs(d["value"] - 2 * 4 * 1024 / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
