@@ -102,3 +102,33 @@ def test_reference_script_method_names_exist_in_the_mirror(script):
     # argparse results / JSON keys are plain data attributes
     missing = sorted(a for a in called if a not in mirror and a not in other)
     assert not missing, missing
+
+
+def test_reference_python_algorithm_layer_finds_its_nodes():
+    """lib/pybeamformer.py (the reference's numpy algorithm layer over the SWIG nodes): every *Ptr class it instantiates and
+    every node method its in-scope classes call exists in the mirror, so that file could run on these nodes unmodified"""
+    import inspect
+    import copy
+    import pickle
+    import numpy
+    import distant_speech_recognition_amd.btk20 as b20
+    from lib2to3 import refactor
+    rt = refactor.RefactoringTool(refactor.get_fixers_from_package("lib2to3.fixes"))
+    src = open("/root/reference/btk20_src/lib/pybeamformer.py").read() + "\n"
+    tree = ast.parse(str(rt.refactor_string(src, "pybeamformer")))
+    names = {n.id for n in ast.walk(tree) if isinstance(n, ast.Name) and isinstance(n.ctx, ast.Load)}
+    assert not [n for n in names if n.endswith("Ptr") and not hasattr(b20, n)]
+    mirror = set()
+    for _, cls in inspect.getmembers(b20, inspect.isclass):
+        mirror |= set(dir(cls))
+    other = set()
+    for o in (list, dict, str, tuple, float, int, set, numpy, numpy.ndarray, numpy.linalg, os, os.path, sys, copy, pickle):
+        other |= set(dir(o))
+    file_methods = {n.name for n in ast.walk(tree) if isinstance(n, ast.FunctionDef)}
+    in_scope = {"SpectralSource", "AnalysisFB", "FileSpectralSource", "MultiChannelSource", "SubbandBeamformer", "SubbandGSCBeamformer",
+                "SubbandMVDRBeamformer", "SubbandGSCLMSBeamformer", "SubbandGSCRLSBeamformer", "SubbandSMIMVDRBeamformer",
+                "SubbandSOSBatchBeamformer", "SubbandBlindMVDRBeamformer", "SubbandGEVBeamformer"}
+    for cls in [n for n in ast.walk(tree) if isinstance(n, ast.ClassDef) and n.name in in_scope]:
+        called = {n.func.attr for n in ast.walk(cls) if isinstance(n, ast.Call) and isinstance(n.func, ast.Attribute)}
+        missing = sorted(a for a in called if a not in mirror and a not in other and a not in file_methods)
+        assert not missing, (cls.name, missing)
