@@ -73,17 +73,62 @@ void cov_mfma_kernel(const float2* __restrict__ X, const float* __restrict__ WT,
   const int qi = wave >> 1, qj = wave & 1;               // quadrant of the 64x64 tile
   f32x16 rr = {0}, ri = {0};                             // Re, Im accumulators (32x32 per wave)
   const int li = lane & 31, lk = lane >> 5;              // MFMA 32x32x2: A[i=lane&31][k=lane>>5], B[k=lane>>5][j=lane&31]
+  const bool same = ti == tj;                            // diagonal tile: the i- and j-rows are the same rows, staged once
+  const float2* Bj = same ? Ai : Aj;
 
+  // register prefetch of the next frame tile: the global loads fly while the MFMAs of the current tile run
+  constexpr int PER = 64 * (CT / 2) / 256;               // float4 pairs per thread and row tile (= 4)
+  float4 pi_[PER], pj_[PER];
+  float wnext = 0.f;
+  auto prefetch = [&](long t0) {
+#pragma unroll
+    for (int q = 0; q < PER; q++) {
+      const int idx = tid + q * 256;
+      const int r = idx / (CT / 2), c2 = idx % (CT / 2);
+      const long t = t0 + 2 * c2;
+      float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
+      const int ni = ti * 64 + r, nj = tj * 64 + r;
+      if (ni < N && t < T) {
+        const float2* p = Xk + (long)ni * T_stride + t;
+        const float2 u = p[0];
+        const float2 v = (t + 1 < T) ? p[1] : make_float2(0.f, 0.f);
+        a = make_float4(u.x, u.y, v.x, v.y);
+      }
+      if (!same && nj < N && t < T) {
+        const float2* p = Xk + (long)nj * T_stride + t;
+        const float2 u = p[0];
+        const float2 v = (t + 1 < T) ? p[1] : make_float2(0.f, 0.f);
+        b = make_float4(u.x, u.y, v.x, v.y);
+      }
+      pi_[q] = a; pj_[q] = b;
+    }
+    if (tid < CT) wnext = tile_weight(wt, wf, t0 + tid, T);
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int q = 0; q < PER; q++) {
+      const int idx = tid + q * 256;
+      const int r = idx / (CT / 2), c2 = idx % (CT / 2);
+      Ai[r * CLD + 2 * c2] = make_float2(pi_[q].x, pi_[q].y);
+      Ai[r * CLD + 2 * c2 + 1] = make_float2(pi_[q].z, pi_[q].w);
+      if (!same) {
+        Aj[r * CLD + 2 * c2] = make_float2(pj_[q].x, pj_[q].y);
+        Aj[r * CLD + 2 * c2 + 1] = make_float2(pj_[q].z, pj_[q].w);
+      }
+    }
+    if (tid < CT) wrow[tid] = wnext;
+  };
+
+  prefetch(0);
   for (long t0 = 0; t0 < T; t0 += CT) {
     __syncthreads();
-    stage_tile(Xk, N, T_stride, T, ti * 64, t0, Ai, tid, 256);
-    stage_tile(Xk, N, T_stride, T, tj * 64, t0, Aj, tid, 256);
-    if (tid < CT) wrow[tid] = tile_weight(wt, wf, t0 + tid, T);
+    commit();
     __syncthreads();
+    if (t0 + CT < T) prefetch(t0 + CT);
 #pragma unroll 4
     for (int kk = 0; kk < CT; kk += 2) {
       const float2 a = Ai[(qi * 32 + li) * CLD + kk + lk];
-      float2 b = Aj[(qj * 32 + li) * CLD + kk + lk];
+      float2 b = Bj[(qj * 32 + li) * CLD + kk + lk];
       const float w = wrow[kk + lk];
       b.x *= w; b.y *= w;
       // Rr += ar br + ai bi ; Ri += ai br - ar bi      (R_ij = a_i conj(b_j))
@@ -164,6 +209,84 @@ void cov_valu_kernel(const float2* __restrict__ X, const float* __restrict__ WT,
     }
 }
 
+// Small arrays (N <= 16): the HERK is HBM-bound (arithmetic intensity N flop/B), a 64x64 MFMA tile would be >= 94 % padding.
+// Lanes own frames: a lane loads the N channel samples of its frame (coalesced along t), multiplies out the upper
+// triangle into registers and the partial sums are reduced once at the end (wave shuffles, then LDS across waves).
+// The N(N+1)/2 pairs are split over PS wave groups so that a lane never holds more than ~40 complex accumulators;
+// the 4/PS waves of a group split the frames.  One workgroup per (stream, bin).
+template <int N>
+__global__ __launch_bounds__(256)
+void cov_small_kernel(const float2* __restrict__ X, const float* __restrict__ WT, const float* __restrict__ WF,
+                      float2* __restrict__ R, int K, long T_stride, long T)
+{
+  constexpr int NP = N * (N + 1) / 2;
+  constexpr int PS = NP <= 40 ? 1 : (NP <= 80 ? 2 : 4);    // pair groups
+  constexpr int PPG = (NP + PS - 1) / PS;                 // pairs per group
+  constexpr int TS = 4 / PS;                              // waves splitting the frames inside a group
+  __shared__ float2 red[4][PPG];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int pg = wave % PS, ts = wave / PS;
+  const int k = blockIdx.x, s = blockIdx.y;
+  const float2* Xk = X + ((long)s * K + k) * N * T_stride;
+  const float* wt = WT ? WT + ((long)s * K + k) * T_stride : nullptr;
+  const float* wf = WF ? WF + (long)s * T_stride : nullptr;
+  float2 acc[PPG];
+#pragma unroll
+  for (int q = 0; q < PPG; q++) acc[q] = make_float2(0.f, 0.f);
+  for (long t = (long)ts * 64 + lane; t < T; t += 64 * TS) {
+    float w = 1.f;
+    if (wt) w *= wt[t];
+    if (wf) w *= wf[t];
+    if (w == 0.f) continue;
+    float2 x[N];
+#pragma unroll
+    for (int n = 0; n < N; n++) x[n] = Xk[(long)n * T_stride + t];
+    // pairs (i <= j) in row-major order of the upper triangle; this wave owns [pg*PPG, (pg+1)*PPG).  The group index is
+    // wave-uniform: one unrolled copy per group keeps every accumulator index a compile-time constant.
+#pragma unroll
+    for (int g = 0; g < PS; g++) {
+      if (g != pg) continue;
+      int p = 0;
+#pragma unroll
+      for (int i = 0; i < N; i++)
+#pragma unroll
+        for (int j = i; j < N; j++, p++) {
+          if (p >= g * PPG && p < (g + 1) * PPG) {
+            const float xr = w * x[j].x, xi = w * x[j].y;
+            acc[p - g * PPG].x += x[i].x * xr + x[i].y * xi;
+            acc[p - g * PPG].y += x[i].y * xr - x[i].x * xi;
+          }
+        }
+    }
+  }
+  // reduce over the 64 lanes, then over the TS waves of the group
+#pragma unroll
+  for (int q = 0; q < PPG; q++) {
+    float ar = acc[q].x, ai = acc[q].y;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { ar += __shfl_xor(ar, o, 64); ai += __shfl_xor(ai, o, 64); }
+    if (lane == 0) red[wave][q] = make_float2(ar, ai);
+  }
+  __syncthreads();
+  float2* Rk = R + ((long)s * K + k) * N * N;
+  for (int p = tid; p < NP; p += 256) {
+    const int g = p / PPG, q = p % PPG;
+    float ar = 0.f, ai = 0.f;
+#pragma unroll
+    for (int tsx = 0; tsx < TS; tsx++) { const float2 v = red[tsx * PS + g][q]; ar += v.x; ai += v.y; }
+    // p -> (i, j) of the upper triangle
+    int i = 0, rem = p;
+    while (rem >= N - i) { rem -= N - i; i++; }
+    const int j = i + rem;
+    float2 o1 = Rk[(long)i * N + j];
+    Rk[(long)i * N + j] = make_float2(o1.x + ar, o1.y + ai);
+    if (i != j) {
+      float2 o2 = Rk[(long)j * N + i];
+      Rk[(long)j * N + i] = make_float2(o2.x + ar, o2.y - ai);
+    }
+  }
+}
+
 // frame gate of accu_stats_from_label: w[s][t] = (energy > threshold) && label[s][t]
 __global__ void cov_gate_kernel(const float* __restrict__ energy, const float* __restrict__ label, long T, long T_stride,
                                 float threshold, float* __restrict__ wf, float* __restrict__ count /* [S] */)
@@ -223,6 +346,20 @@ int btk_cov_accumulate(const void* X, const float* tf_weights, const float* fram
   if (S <= 0 || K <= 0 || N <= 0 || T < 0 || T_stride < T)
     return btk_set_error(BTK_ERR_DIMENSION, "btk_cov_accumulate: bad sizes S=%d K=%d N=%d T=%ld", S, K, N, T);
   if (T == 0) return BTK_OK;
+  if (N <= 16 && use_mfma != 2) {                        // small arrays: HBM-bound lanes-own-frames kernel (use_mfma == 2 forces the tiled ones)
+    const dim3 g2((unsigned)K, (unsigned)S);
+    const float2* Xp = static_cast<const float2*>(X);
+    float2* Rp = static_cast<float2*>(R);
+    hipStream_t st = as_stream(stream);
+    switch (N) {
+#define BTK_COV_SMALL(NN) case NN: hipLaunchKernelGGL(cov_small_kernel<NN>, g2, dim3(256), 0, st, Xp, tf_weights, frame_weights, Rp, K, T_stride, T); break;
+      BTK_COV_SMALL(1) BTK_COV_SMALL(2) BTK_COV_SMALL(3) BTK_COV_SMALL(4) BTK_COV_SMALL(5) BTK_COV_SMALL(6) BTK_COV_SMALL(7) BTK_COV_SMALL(8)
+      BTK_COV_SMALL(9) BTK_COV_SMALL(10) BTK_COV_SMALL(11) BTK_COV_SMALL(12) BTK_COV_SMALL(13) BTK_COV_SMALL(14) BTK_COV_SMALL(15) BTK_COV_SMALL(16)
+#undef BTK_COV_SMALL
+    }
+    BTK_HIP_CHECK(hipGetLastError());
+    return BTK_OK;
+  }
   const int ntile = (N + 63) / 64;
   const size_t lds = sizeof(float2) * 2 * 64 * CLD + sizeof(float) * CT;
   dim3 grid((unsigned)(ntile * ntile), (unsigned)K, (unsigned)S);
