@@ -111,24 +111,43 @@ void wpe_herk_kernel(const float2* __restrict__ X, const float* __restrict__ Win
   const bool vI = pI < P, vJ = pJ < P;
   const int offI = vI ? (pI / g.L - chI0) * SPW + (g.L - 1 - pI % g.L) : 0;
   const int offJ = vJ ? (pJ / g.L - chJ0) * SPW + (g.L - 1 - pJ % g.L) : 0;
+  // register prefetch of the next tile's spans and weights (the global loads fly under the MFMAs of the current tile);
+  // geometries whose spans exceed WPF elements per thread (very short filters) stage directly
+  constexpr int WPF = 6;
+  const int nelem = 2 * nspan * SPW;
+  const bool use_pf = nelem <= WPF * 256;
+  float2 pf[WPF];
+  float wpf = 0.f;
+  auto span_load = [&](int idx, long t0) -> float2 {
+    const int which = idx / (nspan * SPW), e = idx % (nspan * SPW);
+    const int ch = (which ? chJ0 : chI0) + e / SPW;
+    const long i = t0 - g.lowerN - (g.L - 1) + e % SPW;          // span element j holds sample i (zero outside [0, T))
+    return (ch < g.C && i >= 0 && i < g.T) ? Xk[(long)ch * g.T_stride + i] : make_float2(0.f, 0.f);
+  };
+  auto weight_load = [&](long t0) -> float {
+    const int cb = tid / WT_, tt = tid % WT_;
+    const long t = t0 + tt;
+    const float* w = Winv + (((long)s * g.C + c0 + cb) * g.K + k) * g.T_stride;
+    return (t < g.T && t >= g.lowerN) ? w[t] : 0.f;
+  };
+  auto prefetch = [&](long t0) {
+#pragma unroll
+    for (int q = 0; q < WPF; q++) { const int idx = tid + q * 256; if (idx < nelem) pf[q] = span_load(idx, t0); }
+    if (tid < CB * WT_) wpf = weight_load(t0);
+  };
+  if (use_pf) prefetch(0);
   for (long t0 = 0; t0 < g.T; t0 += WT_) {
     __syncthreads();
-    // span element j of channel ch holds sample i = t0 - lowerN - (L-1) + j (zero outside [0, T))
-    for (int idx = tid; idx < 2 * nspan * SPW; idx += 256) {
-      const int which = idx / (nspan * SPW), e = idx % (nspan * SPW);
-      const int ch = (which ? chJ0 : chI0) + e / SPW;
-      const long i = t0 - g.lowerN - (g.L - 1) + e % SPW;
-      float2 v = make_float2(0.f, 0.f);
-      if (ch < g.C && i >= 0 && i < g.T) v = Xk[(long)ch * g.T_stride + i];
-      (which ? spanJ : spanI)[e] = v;
-    }
-    if (tid < CB * WT_) {
-      const int cb = tid / WT_, tt = tid % WT_;
-      const long t = t0 + tt;
-      const float* w = Winv + (((long)s * g.C + c0 + cb) * g.K + k) * g.T_stride;
-      wrow[cb * WT_ + tt] = (t < g.T && t >= g.lowerN) ? w[t] : 0.f;
+    if (use_pf) {
+#pragma unroll
+      for (int q = 0; q < WPF; q++) { const int idx = tid + q * 256; if (idx < nelem) spanI[idx] = pf[q]; }
+      if (tid < CB * WT_) wrow[tid] = wpf;
+    } else {
+      for (int idx = tid; idx < nelem; idx += 256) spanI[idx] = span_load(idx, t0);
+      if (tid < CB * WT_) wrow[tid] = weight_load(t0);
     }
     __syncthreads();
+    if (use_pf && t0 + WT_ < g.T) prefetch(t0 + WT_);
     if (!quad_active) continue;
 #pragma unroll 2
     for (int kk = 0; kk < WT_; kk += 2) {
