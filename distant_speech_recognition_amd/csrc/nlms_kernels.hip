@@ -51,24 +51,54 @@ struct NlmsParams {
 };
 
 // stream_state[s] = { E_avg, gamma, isamp, ttl_updates } (doubles, in/out)
-__global__ void nlms_control_kernel(const float* __restrict__ energy, long T, NlmsParams p,
-                                    double* __restrict__ stream_state, float* __restrict__ ctrl /* [S][T] */)
+// One wavefront per stream.  E_avg obeys the linear recurrence E_t = beta E_{t-1} + (1-beta) en_t whatever the gate
+// decides, so 64 frames at a time are scanned as affine maps (float64, like the reference's Python floats); the gate of
+// frame t compares with E_{t-1}; the step size follows the deterministic halving schedule (gamma *= 0.5 whenever
+// isamp > 0 and isamp % slowdown_after == 0, pybeamformer.py:668-670), i.e. a power of two of the block's first gamma.
+__global__ __launch_bounds__(64)
+void nlms_control_kernel(const float* __restrict__ energy, long T, NlmsParams p,
+                         double* __restrict__ stream_state, float* __restrict__ ctrl /* [S][T] */)
 {
-  const int s = blockIdx.x;
+  const int s = blockIdx.x, lane = threadIdx.x;
   double* st = stream_state + 4 * (long)s;
-  double E = st[0], gamma = st[1];
-  long isamp = (long)st[2], ttl = (long)st[3];
+  double E = st[0];
+  const double gamma0 = st[1];
+  const long isamp0 = (long)st[2];
+  long ttl = (long)st[3];
   const float* e = energy + (long)s * T;
   float* c = ctrl + (long)s * T;
-  for (long t = 0; t < T; t++, isamp++) {
-    if (isamp > 0 && (isamp % p.slowdown_after) == 0) gamma *= 0.5;          // pybeamformer.py:668-670
-    const double en = e[t];
-    const bool adapt = en > E / (double)p.sil_thresh;                       // :672, :690
-    if (adapt) ttl++;
-    c[t] = adapt ? (float)gamma : 0.f;
-    E = E * (double)p.beta + (1.0 - (double)p.beta) * en;                   // :731
+  const double beta = (double)p.beta, omb = 1.0 - (double)p.beta, sil = (double)p.sil_thresh;
+  const long sa = p.slowdown_after;
+  // halvings applied before frame isamp0 are already in gamma0: multiples of sa in [1, isamp0 - 1]
+  const long h0 = isamp0 > 0 ? (isamp0 - 1) / sa : 0;
+  for (long t0 = 0; t0 < T; t0 += 64) {
+    const long t = t0 + lane;
+    const bool ok = t < T;
+    const double en = ok ? (double)e[t] : 0.0;
+    double a = ok ? beta : 1.0, b = ok ? omb * en : 0.0;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const double a2 = __shfl_up(a, d, 64), b2 = __shfl_up(b, d, 64);
+      if (lane >= d) { b = fma(a, b2, b); a *= a2; }
+    }
+    const double Et = fma(a, E, b);                            // E after frame t
+    double Eprev = __shfl_up(Et, 1, 64);
+    if (lane == 0) Eprev = E;
+    const bool adapt = ok && en > Eprev / sil;                 // :672, :690
+    const long isamp = isamp0 + t;
+    const long h = isamp > 0 ? isamp / sa : 0;                 // multiples of sa in [1, isamp]
+    const double gamma = ldexp(gamma0, -(int)(h - h0));
+    if (ok) c[t] = adapt ? (float)gamma : 0.f;
+    ttl += __popcll(__ballot(adapt));
+    const int last = (T - t0) >= 64 ? 63 : (int)(T - t0) - 1;
+    E = __shfl(Et, last, 64);
   }
-  st[0] = E; st[1] = gamma; st[2] = (double)isamp; st[3] = (double)ttl;
+  if (lane == 0) {
+    const long isamp_end = isamp0 + T;
+    // gamma as the sequential loop leaves it: halvings for every frame processed so far, i.e. multiples of sa in [1, isamp_end - 1]
+    const long h_end = isamp_end > 0 ? (isamp_end - 1) / sa : 0;
+    st[0] = E; st[1] = ldexp(gamma0, -(int)(h_end - h0)); st[2] = (double)isamp_end; st[3] = (double)ttl;
+  }
 }
 
 template <int GROUP>
@@ -460,7 +490,7 @@ int btk_nlms_process(const float* params /* host, 8 floats */, const void* vs, c
   hipLaunchKernelGGL(nlms_energy_kernel, dim3((unsigned)((T + 255) / 256), (unsigned)S), dim3(256), 0, st,
                      Xp, K, N, M, T_stride, T, energy, T);
   BTK_HIP_CHECK(hipMemcpyAsync(state_before, stream_state, sizeof(double) * 4 * S, hipMemcpyDeviceToDevice, st));
-  hipLaunchKernelGGL(nlms_control_kernel, dim3((unsigned)S), dim3(1), 0, st, energy, T, p, stream_state, ctrl);
+  hipLaunchKernelGGL(nlms_control_kernel, dim3((unsigned)S), dim3(64), 0, st, energy, T, p, stream_state, ctrl);
   BTK_HIP_CHECK(hipGetLastError());
 
   const float2* VS = static_cast<const float2*>(vs);

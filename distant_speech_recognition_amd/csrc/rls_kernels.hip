@@ -75,24 +75,38 @@ struct RlsParams {
   int qctype, normalize, update;
 };
 
-// stream_state[s] = { E_avg, unused, isamp, ttl_updates } (doubles, in/out); ctrl[s][t] = 1 adapt / 0 hold
-__global__ void rls_control_kernel(const float* __restrict__ energy, long T, double beta, double sil_thresh,
-                                   double* __restrict__ stream_state, float* __restrict__ ctrl)
+// stream_state[s] = { E_avg, unused, isamp, ttl_updates } (doubles, in/out); ctrl[s][t] = 1 adapt / 0 hold.
+// One wavefront per stream: E_avg is a linear recurrence independent of the gate, scanned 64 frames at a time in float64.
+__global__ __launch_bounds__(64)
+void rls_control_kernel(const float* __restrict__ energy, long T, double beta, double sil_thresh,
+                        double* __restrict__ stream_state, float* __restrict__ ctrl)
 {
-  const int s = blockIdx.x;
+  const int s = blockIdx.x, lane = threadIdx.x;
   double* st = stream_state + 4 * (long)s;
   double E = st[0];
-  long isamp = (long)st[2], ttl = (long)st[3];
+  long ttl = (long)st[3];
   const float* e = energy + (long)s * T;
   float* c = ctrl + (long)s * T;
-  for (long t = 0; t < T; t++, isamp++) {
-    const double en = e[t];
-    const bool adapt = en > E / sil_thresh;                                  // pybeamformer.py:827
-    if (adapt) ttl++;
-    c[t] = adapt ? 1.f : 0.f;
-    E = E * beta + (1.0 - beta) * en;                                        // :902
+  for (long t0 = 0; t0 < T; t0 += 64) {
+    const long t = t0 + lane;
+    const bool ok = t < T;
+    const double en = ok ? (double)e[t] : 0.0;
+    double a = ok ? beta : 1.0, b = ok ? (1.0 - beta) * en : 0.0;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const double a2 = __shfl_up(a, d, 64), b2 = __shfl_up(b, d, 64);
+      if (lane >= d) { b = fma(a, b2, b); a *= a2; }
+    }
+    const double Et = fma(a, E, b);
+    double Eprev = __shfl_up(Et, 1, 64);
+    if (lane == 0) Eprev = E;
+    const bool adapt = ok && en > Eprev / sil_thresh;          // pybeamformer.py:827
+    if (ok) c[t] = adapt ? 1.f : 0.f;
+    ttl += __popcll(__ballot(adapt));
+    const int last = (T - t0) >= 64 ? 63 : (int)(T - t0) - 1;
+    E = __shfl(Et, last, 64);
   }
-  st[0] = E; st[2] = (double)isamp; st[3] = (double)ttl;
+  if (lane == 0) { st[0] = E; st[2] = (double)((long)st[2] + T); st[3] = (double)ttl; }
 }
 
 // P = p0 (I - v v^H / |v|^2) (mode 1) or p0 (I - conj(v) v^T / |v|^2) (mode 0), w = 0
@@ -455,7 +469,7 @@ int btk_rls_process(int mode, const double* params /* host, 10 doubles */, const
   if (mode == 1) {
     const int rc = btk_frame_energy(X, S, M, N, T_stride, T, energy, T, stream);
     if (rc != BTK_OK) return rc;
-    hipLaunchKernelGGL(rls_control_kernel, dim3((unsigned)S), dim3(1), 0, st, energy, T, p.beta, p.sil_thresh, stream_state, ctrl);
+    hipLaunchKernelGGL(rls_control_kernel, dim3((unsigned)S), dim3(64), 0, st, energy, T, p.beta, p.sil_thresh, stream_state, ctrl);
     BTK_HIP_CHECK(hipGetLastError());
   }
   const float2* Xp = static_cast<const float2*>(X);
