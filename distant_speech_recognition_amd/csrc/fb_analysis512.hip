@@ -62,6 +62,82 @@ __device__ __forceinline__ void dft16p(float2 (&v)[16])
   }
 }
 
+
+// ---- packed-float32 complex arithmetic (v_pk_*_f32 with op_sel / neg modifiers).  The compiler forms packed adds and
+// FMAs from float2 code on its own, but materialises every "multiply by +-i" and conjugation with v_xor + v_mov pairs
+// (a quarter of the FFT's instructions); the modifiers do those swaps and sign flips for free, so the few shapes the FFT
+// and the beamformer sum need are spelled out.  op_sel[i] / op_sel_hi[i] pick the low or high dword of source i for the
+// low / high result, neg_lo / neg_hi negate that source for the low / high result.
+typedef float f2 __attribute__((ext_vector_type(2)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ f2 add_ib(f2 a, f2 b)      // a + i b = (a.x - b.y, a.y + b.x)
+{
+  f2 r;
+  asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ f2 sub_ib(f2 a, f2 b)      // a - i b = (a.x + b.y, a.y - b.x)
+{
+  f2 r;
+  asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ f2 cmulv(f2 a, f2 w)       // a w
+{
+  f2 t, r;
+  asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1]" : "=v"(t) : "v"(a), "v"(w));                    // (a.x w.x, a.x w.y)
+  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]" : "=v"(r) : "v"(a), "v"(w), "v"(t));   // + (-a.y w.y, a.y w.x)
+  return r;
+}
+__device__ __forceinline__ f2 cmulc(f2 a, f2 w) { return __builtin_elementwise_fma(a.yy, f2{-w.y, w.x}, a.xx * w); }   // constant w
+__device__ __forceinline__ void acc_conjw_z(f2& A, f2 w, f2 z)          // A += conj(w) z
+{
+  asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "+v"(A) : "v"(w), "v"(z));                       // (w.x z.x, w.x z.y)
+  asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_hi:[0,1,0]" : "+v"(A) : "v"(w), "v"(z));        // (w.y z.y, -w.y z.x)
+}
+__device__ __forceinline__ void acc_conjw_conjz(f2& B, f2 w, f2 z)      // B += conj(w) conj(z)
+{
+  asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_hi:[0,1,0]" : "+v"(B) : "v"(w), "v"(z));        // (w.x z.x, -w.x z.y)
+  asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0] neg_hi:[0,1,0]" : "+v"(B) : "v"(w), "v"(z));   // (-w.y z.y, -w.y z.x)
+}
+__device__ __forceinline__ void dft4q(f2& a0, f2& a1, f2& a2, f2& a3)
+{
+  const f2 s02 = a0 + a2, d02 = a0 - a2, s13 = a1 + a3, t = a1 - a3;
+  a0 = s02 + s13; a1 = add_ib(d02, t); a2 = s02 - s13; a3 = sub_ib(d02, t);
+}
+__device__ __forceinline__ void dft4q_i2(f2& a0, f2& a1, f2& a2, f2& a3)   // a2 stands for i a2
+{
+  const f2 s02 = add_ib(a0, a2), d02 = sub_ib(a0, a2), s13 = a1 + a3, t = a1 - a3;
+  a0 = s02 + s13; a1 = add_ib(d02, t); a2 = s02 - s13; a3 = sub_ib(d02, t);
+}
+// dft16p on packed registers (same factorisation and twiddles)
+__device__ __forceinline__ void dft16q(f2 (&v)[16])
+{
+  constexpr float C1 = 0.92387953251128674f, S1 = 0.38268343236508977f, H = 0.70710678118654752f;
+  f2 t[4][4];
+#pragma unroll
+  for (int b = 0; b < 4; b++) {
+    f2 x0 = v[b], x1 = v[4 + b], x2 = v[8 + b], x3 = v[12 + b];
+    dft4q(x0, x1, x2, x3);
+    t[b][0] = x0; t[b][1] = x1; t[b][2] = x2; t[b][3] = x3;
+  }
+  t[1][1] = cmulc(t[1][1], f2{C1, S1});
+  t[1][2] = cmulc(t[1][2], f2{H, H});
+  t[1][3] = cmulc(t[1][3], f2{S1, C1});
+  t[2][1] = cmulc(t[2][1], f2{H, H});
+  t[2][3] = cmulc(t[2][3], f2{-H, H});                  // t[2][2] *= i is folded into dft4q_i2
+  t[3][1] = cmulc(t[3][1], f2{S1, C1});
+  t[3][2] = cmulc(t[3][2], f2{-H, H});
+  t[3][3] = cmulc(t[3][3], f2{-C1, -S1});
+#pragma unroll
+  for (int c = 0; c < 4; c++) {
+    f2 y0 = t[0][c], y1 = t[1][c], y2 = t[2][c], y3 = t[3][c];
+    if (c == 2) dft4q_i2(y0, y1, y2, y3); else dft4q(y0, y1, y2, y3);
+    v[c] = y0; v[c + 4] = y1; v[c + 8] = y2; v[c + 12] = y3;
+  }
+}
+
 constexpr int A_RUN = 16;             // consecutive tiles (16 frames each) one workgroup walks through
 
 template <int R>     // R = M / D in {1, 2, 4}
@@ -438,6 +514,212 @@ void analysis512_bf_kernel(const float* __restrict__ pcm, long nsamples, long pc
   }
 }
 
+// Second form of the fused kernel: the beamformer sum is taken in the Z domain (Z = the 256-point complex FFT of the
+// packed real frame) and the Hermitian post-pass runs ONCE per tile instead of once per channel.  With
+//   X_n[k] = hg [(1 - j W^k) Z_n[k] + (1 + j W^k) conj Z_n[256-k]],   hg = gain / 2,  W = e^{+j 2 pi / 512},
+//   Y[k]   = sum_n conj(w_n[k]) X_n[k] = hg [(1 - j W^k) A[k] + (1 + j W^k) B[k]],
+//   A[k]   = sum_n conj(w_n[k]) Z_n[k],        B[k] = sum_n conj(w_n[k]) conj Z_n[(256-k) & 255],
+// the FFT lane that holds Z_n[q] (q = j + 16 k2, registers k2 = 0..15) accumulates A[q] and B'[q] = B[(256-q) & 255]
+// straight from its registers: no FFT result goes back to LDS, no cross-lane partner is needed per channel.
+// Wq [Sw][N][257] float4: entry i < 256 = (w[i], w[(256-i) & 255]), entry 256 = (w[256], 0, 0).
+template <int R>
+__global__ __launch_bounds__(A_NT, 2)
+void analysis512_bfz_kernel(const float* __restrict__ pcm, long nsamples, long pcm_stride,
+                            const float* __restrict__ proto, const float2* __restrict__ twg,
+                            int laN, float gain, int N, int K, const float4* __restrict__ Wq, long w_stream_stride,
+                            float2* __restrict__ Y, long T_stride, long t0, long tcount, int ntiles, int tiles_per_xcd, int S)
+{
+  constexpr int D = A_M / R;
+  constexpr int SPAN = (A_TT - 1) * D + A_MT * A_M;
+  constexpr int FB_BYTES = A_TT * FRS * 8;
+  constexpr int REG_U = (SPAN * 4 > FB_BYTES) ? SPAN * 4 : FB_BYTES;
+  constexpr int NV4 = (SPAN / 4 + A_NT - 1) / A_NT;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* xs = reinterpret_cast<float*>(smem);
+  float2* fbuf = reinterpret_cast<float2*>(smem);
+  float4* wq = reinterpret_cast<float4*>(smem + REG_U);                       // [256] weight pairs of the current channel
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.x;
+  const int xcd = b & 7, j0 = b >> 3;
+  const int s = j0 / tiles_per_xcd;
+  const int tile = xcd * tiles_per_xcd + j0 % tiles_per_xcd;
+  if (s >= S || tile >= ntiles) return;
+  const long tt0 = (long)tile * A_TT;
+  const int fl = lane >> 4, j = lane & 15;
+
+  const bool vec_ok = ((pcm_stride & 3) == 0) && ((reinterpret_cast<uintptr_t>(pcm) & 15) == 0);
+  const long g0 = (t0 + tt0 + laN + 1) * (long)D - (long)A_MT * A_M;
+  const bool inb = vec_ok && g0 >= 0 && g0 + SPAN <= nsamples;
+  const float4* wts = Wq + (long)s * w_stream_stride;
+  float4 pre[NV4];
+  float4 wpre;
+  float2 w256pre, w256 = make_float2(0.f, 0.f);
+  auto fetch = [&](int n) {
+    const float* src = pcm + ((long)s * N + n) * pcm_stride;
+    if (inb) {
+#pragma unroll
+      for (int q = 0; q < NV4; q++) {
+        const int l = (tid + q * A_NT) * 4;
+        if (l < SPAN) pre[q] = *reinterpret_cast<const float4*>(src + g0 + l);
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < NV4; q++) {
+        const int l = (tid + q * A_NT) * 4;
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+          const long g = g0 + l + e;
+          v[e] = (l + e < SPAN && g >= 0 && g < nsamples) ? src[g] : 0.0f;
+        }
+        pre[q] = make_float4(v[0], v[1], v[2], v[3]);
+      }
+    }
+    wpre = wts[(long)n * 257 + tid];
+    const float4 t = wts[(long)n * 257 + 256];
+    w256pre = make_float2(t.x, t.y);
+  };
+
+  float2 h[A_MT];
+#pragma unroll
+  for (int k = 0; k < A_MT; k++) h[k] = *reinterpret_cast<const float2*>(proto + 2 * tid + A_M * k);
+  f2 twr[15];                                                                 // W_256^{j k1}, k1 = 1..15
+#pragma unroll
+  for (int k1 = 1; k1 < 16; k1++) { const float2 t = twg[(2 * j * k1) & 511]; twr[k1 - 1] = f2{t.x, t.y}; }
+  f2 accA[16], accB[16];
+#pragma unroll
+  for (int k2 = 0; k2 < 16; k2++) { accA[k2] = f2{0.f, 0.f}; accB[k2] = f2{0.f, 0.f}; }
+  float2 acc256 = make_float2(0.f, 0.f);
+
+  fetch(0);
+  for (int n = 0; n < N; n++) {
+    // ---- phase 1: registers -> LDS (PCM span + weight pairs)
+#pragma unroll
+    for (int q = 0; q < NV4; q++) {
+      const int l = (tid + q * A_NT) * 4;
+      if (l < SPAN) *reinterpret_cast<float4*>(xs + l) = pre[q];
+    }
+    wq[tid] = wpre;
+    w256 = w256pre;
+    __syncthreads();
+
+    // ---- phase 2: polyphase (sliding register window), frames overwrite the span after the barrier
+    {
+      constexpr int NW = A_TT + (A_MT - 1) * R;
+      float2 win[NW];
+      const float* wbase = xs + (A_M - 2 - 2 * tid);
+#pragma unroll
+      for (int i = 0; i < NW; i++) win[i] = *reinterpret_cast<const float2*>(wbase + i * D);
+      __syncthreads();
+      const int zoff = (tid >> 4) * 17 + (tid & 15);
+#pragma unroll
+      for (int f = 0; f < A_TT; f++) {
+        float p0 = 0.f, p1 = 0.f;
+#pragma unroll
+        for (int k = 0; k < A_MT; k++) {
+          const float2 x = win[f + R * (A_MT - 1 - k)];
+          p0 = fmaf(h[k].x, x.y, p0);
+          p1 = fmaf(h[k].y, x.x, p1);
+        }
+        fbuf[f * FRS + zoff] = make_float2(p0, p1);
+      }
+    }
+    __syncthreads();
+    if (n + 1 < N) fetch(n + 1);          // lands under phases 3-4
+
+    // ---- phase 3: wave-private 256-point FFT of 4 frames; the result stays in registers
+    f2 v[16];
+    const f4* wl = reinterpret_cast<const f4*>(wq) + j;
+    f4 wg[2][4];                                                      // weight pairs, fetched one group of 4 bins ahead
+    {
+      f2* fb = reinterpret_cast<f2*>(fbuf) + (wave * 4 + fl) * FRS;
+#pragma unroll
+      for (int r = 0; r < 16; r++) v[r] = fb[r * 17 + j];
+      dft16q(v);
+#pragma unroll
+      for (int k1 = 1; k1 < 16; k1++) v[k1] = cmulv(v[k1], twr[k1 - 1]);
+#pragma unroll
+      for (int k1 = 0; k1 < 16; k1++) fb[j * 17 + k1] = v[k1];
+#pragma unroll
+      for (int jp = 0; jp < 16; jp++) v[jp] = fb[jp * 17 + j];
+#pragma unroll
+      for (int q = 0; q < 4; q++) wg[0][q] = wl[q * 16];
+      dft16q(v);                                                      // v[k2] = Z[j + 16 k2]
+    }
+    // ---- phase 4: A[q] += conj(w[q]) Z[q],  B'[q] += conj(w[(256-q)&255]) conj(Z[q])
+    {
+#pragma unroll
+      for (int g = 0; g < 4; g++) {
+        if (g < 3) {
+#pragma unroll
+          for (int q = 0; q < 4; q++) wg[(g + 1) & 1][q] = wl[((g + 1) * 4 + q) * 16];
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          const int k2 = g * 4 + q;
+          const f4 w4 = wg[g & 1][q];
+          acc_conjw_z(accA[k2], w4.xy, v[k2]);
+          acc_conjw_conjz(accB[k2], w4.zw, v[k2]);
+        }
+      }
+      const float r = v[0].x - v[0].y;                                // bin 256 (lanes j == 0): X = gain (Z0.re - Z0.im)
+      acc256.x = fmaf(w256.x, r, acc256.x);
+      acc256.y = fmaf(-w256.y, r, acc256.y);
+    }
+    __syncthreads();                                                  // frames and weight pairs consumed
+  }
+
+  // ---- once per tile: B[k] = B'[(256-k)&255] through the wave's own frame buffers, Hermitian post-pass,
+  //      then a transposed store Y[s][k][tt0 .. tt0+15] (128-byte runs per bin)
+  {
+    const float hg = 0.5f * gain;
+    float2* fb = fbuf + (wave * 4 + fl) * FRS;
+#pragma unroll
+    for (int k2 = 0; k2 < 16; k2++) fb[k2 * 17 + j] = make_float2(accB[k2].x, accB[k2].y);
+    float2 yv[16];
+#pragma unroll
+    for (int k2 = 0; k2 < 16; k2++) {
+      const int k = j + 16 * k2;
+      const int kp = (A_NF - k) & 255;
+      const float2 Bk = fb[(kp >> 4) * 17 + (kp & 15)];
+      const float2 w = twg[k];
+      const float2 c1 = make_float2(1.f + w.y, -w.x), c2 = make_float2(1.f - w.y, w.x);
+      const float2 a = make_float2(accA[k2].x, accA[k2].y);
+      yv[k2] = make_float2(hg * ((c1.x * a.x - c1.y * a.y) + (c2.x * Bk.x - c2.y * Bk.y)),
+                           hg * ((c1.x * a.y + c1.y * a.x) + (c2.x * Bk.y + c2.y * Bk.x)));
+    }
+#pragma unroll
+    for (int k2 = 0; k2 < 16; k2++) fb[k2 * 17 + j] = yv[k2];
+    if (j == 0) fb[16 * 17] = make_float2(gain * acc256.x, gain * acc256.y);
+  }
+  __syncthreads();
+  {
+    const int f = tid & 15, kq = tid >> 4;
+    if (tt0 + f < tcount) {
+      float2* yo = Y + (long)s * K * T_stride + tt0 + f;
+      const float2* zf = fbuf + f * FRS;
+#pragma unroll 4
+      for (int it = 0; it < 16; it++) yo[(long)(kq + 16 * it) * T_stride] = zf[it * 17 + kq];
+      if (kq == 0) yo[(long)A_NF * T_stride] = zf[16 * 17];
+    }
+  }
+}
+
+// W [Sw][K][N] -> Wq [Sw][N][257] float4 (see analysis512_bfz_kernel)
+__global__ void pair_weights_kernel(const float2* __restrict__ W, float4* __restrict__ Wq, int K, int N, int Sw)
+{
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)Sw * N * 257) return;
+  const int e = (int)(i % 257);
+  const int n = (int)((i / 257) % N);
+  const long s = i / ((long)N * 257);
+  const float2* Ws = W + s * (long)K * N;
+  const float2 a = Ws[(long)e * N + n];
+  const float2 bq = (e < 256) ? Ws[(long)((256 - e) & 255) * N + n] : make_float2(0.f, 0.f);
+  Wq[i] = make_float4(a.x, a.y, bq.x, bq.y);
+}
+
 // W [Sw][K][N] -> Wt [Sw][N][K]
 __global__ void transpose_weights_kernel(const float2* __restrict__ W, float2* __restrict__ Wt, int K, int N, int Sw)
 {
@@ -451,29 +733,46 @@ __global__ void transpose_weights_kernel(const float2* __restrict__ W, float2* _
 
 template <int R>
 int launch512_bf(const btk_fb* fb, const float* pcm, long nsamples, long pcm_stride, int S, int N, const float2* W,
-                 int per_stream, float2* Wt, float2* Y, long T_stride, long t0, long tcount, hipStream_t st)
+                 int per_stream, void* scratch, float2* Y, long T_stride, long t0, long tcount, hipStream_t st)
 {
   constexpr int D = A_M / R;
   constexpr int SPAN = (A_TT - 1) * D + A_MT * A_M;
   constexpr int FB_BYTES = A_TT * FRS * 8;
   constexpr int REG_U = (SPAN * 4 > FB_BYTES) ? SPAN * 4 : FB_BYTES;
-  const size_t lds = REG_U + sizeof(float2) * (A_NF + 1 + 256 + A_NF + 1);
   const int K = fb->K;
   const int Sw = per_stream ? S : 1;
-  const long nw = (long)Sw * K * N;
-  hipLaunchKernelGGL(transpose_weights_kernel, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, st, W, Wt, K, N, Sw);
   const int ntiles = (int)((tcount + A_TT - 1) / A_TT);
   const int tiles_per_xcd = (ntiles + 7) / 8;
   const long nblocks = (long)8 * tiles_per_xcd * S;
-  auto kern = analysis512_bf_kernel<R>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    BTK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_set = true;
-  }
   const float gain = fb->gain_factor > 0 ? (float)fb->gain_factor : 1.0f;
-  hipLaunchKernelGGL(kern, dim3((unsigned)nblocks), dim3(A_NT), lds, st, pcm, nsamples, pcm_stride, fb->d_proto, fb->d_tw,
-                     fb->laN, gain, N, K, Wt, per_stream ? (long)N * K : 0L, Y, T_stride, t0, tcount, ntiles, tiles_per_xcd, S);
+  static const bool v1 = getenv("BTK_FUSED_V1") != nullptr;                   // diagnostics: per-channel post-pass form
+  if (v1) {
+    float2* Wt = static_cast<float2*>(scratch);
+    const size_t lds = REG_U + sizeof(float2) * (A_NF + 1 + 256 + A_NF + 1);
+    const long nw = (long)Sw * K * N;
+    hipLaunchKernelGGL(transpose_weights_kernel, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, st, W, Wt, K, N, Sw);
+    auto kern = analysis512_bf_kernel<R>;
+    static bool attr_set = false;
+    if (!attr_set) {
+      BTK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblocks), dim3(A_NT), lds, st, pcm, nsamples, pcm_stride, fb->d_proto, fb->d_tw,
+                       fb->laN, gain, N, K, Wt, per_stream ? (long)N * K : 0L, Y, T_stride, t0, tcount, ntiles, tiles_per_xcd, S);
+  } else {
+    float4* Wq = static_cast<float4*>(scratch);
+    const size_t lds = REG_U + sizeof(float4) * 256;
+    const long nw = (long)Sw * N * 257;
+    hipLaunchKernelGGL(pair_weights_kernel, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, st, W, Wq, K, N, Sw);
+    auto kern = analysis512_bfz_kernel<R>;
+    static bool attr_set = false;
+    if (!attr_set) {
+      BTK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblocks), dim3(A_NT), lds, st, pcm, nsamples, pcm_stride, fb->d_proto, fb->d_tw,
+                       fb->laN, gain, N, K, Wq, per_stream ? (long)N * 257 : 0L, Y, T_stride, t0, tcount, ntiles, tiles_per_xcd, S);
+  }
   BTK_HIP_CHECK(hipGetLastError());
   return BTK_OK;
 }
@@ -670,7 +969,7 @@ int btk_analysis512_bf_try(const btk_fb* fb, const float* pcm, long nsamples, lo
 {
   if (fb->M != A_M || fb->m != A_MT) return 0;
   const float2* Wp = static_cast<const float2*>(W);
-  float2* Wt = static_cast<float2*>(Wt_scratch);
+  void* Wt = Wt_scratch;
   float2* Yp = static_cast<float2*>(Y);
   int rc;
   switch (fb->R) {
