@@ -68,6 +68,7 @@ __device__ __forceinline__ void dft16p(float2 (&v)[16])
 // (a quarter of the FFT's instructions); the modifiers do those swaps and sign flips for free, so the few shapes the FFT
 // and the beamformer sum need are spelled out.  op_sel[i] / op_sel_hi[i] pick the low or high dword of source i for the
 // low / high result, neg_lo / neg_hi negate that source for the low / high result.
+constexpr int WSTR = 320;              // float4 per channel in the weight-pair table: 257 used, padded to 5 x 64 for 1 KiB LDS-DMA pieces
 typedef float f2 __attribute__((ext_vector_type(2)));
 typedef float f4 __attribute__((ext_vector_type(4)));
 
@@ -521,9 +522,9 @@ void analysis512_bf_kernel(const float* __restrict__ pcm, long nsamples, long pc
 //   A[k]   = sum_n conj(w_n[k]) Z_n[k],        B[k] = sum_n conj(w_n[k]) conj Z_n[(256-k) & 255],
 // the FFT lane that holds Z_n[q] (q = j + 16 k2, registers k2 = 0..15) accumulates A[q] and B'[q] = B[(256-q) & 255]
 // straight from its registers: no FFT result goes back to LDS, no cross-lane partner is needed per channel.
-// Wq [Sw][N][257] float4: entry i < 256 = (w[i], w[(256-i) & 255]), entry 256 = (w[256], 0, 0).
-template <int R>
-__global__ __launch_bounds__(A_NT, 2)
+// Wq [Sw][N][WSTR] float4: entry i < 256 = (w[i], w[(256-i) & 255]), entry 256 = (w[256], 0, 0), the rest 0.
+template <int R, int VAR>
+__global__ __launch_bounds__(A_NT, (VAR & 8) ? 3 : 2)
 void analysis512_bfz_kernel(const float* __restrict__ pcm, long nsamples, long pcm_stride,
                             const float* __restrict__ proto, const float2* __restrict__ twg,
                             int laN, float gain, int N, int K, const float4* __restrict__ Wq, long w_stream_stride,
@@ -531,13 +532,22 @@ void analysis512_bfz_kernel(const float* __restrict__ pcm, long nsamples, long p
 {
   constexpr int D = A_M / R;
   constexpr int SPAN = (A_TT - 1) * D + A_MT * A_M;
-  constexpr int FB_BYTES = A_TT * FRS * 8;
+  // frame stride 272 = 16 (mod 32) float2: the four frames of a wavefront land on disjoint bank halves in both FFT passes
+  // (with 273 the transposing writes of frames fl and fl+1 collide two-way)
+  constexpr int FRZ = 272;
+  constexpr int FB_BYTES = A_TT * FRZ * 8;
   constexpr int REG_U = (SPAN * 4 > FB_BYTES) ? SPAN * 4 : FB_BYTES;
   constexpr int NV4 = (SPAN / 4 + A_NT - 1) / A_NT;
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  // PIPE: the PCM span has its own region and the weight pairs are double-buffered, so channel n+1 is staged into LDS
+  // while channel n is transformed -- two workgroup barriers per channel instead of four.  Without it (R = 1: the span
+  // alone is 38 KB) the span and the FFT frames share one region.
+  constexpr bool PIPE = (VAR & 2) && R >= 2;
+  constexpr int FB_OFF = PIPE ? SPAN * 4 : 0;
+  constexpr int WQ_OFF = PIPE ? SPAN * 4 + FB_BYTES : REG_U;
   float* xs = reinterpret_cast<float*>(smem);
-  float2* fbuf = reinterpret_cast<float2*>(smem);
-  float4* wq = reinterpret_cast<float4*>(smem + REG_U);                       // [256] weight pairs of the current channel
+  float2* fbuf = reinterpret_cast<float2*>(smem + FB_OFF);
+  float4* wq = reinterpret_cast<float4*>(smem + WQ_OFF);                      // [1 or 2][WSTR] weight pairs of a channel
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int b = blockIdx.x;
@@ -554,7 +564,7 @@ void analysis512_bfz_kernel(const float* __restrict__ pcm, long nsamples, long p
   const float4* wts = Wq + (long)s * w_stream_stride;
   float4 pre[NV4];
   float4 wpre;
-  float2 w256pre, w256 = make_float2(0.f, 0.f);
+  float2 w256pre;
   auto fetch = [&](int n) {
     const float* src = pcm + ((long)s * N + n) * pcm_stride;
     if (inb) {
@@ -576,14 +586,22 @@ void analysis512_bfz_kernel(const float* __restrict__ pcm, long nsamples, long p
         pre[q] = make_float4(v[0], v[1], v[2], v[3]);
       }
     }
-    wpre = wts[(long)n * 257 + tid];
-    const float4 t = wts[(long)n * 257 + 256];
+    wpre = wts[(long)n * WSTR + tid];
+    const float4 t = wts[(long)n * WSTR + 256];
     w256pre = make_float2(t.x, t.y);
   };
 
-  float2 h[A_MT];
+  // polyphase mapping: with D = M / R the windows of the pair indices n and n + D/2 are the same LDS words shifted by one
+  // frame, so a thread takes G = 2 such indices (n0, n0 + 128) for half of the tile's frames and reads every word once
+  constexpr int G = (R >= 2 && (VAR & 1)) ? 2 : 1;
+  constexpr int NPG = 256 / G, FPT = A_TT / G, CG = R / G;
+  constexpr int NWG = FPT + (A_MT - 1) * R + (G - 1) * CG;
+  const int n0 = tid % NPG, fg = tid / NPG;
+  float2 h[G][A_MT];
 #pragma unroll
-  for (int k = 0; k < A_MT; k++) h[k] = *reinterpret_cast<const float2*>(proto + 2 * tid + A_M * k);
+  for (int q = 0; q < G; q++)
+#pragma unroll
+    for (int k = 0; k < A_MT; k++) h[q][k] = *reinterpret_cast<const float2*>(proto + 2 * (n0 + q * NPG) + A_M * k);
   f2 twr[15];                                                                 // W_256^{j k1}, k1 = 1..15
 #pragma unroll
   for (int k1 = 1; k1 < 16; k1++) { const float2 t = twg[(2 * j * k1) & 511]; twr[k1 - 1] = f2{t.x, t.y}; }
@@ -592,48 +610,98 @@ void analysis512_bfz_kernel(const float* __restrict__ pcm, long nsamples, long p
   for (int k2 = 0; k2 < 16; k2++) { accA[k2] = f2{0.f, 0.f}; accB[k2] = f2{0.f, 0.f}; }
   float2 acc256 = make_float2(0.f, 0.f);
 
-  fetch(0);
-  for (int n = 0; n < N; n++) {
-    // ---- phase 1: registers -> LDS (PCM span + weight pairs)
+  // registers -> LDS: PCM span + weight pairs of one channel
+  auto stage = [&](int buf) {
 #pragma unroll
     for (int q = 0; q < NV4; q++) {
       const int l = (tid + q * A_NT) * 4;
       if (l < SPAN) *reinterpret_cast<float4*>(xs + l) = pre[q];
     }
-    wq[tid] = wpre;
-    w256 = w256pre;
-    __syncthreads();
-
-    // ---- phase 2: polyphase (sliding register window), frames overwrite the span after the barrier
-    {
-      constexpr int NW = A_TT + (A_MT - 1) * R;
-      float2 win[NW];
-      const float* wbase = xs + (A_M - 2 - 2 * tid);
+    wq[buf * WSTR + tid] = wpre;
+    if (tid == 0) wq[buf * WSTR + 256] = make_float4(w256pre.x, w256pre.y, 0.f, 0.f);
+  };
+  // PIPE: LDS-DMA (global_load_lds_dwordx4: 1 KiB per wave-instruction, lane-linear destination) of the span and the
+  // weight pairs of channel n; issued by asm so that hipcc does not order the FFT's LDS traffic behind it -- the
+  // matching s_waitcnt vmcnt(0) sits before the barrier that opens channel n.  Edge tiles (span not inside the
+  // recording, or unaligned) go through registers synchronously.
+  const unsigned xs_lds = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;   // LDS byte offset of the dynamic region
+  auto glds16 = [&](const void* gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+  };
+  auto dma = [&](int n) {
+    if (inb) {
+      const float* src = pcm + ((long)s * N + n) * pcm_stride + g0;
+      constexpr int NCH = (SPAN * 4 + 1023) / 1024;
 #pragma unroll
-      for (int i = 0; i < NW; i++) win[i] = *reinterpret_cast<const float2*>(wbase + i * D);
-      __syncthreads();
-      const int zoff = (tid >> 4) * 17 + (tid & 15);
-#pragma unroll
-      for (int f = 0; f < A_TT; f++) {
-        float p0 = 0.f, p1 = 0.f;
-#pragma unroll
-        for (int k = 0; k < A_MT; k++) {
-          const float2 x = win[f + R * (A_MT - 1 - k)];
-          p0 = fmaf(h[k].x, x.y, p0);
-          p1 = fmaf(h[k].y, x.x, p1);
+      for (int i = 0; i < (NCH + 3) / 4; i++) {
+        const int c = __builtin_amdgcn_readfirstlane(wave + 4 * i);
+        if (c < NCH) {
+          const int l = c * 256 + lane * 4;
+          if (l < SPAN) glds16(src + l, xs_lds + c * 1024);
         }
-        fbuf[f * FRS + zoff] = make_float2(p0, p1);
+      }
+      const float4* wsrc = wts + (long)n * WSTR;
+      const unsigned wq_lds = xs_lds + WQ_OFF + (n & 1) * (WSTR * 16);
+#pragma unroll
+      for (int i = 0; i < 2; i++) {
+        const int c = __builtin_amdgcn_readfirstlane(wave + 4 * i);
+        if (c < WSTR / 64) glds16(wsrc + c * 64 + lane, wq_lds + c * 1024);
+      }
+    } else {
+      fetch(n);
+      stage(n & 1);
+    }
+  };
+
+  if (PIPE) dma(0);
+  else fetch(0);
+  for (int n = 0; n < N; n++) {
+    // ---- phase 1: registers -> LDS (PCM span + weight pairs)
+    if (!PIPE) stage(0);
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // the LDS-DMA of channel n has landed
+    __syncthreads();
+    const int wbuf = PIPE ? (n & 1) : 0;
+
+    // ---- phase 2: polyphase (sliding register window), frames overwrite the span after the barrier.
+    //      V[i] = xs[(M - 2 - 2 n0 - (G-1) 512/G) + (f0 + i) D]; index n0 + q NPG, frame f0 + g, tap k uses
+    //      V[g + R (m-1-k) + (G-1-q) CG]  (= xs[f D + m M - 2 - 2 n - M k], modulated.cc:380-392)
+    {
+      float2 win[NWG];
+      const float* wbase = xs + (A_M - 2 - 2 * n0 - (G - 1) * (A_M / G)) + fg * FPT * D;
+#pragma unroll
+      for (int i = 0; i < NWG; i++) win[i] = *reinterpret_cast<const float2*>(wbase + i * D);
+      if (!PIPE) __syncthreads();
+      else __builtin_amdgcn_sched_barrier(0);            // keep the window reads back to back (one LDS latency, not NWG)
+#pragma unroll
+      for (int q = 0; q < G; q++) {
+        const int nn = n0 + q * NPG;
+        const int zoff = (nn >> 4) * 17 + (nn & 15);
+#pragma unroll
+        for (int g = 0; g < FPT; g++) {
+          float p0 = 0.f, p1 = 0.f;
+#pragma unroll
+          for (int k = 0; k < A_MT; k++) {
+            const float2 x = win[g + R * (A_MT - 1 - k) + (G - 1 - q) * CG];
+            p0 = fmaf(h[q][k].x, x.y, p0);
+            p1 = fmaf(h[q][k].y, x.x, p1);
+          }
+          fbuf[(fg * FPT + g) * FRZ + zoff] = make_float2(p0, p1);
+        }
       }
     }
     __syncthreads();
-    if (n + 1 < N) fetch(n + 1);          // lands under phases 3-4
+    if (PIPE) {
+      if (n + 1 < N) dma(n + 1);          // every window read of channel n is behind the barrier; lands under phases 3-4
+    } else if (n + 1 < N) fetch(n + 1);   // lands under phases 3-4
 
     // ---- phase 3: wave-private 256-point FFT of 4 frames; the result stays in registers
     f2 v[16];
-    const f4* wl = reinterpret_cast<const f4*>(wq) + j;
+    const f4* wl = reinterpret_cast<const f4*>(wq) + wbuf * WSTR + j;
     f4 wg[2][4];                                                      // weight pairs, fetched one group of 4 bins ahead
     {
-      f2* fb = reinterpret_cast<f2*>(fbuf) + (wave * 4 + fl) * FRS;
+      f2* fb = reinterpret_cast<f2*>(fbuf) + (wave * 4 + fl) * FRZ;
 #pragma unroll
       for (int r = 0; r < 16; r++) v[r] = fb[r * 17 + j];
       dft16q(v);
@@ -664,17 +732,19 @@ void analysis512_bfz_kernel(const float* __restrict__ pcm, long nsamples, long p
         }
       }
       const float r = v[0].x - v[0].y;                                // bin 256 (lanes j == 0): X = gain (Z0.re - Z0.im)
+      const float4 w256 = wq[wbuf * WSTR + 256];
       acc256.x = fmaf(w256.x, r, acc256.x);
       acc256.y = fmaf(-w256.y, r, acc256.y);
     }
-    __syncthreads();                                                  // frames and weight pairs consumed
+    if (!PIPE) __syncthreads();                                       // frames and weight pairs consumed
   }
 
+  if (PIPE) __syncthreads();
   // ---- once per tile: B[k] = B'[(256-k)&255] through the wave's own frame buffers, Hermitian post-pass,
   //      then a transposed store Y[s][k][tt0 .. tt0+15] (128-byte runs per bin)
   {
     const float hg = 0.5f * gain;
-    float2* fb = fbuf + (wave * 4 + fl) * FRS;
+    float2* fb = fbuf + (wave * 4 + fl) * FRZ;
 #pragma unroll
     for (int k2 = 0; k2 < 16; k2++) fb[k2 * 17 + j] = make_float2(accB[k2].x, accB[k2].y);
     float2 yv[16];
@@ -691,33 +761,262 @@ void analysis512_bfz_kernel(const float* __restrict__ pcm, long nsamples, long p
     }
 #pragma unroll
     for (int k2 = 0; k2 < 16; k2++) fb[k2 * 17 + j] = yv[k2];
-    if (j == 0) fb[16 * 17] = make_float2(gain * acc256.x, gain * acc256.y);
+    if (j == 0) reinterpret_cast<float2*>(wq)[wave * 4 + fl] = make_float2(gain * acc256.x, gain * acc256.y);   // weights are dead
   }
   __syncthreads();
   {
     const int f = tid & 15, kq = tid >> 4;
     if (tt0 + f < tcount) {
       float2* yo = Y + (long)s * K * T_stride + tt0 + f;
-      const float2* zf = fbuf + f * FRS;
+      const float2* zf = fbuf + f * FRZ;
 #pragma unroll 4
       for (int it = 0; it < 16; it++) yo[(long)(kq + 16 * it) * T_stride] = zf[it * 17 + kq];
-      if (kq == 0) yo[(long)A_NF * T_stride] = zf[16 * 17];
+      if (kq == 0) yo[(long)A_NF * T_stride] = reinterpret_cast<const float2*>(wq)[f];
     }
   }
 }
 
-// W [Sw][K][N] -> Wq [Sw][N][257] float4 (see analysis512_bfz_kernel)
+// Third form: wave-specialised.  The per-channel work has an LDS-heavy half (stage the PCM span, polyphase window ->
+// 16 frames) and a VALU-heavy half (256-point FFTs + the beamformer sum); with every wavefront doing both in lockstep
+// the two halves never overlap and both the LDS and the VALUs sit idle two thirds of the time.  Here a 512-thread
+// workgroup splits the roles: waves 0-3 (producers) stage channel n+2 and run the polyphase of channel n+1 into one of
+// two frame buffers while waves 4-7 (consumers, one per SIMD, 4 frames each) transform channel n and accumulate A / B'.
+// Two workgroup barriers per channel:
+//   B1(n): span(n+1) staged, frames(n) written            | consumers are done with frames(n-1) and weights(n-1)
+//   B2(n): every window read of span(n+1) has returned    -> the producers may overwrite the span with channel n+2
+// LDS: span | frames[2][16][272] | weight pairs[3][WSTR]  (R = 2: 23.0 + 68.0 + 12.0 KB; one workgroup per CU).
+constexpr int W_NT = 512;
+
+template <int R>
+__global__ __launch_bounds__(W_NT, 1)
+void analysis512_bfw_kernel(const float* __restrict__ pcm, long nsamples, long pcm_stride,
+                            const float* __restrict__ proto, const float2* __restrict__ twg,
+                            int laN, float gain, int N, int K, const float4* __restrict__ Wq, long w_stream_stride,
+                            float2* __restrict__ Y, long T_stride, long t0, long tcount, int ntiles, int tiles_per_xcd, int S)
+{
+  constexpr int D = A_M / R;
+  constexpr int SPAN = (A_TT - 1) * D + A_MT * A_M;
+  constexpr int FRZ = 272;                                                    // 16 (mod 32) float2, see analysis512_bfz_kernel
+  constexpr int FB_BYTES = A_TT * FRZ * 8;
+  constexpr int NV4 = (SPAN / 4 + 255) / 256;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* xs = reinterpret_cast<float*>(smem);
+  float2* fbuf = reinterpret_cast<float2*>(smem + SPAN * 4);                  // [2][16][FRZ]
+  float4* wq = reinterpret_cast<float4*>(smem + SPAN * 4 + 2 * FB_BYTES);     // [3][WSTR]
+
+  const int tid = threadIdx.x;
+  const int b = blockIdx.x;
+  const int xcd = b & 7, j0 = b >> 3;
+  const int s = j0 / tiles_per_xcd;
+  const int tile = xcd * tiles_per_xcd + j0 % tiles_per_xcd;
+  if (s >= S || tile >= ntiles) return;
+  const long tt0 = (long)tile * A_TT;
+
+  // consumer state lives outside the role branch: the epilogue needs it
+  const int ct = tid & 255, lane = ct & 63, cw = ct >> 6, fl = lane >> 4, j = lane & 15;
+  f2 accA[16], accB[16];
+#pragma unroll
+  for (int k2 = 0; k2 < 16; k2++) { accA[k2] = f2{0.f, 0.f}; accB[k2] = f2{0.f, 0.f}; }
+  float2 acc256 = make_float2(0.f, 0.f);
+
+  if (tid < 256) {
+    // ------------------------------------------------------------ producers
+    const bool vec_ok = ((pcm_stride & 3) == 0) && ((reinterpret_cast<uintptr_t>(pcm) & 15) == 0);
+    const long g0 = (t0 + tt0 + laN + 1) * (long)D - (long)A_MT * A_M;
+    const bool inb = vec_ok && g0 >= 0 && g0 + SPAN <= nsamples;
+    const float4* wts = Wq + (long)s * w_stream_stride;
+    float4 pre[NV4];
+    float4 wpre;
+    float2 w256pre;
+    auto fetch = [&](int n) {
+      const float* src = pcm + ((long)s * N + n) * pcm_stride;
+      if (inb) {
+#pragma unroll
+        for (int q = 0; q < NV4; q++) {
+          const int l = (tid + q * 256) * 4;
+          if (l < SPAN) pre[q] = *reinterpret_cast<const float4*>(src + g0 + l);
+        }
+      } else {
+#pragma unroll
+        for (int q = 0; q < NV4; q++) {
+          const int l = (tid + q * 256) * 4;
+          float v[4];
+#pragma unroll
+          for (int e = 0; e < 4; e++) {
+            const long g = g0 + l + e;
+            v[e] = (l + e < SPAN && g >= 0 && g < nsamples) ? src[g] : 0.0f;
+          }
+          pre[q] = make_float4(v[0], v[1], v[2], v[3]);
+        }
+      }
+      wpre = wts[(long)n * WSTR + tid];
+      const float4 t = wts[(long)n * WSTR + 256];
+      w256pre = make_float2(t.x, t.y);
+    };
+    auto stage = [&](int slot) {
+#pragma unroll
+      for (int q = 0; q < NV4; q++) {
+        const int l = (tid + q * 256) * 4;
+        if (l < SPAN) *reinterpret_cast<float4*>(xs + l) = pre[q];
+      }
+      wq[slot * WSTR + tid] = wpre;
+      if (tid == 0) wq[slot * WSTR + 256] = make_float4(w256pre.x, w256pre.y, 0.f, 0.f);
+    };
+    // polyphase mapping as in analysis512_bfz_kernel: G pair indices (n0 + q NPG) x FPT frames per thread
+    constexpr int G = (R >= 2) ? 2 : 1;
+    constexpr int NPG = 256 / G, FPT = A_TT / G, CG = R / G;
+    constexpr int NWG = FPT + (A_MT - 1) * R + (G - 1) * CG;
+    const int n0 = tid % NPG, fg = tid / NPG;
+    float2 h[G][A_MT];
+#pragma unroll
+    for (int q = 0; q < G; q++)
+#pragma unroll
+      for (int k = 0; k < A_MT; k++) h[q][k] = *reinterpret_cast<const float2*>(proto + 2 * (n0 + q * NPG) + A_M * k);
+    auto poly = [&](int buf) {
+      float2* fbo = fbuf + buf * (A_TT * FRZ);
+      float2 win[NWG];
+      const float* wbase = xs + (A_M - 2 - 2 * n0 - (G - 1) * (A_M / G)) + fg * FPT * D;
+#pragma unroll
+      for (int i = 0; i < NWG; i++) win[i] = *reinterpret_cast<const float2*>(wbase + i * D);
+      __builtin_amdgcn_sched_barrier(0);                 // window reads back to back: one LDS latency, not NWG
+#pragma unroll
+      for (int q = 0; q < G; q++) {
+        const int nn = n0 + q * NPG;
+        const int zoff = (nn >> 4) * 17 + (nn & 15);
+#pragma unroll
+        for (int g = 0; g < FPT; g++) {
+          float p0 = 0.f, p1 = 0.f;
+#pragma unroll
+          for (int k = 0; k < A_MT; k++) {
+            const float2 x = win[g + R * (A_MT - 1 - k) + (G - 1 - q) * CG];
+            p0 = fmaf(h[q][k].x, x.y, p0);
+            p1 = fmaf(h[q][k].y, x.x, p1);
+          }
+          fbo[(fg * FPT + g) * FRZ + zoff] = make_float2(p0, p1);
+        }
+      }
+    };
+
+    fetch(0);
+    stage(0);
+    if (N > 1) fetch(1);
+    __syncthreads();                                     // P0: span(0) staged
+    poly(0);
+    __syncthreads();                                     // P1: window reads of span(0) done, frames(0) written
+    if (N > 1) { stage(1); if (N > 2) fetch(2); }
+    int slot2 = 2;                                       // (n + 2) % 3
+    for (int n = 0; n < N; n++) {
+      __syncthreads();                                   // B1(n)
+      if (n + 1 < N) poly((n + 1) & 1);
+      __syncthreads();                                   // B2(n)
+      if (n + 2 < N) { stage(slot2); if (n + 3 < N) fetch(n + 3); }
+      slot2 = (slot2 == 2) ? 0 : slot2 + 1;
+    }
+  } else {
+    // ------------------------------------------------------------ consumers
+    f2 twr[15];                                                               // W_256^{j k1}, k1 = 1..15
+#pragma unroll
+    for (int k1 = 1; k1 < 16; k1++) { const float2 t = twg[(2 * j * k1) & 511]; twr[k1 - 1] = f2{t.x, t.y}; }
+    __syncthreads();                                     // P0
+    __syncthreads();                                     // P1
+    int slot = 0;                                        // n % 3
+    for (int n = 0; n < N; n++) {
+      __syncthreads();                                   // B1(n): frames(n) and weight pairs(n) are in LDS
+      f2 v[16];
+      f2* fb = reinterpret_cast<f2*>(fbuf) + (n & 1) * (A_TT * FRZ) + (cw * 4 + fl) * FRZ;
+      const f4* wl = reinterpret_cast<const f4*>(wq) + slot * WSTR + j;
+      f4 wg[2][4];
+#pragma unroll
+      for (int r = 0; r < 16; r++) v[r] = fb[r * 17 + j];
+      dft16q(v);
+#pragma unroll
+      for (int k1 = 1; k1 < 16; k1++) v[k1] = cmulv(v[k1], twr[k1 - 1]);
+#pragma unroll
+      for (int k1 = 0; k1 < 16; k1++) fb[j * 17 + k1] = v[k1];
+#pragma unroll
+      for (int jp = 0; jp < 16; jp++) v[jp] = fb[jp * 17 + j];
+#pragma unroll
+      for (int q = 0; q < 4; q++) wg[0][q] = wl[q * 16];
+      __syncthreads();                                   // B2(n)
+      dft16q(v);                                                        // v[k2] = Z[j + 16 k2]
+#pragma unroll
+      for (int g = 0; g < 4; g++) {
+        if (g < 3) {
+#pragma unroll
+          for (int q = 0; q < 4; q++) wg[(g + 1) & 1][q] = wl[((g + 1) * 4 + q) * 16];
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          const int k2 = g * 4 + q;
+          const f4 w4 = wg[g & 1][q];
+          acc_conjw_z(accA[k2], w4.xy, v[k2]);
+          acc_conjw_conjz(accB[k2], w4.zw, v[k2]);
+        }
+      }
+      const float r = v[0].x - v[0].y;                                  // bin 256 (lanes j == 0)
+      const float4 w256 = wq[slot * WSTR + 256];
+      acc256.x = fmaf(w256.x, r, acc256.x);
+      acc256.y = fmaf(-w256.y, r, acc256.y);
+      slot = (slot == 2) ? 0 : slot + 1;
+    }
+  }
+  __syncthreads();
+
+  // ---- once per tile (consumers): B[k] = B'[(256-k)&255] through the wave's own frames, Hermitian post-pass
+  if (tid >= 256) {
+    const float hg = 0.5f * gain;
+    float2* fb = fbuf + (cw * 4 + fl) * FRZ;
+#pragma unroll
+    for (int k2 = 0; k2 < 16; k2++) fb[k2 * 17 + j] = make_float2(accB[k2].x, accB[k2].y);
+    float2 yv[16];
+#pragma unroll
+    for (int k2 = 0; k2 < 16; k2++) {
+      const int k = j + 16 * k2;
+      const int kp = (A_NF - k) & 255;
+      const float2 Bk = fb[(kp >> 4) * 17 + (kp & 15)];
+      const float2 w = twg[k];
+      const float2 c1 = make_float2(1.f + w.y, -w.x), c2 = make_float2(1.f - w.y, w.x);
+      const float2 a = make_float2(accA[k2].x, accA[k2].y);
+      yv[k2] = make_float2(hg * ((c1.x * a.x - c1.y * a.y) + (c2.x * Bk.x - c2.y * Bk.y)),
+                           hg * ((c1.x * a.y + c1.y * a.x) + (c2.x * Bk.y + c2.y * Bk.x)));
+    }
+#pragma unroll
+    for (int k2 = 0; k2 < 16; k2++) fb[k2 * 17 + j] = yv[k2];
+    if (j == 0) reinterpret_cast<float2*>(wq)[cw * 4 + fl] = make_float2(gain * acc256.x, gain * acc256.y);   // weights are dead
+  }
+  __syncthreads();
+  // ---- transposed store Y[s][k][tt0 .. tt0+15] by all 512 threads (128-byte runs per bin)
+  {
+    const int f = tid & 15, kq = tid >> 4;               // kq < 32
+    if (tt0 + f < tcount) {
+      float2* yo = Y + (long)s * K * T_stride + tt0 + f;
+      const float2* zf = fbuf + f * FRZ;
+#pragma unroll
+      for (int it = 0; it < 8; it++) {
+        const int k = kq + 32 * it;
+        yo[(long)k * T_stride] = zf[(k >> 4) * 17 + (k & 15)];
+      }
+      if (kq == 0) yo[(long)A_NF * T_stride] = reinterpret_cast<const float2*>(wq)[f];
+    }
+  }
+}
+
+// W [Sw][K][N] -> Wq [Sw][N][WSTR] float4 (see analysis512_bfz_kernel)
 __global__ void pair_weights_kernel(const float2* __restrict__ W, float4* __restrict__ Wq, int K, int N, int Sw)
 {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= (long)Sw * N * 257) return;
-  const int e = (int)(i % 257);
-  const int n = (int)((i / 257) % N);
-  const long s = i / ((long)N * 257);
+  if (i >= (long)Sw * N * WSTR) return;
+  const int e = (int)(i % WSTR);
+  const int n = (int)((i / WSTR) % N);
+  const long s = i / ((long)N * WSTR);
   const float2* Ws = W + s * (long)K * N;
-  const float2 a = Ws[(long)e * N + n];
-  const float2 bq = (e < 256) ? Ws[(long)((256 - e) & 255) * N + n] : make_float2(0.f, 0.f);
-  Wq[i] = make_float4(a.x, a.y, bq.x, bq.y);
+  float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (e <= 256) {
+    const float2 a = Ws[(long)e * N + n];
+    const float2 bq = (e < 256) ? Ws[(long)((256 - e) & 255) * N + n] : make_float2(0.f, 0.f);
+    o = make_float4(a.x, a.y, bq.x, bq.y);
+  }
+  Wq[i] = o;
 }
 
 // W [Sw][K][N] -> Wt [Sw][N][K]
@@ -729,6 +1028,13 @@ __global__ void transpose_weights_kernel(const float2* __restrict__ W, float2* _
   const int k = (int)((i / N) % K);
   const long s = i / ((long)N * K);
   Wt[(s * N + n) * K + k] = W[i];
+}
+
+// diagnostics: BTK_FUSED_FORM = 1 -> single-role workgroups (analysis512_bfz_kernel), default 2 -> wave-specialised
+static int fused_form()
+{
+  static const int f = getenv("BTK_FUSED_FORM") ? atoi(getenv("BTK_FUSED_FORM")) : 1;
+  return f;
 }
 
 template <int R>
@@ -759,19 +1065,36 @@ int launch512_bf(const btk_fb* fb, const float* pcm, long nsamples, long pcm_str
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)nblocks), dim3(A_NT), lds, st, pcm, nsamples, pcm_stride, fb->d_proto, fb->d_tw,
                        fb->laN, gain, N, K, Wt, per_stream ? (long)N * K : 0L, Y, T_stride, t0, tcount, ntiles, tiles_per_xcd, S);
+  } else if (fused_form() == 2) {
+    float4* Wq = static_cast<float4*>(scratch);
+    const size_t lds = (size_t)SPAN * 4 + 2 * (A_TT * 272 * 8) + sizeof(float4) * WSTR * 3;
+    const long nw = (long)Sw * N * WSTR;
+    hipLaunchKernelGGL(pair_weights_kernel, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, st, W, Wq, K, N, Sw);
+    auto kern = analysis512_bfw_kernel<R>;
+    static bool attr_set = false;
+    if (!attr_set) {
+      BTK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblocks), dim3(W_NT), lds, st, pcm, nsamples, pcm_stride, fb->d_proto, fb->d_tw,
+                       fb->laN, gain, N, K, Wq, per_stream ? (long)N * WSTR : 0L, Y, T_stride, t0, tcount, ntiles, tiles_per_xcd, S);
   } else {
     float4* Wq = static_cast<float4*>(scratch);
-    const size_t lds = REG_U + sizeof(float4) * 256;
-    const long nw = (long)Sw * N * 257;
+    static const int var = getenv("BTK_FUSED_VAR") ? atoi(getenv("BTK_FUSED_VAR")) : 1;
+    const bool pipe = (var & 2) && R >= 2;
+    const int fbz = A_TT * 272 * 8;
+    const int regz = SPAN * 4 > fbz ? SPAN * 4 : fbz;
+    const size_t lds = pipe ? (size_t)SPAN * 4 + fbz + sizeof(float4) * WSTR * 2 : (size_t)regz + sizeof(float4) * WSTR;
+    const long nw = (long)Sw * N * WSTR;
     hipLaunchKernelGGL(pair_weights_kernel, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, st, W, Wq, K, N, Sw);
-    auto kern = analysis512_bfz_kernel<R>;
+    auto kern = var == 3 ? analysis512_bfz_kernel<R, 3> : analysis512_bfz_kernel<R, 1>;
     static bool attr_set = false;
     if (!attr_set) {
       BTK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       attr_set = true;
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)nblocks), dim3(A_NT), lds, st, pcm, nsamples, pcm_stride, fb->d_proto, fb->d_tw,
-                       fb->laN, gain, N, K, Wq, per_stream ? (long)N * 257 : 0L, Y, T_stride, t0, tcount, ntiles, tiles_per_xcd, S);
+                       fb->laN, gain, N, K, Wq, per_stream ? (long)N * WSTR : 0L, Y, T_stride, t0, tcount, ntiles, tiles_per_xcd, S);
   }
   BTK_HIP_CHECK(hipGetLastError());
   return BTK_OK;

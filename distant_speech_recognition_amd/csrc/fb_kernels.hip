@@ -414,8 +414,8 @@ int btk_fb_analysis_bf(const btk_fb_t* fb, const float* pcm, long nsamples, long
   if (S <= 0 || N <= 0 || tcount < 0 || T_stride < tcount || pcm_stride < nsamples)
     return btk_set_error(BTK_ERR_DIMENSION, "btk_fb_analysis_bf: bad sizes S=%d N=%d tcount=%ld T_stride=%ld", S, N, tcount, T_stride);
   if (tcount == 0) return BTK_OK;
-  // fused geometries stage the weight pairs [Sw][N][257] float4 (fb_analysis512.hip); the staged fall-back checks its own size below
-  const long wt_bytes = (fb->M == 512 && fb->m == 4) ? (long)sizeof(float4) * (per_stream_weights ? S : 1) * 257 * N : 0;
+  // fused geometries stage the weight pairs [Sw][N][320] float4 (fb_analysis512.hip); the staged fall-back checks its own size below
+  const long wt_bytes = (fb->M == 512 && fb->m == 4) ? (long)sizeof(float4) * (per_stream_weights ? S : 1) * 320 * N : 0;
   if (scratch_bytes < wt_bytes) return btk_set_error(BTK_ERR_PARAMETER, "btk_fb_analysis_bf: scratch too small (%ld < %ld)", scratch_bytes, wt_bytes);
   hipStream_t st = as_stream(stream);
   static const bool nofuse = getenv("BTK_DISABLE_FUSED") != nullptr;
@@ -437,7 +437,7 @@ long btk_fb_analysis_bf_scratch_bytes(const btk_fb_t* fb, int S, int N, int per_
 {
   if (!fb) return -1;
   const bool fused = fb->M == 512 && fb->m == 4 && (fb->R == 1 || fb->R == 2 || fb->R == 4) && getenv("BTK_DISABLE_FUSED") == nullptr;
-  if (fused) return (long)sizeof(float4) * (per_stream_weights ? S : 1) * 257 * N;      // weight pairs, see fb_analysis512.hip
+  if (fused) return (long)sizeof(float4) * (per_stream_weights ? S : 1) * 320 * N;      // weight pairs [Sw][N][320], see fb_analysis512.hip
   return (long)sizeof(float2) * S * fb->K * N * tcount;
 }
 
