@@ -199,9 +199,15 @@ void analysis512_kernel(const float* __restrict__ pcm, long nsamples, long pcm_s
     }
   };
 
-  float2 h[A_MT];                                                             // prototype taps of pair index n = tid
+  constexpr int G = (R >= 2) ? 2 : 1;
+  constexpr int NPG = 256 / G, FPT = A_TT / G, CG = R / G;
+  constexpr int NWG = FPT + (A_MT - 1) * R + (G - 1) * CG;
+  const int n0 = tid % NPG, fg = tid / NPG;
+  float2 h[G][A_MT];                                                          // prototype taps of the pair indices n0 + q NPG
 #pragma unroll
-  for (int k = 0; k < A_MT; k++) h[k] = *reinterpret_cast<const float2*>(proto + 2 * tid + A_M * k);
+  for (int q = 0; q < G; q++)
+#pragma unroll
+    for (int k = 0; k < A_MT; k++) h[q][k] = *reinterpret_cast<const float2*>(proto + 2 * (n0 + q * NPG) + A_M * k);
   const int s = chan / N, nch = chan % N;
   const long kstride = (long)N * T_stride;
   const float hg = 0.5f * gain;
@@ -218,29 +224,35 @@ void analysis512_kernel(const float* __restrict__ pcm, long nsamples, long pcm_s
     __syncthreads();
     if (tile + 1 < tile_end) fetch(tile + 1);
 
-    // ---- phase 2: polyphase with a sliding register window; thread owns pair index n = tid.
-    //      The window is pulled into registers first: after the barrier the span is dead and the
-    //      FFT frames may overwrite it.
+    // ---- phase 2: polyphase with a sliding register window.  With D = M / R the windows of the pair indices n and
+    //      n + D/2 are the same LDS words shifted by one frame, so a thread takes G = 2 such indices (n0, n0 + 128)
+    //      for half of the tile's frames and reads every word once:
+    //      V[i] = xs[(M - 2 - 2 n0 - (G-1) 512/G) + (f0 + i) D]; index n0 + q NPG, frame f0 + g, tap k uses
+    //      V[g + R (m-1-k) + (G-1-q) CG]  (= xs[f D + m M - 2 - 2 n - M k], modulated.cc:380-392).
+    //      The window is pulled into registers first: after the barrier the span is dead and the FFT frames may
+    //      overwrite it.
     {
-      const int n = tid;
-      constexpr int NW = A_TT + (A_MT - 1) * R;
-      float2 win[NW];
-      const float* wbase = xs + (A_M - 2 - 2 * n);
+      float2 win[NWG];
+      const float* wbase = xs + (A_M - 2 - 2 * n0 - (G - 1) * (A_M / G)) + fg * FPT * D;
 #pragma unroll
-      for (int i = 0; i < NW; i++) win[i] = *reinterpret_cast<const float2*>(wbase + i * D);
+      for (int i = 0; i < NWG; i++) win[i] = *reinterpret_cast<const float2*>(wbase + i * D);
       __syncthreads();
-      const int zoff = (n >> 4) * 17 + (n & 15);
       if (ablate != 2) {
 #pragma unroll
-        for (int f = 0; f < A_TT; f++) {
-          float p0 = 0.f, p1 = 0.f;
+        for (int q = 0; q < G; q++) {
+          const int nn = n0 + q * NPG;
+          const int zoff = (nn >> 4) * 17 + (nn & 15);
 #pragma unroll
-          for (int k = 0; k < A_MT; k++) {
-            const float2 x = win[f + R * (A_MT - 1 - k)];      // xs[f D + m M - 2 - 2n - M k]
-            p0 = fmaf(h[k].x, x.y, p0);
-            p1 = fmaf(h[k].y, x.x, p1);
+          for (int g = 0; g < FPT; g++) {
+            float p0 = 0.f, p1 = 0.f;
+#pragma unroll
+            for (int k = 0; k < A_MT; k++) {
+              const float2 x = win[g + R * (A_MT - 1 - k) + (G - 1 - q) * CG];
+              p0 = fmaf(h[q][k].x, x.y, p0);
+              p1 = fmaf(h[q][k].y, x.x, p1);
+            }
+            fbuf[(fg * FPT + g) * FRS + zoff] = make_float2(p0, p1);      // frame f -> wave f/4, slot f%4
           }
-          fbuf[f * FRS + zoff] = make_float2(p0, p1);          // frame f -> wave f/4, slot f%4
         }
       }
     }
@@ -249,19 +261,20 @@ void analysis512_kernel(const float* __restrict__ pcm, long nsamples, long pcm_s
     // ---- phase 3: wave-private 256-point FFT of 4 frames (no workgroup barrier inside)
     if (ablate != 2) {
       const int fl = lane >> 4, j = lane & 15;
-      float2* fb = fbuf + (wave * 4 + fl) * FRS;
-      float2 v[16];
+      f2* fb = reinterpret_cast<f2*>(fbuf) + (wave * 4 + fl) * FRS;
+      const f2* twq = reinterpret_cast<const f2*>(twj);
+      f2 v[16];
 #pragma unroll
       for (int r = 0; r < 16; r++) v[r] = fb[r * 17 + j];              // x[16 r + j]
-      dft16p(v);                                                      // A[j][k1]
+      dft16q(v);                                                      // A[j][k1]
 #pragma unroll
-      for (int k1 = 1; k1 < 16; k1++) v[k1] = cmulf(v[k1], twj[k1 * 16 + j]);
+      for (int k1 = 1; k1 < 16; k1++) v[k1] = cmulv(v[k1], twq[k1 * 16 + j]);
 #pragma unroll
       for (int k1 = 0; k1 < 16; k1++) fb[j * 17 + k1] = v[k1];         // row j
       // lane now plays k1 = j: column k1 over rows j'
 #pragma unroll
       for (int jp = 0; jp < 16; jp++) v[jp] = fb[jp * 17 + j];
-      dft16p(v);                                                      // Z[k1 + 16 k2]
+      dft16q(v);                                                      // Z[k1 + 16 k2]
 #pragma unroll
       for (int k2 = 0; k2 < 16; k2++) fb[k2 * 17 + j] = v[k2];         // natural order: idx(k) = (k>>4)*17 + (k&15)
     }
@@ -328,194 +341,11 @@ int launch512(const btk_fb* fb, const float* pcm, long nsamples, long pcm_stride
 // Fused analysis -> fixed-weight beamformer (SubbandDS/GSC/MVDR::next over OverSampledDFTAnalysisBank
 // channels, reference beamformer.cc:1267-1311 + modulated.cc:375-409) for static weights.
 // One workgroup = one (stream, 16-frame tile); it walks over the N channels, computes each channel's
-// spectrum exactly as analysis512_kernel does and accumulates y_k[t] += conj(w_k[n]) X_n[k][t] in
+// 256-point complex FFT exactly as analysis512_kernel does and accumulates the beamformer sum in
 // registers.  The N x K snapshot block never goes to HBM: traffic drops from N(4D+8K)+8K(N+1) to
-// 4 D N + 8 K bytes per frame.  Wt is the weight matrix transposed to [Sw][N][K] (one contiguous
-// column of 257 weights per channel).
-template <int R>
-__global__ __launch_bounds__(A_NT, 2)
-void analysis512_bf_kernel(const float* __restrict__ pcm, long nsamples, long pcm_stride,
-                           const float* __restrict__ proto, const float2* __restrict__ twg,
-                           int laN, float gain, int N, int K, const float2* __restrict__ Wt, long w_stream_stride,
-                           float2* __restrict__ Y, long T_stride, long t0, long tcount, int ntiles, int tiles_per_xcd, int S)
-{
-  constexpr int D = A_M / R;
-  constexpr int SPAN = (A_TT - 1) * D + A_MT * A_M;
-  constexpr int FB_BYTES = A_TT * FRS * 8;
-  constexpr int REG_U = (SPAN * 4 > FB_BYTES) ? SPAN * 4 : FB_BYTES;
-  constexpr int NV4 = (SPAN / 4 + A_NT - 1) / A_NT;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  float* xs = reinterpret_cast<float*>(smem);
-  float2* fbuf = reinterpret_cast<float2*>(smem);
-  float2* tw = reinterpret_cast<float2*>(smem + REG_U);                       // [257]
-  float2* twj = tw + (A_NF + 1);                                              // [256]
-  float2* wcol = twj + 256;                                                   // [257] weights of the current channel
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  // XCD-aware mapping: each XCD owns a contiguous range of tiles of every stream, so neighbouring tiles
-  // (which share m M - D samples of PCM per channel) hit the same L2
-  const int b = blockIdx.x;
-  const int xcd = b & 7, j0 = b >> 3;
-  const int s = j0 / tiles_per_xcd;
-  const int tile = xcd * tiles_per_xcd + j0 % tiles_per_xcd;
-  if (s >= S || tile >= ntiles) return;
-  const long tt0 = (long)tile * A_TT;
-
-  for (int j = tid; j <= A_NF; j += A_NT) tw[j] = twg[j];
-  twj[tid] = twg[(2 * (tid & 15) * (tid >> 4)) & 511];
-
-  const bool vec_ok = ((pcm_stride & 3) == 0) && ((reinterpret_cast<uintptr_t>(pcm) & 15) == 0);
-  const long g0 = (t0 + tt0 + laN + 1) * (long)D - (long)A_MT * A_M;
-  const bool inb = vec_ok && g0 >= 0 && g0 + SPAN <= nsamples;
-  const float2* wts = Wt + (long)s * w_stream_stride;
-  float4 pre[NV4];
-  float2 wpre0, wpre1;
-  auto fetch = [&](int n) {
-    const float* src = pcm + ((long)s * N + n) * pcm_stride;
-    if (inb) {
-#pragma unroll
-      for (int q = 0; q < NV4; q++) {
-        const int l = (tid + q * A_NT) * 4;
-        if (l < SPAN) pre[q] = *reinterpret_cast<const float4*>(src + g0 + l);
-      }
-    } else {
-#pragma unroll
-      for (int q = 0; q < NV4; q++) {
-        const int l = (tid + q * A_NT) * 4;
-        float v[4];
-#pragma unroll
-        for (int e = 0; e < 4; e++) {
-          const long g = g0 + l + e;
-          v[e] = (l + e < SPAN && g >= 0 && g < nsamples) ? src[g] : 0.0f;
-        }
-        pre[q] = make_float4(v[0], v[1], v[2], v[3]);
-      }
-    }
-    wpre0 = wts[(long)n * K + tid];
-    wpre1 = (tid == 0) ? wts[(long)n * K + A_NF] : make_float2(0.f, 0.f);
-  };
-
-  float2 h[A_MT];
-#pragma unroll
-  for (int k = 0; k < A_MT; k++) h[k] = *reinterpret_cast<const float2*>(proto + 2 * tid + A_M * k);
-  const float hg = 0.5f * gain;
-  // thread (kq = tid>>4, f = tid&15) owns the bin pairs (k, 256-k), k = kq + 16 it, it < 8, of frame f;
-  // the pair shares Z[k], Z[256-k], E and W^k O.  Bin 128 (its own partner) goes to the kq == 0 threads.
-  float2 accA[8], accB[8];
-#pragma unroll
-  for (int it = 0; it < 8; it++) { accA[it] = make_float2(0.f, 0.f); accB[it] = make_float2(0.f, 0.f); }
-  float2 acc128 = make_float2(0.f, 0.f);
-
-  fetch(0);
-  for (int n = 0; n < N; n++) {
-    // ---- phase 1: registers -> LDS (PCM span + weight column), then prefetch the next channel
-#pragma unroll
-    for (int q = 0; q < NV4; q++) {
-      const int l = (tid + q * A_NT) * 4;
-      if (l < SPAN) *reinterpret_cast<float4*>(xs + l) = pre[q];
-    }
-    wcol[tid] = wpre0;
-    if (tid == 0) wcol[A_NF] = wpre1;
-    __syncthreads();
-
-    // ---- phase 2: polyphase (sliding register window), frames overwrite the span after the barrier
-    {
-      constexpr int NW = A_TT + (A_MT - 1) * R;
-      float2 win[NW];
-      const float* wbase = xs + (A_M - 2 - 2 * tid);
-#pragma unroll
-      for (int i = 0; i < NW; i++) win[i] = *reinterpret_cast<const float2*>(wbase + i * D);
-      __syncthreads();
-      const int zoff = (tid >> 4) * 17 + (tid & 15);
-#pragma unroll
-      for (int f = 0; f < A_TT; f++) {
-        float p0 = 0.f, p1 = 0.f;
-#pragma unroll
-        for (int k = 0; k < A_MT; k++) {
-          const float2 x = win[f + R * (A_MT - 1 - k)];
-          p0 = fmaf(h[k].x, x.y, p0);
-          p1 = fmaf(h[k].y, x.x, p1);
-        }
-        fbuf[f * FRS + zoff] = make_float2(p0, p1);
-      }
-    }
-    __syncthreads();
-    if (n + 1 < N) fetch(n + 1);          // issued once the window registers are dead; lands under phases 3-4
-
-    // ---- phase 3: wave-private 256-point FFT of 4 frames
-    {
-      const int fl = lane >> 4, j = lane & 15;
-      float2* fb = fbuf + (wave * 4 + fl) * FRS;
-      float2 v[16];
-#pragma unroll
-      for (int r = 0; r < 16; r++) v[r] = fb[r * 17 + j];
-      dft16p(v);
-#pragma unroll
-      for (int k1 = 1; k1 < 16; k1++) v[k1] = cmulf(v[k1], twj[k1 * 16 + j]);
-#pragma unroll
-      for (int k1 = 0; k1 < 16; k1++) fb[j * 17 + k1] = v[k1];
-#pragma unroll
-      for (int jp = 0; jp < 16; jp++) v[jp] = fb[jp * 17 + j];
-      dft16p(v);
-#pragma unroll
-      for (int k2 = 0; k2 < 16; k2++) fb[k2 * 17 + j] = v[k2];
-    }
-    __syncthreads();
-
-    // ---- phase 4: Hermitian post-pass + beamformer accumulation  y += conj(w) X, two bins per pass:
-    //      X[k] = E + W^k O,  X[256-k] = conj(E - W^k O)
-    {
-      const int f = tid & 15, kq = tid >> 4;
-      const float2* zf = fbuf + f * FRS;
-#pragma unroll
-      for (int it = 0; it < 8; it++) {
-        const int k = kq + 16 * it;
-        const int kp = (A_NF - k) & 255;
-        const float2 zk = zf[it * 17 + kq];
-        const float2 zq = zf[(kp >> 4) * 17 + (kp & 15)];
-        const float2 e = make_float2(hg * (zk.x + zq.x), hg * (zk.y - zq.y));
-        const float2 o = make_float2(hg * (zk.y + zq.y), -hg * (zk.x - zq.x));
-        const float2 w = tw[k];
-        const float2 wo = make_float2(w.x * o.x - w.y * o.y, w.x * o.y + w.y * o.x);
-        const float xr = e.x + wo.x, xi = e.y + wo.y;                  // X[k]
-        const float yr = e.x - wo.x, yi = -(e.y - wo.y);               // X[256-k]
-        const float2 wa = wcol[k], wb = wcol[A_NF - k];
-        accA[it].x = fmaf(wa.x, xr, fmaf(wa.y, xi, accA[it].x));
-        accA[it].y = fmaf(wa.x, xi, fmaf(-wa.y, xr, accA[it].y));
-        accB[it].x = fmaf(wb.x, yr, fmaf(wb.y, yi, accB[it].x));
-        accB[it].y = fmaf(wb.x, yi, fmaf(-wb.y, yr, accB[it].y));
-      }
-      if (kq == 0) {                                                   // k = 128 pairs with itself
-        const float2 zk = zf[8 * 17];
-        const float2 e = make_float2(hg * (zk.x + zk.x), 0.f);
-        const float2 o = make_float2(hg * (zk.y + zk.y), 0.f);
-        const float2 w = tw[128];
-        const float xr = e.x + w.x * o.x, xi = w.y * o.x;
-        const float2 wn = wcol[128];
-        acc128.x = fmaf(wn.x, xr, fmaf(wn.y, xi, acc128.x));
-        acc128.y = fmaf(wn.x, xi, fmaf(-wn.y, xr, acc128.y));
-      }
-    }
-    __syncthreads();
-  }
-
-  // ---- store Y[s][k][tt0 .. tt0+15]
-  {
-    const int f = tid & 15, kq = tid >> 4;
-    if (tt0 + f < tcount) {
-      float2* yo = Y + (long)s * K * T_stride + tt0 + f;
-#pragma unroll
-      for (int it = 0; it < 8; it++) {
-        const int k = kq + 16 * it;
-        yo[(long)k * T_stride] = accA[it];
-        yo[(long)(A_NF - k) * T_stride] = accB[it];
-      }
-      if (kq == 0) yo[(long)128 * T_stride] = acc128;
-    }
-  }
-}
-
-// Second form of the fused kernel: the beamformer sum is taken in the Z domain (Z = the 256-point complex FFT of the
+// 4 D N + 8 K bytes per frame.
+//
+// The beamformer sum is taken in the Z domain (Z = the 256-point complex FFT of the
 // packed real frame) and the Hermitian post-pass runs ONCE per tile instead of once per channel.  With
 //   X_n[k] = hg [(1 - j W^k) Z_n[k] + (1 + j W^k) conj Z_n[256-k]],   hg = gain / 2,  W = e^{+j 2 pi / 512},
 //   Y[k]   = sum_n conj(w_n[k]) X_n[k] = hg [(1 - j W^k) A[k] + (1 + j W^k) B[k]],
@@ -524,7 +354,7 @@ void analysis512_bf_kernel(const float* __restrict__ pcm, long nsamples, long pc
 // straight from its registers: no FFT result goes back to LDS, no cross-lane partner is needed per channel.
 // Wq [Sw][N][WSTR] float4: entry i < 256 = (w[i], w[(256-i) & 255]), entry 256 = (w[256], 0, 0), the rest 0.
 template <int R, int VAR>
-__global__ __launch_bounds__(A_NT, (VAR & 8) ? 3 : 2)
+__global__ __launch_bounds__(A_NT, 2)
 void analysis512_bfz_kernel(const float* __restrict__ pcm, long nsamples, long pcm_stride,
                             const float* __restrict__ proto, const float2* __restrict__ twg,
                             int laN, float gain, int N, int K, const float4* __restrict__ Wq, long w_stream_stride,
@@ -625,21 +455,22 @@ void analysis512_bfz_kernel(const float* __restrict__ pcm, long nsamples, long p
   // matching s_waitcnt vmcnt(0) sits before the barrier that opens channel n.  Edge tiles (span not inside the
   // recording, or unaligned) go through registers synchronously.
   const unsigned xs_lds = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;   // LDS byte offset of the dynamic region
-  auto glds16 = [&](const void* gsrc, unsigned lds_dst) {
+  auto glds16s = [&](const void* gbase, unsigned voff, unsigned lds_dst) {       // uniform base (SGPR pair) + 32-bit lane offset
     unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(gbase), "s"(lds_dst) : "memory");
   };
   auto dma = [&](int n) {
     if (inb) {
       const float* src = pcm + ((long)s * N + n) * pcm_stride + g0;
       constexpr int NCH = (SPAN * 4 + 1023) / 1024;
+      constexpr int NI = (NCH + 3) / 4;
 #pragma unroll
-      for (int i = 0; i < (NCH + 3) / 4; i++) {
+      for (int i = 0; i < NI; i++) {
         const int c = __builtin_amdgcn_readfirstlane(wave + 4 * i);
         if (c < NCH) {
           const int l = c * 256 + lane * 4;
-          if (l < SPAN) glds16(src + l, xs_lds + c * 1024);
+          if (l < SPAN) glds16s(src, (unsigned)l * 4u, xs_lds + c * 1024);
         }
       }
       const float4* wsrc = wts + (long)n * WSTR;
@@ -647,7 +478,7 @@ void analysis512_bfz_kernel(const float* __restrict__ pcm, long nsamples, long p
 #pragma unroll
       for (int i = 0; i < 2; i++) {
         const int c = __builtin_amdgcn_readfirstlane(wave + 4 * i);
-        if (c < WSTR / 64) glds16(wsrc + c * 64 + lane, wq_lds + c * 1024);
+        if (c < WSTR / 64) glds16s(wsrc, (unsigned)(c * 64 + lane) * 16u, wq_lds + c * 1024);
       }
     } else {
       fetch(n);
@@ -776,231 +607,6 @@ void analysis512_bfz_kernel(const float* __restrict__ pcm, long nsamples, long p
   }
 }
 
-// Third form: wave-specialised.  The per-channel work has an LDS-heavy half (stage the PCM span, polyphase window ->
-// 16 frames) and a VALU-heavy half (256-point FFTs + the beamformer sum); with every wavefront doing both in lockstep
-// the two halves never overlap and both the LDS and the VALUs sit idle two thirds of the time.  Here a 512-thread
-// workgroup splits the roles: waves 0-3 (producers) stage channel n+2 and run the polyphase of channel n+1 into one of
-// two frame buffers while waves 4-7 (consumers, one per SIMD, 4 frames each) transform channel n and accumulate A / B'.
-// Two workgroup barriers per channel:
-//   B1(n): span(n+1) staged, frames(n) written            | consumers are done with frames(n-1) and weights(n-1)
-//   B2(n): every window read of span(n+1) has returned    -> the producers may overwrite the span with channel n+2
-// LDS: span | frames[2][16][272] | weight pairs[3][WSTR]  (R = 2: 23.0 + 68.0 + 12.0 KB; one workgroup per CU).
-constexpr int W_NT = 512;
-
-template <int R>
-__global__ __launch_bounds__(W_NT, 1)
-void analysis512_bfw_kernel(const float* __restrict__ pcm, long nsamples, long pcm_stride,
-                            const float* __restrict__ proto, const float2* __restrict__ twg,
-                            int laN, float gain, int N, int K, const float4* __restrict__ Wq, long w_stream_stride,
-                            float2* __restrict__ Y, long T_stride, long t0, long tcount, int ntiles, int tiles_per_xcd, int S)
-{
-  constexpr int D = A_M / R;
-  constexpr int SPAN = (A_TT - 1) * D + A_MT * A_M;
-  constexpr int FRZ = 272;                                                    // 16 (mod 32) float2, see analysis512_bfz_kernel
-  constexpr int FB_BYTES = A_TT * FRZ * 8;
-  constexpr int NV4 = (SPAN / 4 + 255) / 256;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  float* xs = reinterpret_cast<float*>(smem);
-  float2* fbuf = reinterpret_cast<float2*>(smem + SPAN * 4);                  // [2][16][FRZ]
-  float4* wq = reinterpret_cast<float4*>(smem + SPAN * 4 + 2 * FB_BYTES);     // [3][WSTR]
-
-  const int tid = threadIdx.x;
-  const int b = blockIdx.x;
-  const int xcd = b & 7, j0 = b >> 3;
-  const int s = j0 / tiles_per_xcd;
-  const int tile = xcd * tiles_per_xcd + j0 % tiles_per_xcd;
-  if (s >= S || tile >= ntiles) return;
-  const long tt0 = (long)tile * A_TT;
-
-  // consumer state lives outside the role branch: the epilogue needs it
-  const int ct = tid & 255, lane = ct & 63, cw = ct >> 6, fl = lane >> 4, j = lane & 15;
-  f2 accA[16], accB[16];
-#pragma unroll
-  for (int k2 = 0; k2 < 16; k2++) { accA[k2] = f2{0.f, 0.f}; accB[k2] = f2{0.f, 0.f}; }
-  float2 acc256 = make_float2(0.f, 0.f);
-
-  if (tid < 256) {
-    // ------------------------------------------------------------ producers
-    const bool vec_ok = ((pcm_stride & 3) == 0) && ((reinterpret_cast<uintptr_t>(pcm) & 15) == 0);
-    const long g0 = (t0 + tt0 + laN + 1) * (long)D - (long)A_MT * A_M;
-    const bool inb = vec_ok && g0 >= 0 && g0 + SPAN <= nsamples;
-    const float4* wts = Wq + (long)s * w_stream_stride;
-    float4 pre[NV4];
-    float4 wpre;
-    float2 w256pre;
-    auto fetch = [&](int n) {
-      const float* src = pcm + ((long)s * N + n) * pcm_stride;
-      if (inb) {
-#pragma unroll
-        for (int q = 0; q < NV4; q++) {
-          const int l = (tid + q * 256) * 4;
-          if (l < SPAN) pre[q] = *reinterpret_cast<const float4*>(src + g0 + l);
-        }
-      } else {
-#pragma unroll
-        for (int q = 0; q < NV4; q++) {
-          const int l = (tid + q * 256) * 4;
-          float v[4];
-#pragma unroll
-          for (int e = 0; e < 4; e++) {
-            const long g = g0 + l + e;
-            v[e] = (l + e < SPAN && g >= 0 && g < nsamples) ? src[g] : 0.0f;
-          }
-          pre[q] = make_float4(v[0], v[1], v[2], v[3]);
-        }
-      }
-      wpre = wts[(long)n * WSTR + tid];
-      const float4 t = wts[(long)n * WSTR + 256];
-      w256pre = make_float2(t.x, t.y);
-    };
-    auto stage = [&](int slot) {
-#pragma unroll
-      for (int q = 0; q < NV4; q++) {
-        const int l = (tid + q * 256) * 4;
-        if (l < SPAN) *reinterpret_cast<float4*>(xs + l) = pre[q];
-      }
-      wq[slot * WSTR + tid] = wpre;
-      if (tid == 0) wq[slot * WSTR + 256] = make_float4(w256pre.x, w256pre.y, 0.f, 0.f);
-    };
-    // polyphase mapping as in analysis512_bfz_kernel: G pair indices (n0 + q NPG) x FPT frames per thread
-    constexpr int G = (R >= 2) ? 2 : 1;
-    constexpr int NPG = 256 / G, FPT = A_TT / G, CG = R / G;
-    constexpr int NWG = FPT + (A_MT - 1) * R + (G - 1) * CG;
-    const int n0 = tid % NPG, fg = tid / NPG;
-    float2 h[G][A_MT];
-#pragma unroll
-    for (int q = 0; q < G; q++)
-#pragma unroll
-      for (int k = 0; k < A_MT; k++) h[q][k] = *reinterpret_cast<const float2*>(proto + 2 * (n0 + q * NPG) + A_M * k);
-    auto poly = [&](int buf) {
-      float2* fbo = fbuf + buf * (A_TT * FRZ);
-      float2 win[NWG];
-      const float* wbase = xs + (A_M - 2 - 2 * n0 - (G - 1) * (A_M / G)) + fg * FPT * D;
-#pragma unroll
-      for (int i = 0; i < NWG; i++) win[i] = *reinterpret_cast<const float2*>(wbase + i * D);
-      __builtin_amdgcn_sched_barrier(0);                 // window reads back to back: one LDS latency, not NWG
-#pragma unroll
-      for (int q = 0; q < G; q++) {
-        const int nn = n0 + q * NPG;
-        const int zoff = (nn >> 4) * 17 + (nn & 15);
-#pragma unroll
-        for (int g = 0; g < FPT; g++) {
-          float p0 = 0.f, p1 = 0.f;
-#pragma unroll
-          for (int k = 0; k < A_MT; k++) {
-            const float2 x = win[g + R * (A_MT - 1 - k) + (G - 1 - q) * CG];
-            p0 = fmaf(h[q][k].x, x.y, p0);
-            p1 = fmaf(h[q][k].y, x.x, p1);
-          }
-          fbo[(fg * FPT + g) * FRZ + zoff] = make_float2(p0, p1);
-        }
-      }
-    };
-
-    fetch(0);
-    stage(0);
-    if (N > 1) fetch(1);
-    __syncthreads();                                     // P0: span(0) staged
-    poly(0);
-    __syncthreads();                                     // P1: window reads of span(0) done, frames(0) written
-    if (N > 1) { stage(1); if (N > 2) fetch(2); }
-    int slot2 = 2;                                       // (n + 2) % 3
-    for (int n = 0; n < N; n++) {
-      __syncthreads();                                   // B1(n)
-      if (n + 1 < N) poly((n + 1) & 1);
-      __syncthreads();                                   // B2(n)
-      if (n + 2 < N) { stage(slot2); if (n + 3 < N) fetch(n + 3); }
-      slot2 = (slot2 == 2) ? 0 : slot2 + 1;
-    }
-  } else {
-    // ------------------------------------------------------------ consumers
-    f2 twr[15];                                                               // W_256^{j k1}, k1 = 1..15
-#pragma unroll
-    for (int k1 = 1; k1 < 16; k1++) { const float2 t = twg[(2 * j * k1) & 511]; twr[k1 - 1] = f2{t.x, t.y}; }
-    __syncthreads();                                     // P0
-    __syncthreads();                                     // P1
-    int slot = 0;                                        // n % 3
-    for (int n = 0; n < N; n++) {
-      __syncthreads();                                   // B1(n): frames(n) and weight pairs(n) are in LDS
-      f2 v[16];
-      f2* fb = reinterpret_cast<f2*>(fbuf) + (n & 1) * (A_TT * FRZ) + (cw * 4 + fl) * FRZ;
-      const f4* wl = reinterpret_cast<const f4*>(wq) + slot * WSTR + j;
-      f4 wg[2][4];
-#pragma unroll
-      for (int r = 0; r < 16; r++) v[r] = fb[r * 17 + j];
-      dft16q(v);
-#pragma unroll
-      for (int k1 = 1; k1 < 16; k1++) v[k1] = cmulv(v[k1], twr[k1 - 1]);
-#pragma unroll
-      for (int k1 = 0; k1 < 16; k1++) fb[j * 17 + k1] = v[k1];
-#pragma unroll
-      for (int jp = 0; jp < 16; jp++) v[jp] = fb[jp * 17 + j];
-#pragma unroll
-      for (int q = 0; q < 4; q++) wg[0][q] = wl[q * 16];
-      __syncthreads();                                   // B2(n)
-      dft16q(v);                                                        // v[k2] = Z[j + 16 k2]
-#pragma unroll
-      for (int g = 0; g < 4; g++) {
-        if (g < 3) {
-#pragma unroll
-          for (int q = 0; q < 4; q++) wg[(g + 1) & 1][q] = wl[((g + 1) * 4 + q) * 16];
-        }
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-          const int k2 = g * 4 + q;
-          const f4 w4 = wg[g & 1][q];
-          acc_conjw_z(accA[k2], w4.xy, v[k2]);
-          acc_conjw_conjz(accB[k2], w4.zw, v[k2]);
-        }
-      }
-      const float r = v[0].x - v[0].y;                                  // bin 256 (lanes j == 0)
-      const float4 w256 = wq[slot * WSTR + 256];
-      acc256.x = fmaf(w256.x, r, acc256.x);
-      acc256.y = fmaf(-w256.y, r, acc256.y);
-      slot = (slot == 2) ? 0 : slot + 1;
-    }
-  }
-  __syncthreads();
-
-  // ---- once per tile (consumers): B[k] = B'[(256-k)&255] through the wave's own frames, Hermitian post-pass
-  if (tid >= 256) {
-    const float hg = 0.5f * gain;
-    float2* fb = fbuf + (cw * 4 + fl) * FRZ;
-#pragma unroll
-    for (int k2 = 0; k2 < 16; k2++) fb[k2 * 17 + j] = make_float2(accB[k2].x, accB[k2].y);
-    float2 yv[16];
-#pragma unroll
-    for (int k2 = 0; k2 < 16; k2++) {
-      const int k = j + 16 * k2;
-      const int kp = (A_NF - k) & 255;
-      const float2 Bk = fb[(kp >> 4) * 17 + (kp & 15)];
-      const float2 w = twg[k];
-      const float2 c1 = make_float2(1.f + w.y, -w.x), c2 = make_float2(1.f - w.y, w.x);
-      const float2 a = make_float2(accA[k2].x, accA[k2].y);
-      yv[k2] = make_float2(hg * ((c1.x * a.x - c1.y * a.y) + (c2.x * Bk.x - c2.y * Bk.y)),
-                           hg * ((c1.x * a.y + c1.y * a.x) + (c2.x * Bk.y + c2.y * Bk.x)));
-    }
-#pragma unroll
-    for (int k2 = 0; k2 < 16; k2++) fb[k2 * 17 + j] = yv[k2];
-    if (j == 0) reinterpret_cast<float2*>(wq)[cw * 4 + fl] = make_float2(gain * acc256.x, gain * acc256.y);   // weights are dead
-  }
-  __syncthreads();
-  // ---- transposed store Y[s][k][tt0 .. tt0+15] by all 512 threads (128-byte runs per bin)
-  {
-    const int f = tid & 15, kq = tid >> 4;               // kq < 32
-    if (tt0 + f < tcount) {
-      float2* yo = Y + (long)s * K * T_stride + tt0 + f;
-      const float2* zf = fbuf + f * FRZ;
-#pragma unroll
-      for (int it = 0; it < 8; it++) {
-        const int k = kq + 32 * it;
-        yo[(long)k * T_stride] = zf[(k >> 4) * 17 + (k & 15)];
-      }
-      if (kq == 0) yo[(long)A_NF * T_stride] = reinterpret_cast<const float2*>(wq)[f];
-    }
-  }
-}
-
 // W [Sw][K][N] -> Wq [Sw][N][WSTR] float4 (see analysis512_bfz_kernel)
 __global__ void pair_weights_kernel(const float2* __restrict__ W, float4* __restrict__ Wq, int K, int N, int Sw)
 {
@@ -1019,83 +625,36 @@ __global__ void pair_weights_kernel(const float2* __restrict__ W, float4* __rest
   Wq[i] = o;
 }
 
-// W [Sw][K][N] -> Wt [Sw][N][K]
-__global__ void transpose_weights_kernel(const float2* __restrict__ W, float2* __restrict__ Wt, int K, int N, int Sw)
-{
-  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= (long)Sw * K * N) return;
-  const int n = (int)(i % N);
-  const int k = (int)((i / N) % K);
-  const long s = i / ((long)N * K);
-  Wt[(s * N + n) * K + k] = W[i];
-}
-
-// diagnostics: BTK_FUSED_FORM = 1 -> single-role workgroups (analysis512_bfz_kernel), default 2 -> wave-specialised
-static int fused_form()
-{
-  static const int f = getenv("BTK_FUSED_FORM") ? atoi(getenv("BTK_FUSED_FORM")) : 1;
-  return f;
-}
-
 template <int R>
 int launch512_bf(const btk_fb* fb, const float* pcm, long nsamples, long pcm_stride, int S, int N, const float2* W,
                  int per_stream, void* scratch, float2* Y, long T_stride, long t0, long tcount, hipStream_t st)
 {
   constexpr int D = A_M / R;
   constexpr int SPAN = (A_TT - 1) * D + A_MT * A_M;
-  constexpr int FB_BYTES = A_TT * FRS * 8;
-  constexpr int REG_U = (SPAN * 4 > FB_BYTES) ? SPAN * 4 : FB_BYTES;
   const int K = fb->K;
   const int Sw = per_stream ? S : 1;
   const int ntiles = (int)((tcount + A_TT - 1) / A_TT);
   const int tiles_per_xcd = (ntiles + 7) / 8;
   const long nblocks = (long)8 * tiles_per_xcd * S;
   const float gain = fb->gain_factor > 0 ? (float)fb->gain_factor : 1.0f;
-  static const bool v1 = getenv("BTK_FUSED_V1") != nullptr;                   // diagnostics: per-channel post-pass form
-  if (v1) {
-    float2* Wt = static_cast<float2*>(scratch);
-    const size_t lds = REG_U + sizeof(float2) * (A_NF + 1 + 256 + A_NF + 1);
-    const long nw = (long)Sw * K * N;
-    hipLaunchKernelGGL(transpose_weights_kernel, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, st, W, Wt, K, N, Sw);
-    auto kern = analysis512_bf_kernel<R>;
-    static bool attr_set = false;
-    if (!attr_set) {
-      BTK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      attr_set = true;
-    }
-    hipLaunchKernelGGL(kern, dim3((unsigned)nblocks), dim3(A_NT), lds, st, pcm, nsamples, pcm_stride, fb->d_proto, fb->d_tw,
-                       fb->laN, gain, N, K, Wt, per_stream ? (long)N * K : 0L, Y, T_stride, t0, tcount, ntiles, tiles_per_xcd, S);
-  } else if (fused_form() == 2) {
-    float4* Wq = static_cast<float4*>(scratch);
-    const size_t lds = (size_t)SPAN * 4 + 2 * (A_TT * 272 * 8) + sizeof(float4) * WSTR * 3;
-    const long nw = (long)Sw * N * WSTR;
-    hipLaunchKernelGGL(pair_weights_kernel, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, st, W, Wq, K, N, Sw);
-    auto kern = analysis512_bfw_kernel<R>;
-    static bool attr_set = false;
-    if (!attr_set) {
-      BTK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      attr_set = true;
-    }
-    hipLaunchKernelGGL(kern, dim3((unsigned)nblocks), dim3(W_NT), lds, st, pcm, nsamples, pcm_stride, fb->d_proto, fb->d_tw,
-                       fb->laN, gain, N, K, Wq, per_stream ? (long)N * WSTR : 0L, Y, T_stride, t0, tcount, ntiles, tiles_per_xcd, S);
-  } else {
-    float4* Wq = static_cast<float4*>(scratch);
-    static const int var = getenv("BTK_FUSED_VAR") ? atoi(getenv("BTK_FUSED_VAR")) : 1;
-    const bool pipe = (var & 2) && R >= 2;
-    const int fbz = A_TT * 272 * 8;
-    const int regz = SPAN * 4 > fbz ? SPAN * 4 : fbz;
-    const size_t lds = pipe ? (size_t)SPAN * 4 + fbz + sizeof(float4) * WSTR * 2 : (size_t)regz + sizeof(float4) * WSTR;
-    const long nw = (long)Sw * N * WSTR;
-    hipLaunchKernelGGL(pair_weights_kernel, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, st, W, Wq, K, N, Sw);
-    auto kern = var == 3 ? analysis512_bfz_kernel<R, 3> : analysis512_bfz_kernel<R, 1>;
-    static bool attr_set = false;
-    if (!attr_set) {
-      BTK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      attr_set = true;
-    }
-    hipLaunchKernelGGL(kern, dim3((unsigned)nblocks), dim3(A_NT), lds, st, pcm, nsamples, pcm_stride, fb->d_proto, fb->d_tw,
-                       fb->laN, gain, N, K, Wq, per_stream ? (long)N * WSTR : 0L, Y, T_stride, t0, tcount, ntiles, tiles_per_xcd, S);
+  float4* Wq = static_cast<float4*>(scratch);
+  // BTK_FUSED_VAR = 1 (diagnostics): register staging with the span and the frames sharing one LDS region -- the only
+  // form for R = 1, whose 38 KB span leaves no room for a separate region; default 3: LDS-DMA staging
+  static const int var = getenv("BTK_FUSED_VAR") ? atoi(getenv("BTK_FUSED_VAR")) : 3;
+  const bool pipe = (var & 2) && R >= 2;
+  const int fbz = A_TT * 272 * 8;
+  const int regz = SPAN * 4 > fbz ? SPAN * 4 : fbz;
+  const size_t lds = pipe ? (size_t)SPAN * 4 + fbz + sizeof(float4) * WSTR * 2 : (size_t)regz + sizeof(float4) * WSTR;
+  const long nw = (long)Sw * N * WSTR;
+  hipLaunchKernelGGL(pair_weights_kernel, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, st, W, Wq, K, N, Sw);
+  auto kern = pipe ? analysis512_bfz_kernel<R, 3> : analysis512_bfz_kernel<R, 1>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    BTK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
   }
+  hipLaunchKernelGGL(kern, dim3((unsigned)nblocks), dim3(A_NT), lds, st, pcm, nsamples, pcm_stride, fb->d_proto, fb->d_tw,
+                     fb->laN, gain, N, K, Wq, per_stream ? (long)N * WSTR : 0L, Y, T_stride, t0, tcount, ntiles, tiles_per_xcd, S);
   BTK_HIP_CHECK(hipGetLastError());
   return BTK_OK;
 }
