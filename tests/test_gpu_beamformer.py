@@ -123,3 +123,33 @@ def test_fused_analysis_beamform_equals_staged(dev, N, r, S, L):
         assert got.shape == ref.shape
         scale = float(ref.abs().max())
         assert float((got - ref).abs().max()) <= 2e-6 * np.sqrt(N) * scale + 1e-6 * scale
+
+
+@pytest.mark.parametrize("N,r,S,T", [(6, 1, 3, 300), (4, 2, 2, 517), (64, 1, 2, 160)])
+def test_fused_interior_tiles_lds_dma_path(orc, dev, N, r, S, T):
+    """Aligned recordings long enough that most 16-frame tiles lie inside them: those take the LDS-DMA staging path of
+    the fused kernel (edge tiles go through registers).  Fused == staged on every frame, and both == the oracle on a
+    sample of frames from the middle of the recording."""
+    import torch
+    from distant_speech_recognition_amd import engine as eng
+    M, m = 512, 4
+    D, K = M >> r, M // 2 + 1
+    h = design_prototype(M, m)
+    fb = eng.FilterBank(h, M, m, r, 2)
+    L = (T - fb.processing_delay + fb.lookahead) * D
+    assert L % 4 == 0 and fb.num_frames(L) == T
+    pcm, _ = synthetic_pcm(S, N, L, seed=17 + N)
+    p = torch.from_numpy(pcm).to(dev)
+    rng = np.random.default_rng(N * 7 + r)
+    Wn = ((rng.normal(size=(S, K, N)) + 1j * rng.normal(size=(S, K, N))) / N).astype(np.complex64)
+    for W in (torch.from_numpy(Wn).to(dev), torch.from_numpy(Wn[1]).to(dev)):
+        ref = eng.bf_apply(W, fb.analysis(p))
+        got = fb.analysis_beamform(p, W)
+        scale = float(ref.abs().max())
+        assert float((got - ref).abs().max()) <= 2e-6 * np.sqrt(N) * scale + 1e-6 * scale
+    # oracle on frames 100..115 of stream 1 (an interior tile), shared weights Wn[1]
+    Xo = np.stack([orc.analysis(h, M, m, r, 2, pcm[1, n]) for n in range(N)], axis=1)      # [T][N][M]
+    t0 = 96
+    Yo = np.einsum("kn,tnk->kt", np.conj(Wn[1].astype(np.complex128)), Xo[t0:t0 + 16, :, :K])
+    g = got[1, :, t0:t0 + 16].cpu().numpy()
+    assert np.max(np.abs(g - Yo)) <= 4e-6 * np.sqrt(N) * np.max(np.abs(Yo))
