@@ -604,6 +604,29 @@ class SubbandMVDRGSCPtr(SubbandMVDRPtr):
             self._bfw[0].B[k] = engine.weights_blocking_matrix(self._wmvdr[k], 1)
         return True
 
+    def upgrade_blocking_matrix(self):
+        """B <- blocking matrix of the entire vector wq - wl, bins 1..M-1 (beamformer.cc:2674-2691)."""
+        if not self._bfw:
+            raise j_error("call calc_gsc_weights_x() once\n")
+        bw = self._bfw[0]
+        for k in range(1, self._fftlen):
+            bw.B[k] = engine.weights_blocking_matrix(bw.wq[k] - bw.wl[k], bw.NC)
+
+    def blocking_matrix_output(self, out_chan_no=0):
+        """b_i^H x of the current frame for bins 0..M/2 (beamformer.cc:2693-2717); like the reference it overwrites
+        those bins of the node's output vector and returns it."""
+        if not self._bfw:
+            raise j_error("call calc_gsc_weights_x() once\n")
+        bw = self._bfw[0]
+        snaps = self.snapshot_array()
+        if self._vector is None:
+            self._vector = np.zeros(self._fftlen, np.complex128)
+        for k in range(self._K):
+            self._vector[k] = np.vdot(bw.B[k][:, out_chan_no], snaps.snapshot(k))
+        return self._vector
+
+    upgradeBlockingMatrix, blockingMatrixOutput = upgrade_blocking_matrix, blocking_matrix_output
+
     def effective_weights(self):
         self._check_weights()
         if self._wmvdr is None:

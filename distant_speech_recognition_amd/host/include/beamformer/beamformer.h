@@ -168,3 +168,30 @@ class SubbandMVDR : public SubbandDS {
   gsl_vector_complex* wm_view_;
 };
 typedef Inherit<SubbandMVDR, SubbandDSPtr> SubbandMVDRPtr;
+
+// SubbandMVDRGSC (reference beamformer.h:385-437, beamformer.cc:2604-2773): MVDR quiescent vector + GSC lower branch.
+//   1. set_channel()  2. calc_array_manifold_vectors()  3. set_noise_spatial_spectral_matrix() / set_diffuse_noise_model()
+//   4. calc_mvdr_weights()  5. calc_blocking_matrix1() or calc_blocking_matrix2()  6. set_active_weights_f()
+// calc_blocking_matrix1/2 re-create the weight object like the reference's alloc_bfweight_ (active weights start over).
+class SubbandMVDRGSC : public SubbandMVDR {
+ public:
+  SubbandMVDRGSC(unsigned fftLen = 512, bool halfBandShift = false, const String& nm = "SubbandMVDR")
+      : SubbandMVDR(fftLen, halfBandShift, nm), normalize_weight_(false) {}
+  void normalize_weight(bool flag) { normalize_weight_ = flag; weights_version_++; }
+  void set_active_weights_f(unsigned fbinX, const gsl_vector* packedWeight);
+  void zero_active_weights();
+  bool calc_blocking_matrix1(float samplerate, const gsl_vector* delaysT);
+  bool calc_blocking_matrix2();
+  void upgrade_blocking_matrix();
+  const gsl_vector_complex* blocking_matrix_output(int outChanX = 0);
+  virtual void effective_weights(std::vector<float>& w);
+  void setActiveWeights_f(unsigned fbinX, const gsl_vector* packedWeight) { set_active_weights_f(fbinX, packedWeight); }
+  void zeroActiveWeights() { zero_active_weights(); }
+  bool calcBlockingMatrix1(float sampleRate, const gsl_vector* delaysT) { return calc_blocking_matrix1(sampleRate, delaysT); }
+  bool calcBlockingMatrix2() { return calc_blocking_matrix2(); }
+  void upgradeBlockingMatrix() { upgrade_blocking_matrix(); }
+  const gsl_vector_complex* blockingMatrixOutput(int outChanX = 0) { return blocking_matrix_output(outChanX); }
+ protected:
+  bool normalize_weight_;
+};
+typedef Inherit<SubbandMVDRGSC, SubbandMVDRPtr> SubbandMVDRGSCPtr;

@@ -558,7 +558,7 @@ void SubbandGSC::calc_gsc_weights(float samplerate, const gsl_vector* delaysT)
 void SubbandGSC::set_quiescent_weights_f(unsigned fbinX, const gsl_vector_complex* srcWq)
 {
   alloc_bfweight_(1);
-  memcpy(&bfweight_->wq[(size_t)fbinX * chanN()], srcWq->data, sizeof(double) * 2 * chanN());
+  memcpy(static_cast<void*>(&bfweight_->wq[(size_t)fbinX * chanN()]), srcWq->data, sizeof(double) * 2 * chanN());
   bfweight_->calcBlockingMatrix(fbinX);
 }
 
@@ -687,6 +687,86 @@ void SubbandMVDR::effective_weights(std::vector<float>& w)
   if (!bfweight_) throw j_error("call calc_array_manifold_vectorsX() once\n");
   if (!have_mvdr_) throw j_error("call calc_mvdr_weights() once\n");
   w = wmvdr_;
+}
+
+// ================================================================================ SubbandMVDRGSC
+void SubbandMVDRGSC::set_active_weights_f(unsigned fbinX, const gsl_vector* packedWeight)
+{
+  if (!bfweight_) throw j_error("set the quiescent vector once\n");
+  bfweight_->calcSidelobeCancellerP_f(fbinX, packedWeight);
+  weights_version_++;
+}
+
+void SubbandMVDRGSC::zero_active_weights()
+{
+  if (!bfweight_) throw j_error("call calc_gsc_weights_x() once\n");
+  std::vector<cd> z(chanN() - bfweight_->NC(), cd(0.0, 0.0));
+  for (unsigned k = 0; k < fftLen_; k++) bfweight_->calcSidelobeCancellerU_f(k, z.data());
+  weights_version_++;
+}
+
+// blocking matrix orthogonal to the delay-and-sum weights (beamformer.cc:2637-2642)
+bool SubbandMVDRGSC::calc_blocking_matrix1(float samplerate, const gsl_vector* delaysT)
+{
+  alloc_bfweight_(1);
+  bfweight_->calcMainlobe(samplerate, delaysT, true);
+  return true;
+}
+
+// blocking matrix orthogonal to the MVDR weights (beamformer.cc:2648-2672): bins 1..M/2, the others stay zero
+bool SubbandMVDRGSC::calc_blocking_matrix2()
+{
+  if (!have_mvdr_) return false;
+  alloc_bfweight_(1);
+  const unsigned N = chanN();
+  for (unsigned k = 1; k <= fftLen2_; k++) {
+    for (unsigned c = 0; c < N; c++)
+      bfweight_->wq[(size_t)k * N + c] = cd(wmvdr_[2 * ((size_t)k * N + c)], wmvdr_[2 * ((size_t)k * N + c) + 1]);
+    bfweight_->calcBlockingMatrix(k);
+  }
+  return true;
+}
+
+// B <- blocking matrix of the entire vector wq - wl (beamformer.cc:2674-2691)
+void SubbandMVDRGSC::upgrade_blocking_matrix()
+{
+  if (!bfweight_) throw j_error("call calc_gsc_weights_x() once\n");
+  const unsigned N = chanN(), bs = N - bfweight_->NC();
+  std::vector<cd> w(N);
+  for (unsigned k = 1; k < fftLen_; k++) {
+    for (unsigned c = 0; c < N; c++) w[c] = bfweight_->wq[(size_t)k * N + c] - bfweight_->wl[(size_t)k * N + c];
+    check_abi(btk_weights_blocking_matrix(reinterpret_cast<const double*>(w.data()), (int)N, (int)bfweight_->NC(),
+                                          reinterpret_cast<double*>(&bfweight_->B[(size_t)k * N * bs])));
+  }
+}
+
+// b_i^H x of the current frame for bins 0..M/2 (beamformer.cc:2693-2717); the other bins keep the beamformer output
+const gsl_vector_complex* SubbandMVDRGSC::blocking_matrix_output(int outChanX)
+{
+  if (!bfweight_) throw j_error("call calc_gsc_weights_x() once\n");
+  const unsigned N = chanN(), bs = N - bfweight_->NC();
+  if (outChanX < 0 || (unsigned)outChanX >= bs) throw jdimension_error("blocking matrix has %d columns\n", (int)bs);
+  SnapShotArrayPtr snaps = snapshot_array();
+  for (unsigned k = 0; k <= fftLen2_; k++) {
+    const gsl_vector_complex* x = snaps->snapshot(k);
+    cd acc(0.0, 0.0);
+    for (unsigned c = 0; c < N; c++)
+      acc += std::conj(bfweight_->B[((size_t)k * N + c) * bs + outChanX]) * cd(x->data[2 * c], x->data[2 * c + 1]);
+    vector_->data[2 * k] = acc.real(); vector_->data[2 * k + 1] = acc.imag();
+  }
+  return vector_;
+}
+
+void SubbandMVDRGSC::effective_weights(std::vector<float>& w)
+{
+  if (!bfweight_) throw j_error("call calc_array_manifold_vectorsX() once\n");
+  if (!have_mvdr_) throw j_error("call calc_mvdr_weights() once\n");
+  const unsigned N = chanN(), K = fftLen2_ + 1;
+  std::vector<cd> wq((size_t)fftLen_ * N, cd(0.0, 0.0));
+  for (size_t i = 0; i < (size_t)K * N; i++) wq[i] = cd(wmvdr_[2 * i], wmvdr_[2 * i + 1]);
+  w.resize((size_t)2 * K * N);
+  check_abi(btk_weights_gsc_effective(reinterpret_cast<const double*>(wq.data()), reinterpret_cast<const double*>(bfweight_->wl.data()),
+                                      (int)fftLen_, (int)N, normalize_weight_ ? 1 : 0, w.data()));
 }
 
 // ================================================================================ ZelinskiPostFilter

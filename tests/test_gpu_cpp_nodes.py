@@ -95,3 +95,87 @@ def test_beamformer_ds_binary_other_geometries(orc, dev, tmp_path, kinect_pcm, M
     ref = orc.synthesis(g, M_, m_, r_, 0, Y)
     assert out.shape == ref.shape
     assert np.max(np.abs(out - ref)) < 1e-4 * np.max(np.abs(ref)) + 0.5
+
+
+EXE_MVDRGSC = os.path.join(ROOT, "distant_speech_recognition_amd", "host", "examples", "beamformer_mvdrgsc")
+
+
+def _write_inputs(tmp_path, proto256, kinect_pcm, L, delays):
+    h, g = proto256
+    coeffs = str(tmp_path / "coeffs.f64")
+    np.concatenate([h, g]).astype(np.float64).tofile(coeffs)
+    chan_args = []
+    for c in range(4):
+        p = str(tmp_path / ("c%d.wav" % c))
+        w = wave.open(p, "wb")
+        w.setnchannels(1); w.setsampwidth(2); w.setframerate(FS)
+        w.writeframes(kinect_pcm[c][:L].astype(np.int16).tobytes())
+        w.close()
+        chan_args += [repr(float(delays[c])), p]
+    return coeffs, chan_args
+
+
+def _mvdrgsc_oracle(orc, X, delays, bm):
+    K = M // 2 + 1
+    wq_ds = orc.calc_mainlobe(M, 4, FS, delays)
+    R = orc.diagonal_loading(orc.diffuse_noise_model(MPOS, M, FS), M, 0.01)
+    wfull = np.zeros((M, 4), np.complex128)
+    wfull[:K] = orc.mvdr_weights(R, wq_ds, M)
+    base = wq_ds if bm == 1 else wfull
+    B = np.zeros((M, 4, 3), np.complex128)
+    for k in range(M):
+        if bm == 1 or 1 <= k <= M // 2:
+            B[k] = orc.blocking_matrix(base[k], 1)
+    wl = np.zeros((M, 4), np.complex128)
+    for k in range(1, M // 2 + 1):
+        i = np.arange(3)
+        wl[k] = orc.sidelobe_canceller(B[k], 0.05 * (np.cos(0.37 * k + i) + 1j * np.sin(0.11 * k * (i + 1))))
+    return wq_ds, wfull, wl, B
+
+
+@pytest.mark.parametrize("bm", [1, 2])
+def test_beamformer_mvdrgsc_binary_matches_oracle(orc, dev, tmp_path, proto256, kinect_pcm, bm):
+    """C++ SubbandMVDRGSC node (reference beamformer.h:385-437): MVDR quiescent + GSC lower branch with the blocking
+    matrix of calc_blocking_matrix1 / calc_blocking_matrix2, through the synthesis bank."""
+    from tests.util import la_delays
+    assert os.path.exists(EXE_MVDRGSC), "build the host layer: make -C distant_speech_recognition_amd/host"
+    h, g = proto256
+    delays = la_delays(MPOS, -1.306379)
+    L = 30000
+    coeffs, chan_args = _write_inputs(tmp_path, proto256, kinect_pcm, L, delays)
+    mpos = ";".join(",".join(repr(float(v)) for v in row) for row in MPOS)
+    env = dict(os.environ, BTK_EXAMPLE_BM=str(bm))
+    res = subprocess.run([EXE_MVDRGSC, coeffs, str(M), str(m), str(r), "0.01", str(tmp_path / "out.f32"), mpos] + chan_args,
+                         capture_output=True, text=True, timeout=120, env=env)
+    assert res.returncode == 0, res.stderr
+    assert "0 identity fall-backs" in res.stderr
+    out = np.fromfile(str(tmp_path / "out.f32"), np.float32)
+    X = np.stack([orc.analysis(h, M, m, r, 0, kinect_pcm[c][:L]) for c in range(4)], axis=1)
+    wq_ds, wfull, wl, B = _mvdrgsc_oracle(orc, X, delays, bm)
+    ref = orc.synthesis(g, M, m, r, 0, orc.gsc_frames(X, wfull, wl))
+    assert out.shape == ref.shape
+    assert np.max(np.abs(out - ref)) < 2e-3 * np.max(np.abs(kinect_pcm[:, :L])) + 0.5      # float32 SVD vs Cholesky MVDR
+
+
+def test_mvdrgsc_blocking_matrix_output_and_upgrade(orc, dev, tmp_path, proto256, kinect_pcm):
+    """blocking_matrix_output(0) frame by frame after upgrade_blocking_matrix(): b_0^H x with B_k orthogonal to wq_k - wl_k"""
+    from tests.util import la_delays
+    h, g = proto256
+    delays = la_delays(MPOS, -1.306379)
+    L = 12000
+    coeffs, chan_args = _write_inputs(tmp_path, proto256, kinect_pcm, L, delays)
+    mpos = ";".join(",".join(repr(float(v)) for v in row) for row in MPOS)
+    env = dict(os.environ, BTK_EXAMPLE_BM="1", BTK_EXAMPLE_UPGRADE="1", BTK_EXAMPLE_BMOUT=str(tmp_path / "bo.f64"))
+    res = subprocess.run([EXE_MVDRGSC, coeffs, str(M), str(m), str(r), "0.01", str(tmp_path / "out.f32"), mpos] + chan_args,
+                         capture_output=True, text=True, timeout=120, env=env)
+    assert res.returncode == 0, res.stderr
+    K = M // 2 + 1
+    bo = np.fromfile(str(tmp_path / "bo.f64"), np.float64).reshape(-1, K, 2)
+    bo = bo[..., 0] + 1j * bo[..., 1]
+    X = np.stack([orc.analysis(h, M, m, r, 0, kinect_pcm[c][:L]) for c in range(4)], axis=1)
+    wq_ds, wfull, wl, B = _mvdrgsc_oracle(orc, X, delays, 1)
+    assert bo.shape[0] == X.shape[0]
+    for k in range(1, K):
+        B[k] = orc.blocking_matrix(wq_ds[k] - wl[k], 1)
+    want = np.stack([[np.vdot(B[k][:, 0], X[t, :, k]) for k in range(K)] for t in range(X.shape[0])])
+    assert np.max(np.abs(bo - want)) < 1e-5 * np.max(np.abs(X))
