@@ -55,9 +55,10 @@ class MultiChannelWPEDereverberationPtr(object):
     def estimate_filter(self, start_frame_no=0, end_frame_no=-1):
         X = self._snapshots()
         T = X.shape[-1]
-        a = max(int(start_frame_no), 0)
-        b = T if end_frame_no < 0 else min(int(end_frame_no), T)
-        Xe = X[..., a:b].contiguous()
+        # fill_buffer_ (dereverberation.cc:506-529) counts frX from 0 and pulls one frame per frX in [start, end) from
+        # the inputs' CURRENT position: the estimate sees the FIRST end - start frames (all of them when end < 0)
+        n = T if end_frame_no < 0 else min(max(int(end_frame_no) - max(int(start_frame_no), 0), 0), T)
+        Xe = X[..., :n].contiguous()
         self._frames_num = Xe.shape[-1]
         try:
             self._G = engine.wpe_estimate(Xe, self._M, self._lower, self._upper, self._iters, self._load_db, self._band_width,
@@ -132,8 +133,9 @@ class SingleChannelWPEDereverberationFeaturePtr(_BlockServedStream, VectorComple
         self._core.set_input(samples)
 
     def estimate_filter(self, start_frame_no=0, frame_num=-1):
-        end = -1 if frame_num < 0 else start_frame_no + frame_num
-        return self._core.estimate_filter(start_frame_no, end)
+        # the header calls the second argument frame_num, the implementation uses it as an END index
+        # (dereverberation.cc:74-94, 214-215): same counting rule as the multi-channel estimator
+        return self._core.estimate_filter(start_frame_no, frame_num)
 
     def print_objective_func(self, subband_no):
         pass

@@ -15,6 +15,7 @@
 #include "modulated/modulated.h"
 #include "beamformer/beamformer.h"
 #include "postfilter/postfilter.h"
+#include "dereverberation/dereverberation.h"
 
 namespace {
 
@@ -1164,4 +1165,245 @@ const gsl_vector_complex* SubbandGSCRLS::next(int frame_no)
   serve_frame(Yhost_, T_, fftLen_, idx, vector_);
   increment_();
   return vector_;
+}
+
+
+// ================================================================================ WPE dereverberation
+// (reference dereverberation/dereverberation.cc:40-307, 312-760)
+namespace {
+unsigned wpe_band_width(unsigned M, double bandWidth, double sampleRate)
+{
+  if (bandWidth == 0.0) return M / 2;                                      // set_band_width_ (:361-369)
+  if (bandWidth > sampleRate / 2.0) throw jdimension_error("Bandwidth is greater than the Nyquist rate.\n");
+  return (unsigned)((bandWidth / (sampleRate / 2.0)) * (M / 2));
+}
+}  // namespace
+
+MultiChannelWPEDereverberation::MultiChannelWPEDereverberation(unsigned subbandsN, unsigned channelsN, unsigned lowerN,
+                                                               unsigned upperN, unsigned iterationsN, double loadDb,
+                                                               double bandWidth, double diagonal_bias, double sampleRate)
+    : subbandsN_(subbandsN), channelsN_(channelsN), lowerN_(lowerN), upperN_(upperN), iterationsN_(iterationsN),
+      load_db_(loadDb), diagonal_bias_(diagonal_bias), lower_bw_(wpe_band_width(subbandsN, bandWidth, sampleRate)),
+      upper_bw_(subbandsN - lower_bw_), estimated_(false), framesN_(0), dG_(NULL), T_(0), have_out_(false),
+      output_(new gsl_vector_complex*[channelsN]), frame_no_(-1)
+{
+  for (unsigned c = 0; c < channelsN_; c++) output_[c] = gsl_vector_complex_calloc(subbandsN_);
+}
+
+MultiChannelWPEDereverberation::~MultiChannelWPEDereverberation()
+{
+  for (unsigned c = 0; c < channelsN_; c++) gsl_vector_complex_free(output_[c]);
+  delete[] output_;
+  dev_free(dG_);
+}
+
+void MultiChannelWPEDereverberation::set_input(VectorComplexFeatureStreamPtr& samples)
+{
+  if (sources_.size() == channelsN_) throw jallocation_error("Channel capacity exceeded.");
+  sources_.push_back(samples);
+}
+
+void MultiChannelWPEDereverberation::reset()
+{
+  frame_no_ = -1;
+  for (size_t c = 0; c < sources_.size(); c++) sources_[c]->reset();
+  have_out_ = false;
+  out_.clear();
+}
+
+void MultiChannelWPEDereverberation::reset_filter() { estimated_ = false; framesN_ = 0; }
+
+void MultiChannelWPEDereverberation::next_speaker()
+{
+  reset();
+  if (dG_) {
+    const unsigned K = subbandsN_ / 2 + 1, P = channelsN_ * (upperN_ - lowerN_ + 1);
+    check_hip(hipMemset(dG_, 0, sizeof(float) * 2 * channelsN_ * K * P), "hipMemset");
+  }
+}
+
+long MultiChannelWPEDereverberation::snapshots_(void** dX)
+{
+  const unsigned C = channelsN_, K = subbandsN_ / 2 + 1;
+  if (sources_.size() != C) throw jallocation_error("%u of %u input channels are set\n", (unsigned)sources_.size(), C);
+  std::vector<std::vector<float> > fr(C);
+  long T = -1;
+  for (unsigned c = 0; c < C; c++) {
+    const long t = drain_complex(sources_[c], subbandsN_, fr[c]);
+    if (T < 0 || t < T) T = t;
+  }
+  std::vector<float> Xh((size_t)2 * K * C * (T > 0 ? T : 0));
+  for (unsigned k = 0; k < K; k++)
+    for (unsigned c = 0; c < C; c++)
+      for (long t = 0; t < T; t++) {
+        Xh[2 * (((size_t)k * C + c) * T + t)] = fr[c][2 * ((size_t)t * K + k)];
+        Xh[2 * (((size_t)k * C + c) * T + t) + 1] = fr[c][2 * ((size_t)t * K + k) + 1];
+      }
+  *dX = dev_alloc(sizeof(float) * Xh.size());
+  if (!Xh.empty()) h2d(*dX, Xh.data(), sizeof(float) * Xh.size());
+  return T;
+}
+
+// fill_buffer_ (:506-529) counts frX from 0 and pulls one frame per frX in [start, end) from the inputs' current
+// position: the estimate sees the FIRST end - start frames of the inputs (all of them when end < 0).
+unsigned MultiChannelWPEDereverberation::estimate_filter(int start_frame_no, int end_frame_no)
+{
+  const unsigned C = channelsN_, K = subbandsN_ / 2 + 1, P = C * (upperN_ - lowerN_ + 1);
+  void* dX = NULL;
+  const long T = snapshots_(&dX);
+  long n = T;
+  if (end_frame_no >= 0) {
+    n = (long)end_frame_no - (start_frame_no > 0 ? start_frame_no : 0);
+    n = n < 0 ? 0 : (n > T ? T : n);
+  }
+  if (!dG_) {
+    dG_ = dev_alloc(sizeof(float) * 2 * C * K * P);
+    check_hip(hipMemset(dG_, 0, sizeof(float) * 2 * C * K * P), "hipMemset");
+  }
+  const long wsb = btk_wpe_workspace_bytes(1, (int)K, (int)C, (int)lowerN_, (int)upperN_, T > 0 ? T : 1);
+  void* ws = dev_alloc((size_t)(wsb > 0 ? wsb : 16));
+  void* dfail = dev_alloc(sizeof(int));
+  check_hip(hipMemset(dfail, 0, sizeof(int)), "hipMemset");
+  int fail = 0;
+  try {
+    check_abi(btk_wpe_estimate(dX, 1, (int)K, (int)C, T > 0 ? T : 1, n, (int)lowerN_, (int)upperN_, (int)iterationsN_, load_db_,
+                               diagonal_bias_, (int)lower_bw_, (int)upper_bw_, dG_, ws, (int*)dfail, NULL));
+    check_abi(btk_synchronize(NULL));
+    d2h(&fail, dfail, sizeof(int));
+  } catch (...) {
+    dev_free(dX); dev_free(ws); dev_free(dfail);
+    throw;
+  }
+  dev_free(dX); dev_free(ws); dev_free(dfail);
+  if (fail > 0)
+    throw jnumeric_error("MultiChannelWPEDereverberation: Cholesky decomposition failed (%d systems).\n"
+                         "Some channels may be too similar. Try to increase 'diagonal_bias'", fail);
+  for (size_t c = 0; c < sources_.size(); c++) sources_[c]->reset();       // (:428-431)
+  framesN_ = (unsigned)n;
+  estimated_ = true;
+  have_out_ = false;
+  out_.clear();
+  return framesN_;
+}
+
+void MultiChannelWPEDereverberation::prepare_output_()
+{
+  const unsigned C = channelsN_, K = subbandsN_ / 2 + 1;
+  void* dX = NULL;
+  T_ = snapshots_(&dX);
+  out_.assign((size_t)2 * K * C * (T_ > 0 ? T_ : 0), 0.f);
+  if (T_ > 0) {
+    void* dO = dev_alloc(sizeof(float) * out_.size());
+    try {
+      check_abi(btk_wpe_apply(dX, dG_, dO, 1, (int)K, (int)C, T_, T_, (int)lowerN_, (int)upperN_, (int)lower_bw_, (int)upper_bw_, NULL));
+      check_abi(btk_synchronize(NULL));
+      d2h(out_.data(), dO, sizeof(float) * out_.size());
+    } catch (...) { dev_free(dX); dev_free(dO); throw; }
+    dev_free(dO);
+  }
+  dev_free(dX);
+  have_out_ = true;
+}
+
+const gsl_vector_complex* MultiChannelWPEDereverberation::get_output(unsigned channelX)
+{
+  if (channelX >= channelsN_)
+    throw jindex_error("Invalid channel index: it exceeds the number of channels: %u >= %u\n", channelX, channelsN_);
+  return output_[channelX];
+}
+
+gsl_vector_complex** MultiChannelWPEDereverberation::calc_every_channel_output(int frame_no)
+{
+  if (!estimated_) throw jinitialization_error("Call SingleChannelWPEDereverberationFeature::estimate_filter()\n");
+  if (frame_no >= 0 && frame_no - 1 != frame_no_)
+    throw jindex_error("Problem in 'MultiChannelWPEDereverberation': %d - 1 != %d\n", frame_no, frame_no_);
+  if (!have_out_) prepare_output_();
+  frame_no_++;
+  if (frame_no_ >= T_) throw jiterator_error("end of samples!");
+  const unsigned C = channelsN_, K = subbandsN_ / 2 + 1, M = subbandsN_;
+  for (unsigned c = 0; c < C; c++)
+    for (unsigned k = 0; k < K; k++) {
+      const double re = out_[2 * (((size_t)k * C + c) * T_ + frame_no_)], im = out_[2 * (((size_t)k * C + c) * T_ + frame_no_) + 1];
+      output_[c]->data[2 * k] = re; output_[c]->data[2 * k + 1] = im;
+      if (k > 0 && k < M / 2) { output_[c]->data[2 * (M - k)] = re; output_[c]->data[2 * (M - k) + 1] = -im; }
+    }
+  return output_;
+}
+
+MultiChannelWPEDereverberationFeature::MultiChannelWPEDereverberationFeature(MultiChannelWPEDereverberationPtr& source, unsigned channelX,
+                                                                             unsigned primaryChannelX, const String& nm)
+    : VectorComplexFeatureStream(source->size(), nm), source_(source), channelX_(channelX), primaryChannelX_(primaryChannelX)
+{
+  if (channelX >= source->channelsN())
+    throw jindex_error("Invalid channel index: it exceeds the number of channels: %u >= %u\n", channelX, source->channelsN());
+}
+
+const std::vector<float>& MultiChannelWPEDereverberation::output_block(long* T)
+{
+  if (!estimated_) throw jinitialization_error("Call SingleChannelWPEDereverberationFeature::estimate_filter()\n");
+  if (!have_out_) prepare_output_();
+  *T = T_;
+  return out_;
+}
+
+// In the reference the primary channel's node drives the per-frame estimator and the others read what it computed
+// (:716-731).  Here every channel's node serves its own frame counter from the utterance block, so a downstream node
+// that drains one channel before the next (the block-served synthesis bank) still sees the right frames.
+const gsl_vector_complex* MultiChannelWPEDereverberationFeature::next(int frame_no)
+{
+  if (frame_no == frame_no_ && frame_no_ >= 0) return vector_;
+  if (frame_no >= 0 && frame_no - 1 != frame_no_)
+    throw jindex_error("Problem in 'MultiChannelWPEDereverberationFeature': %d - 1 != %d\n", frame_no, frame_no_);
+  long T = 0;
+  const std::vector<float>& blk = source_->output_block(&T);
+  const long idx = frame_no_ + 1;
+  if (idx >= T) { is_end_ = true; throw jiterator_error("end of samples!"); }
+  const unsigned C = source_->channelsN(), M = size(), K = M / 2 + 1;
+  for (unsigned k = 0; k < K; k++) {
+    const double re = blk[2 * (((size_t)k * C + channelX_) * T + idx)], im = blk[2 * (((size_t)k * C + channelX_) * T + idx) + 1];
+    vector_->data[2 * k] = re; vector_->data[2 * k + 1] = im;
+    if (k > 0 && k < M / 2) { vector_->data[2 * (M - k)] = re; vector_->data[2 * (M - k) + 1] = -im; }
+  }
+  increment_();
+  return vector_;
+}
+
+void MultiChannelWPEDereverberationFeature::reset()
+{
+  source_->reset();
+  VectorComplexFeatureStream::reset();
+}
+
+SingleChannelWPEDereverberationFeature::SingleChannelWPEDereverberationFeature(VectorComplexFeatureStreamPtr& samples, unsigned lowerN,
+                                                                               unsigned upperN, unsigned iterationsN, double loadDb,
+                                                                               double bandWidth, double sampleRate, const String& nm)
+    : VectorComplexFeatureStream(samples->size(), nm),
+      core_(new MultiChannelWPEDereverberation(samples->size(), 1, lowerN, upperN, iterationsN, loadDb, bandWidth, 0.0, sampleRate))
+{
+  core_->set_input(samples);
+}
+
+const gsl_vector_complex* SingleChannelWPEDereverberationFeature::next(int frame_no)
+{
+  if (frame_no == frame_no_ && frame_no_ >= 0) return vector_;
+  if (frame_no >= 0 && frame_no - 1 != frame_no_)
+    throw jindex_error("Problem in Feature %s: %d != %d\n", name().c_str(), frame_no - 1, frame_no_);
+  gsl_vector_complex** out;
+  try { out = core_->calc_every_channel_output(-5); }
+  catch (jiterator_error&) { is_end_ = true; throw jiterator_error("end of samples!"); }
+  increment_();
+  memcpy(vector_->data, out[0]->data, sizeof(double) * 2 * size());
+  return vector_;
+}
+
+void SingleChannelWPEDereverberationFeature::reset()
+{
+  core_->reset();
+  VectorComplexFeatureStream::reset();
+}
+
+void SingleChannelWPEDereverberationFeature::next_speaker()
+{
+  core_->next_speaker();
+  VectorComplexFeatureStream::reset();
 }

@@ -179,3 +179,30 @@ def test_mvdrgsc_blocking_matrix_output_and_upgrade(orc, dev, tmp_path, proto256
         B[k] = orc.blocking_matrix(wq_ds[k] - wl[k], 1)
     want = np.stack([[np.vdot(B[k][:, 0], X[t, :, k]) for k in range(K)] for t in range(X.shape[0])])
     assert np.max(np.abs(bo - want)) < 1e-5 * np.max(np.abs(X))
+
+
+EXE_WPE = os.path.join(ROOT, "distant_speech_recognition_amd", "host", "examples", "subband_dereverberator")
+
+
+@pytest.mark.parametrize("nchan,lower,upper,bias", [(2, 0, 7, 1e-4), (1, 1, 12, 0.0), (3, 2, 5, 1e-4)])
+def test_subband_dereverberator_binary_matches_oracle(orc, dev, tmp_path, proto256, kinect_pcm, nchan, lower, upper, bias):
+    """C++ WPE nodes (reference dereverberation.h:31-190) in the flow of unit_test/test_subband_dereverberator.py:
+    estimate_filter() on the utterance, then lock-step pull of the dereverberated channels through synthesis banks."""
+    assert os.path.exists(EXE_WPE), "build the host layer: make -C distant_speech_recognition_amd/host"
+    h, g = proto256
+    L = 40000
+    coeffs, chan_args = _write_inputs(tmp_path, proto256, kinect_pcm, L, np.zeros(4))
+    wavs = chan_args[1::2][:nchan]
+    prefix = str(tmp_path / "dereverb")
+    res = subprocess.run([EXE_WPE, coeffs, str(M), str(m), str(r), str(lower), str(upper), "2", "-18.0", repr(bias), prefix] + wavs,
+                         capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stderr
+    X = np.stack([orc.analysis(h, M, m, r, 0, kinect_pcm[c][:L]) for c in range(nchan)], axis=1)
+    assert "%d frames used for the estimate" % X.shape[0] in res.stderr
+    G = orc.wpe_estimate(X, lower, upper, 2, -18.0, 0.0, bias)
+    Yd = orc.wpe_apply(X, G, lower, upper)
+    for c in range(nchan):
+        out = np.fromfile(prefix + ".c%d.f32" % c, np.float32)
+        ref = orc.synthesis(g, M, m, r, 0, Yd[:, c])
+        assert out.shape == ref.shape
+        assert np.max(np.abs(out - ref)) < 1e-3 * np.max(np.abs(ref)) + 0.5
