@@ -118,7 +118,11 @@ def main():
     W = torch.from_numpy(eng.weights_gsc_effective(wq, wl, M)).to(dev)
 
     X = torch.empty((S, K, N, T), dtype=torch.complex64, device=dev)
-    Y = torch.empty((S, K, T), dtype=torch.complex64, device=dev)
+    # the chain's Y [S][K][T]: rows 48 frames apart from contiguous when a row is a multiple of 4 KiB (power-of-two row strides
+    # put the 257 bin rows of a tile on the same HBM channels; the C-ABI takes any T_stride >= T); the staged stages below
+    # share X's T_stride and use their own contiguous block
+    Y = eng.padded_rows((S, K, T), torch.complex64, dev) if not args.staged else torch.empty((S, K, T), dtype=torch.complex64, device=dev)
+    Yc = Y if Y.is_contiguous() else torch.empty((S, K, T), dtype=torch.complex64, device=dev)
     nblk = sfb.num_blocks(T)
     out = torch.empty((S, nblk * D), dtype=torch.float32, device=dev)
 
@@ -168,14 +172,14 @@ def main():
         return a.elapsed_time(b) * 1e-3 / n
     if fused:
         t_ana = _time(lambda: afb.analysis(pcm, out=X))
-        t_bf = _time(lambda: eng.bf_apply(W, X, out=Y))
+        t_bf = _time(lambda: eng.bf_apply(W, X, out=Yc))
     else:
         t_ana, t_bf = t_a, t_b
     # the adaptive variant of the same beamformer (SubbandGSCLMSBeamformer: NLMS canceller on the snapshots), reported
     # next to the static-weight chain; the recursion is sequential in t, so its rate depends on the number of streams
     vs = torch.from_numpy(np.stack([np.exp(-2j * np.pi * k * (FS / M) * delays) / N for k in range(K)]).astype(np.complex64)).to(dev)
     nst = eng.NLMSState(S, M, N, dev)
-    t_nlms = _time(lambda: eng.nlms_process(vs, X, nst, out=Y))
+    t_nlms = _time(lambda: eng.nlms_process(vs, X, nst, out=Yc))
 
     if rank == 0:
         frames_per_step = S * T * world
@@ -225,7 +229,8 @@ def main():
             "xRT": value / (FS / D),
             "config": {"workload": "C0: %d-mic %d-bin SubbandGSC, analysis->GSC apply->synthesis (%s), m=4 r=1 (D=%d), "
                                    "%d streams/GPU x %d frames/step" % (N, M, "fused analysis+apply" if fused else "staged", D, S, T),
-                       "streams_per_gpu": S, "frames_per_stream": T, "parallelism": "stream-sharded x%d" % world},
+                       "streams_per_gpu": S, "frames_per_stream": T, "parallelism": "stream-sharded x%d" % world,
+                       "y_row_stride_frames": int(Y.stride(1))},
             "roofline": roof,
             "stages": {
                 "fused_analysis_apply": ({"ms": t_a * 1e3, "frames_per_s": S * T / t_a,

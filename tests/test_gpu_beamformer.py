@@ -153,3 +153,28 @@ def test_fused_interior_tiles_lds_dma_path(orc, dev, N, r, S, T):
     Yo = np.einsum("kn,tnk->kt", np.conj(Wn[1].astype(np.complex128)), Xo[t0:t0 + 16, :, :K])
     g = got[1, :, t0:t0 + 16].cpu().numpy()
     assert np.max(np.abs(g - Yo)) <= 4e-6 * np.sqrt(N) * np.max(np.abs(Yo))
+
+
+def test_fused_chain_with_row_padded_output(dev):
+    """Y handed over as a [..., :T] view of a buffer with padded rows (engine.padded_rows: what analysis_beamform
+    allocates itself when a contiguous row would be a multiple of 4 KiB): the fused kernel and the synthesis bank take
+    the row stride through the C-ABI's T_stride and give the same bits as with contiguous rows."""
+    import torch
+    from distant_speech_recognition_amd import engine as eng
+    M, m, r, N, S, T = 512, 4, 1, 5, 2, 512
+    fb = eng.FilterBank(design_prototype(M, m), M, m, r, 2)
+    sfb = eng.FilterBank(design_prototype(M, m, "g"), M, m, r, 2, synthesis=True)
+    L = (T - fb.processing_delay + fb.lookahead) * (M >> r)
+    pcm, _ = synthetic_pcm(S, N, L, seed=3)
+    p = torch.from_numpy(pcm).to(dev)
+    rng = np.random.default_rng(5)
+    K = M // 2 + 1
+    W = torch.from_numpy(((rng.normal(size=(K, N)) + 1j * rng.normal(size=(K, N))) / N).astype(np.complex64)).to(dev)
+    Yc = torch.empty((S, K, T), dtype=torch.complex64, device=dev)
+    fb.analysis_beamform(p, W, out=Yc)
+    Yp = fb.analysis_beamform(p, W)                       # default allocation: T * 8 B = 4 KiB rows -> padded
+    assert not Yp.is_contiguous() and Yp.stride(1) > T and Yp.shape == Yc.shape
+    assert torch.equal(Yp, Yc)
+    assert torch.equal(sfb.synthesize(Yp), sfb.synthesize(Yc))
+    with pytest.raises(ValueError):
+        sfb.synthesize(Yc.transpose(1, 2))                # rows must be contiguous
