@@ -414,6 +414,7 @@ int btk_fb_analysis_bf(const btk_fb_t* fb, const float* pcm, long nsamples, long
   if (S <= 0 || N <= 0 || tcount < 0 || T_stride < tcount || pcm_stride < nsamples)
     return btk_set_error(BTK_ERR_DIMENSION, "btk_fb_analysis_bf: bad sizes S=%d N=%d tcount=%ld T_stride=%ld", S, N, tcount, T_stride);
   if (tcount == 0) return BTK_OK;
+  if (reinterpret_cast<uintptr_t>(scratch) & 15) return btk_set_error(BTK_ERR_PARAMETER, "btk_fb_analysis_bf: scratch must be 16-byte aligned");
   // fused geometries stage the weight pairs [Sw][N][320] float4 (fb_analysis512.hip); the staged fall-back checks its own size below
   const long wt_bytes = (fb->M == 512 && fb->m == 4) ? (long)sizeof(float4) * (per_stream_weights ? S : 1) * 320 * N : 0;
   if (scratch_bytes < wt_bytes) return btk_set_error(BTK_ERR_PARAMETER, "btk_fb_analysis_bf: scratch too small (%ld < %ld)", scratch_bytes, wt_bytes);

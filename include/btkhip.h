@@ -90,7 +90,9 @@ int  btk_bf_apply(const void* W, int per_stream_weights, const void* X, void* Y,
 /* Fused OverSampledDFTAnalysisBank x N -> fixed-weight beamformer (the chain SubbandGSC::next pulls per frame,
  * beamformer.cc:1267-1311): Y[s][k][t] = sum_n conj(W[k][n]) X_n[k][t] without materialising the snapshots in HBM
  * (M = 512, m = 4 today; other geometries run btk_fb_analysis + btk_bf_apply through `scratch`).
- * scratch [dev] of btk_fb_analysis_bf_scratch_bytes(...) bytes.  Use the staged calls when a post-filter, the
+ * scratch [dev] of btk_fb_analysis_bf_scratch_bytes(...) bytes, 16-byte aligned (the fused kernel stages its weight
+ * pairs [Sw][N][320] float4 there and fetches them by LDS-DMA).  Y rows may be spaced T_stride >= tcount frames apart
+ * (fused geometries); rows a multiple of 4 KiB apart are worth padding.  Use the staged calls when a post-filter, the
  * adaptive canceller or covariance accumulation needs the snapshots.                                          */
 long btk_fb_analysis_bf_scratch_bytes(const btk_fb_t* fb, int S, int N, int per_stream_weights, long tcount);
 int  btk_fb_analysis_bf(const btk_fb_t* fb, const float* pcm, long nsamples, long pcm_stride, int S, int N,
