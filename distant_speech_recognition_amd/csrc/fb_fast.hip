@@ -336,6 +336,234 @@ int fast_analysis_r(const btk_fb* fb, const float* pcm, long nsamples, long pcm_
 }
 
 
+// ------------------------------------------------------------------------------------------------ fused analysis -> apply
+// OverSampledDFTAnalysisBank x N -> SubbandDS/GSC/MVDR::next for static weights (beamformer.cc:1267-1311 over
+// modulated.cc:375-409) at M = 256, the reference's default geometry, m = 4 (M = 512 has its own kernel in
+// fb_analysis512.hip; the template also instantiates for M = 1024 / 2048 but spills there and is not dispatched).
+// One workgroup = one (stream, TT-frame tile); it walks over the N channels, transforms each exactly as
+// fast_analysis_kernel does and adds conj(w_n[k]) X_n[k][t] to the bins it owns: thread (f = tid % TT, kq = tid / TT)
+// keeps bins kq, kq + KQ, ... of frame f in registers.  The N x K snapshot block never reaches HBM.
+// Wt [Sw][N][K] complex64: one contiguous column of K weights per channel.
+__global__ void f_transpose_weights_kernel(const float2* __restrict__ W, float2* __restrict__ Wt, int K, int N, int Sw)
+{
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)Sw * K * N) return;
+  const int n = (int)(i % N);
+  const int k = (int)((i / N) % K);
+  const long s = i / ((long)N * K);
+  Wt[(s * N + n) * K + k] = W[i];
+}
+
+template <int LOG2M, int R>
+__global__ __launch_bounds__(F_NT, 2)
+void fast_analysis_bf_kernel(const float* __restrict__ pcm, long nsamples, long pcm_stride,
+                             const float* __restrict__ proto, const float2* __restrict__ twg,
+                             int laN, float gain, int N, int K, const float2* __restrict__ Wt, long w_stream_stride,
+                             float2* __restrict__ Y, long T_stride, long t0, long tcount, int ntiles, int tiles_per_xcd, int S)
+{
+  using G = FG<LOG2M>;
+  constexpr int M = G::M, NF = G::NF, TT = G::TT, FRS = G::FRS, P2 = G::P2, LA = G::LA;
+  constexpr int D = M / R;
+  constexpr int SPAN = (TT - 1) * D + F_MT * M;
+  constexpr int FB_BYTES = TT * FRS * 8;
+  constexpr int REG_U = ((SPAN * 4 > FB_BYTES) ? SPAN * 4 : FB_BYTES + 15) & ~15;
+  constexpr int NV4 = (SPAN / 4 + F_NT - 1) / F_NT;
+  constexpr int NWP = (NF + 1 + F_NT - 1) / F_NT;                // weights of a column per thread
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* xs = reinterpret_cast<float*>(smem);
+  float2* fbuf = reinterpret_cast<float2*>(smem);
+  float2* twj = reinterpret_cast<float2*>(smem + REG_U);        // [P1][P2] W_NF^{j k1}
+  float2* wcol = twj + NF;                                      // [NF + 1] weights of the current channel
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // XCD-aware mapping: each XCD owns a contiguous range of tiles of every stream (neighbouring tiles share their halo in L2)
+  const int b = blockIdx.x;
+  const int xcd = b & 7, j0 = b >> 3;
+  const int s = j0 / tiles_per_xcd;
+  const int tile = xcd * tiles_per_xcd + j0 % tiles_per_xcd;
+  if (s >= S || tile >= ntiles) return;
+  const long tt0 = (long)tile * TT;
+
+  for (int i = tid; i < NF; i += F_NT) twj[i] = twg[(2 * (i % P2) * (i / P2)) & (M - 1)];
+
+  const bool vec_ok = ((pcm_stride & 3) == 0) && ((reinterpret_cast<uintptr_t>(pcm) & 15) == 0);
+  const long g0 = (t0 + tt0 + laN + 1) * (long)D - (long)F_MT * M;
+  const bool inb = vec_ok && g0 >= 0 && g0 + SPAN <= nsamples;
+  const float2* wts = Wt + (long)s * w_stream_stride;
+  float4 pre[NV4];
+  float2 wpre[NWP];
+  auto fetch = [&](int n) {
+    const float* src = pcm + ((long)s * N + n) * pcm_stride;
+    if (inb) {
+#pragma unroll
+      for (int q = 0; q < NV4; q++) {
+        const int l = (tid + q * F_NT) * 4;
+        if (l < SPAN) pre[q] = *reinterpret_cast<const float4*>(src + g0 + l);
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < NV4; q++) {
+        const int l = (tid + q * F_NT) * 4;
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+          const long g = g0 + l + e;
+          v[e] = (l + e < SPAN && g >= 0 && g < nsamples) ? src[g] : 0.0f;
+        }
+        pre[q] = make_float4(v[0], v[1], v[2], v[3]);
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < NWP; q++) {
+      const int k = tid + q * F_NT;
+      wpre[q] = (k <= NF) ? wts[(long)n * K + k] : make_float2(0.f, 0.f);
+    }
+  };
+
+  constexpr int NOWN = G::NOWN, FPT = G::FPT, KQ = G::KQ, NIT = NF / KQ;
+  const int nbase = (NF >= F_NT) ? tid : (tid % NF);
+  const int f0 = (NF >= F_NT) ? 0 : (tid / NF) * FPT;
+  float2 h[NOWN][F_MT];
+#pragma unroll
+  for (int q = 0; q < NOWN; q++)
+#pragma unroll
+    for (int k = 0; k < F_MT; k++) h[q][k] = *reinterpret_cast<const float2*>(proto + 2 * (nbase + q * F_NT) + M * k);
+  const float hg = 0.5f * gain;
+  const int f = tid % TT, kq = tid / TT;
+  float2 acc[NIT];
+#pragma unroll
+  for (int it = 0; it < NIT; it++) acc[it] = make_float2(0.f, 0.f);
+  float2 accN = make_float2(0.f, 0.f);                          // bin NF = M/2 (kq == 0 threads)
+
+  // M >= 1024: the span prefetch (12-24 float4 per thread) does not fit next to the accumulators -> fetched at the top
+  constexpr bool PREFETCH = LOG2M <= 9;
+  if (PREFETCH) fetch(0);
+  for (int n = 0; n < N; n++) {
+    if (!PREFETCH) fetch(n);
+#pragma unroll
+    for (int q = 0; q < NV4; q++) {
+      const int l = (tid + q * F_NT) * 4;
+      if (l < SPAN) *reinterpret_cast<float4*>(xs + l) = pre[q];
+    }
+#pragma unroll
+    for (int q = 0; q < NWP; q++) {
+      const int k = tid + q * F_NT;
+      if (k <= NF) wcol[k] = wpre[q];
+    }
+    __syncthreads();
+
+    // ---- polyphase with register windows (all windows are pulled before the frames overwrite the span)
+    {
+      constexpr int NW = FPT + (F_MT - 1) * R;
+      float2 win[NOWN][NW];
+#pragma unroll
+      for (int q = 0; q < NOWN; q++) {
+        const float* wbase = xs + (M - 2 - 2 * (nbase + q * F_NT)) + f0 * D;
+#pragma unroll
+        for (int i = 0; i < NW; i++) win[q][i] = *reinterpret_cast<const float2*>(wbase + i * D);
+      }
+      __syncthreads();
+#pragma unroll
+      for (int q = 0; q < NOWN; q++) {
+        const int nn = nbase + q * F_NT;
+        const int zoff = (nn / P2) * LA + (nn % P2);
+#pragma unroll
+        for (int ff = 0; ff < FPT; ff++) {
+          float p0 = 0.f, p1 = 0.f;
+#pragma unroll
+          for (int k = 0; k < F_MT; k++) {
+            const float2 x = win[q][ff + R * (F_MT - 1 - k)];
+            p0 = fmaf(h[q][k].x, x.y, p0);
+            p1 = fmaf(h[q][k].y, x.x, p1);
+          }
+          fbuf[(f0 + ff) * FRS + zoff] = make_float2(p0, p1);
+        }
+      }
+    }
+    __syncthreads();
+    if (PREFETCH && n + 1 < N) fetch(n + 1);                      // lands under the FFT and the accumulation
+
+    wave_fft<LOG2M, false>(fbuf + wave * G::FPW * FRS, twj, lane);
+    __syncthreads();
+
+    // ---- Hermitian post-pass + beamformer sum: y_k += conj(w_k) X_k
+    {
+      const float2* zf = fbuf + f * FRS;
+#pragma unroll
+      for (int it = 0; it < NIT; it++) {
+        const int k = kq + KQ * it;
+        const int kp = (NF - k) & (NF - 1);
+        const float2 zk = zf[zidx<LOG2M>(k)];
+        const float2 zq = zf[zidx<LOG2M>(kp)];
+        const float2 e = make_float2(hg * (zk.x + zq.x), hg * (zk.y - zq.y));
+        const float2 o = make_float2(hg * (zk.y + zq.y), -hg * (zk.x - zq.x));
+        const float2 w = twg[k];                                  // e^{+j 2 pi k / M}, L1-resident
+        const float xr = e.x + (w.x * o.x - w.y * o.y), xi = e.y + (w.x * o.y + w.y * o.x);
+        const float2 wk = wcol[k];
+        acc[it].x = fmaf(wk.x, xr, fmaf(wk.y, xi, acc[it].x));
+        acc[it].y = fmaf(wk.x, xi, fmaf(-wk.y, xr, acc[it].y));
+      }
+      if (kq == 0) {
+        const float2 z0 = zf[0];
+        const float xr = gain * (z0.x - z0.y);
+        const float2 wk = wcol[NF];
+        accN.x = fmaf(wk.x, xr, accN.x);
+        accN.y = fmaf(-wk.y, xr, accN.y);
+      }
+    }
+    __syncthreads();
+  }
+
+  if (tt0 + f < tcount) {
+    float2* yo = Y + (long)s * K * T_stride + tt0 + f;
+#pragma unroll
+    for (int it = 0; it < NIT; it++) yo[(long)(kq + KQ * it) * T_stride] = acc[it];
+    if (kq == 0) yo[(long)NF * T_stride] = accN;
+  }
+}
+
+template <int LOG2M, int R>
+int launch_fast_analysis_bf(const btk_fb* fb, const float* pcm, long nsamples, long pcm_stride, int S, int N, const float2* W,
+                            int per_stream, float2* Wt, float2* Y, long T_stride, long t0, long tcount, hipStream_t st)
+{
+  using G = FG<LOG2M>;
+  constexpr int D = G::M / R;
+  constexpr int SPAN = (G::TT - 1) * D + F_MT * G::M;
+  constexpr int FB_BYTES = G::TT * G::FRS * 8;
+  constexpr int REG_U = ((SPAN * 4 > FB_BYTES) ? SPAN * 4 : FB_BYTES + 15) & ~15;
+  const size_t lds = REG_U + sizeof(float2) * (G::NF + G::NF + 1);
+  if (lds > 160 * 1024) return 0;
+  const int K = fb->K, Sw = per_stream ? S : 1;
+  const long nw = (long)Sw * K * N;
+  hipLaunchKernelGGL(f_transpose_weights_kernel, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, st, W, Wt, K, N, Sw);
+  const int ntiles = (int)((tcount + G::TT - 1) / G::TT);
+  const int tiles_per_xcd = (ntiles + 7) / 8;
+  const long nblocks = (long)8 * tiles_per_xcd * S;
+  auto kern = fast_analysis_bf_kernel<LOG2M, R>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    BTK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
+  }
+  const float gain = fb->gain_factor > 0 ? (float)fb->gain_factor : 1.0f;
+  hipLaunchKernelGGL(kern, dim3((unsigned)nblocks), dim3(F_NT), lds, st, pcm, nsamples, pcm_stride, fb->d_proto, fb->d_tw,
+                     fb->laN, gain, N, K, Wt, per_stream ? (long)N * K : 0L, Y, T_stride, t0, tcount, ntiles, tiles_per_xcd, S);
+  BTK_HIP_CHECK(hipGetLastError());
+  return 1;
+}
+
+template <int LOG2M>
+int fast_analysis_bf_r(const btk_fb* fb, const float* pcm, long nsamples, long pcm_stride, int S, int N, const float2* W,
+                       int per_stream, float2* Wt, float2* Y, long T_stride, long t0, long tcount, hipStream_t st)
+{
+  switch (fb->R) {
+    case 1: return launch_fast_analysis_bf<LOG2M, 1>(fb, pcm, nsamples, pcm_stride, S, N, W, per_stream, Wt, Y, T_stride, t0, tcount, st);
+    case 2: return launch_fast_analysis_bf<LOG2M, 2>(fb, pcm, nsamples, pcm_stride, S, N, W, per_stream, Wt, Y, T_stride, t0, tcount, st);
+    case 4: return launch_fast_analysis_bf<LOG2M, 4>(fb, pcm, nsamples, pcm_stride, S, N, W, per_stream, Wt, Y, T_stride, t0, tcount, st);
+  }
+  return 0;
+}
+
 // ------------------------------------------------------------------------------------------------ synthesis
 // Same schedule as synthesis512_kernel (fb_analysis512.hip) for any M: a workgroup walks through F_SRUN output
 // blocks of one stream; the real sequences v_f live in a ring of TT + m R frame buffers; every iteration adds
@@ -535,6 +763,22 @@ int btk_fast_analysis_try(const btk_fb* fb, const float* pcm, long nsamples, lon
     case 512:  return fast_analysis_r<9>(fb, pcm, nsamples, pcm_stride, S, N, Xp, T_stride, t0, tcount, st);
     case 1024: return fast_analysis_r<10>(fb, pcm, nsamples, pcm_stride, S, N, Xp, T_stride, t0, tcount, st);
     case 2048: return fast_analysis_r<11>(fb, pcm, nsamples, pcm_stride, S, N, Xp, T_stride, t0, tcount, st);
+  }
+  return 0;
+}
+
+// fused analysis + fixed-weight beamformer for M = 256 (the reference's default geometry), m = 4; scratch: Sw K N complex64
+int btk_fast_analysis_bf_try(const btk_fb* fb, const float* pcm, long nsamples, long pcm_stride, int S, int N, const void* W,
+                             int per_stream, void* Wt_scratch, void* Y, long T_stride, long t0, long tcount, hipStream_t st)
+{
+  if (fb->m != F_MT) return 0;
+  const float2* Wp = static_cast<const float2*>(W);
+  float2* Wt = static_cast<float2*>(Wt_scratch);
+  float2* Yp = static_cast<float2*>(Y);
+  switch (fb->M) {
+    // M = 1024 / 2048: 32 accumulators + 32-point passes + two pair indices per thread spill ~1 KB of scratch per thread
+    // in this form; those geometries stay with the staged pair until the accumulators move to the Z domain
+    case 256:  return fast_analysis_bf_r<8>(fb, pcm, nsamples, pcm_stride, S, N, Wp, per_stream, Wt, Yp, T_stride, t0, tcount, st);
   }
   return 0;
 }

@@ -415,14 +415,23 @@ int btk_fb_analysis_bf(const btk_fb_t* fb, const float* pcm, long nsamples, long
     return btk_set_error(BTK_ERR_DIMENSION, "btk_fb_analysis_bf: bad sizes S=%d N=%d tcount=%ld T_stride=%ld", S, N, tcount, T_stride);
   if (tcount == 0) return BTK_OK;
   if (reinterpret_cast<uintptr_t>(scratch) & 15) return btk_set_error(BTK_ERR_PARAMETER, "btk_fb_analysis_bf: scratch must be 16-byte aligned");
-  // fused geometries stage the weight pairs [Sw][N][320] float4 (fb_analysis512.hip); the staged fall-back checks its own size below
-  const long wt_bytes = (fb->M == 512 && fb->m == 4) ? (long)sizeof(float4) * (per_stream_weights ? S : 1) * 320 * N : 0;
-  if (scratch_bytes < wt_bytes) return btk_set_error(BTK_ERR_PARAMETER, "btk_fb_analysis_bf: scratch too small (%ld < %ld)", scratch_bytes, wt_bytes);
+  // fused geometries stage their weights in `scratch`: pairs [Sw][N][320] float4 at M = 512 (fb_analysis512.hip), the
+  // transposed matrix [Sw][N][K] complex64 at M = 256 (fb_fast.hip); the staged fall-back checks its own size below
+  const bool fuse512 = fb->M == 512 && fb->m == 4;
+  const bool fusefast = fb->m == 4 && fb->M == 256 && (fb->R == 1 || fb->R == 2 || fb->R == 4);
+  const long Sw = per_stream_weights ? S : 1;
+  const long wt_bytes = fuse512 ? (long)sizeof(float4) * Sw * 320 * N : fusefast ? (long)sizeof(float2) * Sw * fb->K * N : 0;
   hipStream_t st = as_stream(stream);
   static const bool nofuse = getenv("BTK_DISABLE_FUSED") != nullptr;
   if (!nofuse) {
-    const int rc = btk_analysis512_bf_try(fb, pcm, nsamples, pcm_stride, S, N, W, per_stream_weights, scratch, Y, T_stride, t0, tcount, st);
+    if ((fuse512 || fusefast) && scratch_bytes < wt_bytes)
+      return btk_set_error(BTK_ERR_PARAMETER, "btk_fb_analysis_bf: scratch too small (%ld < %ld)", scratch_bytes, wt_bytes);
+    int rc = btk_analysis512_bf_try(fb, pcm, nsamples, pcm_stride, S, N, W, per_stream_weights, scratch, Y, T_stride, t0, tcount, st);
     if (rc != 0) return rc > 0 ? BTK_OK : rc;
+    if (fusefast) {
+      rc = btk_fast_analysis_bf_try(fb, pcm, nsamples, pcm_stride, S, N, W, per_stream_weights, scratch, Y, T_stride, t0, tcount, st);
+      if (rc != 0) return rc > 0 ? BTK_OK : rc;
+    }
   }
   const long x_bytes = (long)sizeof(float2) * S * fb->K * N * tcount;
   if (scratch_bytes < x_bytes)
@@ -437,8 +446,12 @@ int btk_fb_analysis_bf(const btk_fb_t* fb, const float* pcm, long nsamples, long
 long btk_fb_analysis_bf_scratch_bytes(const btk_fb_t* fb, int S, int N, int per_stream_weights, long tcount)
 {
   if (!fb) return -1;
-  const bool fused = fb->M == 512 && fb->m == 4 && (fb->R == 1 || fb->R == 2 || fb->R == 4) && getenv("BTK_DISABLE_FUSED") == nullptr;
-  if (fused) return (long)sizeof(float4) * (per_stream_weights ? S : 1) * 320 * N;      // weight pairs [Sw][N][320], see fb_analysis512.hip
+  const bool rok = fb->R == 1 || fb->R == 2 || fb->R == 4;
+  const bool nofuse = getenv("BTK_DISABLE_FUSED") != nullptr;
+  if (!nofuse && rok && fb->m == 4 && fb->M == 512)
+    return (long)sizeof(float4) * (per_stream_weights ? S : 1) * 320 * N;                // weight pairs [Sw][N][320], see fb_analysis512.hip
+  if (!nofuse && rok && fb->m == 4 && fb->M == 256)
+    return (long)sizeof(float2) * (per_stream_weights ? S : 1) * fb->K * N;              // transposed weights [Sw][N][K], see fb_fast.hip
   return (long)sizeof(float2) * S * fb->K * N * tcount;
 }
 

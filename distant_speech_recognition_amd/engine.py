@@ -126,7 +126,7 @@ class FilterBank:
             W = W.unsqueeze(0)
         per_stream = int(W.shape[0] == S and S > 1)
         if out is None:
-            fused = self.M == 512 and self.m == 4 and self.r <= 2       # the staged fall-back needs contiguous rows
+            fused = self.M in (256, 512) and self.m == 4 and self.r <= 2          # the staged fall-back needs contiguous rows
             out = (padded_rows((S, self.K, tcount), torch.complex64, pcm.device) if fused
                    else torch.empty((S, self.K, tcount), dtype=torch.complex64, device=pcm.device))
         t_stride = _row_stride(out, "Y")          # out may be a [..., :T] view of a row-padded buffer

@@ -178,3 +178,33 @@ def test_fused_chain_with_row_padded_output(dev):
     assert torch.equal(sfb.synthesize(Yp), sfb.synthesize(Yc))
     with pytest.raises(ValueError):
         sfb.synthesize(Yc.transpose(1, 2))                # rows must be contiguous
+
+
+@pytest.mark.parametrize("N,r,S,T", [(6, 1, 2, 300), (4, 2, 3, 133), (5, 0, 1, 70), (64, 1, 1, 96)])
+def test_fused_default_geometry_m256(orc, dev, N, r, S, T):
+    """The reference's default geometry (M = 256, m = 4, unit_test/test_online_beamforming.py:259-262) has its own fused
+    analysis -> apply kernel (fb_fast.hip): equal to the staged pair on every frame (aligned and odd-length recordings,
+    shared and per-stream weights) and to the oracle on a block of frames."""
+    import torch
+    from distant_speech_recognition_amd import engine as eng
+    M, m = 256, 4
+    D, K = M >> r, M // 2 + 1
+    h = design_prototype(M, m)
+    fb = eng.FilterBank(h, M, m, r, 2)
+    for extra in (0, 37):
+        L = (T - fb.processing_delay + fb.lookahead) * D + extra
+        pcm, _ = synthetic_pcm(S, N, L, seed=29 + N + extra)
+        p = torch.from_numpy(pcm).to(dev)
+        rng = np.random.default_rng(N * 11 + r)
+        Wn = ((rng.normal(size=(S, K, N)) + 1j * rng.normal(size=(S, K, N))) / N).astype(np.complex64)
+        for W in (torch.from_numpy(Wn).to(dev), torch.from_numpy(Wn[0]).to(dev)):
+            ref = eng.bf_apply(W, fb.analysis(p))
+            got = fb.analysis_beamform(p, W)
+            assert got.shape == ref.shape
+            scale = float(ref.abs().max())
+            assert float((got - ref).abs().max()) <= 2e-6 * np.sqrt(N) * scale + 1e-6 * scale
+    Xo = np.stack([orc.analysis(h, M, m, r, 2, pcm[0, n]) for n in range(N)], axis=1)      # [T'][N][M]
+    t0 = min(32, Xo.shape[0] - 16)
+    Yo = np.einsum("kn,tnk->kt", np.conj(Wn[0].astype(np.complex128)), Xo[t0:t0 + 16, :, :K])
+    g = got[0, :, t0:t0 + 16].cpu().numpy()
+    assert np.max(np.abs(g - Yo)) <= 4e-6 * np.sqrt(N) * np.max(np.abs(Yo))
