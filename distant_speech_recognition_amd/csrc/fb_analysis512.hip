@@ -709,34 +709,53 @@ void synthesis512_kernel(const float2* __restrict__ Y, long nframes, long T_stri
   __syncthreads();
 
   const long f_lo = bt0 + pd - HALO;                          // oldest frame the run needs
+  // A. Hermitian pre-pass: Zc[k] = (Y[k] + conj Y[256-k]) + j W^-k (Y[k] - conj Y[256-k]).  Thread (fi = tid & 15,
+  //    kq = tid >> 4) loads the bin pairs (k, 256 - k), k = kq + 16 it, it < 8, of frame fi ONCE and forms both Zc[k]
+  //    and Zc[256-k] (bin 128 pairs with itself: the kq == 0 threads).  The loads of chunk c+1 are issued before the
+  //    FFT and the overlap-add of chunk c: their HBM latency was the longest stretch of a chunk.
+  const int fi = tid & 15, kq = tid >> 4;
+  float2 pa[8], pb[8], p128 = make_float2(0.f, 0.f);
+  auto prefetch = [&](long fc0) {
+    const long f = fc0 + fi;
+    const bool fok = f >= f_lo && f >= 0 && f < nframes;
+#pragma unroll
+    for (int it = 0; it < 8; it++) {
+      const int k = kq + 16 * it;
+      pa[it] = fok ? Ys[(long)k * T_stride + f] : make_float2(0.f, 0.f);
+      pb[it] = fok ? Ys[(long)(A_NF - k) * T_stride + f] : make_float2(0.f, 0.f);
+    }
+    if (kq == 0) p128 = fok ? Ys[(long)128 * T_stride + f] : make_float2(0.f, 0.f);
+  };
+  auto zc = [&](float2 a, float2 bq, int k) {                 // Zc[k] from Y[k] = a, Y[256-k] = bq
+    const float2 sm = make_float2(a.x + bq.x, a.y - bq.y), df = make_float2(a.x - bq.x, a.y + bq.y);
+    const float2 w = tw[k];
+    const float2 t = make_float2(w.x * df.x + w.y * df.y, w.x * df.y - w.y * df.x);     // conj(W^k) * df
+    return make_float2(sm.x - t.y, sm.y + t.x);
+  };
+  prefetch(f_lo + HALO - 16);
   // chunk c covers frames fc0 .. fc0+15; chunk -1 is the history (only its last HALO frames matter)
   for (long fc0 = f_lo + HALO - 16; fc0 < bend + pd; fc0 += 16) {
-    // ---- A. Hermitian pre-pass: Zc[k] = (Y[k] + conj Y[256-k]) + j W^-k (Y[k] - conj Y[256-k])
     {
-      const int fi = tid & 15, kq = tid >> 4;
       const long f = fc0 + fi;
-      const bool fok = f >= f_lo && f >= 0 && f < nframes;
       const int slot = (int)(((f - f_lo) % NRING + NRING) % NRING);
       float2* zf = ring + slot * FRS;
       if (f >= f_lo) {
-#pragma unroll 4
-        for (int it = 0; it < 16; it++) {
+#pragma unroll
+        for (int it = 0; it < 8; it++) {
           const int k = kq + 16 * it;
-          float2 z = make_float2(0.f, 0.f);
-          if (fok) {
-            float2 a = Ys[(long)k * T_stride + f];
-            float2 bq = Ys[(long)(A_NF - k) * T_stride + f];
-            if (k == 0) { a.y = 0.f; bq.y = 0.f; }               // imaginary parts of bins 0 and M/2 are ignored
-            const float2 sm = make_float2(a.x + bq.x, a.y - bq.y), df = make_float2(a.x - bq.x, a.y + bq.y);
-            const float2 w = tw[k];
-            const float2 t = make_float2(w.x * df.x + w.y * df.y, w.x * df.y - w.y * df.x);   // conj(W^k) * df
-            z = make_float2(sm.x - t.y, sm.y + t.x);
+          float2 a = pa[it], bq = pb[it];
+          if (k == 0) { a.y = 0.f; bq.y = 0.f; }                 // imaginary parts of bins 0 and M/2 are ignored
+          zf[it * 17 + kq] = zc(a, bq, k);
+          if (k > 0) {
+            const int kk = A_NF - k;                             // 144 .. 255
+            zf[(kk >> 4) * 17 + (kk & 15)] = zc(bq, a, kk);
           }
-          zf[it * 17 + kq] = z;
         }
+        if (kq == 0) zf[8 * 17] = zc(p128, p128, 128);
       }
     }
     __syncthreads();
+    if (fc0 + 16 < bend + pd) prefetch(fc0 + 16);             // lands under B and C
     // ---- B. forward FFT of the 16 new frames (4 per wavefront): conj -> positive-exponent passes -> conj
     {
       const int fl = lane >> 4, j = lane & 15;
