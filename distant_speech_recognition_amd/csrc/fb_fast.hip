@@ -599,32 +599,51 @@ void fast_synthesis_kernel(const float2* __restrict__ Y, long nframes, long T_st
   __syncthreads();
 
   const long f_lo = bt0 + pd - HALO;
+  // A. Hermitian pre-pass: thread (fi = tid % TT, kq = tid / TT) loads the bin pairs (k, NF - k), k = kq + KQ it < NF/2,
+  //    of frame fi once and forms both Zc[k] and Zc[NF - k] (bin NF/2 pairs with itself: the kq == 0 threads); the loads
+  //    of the next chunk are issued before the FFT and the overlap-add of the current one (see synthesis512_kernel).
+  constexpr int NPAIR = NF / KQ / 2;
+  const int fi = tid % TT, kq = tid / TT;
+  float2 pa[NPAIR], pb[NPAIR], pmid = make_float2(0.f, 0.f);
+  auto prefetch = [&](long fc0) {
+    const long f = fc0 + fi;
+    const bool fok = f >= f_lo && f >= 0 && f < nframes;
+#pragma unroll
+    for (int it = 0; it < NPAIR; it++) {
+      const int k = kq + KQ * it;
+      pa[it] = fok ? Ys[(long)k * T_stride + f] : make_float2(0.f, 0.f);
+      pb[it] = fok ? Ys[(long)(NF - k) * T_stride + f] : make_float2(0.f, 0.f);
+    }
+    if (kq == 0) pmid = fok ? Ys[(long)(NF / 2) * T_stride + f] : make_float2(0.f, 0.f);
+  };
+  auto zc = [&](float2 a, float2 bq, int k) {                 // Zc[k] from Y[k] = a, Y[NF-k] = bq
+    const float2 sm = make_float2(a.x + bq.x, a.y - bq.y), df = make_float2(a.x - bq.x, a.y + bq.y);
+    const float2 w = twg[k];
+    const float2 t = make_float2(w.x * df.x + w.y * df.y, w.x * df.y - w.y * df.x);
+    return make_float2(sm.x - t.y, sm.y + t.x);
+  };
+  prefetch(f_lo + HALO - TT);
   for (long fc0 = f_lo + HALO - TT; fc0 < bend + pd; fc0 += TT) {
-    // ---- A. Hermitian pre-pass
     {
-      const int fi = tid % TT, kq = tid / TT;
       const long f = fc0 + fi;
-      const bool fok = f >= 0 && f < nframes;
       if (f >= f_lo) {
         float2* zf = ring + (int)((f - f_lo) % NRING) * FRS;
-#pragma unroll 4
-        for (int it = 0; it < NF / KQ; it++) {
+#pragma unroll
+        for (int it = 0; it < NPAIR; it++) {
           const int k = kq + KQ * it;
-          float2 z = make_float2(0.f, 0.f);
-          if (fok) {
-            float2 a = Ys[(long)k * T_stride + f];
-            float2 bq = Ys[(long)(NF - k) * T_stride + f];
-            if (k == 0) { a.y = 0.f; bq.y = 0.f; }
-            const float2 sm = make_float2(a.x + bq.x, a.y - bq.y), df = make_float2(a.x - bq.x, a.y + bq.y);
-            const float2 w = twg[k];
-            const float2 t = make_float2(w.x * df.x + w.y * df.y, w.x * df.y - w.y * df.x);
-            z = make_float2(sm.x - t.y, sm.y + t.x);
+          float2 a = pa[it], bq = pb[it];
+          if (k == 0) { a.y = 0.f; bq.y = 0.f; }                 // imaginary parts of bins 0 and M/2 are ignored
+          zf[(k / P2) * G::LA + (k % P2)] = zc(a, bq, k);       // input layout of pass 1: n = P2 r + j
+          if (k > 0) {
+            const int kk = NF - k;
+            zf[(kk / P2) * G::LA + (kk % P2)] = zc(bq, a, kk);
           }
-          zf[(k / P2) * G::LA + (k % P2)] = z;                  // input layout of pass 1: n = P2 r + j
         }
+        if (kq == 0) zf[((NF / 2) / P2) * G::LA + ((NF / 2) % P2)] = zc(pmid, pmid, NF / 2);
       }
     }
     __syncthreads();
+    if (fc0 + TT < bend + pd) prefetch(fc0 + TT);              // lands under B and C
     // ---- B. forward FFT of this wave's FPW new frames
     {
       // frames of a wave are consecutive ring slots only when they do not wrap; handle frame by frame groups
