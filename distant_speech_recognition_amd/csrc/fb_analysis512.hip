@@ -18,6 +18,7 @@
 // into registers before the frames overwrite the span) + 4 KB of twiddles -> four workgroups per CU.
 #include "btk_internal.h"
 #include "fft_lds.h"
+#include "fft_packed.h"
 #include <cstdlib>
 
 namespace {
@@ -63,81 +64,7 @@ __device__ __forceinline__ void dft16p(float2 (&v)[16])
 }
 
 
-// ---- packed-float32 complex arithmetic (v_pk_*_f32 with op_sel / neg modifiers).  The compiler forms packed adds and
-// FMAs from float2 code on its own, but materialises every "multiply by +-i" and conjugation with v_xor + v_mov pairs
-// (a quarter of the FFT's instructions); the modifiers do those swaps and sign flips for free, so the few shapes the FFT
-// and the beamformer sum need are spelled out.  op_sel[i] / op_sel_hi[i] pick the low or high dword of source i for the
-// low / high result, neg_lo / neg_hi negate that source for the low / high result.
 constexpr int WSTR = 320;              // float4 per channel in the weight-pair table: 257 used, padded to 5 x 64 for 1 KiB LDS-DMA pieces
-typedef float f2 __attribute__((ext_vector_type(2)));
-typedef float f4 __attribute__((ext_vector_type(4)));
-
-__device__ __forceinline__ f2 add_ib(f2 a, f2 b)      // a + i b = (a.x - b.y, a.y + b.x)
-{
-  f2 r;
-  asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(a), "v"(b));
-  return r;
-}
-__device__ __forceinline__ f2 sub_ib(f2 a, f2 b)      // a - i b = (a.x + b.y, a.y - b.x)
-{
-  f2 r;
-  asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
-  return r;
-}
-__device__ __forceinline__ f2 cmulv(f2 a, f2 w)       // a w
-{
-  f2 t, r;
-  asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1]" : "=v"(t) : "v"(a), "v"(w));                    // (a.x w.x, a.x w.y)
-  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]" : "=v"(r) : "v"(a), "v"(w), "v"(t));   // + (-a.y w.y, a.y w.x)
-  return r;
-}
-__device__ __forceinline__ f2 cmulc(f2 a, f2 w) { return __builtin_elementwise_fma(a.yy, f2{-w.y, w.x}, a.xx * w); }   // constant w
-__device__ __forceinline__ void acc_conjw_z(f2& A, f2 w, f2 z)          // A += conj(w) z
-{
-  asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "+v"(A) : "v"(w), "v"(z));                       // (w.x z.x, w.x z.y)
-  asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_hi:[0,1,0]" : "+v"(A) : "v"(w), "v"(z));        // (w.y z.y, -w.y z.x)
-}
-__device__ __forceinline__ void acc_conjw_conjz(f2& B, f2 w, f2 z)      // B += conj(w) conj(z)
-{
-  asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_hi:[0,1,0]" : "+v"(B) : "v"(w), "v"(z));        // (w.x z.x, -w.x z.y)
-  asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0] neg_hi:[0,1,0]" : "+v"(B) : "v"(w), "v"(z));   // (-w.y z.y, -w.y z.x)
-}
-__device__ __forceinline__ void dft4q(f2& a0, f2& a1, f2& a2, f2& a3)
-{
-  const f2 s02 = a0 + a2, d02 = a0 - a2, s13 = a1 + a3, t = a1 - a3;
-  a0 = s02 + s13; a1 = add_ib(d02, t); a2 = s02 - s13; a3 = sub_ib(d02, t);
-}
-__device__ __forceinline__ void dft4q_i2(f2& a0, f2& a1, f2& a2, f2& a3)   // a2 stands for i a2
-{
-  const f2 s02 = add_ib(a0, a2), d02 = sub_ib(a0, a2), s13 = a1 + a3, t = a1 - a3;
-  a0 = s02 + s13; a1 = add_ib(d02, t); a2 = s02 - s13; a3 = sub_ib(d02, t);
-}
-// dft16p on packed registers (same factorisation and twiddles)
-__device__ __forceinline__ void dft16q(f2 (&v)[16])
-{
-  constexpr float C1 = 0.92387953251128674f, S1 = 0.38268343236508977f, H = 0.70710678118654752f;
-  f2 t[4][4];
-#pragma unroll
-  for (int b = 0; b < 4; b++) {
-    f2 x0 = v[b], x1 = v[4 + b], x2 = v[8 + b], x3 = v[12 + b];
-    dft4q(x0, x1, x2, x3);
-    t[b][0] = x0; t[b][1] = x1; t[b][2] = x2; t[b][3] = x3;
-  }
-  t[1][1] = cmulc(t[1][1], f2{C1, S1});
-  t[1][2] = cmulc(t[1][2], f2{H, H});
-  t[1][3] = cmulc(t[1][3], f2{S1, C1});
-  t[2][1] = cmulc(t[2][1], f2{H, H});
-  t[2][3] = cmulc(t[2][3], f2{-H, H});                  // t[2][2] *= i is folded into dft4q_i2
-  t[3][1] = cmulc(t[3][1], f2{S1, C1});
-  t[3][2] = cmulc(t[3][2], f2{-H, H});
-  t[3][3] = cmulc(t[3][3], f2{-C1, -S1});
-#pragma unroll
-  for (int c = 0; c < 4; c++) {
-    f2 y0 = t[0][c], y1 = t[1][c], y2 = t[2][c], y3 = t[3][c];
-    if (c == 2) dft4q_i2(y0, y1, y2, y3); else dft4q(y0, y1, y2, y3);
-    v[c] = y0; v[c + 4] = y1; v[c + 8] = y2; v[c + 12] = y3;
-  }
-}
 
 constexpr int A_RUN = 16;             // consecutive tiles (16 frames each) one workgroup walks through
 

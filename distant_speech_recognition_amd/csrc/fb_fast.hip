@@ -11,6 +11,7 @@
 // LDS frame layout: input z[n] at r (P2+1) + j; A' and Z at j (P1+1) + k1 == (kappa / P1)(P1+1) + kappa % P1.
 #include "btk_internal.h"
 #include "fft_lds.h"
+#include "fft_packed.h"
 #include <cstdlib>
 
 namespace {
@@ -114,35 +115,37 @@ template <int LOG2M> struct FG {
   static constexpr int KQ = F_NT / TT;                        // bin lanes in the store pass
 };
 
-// wave-private FFT of this wave's FPW frames (positive exponent); CONJ: forward transform through conjugation
+// wave-private FFT of this wave's FPW frames (positive exponent); CONJ: forward transform through conjugation.
+// Packed float32 arithmetic (fft_packed.h): the +-i products and twiddles ride on op_sel / neg modifiers.
 template <int LOG2M, bool CONJ>
 __device__ __forceinline__ void wave_fft(float2* __restrict__ frames /* this wave's first frame */, const float2* __restrict__ twj, int lane)
 {
   using G = FG<LOG2M>;
   constexpr int P1 = G::P1, P2 = G::P2, LA = G::LA, LB = G::LB, FRS = G::FRS;
+  const f2* twq = reinterpret_cast<const f2*>(twj);
 #pragma unroll
   for (int rd = 0; rd < G::FPW / G::FP1; rd++) {               // pass 1: lane = (frame, j)
     const int fl = lane / P2, j = lane % P2;
-    float2* fb = frames + (rd * G::FP1 + fl) * FRS;
-    float2 v[P1];
+    f2* fb = reinterpret_cast<f2*>(frames) + (rd * G::FP1 + fl) * FRS;
+    f2 v[P1];
 #pragma unroll
-    for (int r = 0; r < P1; r++) { const float2 z = fb[r * LA + j]; v[r] = CONJ ? cconjf(z) : z; }
-    f_dftp<P1>(v);
+    for (int r = 0; r < P1; r++) { const f2 z = fb[r * LA + j]; v[r] = CONJ ? f2{z.x, -z.y} : z; }
+    dftq<P1>(v);
 #pragma unroll
-    for (int k1 = 1; k1 < P1; k1++) v[k1] = cmulf(v[k1], twj[k1 * P2 + j]);
+    for (int k1 = 1; k1 < P1; k1++) v[k1] = cmulv(v[k1], twq[k1 * P2 + j]);
 #pragma unroll
     for (int k1 = 0; k1 < P1; k1++) fb[j * LB + k1] = v[k1];
   }
 #pragma unroll
   for (int rd = 0; rd < G::FPW / G::FP2; rd++) {               // pass 2: lane = (frame, k1)
     const int fl = lane / P1, k1 = lane % P1;
-    float2* fb = frames + (rd * G::FP2 + fl) * FRS;
-    float2 v[P2];
+    f2* fb = reinterpret_cast<f2*>(frames) + (rd * G::FP2 + fl) * FRS;
+    f2 v[P2];
 #pragma unroll
     for (int jp = 0; jp < P2; jp++) v[jp] = fb[jp * LB + k1];
-    f_dftp<P2>(v);
+    dftq<P2>(v);
 #pragma unroll
-    for (int k2 = 0; k2 < P2; k2++) fb[k2 * LB + k1] = CONJ ? cconjf(v[k2]) : v[k2];
+    for (int k2 = 0; k2 < P2; k2++) fb[k2 * LB + k1] = CONJ ? f2{v[k2].x, -v[k2].y} : v[k2];
   }
 }
 
