@@ -26,44 +26,6 @@ namespace {
 constexpr int A_M = 512, A_NF = 256, A_MT = 4, A_TT = 16, A_NT = 256;
 constexpr int FRS = 273;               // float2 per FFT frame buffer: 16 rows x 17 (+1: frame stride = 34 banks mod 64)
 
-__device__ __forceinline__ void dft4p(float2& a0, float2& a1, float2& a2, float2& a3)
-{
-  const float2 s02 = caddf(a0, a2), d02 = csubf(a0, a2);
-  const float2 s13 = caddf(a1, a3), d13 = cmul_i<+1>(csubf(a1, a3));
-  a0 = caddf(s02, s13); a1 = caddf(d02, d13); a2 = csubf(s02, s13); a3 = csubf(d02, d13);
-}
-
-// in-register 16-point DFT, positive exponent: v[k] <- sum_r v[r] e^{+j 2 pi r k / 16}
-__device__ __forceinline__ void dft16p(float2 (&v)[16])
-{
-  constexpr float C1 = 0.92387953251128674f, S1 = 0.38268343236508977f, H = 0.70710678118654752f;
-  // r = 4a + b: DFT4 over a for each b -> T[b][c] in v[4c' ...]; keep as t[b][c]
-  float2 t[4][4];
-#pragma unroll
-  for (int b = 0; b < 4; b++) {
-    float2 x0 = v[b], x1 = v[4 + b], x2 = v[8 + b], x3 = v[12 + b];
-    dft4p(x0, x1, x2, x3);
-    t[b][0] = x0; t[b][1] = x1; t[b][2] = x2; t[b][3] = x3;
-  }
-  // twiddle W16^{b c}
-  t[1][1] = cmulf(t[1][1], make_float2(C1, S1));
-  t[1][2] = cmulf(t[1][2], make_float2(H, H));
-  t[1][3] = cmulf(t[1][3], make_float2(S1, C1));
-  t[2][1] = cmulf(t[2][1], make_float2(H, H));
-  t[2][2] = cmul_i<+1>(t[2][2]);
-  t[2][3] = cmulf(t[2][3], make_float2(-H, H));
-  t[3][1] = cmulf(t[3][1], make_float2(S1, C1));
-  t[3][2] = cmulf(t[3][2], make_float2(-H, H));
-  t[3][3] = cmulf(t[3][3], make_float2(-C1, -S1));     // W16^9
-#pragma unroll
-  for (int c = 0; c < 4; c++) {
-    float2 y0 = t[0][c], y1 = t[1][c], y2 = t[2][c], y3 = t[3][c];
-    dft4p(y0, y1, y2, y3);
-    v[c] = y0; v[c + 4] = y1; v[c + 8] = y2; v[c + 12] = y3;   // k = c + 4 d
-  }
-}
-
-
 constexpr int WSTR = 320;              // float4 per channel in the weight-pair table: 257 used, padded to 5 x 64 for 1 KiB LDS-DMA pieces
 
 constexpr int A_RUN = 16;             // consecutive tiles (16 frames each) one workgroup walks through
@@ -689,20 +651,21 @@ void synthesis512_kernel(const float2* __restrict__ Y, long nframes, long T_stri
       const long f = fc0 + wave * 4 + fl;
       if (f >= f_lo) {
         const int slot = (int)(((f - f_lo) % NRING + NRING) % NRING);
-        float2* fb = ring + slot * FRS;
-        float2 v[16];
+        f2* fb = reinterpret_cast<f2*>(ring) + slot * FRS;
+        const f2* twq = reinterpret_cast<const f2*>(twj);
+        f2 v[16];
 #pragma unroll
-        for (int r = 0; r < 16; r++) v[r] = cconjf(fb[r * 17 + j]);
-        dft16p(v);
+        for (int r = 0; r < 16; r++) { const f2 z = fb[r * 17 + j]; v[r] = f2{z.x, -z.y}; }
+        dft16q(v);
 #pragma unroll
-        for (int k1 = 1; k1 < 16; k1++) v[k1] = cmulf(v[k1], twj[k1 * 16 + j]);
+        for (int k1 = 1; k1 < 16; k1++) v[k1] = cmulv(v[k1], twq[k1 * 16 + j]);
 #pragma unroll
         for (int k1 = 0; k1 < 16; k1++) fb[j * 17 + k1] = v[k1];
 #pragma unroll
         for (int jp = 0; jp < 16; jp++) v[jp] = fb[jp * 17 + j];
-        dft16p(v);
+        dft16q(v);
 #pragma unroll
-        for (int k2 = 0; k2 < 16; k2++) fb[k2 * 17 + j] = cconjf(v[k2]);     // z[n]: v[2n] = Re, v[2n+1] = Im
+        for (int k2 = 0; k2 < 16; k2++) fb[k2 * 17 + j] = f2{v[k2].x, -v[k2].y};     // z[n]: v[2n] = Re, v[2n+1] = Im
       }
     }
     __syncthreads();

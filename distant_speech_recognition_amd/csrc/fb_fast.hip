@@ -155,6 +155,80 @@ template <int LOG2M> __device__ __forceinline__ int zidx(int kappa)
   return (kappa >> G::LOG2P1) * G::LB + (kappa & (G::P1 - 1));
 }
 
+// Polyphase ownership.  With D = M / R the windows of the sample-pair indices n and n + M/(2 GP) (GP = 2 for R >= 2)
+// are the same LDS words shifted by CG = R / GP frames, so a thread owns GP such indices of NCL classes for FPT frames
+// and reads every word once: NW = FPT + (m-1) R + (GP-1) CG words for GP FPT outputs per class.
+//   V[i] = xs[(M - 2 - 2 n0 - (GP-1) M/GP) + (f0 + i) D];  index n0 + q NPG, frame f0 + g, tap k uses
+//   V[g + R (m-1-k) + (GP-1-q) CG]   (= xs[f D + m M - 2 - 2 n - M k], modulated.cc:380-392)
+template <int LOG2M, int R, bool PAIR = true> struct PP {
+  using G = FG<LOG2M>;
+  static constexpr int GP = (PAIR && R >= 2) ? 2 : 1;
+  static constexpr int NPG = G::NF / GP;                        // classes
+  static constexpr int NCL = NPG > F_NT ? NPG / F_NT : 1;       // classes per thread
+  static constexpr int NSP = NPG < F_NT ? F_NT / NPG : 1;       // frame groups when there are fewer classes than threads
+  static constexpr int FPT = G::TT / NSP;
+  static constexpr int CG = R / GP;
+  static constexpr int NW = FPT + (F_MT - 1) * R + (GP - 1) * CG;
+};
+
+template <int LOG2M, int R, bool PAIR>
+__device__ __forceinline__ void pp_taps(const float* __restrict__ proto, int tid, float2 (&h)[PP<LOG2M, R, PAIR>::NCL][PP<LOG2M, R, PAIR>::GP][F_MT])
+{
+  using P = PP<LOG2M, R, PAIR>;
+  constexpr int M = 1 << LOG2M;
+  const int n0 = (P::NPG >= F_NT) ? tid : (tid % P::NPG);
+#pragma unroll
+  for (int c = 0; c < P::NCL; c++)
+#pragma unroll
+    for (int q = 0; q < P::GP; q++)
+#pragma unroll
+      for (int k = 0; k < F_MT; k++)
+        h[c][q][k] = *reinterpret_cast<const float2*>(proto + 2 * (n0 + c * F_NT + q * P::NPG) + M * k);
+}
+
+template <int LOG2M, int R, bool PAIR>
+__device__ __forceinline__ void pp_pull(const float* __restrict__ xs, int tid, float2 (&win)[PP<LOG2M, R, PAIR>::NCL][PP<LOG2M, R, PAIR>::NW])
+{
+  using P = PP<LOG2M, R, PAIR>;
+  constexpr int M = 1 << LOG2M, D = M / R;
+  const int n0 = (P::NPG >= F_NT) ? tid : (tid % P::NPG);
+  const int f0 = (P::NPG >= F_NT) ? 0 : (tid / P::NPG) * P::FPT;
+#pragma unroll
+  for (int c = 0; c < P::NCL; c++) {
+    const float* wbase = xs + (M - 2 - 2 * (n0 + c * F_NT) - (P::GP - 1) * (M / P::GP)) + f0 * D;
+#pragma unroll
+    for (int i = 0; i < P::NW; i++) win[c][i] = *reinterpret_cast<const float2*>(wbase + i * D);
+  }
+}
+
+template <int LOG2M, int R, bool PAIR>
+__device__ __forceinline__ void pp_emit(float2* __restrict__ fbuf, int tid, const float2 (&win)[PP<LOG2M, R, PAIR>::NCL][PP<LOG2M, R, PAIR>::NW],
+                                        const float2 (&h)[PP<LOG2M, R, PAIR>::NCL][PP<LOG2M, R, PAIR>::GP][F_MT])
+{
+  using P = PP<LOG2M, R, PAIR>;
+  using G = FG<LOG2M>;
+  const int n0 = (P::NPG >= F_NT) ? tid : (tid % P::NPG);
+  const int f0 = (P::NPG >= F_NT) ? 0 : (tid / P::NPG) * P::FPT;
+#pragma unroll
+  for (int c = 0; c < P::NCL; c++)
+#pragma unroll
+    for (int q = 0; q < P::GP; q++) {
+      const int nn = n0 + c * F_NT + q * P::NPG;
+      const int zoff = (nn / G::P2) * G::LA + (nn % G::P2);
+#pragma unroll
+      for (int g = 0; g < P::FPT; g++) {
+        float p0 = 0.f, p1 = 0.f;
+#pragma unroll
+        for (int k = 0; k < F_MT; k++) {
+          const float2 x = win[c][g + R * (F_MT - 1 - k) + (P::GP - 1 - q) * P::CG];
+          p0 = fmaf(h[c][q][k].x, x.y, p0);
+          p1 = fmaf(h[c][q][k].y, x.x, p1);
+        }
+        fbuf[(f0 + g) * G::FRS + zoff] = make_float2(p0, p1);
+      }
+    }
+}
+
 constexpr int F_RUN = 8;       // consecutive tiles a workgroup walks through
 
 // ------------------------------------------------------------------------------------------------ analysis
@@ -166,7 +240,7 @@ void fast_analysis_kernel(const float* __restrict__ pcm, long nsamples, long pcm
                           long T_stride, long t0, long tcount, int ntiles, int nruns, int nchan)
 {
   using G = FG<LOG2M>;
-  constexpr int M = G::M, NF = G::NF, TT = G::TT, FRS = G::FRS, P2 = G::P2, LA = G::LA;
+  constexpr int M = G::M, NF = G::NF, TT = G::TT, FRS = G::FRS, P2 = G::P2;
   constexpr int D = M / R;
   constexpr int SPAN = (TT - 1) * D + F_MT * M;
   constexpr int FB_BYTES = TT * FRS * 8;
@@ -214,15 +288,9 @@ void fast_analysis_kernel(const float* __restrict__ pcm, long nsamples, long pcm
     }
   };
 
-  // pair indices owned by this thread and their taps
-  constexpr int NOWN = G::NOWN, FPT = G::FPT;
-  const int nbase = (NF >= F_NT) ? tid : (tid % NF);
-  const int f0 = (NF >= F_NT) ? 0 : (tid / NF) * FPT;
-  float2 h[NOWN][F_MT];
-#pragma unroll
-  for (int q = 0; q < NOWN; q++)
-#pragma unroll
-    for (int k = 0; k < F_MT; k++) h[q][k] = *reinterpret_cast<const float2*>(proto + 2 * (nbase + q * F_NT) + M * k);
+  using P = PP<LOG2M, R, true>;
+  float2 h[P::NCL][P::GP][F_MT];                                 // taps of the pair indices this thread owns
+  pp_taps<LOG2M, R, true>(proto, tid, h);
   const int s = chan / N, nch = chan % N;
   const long kstride = (long)N * T_stride;
   const float hg = 0.5f * gain;
@@ -240,31 +308,10 @@ void fast_analysis_kernel(const float* __restrict__ pcm, long nsamples, long pcm
 
     // ---- polyphase with register windows (all windows are pulled before the frames overwrite the span)
     {
-      constexpr int NW = FPT + (F_MT - 1) * R;
-      float2 win[NOWN][NW];
-#pragma unroll
-      for (int q = 0; q < NOWN; q++) {
-        const float* wbase = xs + (M - 2 - 2 * (nbase + q * F_NT)) + f0 * D;
-#pragma unroll
-        for (int i = 0; i < NW; i++) win[q][i] = *reinterpret_cast<const float2*>(wbase + i * D);
-      }
+      float2 win[P::NCL][P::NW];
+      pp_pull<LOG2M, R, true>(xs, tid, win);
       __syncthreads();
-#pragma unroll
-      for (int q = 0; q < NOWN; q++) {
-        const int n = nbase + q * F_NT;
-        const int zoff = (n / P2) * LA + (n % P2);
-#pragma unroll
-        for (int f = 0; f < FPT; f++) {
-          float p0 = 0.f, p1 = 0.f;
-#pragma unroll
-          for (int k = 0; k < F_MT; k++) {
-            const float2 x = win[q][f + R * (F_MT - 1 - k)];
-            p0 = fmaf(h[q][k].x, x.y, p0);
-            p1 = fmaf(h[q][k].y, x.x, p1);
-          }
-          fbuf[(f0 + f) * FRS + zoff] = make_float2(p0, p1);
-        }
-      }
+      pp_emit<LOG2M, R, true>(fbuf, tid, win, h);
     }
     __syncthreads();
 
