@@ -394,21 +394,24 @@ void analysis512_bfz_kernel(const float* __restrict__ pcm, long nsamples, long p
       for (int i = 0; i < NWG; i++) win[i] = *reinterpret_cast<const float2*>(wbase + i * D);
       if (!PIPE) __syncthreads();
       else __builtin_amdgcn_sched_barrier(0);            // keep the window reads back to back (one LDS latency, not NWG)
+      // tap-major order: consecutive FMAs belong to different outputs (no dependent back-to-back packed FMAs)
+      float2 po[G][FPT];
+#pragma unroll
+      for (int k = 0; k < A_MT; k++)
+#pragma unroll
+        for (int q = 0; q < G; q++)
+#pragma unroll
+          for (int g = 0; g < FPT; g++) {
+            const float2 x = win[g + R * (A_MT - 1 - k) + (G - 1 - q) * CG];
+            po[q][g].x = (k == 0) ? h[q][k].x * x.y : fmaf(h[q][k].x, x.y, po[q][g].x);
+            po[q][g].y = (k == 0) ? h[q][k].y * x.x : fmaf(h[q][k].y, x.x, po[q][g].y);
+          }
 #pragma unroll
       for (int q = 0; q < G; q++) {
         const int nn = n0 + q * NPG;
         const int zoff = (nn >> 4) * 17 + (nn & 15);
 #pragma unroll
-        for (int g = 0; g < FPT; g++) {
-          float p0 = 0.f, p1 = 0.f;
-#pragma unroll
-          for (int k = 0; k < A_MT; k++) {
-            const float2 x = win[g + R * (A_MT - 1 - k) + (G - 1 - q) * CG];
-            p0 = fmaf(h[q][k].x, x.y, p0);
-            p1 = fmaf(h[q][k].y, x.x, p1);
-          }
-          fbuf[(fg * FPT + g) * FRZ + zoff] = make_float2(p0, p1);
-        }
+        for (int g = 0; g < FPT; g++) fbuf[(fg * FPT + g) * FRZ + zoff] = po[q][g];
       }
     }
     __syncthreads();
