@@ -349,6 +349,7 @@ void analysis512_bfz_kernel(const float* __restrict__ pcm, long nsamples, long p
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(voff), "s"(gbase), "s"(lds_dst) : "memory");
   };
+  const int wv = __builtin_amdgcn_readfirstlane(wave);                          // wave index in an SGPR: piece bookkeeping stays scalar
   auto dma = [&](int n) {
     if (inb) {
       const float* src = pcm + ((long)s * N + n) * pcm_stride + g0;
@@ -356,17 +357,17 @@ void analysis512_bfz_kernel(const float* __restrict__ pcm, long nsamples, long p
       constexpr int NI = (NCH + 3) / 4;
 #pragma unroll
       for (int i = 0; i < NI; i++) {
-        const int c = __builtin_amdgcn_readfirstlane(wave + 4 * i);
+        const int c = wv + 4 * i;
         if (c < NCH) {
           const int l = c * 256 + lane * 4;
-          if (l < SPAN) glds16s(src, (unsigned)l * 4u, xs_lds + c * 1024);
+          if ((SPAN % 256) == 0 || l < SPAN) glds16s(src, (unsigned)l * 4u, xs_lds + c * 1024);
         }
       }
       const float4* wsrc = wts + (long)n * WSTR;
       const unsigned wq_lds = xs_lds + WQ_OFF + (n & 1) * (WSTR * 16);
 #pragma unroll
       for (int i = 0; i < 2; i++) {
-        const int c = __builtin_amdgcn_readfirstlane(wave + 4 * i);
+        const int c = wv + 4 * i;
         if (c < WSTR / 64) glds16s(wsrc, (unsigned)(c * 64 + lane) * 16u, wq_lds + c * 1024);
       }
     } else {
