@@ -23,7 +23,15 @@ HBM = 8.0e12
 FS = 16000.0
 
 
-def timed(torch, fn, n=3, warm=1):
+def timed(torch, fn, n=3, warm=1, prewarm_ms=40.0):
+    """(seconds per call, last result) after a wall-clock pre-warm: the GPU idles during the host-side set-up of a
+    stage and its clocks need tens of ms of load to come back up (same reason as bench.py --prewarm-ms)."""
+    import time
+    t0 = time.perf_counter()
+    r = None
+    while (time.perf_counter() - t0) * 1e3 < prewarm_ms:
+        r = fn()
+        torch.cuda.synchronize()
     for _ in range(warm):
         r = fn()
     torch.cuda.synchronize()

@@ -14,7 +14,14 @@ sys.path.insert(0, ROOT)
 HBM, FP32 = 8.0e12, 157.3e12
 
 
-def timeit(torch, fn, n=5, warm=2):
+def timeit(torch, fn, n=5, warm=2, prewarm_ms=40.0):
+    """HIP-event time per call after `warm` calls and a wall-clock pre-warm: host-side set-up between stages leaves the
+    GPU idle and its clocks need tens of ms of load to come back up (same reason as bench.py --prewarm-ms)."""
+    import time
+    t0 = time.perf_counter()
+    while (time.perf_counter() - t0) * 1e3 < prewarm_ms:
+        fn()
+        torch.cuda.synchronize()
     for _ in range(warm):
         fn()
     torch.cuda.synchronize()
