@@ -1,3 +1,6 @@
+"""Why bench.py read 1.80 ms for the fused kernel where profiles/fused_ab.py read 1.62: same kernels timed in loops with
+bench.py's own PCM generator and with noise, kernel alone and in the chain -- no data dependence; the gap was the GPU
+clock ramp after the seconds of host-side weight design (bench.py now pre-warms for 100 ms, --prewarm-ms)."""
 import os, sys, numpy as np, torch
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import bench
