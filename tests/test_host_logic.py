@@ -130,3 +130,20 @@ def test_tools_configuration_handling(tmp_path):
     mt, mj = sb.load_tfmasks({"target": {"tfmask_path": str(tmp_path / "m.npy")},
                               "noises": [{"tfmask_path": str(tmp_path / "m.pickle")}, {"tfmask_path": str(tmp_path / "m.npy")}]})
     assert np.array_equal(mt, rows) and np.allclose(mj, rows)
+
+
+def test_padded_rows_layout():
+    """engine.padded_rows: rows a multiple of 4 KiB long get 48 elements of padding (a [..., :T] view), other lengths stay
+    contiguous; _row_stride only takes device tensors (no CPU path)."""
+    import torch
+    from distant_speech_recognition_amd import engine as eng
+    y = eng.padded_rows((2, 257, 4096), torch.complex64, "cpu")            # 4096 * 8 B = 32 KiB rows
+    assert y.shape == (2, 257, 4096) and y.stride() == (257 * 4144, 4144, 1) and not y.is_contiguous()
+    z = eng.padded_rows((2, 257, 1000), torch.complex64, "cpu")
+    assert z.is_contiguous()
+    e = eng.padded_rows((3, 0), torch.float32, "cpu")
+    assert e.shape == (3, 0)
+    f = eng.padded_rows((4, 1024), torch.float32, "cpu")                   # 4 KiB rows of floats
+    assert f.stride() == (1072, 1)
+    with pytest.raises(ValueError):
+        eng._row_stride(y, "Y")
