@@ -347,12 +347,13 @@ void nlms_bin2_kernel(const float2* __restrict__ X, const float2* __restrict__ V
     __syncthreads();
     if (t0 + TBF < T) prefetch(t0 + TBF);
     float2 yout = make_float2(0.f, 0.f);
+    float uu = 0.f;
     const int nsteps = (T - t0) < TBF ? (int)(T - t0) : TBF;
 #pragma unroll
     for (int tt = 0; tt < TBF; tt++) {
       if (tt < nsteps) {
         float2 x[CPL];
-        float ycr = 0.f, yci = 0.f, pr = 0.f, pi = 0.f, xx = 0.f, uu = 0.f;
+        float ycr = 0.f, yci = 0.f, pr = 0.f, pi = 0.f, xx = 0.f;
 #pragma unroll
         for (int c = 0; c < CPL; c++) {
           x[c] = tile[(gi * NR + gl + GROUP * c) * LDWv + tt];
@@ -361,11 +362,18 @@ void nlms_bin2_kernel(const float2* __restrict__ X, const float2* __restrict__ V
           pr = fmaf(u[c].x, x[c].x, fmaf(-u[c].y, x[c].y, pr));
           pi = fmaf(u[c].x, x[c].y, fmaf(u[c].y, x[c].x, pi));
           xx = fmaf(x[c].x, x[c].x, fmaf(x[c].y, x[c].y, xx));
-          uu = fmaf(u[c].x, u[c].x, fmaf(u[c].y, u[c].y, uu));
         }
         ycr = group_sum2<GROUP>(ycr); yci = group_sum2<GROUP>(yci);
         pr = group_sum2<GROUP>(pr);   pi = group_sum2<GROUP>(pi);
-        xx = group_sum2<GROUP>(xx);   uu = group_sum2<GROUP>(uu);
+        xx = group_sum2<GROUP>(xx);
+        // |u|^2: summed from u at the first step of a tile, carried as cK^2 nrm (the same expansion the clip uses) after
+        // an update inside it -- rounding drift is bounded to TBF steps
+        if (tt == 0) {
+          float uup = 0.f;
+#pragma unroll
+          for (int c = 0; c < CPL; c++) uup = fmaf(u[c].x, u[c].x, fmaf(u[c].y, u[c].y, uup));
+          uu = group_sum2<GROUP>(uup);
+        }
 
         const long isamp = isamp0 + t0 + tt;
         float se = (isamp > 0) ? fmaf(sig, p.beta, (1.f - p.beta) * xx) : xx;
@@ -390,6 +398,7 @@ void nlms_bin2_kernel(const float2* __restrict__ X, const float2* __restrict__ V
             u[c] = make_float2(cK * nr, cK * ni);
           }
           sig = se;
+          uu = cK * cK * nrm;
           pnr = cK * (c1 * pr + c2r * gg);
           pni = cK * (c1 * pi + c2i * gg);
         }
