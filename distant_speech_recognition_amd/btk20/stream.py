@@ -1,7 +1,8 @@
 """FeatureStream protocol (stream/stream.h:16-54, stream/stream.i:145-154, stream/pyStream.h:25-168)."""
 import numpy as np
 
-from .common import jconsistency_error, jiterator_error
+from .._lib import BtkError
+from .common import jconsistency_error, jiterator_error, raise_from_code
 
 __all__ = ["FeatureStream", "VectorFloatFeatureStream", "VectorComplexFeatureStream",
            "PyVectorFloatFeatureStreamPtr", "PyVectorComplexFeatureStreamPtr", "device"]
@@ -153,9 +154,21 @@ class _PyFeatureStream(FeatureStream):
             self._iter = iter(self._obj)
         try:
             v = next(self._iter)
-        except (StopIteration, RuntimeError):
+        except StopIteration:
             self._is_end = True
             raise jiterator_error("end of samples!")
+        except RuntimeError as e:
+            # PEP 479: a StopIteration that escapes inside a generator body surfaces as
+            # RuntimeError(__cause__=StopIteration) -- that, and only that, is an end of stream.
+            # Anything else (BtkError from the C-ABI, torch/HIP failures) is an error, as in the
+            # reference where every exception but StopIteration becomes jpython_error
+            # (stream/pyStream.h:89-111).
+            if isinstance(e.__cause__, StopIteration):
+                self._is_end = True
+                raise jiterator_error("end of samples!")
+            if isinstance(e, BtkError):
+                raise_from_code(e)
+            raise
         v = np.asarray(v, self._dtype)
         if v.shape != (self._size,):
             raise jconsistency_error("Feature size mismatch (%d vs. %d)" % (v.size, self._size))

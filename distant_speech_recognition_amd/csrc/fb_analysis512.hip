@@ -20,6 +20,7 @@
 #include "fft_lds.h"
 #include "fft_packed.h"
 #include <cstdlib>
+#include <type_traits>
 
 namespace {
 
@@ -212,11 +213,8 @@ int launch512(const btk_fb* fb, const float* pcm, long nsamples, long pcm_stride
   const int nruns = (ntiles + A_RUN - 1) / A_RUN;
   const long nblocks = (long)((nchan + 7) / 8) * nruns * 8;
   auto kern = analysis512_kernel<R>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    BTK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_set = true;
-  }
+  // per launch: the attribute is per device, and one process may drive several GPUs (btk_set_device)
+  BTK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const float gain = fb->gain_factor > 0 ? (float)fb->gain_factor : 1.0f;
   static const int ablate = getenv("BTK_ANALYSIS512_ABLATE") ? atoi(getenv("BTK_ANALYSIS512_ABLATE")) : 0;   // diagnostics only
   hipLaunchKernelGGL(kern, dim3((unsigned)nblocks), dim3(A_NT), lds, st, pcm, nsamples, pcm_stride, fb->d_proto, fb->d_tw,
@@ -262,8 +260,14 @@ void analysis512_bfz_kernel(const float* __restrict__ pcm, long nsamples, long p
   // while channel n is transformed -- two workgroup barriers per channel instead of four.  Without it (R = 1: the span
   // alone is 38 KB) the span and the FFT frames share one region.
   constexpr bool PIPE = (VAR & 2) && R >= 2;
-  constexpr int FB_OFF = PIPE ? SPAN * 4 : 0;
-  constexpr int WQ_OFF = PIPE ? SPAN * 4 + FB_BYTES : REG_U;
+  // GW (VAR & 4, interior tiles): the polyphase window goes HBM -> registers directly (coalesced 8-byte loads, issued one
+  // channel ahead), the PCM span never enters LDS.  The LDS pipe is what bounds this kernel (profiles/ubench/lds_rate:
+  // ~64 B/clk per CU for writes, ~120 for 8-byte reads, ~230 for contiguous 16-byte reads; the bfz form moves 23 KiB of
+  // writes and 39 KiB of reads per wave and channel = ~630 of the ~680 cycles a channel takes per wave): dropping the
+  // span saves its 5.75 KiB of DMA writes and 7.5 KiB of window reads per wave and channel.
+  constexpr bool GW = PIPE && (VAR & 4);
+  constexpr int FB_OFF = (PIPE && !GW) ? SPAN * 4 : 0;
+  constexpr int WQ_OFF = PIPE ? FB_OFF + FB_BYTES : REG_U;
   float* xs = reinterpret_cast<float*>(smem);
   float2* fbuf = reinterpret_cast<float2*>(smem + FB_OFF);
   float4* wq = reinterpret_cast<float4*>(smem + WQ_OFF);                      // [1 or 2][WSTR] weight pairs of a channel
@@ -284,8 +288,10 @@ void analysis512_bfz_kernel(const float* __restrict__ pcm, long nsamples, long p
   float4 pre[NV4];
   float4 wpre;
   float2 w256pre;
+  const float* pcm_e = pcm;                  // the edge path's own copies of the two base pointers: laundered through an
+  const float4* wts_e = wts;                 // asm at its entry so that hipcc cannot hoist its loads above the branch
   auto fetch = [&](int n) {
-    const float* src = pcm + ((long)s * N + n) * pcm_stride;
+    const float* src = pcm_e + ((long)s * N + n) * pcm_stride;
     if (inb) {
 #pragma unroll
       for (int q = 0; q < NV4; q++) {
@@ -305,8 +311,8 @@ void analysis512_bfz_kernel(const float* __restrict__ pcm, long nsamples, long p
         pre[q] = make_float4(v[0], v[1], v[2], v[3]);
       }
     }
-    wpre = wts[(long)n * WSTR + tid];
-    const float4 t = wts[(long)n * WSTR + 256];
+    wpre = wts_e[(long)n * WSTR + tid];
+    const float4 t = wts_e[(long)n * WSTR + 256];
     w256pre = make_float2(t.x, t.y);
   };
 
@@ -324,6 +330,16 @@ void analysis512_bfz_kernel(const float* __restrict__ pcm, long nsamples, long p
   f2 twr[15];                                                                 // W_256^{j k1}, k1 = 1..15
 #pragma unroll
   for (int k1 = 1; k1 < 16; k1++) { const float2 t = twg[(2 * j * k1) & 511]; twr[k1 - 1] = f2{t.x, t.y}; }
+  // The taps and twiddles are first used inside the channel loop; without a use in front of it hipcc keeps their
+  // s_waitcnt vmcnt(k) inside the loop, where every iteration it also waits for the LDS-DMA of the NEXT channel that
+  // was issued a few instructions earlier (vector-memory counters retire in order): the latency the DMA is meant
+  // to hide lands in the middle of the FFT.  An empty asm that reads them retires those loads here.
+#pragma unroll
+  for (int q = 0; q < G; q++)
+#pragma unroll
+    for (int k = 0; k < A_MT; k++) asm volatile("" : "+v"(h[q][k].x), "+v"(h[q][k].y));
+#pragma unroll
+  for (int k1 = 0; k1 < 15; k1++) asm volatile("" : "+v"(twr[k1]));
   f2 accA[16], accB[16];
 #pragma unroll
   for (int k2 = 0; k2 < 16; k2++) { accA[k2] = f2{0.f, 0.f}; accB[k2] = f2{0.f, 0.f}; }
@@ -350,17 +366,19 @@ void analysis512_bfz_kernel(const float* __restrict__ pcm, long nsamples, long p
                  : "=&s"(keep) : "v"(voff), "s"(gbase), "s"(lds_dst) : "memory");
   };
   const int wv = __builtin_amdgcn_readfirstlane(wave);                          // wave index in an SGPR: piece bookkeeping stays scalar
-  auto dma = [&](int n) {
-    if (inb) {
-      const float* src = pcm + ((long)s * N + n) * pcm_stride + g0;
-      constexpr int NCH = (SPAN * 4 + 1023) / 1024;
-      constexpr int NI = (NCH + 3) / 4;
+  auto dma = [&](int n, auto fast) {
+    if constexpr (decltype(fast)::value) {
+      if constexpr (!GW) {
+        const float* src = pcm + ((long)s * N + n) * pcm_stride + g0;
+        constexpr int NCH = (SPAN * 4 + 1023) / 1024;
+        constexpr int NI = (NCH + 3) / 4;
 #pragma unroll
-      for (int i = 0; i < NI; i++) {
-        const int c = wv + 4 * i;
-        if (c < NCH) {
-          const int l = c * 256 + lane * 4;
-          if ((SPAN % 256) == 0 || l < SPAN) glds16s(src, (unsigned)l * 4u, xs_lds + c * 1024);
+        for (int i = 0; i < NI; i++) {
+          const int c = wv + 4 * i;
+          if (c < NCH) {
+            const int l = c * 256 + lane * 4;
+            if ((SPAN % 256) == 0 || l < SPAN) glds16s(src, (unsigned)l * 4u, xs_lds + c * 1024);
+          }
         }
       }
       const float4* wsrc = wts + (long)n * WSTR;
@@ -376,12 +394,27 @@ void analysis512_bfz_kernel(const float* __restrict__ pcm, long nsamples, long p
     }
   };
 
-  if (PIPE) dma(0);
-  else fetch(0);
-  for (int n = 0; n < N; n++) {
+  // The channel loop exists twice: interior tiles (FAST: the loads of the loop are the asm LDS-DMA and, with GW, the window
+  // loads; no edge-path load can be pending in it) and edge tiles (register staging through the span region, guarded
+  // loads, compiler-managed waits).  One loop with a runtime branch let hipcc hoist edge-path loads above the branch.
+  float2 win[NWG];                            // polyphase window of the channel about to be transformed (GW: loaded a channel ahead)
+  auto channels = [&](auto fast) {
+  constexpr bool FAST = decltype(fast)::value;
+  constexpr bool GWF = GW && FAST;            // edge tiles of the GW form stage the span through the frame region (see below)
+  if constexpr (!FAST) asm volatile("" : "+s"(pcm_e), "+s"(wts_e));
+  // GW: V[i] of channel n straight from HBM / L2 (8-byte loads, 512 contiguous bytes per wave-instruction)
+  auto wload = [&](float2 (&win)[NWG], int n) {
+    const float* wsrc = pcm + ((long)s * N + n) * pcm_stride + g0 + (A_M - 2 - 2 * n0 - (G - 1) * (A_M / G)) + fg * FPT * D;
+#pragma unroll
+    for (int i = 0; i < NWG; i++) win[i] = *reinterpret_cast<const float2*>(wsrc + i * D);
+  };
+  // SHARED: the PCM span is staged through registers into the region the FFT frames overwrite (R = 1, and the edge
+  // tiles of the GW form): four barriers per channel instead of two
+  constexpr bool SHARED = !PIPE || (GW && !FAST);
+  auto body = [&](int n, float2 (&win)[NWG]) {
     // ---- phase 1: registers -> LDS (PCM span + weight pairs)
-    if (!PIPE) stage(0);
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // the LDS-DMA of channel n has landed
+    if (SHARED) stage(PIPE ? (n & 1) : 0);
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // the LDS-DMA of channel n (and, GW, its window) has landed
     __syncthreads();
     const int wbuf = PIPE ? (n & 1) : 0;
 
@@ -389,12 +422,13 @@ void analysis512_bfz_kernel(const float* __restrict__ pcm, long nsamples, long p
     //      V[i] = xs[(M - 2 - 2 n0 - (G-1) 512/G) + (f0 + i) D]; index n0 + q NPG, frame f0 + g, tap k uses
     //      V[g + R (m-1-k) + (G-1-q) CG]  (= xs[f D + m M - 2 - 2 n - M k], modulated.cc:380-392)
     {
-      float2 win[NWG];
-      const float* wbase = xs + (A_M - 2 - 2 * n0 - (G - 1) * (A_M / G)) + fg * FPT * D;
+      if constexpr (!GWF) {
+        const float* wbase = xs + (A_M - 2 - 2 * n0 - (G - 1) * (A_M / G)) + fg * FPT * D;
 #pragma unroll
-      for (int i = 0; i < NWG; i++) win[i] = *reinterpret_cast<const float2*>(wbase + i * D);
-      if (!PIPE) __syncthreads();
-      else __builtin_amdgcn_sched_barrier(0);            // keep the window reads back to back (one LDS latency, not NWG)
+        for (int i = 0; i < NWG; i++) win[i] = *reinterpret_cast<const float2*>(wbase + i * D);
+        if (SHARED) __syncthreads();                     // the frames overwrite the span
+        else __builtin_amdgcn_sched_barrier(0);          // keep the window reads back to back (one LDS latency, not NWG)
+      }
       // tap-major order: consecutive FMAs belong to different outputs (no dependent back-to-back packed FMAs)
       float2 po[G][FPT];
 #pragma unroll
@@ -416,9 +450,13 @@ void analysis512_bfz_kernel(const float* __restrict__ pcm, long nsamples, long p
       }
     }
     __syncthreads();
-    if (PIPE) {
-      if (n + 1 < N) dma(n + 1);          // every window read of channel n is behind the barrier; lands under phases 3-4
-    } else if (n + 1 < N) fetch(n + 1);   // lands under phases 3-4
+    if (n + 1 < N) {
+      if (SHARED) fetch(n + 1);           // lands under phases 3-4
+      else {
+        dma(n + 1, fast);                 // every window read of channel n is behind the barrier; lands under phases 3-4
+        if constexpr (GWF) wload(win, n + 1);
+      }
+    }
 
     // ---- phase 3: wave-private 256-point FFT of 4 frames; the result stays in registers
     f2 v[16];
@@ -460,8 +498,15 @@ void analysis512_bfz_kernel(const float* __restrict__ pcm, long nsamples, long p
       acc256.x = fmaf(w256.x, r, acc256.x);
       acc256.y = fmaf(-w256.y, r, acc256.y);
     }
-    if (!PIPE) __syncthreads();                                       // frames and weight pairs consumed
-  }
+    if (SHARED) __syncthreads();                                      // frames and weight pairs consumed
+  };
+  if (SHARED) fetch(0);
+  else dma(0, fast);
+  if constexpr (GWF) wload(win, 0);
+  for (int n = 0; n < N; n++) body(n, win);
+  };
+  if (PIPE && inb) channels(std::true_type{});
+  else channels(std::false_type{});
 
   if (PIPE) __syncthreads();
   // ---- once per tile: B[k] = B'[(256-k)&255] through the wave's own frame buffers, Hermitian post-pass,
@@ -531,21 +576,21 @@ int launch512_bf(const btk_fb* fb, const float* pcm, long nsamples, long pcm_str
   const long nblocks = (long)8 * tiles_per_xcd * S;
   const float gain = fb->gain_factor > 0 ? (float)fb->gain_factor : 1.0f;
   float4* Wq = static_cast<float4*>(scratch);
-  // BTK_FUSED_VAR = 1 (diagnostics): register staging with the span and the frames sharing one LDS region -- the only
-  // form for R = 1, whose 38 KB span leaves no room for a separate region; default 3: LDS-DMA staging
-  static const int var = getenv("BTK_FUSED_VAR") ? atoi(getenv("BTK_FUSED_VAR")) : 3;
+  // BTK_FUSED_VAR (diagnostics, read once): 1 = register staging with the span and the frames sharing one LDS region (the only
+  // form for R = 1, whose 38 KB span leaves no room for a separate region), 3 = LDS-DMA staging of the span,
+  // 7 (default for R = 2) = polyphase window straight from HBM, only frames and weights in LDS
+  static const int var = getenv("BTK_FUSED_VAR") ? atoi(getenv("BTK_FUSED_VAR")) : (R == 2 ? 7 : 3);
   const bool pipe = (var & 2) && R >= 2;
+  const bool gw = pipe && (var & 4) && R == 2;
   const int fbz = A_TT * 272 * 8;
   const int regz = SPAN * 4 > fbz ? SPAN * 4 : fbz;
-  const size_t lds = pipe ? (size_t)SPAN * 4 + fbz + sizeof(float4) * WSTR * 2 : (size_t)regz + sizeof(float4) * WSTR;
+  const size_t lds = pipe ? (size_t)(gw ? 0 : SPAN * 4) + fbz + sizeof(float4) * WSTR * 2 : (size_t)regz + sizeof(float4) * WSTR;
   const long nw = (long)Sw * N * WSTR;
   hipLaunchKernelGGL(pair_weights_kernel, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, st, W, Wq, K, N, Sw);
   auto kern = pipe ? analysis512_bfz_kernel<R, 3> : analysis512_bfz_kernel<R, 1>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    BTK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_set = true;
-  }
+  if (gw) kern = analysis512_bfz_kernel<2, 7>;
+  // per launch: the attribute is per device, and one process may drive several GPUs (btk_set_device)
+  BTK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(kern, dim3((unsigned)nblocks), dim3(A_NT), lds, st, pcm, nsamples, pcm_stride, fb->d_proto, fb->d_tw,
                      fb->laN, gain, N, K, Wq, per_stream ? (long)N * WSTR : 0L, Y, T_stride, t0, tcount, ntiles, tiles_per_xcd, S);
   BTK_HIP_CHECK(hipGetLastError());
@@ -724,11 +769,8 @@ int launch_syn512(const btk_fb* fb, const float2* Y, long nframes, long T_stride
   constexpr int NRING = 16 + HALO + 1;
   const size_t lds = sizeof(float2) * ((size_t)NRING * FRS + A_NF + 1 + 256);
   auto kern = synthesis512_kernel<R>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    BTK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_set = true;
-  }
+  // per launch: the attribute is per device, and one process may drive several GPUs (btk_set_device)
+  BTK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   // run length: S_RUN blocks amortise the m R - 1 frame ring priming best, but few streams need shorter runs to fill
   // the chip (a single stream of 4096 blocks would be 32 workgroups); multiples of the 16-frame chunk, >= 512 runs
   long srun = ((bcount * S / 512 + 15) / 16) * 16;

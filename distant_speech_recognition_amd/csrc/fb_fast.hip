@@ -361,11 +361,8 @@ int launch_fast_analysis(const btk_fb* fb, const float* pcm, long nsamples, long
   const int nruns = (ntiles + F_RUN - 1) / F_RUN;
   const long nblocks = (long)((nchan + 7) / 8) * nruns * 8;
   auto kern = fast_analysis_kernel<LOG2M, R>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    BTK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_set = true;
-  }
+  // per launch: the attribute is per device, and one process may drive several GPUs (btk_set_device)
+  BTK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const float gain = fb->gain_factor > 0 ? (float)fb->gain_factor : 1.0f;
   hipLaunchKernelGGL(kern, dim3((unsigned)nblocks), dim3(F_NT), lds, st, pcm, nsamples, pcm_stride, fb->d_proto, fb->d_tw,
                      fb->laN, gain, N, fb->K, X, T_stride, t0, tcount, ntiles, nruns, nchan);
@@ -590,11 +587,8 @@ int launch_fast_analysis_bf(const btk_fb* fb, const float* pcm, long nsamples, l
   const int tiles_per_xcd = (ntiles + 7) / 8;
   const long nblocks = (long)8 * tiles_per_xcd * S;
   auto kern = fast_analysis_bf_kernel<LOG2M, R>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    BTK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_set = true;
-  }
+  // per launch: the attribute is per device, and one process may drive several GPUs (btk_set_device)
+  BTK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const float gain = fb->gain_factor > 0 ? (float)fb->gain_factor : 1.0f;
   hipLaunchKernelGGL(kern, dim3((unsigned)nblocks), dim3(F_NT), lds, st, pcm, nsamples, pcm_stride, fb->d_proto, fb->d_tw,
                      fb->laN, gain, N, K, Wt, per_stream ? (long)N * K : 0L, Y, T_stride, t0, tcount, ntiles, tiles_per_xcd, S);
@@ -792,11 +786,8 @@ int launch_fast_synthesis(const btk_fb* fb, const float2* Y, long nframes, long 
   const size_t lds = sizeof(float2) * ((size_t)NRING * G::FRS + G::NF);
   if (lds > 160 * 1024) return 0;
   auto kern = fast_synthesis_kernel<LOG2M, R>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    BTK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_set = true;
-  }
+  // per launch: the attribute is per device, and one process may drive several GPUs (btk_set_device)
+  BTK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   // shorter runs when few streams would leave the chip empty (see synthesis512): multiples of TT, aiming at >= 512 runs
   long srun = ((bcount * S / 512 + G::TT - 1) / G::TT) * G::TT;
   srun = srun < 2 * G::TT ? 2 * G::TT : (srun > F_SRUN ? F_SRUN : srun);
