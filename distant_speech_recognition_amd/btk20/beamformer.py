@@ -520,14 +520,14 @@ class SubbandMVDRPtr(SubbandDSPtr):
         engine.mvdr_diagonal_loading(self._R[fbin_no], diagonal_weight)
 
     def divide_nondiagonal_elements(self, fbin_no, mu):
-        import torch
-        N = self.chan_num()
-        eye = torch.eye(N, device=device(), dtype=torch.bool)
-        self._R[fbin_no] = torch.where(eye, self._R[fbin_no], self._R[fbin_no] / (1.0 + mu))
+        if self._R is None:
+            raise j_error("Construct first a noise covariance matrix\n")
+        engine.mvdr_divide_nondiagonal(self._R[fbin_no:fbin_no + 1], mu)      # in place on the bin's slice
 
     def divide_all_nondiagonal_elements(self, mu):
-        for k in range(self._K):
-            self.divide_nondiagonal_elements(k, mu)
+        if self._R is None:
+            raise j_error("Construct first a noise covariance matrix\n")
+        engine.mvdr_divide_nondiagonal(self._R, mu)                            # bins 0..M/2 (beamformer.h:357-360)
 
     def calc_mvdr_weights(self, samplerate, dthreshold=1.0e-8, calc_inverse_matrix=True):
         import torch

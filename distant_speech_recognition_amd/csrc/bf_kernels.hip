@@ -75,9 +75,10 @@ void bf_apply_kernel(const float2* __restrict__ W, long w_stream_stride, const f
 extern "C" int btk_bf_apply(const void* W, int per_stream_weights, const void* X, void* Y,
                             int S, int K, int N, long T_stride, long T, void* stream)
 {
-  if (S <= 0 || K <= 0 || N <= 0 || T < 0 || T_stride < T)
+  if (S <= 0 || K < 0 || N <= 0 || T < 0 || T_stride < T)
     return btk_set_error(BTK_ERR_DIMENSION, "btk_bf_apply: bad sizes S=%d K=%d N=%d T=%ld T_stride=%ld", S, K, N, T, T_stride);
-  if (T == 0) return BTK_OK;
+  if (T == 0 || K == 0) return BTK_OK;                  // K == 0: the empty bin shard of a trailing rank (sharding.py)
+  if (!W || !X || !Y) return btk_set_error(BTK_ERR_PARAMETER, "btk_bf_apply: null argument");
   const long wss = per_stream_weights ? (long)K * N : 0;
   const bool vec = (T_stride % 2 == 0) && ((reinterpret_cast<uintptr_t>(X) & 15) == 0) &&
                    ((reinterpret_cast<uintptr_t>(Y) & 15) == 0);

@@ -293,9 +293,8 @@ extern "C" int btk_weights_mainlobe_2(int M, int N, float samplerate, const doub
 
 // LCMV quiescent weights with NC >= 2 constraints (look direction + NC-1 nulls): BeamformerWeights::calcMainlobeN
 // (reference beamformer/beamformer.cc:600-721).  NC = 2 is btk_weights_mainlobe_2 (closed-form 2x2 inverse); for
-// NC > 2 the reference inverts the NC x NC Gram matrix C^H C with its float32 SVD pseudoinverse (:352-355) -- here a
-// float64 Gauss-Jordan inverse with partial pivoting (same result to float32 precision for the well-conditioned
-// Gram matrices of distinct directions; a singular Gram matrix is reported as BTK_ERR_NUMERIC).
+// NC > 2 the reference inverts the NC x NC Gram matrix C^H C with pseudoinverse(invMat, invMat) (:352-355): float32
+// SVD, singular values below 1e-8 zeroed, the return value ignored -- btk_pinv (pinv_host.hip) has exactly that rule.
 namespace {
 bool lcmv_solve_n(cd* wt, const std::vector<std::vector<cd> >& wj, int N, int NC)
 {
@@ -307,21 +306,8 @@ bool lcmv_solve_n(cd* wt, const std::vector<std::vector<cd> >& wj, int N, int NC
       for (int i = 0; i < N; i++) acc += std::conj(col(a, i)) * col(b, i);
       G[(size_t)a * NC + b] = acc;
     }
-  for (int a = 0; a < NC; a++) inv[(size_t)a * NC + a] = cd(1, 0);
-  for (int c = 0; c < NC; c++) {
-    int piv = c;
-    for (int r = c + 1; r < NC; r++) if (std::abs(G[(size_t)r * NC + c]) > std::abs(G[(size_t)piv * NC + c])) piv = r;
-    if (!(std::abs(G[(size_t)piv * NC + c]) > 1.0e-12)) return false;
-    if (piv != c)
-      for (int b = 0; b < NC; b++) { std::swap(G[(size_t)c * NC + b], G[(size_t)piv * NC + b]); std::swap(inv[(size_t)c * NC + b], inv[(size_t)piv * NC + b]); }
-    const cd d = G[(size_t)c * NC + c];
-    for (int b = 0; b < NC; b++) { G[(size_t)c * NC + b] /= d; inv[(size_t)c * NC + b] /= d; }
-    for (int r = 0; r < NC; r++) {
-      if (r == c) continue;
-      const cd f = G[(size_t)r * NC + c];
-      for (int b = 0; b < NC; b++) { G[(size_t)r * NC + b] -= f * G[(size_t)c * NC + b]; inv[(size_t)r * NC + b] -= f * inv[(size_t)c * NC + b]; }
-    }
-  }
+  if (btk_pinv(reinterpret_cast<const double*>(G.data()), NC, NC, 1.0e-8f, reinterpret_cast<double*>(inv.data()), nullptr) != BTK_OK)
+    return false;
   // wt <- C inv g, g = e_0
   std::vector<cd> out(N);
   for (int i = 0; i < N; i++) {

@@ -40,6 +40,14 @@ __global__ void diag_load_kernel(float2* __restrict__ R, int N, float w)
   for (int c = threadIdx.x; c < N; c += blockDim.x) Rk[(long)c * N + c].x += w;
 }
 
+// R_xy /= (1 + mu) for x != y  (SubbandMVDR::divide_nondiagonal_elements, beamformer.cc:2589-2599)
+__global__ void divide_nondiag_kernel(float2* __restrict__ R, int N, float inv1pmu)
+{
+  float2* Rk = R + (long)blockIdx.x * N * N;
+  for (int idx = threadIdx.x; idx < N * N; idx += blockDim.x)
+    if (idx / N != idx % N) { Rk[idx].x *= inv1pmu; Rk[idx].y *= inv1pmu; }
+}
+
 // One workgroup per bin.  A (N x N, row-major, lower triangle used) lives in `mat` (LDS or global).
 // Right-looking Cholesky A = L L^H, then forward/back substitution for L y = d, L^H z = y.
 template <bool IN_LDS>
@@ -47,7 +55,8 @@ __global__ __launch_bounds__(256)
 void mvdr_solve_kernel(const float2* __restrict__ R, const float2* __restrict__ Dq /* [K][N] d=wq */,
                        float2* __restrict__ Wout /* [K][N] or null */, float2* __restrict__ scratch,
                        int N, float threshold, int* __restrict__ fallback_count,
-                       float2* __restrict__ lambda_out /* [K] or null: d^H invR d */, int k_offset /* global index of bin 0 */)
+                       float2* __restrict__ lambda_out /* [K] or null: d^H invR d */, int k_offset /* global index of bin 0 */,
+                       int* __restrict__ fail_flags /* [K] or null: 1 where the Cholesky factorisation stopped */)
 {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int k = blockIdx.x;
@@ -62,7 +71,7 @@ void mvdr_solve_kernel(const float2* __restrict__ R, const float2* __restrict__ 
   const bool dc_bin = (k + k_offset) == 0;
   if (dc_bin && Wout) {                                            // wmvdr_[0] = ones (calc_mvdr_weights starts at bin 1)
     for (int c = tid; c < N; c += 256) Wout[(long)k * N + c] = make_float2(1.f, 0.f);
-    if (!lambda_out) return;
+    if (!lambda_out) { if (fail_flags && tid == 0) fail_flags[k] = 0; return; }
   }
   for (int idx = tid; idx < N * N; idx += 256) mat[idx] = Rk[idx];
   for (int c = tid; c < N; c += 256) rhs[c] = Dq[(long)k * N + c];
@@ -99,8 +108,10 @@ void mvdr_solve_kernel(const float2* __restrict__ R, const float2* __restrict__ 
     __syncthreads();
   }
   __syncthreads();
+  if (fail_flags && tid == 0) fail_flags[k] = bad ? 1 : 0;
   if (bad) {
-    // pseudoinverse() reported failure -> invR = identity -> tmpH = d  (beamformer.cc:2381-2383)
+    // pseudoinverse() reported failure -> invR = identity -> tmpH = d  (beamformer.cc:2381-2383); callers that need the
+    // reference's result for matrices that are not positive definite re-solve the flagged bins (btk_mvdr_pinv_fallback)
     if (tid == 0) atomicAdd(fallback_count, 1);
   } else {
     // forward substitution L y = d (column sweep)
@@ -174,7 +185,7 @@ int btk_mvdr_diagonal_loading(void* R, int nbins, int N, float weight, void* str
 }
 
 static int mvdr_solve(const void* R, const void* wq, void* W, void* lambda_out, int K, int N, float threshold,
-                      void* scratch, int* fallback_count, void* stream, int k_offset = 0)
+                      void* scratch, int* fallback_count, void* stream, int k_offset = 0, int* fail_flags = nullptr)
 {
   if (!R || !wq || !fallback_count) return btk_set_error(BTK_ERR_PARAMETER, "btk_mvdr_weights: null argument");
   if (K < 1 || N < 1) return btk_set_error(BTK_ERR_DIMENSION, "btk_mvdr_weights: bad sizes");
@@ -185,12 +196,12 @@ static int mvdr_solve(const void* R, const void* wq, void* W, void* lambda_out, 
       BTK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_mat));
     hipLaunchKernelGGL(kern, dim3((unsigned)K), dim3(256), lds_mat, as_stream(stream), static_cast<const float2*>(R),
                        static_cast<const float2*>(wq), static_cast<float2*>(W), nullptr, N, threshold, fallback_count,
-                       static_cast<float2*>(lambda_out), k_offset);
+                       static_cast<float2*>(lambda_out), k_offset, fail_flags);
   } else {
     if (!scratch) return btk_set_error(BTK_ERR_PARAMETER, "btk_mvdr_weights: N=%d needs a [K][N][N] complex64 scratch buffer", N);
     hipLaunchKernelGGL(mvdr_solve_kernel<false>, dim3((unsigned)K), dim3(256), 2064 + sizeof(float2) * N, as_stream(stream),
                        static_cast<const float2*>(R), static_cast<const float2*>(wq), static_cast<float2*>(W),
-                       static_cast<float2*>(scratch), N, threshold, fallback_count, static_cast<float2*>(lambda_out), k_offset);
+                       static_cast<float2*>(scratch), N, threshold, fallback_count, static_cast<float2*>(lambda_out), k_offset, fail_flags);
   }
   BTK_HIP_CHECK(hipGetLastError());
   return BTK_OK;
@@ -209,6 +220,24 @@ int btk_mvdr_weights_shard(const void* R, const void* wq, void* W, int K, int N,
   if (!W) return btk_set_error(BTK_ERR_PARAMETER, "btk_mvdr_weights_shard: null argument");
   if (first_bin < 0) return btk_set_error(BTK_ERR_DIMENSION, "btk_mvdr_weights_shard: first_bin = %d", first_bin);
   return mvdr_solve(R, wq, W, nullptr, K, N, threshold, scratch, fallback_count, stream, first_bin);
+}
+
+int btk_mvdr_weights_flags(const void* R, const void* wq, void* W, int K, int N, int first_bin, float threshold,
+                           void* scratch, int* fallback_count, int* fail_flags, void* stream)
+{
+  if (!W || !fail_flags) return btk_set_error(BTK_ERR_PARAMETER, "btk_mvdr_weights_flags: null argument");
+  if (first_bin < 0) return btk_set_error(BTK_ERR_DIMENSION, "btk_mvdr_weights_flags: first_bin = %d", first_bin);
+  return mvdr_solve(R, wq, W, nullptr, K, N, threshold, scratch, fallback_count, stream, first_bin, fail_flags);
+}
+
+int btk_mvdr_divide_nondiagonal(void* R, int nbins, int N, float mu, void* stream)
+{
+  if (!R) return btk_set_error(BTK_ERR_PARAMETER, "Construct first a noise covariance matrix");
+  if (nbins < 1 || N < 1) return btk_set_error(BTK_ERR_DIMENSION, "btk_mvdr_divide_nondiagonal: bad sizes");
+  hipLaunchKernelGGL(divide_nondiag_kernel, dim3((unsigned)nbins), dim3(256), 0, as_stream(stream), static_cast<float2*>(R), N,
+                     (float)(1.0 / (1.0 + (double)mu)));
+  BTK_HIP_CHECK(hipGetLastError());
+  return BTK_OK;
 }
 
 int btk_mvdr_lambda(const void* R, const void* d, void* lambda, int K, int N, float threshold,

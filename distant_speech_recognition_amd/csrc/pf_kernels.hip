@@ -100,7 +100,7 @@ void zelinski_iir_kernel(float2* __restrict__ Y, const float2* __restrict__ Cc, 
       float Wf = (num / ps) * scale;
       if (Wf >= 1.0f) Wf = 1.0f;
       if (Wf < 1.0e-4f) Wf = 1.0e-4f;
-      if (apply) {
+      if (apply && type != 0) {                                 // NO_USE_POST_FILTER: the CSDs are just updated (postfilter.cc:197-199)
         float2 y = Y[row * T_stride + t];
         Y[row * T_stride + t] = make_float2(Wf * y.x, Wf * y.y);
       }

@@ -34,6 +34,20 @@ def _need_cuda(t, name):
         raise ValueError("%s must be contiguous" % name)
 
 
+def _check(t, name, dtype, shape):
+    """The C-ABI sees raw pointers: dtype, residency, contiguity and shape are checked here.  shape: an int (number of
+    dimensions) or a tuple whose None entries are free."""
+    _need_cuda(t, name)
+    if t.dtype != dtype:
+        raise _lib.BtkError(_lib.BTK_ERR_DIMENSION, "%s must be %s, got %s" % (name, dtype, t.dtype))
+    if isinstance(shape, int):
+        ok = t.dim() == shape
+    else:
+        ok = t.dim() == len(shape) and all(e is None or int(e) == int(g) for e, g in zip(shape, t.shape))
+    if not ok:
+        raise _lib.BtkError(_lib.BTK_ERR_DIMENSION, "%s has shape %s, expected %s" % (name, tuple(t.shape), shape))
+
+
 def _row_stride(t, name):
     """Row stride (in elements) of a cuda tensor [..., rows, T] whose rows are contiguous and evenly spaced -- a contiguous
     tensor or a [..., :T] view of a buffer with padded rows (the C-ABI takes T_stride >= T everywhere)."""
@@ -92,14 +106,16 @@ class FilterBank:
 
     def analysis(self, pcm, nsamples=None, t0=0, tcount=None, out=None):
         """pcm float32 [S][N][L] (cuda) -> X complex64 [S][K][N][T]."""
-        _need_cuda(pcm, "pcm")
+        _check(pcm, "pcm", torch.float32, 3)
         S, N, L = pcm.shape
         nsamples = L if nsamples is None else nsamples
         if tcount is None:
             tcount = self.num_frames(nsamples) - t0
         if out is None:
             out = torch.empty((S, self.K, N, tcount), dtype=torch.complex64, device=pcm.device)
-        _need_cuda(out, "X")
+        _check(out, "X", torch.complex64, (S, self.K, N, None))
+        if out.shape[3] < tcount:
+            raise _lib.BtkError(_lib.BTK_ERR_DIMENSION, "X holds %d frames, %d requested" % (out.shape[3], tcount))
         check(_lib.lib().btk_fb_analysis(self._h, _ptr(pcm), nsamples, L, S, N, _ptr(out), out.shape[3], t0, tcount, _stream()))
         return out
 
@@ -117,19 +133,25 @@ class FilterBank:
     def analysis_beamform(self, pcm, W, nsamples=None, t0=0, tcount=None, out=None):
         """Fused analysis -> fixed-weight beamformer: pcm [S][N][L], W complex64 [S|1][K][N] -> Y [S][K][T]
         (the N x K snapshots are not written to HBM)."""
-        _need_cuda(pcm, "pcm"); _need_cuda(W, "W")
+        _check(pcm, "pcm", torch.float32, 3)
         S, N, L = pcm.shape
         nsamples = L if nsamples is None else nsamples
         if tcount is None:
             tcount = self.num_frames(nsamples) - t0
         if W.dim() == 2:
             W = W.unsqueeze(0)
+        _check(W, "W", torch.complex64, (None, self.K, N))
+        if W.shape[0] not in (1, S):
+            raise _lib.BtkError(_lib.BTK_ERR_DIMENSION, "weights %s do not match pcm %s" % (tuple(W.shape), tuple(pcm.shape)))
         per_stream = int(W.shape[0] == S and S > 1)
         if out is None:
             fused = self.M in (256, 512) and self.m == 4 and self.r <= 2          # the staged fall-back needs contiguous rows
             out = (padded_rows((S, self.K, tcount), torch.complex64, pcm.device) if fused
                    else torch.empty((S, self.K, tcount), dtype=torch.complex64, device=pcm.device))
         t_stride = _row_stride(out, "Y")          # out may be a [..., :T] view of a row-padded buffer
+        if out.dtype != torch.complex64 or tuple(out.shape[:2]) != (S, self.K) or out.shape[2] < tcount:
+            raise _lib.BtkError(_lib.BTK_ERR_DIMENSION, "Y must be complex64 [%d][%d][>=%d], got %s %s"
+                                % (S, self.K, tcount, out.dtype, tuple(out.shape)))
         nb = _lib.lib().btk_fb_analysis_bf_scratch_bytes(self._h, S, N, per_stream, tcount)
         if getattr(self, "_bf_scratch", None) is None or self._bf_scratch.numel() < nb:
             self._bf_scratch = torch.empty(nb, dtype=torch.uint8, device=pcm.device)
@@ -158,15 +180,16 @@ class FilterBank:
 
 def bf_apply(W, X, out=None):
     """y_k[t] = w_k^H x_k[t].  W complex64 [S|1][K][N], X complex64 [S][K][N][T] -> Y [S][K][T]."""
-    _need_cuda(W, "W")
-    _need_cuda(X, "X")
+    _check(X, "X", torch.complex64, 4)
     S, K, N, T = X.shape
     if W.dim() == 2:
         W = W.unsqueeze(0)
+    _check(W, "W", torch.complex64, 3)
     if W.shape[1:] != (K, N) or W.shape[0] not in (1, S):
         raise _lib.BtkError(_lib.BTK_ERR_DIMENSION, "weights %s do not match X %s" % (tuple(W.shape), tuple(X.shape)))
     if out is None:
         out = torch.empty((S, K, T), dtype=torch.complex64, device=X.device)
+    _check(out, "Y", torch.complex64, (S, K, T))
     check(_lib.lib().btk_bf_apply(_ptr(W), int(W.shape[0] == S and S > 1), _ptr(X), _ptr(out), S, K, N, T, T, _stream()))
     return out
 
@@ -279,13 +302,14 @@ class NLMSState:
 
 def nlms_process(vs, X, state, out=None):
     """Adaptive GSC over a block: vs complex64 [K][N] (cuda), X [S][K][N][T] -> Y [S][K][T]; state updated in place."""
-    _need_cuda(vs, "vs")
-    _need_cuda(X, "X")
+    _check(X, "X", torch.complex64, 4)
     S, K, N, T = X.shape
-    if (S, K, N) != (state.S, state.K, state.N) or vs.shape != (K, N):
+    _check(vs, "vs", torch.complex64, (K, N))
+    if (S, K, N) != (state.S, state.K, state.N):
         raise _lib.BtkError(_lib.BTK_ERR_DIMENSION, "nlms_process: shapes do not match the state")
     if out is None:
         out = torch.empty((S, K, T), dtype=torch.complex64, device=X.device)
+    _check(out, "Y", torch.complex64, (S, K, T))
     params = state.params_array()
     ws = state.workspace(T)
     check(_lib.lib().btk_nlms_process(_np_ptr(params), _ptr(vs), _ptr(X), _ptr(out), S, state.M, N, T, T,
@@ -423,12 +447,16 @@ class ZelinskiState:
 def bf_apply_zelinski(W, D, X, state, alpha=0.6, type_=2, min_frames=0, out=None):
     """Beamform + Zelinski post-filter over a block (ZelinskiPostFilter over SubbandDS/GSC/MVDR).
     W, D complex64 [S|1][K][N]; X [S][K][N][T] -> Y [S][K][T] (post-filtered)."""
-    _need_cuda(W, "W"); _need_cuda(D, "D"); _need_cuda(X, "X")
+    _check(X, "X", torch.complex64, 4)
     S, K, N, T = X.shape
     if W.dim() == 2:
         W, D = W.unsqueeze(0), D.unsqueeze(0)
+    _check(W, "W", torch.complex64, (None, K, N)); _check(D, "D", torch.complex64, tuple(W.shape))
+    if W.shape[0] not in (1, S):
+        raise _lib.BtkError(_lib.BTK_ERR_DIMENSION, "weights %s do not match X %s" % (tuple(W.shape), tuple(X.shape)))
     if out is None:
         out = torch.empty((S, K, T), dtype=torch.complex64, device=X.device)
+    _check(out, "Y", torch.complex64, (S, K, T))
     Cc = torch.empty((S, K, T), dtype=torch.complex64, device=X.device)
     Ee = torch.empty((S, K, T), dtype=torch.float32, device=X.device)
     L = _lib.lib()
@@ -629,18 +657,50 @@ def mvdr_diagonal_loading(R, weight):
 
 def mvdr_weights(R, wq, threshold=1.0e-8, first_bin=0):
     """R complex64 [K][N][N], wq complex64 [K][N] (cuda) -> (W [K][N], number of identity fall-backs).
-    first_bin: global index of row 0 when R / wq are one rank's bin range (only global bin 0 gets the all-ones weight)."""
-    _need_cuda(R, "R"); _need_cuda(wq, "wq")
-    K, N, _ = R.shape
+    first_bin: global index of row 0 when R / wq are one rank's bin range (only global bin 0 gets the all-ones weight).
+    Bins whose Cholesky factorisation stops (R_k not positive definite, pivot <= threshold) are re-solved with the
+    reference's float32-SVD pseudo-inverse rule (btk_mvdr_pinv_fallback): identity only where a singular value is below
+    the threshold, the pseudo-inverse weights otherwise (beamformer.cc:232-289, 2372-2397)."""
+    _check(R, "R", torch.complex64, 3); _check(wq, "wq", torch.complex64, (R.shape[0], R.shape[1]))
+    K, N, N2 = R.shape
+    if N2 != N:
+        raise _lib.BtkError(_lib.BTK_ERR_DIMENSION, "R must be [K][N][N], got %s" % (tuple(R.shape),))
     W = torch.empty((K, N), dtype=torch.complex64, device=R.device)
     fb = torch.zeros(1, dtype=torch.int32, device=R.device)
+    flags = torch.zeros(max(K, 1), dtype=torch.int32, device=R.device)
     scratch = None
     if 2064 + 8 * (N * N + N) > 150 * 1024:
         scratch = torch.empty((K, N, N), dtype=torch.complex64, device=R.device)
+    nident = 0
     if K > 0:
-        check(_lib.lib().btk_mvdr_weights_shard(_ptr(R), _ptr(wq), _ptr(W), K, N, int(first_bin), float(threshold),
-                                                None if scratch is None else _ptr(scratch), _ptr(fb), _stream()))
-    return W, int(fb.item())
+        check(_lib.lib().btk_mvdr_weights_flags(_ptr(R), _ptr(wq), _ptr(W), K, N, int(first_bin), float(threshold),
+                                                None if scratch is None else _ptr(scratch), _ptr(fb), _ptr(flags), _stream()))
+        if int(fb.item()) > 0:
+            ni = C.c_int(0)
+            check(_lib.lib().btk_mvdr_pinv_fallback(_ptr(R), _ptr(wq), _ptr(W), K, N, int(first_bin), float(threshold),
+                                                    _ptr(flags), C.byref(ni), _stream()))
+            nident = ni.value
+    return W, nident
+
+
+def mvdr_divide_nondiagonal(R, mu):
+    """divide_all_nondiagonal_elements (beamformer.h:357-362): R_xy /= 1 + mu for x != y, in place; R complex64 [K][N][N]."""
+    _check(R, "R", torch.complex64, 3)
+    K, N, _ = R.shape
+    if K > 0:
+        check(_lib.lib().btk_mvdr_divide_nondiagonal(_ptr(R), K, N, float(mu), _stream()))
+    return R
+
+
+def pinv(A, threshold=1.0e-8):
+    """pseudoinverse() (beamformer.cc:232-289) of one host matrix: (invA complex128 [N][M], ok) with ok == the reference's
+    return value (False when a singular value fell below the threshold)."""
+    A = np.ascontiguousarray(A, np.complex128)
+    M, N = A.shape
+    out = np.zeros((N, M), np.complex128)
+    nz = C.c_int(0)
+    check(_lib.lib().btk_pinv(_np_ptr(A), M, N, float(threshold), _np_ptr(out), C.byref(nz)))
+    return out, nz.value == 0
 
 
 # ---------------------------------------------------------------------------- WPE dereverberation

@@ -32,10 +32,26 @@ typedef refcountable_ptr<SnapShotArray> SnapShotArrayPtr;
 class BeamformerWeights {
  public:
   BeamformerWeights(unsigned fftLen, unsigned chanN, bool halfBandShift, unsigned NC = 1);
+  ~BeamformerWeights();
   void calcMainlobe(float samplerate, const gsl_vector* delays, bool isGSC);
+  void calcMainlobe2(float samplerate, const gsl_vector* delaysT, const gsl_vector* delaysJ, bool isGSC);
+  void calcMainlobeN(float samplerate, const gsl_vector* delaysT, const gsl_matrix* delaysIs, unsigned NC, bool isGSC);
   void calcSidelobeCancellerP_f(unsigned fbinX, const gsl_vector* packedWeight);
   void calcSidelobeCancellerU_f(unsigned fbinX, const std::complex<double>* wa);
+  void calcSidelobeCancellerU_f(unsigned fbinX, const gsl_vector_complex* wa);
   void calcBlockingMatrix(unsigned fbinX);
+  // FIR taps of the effective weights wq - B wa per channel (inverse FFT of the conjugated, half-length-shifted weights,
+  // windowed): reference beamformer.cc:775-828.  winType: 0 rectangle, 2 Hanning, anything else Hamming (modulated.cc:47-72)
+  bool write_fir_coeff(const String& fn, unsigned winType);
+  bool writeFIRCoeff(const String& fn, unsigned winType) { return write_fir_coeff(fn, winType); }
+  void setSidelobeCanceller_f(unsigned fbinX, gsl_vector_complex* wl_f);
+  void setQuiescentVector(unsigned fbinX, gsl_vector_complex* wq_f, bool isGSC = false);
+  void setQuiescentVectorAll(gsl_complex z, bool isGSC = false);
+  void setTimeAlignment() { ta = wq; }
+  // gsl views of one bin (copies refreshed at every call, owned by this object)
+  gsl_vector_complex* wq_f(unsigned fbinX);
+  gsl_vector_complex* wl_f(unsigned fbinX);
+  gsl_matrix_complex* B_f(unsigned fbinX);
   unsigned fftLen() const { return fftLen_; }
   unsigned chanN() const { return chanN_; }
   unsigned NC() const { return NC_; }
@@ -43,14 +59,18 @@ class BeamformerWeights {
   std::vector<std::complex<double> > wq, wl, ta, wa, B;   // [M][N], [M][N], [M][N], [M][N-NC], [M][N][N-NC]
  private:
   unsigned fftLen_, chanN_, NC_;
+  gsl_vector_complex *wq_view_, *wl_view_;
+  gsl_matrix_complex* B_view_;
 };
 
 class SubbandBeamformer : public VectorComplexFeatureStream {
  public:
-  SubbandBeamformer(unsigned fftLen, bool halfBandShift = false, const String& nm = "SubbandBeamformer");
+  SubbandBeamformer(unsigned fftLen = 512, bool halfBandShift = false, const String& nm = "SubbandBeamformer");
   ~SubbandBeamformer();
   bool is_end() { return is_end_; }
+  bool isEnd() { return is_end(); }
   unsigned fftLen() const { return fftLen_; }
+  unsigned fftLen2() const { return fftLen2_; }
   unsigned chanN() const { return (unsigned)channelList_.size(); }
   virtual void reset();
   unsigned dim() const { return fftLen_; }
@@ -58,8 +78,10 @@ class SubbandBeamformer : public VectorComplexFeatureStream {
   virtual void clear_channel();
   const gsl_vector_complex* snapshot_array_f(unsigned fbinX) { return snapshot_array()->snapshot(fbinX); }
   virtual SnapShotArrayPtr snapshot_array();
-  void setChannel(VectorComplexFeatureStreamPtr& chan) { set_channel(chan); }       // legacy API
+  void setChannel(VectorComplexFeatureStreamPtr& chan) { set_channel(chan); }       // ENABLE_LEGACY_BTK_API aliases
   void clearChannel() { clear_channel(); }
+  const gsl_vector_complex* snapShotArray_f(unsigned fbinX) { return snapshot_array_f(fbinX); }
+  SnapShotArrayPtr getSnapShotArray() { return snapshot_array(); }
   // device hooks
   void* device_snapshots();       // complex64 [1][K][N][T] on the device
   long num_frames() { device_snapshots(); return T_; }
@@ -76,7 +98,7 @@ class SubbandBeamformer : public VectorComplexFeatureStream {
 
 class SubbandDS : public SubbandBeamformer {
  public:
-  SubbandDS(unsigned fftLen, bool halfBandShift = false, const String& nm = "SubbandDS");
+  SubbandDS(unsigned fftLen = 512, bool halfBandShift = false, const String& nm = "SubbandDS");
   ~SubbandDS();
   virtual const gsl_vector_complex* next(int frame_no = -5);
   virtual void reset();
@@ -84,7 +106,14 @@ class SubbandDS : public SubbandBeamformer {
   virtual const gsl_vector_complex* get_weights(unsigned fbinX);
   virtual BeamformerWeights* beamformer_weight_object(unsigned srcX = 0) const { return bfweight_; }
   virtual void calc_array_manifold_vectors(float samplerate, const gsl_vector* delays);
+  // LCMV quiescent weights: look direction + one / NC-1 nulls (reference beamformer.h:142-156, beamformer.cc:1159-1206)
+  virtual void calc_array_manifold_vectors_2(float samplerate, const gsl_vector* delaysT, const gsl_vector* delaysJ);
+  virtual void calc_array_manifold_vectors_n(float samplerate, const gsl_vector* delaysT, const gsl_matrix* delaysJ, unsigned NC = 2);
+  const gsl_vector_complex* getWeights(unsigned fbinX) { return get_weights(fbinX); }            // ENABLE_LEGACY_BTK_API aliases
+  BeamformerWeights* getBeamformerWeightObject(unsigned srcX = 0) const { return beamformer_weight_object(srcX); }
   void calcArrayManifoldVectors(float samplerate, const gsl_vector* delays) { calc_array_manifold_vectors(samplerate, delays); }
+  void calcArrayManifoldVectors2(float sampleRate, const gsl_vector* delaysT, const gsl_vector* delaysJ) { calc_array_manifold_vectors_2(sampleRate, delaysT, delaysJ); }
+  void calcArrayManifoldVectorsN(float sampleRate, const gsl_vector* delaysT, const gsl_matrix* delaysJ, unsigned NC = 2) { calc_array_manifold_vectors_n(sampleRate, delaysT, delaysJ, NC); }
   // engine hooks for downstream GPU nodes (post-filter, synthesis)
   virtual void effective_weights(std::vector<float>& w);   // complex64 [K][N]
   void alignment_vector(bool use_wq, std::vector<float>& d);
@@ -102,15 +131,26 @@ typedef Inherit<SubbandDS, VectorComplexFeatureStreamPtr> SubbandDSPtr;
 
 class SubbandGSC : public SubbandDS {
  public:
-  SubbandGSC(unsigned fftLen, bool halfBandShift = false, const String& nm = "SubbandGSC")
+  SubbandGSC(unsigned fftLen = 512, bool halfBandShift = false, const String& nm = "SubbandGSC")
       : SubbandDS(fftLen, halfBandShift, nm), normalize_weight_(false) {}
   void normalize_weight(bool flag) { normalize_weight_ = flag; weights_version_++; }
   void set_quiescent_weights_f(unsigned fbinX, const gsl_vector_complex* srcWq);
   void set_active_weights_f(unsigned fbinX, const gsl_vector* packedWeight);
   void zero_active_weights();
   void calc_gsc_weights(float samplerate, const gsl_vector* delaysT);
-  void calcGSCWeights(float samplerate, const gsl_vector* delaysT) { calc_gsc_weights(samplerate, delaysT); }
+  void calc_gsc_weights_2(float samplerate, const gsl_vector* delaysT, const gsl_vector* delaysJ);
+  void calc_gsc_weights_n(float samplerate, const gsl_vector* delaysT, const gsl_matrix* delaysJ, unsigned NC = 2);
+  bool write_fir_coeff(const String& fn, unsigned winType = 1);
+  gsl_matrix_complex* blocking_matrix(unsigned srcX, unsigned fbinX);
+  void normalizeWeight(bool flag) { normalize_weight(flag); }                                  // ENABLE_LEGACY_BTK_API aliases
+  void setQuiescentWeights_f(unsigned fbinX, const gsl_vector_complex* srcWq) { set_quiescent_weights_f(fbinX, srcWq); }
   void setActiveWeights_f(unsigned fbinX, const gsl_vector* packedWeight) { set_active_weights_f(fbinX, packedWeight); }
+  void zeroActiveWeights() { zero_active_weights(); }
+  void calcGSCWeights(float samplerate, const gsl_vector* delaysT) { calc_gsc_weights(samplerate, delaysT); }
+  void calcGSCWeights2(float sampleRate, const gsl_vector* delaysT, const gsl_vector* delaysJ) { calc_gsc_weights_2(sampleRate, delaysT, delaysJ); }
+  void calcGSCWeightsN(float sampleRate, const gsl_vector* delaysT, const gsl_matrix* delaysJ, unsigned NC = 2) { calc_gsc_weights_n(sampleRate, delaysT, delaysJ, NC); }
+  bool writeFIRCoeff(const String& fn, unsigned winType = 1) { return write_fir_coeff(fn, winType); }
+  gsl_matrix_complex* getBlockingMatrix(unsigned srcX, unsigned fbinX) { return blocking_matrix(srcX, fbinX); }
   virtual void effective_weights(std::vector<float>& w);
  protected:
   virtual const char* need_weights_msg_() const { return "call calc_gsc_weights_X() once\n"; }
@@ -148,7 +188,7 @@ typedef Inherit<SubbandGSCRLS, SubbandGSCPtr> SubbandGSCRLSPtr;
 
 class SubbandMVDR : public SubbandDS {
  public:
-  SubbandMVDR(unsigned fftLen, bool halfBandShift = false, const String& nm = "SubbandMVDR");
+  SubbandMVDR(unsigned fftLen = 512, bool halfBandShift = false, const String& nm = "SubbandMVDR");
   ~SubbandMVDR();
   virtual void clear_channel();
   bool calc_mvdr_weights(float samplerate, float dThreshold = 1.0E-8, bool calcInverseMatrix = true);
@@ -157,6 +197,19 @@ class SubbandMVDR : public SubbandDS {
   bool set_diffuse_noise_model(const gsl_matrix* micPositions, float samplerate, float sspeed = 343740.0);
   void set_all_diagonal_loading(float diagonalWeight);
   void set_diagonal_looading(unsigned fbinX, float diagonalWeight);          // sic (reference spelling)
+  // R_xy /= 1 + mu for x != y instead of diagonal loading (reference beamformer.h:353-362, beamformer.cc:2589-2599)
+  void divide_all_nondiagonal_elements(float mu);
+  void divide_nondiagonal_elements(unsigned fbinX, float mu);
+  const gsl_matrix_complex* noise_spatial_spectral_matrix(unsigned fbinX);   // host copy of R_k (refreshed at every call)
+  bool calcMVDRWeights(float sampleRate, float dThreshold = 1.0E-8, bool calcInverseMatrix = true) { return calc_mvdr_weights(sampleRate, dThreshold, calcInverseMatrix); }   // ENABLE_LEGACY_BTK_API aliases
+  const gsl_vector_complex* getMVDRWeights(unsigned fbinX) { return mvdr_weights(fbinX); }
+  const gsl_matrix_complex* getNoiseSpatialSpectralMatrix(unsigned fbinX) { return noise_spatial_spectral_matrix(fbinX); }
+  bool setNoiseSpatialSpectralMatrix(unsigned fbinX, gsl_matrix_complex* Rnn) { return set_noise_spatial_spectral_matrix(fbinX, Rnn); }
+  bool setDiffuseNoiseModel(const gsl_matrix* micPositions, float sampleRate, float sspeed = 343740.0) { return set_diffuse_noise_model(micPositions, sampleRate, sspeed); }
+  void setAllLevelsOfDiagonalLoading(float diagonalWeight) { set_all_diagonal_loading(diagonalWeight); }
+  void setLevelOfDiagonalLoading(unsigned fbinX, float diagonalWeight) { set_diagonal_looading(fbinX, diagonalWeight); }
+  void divideAllNonDiagonalElements(float mu) { divide_all_nondiagonal_elements(mu); }
+  void divideNonDiagonalElements(unsigned fbinX, float mu) { divide_nondiagonal_elements(fbinX, mu); }
   virtual void effective_weights(std::vector<float>& w);
   int identity_fallbacks() const { return fallbacks_; }
  protected:
@@ -166,6 +219,7 @@ class SubbandMVDR : public SubbandDS {
   bool have_mvdr_;
   int fallbacks_;
   gsl_vector_complex* wm_view_;
+  gsl_matrix_complex* R_view_;
 };
 typedef Inherit<SubbandMVDR, SubbandDSPtr> SubbandMVDRPtr;
 

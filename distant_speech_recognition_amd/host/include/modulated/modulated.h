@@ -14,6 +14,7 @@ class OverSampledDFTAnalysisBank : public VectorComplexFeatureStream {
   virtual void reset();
   unsigned fftlen() const { return M_; }
   unsigned shiftlen() const { return D_; }
+  bool isEnd() { return is_end(); }                     // src/superdirectiveBeamformer.cc:206 calls it (the reference's own header lost it)
   unsigned fftLen() const { return fftlen(); }          // ENABLE_LEGACY_BTK_API aliases
   unsigned nBlocks() const { return m_; }
   unsigned subSampRate() const { return r_; }

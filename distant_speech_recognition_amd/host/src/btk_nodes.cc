@@ -341,7 +341,124 @@ void SnapShotArray::update()
 BeamformerWeights::BeamformerWeights(unsigned fftLen, unsigned chanN, bool, unsigned NC)
     : wq((size_t)fftLen * chanN), wl((size_t)fftLen * chanN), ta((size_t)fftLen * chanN),
       wa(chanN > NC ? (size_t)fftLen * (chanN - NC) : 0), B(chanN > NC ? (size_t)fftLen * chanN * (chanN - NC) : 0),
-      fftLen_(fftLen), chanN_(chanN), NC_(NC) {}
+      fftLen_(fftLen), chanN_(chanN), NC_(NC), wq_view_(gsl_vector_complex_calloc(chanN)), wl_view_(gsl_vector_complex_calloc(chanN)),
+      B_view_(gsl_matrix_complex_alloc(chanN, chanN > NC ? chanN - NC : 0)) {}
+
+BeamformerWeights::~BeamformerWeights()
+{
+  gsl_vector_complex_free(wq_view_); gsl_vector_complex_free(wl_view_); gsl_matrix_complex_free(B_view_);
+}
+
+gsl_vector_complex* BeamformerWeights::wq_f(unsigned fbinX)
+{
+  memcpy(wq_view_->data, &wq[(size_t)fbinX * chanN_], sizeof(double) * 2 * chanN_);
+  return wq_view_;
+}
+gsl_vector_complex* BeamformerWeights::wl_f(unsigned fbinX)
+{
+  memcpy(wl_view_->data, &wl[(size_t)fbinX * chanN_], sizeof(double) * 2 * chanN_);
+  return wl_view_;
+}
+gsl_matrix_complex* BeamformerWeights::B_f(unsigned fbinX)
+{
+  const unsigned bs = chanN_ - NC_;
+  if (bs) memcpy(B_view_->data, &B[(size_t)fbinX * chanN_ * bs], sizeof(double) * 2 * chanN_ * bs);
+  return B_view_;
+}
+
+void BeamformerWeights::calcMainlobe2(float samplerate, const gsl_vector* delaysT, const gsl_vector* delaysI, bool isGSC)
+{
+  if (delaysI->size != chanN_)
+    throw jdimension_error("The number of delays for an interference signal does not match number of channels (%d vs. %d).\n",
+                           (int)delaysI->size, chanN_);
+  if (chanN_ < 2) throw jdimension_error("The number of channels must be > 2 but it is %d\n", chanN_);
+  gsl_matrix* delaysIs = gsl_matrix_alloc(1, chanN_);
+  for (unsigned c = 0; c < chanN_; c++) gsl_matrix_set(delaysIs, 0, c, gsl_vector_get(delaysI, c));
+  try { calcMainlobeN(samplerate, delaysT, delaysIs, 2, isGSC); } catch (...) { gsl_matrix_free(delaysIs); throw; }
+  gsl_matrix_free(delaysIs);
+}
+
+void BeamformerWeights::calcMainlobeN(float samplerate, const gsl_vector* delaysT, const gsl_matrix* delaysIs, unsigned NC, bool isGSC)
+{
+  if (NC < 2 || NC > chanN_)
+    throw jdimension_error("1 < the number of constraints %d <= the number of sensors %d.\n", NC, chanN_);
+  if (delaysT->size != chanN_)
+    throw jdimension_error("The number of delays does not match number of channels (%d vs. %d).\n", (int)delaysT->size, chanN_);
+  if (NC != NC_) throw jdimension_error("The weight object was allocated for %d constraints, not %d\n", NC_, NC);
+  std::vector<double> dt(chanN_), di((size_t)(NC - 1) * chanN_);
+  for (unsigned c = 0; c < chanN_; c++) dt[c] = gsl_vector_get(delaysT, c);
+  for (unsigned n = 0; n + 1 < NC; n++)
+    for (unsigned c = 0; c < chanN_; c++) di[(size_t)n * chanN_ + c] = gsl_matrix_get(delaysIs, n, c);
+  check_abi(btk_weights_mainlobe_n((int)fftLen_, (int)chanN_, samplerate, dt.data(), di.data(), (int)NC, reinterpret_cast<double*>(wq.data())));
+  // ta_ keeps the plain look-direction manifold calcMainlobe copied before the constraints were applied (beamformer.cc:562)
+  check_abi(btk_weights_mainlobe((int)fftLen_, (int)chanN_, samplerate, dt.data(), reinterpret_cast<double*>(ta.data())));
+  if (isGSC)
+    for (unsigned k = 0; k < fftLen_; k++) calcBlockingMatrix(k);
+}
+
+void BeamformerWeights::calcSidelobeCancellerU_f(unsigned fbinX, const gsl_vector_complex* w)
+{
+  const unsigned bs = chanN_ - NC_;
+  if (w->size != bs) throw jdimension_error("the size of an active weight vector must be %d but it is %d\n", bs, (int)w->size);
+  std::vector<cd> v(bs);
+  for (unsigned i = 0; i < bs; i++) { const gsl_complex z = gsl_vector_complex_get(w, i); v[i] = cd(GSL_REAL(z), GSL_IMAG(z)); }
+  calcSidelobeCancellerU_f(fbinX, v.data());
+}
+
+void BeamformerWeights::setSidelobeCanceller_f(unsigned fbinX, gsl_vector_complex* wl_in)
+{
+  memcpy(static_cast<void*>(&wl[(size_t)fbinX * chanN_]), wl_in->data, sizeof(double) * 2 * chanN_);
+}
+
+void BeamformerWeights::setQuiescentVector(unsigned fbinX, gsl_vector_complex* wq_in, bool isGSC)
+{
+  for (unsigned c = 0; c < chanN_; c++) { const gsl_complex z = gsl_vector_complex_get(wq_in, c); wq[(size_t)fbinX * chanN_ + c] = cd(GSL_REAL(z), GSL_IMAG(z)); }
+  if (isGSC) calcBlockingMatrix(fbinX);
+}
+
+void BeamformerWeights::setQuiescentVectorAll(gsl_complex z, bool isGSC)
+{
+  for (unsigned k = 0; k < fftLen_; k++) {
+    for (unsigned c = 0; c < chanN_; c++) wq[(size_t)k * chanN_ + c] = cd(GSL_REAL(z), GSL_IMAG(z));
+    if (isGSC) calcBlockingMatrix(k);
+  }
+}
+
+// reference beamformer.cc:775-828.  The inverse DFT (gsl_fft_complex_radix2_inverse: e^{+j 2 pi k n / M} / M) of the
+// Hermitian-extended sequence val[k] = e^{j pi (k+1)} conj(wq[k] - wl[k]) is taken directly: M^2 / 2 operations per
+// channel, one-off.
+bool BeamformerWeights::write_fir_coeff(const String& fn, unsigned winType)
+{
+  const unsigned M = fftLen_, M2 = fftLen_ / 2;
+  FILE* fp = fopen(fn.c_str(), "w");
+  if (!fp) { printf("could not open %s\n", fn.c_str()); return false; }
+  fprintf(fp, "%d %d\n", chanN_, M);
+  std::vector<double> window(M);
+  for (unsigned i = 0; i < M; i++)
+    window[i] = winType == 0 ? 1.0 : winType == 2 ? 0.5 * (1 - cos((2.0 * M_PI * i) / (double)(M - 1)))
+                                                  : 0.54 - 0.46 * cos(2. * M_PI / (double)(M - 1) * i);
+  std::vector<cd> val(M);
+  for (unsigned c = 0; c < chanN_; c++) {
+    std::fill(val.begin(), val.end(), cd(0, 0));
+    for (unsigned k = 0; k <= M2; k++) {
+      const cd wH = std::conj(wq[(size_t)k * chanN_ + c] - wl[(size_t)k * chanN_ + c]);
+      const cd v = std::polar(1.0, M_PI * (k + 1)) * wH;                       // shift fftLen/2
+      val[k] = v;
+      if (k > 0 && k < M2) val[M - k] = std::conj(v);
+    }
+    for (unsigned n = 0; n < M; n++) {
+      double acc = 0.0;                                                          // real part of the inverse DFT
+      for (unsigned k = 0; k < M; k++) {
+        const double ph = 2.0 * M_PI * (double)((unsigned long)k * n % M) / M;
+        acc += val[k].real() * cos(ph) - val[k].imag() * sin(ph);
+      }
+      fprintf(fp, "%e ", window[n] * acc / M);
+    }
+    fprintf(fp, "\n");
+  }
+  fclose(fp);
+  return true;
+}
 
 void BeamformerWeights::calcMainlobe(float samplerate, const gsl_vector* delays, bool isGSC)
 {
@@ -488,6 +605,18 @@ void SubbandDS::calc_array_manifold_vectors(float samplerate, const gsl_vector* 
   bfweight_->calcMainlobe(samplerate, delays, false);
 }
 
+void SubbandDS::calc_array_manifold_vectors_2(float samplerate, const gsl_vector* delaysT, const gsl_vector* delaysJ)
+{
+  alloc_bfweight_(2);
+  bfweight_->calcMainlobe2(samplerate, delaysT, delaysJ, false);
+}
+
+void SubbandDS::calc_array_manifold_vectors_n(float samplerate, const gsl_vector* delaysT, const gsl_matrix* delaysJ, unsigned NC)
+{
+  alloc_bfweight_((int)NC);
+  bfweight_->calcMainlobeN(samplerate, delaysT, delaysJ, NC, false);
+}
+
 const gsl_vector_complex* SubbandDS::get_weights(unsigned fbinX)
 {
   const unsigned N = chanN();
@@ -556,6 +685,30 @@ void SubbandGSC::calc_gsc_weights(float samplerate, const gsl_vector* delaysT)
   bfweight_->calcMainlobe(samplerate, delaysT, true);
 }
 
+void SubbandGSC::calc_gsc_weights_2(float samplerate, const gsl_vector* delaysT, const gsl_vector* delaysJ)
+{
+  alloc_bfweight_(2);
+  bfweight_->calcMainlobe2(samplerate, delaysT, delaysJ, true);
+}
+
+void SubbandGSC::calc_gsc_weights_n(float samplerate, const gsl_vector* delaysT, const gsl_matrix* delaysIs, unsigned NC)
+{
+  alloc_bfweight_((int)NC);
+  bfweight_->calcMainlobeN(samplerate, delaysT, delaysIs, NC, true);
+}
+
+bool SubbandGSC::write_fir_coeff(const String& fn, unsigned winType)
+{
+  if (!bfweight_) { fprintf(stderr, "call calc_array_manifold_vectorsX() once\n"); return false; }
+  return bfweight_->write_fir_coeff(fn, winType);
+}
+
+gsl_matrix_complex* SubbandGSC::blocking_matrix(unsigned srcX, unsigned fbinX)
+{
+  if (!bfweight_ || srcX != 0) throw j_error("call calc_gsc_weights_x() once\n");
+  return bfweight_->B_f(fbinX);
+}
+
 void SubbandGSC::set_quiescent_weights_f(unsigned fbinX, const gsl_vector_complex* srcWq)
 {
   alloc_bfweight_(1);
@@ -589,8 +742,34 @@ void SubbandGSC::effective_weights(std::vector<float>& w)
 
 // ================================================================================ SubbandMVDR
 SubbandMVDR::SubbandMVDR(unsigned fftLen, bool halfBandShift, const String& nm)
-    : SubbandDS(fftLen, halfBandShift, nm), dR_(NULL), have_mvdr_(false), fallbacks_(0), wm_view_(gsl_vector_complex_calloc(1)) {}
-SubbandMVDR::~SubbandMVDR() { dev_free(dR_); gsl_vector_complex_free(wm_view_); }
+    : SubbandDS(fftLen, halfBandShift, nm), dR_(NULL), have_mvdr_(false), fallbacks_(0), wm_view_(gsl_vector_complex_calloc(1)),
+      R_view_(NULL) {}
+SubbandMVDR::~SubbandMVDR() { dev_free(dR_); gsl_vector_complex_free(wm_view_); gsl_matrix_complex_free(R_view_); }
+
+void SubbandMVDR::divide_all_nondiagonal_elements(float mu)
+{
+  if (!dR_) throw j_error("Construct first a noise covariance matrix\n");
+  check_abi(btk_mvdr_divide_nondiagonal(dR_, (int)(fftLen2_ + 1), (int)chanN(), mu, NULL));
+}
+
+void SubbandMVDR::divide_nondiagonal_elements(unsigned fbinX, float mu)
+{
+  if (!dR_) throw j_error("Construct first a noise covariance matrix\n");
+  const unsigned N = chanN();
+  check_abi(btk_mvdr_divide_nondiagonal(static_cast<float*>(dR_) + (size_t)fbinX * 2 * N * N, 1, (int)N, mu, NULL));
+}
+
+const gsl_matrix_complex* SubbandMVDR::noise_spatial_spectral_matrix(unsigned fbinX)
+{
+  if (!dR_) return NULL;                                       // the reference returns its NULL R_[fbinX]
+  const unsigned N = chanN();
+  if (!R_view_ || R_view_->size1 != N) { gsl_matrix_complex_free(R_view_); R_view_ = gsl_matrix_complex_alloc(N, N); }
+  std::vector<float> r((size_t)2 * N * N);
+  check_abi(btk_synchronize(NULL));
+  d2h(r.data(), static_cast<float*>(dR_) + (size_t)fbinX * 2 * N * N, sizeof(float) * r.size());
+  for (size_t i = 0; i < (size_t)2 * N * N; i++) R_view_->data[i] = r[i];
+  return R_view_;
+}
 void SubbandMVDR::clear_channel() { SubbandDS::clear_channel(); dev_free(dR_); dR_ = NULL; have_mvdr_ = false; }
 
 void SubbandMVDR::alloc_R_()
@@ -658,14 +837,19 @@ bool SubbandMVDR::calc_mvdr_weights(float, float dThreshold, bool)
   void* dfb = dev_alloc(sizeof(int));
   void* scratch = NULL;
   if (8 * ((size_t)N * N + N) > 150 * 1024) scratch = dev_alloc(sizeof(float) * 2 * K * N * N);
+  void* dflags = dev_alloc(sizeof(int) * K);
   h2d(dD, d.data(), sizeof(float) * d.size());
   check_hip(hipMemset(dfb, 0, sizeof(int)), "hipMemset");
-  check_abi(btk_mvdr_weights(dR_, dD, dW, (int)K, (int)N, dThreshold, scratch, (int*)dfb, NULL));
+  check_abi(btk_mvdr_weights_flags(dR_, dD, dW, (int)K, (int)N, 0, dThreshold, scratch, (int*)dfb, (int*)dflags, NULL));
   check_abi(btk_synchronize(NULL));
+  int stopped = 0;
+  d2h(&stopped, dfb, sizeof(int));
+  fallbacks_ = 0;
+  if (stopped > 0)     // bins the Cholesky solve gave up on: the reference's float32-SVD pseudo-inverse rule (beamformer.cc:232-289)
+    check_abi(btk_mvdr_pinv_fallback(dR_, dD, dW, (int)K, (int)N, 0, dThreshold, (const int*)dflags, &fallbacks_, NULL));
   wmvdr_.resize(d.size());
   d2h(wmvdr_.data(), dW, sizeof(float) * wmvdr_.size());
-  d2h(&fallbacks_, dfb, sizeof(int));
-  dev_free(dD); dev_free(dW); dev_free(dfb); dev_free(scratch);
+  dev_free(dD); dev_free(dW); dev_free(dfb); dev_free(dflags); dev_free(scratch);
   have_mvdr_ = true;
   weights_version_++;
   return true;

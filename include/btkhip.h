@@ -239,6 +239,22 @@ int  btk_mvdr_diffuse_model(const float* mpos, int N, int M, float samplerate, f
 int  btk_mvdr_diagonal_loading(void* R, int nbins, int N, float weight, void* stream);
 int  btk_mvdr_weights(const void* R, const void* wq, void* W, int K, int N, float threshold,
                       void* scratch, int* fallback_count, void* stream);
+/* btk_mvdr_divide_nondiagonal: divide_nondiagonal_elements / divide_all_nondiagonal_elements (beamformer.cc:2589-2599,
+ *   beamformer.h:357-362): R_xy /= (1 + mu), x != y, over nbins matrices.
+ * btk_mvdr_weights_flags: btk_mvdr_weights(_shard) that also reports WHICH bins stopped in the Cholesky factorisation
+ *   (fail_flags [dev] int32 [K]); btk_mvdr_pinv_fallback re-solves exactly those bins with the reference's own rule -- the
+ *   float32-rounded matrix is pseudo-inverted through its SVD, singular values < threshold are zeroed and make the call
+ *   "fail", upon which the identity is substituted (pseudoinverse(), beamformer.cc:232-289; :2381-2383) -- and patches W.
+ *   It synchronises the stream; *identity_count [host] = bins that ended with the identity.  A Hermitian R_k that is
+ *   indefinite but non-singular gets the pseudo-inverse weights the reference computes, not the identity.
+ * btk_pinv: that pseudo-inverse for one host matrix A complex128 [M][N] -> invA [N][M]; *below_threshold = number of
+ *   singular values zeroed (> 0 == the reference's `return false`).                                                   */
+int  btk_mvdr_divide_nondiagonal(void* R, int nbins, int N, float mu, void* stream);
+int  btk_mvdr_weights_flags(const void* R, const void* wq, void* W, int K, int N, int first_bin, float threshold,
+                            void* scratch, int* fallback_count, int* fail_flags, void* stream);
+int  btk_mvdr_pinv_fallback(const void* R, const void* wq, void* W, int K, int N, int first_bin, float threshold,
+                            const int* fail_flags, int* identity_count, void* stream);
+int  btk_pinv(const double* A, int M, int N, float threshold, double* invA, int* below_threshold);
 /* The same solve for a bin SHARD [first_bin, first_bin + K) of a bin-sharded run: only global bin 0 gets the
  * all-ones weight of calc_mvdr_weights (beamformer.cc:2369-2371).                                                    */
 int  btk_mvdr_weights_shard(const void* R, const void* wq, void* W, int K, int N, int first_bin, float threshold,

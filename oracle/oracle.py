@@ -529,14 +529,16 @@ def diagonal_loading(R, M, w):
     return R
 
 
-def pseudoinverse(A, threshold=1.0e-8):
+def pseudoinverse(A, threshold=1.0e-8, return_info=False):
     """pseudoinverse(): beamformer.cc:232-289.  float32 LINPACK csvdc (job=11) through the compiled
     reference (oracle/_ref) when present, numpy float32 SVD otherwise.
-    Returns (invA complex128, ok)."""
+    Returns (invA complex128, ok) -- with return_info also csvdc's INFO (non-zero: its QR iteration did not converge
+    within 30 sweeps for INFO singular values; the reference then reports failure like for a thresholded value)."""
     A = _c128(A)
     Mr, Nc_ = A.shape
     R = ref_lib()
     ok = True
+    info = 0
     if R is not None:
         a = np.asfortranarray(A.astype(np.complex64))
         s = np.zeros(Mr + Nc_, np.complex64)
@@ -562,6 +564,8 @@ def pseudoinverse(A, threshold=1.0e-8):
     for i in range(Mr):
         for j in range(Nc_):
             inv[j, i] = np.sum(V[j, :Nc_] * sinv * np.conj(U[i, :Nc_]))
+    if return_info:
+        return inv.astype(np.complex128), ok, int(info)
     return inv.astype(np.complex128), ok
 
 

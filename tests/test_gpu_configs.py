@@ -42,8 +42,10 @@ def test_c3_mvdr_64mic_1024bins(orc, dev):
         xk = Xh[k].astype(np.complex128)                         # [N][T]
         Rref = (xk @ xk.conj().T) / T + 100.0 * np.eye(N)
         assert np.linalg.norm(Rh[k] - Rref) <= 2e-5 * np.linalg.norm(Rref)
-        z = np.linalg.solve(Rref, wq[k])
-        w = z / (N * np.vdot(wq[k], z))
+        inv, ok = orc.pseudoinverse(Rref)                       # the reference's float32 csvdc (oracle/_ref), beamformer.cc:232-289
+        assert ok
+        tH = inv.conj().T @ wq[k]
+        w = tH / (N * np.vdot(tH, wq[k]))                       # calc_mvdr_weights, beamformer.cc:2386-2396
         yref = w.conj() @ xk
         assert np.max(np.abs(Y[k] - yref)) <= 2e-3 * np.max(np.abs(yref))
     assert np.allclose(W[0].cpu().numpy(), 1.0)
@@ -72,6 +74,18 @@ def test_c5_superdirective_256mic_2048bins_bin_sharded(orc, dev):
         exact = z / (N * np.vdot(wq[k], z))
         # ill-conditioned at low bins (coherence ~ 1): the reference's own float32 SVD is no better than this
         assert np.linalg.norm(Wh[k] - exact) <= 2e-2 * np.linalg.norm(exact)
+        inv, ok, info = orc.pseudoinverse(Rref[k], return_info=True)   # the oracle's pinned path: the reference's compiled csvdc
+        if info != 0:
+            # Reference quirk: LINPACK's float32 QR iteration does not converge on this 256 x 256 matrix (253 of
+            # its singular values sit within 1e-7 of the 0.01 loading at the Nyquist bin); pseudoinverse() then reports
+            # failure and calc_mvdr_weights silently substitutes the identity, i.e. delay-and-sum.  The engine solves the
+            # system; it is compared with the exact solution above and NOT made to reproduce that failure.
+            assert k == 1024
+            continue
+        assert ok
+        tH = inv.conj().T @ wq[k]
+        ref = tH / (N * np.vdot(tH, wq[k]))
+        assert np.linalg.norm(Wh[k] - ref) <= 2e-2 * np.linalg.norm(ref)
         assert abs(np.vdot(Wh[k], wq[k]) - 1.0 / N) < 1e-3 / N + 1e-6
     rng = np.random.default_rng(5)
     Xe = ((rng.normal(size=(S, K, N, T)) + 1j * rng.normal(size=(S, K, N, T))) * 1000).astype(np.complex64)

@@ -206,3 +206,82 @@ def test_subband_dereverberator_binary_matches_oracle(orc, dev, tmp_path, proto2
         ref = orc.synthesis(g, M, m, r, 0, Yd[:, c])
         assert out.shape == ref.shape
         assert np.max(np.abs(out - ref)) < 1e-3 * np.max(np.abs(ref)) + 0.5
+
+
+EXE_SD = os.path.join(ROOT, "distant_speech_recognition_amd", "host", "examples", "beamformer_sd")
+
+
+@pytest.mark.parametrize("NC,pf,alpha", [(1, 2, 0.7), (1, 0, 0.0), (2, 2, 0.6), (3, 0, 0.0)])
+def test_beamformer_sd_binary_matches_oracle(orc, dev, tmp_path, proto256, kinect_pcm, NC, pf, alpha):
+    """The reference's superdirective main (src/superdirectiveBeamformer.cc:151-248) through the C++ nodes and the legacy
+    camelCase API it uses: SubbandMVDR with setDiffuseNoiseModel + divideAllNonDiagonalElements(0.01) + calcMVDRWeights,
+    ZelinskiPostFilter::setBeamformer, synthesis; LCMV quiescent vectors (calcArrayManifoldVectors2 / N) for NC > 1."""
+    from tests.util import la_delays
+    assert os.path.exists(EXE_SD), "build the host layer: make -C distant_speech_recognition_amd/host"
+    h, g = proto256
+    delays = la_delays(MPOS, -1.306379)
+    L = 30000
+    mu = 0.01
+    coeffs, chan_args = _write_inputs(tmp_path, proto256, kinect_pcm, L, delays)
+    mpos = ";".join(",".join(repr(float(v)) for v in row) for row in MPOS)
+    env = dict(os.environ, BTK_EXAMPLE_NC=str(NC))
+    res = subprocess.run([EXE_SD, coeffs, str(M), str(m), str(r), str(pf), str(alpha), str(mu), str(tmp_path / "out.f32"), mpos] + chan_args,
+                         capture_output=True, text=True, timeout=120, env=env)
+    assert res.returncode == 0, res.stderr
+    assert "0 identity fall-backs" in res.stderr
+    out = np.fromfile(str(tmp_path / "out.f32"), np.float32)
+    K = M // 2 + 1
+    X = np.stack([orc.analysis(h, M, m, r, 0, kinect_pcm[c][:L]) for c in range(4)], axis=1)
+    ta = orc.calc_mainlobe(M, 4, FS, delays)
+    if NC == 1:
+        wq = ta
+    elif NC == 2:
+        wq = orc.calc_mainlobe_2(M, 4, FS, delays, -0.5 * delays)
+    else:
+        wq = orc.calc_mainlobe_n(M, 4, FS, delays, np.stack([-0.5 * delays, 0.25 * delays]), 3)
+    R = orc.diffuse_noise_model(MPOS, M, FS)
+    off = ~np.eye(4, dtype=bool)
+    R[:, off] = R[:, off] / (1.0 + mu)
+    got_r = float(res.stderr.split("R_10[0][1] = ")[1].split()[0])               # getNoiseSpatialSpectralMatrix(10)
+    assert abs(got_r - R[10, 0, 1].real) < 2e-6
+    wfull = np.zeros((M, 4), np.complex128)
+    wfull[:K] = orc.mvdr_weights(R, wq, M)
+    Y = orc.gsc_frames(X, wfull, np.zeros((M, 4), np.complex128))
+    if pf:
+        Y, _ = orc.zelinski_frames(X, Y, ta, alpha, pf)
+    ref = orc.synthesis(g, M, m, r, 0, Y)
+    assert out.shape == ref.shape
+    assert np.max(np.abs(out - ref)) < 2e-3 * np.max(np.abs(kinect_pcm[:, :L])) + 0.5      # float32 SVD vs Cholesky MVDR
+
+
+def test_write_fir_coeff_matches_reference_formula(orc, dev, tmp_path, proto256, kinect_pcm):
+    """SubbandGSC::writeFIRCoeff (beamformer.cc:775-828): per channel the windowed real part of the inverse DFT of
+    e^{j pi (k+1)} conj(wq_k - wl_k), Hermitian-extended; getBlockingMatrix returns the N x (N-1) matrix of a bin."""
+    from tests.util import la_delays
+    delays = la_delays(MPOS, -1.306379)
+    coeffs, chan_args = _write_inputs(tmp_path, proto256, kinect_pcm, 4000, delays)
+    mpos = ";".join(",".join(repr(float(v)) for v in row) for row in MPOS)
+    fir = str(tmp_path / "fir.txt")
+    res = subprocess.run([EXE_SD, coeffs, str(M), str(m), str(r), "0", "0", "0", str(tmp_path / "out.f32"), mpos] + chan_args,
+                         capture_output=True, text=True, timeout=120, env=dict(os.environ, BTK_EXAMPLE_FIR=fir))
+    assert res.returncode == 0, res.stderr
+    assert "blocking matrix of bin 5 is 4 x 3" in res.stderr
+    lines = open(fir).read().strip().split("\n")
+    assert lines[0].split() == ["4", str(M)]
+    got = np.array([[float(v) for v in l.split()] for l in lines[1:]])
+    wq, B, _ = orc.gsc_weights(M, 4, FS, delays)
+    wl = np.zeros((M, 4), np.complex128)
+    i = np.arange(3)
+    for k in range(1, M // 2 + 1):
+        wl[k] = orc.sidelobe_canceller(B[k], 0.05 * (np.cos(0.37 * k + i) + 1j * np.sin(0.11 * k * (i + 1))))
+    win = 0.54 - 0.46 * np.cos(2.0 * np.pi / (M - 1) * np.arange(M))          # winType 1 -> Hamming (modulated.cc:62-67)
+    want = np.zeros((4, M))
+    for c in range(4):
+        val = np.zeros(M, np.complex128)
+        for k in range(M // 2 + 1):
+            v = np.exp(1j * np.pi * (k + 1)) * np.conj(wq[k, c] - wl[k, c])
+            val[k] = v
+            if 0 < k < M // 2:
+                val[M - k] = np.conj(v)
+        want[c] = win * np.real(np.fft.ifft(val))                              # gsl_fft_complex_radix2_inverse: e^{+j}, 1/M
+    assert got.shape == want.shape and np.max(np.abs(got - want)) < 1e-6 * np.max(np.abs(want)) + 1e-12
