@@ -44,45 +44,96 @@ def synth_pcm_device(torch, dev, S, N, L, delays, seed):
     return pcm
 
 
-def cpu_baseline(N, M, m, r, dct, frames):
-    """Time the oracle's frame-by-frame pull graph (N analysis banks -> SubbandGSC -> synthesis)
-    on ONE host core, on a bounded sample of the same workload."""
+def ula_positions(N, pitch_mm=20.0):
+    """uniform linear array, centred, 20 mm pitch; positions in mm"""
+    x = (np.arange(N) - (N - 1) / 2.0) * pitch_mm
+    return np.stack([x, np.zeros(N), np.zeros(N)], axis=1)
+
+
+def synth_pcm_host(N, L, delays, seed):
+    """the same distribution as synth_pcm_device for one stream, on the host (CPU baseline input)"""
+    rng = np.random.default_rng(seed)
+    tgt = rng.normal(0.0, 3000.0, L + 64)
+    out = np.empty((N, L), np.float32)
+    for c in range(N):
+        sh = int(round(delays[c] * FS))
+        out[c] = np.clip(np.rint(rng.normal(0.0, 1000.0, L) + tgt[32 + sh: 32 + sh + L]), -32767, 32767)
+    return out
+
+
+def _cpu_stream(a):
+    """one utterance stream through the oracle's frame-by-frame pull graph; returns (frames, seconds)"""
+    N, M, m, r, dct, frames, seed = a
     from oracle import oracle as orc
-    from tests.util import design_prototype, synthetic_pcm
+    from distant_speech_recognition_amd import prototypes
+    from distant_speech_recognition_amd.pybeamformer import calc_la_delays
     D = M >> r
-    h, g = design_prototype(M, m), design_prototype(M, m, "g")
-    pcm, delays = synthetic_pcm(1, N, frames * D, seed=20260927)
+    h, g = prototypes.load(M, m, r)
+    delays = calc_la_delays(ula_positions(N), -1.306379)
+    pcm = synth_pcm_host(N, frames * D, delays, seed)
     wq = orc.calc_mainlobe(M, N, FS, delays)
     wl = np.zeros((M, N), np.complex128)
     t0 = time.perf_counter()
-    _, nbf = orc.pipeline_gsc(h, g, M, m, r, dct, pcm[0], wq, wl)
-    dt = time.perf_counter() - t0
-    return {"value": nbf / dt, "unit": "frames/s", "cores": 1, "kind": "port",
-            "sample": "%d-mic %d-bin SubbandGSC chain, %d frames, 1 stream, oracle/btk_oracle.c -O3" % (N, M, nbf),
-            "xRT": nbf / dt / (FS / D)}
+    _, nbf = orc.pipeline_gsc(h, g, M, m, r, dct, pcm, wq, wl)
+    return nbf, time.perf_counter() - t0
+
+
+def cpu_baseline(N, M, m, r, dct, frames, all_cores=True):
+    """Time the oracle's frame-by-frame pull graph (N analysis banks -> SubbandGSC -> synthesis) on a bounded sample of the
+    same workload: ONE host core (the reference is single-threaded: the faithful figure, `value`), and -- BASELINE.md
+    section 2 item 2 -- one independent process per utterance stream on all cores the box gives this process."""
+    D = M >> r
+    nbf, dt = _cpu_stream((N, M, m, r, dct, frames, 20260927))
+    res = {"value": nbf / dt, "unit": "frames/s", "cores": 1, "kind": "port",
+           "sample": "%d-mic %d-bin SubbandGSC chain, %d frames, 1 stream, oracle/btk_oracle.c -O3" % (N, M, nbf),
+           "xRT": nbf / dt / (FS / D)}
+    if all_cores:
+        import multiprocessing as mp
+        cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        per = max(frames // 4, 256)                       # keeps the whole baseline leg at ~2x the single-core time
+        with mp.get_context("fork").Pool(cores) as pool:
+            t0 = time.perf_counter()
+            outs = pool.map(_cpu_stream, [(N, M, m, r, dct, per, 20260927 + 1000 * i) for i in range(cores)])
+            wall = time.perf_counter() - t0
+        tot = sum(o[0] for o in outs)
+        res["all_cores"] = {"value": tot / wall, "unit": "frames/s", "cores": cores, "kind": "port",
+                            "sample": "%d independent streams (one process each) x %d frames" % (cores, outs[0][0]),
+                            "xRT": tot / wall / (FS / D)}
+    return res
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--prewarm-ms", type=float, default=100.0,
                     help="untimed steps run before the warmup until this much wall time has passed: the host-side weight design "
                          "leaves the GPU idle for seconds and its clocks need tens of ms of load to come back up")
     ap.add_argument("--mics", type=int, default=64)
     ap.add_argument("--bins", type=int, default=512)
-    ap.add_argument("--streams", type=int, default=16, help="utterance streams per GPU")
+    ap.add_argument("--streams", type=int, default=32, help="utterance streams per GPU (BASELINE.md section 3: C0 = 32 on 1 GPU)")
     ap.add_argument("--frames", type=int, default=4096, help="frames per stream per step")
-    ap.add_argument("--cpu-frames", type=int, default=16000, help="frames of the CPU-baseline sample (~12 s of one core)")
+    ap.add_argument("--cpu-frames", type=int, default=12000, help="frames of the single-core CPU-baseline sample (~9 s of one core)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--staged", action="store_true",
                     help="time the staged chain (analysis -> HBM snapshots -> apply) instead of the fused kernel")
     args = ap.parse_args()
 
+    # --gpus N is the contract: one rank per GPU.  Launched bare (no torch.distributed.run environment) with N > 1 the
+    # script starts its own N ranks; launched by the driver (RANK / WORLD_SIZE set) the two must agree.
+    if args.gpus > 1 and "RANK" not in os.environ:
+        import subprocess
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", os.environ.get("MASTER_PORT", "29533"), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd))
+    if int(os.environ.get("WORLD_SIZE", "1")) != args.gpus:
+        sys.exit("bench.py: --gpus %d but WORLD_SIZE=%s -- launch with torch.distributed.run --nproc-per-node %d (or without it: "
+                 "the script spawns its own ranks)" % (args.gpus, os.environ.get("WORLD_SIZE", "1"), args.gpus))
+
     import torch
-    from distant_speech_recognition_amd import engine as eng
-    from tests.util import design_prototype, ula_positions, la_delays
+    from distant_speech_recognition_amd import engine as eng, prototypes
+    from distant_speech_recognition_amd.pybeamformer import calc_la_delays
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -103,12 +154,12 @@ def main():
     N, M, m, r, dct = args.mics, args.bins, 4, 1, 2
     D, K = M >> r, M // 2 + 1
     S, T = args.streams, args.frames
-    h, g = design_prototype(M, m), design_prototype(M, m, "g")
+    h, g = prototypes.load(M, m, r)                           # Nyquist(M) prototypes from the reference's designer (fixtures)
     afb = eng.FilterBank(h, M, m, r, dct)
     sfb = eng.FilterBank(g, M, m, r, dct, synthesis=True)
     L = (T - afb.processing_delay + afb.lookahead) * D          # so that num_frames(L) == T
     assert afb.num_frames(L) == T
-    delays = la_delays(ula_positions(N), -1.306379)
+    delays = calc_la_delays(ula_positions(N), -1.306379)
     pcm = synth_pcm_device(torch, dev, S, N, L, delays, seed=20260927 + 1000 * rank)
 
     # SubbandGSC weights: quiescent + blocking matrix + a fixed (non-zero) active weight vector
@@ -201,7 +252,7 @@ def main():
             """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/make_traffic_json.py), only if
             they were taken at this launch size"""
             try:
-                j = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")))
+                j = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_pmc_traffic.json")))
                 if (j["S"], j["T"], j["N"], j["M"]) != (S, T, N, M):
                     return None
                 for kname, e in j["kernels"].items():
@@ -215,9 +266,10 @@ def main():
             # per frame); the N x K snapshots that SURVEY 8(d) prices for the staged pair never exist in HBM
             roof = {"bound": "hbm", "kernel": "analysis512_bfz_kernel (fused analysis bank + SubbandGSC apply)",
                     "achieved": b_fused_hbm / t_a / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                    "frac": b_fused_hbm / t_a / HBM_PEAK, "traffic": pmc_traffic("analysis512_bfz_kernel"),
+                    "frac": b_fused_hbm / t_a / HBM_PEAK, "frac_survey_8d": (b_ana + b_bf) / t_a / HBM_PEAK,
+                    "traffic": pmc_traffic("analysis512_bfz_kernel"),
                     "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of profiles/pmc_workload.py at this launch "
-                                      "size (profiles/r01_pmc_traffic.json; gfx950 correction 2 x FETCH_SIZE)",
+                                      "size (profiles/r02_pmc_traffic.json; gfx950 correction 2 x FETCH_SIZE)",
                     "bytes_per_launch": b_fused_hbm, "avg_launch_ms": t_a * 1e3,
                     "staged_equivalent": {"bytes_per_launch": b_ana + b_bf, "GBps": (b_ana + b_bf) / t_a / 1e9,
                                           "frac": (b_ana + b_bf) / t_a / HBM_PEAK},
@@ -228,7 +280,7 @@ def main():
         else:
             roof = {"bound": "hbm", "kernel": "analysis512_kernel", "achieved": b_ana / t_ana / 1e9, "peak": HBM_PEAK / 1e9,
                     "unit": "GB/s", "frac": b_ana / t_ana / HBM_PEAK, "traffic": pmc_traffic("analysis512_kernel"),
-                    "traffic_source": "rocprofv3 --pmc passes, profiles/r01_pmc_traffic.json (2 x FETCH_SIZE + WRITE_SIZE)",
+                    "traffic_source": "rocprofv3 --pmc passes, profiles/r02_pmc_traffic.json (2 x FETCH_SIZE + WRITE_SIZE)",
                     "bytes_per_launch": b_ana, "avg_launch_ms": t_ana * 1e3}
         res = {
             "metric": "beamformed subband frames/sec, 64-mic 512-bin SubbandGSC",
@@ -251,8 +303,8 @@ def main():
                 "synthesis": {"ms": t_syn * 1e3, "GBps": b_syn / t_syn / 1e9, "frac": b_syn / t_syn / HBM_PEAK},
                 "adaptive_nlms_canceller": {"ms": t_nlms * 1e3, "GBps": b_bf / t_nlms / 1e9, "frac": b_bf / t_nlms / HBM_PEAK,
                                             "frames_per_s": S * T / t_nlms,
-                                            "note": "sequential recursion per (stream, bin): %d streams fill one wavefront per SIMD; "
-                                                    "see profiles/r01_bench_stages.json for 128 streams" % S},
+                                            "note": "sequential recursion per (stream, bin): %d streams = %.1f wavefronts per SIMD; "
+                                                    "see profiles/r02_bench_stages.json for 128 streams" % (S, S * K / 4 / 1024.0)},
             },
         }
         if not args.no_cpu and world == 1:

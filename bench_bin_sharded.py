@@ -27,7 +27,7 @@ def main():
     args = ap.parse_args()
     import torch
     from distant_speech_recognition_amd import engine as eng, sharding
-    from tests.util import design_prototype, ula_positions, la_delays
+    from bench_util import design_prototype, ula_positions, la_delays
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dev = torch.device("cuda", local_rank)

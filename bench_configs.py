@@ -63,7 +63,7 @@ def stage(ms, frames, bytes_=None, extra=None):
 def main():
     import torch
     from distant_speech_recognition_amd import engine as eng
-    from tests.util import design_prototype, ula_positions, la_delays
+    from bench_util import design_prototype, ula_positions, la_delays
     dev = torch.device("cuda:0")
     out = {}
 
@@ -139,9 +139,9 @@ def main():
     sfb = eng.FilterBank(design_prototype(M, 4, "g"), M, 4, 1, 2, synthesis=True)
     pcm, _ = pcm_for(torch, dev, afb, S, N, T, D, 3)
     t_a, X = timed(torch, lambda: afb.analysis(pcm))
-    # confs/wpe.json shape: lags 1..20 -> P = 160 taps per channel
-    t_we, G = timed(torch, lambda: eng.wpe_estimate(X, M, 1, 20, 2, -18.0, 0.0, 1e-4), n=2, warm=1)
-    t_wa, Xd = timed(torch, lambda: eng.wpe_apply(X, G, M, 1, 20))
+    # unit_test/confs/wpe.json: lower_num 0, upper_num 32 -> 33 lags, P = 8 x 33 = 264 taps per channel and bin
+    t_we, G = timed(torch, lambda: eng.wpe_estimate(X, M, 0, 32, 2, -18.0, 0.0, 1e-4), n=2, warm=1)
+    t_wa, Xd = timed(torch, lambda: eng.wpe_apply(X, G, M, 0, 32))
     delays = la_delays(ula_positions(N), -1.306379)
     wq = eng.weights_mainlobe(M, N, FS, delays)
     W = torch.from_numpy(eng.weights_gsc_effective(wq, np.zeros_like(wq), M)).to(dev)
@@ -154,7 +154,7 @@ def main():
     out["C3_8mic_wpe_gsc_zelinski_16streams_per_gpu"] = {
         "frames": S * T, "streams": S,
         "analysis": stage(t_a, S * T, (4 * D + 8 * K) * N * S * T),
-        "wpe_estimate_2it_lags1to20": stage(t_we, S * T),
+        "wpe_estimate_2it_lags0to32": stage(t_we, S * T),
         "wpe_apply": stage(t_wa, S * T),
         "gsc_apply_zelinski": stage(t_z, S * T, 8 * K * (N + 1) * S * T),
         "synthesis": stage(t_s, S * T, (8 * K + 4 * D) * S * T),

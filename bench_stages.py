@@ -37,7 +37,7 @@ def timeit(torch, fn, n=5, warm=2, prewarm_ms=40.0):
 def main():
     import torch
     from distant_speech_recognition_amd import engine as eng
-    from tests.util import ula_positions, la_delays
+    from bench_util import ula_positions, la_delays
     dev = torch.device("cuda:0")
     out = {}
     # ---- C0 snapshots: 64 mics, 512 bins

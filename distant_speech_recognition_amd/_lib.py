@@ -52,6 +52,9 @@ SIGNATURES = {
     "btk_fb_analysis_bf": (_i, [_vp, _vp, _l, _l, _i, _i, _vp, _i, _vp, _l, _l, _l, _vp, _l, _vp]),
     "btk_nlms_workspace_bytes": (_l, [_i, _l]),
     "btk_nlms_process": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _l, _l, _vp, _vp, _vp, _vp, _vp]),
+    "btk_nlms_process_nc": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _l, _l, _vp, _vp, _vp, _vp, _vp]),
+    "btk_nlms_constraint_vectors": (_i, [_vp, _vp, _i, _i, _vp]),
+    "btk_nlms_u_to_wa_nc": (_i, [_vp, _vp, _i, _i, _vp]),
     "btk_nlms_wa_to_u": (_i, [_vp, _vp, _i, _vp]),
     "btk_nlms_u_to_wa": (_i, [_vp, _vp, _i, _vp]),
     "btk_rls_workspace_bytes": (_l, [_i, _l]),

@@ -230,6 +230,66 @@ int btk_nlms_wa_to_u(const double* waH_in, const double* B_in, int N, double* u_
   return BTK_OK;
 }
 
+// The Nc - 1 orthonormal vectors that, with vs / |vs|, span the orthogonal complement of span(conj(B)) (B [N][N-NC] from
+// btk_weights_blocking_matrix(vs, N, NC)): conj(B) B^T = I - vs vs^H / |vs|^2 - sum_j c_j c_j^H.  Gram-Schmidt on the
+// columns of that residual projector, largest column first.  cx [NC-1][N] complex128.
+int btk_nlms_constraint_vectors(const double* vs_in, const double* B_in, int N, int NC, double* cx_out)
+{
+  if (!vs_in || !B_in || !cx_out) return btk_set_error(BTK_ERR_PARAMETER, "btk_nlms_constraint_vectors: null argument");
+  if (N < 2 || NC < 1 || NC >= N) return btk_set_error(BTK_ERR_DIMENSION, "btk_nlms_constraint_vectors: N=%d NC=%d", N, NC);
+  const cd* vs = reinterpret_cast<const cd*>(vs_in);
+  const cd* B = reinterpret_cast<const cd*>(B_in);
+  cd* cx = reinterpret_cast<cd*>(cx_out);
+  const int bs = N - NC;
+  double vv = 0.0;
+  for (int i = 0; i < N; i++) vv += std::norm(vs[i]);
+  if (!(vv > 0.0)) return btk_set_error(BTK_ERR_NUMERIC, "btk_nlms_constraint_vectors: zero array manifold");
+  std::vector<cd> R((size_t)N * N);                        // residual projector, Hermitian
+  for (int a = 0; a < N; a++)
+    for (int b = 0; b < N; b++) {
+      cd acc = (a == b ? cd(1, 0) : cd(0, 0)) - vs[a] * std::conj(vs[b]) / vv;
+      for (int i = 0; i < bs; i++) acc -= std::conj(B[(size_t)a * bs + i]) * B[(size_t)b * bs + i];
+      R[(size_t)a * N + b] = acc;
+    }
+  std::vector<char> used(N, 0);
+  for (int j = 0; j < NC - 1; j++) {
+    int best = -1; double bn = -1.0;
+    std::vector<cd> v(N), bv(N);
+    for (int col = 0; col < N; col++) {
+      if (used[col]) continue;
+      for (int a = 0; a < N; a++) v[a] = R[(size_t)a * N + col];
+      for (int q = 0; q < j; q++) {                       // orthogonalise against the vectors found so far
+        cd ip(0, 0);
+        for (int a = 0; a < N; a++) ip += std::conj(cx[(size_t)q * N + a]) * v[a];
+        for (int a = 0; a < N; a++) v[a] -= cx[(size_t)q * N + a] * ip;
+      }
+      double nn = 0.0;
+      for (int a = 0; a < N; a++) nn += std::norm(v[a]);
+      if (nn > bn) { bn = nn; best = col; bv = v; }
+    }
+    if (best < 0 || !(bn > 1e-20)) return btk_set_error(BTK_ERR_NUMERIC, "btk_nlms_constraint_vectors: rank of the residual projector < NC - 1");
+    used[best] = 1;
+    const double inv = 1.0 / std::sqrt(bn);
+    for (int a = 0; a < N; a++) cx[(size_t)j * N + a] = bv[a] * inv;
+  }
+  return BTK_OK;
+}
+
+int btk_nlms_u_to_wa_nc(const double* u_in, const double* B_in, int N, int NC, double* waH_out)
+{
+  if (N < 2 || NC < 1 || NC >= N) return btk_set_error(BTK_ERR_DIMENSION, "btk_nlms_u_to_wa_nc: N=%d NC=%d", N, NC);
+  const cd* u = reinterpret_cast<const cd*>(u_in);
+  const cd* B = reinterpret_cast<const cd*>(B_in);
+  cd* wa = reinterpret_cast<cd*>(waH_out);
+  const int bs = N - NC;
+  for (int i = 0; i < bs; i++) {
+    cd acc(0.0, 0.0);
+    for (int n = 0; n < N; n++) acc += u[n] * std::conj(B[(size_t)n * bs + i]);
+    wa[i] = acc;
+  }
+  return BTK_OK;
+}
+
 int btk_nlms_u_to_wa(const double* u_in, const double* B_in, int N, double* waH_out)
 {
   if (N < 2) return btk_set_error(BTK_ERR_DIMENSION, "btk_nlms_u_to_wa: N=%d", N);

@@ -272,13 +272,19 @@ template <int GROUP> __device__ __forceinline__ float group_sum2(float v)
 // GROUP lanes x CPL channels per lane cooperate on one bin; a wavefront carries 64/GROUP bins, so the
 // per-step scalar arithmetic of the recursion is shared by 64/GROUP bins and the reductions stay inside
 // DPP rows.  TBF frames per LDS tile (rows of TBF*8 bytes read as float4 pairs).  Requires even T_stride.
-template <int GROUP, int CPL, int TBF>
+// NC > 1 (Nc constraints, pybeamformer.py:309-341 with Nc > 1): the reference's blocking matrix keeps the FIRST N - Nc
+// Gram-Schmidt columns of the same projector, so conj(B) B^T = I - vs vs^H / |vs|^2 - sum_j c_j c_j^H with Nc - 1 further
+// orthonormal vectors c_j (CX [K][NC-1][N], from btk_nlms_constraint_vectors).  Only Q x and |Q x|^2 change:
+//     Q x = x - vs Yc / |vs|^2 - sum_j c_j (c_j^H x),   |Q x|^2 = |x|^2 - |Yc|^2 / |vs|^2 - sum_j |c_j^H x|^2;
+// u Q x = u x still holds because u stays in the row space of B^T.
+template <int GROUP, int CPL, int TBF, int NC = 1>
 __global__ __launch_bounds__(64)
 void nlms_bin2_kernel(const float2* __restrict__ X, const float2* __restrict__ VS, float2* __restrict__ Y,
                       int K, int N, long T_stride, long T, const float* __restrict__ ctrl,
                       const double* __restrict__ stream_state_before, NlmsParams p,
-                      float2* __restrict__ U, float* __restrict__ sigma2)
+                      float2* __restrict__ U, float* __restrict__ sigma2, const float2* __restrict__ CX = nullptr)
 {
+  constexpr int NX = NC > 1 ? NC - 1 : 1;
   constexpr int BPW = 64 / GROUP;
   constexpr int NR = GROUP * CPL;
   constexpr int LDWv = TBF + 1;
@@ -308,6 +314,16 @@ void nlms_bin2_kernel(const float2* __restrict__ X, const float2* __restrict__ V
   const float vv = group_sum2<GROUP>(vvp);
   const float inv_vv = vv > 0.f ? 1.f / vv : 0.f;
   float sig = kvalid ? sigma2[(long)s * K + k] : 1.f;
+  float2 cx[NX][CPL];
+  if constexpr (NC > 1) {
+#pragma unroll
+    for (int jx = 0; jx < NX; jx++)
+#pragma unroll
+      for (int c = 0; c < CPL; c++) {
+        const int n = gl + GROUP * c;
+        cx[jx][c] = (kvalid && n < N) ? CX[((long)k * NX + jx) * N + n] : make_float2(0.f, 0.f);
+      }
+  }
 
   float4 pre[NPASS];
   float creg = 0.f;
@@ -366,6 +382,20 @@ void nlms_bin2_kernel(const float2* __restrict__ X, const float2* __restrict__ V
         ycr = group_sum2<GROUP>(ycr); yci = group_sum2<GROUP>(yci);
         pr = group_sum2<GROUP>(pr);   pi = group_sum2<GROUP>(pi);
         xx = group_sum2<GROUP>(xx);
+        float dxr[NX], dxi[NX], dd = 0.f;                             // d_j = c_j^H x
+        if constexpr (NC > 1) {
+#pragma unroll
+          for (int jx = 0; jx < NX; jx++) {
+            float ar = 0.f, ai = 0.f;
+#pragma unroll
+            for (int c = 0; c < CPL; c++) {
+              ar = fmaf(cx[jx][c].x, x[c].x, fmaf(cx[jx][c].y, x[c].y, ar));
+              ai = fmaf(cx[jx][c].x, x[c].y, fmaf(-cx[jx][c].y, x[c].x, ai));
+            }
+            dxr[jx] = group_sum2<GROUP>(ar); dxi[jx] = group_sum2<GROUP>(ai);
+            dd = fmaf(dxr[jx], dxr[jx], fmaf(dxi[jx], dxi[jx], dd));
+          }
+        }
         // |u|^2: summed from u at the first step of a tile, carried as cK^2 nrm (the same expansion the clip uses) after
         // an update inside it -- rounding drift is bounded to TBF steps
         if (tt == 0) {
@@ -385,14 +415,21 @@ void nlms_bin2_kernel(const float2* __restrict__ X, const float2* __restrict__ V
           const float a = gam * __builtin_amdgcn_rcpf(se);            // 1-ulp reciprocal: tolerance is 1e-4
           const float c1 = p.reg > 0.f ? 1.f - a * p.reg : 1.f;
           const float c2r = a * er, c2i = a * ei;
-          const float gg = xx - (ycr * ycr + yci * yci) * inv_vv;
+          const float gg = xx - (ycr * ycr + yci * yci) * inv_vv - dd;
           const float nrm = c1 * c1 * uu + (c2r * c2r + c2i * c2i) * gg + 2.f * c1 * (c2r * pr + c2i * pi);
           const float cK = nrm > p.max_wa_l2norm ? __builtin_amdgcn_sqrtf(p.max_wa_l2norm * __builtin_amdgcn_rcpf(nrm)) : 1.f;
           const float sr = ycr * inv_vv, si = yci * inv_vv;
 #pragma unroll
           for (int c = 0; c < CPL; c++) {
-            const float qr = x[c].x - (vs[c].x * sr - vs[c].y * si);
-            const float qi = x[c].y - (vs[c].x * si + vs[c].y * sr);
+            float qr = x[c].x - (vs[c].x * sr - vs[c].y * si);
+            float qi = x[c].y - (vs[c].x * si + vs[c].y * sr);
+            if constexpr (NC > 1) {
+#pragma unroll
+              for (int jx = 0; jx < NX; jx++) {
+                qr -= cx[jx][c].x * dxr[jx] - cx[jx][c].y * dxi[jx];
+                qi -= cx[jx][c].x * dxi[jx] + cx[jx][c].y * dxr[jx];
+              }
+            }
             const float nr = c1 * u[c].x + (c2r * qr + c2i * qi);
             const float ni = c1 * u[c].y + (c2i * qr - c2r * qi);
             u[c] = make_float2(cK * nr, cK * ni);
@@ -424,15 +461,16 @@ void nlms_bin2_kernel(const float2* __restrict__ X, const float2* __restrict__ V
   }
 }
 
-template <int GROUP, int CPL, int TBF>
+template <int GROUP, int CPL, int TBF, int NC = 1>
 int launch_bin2(const float2* X, const float2* VS, float2* Y, int S, int K, int N, long T_stride, long T,
-                const float* ctrl, const double* state_before, NlmsParams p, float2* U, float* sigma2, hipStream_t st)
+                const float* ctrl, const double* state_before, NlmsParams p, float2* U, float* sigma2, hipStream_t st,
+                const float2* CX = nullptr)
 {
   constexpr int BPW = 64 / GROUP;
   const size_t lds = sizeof(float2) * (size_t)64 * CPL * (TBF + 1);
   dim3 grid((unsigned)((K + BPW - 1) / BPW), (unsigned)S);
-  hipLaunchKernelGGL((nlms_bin2_kernel<GROUP, CPL, TBF>), grid, dim3(64), lds, st, X, VS, Y, K, N, T_stride, T,
-                     ctrl, state_before, p, U, sigma2);
+  hipLaunchKernelGGL((nlms_bin2_kernel<GROUP, CPL, TBF, NC>), grid, dim3(64), lds, st, X, VS, Y, K, N, T_stride, T,
+                     ctrl, state_before, p, U, sigma2, CX);
   BTK_HIP_CHECK(hipGetLastError());
   return BTK_OK;
 }
@@ -478,8 +516,17 @@ int btk_nlms_process(const float* params /* host, 8 floats */, const void* vs, c
                      int S, int M, int N, long T_stride, long T,
                      void* u_state, float* sigma2, double* stream_state, void* workspace, void* stream)
 {
-  if (!params || !vs || !X || !Y || !u_state || !sigma2 || !stream_state || !workspace)
+  return btk_nlms_process_nc(params, vs, nullptr, 1, X, Y, S, M, N, T_stride, T, u_state, sigma2, stream_state, workspace, stream);
+}
+
+int btk_nlms_process_nc(const float* params /* host, 8 floats */, const void* vs, const void* cextra, int NC, const void* X, void* Y,
+                        int S, int M, int N, long T_stride, long T,
+                        void* u_state, float* sigma2, double* stream_state, void* workspace, void* stream)
+{
+  if (!params || !vs || !X || !Y || !u_state || !sigma2 || !stream_state || !workspace || (NC > 1 && !cextra))
     return btk_set_error(BTK_ERR_PARAMETER, "btk_nlms_process: null argument");
+  if (NC < 1 || NC > 4 || NC >= N)
+    return btk_set_error(BTK_ERR_DIMENSION, "btk_nlms_process: %d constraints (1..4, < N = %d channels) not supported", NC, N);
   if (S <= 0 || N < 2 || M < 2 || T < 0 || T_stride < T)
     return btk_set_error(BTK_ERR_DIMENSION, "btk_nlms_process: bad sizes S=%d N=%d M=%d T=%ld", S, N, M, T);
   if (N > 256) return btk_set_error(BTK_ERR_DIMENSION, "btk_nlms_process: N=%d > 256 channels not supported", N);
@@ -508,6 +555,20 @@ int btk_nlms_process(const float* params /* host, 8 floats */, const void* vs, c
   static const bool v1 = getenv("BTK_NLMS_V1") != nullptr;                       // A/B switches (benchmarking only)
   static const int alt = getenv("BTK_NLMS_ALT") ? atoi(getenv("BTK_NLMS_ALT")) : 0;
   const bool vec_ok = (T_stride % 2 == 0) && ((reinterpret_cast<uintptr_t>(X) & 15) == 0);
+  if (NC > 1) {
+    if (!vec_ok) return btk_set_error(BTK_ERR_DIMENSION, "btk_nlms_process: Nc > 1 needs an even T_stride and a 16-byte aligned X");
+    const float2* CXp = static_cast<const float2*>(cextra);
+#define BTK_NLMS_NC(G, C, TB_)                                                                                                      \
+    switch (NC) {                                                                                                                    \
+      case 2: return launch_bin2<G, C, TB_, 2>(Xp, VS, Yp, S, K, N, T_stride, T, ctrl, state_before, p, U, sigma2, st, CXp);          \
+      case 3: return launch_bin2<G, C, TB_, 3>(Xp, VS, Yp, S, K, N, T_stride, T, ctrl, state_before, p, U, sigma2, st, CXp);          \
+      default: return launch_bin2<G, C, TB_, 4>(Xp, VS, Yp, S, K, N, T_stride, T, ctrl, state_before, p, U, sigma2, st, CXp);         \
+    }
+    if (N <= 16) { BTK_NLMS_NC(16, 1, 16) }
+    else if (N <= 64) { BTK_NLMS_NC(16, 4, 8) }
+    else { BTK_NLMS_NC(64, 4, 8) }
+#undef BTK_NLMS_NC
+  }
   if (vec_ok && !v1) {
     if (N <= 8)        return launch_bin2<8, 1, 16>(Xp, VS, Yp, S, K, N, T_stride, T, ctrl, state_before, p, U, sigma2, st);
     else if (N <= 16)  return launch_bin2<16, 1, 16>(Xp, VS, Yp, S, K, N, T_stride, T, ctrl, state_before, p, U, sigma2, st);

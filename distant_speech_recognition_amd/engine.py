@@ -270,15 +270,22 @@ class NLMSState:
     """Device-resident state of S independent SubbandGSCLMSBeamformer recursions
     (reset_stats, lib/pybeamformer.py:745-758)."""
 
-    def __init__(self, S, M, N, device, **kw):
+    def __init__(self, S, M, N, device, Nc=1, **kw):
         self.p = dict(NLMS_DEFAULTS)
         self.p.update(kw)
         self.S, self.M, self.N, self.K = S, M, N, M // 2 + 1
+        self.Nc = int(Nc)
+        self.cextra = None                     # Nc > 1: complex64 [K][Nc-1][N], see set_constraints
         self.u = torch.zeros((S, self.K, N), dtype=torch.complex64, device=device)
         self.sigma2 = torch.empty((S, self.K), dtype=torch.float32, device=device)
         self.stream_state = torch.empty((S, 4), dtype=torch.float64, device=device)
         self.reset_stats()
         self._ws = None
+
+    def set_constraints(self, vs):
+        """Nc > 1: derive the extra projector directions from the array manifold vs complex [K][N] (host)."""
+        if self.Nc > 1:
+            self.cextra = torch.from_numpy(nlms_constraint_vectors(vs, self.Nc)).to(self.u.device)
 
     def reset_stats(self):
         self.u.zero_()
@@ -312,18 +319,38 @@ def nlms_process(vs, X, state, out=None):
     _check(out, "Y", torch.complex64, (S, K, T))
     params = state.params_array()
     ws = state.workspace(T)
-    check(_lib.lib().btk_nlms_process(_np_ptr(params), _ptr(vs), _ptr(X), _ptr(out), S, state.M, N, T, T,
-                                      _ptr(state.u), _ptr(state.sigma2), _ptr(state.stream_state), _ptr(ws), _stream()))
+    Nc = getattr(state, "Nc", 1)
+    if Nc > 1:
+        cx = getattr(state, "cextra", None)
+        if cx is None:
+            raise _lib.BtkError(_lib.BTK_ERR_PARAMETER, "nlms_process: Nc = %d needs state.set_constraints(vs) first" % Nc)
+        _check(cx, "cextra", torch.complex64, (K, Nc - 1, N))
+    check(_lib.lib().btk_nlms_process_nc(_np_ptr(params), _ptr(vs), _ptr(state.cextra) if Nc > 1 else None, Nc, _ptr(X), _ptr(out),
+                                         S, state.M, N, T, T, _ptr(state.u), _ptr(state.sigma2), _ptr(state.stream_state),
+                                         _ptr(ws), _stream()))
     return out
 
 
+def nlms_constraint_vectors(vs, Nc):
+    """The Nc - 1 extra orthonormal directions the Nc-constraint canceller's projector loses per bin (include/btkhip.h):
+    vs complex [K][N] (host) -> complex64 [K][Nc-1][N] (host)."""
+    vs = np.ascontiguousarray(vs, np.complex128)
+    K, N = vs.shape
+    out = np.zeros((K, Nc - 1, N), np.complex128)
+    for k in range(K):
+        B = weights_blocking_matrix(vs[k], Nc)
+        check(_lib.lib().btk_nlms_constraint_vectors(_np_ptr(vs[k]), _np_ptr(B), N, Nc, _np_ptr(out[k])))
+    return out.astype(np.complex64)
+
+
 def nlms_u_to_wa(u, B):
-    """wa^H (complex128 [N-1]) from the engine state u (complex [N]) and the bin's blocking matrix B."""
+    """wa^H (complex128 [N-Nc]) from the engine state u (complex [N]) and the bin's blocking matrix B [N][N-Nc]."""
     u = np.ascontiguousarray(u, np.complex128)
     B = np.ascontiguousarray(B, np.complex128)
     N = u.shape[0]
-    wa = np.zeros(N - 1, np.complex128)
-    check(_lib.lib().btk_nlms_u_to_wa(_np_ptr(u), _np_ptr(B), N, _np_ptr(wa)))
+    Nc = N - B.shape[1]
+    wa = np.zeros(N - Nc, np.complex128)
+    check(_lib.lib().btk_nlms_u_to_wa_nc(_np_ptr(u), _np_ptr(B), N, Nc, _np_ptr(wa)))
     return wa
 
 

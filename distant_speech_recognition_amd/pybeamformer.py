@@ -217,8 +217,8 @@ class SubbandGSCLMSBeamformer(SubbandBeamformer):
     def __init__(self, spec_sources, beta=0.97, gamma=0.01, init_diagonal_load=1.0E+6, regularization_param=1.0E-4,
                  energy_floor=90, sil_thresh=1.0E+8, max_wa_l2norm=100.0, min_frames=128, slowdown_after=4096, Nc=1):
         SubbandBeamformer.__init__(self, spec_sources)
-        if Nc != 1:
-            raise NotImplementedError("the GPU canceller supports Nc = 1 (see DESIGN.md)")
+        if not (1 <= Nc <= 4 and Nc < len(spec_sources)):
+            raise ValueError("Nc = %d: the GPU canceller takes 1..4 constraints, fewer than the %d channels" % (Nc, len(spec_sources)))
         self._Nc = Nc
         self._front = SubbandGSCPtr(fftlen=self._fftlen, half_band_shift=False)   # owns channels + device snapshots
         for source in self._spec_sources:
@@ -241,6 +241,8 @@ class SubbandGSCLMSBeamformer(SubbandBeamformer):
         self._BmH = None                               # formed lazily (only needed to export wa)
         self._Y = None
         self._frames = None
+        if self._state is not None:
+            self._state.cextra = None                  # the constraint directions follow the new manifold
 
     def _blocking(self, m):
         return calc_blocking_matrix(self._vs[m], self._Nc)
@@ -255,7 +257,9 @@ class SubbandGSCLMSBeamformer(SubbandBeamformer):
             assert self._vs is not None, "call calc_beamformer_weights() first"
             X = self._front.device_snapshots()
             if self._state is None:
-                self._state = engine.NLMSState(1, self._fftlen, self._chan_num, device(), **self._params)
+                self._state = engine.NLMSState(1, self._fftlen, self._chan_num, device(), Nc=self._Nc, **self._params)
+            if self._Nc > 1 and self._state.cextra is None:
+                self._state.set_constraints(self._vs)
             self._Y = engine.nlms_process(torch.from_numpy(self._vs.astype(np.complex64)).to(device()), X, self._state)
         return self._Y
 
@@ -270,7 +274,7 @@ class SubbandGSCLMSBeamformer(SubbandBeamformer):
     def _waH(self):
         """Active weights in the reference's basis, wa^H = u conj(B) per bin."""
         if self._state is None or self._vs is None:
-            return np.zeros((self._fftlen2 + 1, self._chan_num - 1), complex)
+            return np.zeros((self._fftlen2 + 1, self._chan_num - self._Nc), complex)
         u = self._state.u[0].cpu().numpy().astype(np.complex128)
         return np.stack([engine.nlms_u_to_wa(u[m], self._blocking(m)) for m in range(self._fftlen2 + 1)])
 

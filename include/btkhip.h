@@ -115,6 +115,15 @@ long btk_nlms_workspace_bytes(int S, long T);
 int  btk_nlms_process(const float* params, const void* vs, const void* X, void* Y,
                       int S, int M, int N, long T_stride, long T,
                       void* u_state, float* sigma2, double* stream_state, void* workspace, void* stream);
+/* Nc > 1 constraints (SubbandGSCLMSBeamformer(..., Nc), lib/pybeamformer.py:588-607, 742): the blocking matrix keeps the
+ * first N - Nc Gram-Schmidt columns (calc_blocking_matrix, :309-341), so the canceller's projector loses Nc - 1 more
+ * directions: cextra [dev] complex64 [K][NC-1][N], per bin from btk_nlms_constraint_vectors (host, complex128
+ * [NC-1][N]; B [N][N-NC] from btk_weights_blocking_matrix).  NC = 1 is btk_nlms_process.  1 <= NC <= 4.              */
+int  btk_nlms_process_nc(const float* params, const void* vs, const void* cextra, int NC, const void* X, void* Y,
+                         int S, int M, int N, long T_stride, long T,
+                         void* u_state, float* sigma2, double* stream_state, void* workspace, void* stream);
+int  btk_nlms_constraint_vectors(const double* vs, const double* B, int N, int NC, double* cx);
+int  btk_nlms_u_to_wa_nc(const double* u, const double* B, int N, int NC, double* waH);
 /* Host-side change of basis between the reference's active weights wa^H (complex128 [N-1], as
  * kept in SubbandGSCLMSBeamformer._waH) and the engine state u = wa^H B^T (complex128 [N]);
  * B [host] complex128 [N][N-1] from btk_weights_blocking_matrix.                               */

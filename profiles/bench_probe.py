@@ -5,7 +5,7 @@ import os, sys, numpy as np, torch
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import bench
 from distant_speech_recognition_amd import engine as eng
-from tests.util import design_prototype, ula_positions, la_delays
+from bench_util import design_prototype, ula_positions, la_delays
 dev = torch.device("cuda:0")
 N, M, m, r, dct, S, T = 64, 512, 4, 1, 2, 16, 4096
 D, K = M >> r, M // 2 + 1

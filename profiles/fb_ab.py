@@ -2,7 +2,7 @@
 import os, sys, torch
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "."))
 from distant_speech_recognition_amd import engine as eng
-from tests.util import design_prototype
+from bench_util import design_prototype
 dev = torch.device("cuda:0")
 for M in (256, 512, 1024, 2048):
     S, N = 8, 64

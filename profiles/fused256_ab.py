@@ -3,7 +3,7 @@ import os, sys, json
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from distant_speech_recognition_amd import engine as eng
-from tests.util import design_prototype
+from bench_util import design_prototype
 dev = torch.device("cuda:0")
 N, M, S, T = 64, 256, 16, 8192
 D, K = M // 2, M // 2 + 1

@@ -7,7 +7,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch
 from distant_speech_recognition_amd import engine as eng
-from tests.util import design_prototype, ula_positions, la_delays
+from bench_util import design_prototype, ula_positions, la_delays
 
 dev = torch.device("cuda:0")
 N, M, S, T = 64, 512, 16, 4096

@@ -4,7 +4,7 @@ import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from distant_speech_recognition_amd import engine as eng
-from tests.util import design_prototype, ula_positions, la_delays
+from bench_util import design_prototype, ula_positions, la_delays
 dev = torch.device("cuda:0")
 N, M, S, T = 8, 512, 1, 4096
 D, K = M // 2, M // 2 + 1

@@ -1,7 +1,7 @@
 import sys, os, numpy as np, torch
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "."))
 from distant_speech_recognition_amd import engine as eng
-from tests.util import ula_positions, la_delays
+from bench_util import ula_positions, la_delays
 dev = torch.device("cuda:0")
 for (S, N, M, T) in ((16, 64, 512, 4096), (64, 64, 512, 1024), (128, 64, 512, 512), (64, 8, 512, 4096)):
     K = M // 2 + 1

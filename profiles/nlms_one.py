@@ -2,7 +2,7 @@
 import sys, os, numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from distant_speech_recognition_amd import engine as eng
-from tests.util import ula_positions, la_delays
+from bench_util import ula_positions, la_delays
 dev = torch.device("cuda:0")
 S, N, M, T = int(os.environ.get("NLMS_S", 16)), 64, 512, 4096
 K = M // 2 + 1

@@ -3,7 +3,7 @@ Same analysis / apply launches with the time axis padded by a few frames."""
 import os, sys, torch, numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from distant_speech_recognition_amd import engine as eng
-from tests.util import design_prototype
+from bench_util import design_prototype
 dev = torch.device("cuda:0")
 M, S, N, T = 512, 16, 64, 4096
 D, K = M // 2, M // 2 + 1

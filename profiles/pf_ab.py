@@ -3,7 +3,7 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from distant_speech_recognition_amd import engine as eng
-from tests.util import ula_positions, la_delays
+from bench_util import ula_positions, la_delays
 dev = torch.device("cuda:0")
 for N in (8, 64):
     S, M, T = 16, 512, 4096

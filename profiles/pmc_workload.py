@@ -6,7 +6,7 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from distant_speech_recognition_amd import engine as eng
-from tests.util import design_prototype
+from bench_util import design_prototype
 
 S, N, M, T = int(os.environ.get("PMC_S", 16)), 64, 512, int(os.environ.get("PMC_T", 4096))
 dev = torch.device("cuda:0")

@@ -47,7 +47,9 @@ def test_c3_mvdr_64mic_1024bins(orc, dev):
         tH = inv.conj().T @ wq[k]
         w = tH / (N * np.vdot(tH, wq[k]))                       # calc_mvdr_weights, beamformer.cc:2386-2396
         yref = w.conj() @ xk
-        assert np.max(np.abs(Y[k] - yref)) <= 2e-3 * np.max(np.abs(yref))
+        # + the filter bank's own float32 tolerance (1e-5 of the largest subband sample): with the designed
+        # Nyquist(M) prototype the Nyquist bin carries almost nothing, its samples are rounding residue of the FFT
+        assert np.max(np.abs(Y[k] - yref)) <= 2e-3 * np.max(np.abs(yref)) + 1e-5 * float(np.max(np.abs(Xh)))
     assert np.allclose(W[0].cpu().numpy(), 1.0)
 
 

@@ -88,3 +88,68 @@ def _full(Xe, M):
     full[:, :, :K] = np.transpose(Xe.astype(np.complex128), (2, 1, 0))
     full[:, :, K:] = np.conj(full[:, :, M // 2 - 1:0:-1])
     return full
+
+
+@pytest.mark.parametrize("Nc", [2, 3])
+def test_nlms_nc_constraints_vs_reference_python_golden(orc, dev, proto256, kinect_pcm, Nc):
+    """SubbandGSCLMSBeamformer(..., Nc) with Nc > 1 (lib/pybeamformer.py:588-607, 742): the blocking matrix keeps the first
+    N - Nc Gram-Schmidt columns, the canceller's projector loses Nc - 1 more directions.  GPU output and exported wa^H
+    against what the REFERENCE's own Python produced (tests/golden/gen_golden_pybeamformer_nc.py)."""
+    import os
+    import torch
+    from distant_speech_recognition_amd import engine as eng
+    G = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "pybeamformer_nc_golden.npz"))
+    T, M, N, K = int(G["meta_T"][0]), 256, 4, 129
+    X = _frames_from_kinect(orc, proto256, kinect_pcm, T)
+    delays = G["delays"]
+    vs = np.stack([np.exp(-2j * np.pi * k * (16000.0 / M) * delays) / N for k in range(K)])
+    kw = dict(min_frames=16, gamma=0.05, slowdown_after=64)
+    st = eng.NLMSState(1, M, N, dev, Nc=Nc, **kw)
+    st.set_constraints(vs)
+    assert st.cextra.shape == (K, Nc - 1, N)
+    Y = eng.nlms_process(torch.from_numpy(vs.astype(np.complex64)).to(dev),
+                         torch.from_numpy(_to_engine_layout(X, K)).to(dev), st).cpu().numpy()[0]
+    tag = "nlms_nc%d" % Nc
+    ref = G[tag + "_Y"]
+    assert np.max(np.abs(Y[::5].T - ref)) <= 1e-4 * np.max(np.abs(ref))
+    u = st.u.cpu().numpy()[0].astype(np.complex128)
+    B40 = eng.weights_blocking_matrix(vs[40], Nc)
+    assert np.max(np.abs(B40 - G[tag + "_blockmat_k40"])) < 1e-12                     # the host designer == the reference's
+    for k in (5, 40, 128):
+        wa = eng.nlms_u_to_wa(u[k], eng.weights_blocking_matrix(vs[k], Nc))
+        assert wa.shape == (N - Nc,)
+        assert np.max(np.abs(wa - G[tag + "_waH"][k])) <= 2e-4 * max(1.0, np.max(np.abs(G[tag + "_waH"])))
+    se = st.sigma2.cpu().numpy()[0]
+    assert np.max(np.abs(se - G[tag + "_subband_energy"]) / G[tag + "_subband_energy"]) < 1e-4
+    # the constraint directions: orthonormal, orthogonal to vs and to span(conj(B))
+    cx = st.cextra.cpu().numpy().astype(np.complex128)
+    for k in (1, 40, 128):
+        B = eng.weights_blocking_matrix(vs[k], Nc)
+        assert np.max(np.abs(cx[k].conj() @ cx[k].T - np.eye(Nc - 1))) < 1e-6
+        assert np.max(np.abs(cx[k].conj() @ vs[k])) < 1e-6 and np.max(np.abs(cx[k].conj() @ B.conj())) < 1e-6
+
+
+@pytest.mark.parametrize("N,Nc", [(8, 2), (64, 2), (16, 4), (100, 3)])
+def test_nlms_nc_matches_oracle_synthetic(orc, dev, N, Nc):
+    import torch
+    from distant_speech_recognition_amd import engine as eng
+    from tests.util import ula_positions, la_delays
+    M, T, S = 64, 40, 2
+    rng = np.random.default_rng(N * 10 + Nc)
+    K = M // 2 + 1
+    delays = la_delays(ula_positions(N), -1.306379)
+    kw = dict(min_frames=8, gamma=0.05, slowdown_after=32, max_wa_l2norm=0.5)
+    Xs = (rng.normal(size=(S, T, N, M)) + 1j * rng.normal(size=(S, T, N, M))) * 2000.0
+    Xs[..., K:] = np.conj(Xs[..., M // 2 - 1:0:-1])
+    Xs[..., 0] = Xs[..., 0].real
+    Xs[..., M // 2] = Xs[..., M // 2].real
+    Xe = np.concatenate([_to_engine_layout(Xs[s], K) for s in range(S)])
+    vs = np.stack([np.exp(-2j * np.pi * k * (16000.0 / M) * delays) / N for k in range(K)])
+    st = eng.NLMSState(S, M, N, dev, Nc=Nc, **kw)
+    st.set_constraints(vs)
+    Y = eng.nlms_process(torch.from_numpy(vs.astype(np.complex64)).to(dev), torch.from_numpy(Xe).to(dev), st).cpu().numpy()
+    for s in range(S):
+        o = orc.NLMS(M, N, Nc=Nc, **kw)
+        o.calc_beamformer_weights(16000, delays)
+        ref = o.run(_full(Xe[s], M))
+        assert np.max(np.abs(Y[s].T - ref[:, :K])) <= 2e-4 * np.max(np.abs(ref))

@@ -46,3 +46,32 @@ def test_wpe_matches_oracle(orc, dev, C, M, T, lower, upper, iters):
     assert np.max(np.abs(got - ref[:, :, :K])) <= 1e-3 * np.max(np.abs(ref))
     # dereverberation actually removes energy
     assert np.sum(np.abs(got) ** 2) < 0.99 * np.sum(np.abs(Yo[:, :, :K]) ** 2)
+
+
+def test_wpe_reference_configuration_8ch_lags0to32(orc, dev):
+    """unit_test/confs/wpe.json as shipped: lower_num 0, upper_num 32 (33 lags incl. the current frame), 2 iterations,
+    load_db -18, diagonal_bias 1e-4 -- with 8 channels that is a 264 x 264 system per bin and channel (the blocked
+    Cholesky path of wpe_solve_kernel, several 64 x 64 HERK tiles).  M = 16 keeps the float64 oracle at ~10 s."""
+    import torch
+    from distant_speech_recognition_amd import engine as eng
+    C, M, T, lower, upper, iters = 8, 16, 520, 0, 32, 2
+    rng = np.random.default_rng(2026)
+    K = M // 2 + 1
+    Y = _reverberant(rng, T, C, M)
+    Xe = np.ascontiguousarray(np.transpose(Y[:, :, :K], (2, 1, 0))[None]).astype(np.complex64)
+    Yo = np.zeros((T, C, M), np.complex128)
+    Yo[:, :, :K] = np.transpose(Xe[0].astype(np.complex128), (2, 1, 0))
+    Yo[:, :, K:] = np.conj(Yo[:, :, M // 2 - 1:0:-1])
+    Gref = orc.wpe_estimate(Yo, lower, upper, iters, -18.0, 0.0, 1e-4)
+    ref = orc.wpe_apply(Yo, Gref, lower, upper)
+    Xd = torch.from_numpy(Xe).to(dev)
+    G = eng.wpe_estimate(Xd, M, lower_num=lower, upper_num=upper, iterations_num=iters, load_db=-18.0, diagonal_bias=1e-4)
+    assert G.shape == (1, C, K, C * (upper - lower + 1))
+    out = eng.wpe_apply(Xd, G, M, lower_num=lower, upper_num=upper).cpu().numpy()[0]
+    Gg = G.cpu().numpy()[0]
+    gscale = np.max(np.abs(Gref[:, :K]))
+    # lag 0 is the current frame: its own tap dominates (the filter nearly predicts the frame from itself)
+    assert gscale > 0.1
+    assert np.max(np.abs(Gg - Gref[:, :K])) <= 5e-3 * gscale             # 264-dim normal equations in float32 vs float64
+    got = np.transpose(out, (2, 1, 0))
+    assert np.max(np.abs(got - ref[:, :, :K])) <= 5e-3 * np.max(np.abs(Yo))

@@ -237,3 +237,32 @@ def test_frame_count_formula_equals_literal_loop(orc, M, m, r, dct):
     D = M >> r
     for L in list(range(0, 3 * D + 2)) + [7 * D - 1, 7 * D, 7 * D + 1, 20 * D + 3]:
         assert orc.analysis(h, M, m, r, dct, np.ones(L, np.float32)).shape[0] == orc.analysis_num_frames(L, M, m, r, dct), L
+
+
+def test_designed_prototypes_fixture(orc):
+    """distant_speech_recognition_amd/prototypes: the M = 256 pair IS the reference's shipped pair; the designed pairs for
+    M = 512, 1024, 2048 (reference designer, tests/golden/gen_prototypes.py) share its structure -- Nyquist(M) zeros at the
+    multiples of M except the centre tap, linear phase -- and the oracle's analysis -> synthesis round trip with them has the
+    same ~55 dB reconstruction SNR and zero net delay (delay_compensation_type 2)."""
+    import os
+    import numpy as np
+    from distant_speech_recognition_amd import prototypes
+    G = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "prototype_M256_m4_r1.npz"))
+    h, g = prototypes.load(256)
+    assert np.array_equal(h, G["h"]) and np.array_equal(g, G["g"])
+    for M in (512, 1024, 2048):
+        h, g = prototypes.load(M)
+        assert h.shape == (4 * M,) and g.shape == (4 * M,)
+        zeros = [i for i in range(0, 4 * M, M) if i != 2 * M]
+        assert np.max(np.abs(h[zeros])) == 0.0 and abs(h[2 * M]) > 1e-3          # Nyquist(M): h[kM] = 0 except the centre
+        assert np.max(np.abs(h[1:] - h[1:][::-1])) < 1e-9 * np.max(np.abs(h))    # symmetric about the centre tap
+    M = 512
+    h, g = prototypes.load(M)
+    rng = np.random.default_rng(1)
+    L = 40 * M
+    x = np.rint(np.convolve(rng.normal(0, 3000, L + 8), np.ones(8) / 8, mode="valid")[:L]).astype(np.float32)
+    X = orc.analysis(h, M, 4, 1, 2, x)
+    y = orc.synthesis(g, M, 4, 1, 2, X)
+    a, b = 8 * M, min(len(y), L) - 8 * M
+    snr = 10 * np.log10(np.sum(x[a:b] ** 2) / np.sum((y[a:b] - x[a:b]) ** 2))
+    assert snr > 50.0, snr

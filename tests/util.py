@@ -5,9 +5,14 @@ SSPEED = 343740.0   # mm/s, reference beamformer/beamformer.h:26
 
 
 def design_prototype(M, m, kind="h"):
-    """Deterministic smooth low-pass prototype of m*M taps (windowed sinc, cutoff pi/M).
-    Parity tests only need *some* real prototype shared by oracle and GPU; the reference's own
-    designed prototypes (M=256) are used where reconstruction quality matters."""
+    """The filter-bank prototype the tests run on: the reference designer's Nyquist(M) pair where one exists
+    (distant_speech_recognition_amd/prototypes: M = 256, 512, 1024, 2048 at m = 4, designed for r = 1 -- the BASELINE
+    configs C0..C5); for every other geometry of the sweeps (m != 4, small M) a deterministic Kaiser-windowed sinc of
+    m*M taps -- parity tests only need *some* real prototype shared by oracle and GPU."""
+    from distant_speech_recognition_amd import prototypes
+    if (M, m, 1) in prototypes.available():
+        h, g = prototypes.load(M, m, 1)
+        return h if kind == "h" else g
     L = m * M
     n = np.arange(L) - (L - 1) / 2.0
     w = np.kaiser(L, 8.0)
