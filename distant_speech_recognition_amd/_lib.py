@@ -45,6 +45,7 @@ SIGNATURES = {
     "btk_fb_analysis_num_frames": (_l, [_vp, _l]),
     "btk_fb_synthesis_num_blocks": (_l, [_vp, _l]),
     "btk_fb_analysis": (_i, [_vp, _vp, _l, _l, _i, _i, _vp, _l, _l, _l, _vp]),
+    "btk_fb_analysis_bins": (_i, [_vp, _vp, _l, _l, _i, _i, _vp, _l, _l, _l, _i, _i, _vp]),
     "btk_fb_analysis_polyphase": (_i, [_vp, _vp, _l, _l, _i, _i, _vp, _l, _l, _vp]),
     "btk_fb_synthesis": (_i, [_vp, _vp, _l, _l, _i, _vp, _l, _l, _l, _vp]),
     "btk_bf_apply": (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _l, _l, _vp]),
@@ -86,6 +87,8 @@ SIGNATURES = {
     "btk_wpe_workspace_bytes": (_l, [_i, _i, _i, _i, _i, _l]),
     "btk_wpe_estimate": (_i, [_vp, _i, _i, _i, _l, _l, _i, _i, _i, _d, _d, _i, _i, _vp, _vp, _vp, _vp]),
     "btk_wpe_apply": (_i, [_vp, _vp, _vp, _i, _i, _i, _l, _l, _i, _i, _i, _i, _vp]),
+    "btk_bin_range": (None, [_i, _i, _i, C.POINTER(_i), C.POINTER(_i)]),
+    "btk_allgather_bins": (_i, [_vp, _vp, _vp, _i, _i, _l, _i, _i, _vp]),
     "btk_weights_mainlobe": (_i, [_i, _i, _f, _vp, _vp]),
     "btk_weights_mainlobe_2": (_i, [_i, _i, _f, _vp, _vp, _vp]),
     "btk_weights_mainlobe_n": (_i, [_i, _i, _f, _vp, _vp, _i, _vp]),

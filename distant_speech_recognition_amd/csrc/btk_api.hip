@@ -59,6 +59,7 @@ int btk_fb_create(btk_fb_t** out, int M, int m, int r, int dct, int synthesis, c
   btk_fb* fb = new btk_fb();
   fb->M = M; fb->m = m; fb->r = r; fb->R = 1 << r; fb->D = M / fb->R; fb->K = M / 2 + 1;
   fb->dct = dct; fb->synthesis = synthesis ? 1 : 0; fb->gain_factor = 1;
+  fb->kx0 = 0; fb->kx1 = fb->K;
   fb->laN = 0;
   switch (dct) {                                    // modulated.cc:246-264
     case 1: fb->pd = m * fb->R - 1; break;

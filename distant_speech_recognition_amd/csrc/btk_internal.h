@@ -13,6 +13,7 @@ struct btk_fb {
   int gain_factor;   // gain_factor_ (int, default 1)
   float* d_proto;    // [m*M] float32 prototype on device
   float2* d_tw;      // [M] e^{+j 2 pi j / M}
+  int kx0, kx1;      // bin range the analysis kernels store (a bin shard writes only its bins; 0, K for a whole plan)
 };
 
 int btk_set_error(int code, const char* fmt, ...);

@@ -36,8 +36,9 @@ __global__ __launch_bounds__(A_NT, 3)
 void analysis512_kernel(const float* __restrict__ pcm, long nsamples, long pcm_stride,
                         const float* __restrict__ proto, const float2* __restrict__ twg,
                         int laN, float gain, int N, int K, float2* __restrict__ X,
-                        long T_stride, long t0, long tcount, int ntiles, int nruns, int nchan, int ablate)
+                        long T_stride, long t0, long tcount, int ntiles, int nruns, int nchan, int ablate, int k0, int k1)
 {
+  // X [S][K][N][T_stride] holds the bins [k0, k1) of the plan (K = k1 - k0; the whole range for an unsharded plan)
   constexpr int D = A_M / R;
   constexpr int SPAN = (A_TT - 1) * D + A_MT * A_M;
   constexpr int FB_BYTES = A_TT * FRS * 8;
@@ -188,11 +189,11 @@ void analysis512_kernel(const float* __restrict__ pcm, long nsamples, long pcm_s
         const float2 w = tw[k];
         const float2 xv = make_float2(e.x + (w.x * o.x - w.y * o.y), e.y + (w.x * o.y + w.y * o.x));
         if (ablate == 1) { if (xv.x == 1.2345e33f) xo[0] = xv; }
-        else if (live) xo[(long)(16 * it) * kstride] = xv;
+        else if (live && k >= k0 && k < k1) xo[(long)(16 * it - k0) * kstride] = xv;
       }
-      if (tid < 16 && live && ablate != 1) {                           // k = 256: W^256 = -1, partner Z[0]
+      if (tid < 16 && live && ablate != 1 && A_NF >= k0 && A_NF < k1) {   // k = 256: W^256 = -1, partner Z[0]
         const float2 z0 = zf[0];
-        X[((long)s * K * N + nch) * T_stride + tt0 + f + (long)A_NF * kstride] = make_float2(gain * (z0.x - z0.y), 0.f);
+        X[((long)s * K * N + nch) * T_stride + tt0 + f + (long)(A_NF - k0) * kstride] = make_float2(gain * (z0.x - z0.y), 0.f);
       }
     }
     __syncthreads();                                         // frames consumed before the next span overwrites them
@@ -218,7 +219,7 @@ int launch512(const btk_fb* fb, const float* pcm, long nsamples, long pcm_stride
   const float gain = fb->gain_factor > 0 ? (float)fb->gain_factor : 1.0f;
   static const int ablate = getenv("BTK_ANALYSIS512_ABLATE") ? atoi(getenv("BTK_ANALYSIS512_ABLATE")) : 0;   // diagnostics only
   hipLaunchKernelGGL(kern, dim3((unsigned)nblocks), dim3(A_NT), lds, st, pcm, nsamples, pcm_stride, fb->d_proto, fb->d_tw,
-                     fb->laN, gain, N, fb->K, X, T_stride, t0, tcount, ntiles, nruns, nchan, ablate);
+                     fb->laN, gain, N, fb->kx1 - fb->kx0, X, T_stride, t0, tcount, ntiles, nruns, nchan, ablate, fb->kx0, fb->kx1);
   BTK_HIP_CHECK(hipGetLastError());
   return BTK_OK;
 }

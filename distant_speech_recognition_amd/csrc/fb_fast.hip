@@ -237,8 +237,9 @@ __global__ __launch_bounds__(F_NT, 2)
 void fast_analysis_kernel(const float* __restrict__ pcm, long nsamples, long pcm_stride,
                           const float* __restrict__ proto, const float2* __restrict__ twg,
                           int laN, float gain, int N, int K, float2* __restrict__ X,
-                          long T_stride, long t0, long tcount, int ntiles, int nruns, int nchan)
+                          long T_stride, long t0, long tcount, int ntiles, int nruns, int nchan, int k0, int k1)
 {
+  // X [S][K][N][T_stride] holds the bins [k0, k1) of the plan (K = k1 - k0; the whole range for an unsharded plan)
   using G = FG<LOG2M>;
   constexpr int M = G::M, NF = G::NF, TT = G::TT, FRS = G::FRS, P2 = G::P2;
   constexpr int D = M / R;
@@ -334,11 +335,12 @@ void fast_analysis_kernel(const float* __restrict__ pcm, long nsamples, long pcm
         const float2 e = make_float2(hg * (zk.x + zq.x), hg * (zk.y - zq.y));
         const float2 o = make_float2(hg * (zk.y + zq.y), -hg * (zk.x - zq.x));
         const float2 w = twg[k];                                  // e^{+j 2 pi k / M}, L1-resident
-        if (live) xo[(long)k * kstride] = make_float2(e.x + (w.x * o.x - w.y * o.y), e.y + (w.x * o.y + w.y * o.x));
+        if (live && k >= k0 && k < k1)
+          xo[(long)(k - k0) * kstride] = make_float2(e.x + (w.x * o.x - w.y * o.y), e.y + (w.x * o.y + w.y * o.x));
       }
-      if (kq == 0 && live) {
+      if (kq == 0 && live && NF >= k0 && NF < k1) {
         const float2 z0 = zf[0];
-        xo[(long)NF * kstride] = make_float2(gain * (z0.x - z0.y), 0.f);
+        xo[(long)(NF - k0) * kstride] = make_float2(gain * (z0.x - z0.y), 0.f);
       }
     }
     __syncthreads();
@@ -365,7 +367,7 @@ int launch_fast_analysis(const btk_fb* fb, const float* pcm, long nsamples, long
   BTK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const float gain = fb->gain_factor > 0 ? (float)fb->gain_factor : 1.0f;
   hipLaunchKernelGGL(kern, dim3((unsigned)nblocks), dim3(F_NT), lds, st, pcm, nsamples, pcm_stride, fb->d_proto, fb->d_tw,
-                     fb->laN, gain, N, fb->K, X, T_stride, t0, tcount, ntiles, nruns, nchan);
+                     fb->laN, gain, N, fb->kx1 - fb->kx0, X, T_stride, t0, tcount, ntiles, nruns, nchan, fb->kx0, fb->kx1);
   BTK_HIP_CHECK(hipGetLastError());
   return 1;
 }

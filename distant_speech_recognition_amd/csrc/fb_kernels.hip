@@ -43,8 +43,9 @@ void analysis_kernel(const float* __restrict__ pcm, long nsamples, long pcm_stri
                      const float* __restrict__ proto, const float2* __restrict__ twg,
                      int m_rt, int D, int laN, float gain,
                      int N, int K, float2* __restrict__ X, float* __restrict__ P,
-                     long T_stride, long t0, long tcount, int ntiles, int nchan)
+                     long T_stride, long t0, long tcount, int ntiles, int nchan, int k0, int k1)
 {
+  // X [S][K][N][T_stride] holds the bins [k0, k1) of the plan (K = k1 - k0; the whole range for an unsharded plan)
   using C = FbCfg<LOG2M>;
   constexpr int M = C::M, NF = C::NF, TT = C::TT, STRIDE = C::STRIDE;
   const int m = MT > 0 ? MT : m_rt;
@@ -154,7 +155,7 @@ void analysis_kernel(const float* __restrict__ pcm, long nsamples, long pcm_stri
   float2* xo = X + ((long)s * K * N + nch) * T_stride + tt0;
   for (int idx = tid; idx < TT * (NF + 1); idx += NT) {
     const int f = idx % TT, k = idx / TT;
-    if (tt0 + f < tcount) xo[(long)k * N * T_stride + f] = zbuf[f * STRIDE + k];
+    if (tt0 + f < tcount && k >= k0 && k < k1) xo[(long)(k - k0) * N * T_stride + f] = zbuf[f * STRIDE + k];
   }
 }
 
@@ -268,8 +269,8 @@ int launch_analysis(const btk_fb* fb, const float* pcm, long nsamples, long pcm_
       BTK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                            \
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));         \
     hipLaunchKernelGGL(kern, dim3((unsigned)nblocks), dim3(NT), lds, st, pcm, nsamples, pcm_stride,     \
-                       fb->d_proto, fb->d_tw, fb->m, fb->D, fb->laN, gain, N, fb->K, X, P, T_stride,    \
-                       t0, tcount, ntiles, nchan);                                                      \
+                       fb->d_proto, fb->d_tw, fb->m, fb->D, fb->laN, gain, N, fb->kx1 - fb->kx0, X, P,  \
+                       T_stride, t0, tcount, ntiles, nchan, fb->kx0, fb->kx1);                          \
   } while (0)
   if (P) {
     if (fb->m == 4) BTK_LAUNCH_ANA(4, true); else BTK_LAUNCH_ANA(0, true);
@@ -353,6 +354,17 @@ int btk_fb_analysis(const btk_fb_t* fb, const float* pcm, long nsamples, long pc
     case 2048: return launch_analysis<11>(fb, pcm, nsamples, pcm_stride, S, N, Xp, nullptr, T_stride, t0, tcount, st);
   }
   return btk_set_error(BTK_ERR_PARAMETER, "unsupported M=%d", fb->M);
+}
+
+int btk_fb_analysis_bins(const btk_fb_t* fb, const float* pcm, long nsamples, long pcm_stride, int S, int N, void* X,
+                         long T_stride, long t0, long tcount, int k0, int k1, void* stream)
+{
+  if (!fb || fb->synthesis) return btk_set_error(BTK_ERR_PARAMETER, "btk_fb_analysis_bins: not an analysis plan");
+  if (k0 < 0 || k1 > fb->K || k0 > k1) return btk_set_error(BTK_ERR_DIMENSION, "btk_fb_analysis_bins: bin range [%d, %d) outside [0, %d]", k0, k1, fb->K);
+  if (k0 == k1) return BTK_OK;                           // the empty shard of a trailing rank
+  btk_fb shard = *fb;                                    // the plan itself is shared and stays whole
+  shard.kx0 = k0; shard.kx1 = k1;
+  return btk_fb_analysis(&shard, pcm, nsamples, pcm_stride, S, N, X, T_stride, t0, tcount, stream);
 }
 
 int btk_fb_analysis_polyphase(const btk_fb_t* fb, const float* pcm, long nsamples, long pcm_stride,

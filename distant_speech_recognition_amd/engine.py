@@ -104,19 +104,27 @@ class FilterBank:
     def num_frames(self, nsamples):
         return _lib.lib().btk_fb_analysis_num_frames(self._h, nsamples)
 
-    def analysis(self, pcm, nsamples=None, t0=0, tcount=None, out=None):
-        """pcm float32 [S][N][L] (cuda) -> X complex64 [S][K][N][T]."""
+    def analysis(self, pcm, nsamples=None, t0=0, tcount=None, out=None, bins=None):
+        """pcm float32 [S][N][L] (cuda) -> X complex64 [S][K][N][T]; bins = (k0, k1): only that bin range is computed
+        into X [S][k1-k0][N][T] (the bin shard of one rank, sharding.py)."""
         _check(pcm, "pcm", torch.float32, 3)
         S, N, L = pcm.shape
         nsamples = L if nsamples is None else nsamples
         if tcount is None:
             tcount = self.num_frames(nsamples) - t0
+        k0, k1 = (0, self.K) if bins is None else (int(bins[0]), int(bins[1]))
+        if not (0 <= k0 <= k1 <= self.K):
+            raise _lib.BtkError(_lib.BTK_ERR_DIMENSION, "bin range [%d, %d) outside [0, %d]" % (k0, k1, self.K))
         if out is None:
-            out = torch.empty((S, self.K, N, tcount), dtype=torch.complex64, device=pcm.device)
-        _check(out, "X", torch.complex64, (S, self.K, N, None))
+            out = torch.empty((S, k1 - k0, N, tcount), dtype=torch.complex64, device=pcm.device)
+        _check(out, "X", torch.complex64, (S, k1 - k0, N, None))
         if out.shape[3] < tcount:
             raise _lib.BtkError(_lib.BTK_ERR_DIMENSION, "X holds %d frames, %d requested" % (out.shape[3], tcount))
-        check(_lib.lib().btk_fb_analysis(self._h, _ptr(pcm), nsamples, L, S, N, _ptr(out), out.shape[3], t0, tcount, _stream()))
+        if bins is None:
+            check(_lib.lib().btk_fb_analysis(self._h, _ptr(pcm), nsamples, L, S, N, _ptr(out), out.shape[3], t0, tcount, _stream()))
+        else:
+            check(_lib.lib().btk_fb_analysis_bins(self._h, _ptr(pcm), nsamples, L, S, N, _ptr(out), out.shape[3], t0, tcount,
+                                                  k0, k1, _stream()))
         return out
 
     def analysis_polyphase(self, pcm, nsamples=None, t0=0, tcount=None):
@@ -190,6 +198,8 @@ def bf_apply(W, X, out=None):
     if out is None:
         out = torch.empty((S, K, T), dtype=torch.complex64, device=X.device)
     _check(out, "Y", torch.complex64, (S, K, T))
+    if K == 0 or T == 0:                       # the empty bin shard of a trailing rank: nothing to launch
+        return out
     check(_lib.lib().btk_bf_apply(_ptr(W), int(W.shape[0] == S and S > 1), _ptr(X), _ptr(out), S, K, N, T, T, _stream()))
     return out
 

@@ -64,14 +64,15 @@ def bf_apply_bin_sharded(W_local, X_local, K, group=None):
 
 def pipeline_bin_sharded(afb, sfb, pcm, W_local, K, rank, world, group=None, synth_rank=None):
     """BASELINE config C5 end to end on `world` GPUs: every rank analyses the SAME multichannel PCM (the analysis FFT
-    yields all bins of a channel, so the PCM -- N*D*4 bytes per frame -- is what is replicated), keeps its bin range of
-    the snapshots, beamforms it, ONE all-gather assembles Y [S][K][T], and the synthesis bank runs on `synth_rank`
+    yields all bins of a channel, so the PCM -- N*D*4 bytes per frame -- is what is replicated), stores only its bin range
+    of the snapshots (btk_fb_analysis_bins), beamforms it, ONE all-gather assembles Y [S][K][T], and the synthesis bank runs on `synth_rank`
     (every rank if None).  afb / sfb: engine.FilterBank analysis / synthesis plans; W_local complex64 [K_g][N].
     Returns (pcm_out or None, Y)."""
     k0, k1 = bin_range_for_rank(K, rank, world)
-    X = afb.analysis(pcm)                                   # [S][K][N][T]
-    X_local = X[:, k0:k1].contiguous()
-    del X
+    # every channel is transformed on every rank (the FFT yields all bins), but only this rank's bins are stored: the
+    # snapshot write -- 8 K N bytes per frame, the dominant cost of the analysis bank -- shrinks by `world`, and no
+    # full-size X nor a slice copy exists (an empty trailing shard launches nothing)
+    X_local = afb.analysis(pcm, bins=(k0, k1))              # [S][K_g][N][T]
     from . import engine
     Y = bf_apply_bin_sharded(W_local, X_local, K, group) if world > 1 else engine.bf_apply(W_local, X_local)
     out = sfb.synthesize(Y) if (synth_rank is None or synth_rank == rank) else None

@@ -69,6 +69,11 @@ long btk_fb_synthesis_num_blocks(const btk_fb_t* fb, long nframes);
  * X [dev] [S][K][N][T_stride]; frame t is stored at column t - t0.                         */
 int  btk_fb_analysis(const btk_fb_t* fb, const float* pcm, long nsamples, long pcm_stride,
                      int S, int N, void* X, long T_stride, long t0, long tcount, void* stream);
+/* A bin SHARD of the same transform (frequency-bin sharding): only bins [k0, k1) are written,
+ * X [dev] complex64 [S][k1-k0][N][T_stride].  The FFT of a channel yields all bins, so a rank of a bin-sharded run
+ * transforms every channel but stores -- the dominant cost of the analysis bank -- only 1/world of the snapshots. */
+int  btk_fb_analysis_bins(const btk_fb_t* fb, const float* pcm, long nsamples, long pcm_stride, int S, int N, void* X,
+                          long T_stride, long t0, long tcount, int k0, int k1, void* stream);
 /* Debug/parity entry: the M real polyphase sums of modulated.cc:384-391 (before the FFT),
  * P [dev] float32 [S*N][tcount][M].  Used to pin the integer polyphase indexing bit-exactly. */
 int  btk_fb_analysis_polyphase(const btk_fb_t* fb, const float* pcm, long nsamples, long pcm_stride,
@@ -288,6 +293,18 @@ int  btk_wpe_estimate(const void* X, int S, int K, int C, long T_stride, long T,
                       void* G, void* workspace, int* fail_count, void* stream);
 int  btk_wpe_apply(const void* X, const void* G, void* OUT, int S, int K, int C, long T_stride, long T,
                    int lowerN, int upperN, int lower_bw, int upper_bw, void* stream);
+
+/* ---- Multi-GPU: frequency-bin sharding ---------------------------------------------
+ * One process per GPU.  Rank g owns the bins btk_bin_range(K, g, world) = [g ceil(K/world), ...) -- trailing ranks may
+ * be short or empty -- for analysis storage (btk_fb_analysis_bins), weight design (btk_mvdr_weights_shard), covariance,
+ * beamforming, post-filter; btk_allgather_bins is the ONE collective of the path: every rank contributes its
+ * beamformed block Y_local [dev] complex64 [S][k1-k0][T_stride] and receives Y [dev] complex64 [S][K][T_stride] for the
+ * synthesis bank.  nccl_comm: an initialised ncclComm_t of `world` ranks (RCCL over xGMI); the collective is enqueued on
+ * `stream`.  RCCL is bound at run time, the library does not link it.  Stream sharding needs no entry point: streams are
+ * independent (rank = stream mod world, no collective).                                                                 */
+void btk_bin_range(int K, int rank, int world, int* k0, int* k1);
+int  btk_allgather_bins(void* nccl_comm, const void* Y_local, void* Y, int S, int K, long T_stride, int rank, int world,
+                        void* stream);
 
 /* ---- Host-side weight design (double precision, one-off per look direction) -------------
  * BeamformerWeights::calcMainlobe (beamformer.cc:502-565): wq [host] complex128 [M][N].     */

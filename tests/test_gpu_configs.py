@@ -30,7 +30,9 @@ def test_c3_mvdr_64mic_1024bins(orc, dev):
     R = eng.cov_accumulate(X)                                    # all frames are "noise" here
     cnt = torch.full((S,), float(T), dtype=torch.float32, device=dev)
     eng.cov_finalize(R, cnt)
-    eng.mvdr_diagonal_loading(R, 1e-4 * 1e6)                     # loading relative to the int16-scale power
+    # diagonal loading 1 % of the mean subband power (T = 44 frames < N = 64 channels: R is rank deficient without it)
+    load = 1e-2 * float(torch.diagonal(R[0], dim1=-2, dim2=-1).real.mean())
+    eng.mvdr_diagonal_loading(R, load)
     wq = orc.calc_mainlobe(M, N, 16000, delays)
     W, nfb = eng.mvdr_weights(R[0], torch.from_numpy(wq[:K].astype(np.complex64)).to(dev))
     assert nfb == 0
@@ -40,7 +42,7 @@ def test_c3_mvdr_64mic_1024bins(orc, dev):
     Rh = R.cpu().numpy()[0].astype(np.complex128)
     for k in (1, 17, 300, 512):
         xk = Xh[k].astype(np.complex128)                         # [N][T]
-        Rref = (xk @ xk.conj().T) / T + 100.0 * np.eye(N)
+        Rref = (xk @ xk.conj().T) / T + load * np.eye(N)
         assert np.linalg.norm(Rh[k] - Rref) <= 2e-5 * np.linalg.norm(Rref)
         inv, ok = orc.pseudoinverse(Rref)                       # the reference's float32 csvdc (oracle/_ref), beamformer.cc:232-289
         assert ok

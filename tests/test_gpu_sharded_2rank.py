@@ -89,3 +89,74 @@ def test_bench_two_ranks_contract(dev):
     assert d["unit"] == "frames/s" and d["cpu_baseline"] is None and "roofline" in d and d["config"]["parallelism"].endswith("x2")
     # whole-job aggregate: 2 ranks x 4 streams x 1024 frames per step
     assert abs(d["value"] - 2 * 4 * 1024 / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
+
+
+@pytest.mark.parametrize("M,r,N", [(512, 1, 5), (256, 1, 3), (2048, 1, 2), (64, 0, 4), (128, 2, 3)])
+def test_bin_range_analysis_equals_slice(dev, M, r, N):
+    """btk_fb_analysis_bins (what a rank of a bin-sharded run launches): bit-identical to the bin slice of the whole
+    transform in all three analysis kernels (M = 512 specialised, register-FFT, generic), incl. ranges that contain bin 0,
+    the Nyquist bin, a single bin, and the empty range of a trailing rank."""
+    import torch
+    from distant_speech_recognition_amd import engine as eng, sharding
+    from tests.util import design_prototype
+    m = 4 if M >= 256 else 2
+    K, D = M // 2 + 1, M >> r
+    fb = eng.FilterBank(design_prototype(M, m), M, m, r, 2)
+    g = torch.Generator(device=dev).manual_seed(M + N)
+    pcm = (torch.randn((2, N, 37 * D + 11), device=dev, generator=g) * 1000).round_()
+    X = fb.analysis(pcm)
+    for k0, k1 in ((0, K), (0, 1), (K - 1, K), (K // 3, K // 3 + 7), (K // 2, K), (5, 5)):
+        Xs = fb.analysis(pcm, bins=(k0, k1))
+        assert Xs.shape == (2, k1 - k0, N, X.shape[3])
+        assert torch.equal(Xs, X[:, k0:k1])
+    # the shards of an 8-rank run tile the transform; K = 33 leaves rank 7 empty (ceil(33 / 8) = 5 bins per rank)
+    if M == 64:
+        parts = [fb.analysis(pcm, bins=sharding.bin_range_for_rank(K, rk, 8)) for rk in range(8)]
+        assert parts[7].shape[1] == 0
+        assert torch.equal(torch.cat(parts, dim=1), X)
+        W = torch.randn((K, N), dtype=torch.complex64, device=dev)
+        Ys = [eng.bf_apply(W[a:b].contiguous(), p_) for p_, (a, b) in zip(parts, [sharding.bin_range_for_rank(K, rk, 8) for rk in range(8)])]
+        assert Ys[7].shape == (2, 0, X.shape[3])
+        assert torch.equal(torch.cat(Ys, dim=1), eng.bf_apply(W, X))
+
+
+def test_c_abi_allgather_bins_rccl_world1(dev, tmp_path):
+    """btk_allgather_bins through the C-ABI with a real RCCL communicator (one rank: RCCL refuses two ranks on this box's
+    single GPU; the per-(owner, stream) broadcast group is the same code for any world).  Runs in a process WITHOUT torch so
+    that the library binds /opt/rocm's librccl -- the one the communicator was created with."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r'''
+import ctypes as C, numpy as np, sys
+hip = C.CDLL("/opt/rocm/lib/libamdhip64.so")
+rccl = C.CDLL("/opt/rocm/lib/librccl.so", mode=C.RTLD_GLOBAL)
+lib = C.CDLL(%r)
+class UID(C.Structure): _fields_ = [("b", C.c_char * 128)]
+uid = UID(); assert rccl.ncclGetUniqueId(C.byref(uid)) == 0
+comm = C.c_void_p()
+rccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UID, C.c_int]
+assert rccl.ncclCommInitRank(C.byref(comm), 1, uid, 0) == 0
+S, K, T = 3, 33, 40
+rng = np.random.default_rng(0)
+Yl = (rng.normal(size=(S, K, T)) + 1j * rng.normal(size=(S, K, T))).astype(np.complex64)
+dl, dy = C.c_void_p(), C.c_void_p()
+hip.hipMalloc(C.byref(dl), Yl.nbytes); hip.hipMalloc(C.byref(dy), Yl.nbytes)
+hip.hipMemcpy(dl, Yl.ctypes.data_as(C.c_void_p), C.c_size_t(Yl.nbytes), 1)
+hip.hipMemset(dy, 0, C.c_size_t(Yl.nbytes))
+lib.btk_allgather_bins.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_long, C.c_int, C.c_int, C.c_void_p]
+rc = lib.btk_allgather_bins(comm, dl, dy, S, K, T, 0, 1, None)
+lib.btk_last_error.restype = C.c_char_p
+assert rc == 0, lib.btk_last_error()
+hip.hipDeviceSynchronize()
+out = np.zeros_like(Yl)
+hip.hipMemcpy(out.ctypes.data_as(C.c_void_p), dy, C.c_size_t(Yl.nbytes), 2)
+assert np.array_equal(out, Yl)
+k0, k1 = C.c_int(), C.c_int()
+lib.btk_bin_range(33, 7, 8, C.byref(k0), C.byref(k1)); assert (k0.value, k1.value) == (33, 33)
+lib.btk_bin_range(33, 6, 8, C.byref(k0), C.byref(k1)); assert (k0.value, k1.value) == (30, 33)
+rccl.ncclCommDestroy(comm)
+print("ok")
+''' % os.path.join(root, "distant_speech_recognition_amd", "csrc", "libbtkhip.so")
+    res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0 and "ok" in res.stdout, res.stdout + res.stderr

@@ -41,6 +41,16 @@ def _worker(rank, world, port, K, ret):
         dist.destroy_process_group()
 
 
+def test_bin_allgather_with_empty_trailing_ranks_world4():
+    """K = 5 bins over 4 ranks: ceil(5 / 4) = 2 per rank -> ranks hold 2, 2, 1, 0 bins; the all-gather pads and trims"""
+    import torch.multiprocessing as mp
+    world, port = 4, _free_port()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(world, port, 5, ret), nprocs=world, join=True)
+    assert dict(ret) == {0: 1, 1: 1, 2: 1, 3: 1}
+
+
 @pytest.mark.parametrize("K", [257, 10, 3])
 def test_bin_allgather_and_stream_partition_world2(K):
     import torch.multiprocessing as mp
