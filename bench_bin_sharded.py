@@ -59,6 +59,31 @@ def main():
     torch.cuda.synchronize()
     t_design = time.perf_counter() - t0
 
+    # what the shard saves on ONE GPU (options (i) vs full): the analysis bank storing K/8 of the bins vs all
+    shard_probe = None
+    if world == 1:
+        def _t(fn, n=3):
+            fn(); torch.cuda.synchronize()
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            for _ in range(n): fn()
+            b.record(); torch.cuda.synchronize()
+            return a.elapsed_time(b) / n
+        a8, b8 = sharding.bin_range_for_rank(K, 3, 8)
+        Xf = torch.empty((S, K, N, T), dtype=torch.complex64, device=dev)
+        Xs = torch.empty((S, b8 - a8, N, T), dtype=torch.complex64, device=dev)
+        t_full = _t(lambda: afb.analysis(pcm, out=Xf))
+        t_shard = _t(lambda: afb.analysis(pcm, out=Xs, bins=(a8, b8)))
+        t_slice = _t(lambda: Xf[:, a8:b8].contiguous())
+        Wf = torch.randn((K, N), dtype=torch.complex64, device=dev)
+        t_bf_full = _t(lambda: eng.bf_apply(Wf, Xf))
+        t_bf_shard = _t(lambda: eng.bf_apply(Wf[a8:b8].contiguous(), Xs))
+        shard_probe = {"analysis_all_bins_ms": t_full, "analysis_one_of_8_bin_shards_ms": t_shard,
+                       "slice_copy_the_round1_path_needed_ms": t_slice, "bf_apply_all_bins_ms": t_bf_full,
+                       "bf_apply_one_shard_ms": t_bf_shard,
+                       "note": "rank-side cost of option (i) (replicated PCM + FFT, only the rank's bins stored) on one GPU"}
+        del Xf, Xs
+
     def step():
         return sharding.pipeline_bin_sharded(afb, sfb, pcm, W_local, K, rank, world, synth_rank=0)
     for _ in range(args.warmup):
@@ -85,7 +110,8 @@ def main():
                           "scaling": "strong", "dtype": "f32", "data": "synthetic",
                           "config": {"workload": "C5: %d mics, %d bins, %d frames, bins [%d,%d) on rank 0 of %d" % (N, M, T, k0, k1, world),
                                      "parallelism": "bin-sharded x%d, 1 all-gather of %d bytes per step" % (world, 8 * K * T * S)},
-                          "weight_design_ms": td * 1e3, "pcm_checksum": float(out.double().abs().sum())}))
+                          "weight_design_ms": td * 1e3, "pcm_checksum": float(out.double().abs().sum()),
+                          "shard_probe": shard_probe}))
     if dist:
         dist.destroy_process_group()
 

@@ -21,6 +21,7 @@
 // blocking matrix never has to be read, and the kernel stays HBM-bound (8 K N bytes per frame).
 // wa is recovered on demand as wa^H = u conj(B) (host side, btk_nlms_u_to_wa).
 #include "btk_internal.h"
+#include "fft_packed.h"
 #include <cstdlib>
 
 namespace {
@@ -252,6 +253,18 @@ void nlms_bin_kernel(const float2* __restrict__ X, const float2* __restrict__ VS
   }
 }
 
+// packed-f32 complex accumulation forms of the recursion (next to acc_conjw_z / acc_conjw_conjz of fft_packed.h)
+__device__ __forceinline__ void acc_w_z(f2& A, f2 w, f2 z)              // A += w z
+{
+  asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "+v"(A) : "v"(w), "v"(z));                       // (w.x z.x, w.x z.y)
+  asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]" : "+v"(A) : "v"(w), "v"(z));        // (-w.y z.y, w.y z.x)
+}
+__device__ __forceinline__ void acc_w_conjz(f2& A, f2 w, f2 z)          // A += w conj(z)
+{
+  asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_hi:[0,1,0]" : "+v"(A) : "v"(w), "v"(z));        // (w.x z.x, -w.x z.y)
+  asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1]" : "+v"(A) : "v"(w), "v"(z));                       // (w.y z.y, w.y z.x)
+}
+
 // ---- v2: row-DPP reductions, several bins per wavefront, float4 tile loads --------------------------------
 template <int CTRL> __device__ __forceinline__ float dpp_f(float v)
 {
@@ -301,27 +314,30 @@ void nlms_bin2_kernel(const float2* __restrict__ X, const float2* __restrict__ V
   const bool kvalid = k < K;
   const long isamp0 = (long)stream_state_before[4 * (long)s + 2];
 
-  float2 vs[CPL], u[CPL];
+  f2 vs[CPL], u[CPL];
   float vvp = 0.f;
 #pragma unroll
   for (int c = 0; c < CPL; c++) {
     const int n = gl + GROUP * c;
     const bool ok = kvalid && n < N;
-    vs[c] = ok ? VS[(long)k * N + n] : make_float2(0.f, 0.f);
-    u[c] = ok ? U[((long)s * K + k) * N + n] : make_float2(0.f, 0.f);
-    vvp += vs[c].x * vs[c].x + vs[c].y * vs[c].y;
+    const float2 a = ok ? VS[(long)k * N + n] : make_float2(0.f, 0.f);
+    const float2 b = ok ? U[((long)s * K + k) * N + n] : make_float2(0.f, 0.f);
+    vs[c] = f2{a.x, a.y};
+    u[c] = f2{b.x, b.y};
+    vvp += a.x * a.x + a.y * a.y;
   }
   const float vv = group_sum2<GROUP>(vvp);
   const float inv_vv = vv > 0.f ? 1.f / vv : 0.f;
   float sig = kvalid ? sigma2[(long)s * K + k] : 1.f;
-  float2 cx[NX][CPL];
+  f2 cx[NX][CPL];
   if constexpr (NC > 1) {
 #pragma unroll
     for (int jx = 0; jx < NX; jx++)
 #pragma unroll
       for (int c = 0; c < CPL; c++) {
         const int n = gl + GROUP * c;
-        cx[jx][c] = (kvalid && n < N) ? CX[((long)k * NX + jx) * N + n] : make_float2(0.f, 0.f);
+        const float2 a = (kvalid && n < N) ? CX[((long)k * NX + jx) * N + n] : make_float2(0.f, 0.f);
+        cx[jx][c] = f2{a.x, a.y};
       }
   }
 
@@ -365,44 +381,44 @@ void nlms_bin2_kernel(const float2* __restrict__ X, const float2* __restrict__ V
     float2 yout = make_float2(0.f, 0.f);
     float uu = 0.f;
     const int nsteps = (T - t0) < TBF ? (int)(T - t0) : TBF;
+    // every tile runs all TBF steps: beyond the end of the block the tile holds zeros and the step size read from ctrl is 0
+    // (no update, nothing stored), so the steps need no branch
 #pragma unroll
     for (int tt = 0; tt < TBF; tt++) {
-      if (tt < nsteps) {
-        float2 x[CPL];
-        float ycr = 0.f, yci = 0.f, pr = 0.f, pi = 0.f, xx = 0.f;
+      {
+        // complex arithmetic in packed float32 (v_pk_fma_f32 with op_sel / neg modifiers): 5 packed FMAs per channel for the
+        // five sums, 5 for the update -- half the instructions of the scalar form, and the recursion is issue-bound
+        f2 x[CPL];
+        f2 yc = {0.f, 0.f}, pp = {0.f, 0.f}, xx2 = {0.f, 0.f};
 #pragma unroll
         for (int c = 0; c < CPL; c++) {
-          x[c] = tile[(gi * NR + gl + GROUP * c) * LDWv + tt];
-          ycr = fmaf(vs[c].x, x[c].x, fmaf(vs[c].y, x[c].y, ycr));
-          yci = fmaf(vs[c].x, x[c].y, fmaf(-vs[c].y, x[c].x, yci));
-          pr = fmaf(u[c].x, x[c].x, fmaf(-u[c].y, x[c].y, pr));
-          pi = fmaf(u[c].x, x[c].y, fmaf(u[c].y, x[c].x, pi));
-          xx = fmaf(x[c].x, x[c].x, fmaf(x[c].y, x[c].y, xx));
+          const float2 xv = tile[(gi * NR + gl + GROUP * c) * LDWv + tt];
+          x[c] = f2{xv.x, xv.y};
+          acc_conjw_z(yc, vs[c], x[c]);                              // Yc = vs^H x
+          acc_w_z(pp, u[c], x[c]);                                   // p = u x
+          xx2 = __builtin_elementwise_fma(x[c], x[c], xx2);
         }
-        ycr = group_sum2<GROUP>(ycr); yci = group_sum2<GROUP>(yci);
-        pr = group_sum2<GROUP>(pr);   pi = group_sum2<GROUP>(pi);
-        xx = group_sum2<GROUP>(xx);
+        const float ycr = group_sum2<GROUP>(yc.x), yci = group_sum2<GROUP>(yc.y);
+        const float pr = group_sum2<GROUP>(pp.x), pi = group_sum2<GROUP>(pp.y);
+        const float xx = group_sum2<GROUP>(xx2.x + xx2.y);
         float dxr[NX], dxi[NX], dd = 0.f;                             // d_j = c_j^H x
         if constexpr (NC > 1) {
 #pragma unroll
           for (int jx = 0; jx < NX; jx++) {
-            float ar = 0.f, ai = 0.f;
+            f2 dj = {0.f, 0.f};
 #pragma unroll
-            for (int c = 0; c < CPL; c++) {
-              ar = fmaf(cx[jx][c].x, x[c].x, fmaf(cx[jx][c].y, x[c].y, ar));
-              ai = fmaf(cx[jx][c].x, x[c].y, fmaf(-cx[jx][c].y, x[c].x, ai));
-            }
-            dxr[jx] = group_sum2<GROUP>(ar); dxi[jx] = group_sum2<GROUP>(ai);
+            for (int c = 0; c < CPL; c++) acc_conjw_z(dj, cx[jx][c], x[c]);
+            dxr[jx] = group_sum2<GROUP>(dj.x); dxi[jx] = group_sum2<GROUP>(dj.y);
             dd = fmaf(dxr[jx], dxr[jx], fmaf(dxi[jx], dxi[jx], dd));
           }
         }
         // |u|^2: summed from u at the first step of a tile, carried as cK^2 nrm (the same expansion the clip uses) after
         // an update inside it -- rounding drift is bounded to TBF steps
         if (tt == 0) {
-          float uup = 0.f;
+          f2 uu2 = {0.f, 0.f};
 #pragma unroll
-          for (int c = 0; c < CPL; c++) uup = fmaf(u[c].x, u[c].x, fmaf(u[c].y, u[c].y, uup));
-          uu = group_sum2<GROUP>(uup);
+          for (int c = 0; c < CPL; c++) uu2 = __builtin_elementwise_fma(u[c], u[c], uu2);
+          uu = group_sum2<GROUP>(uu2.x + uu2.y);
         }
 
         const long isamp = isamp0 + t0 + tt;
@@ -418,21 +434,19 @@ void nlms_bin2_kernel(const float2* __restrict__ X, const float2* __restrict__ V
           const float gg = xx - (ycr * ycr + yci * yci) * inv_vv - dd;
           const float nrm = c1 * c1 * uu + (c2r * c2r + c2i * c2i) * gg + 2.f * c1 * (c2r * pr + c2i * pi);
           const float cK = nrm > p.max_wa_l2norm ? __builtin_amdgcn_sqrtf(p.max_wa_l2norm * __builtin_amdgcn_rcpf(nrm)) : 1.f;
-          const float sr = ycr * inv_vv, si = yci * inv_vv;
+          const f2 ns = {-ycr * inv_vv, -yci * inv_vv};                // q = x - vs Yc / |vs|^2
+          const f2 k1 = {cK * c1, cK * c1}, k2 = {cK * c2r, cK * c2i}; // u <- cK (c1 u + c2 conj(q))
 #pragma unroll
           for (int c = 0; c < CPL; c++) {
-            float qr = x[c].x - (vs[c].x * sr - vs[c].y * si);
-            float qi = x[c].y - (vs[c].x * si + vs[c].y * sr);
+            f2 q = x[c];
+            acc_w_z(q, ns, vs[c]);
             if constexpr (NC > 1) {
 #pragma unroll
-              for (int jx = 0; jx < NX; jx++) {
-                qr -= cx[jx][c].x * dxr[jx] - cx[jx][c].y * dxi[jx];
-                qi -= cx[jx][c].x * dxi[jx] + cx[jx][c].y * dxr[jx];
-              }
+              for (int jx = 0; jx < NX; jx++) acc_w_z(q, f2{-dxr[jx], -dxi[jx]}, cx[jx][c]);
             }
-            const float nr = c1 * u[c].x + (c2r * qr + c2i * qi);
-            const float ni = c1 * u[c].y + (c2i * qr - c2r * qi);
-            u[c] = make_float2(cK * nr, cK * ni);
+            f2 un = k1 * u[c];
+            acc_w_conjz(un, k2, q);
+            u[c] = un;
           }
           sig = se;
           uu = cK * cK * nrm;
@@ -444,7 +458,7 @@ void nlms_bin2_kernel(const float2* __restrict__ X, const float2* __restrict__ V
         if (GROUP >= TBF) {
           if (gl == tt) yout = make_float2(outr, outi);
         } else {
-          if (gl == 0 && kvalid) Y[((long)s * K + k) * T_stride + t0 + tt] = make_float2(outr, outi);
+          if (gl == 0 && kvalid && tt < nsteps) Y[((long)s * K + k) * T_stride + t0 + tt] = make_float2(outr, outi);
         }
       }
     }
@@ -455,7 +469,7 @@ void nlms_bin2_kernel(const float2* __restrict__ X, const float2* __restrict__ V
 #pragma unroll
     for (int c = 0; c < CPL; c++) {
       const int n = gl + GROUP * c;
-      if (n < N) U[((long)s * K + k) * N + n] = u[c];
+      if (n < N) U[((long)s * K + k) * N + n] = make_float2(u[c].x, u[c].y);
     }
     if (gl == 0) sigma2[(long)s * K + k] = sig;
   }
