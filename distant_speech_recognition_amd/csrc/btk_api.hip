@@ -1,6 +1,7 @@
 // btk_api.hip -- C-ABI plumbing of libbtkhip: error state, device selection, filter-bank plans and
 // the host-side (float64) weight design that runs once per look direction.
 #include "btk_internal.h"
+#include <cstdlib>
 #include <cmath>
 #include <complex>
 #include <cstring>
@@ -10,6 +11,22 @@
 namespace {
 thread_local std::string g_last_error;
 using cd = std::complex<double>;
+}
+
+const btk_switches_t& btk_switches()
+{
+  static const btk_switches_t sw = [] {
+    auto flag = [](const char* n) { return getenv(n) != nullptr; };
+    auto num = [](const char* n, int dflt) { const char* v = getenv(n); return v ? atoi(v) : dflt; };
+    btk_switches_t s;
+    s.disable_analysis512 = flag("BTK_DISABLE_ANALYSIS512"); s.disable_synthesis512 = flag("BTK_DISABLE_SYNTHESIS512");
+    s.disable_fast = flag("BTK_DISABLE_FAST"); s.disable_fused = flag("BTK_DISABLE_FUSED");
+    s.nlms_v1 = flag("BTK_NLMS_V1"); s.wpe_noskip = flag("BTK_WPE_NOSKIP");
+    s.nlms_alt = num("BTK_NLMS_ALT", 0); s.fused_var = num("BTK_FUSED_VAR", -1);
+    s.analysis512_ablate = num("BTK_ANALYSIS512_ABLATE", 0); s.pf_jb = num("BTK_PF_JB", 0);
+    return s;
+  }();                                                   // C++11 magic static: initialised once, thread-safe
+  return sw;
 }
 
 int btk_set_error(int code, const char* fmt, ...)

@@ -20,6 +20,7 @@
 #include "fft_lds.h"
 #include "fft_packed.h"
 #include <cstdlib>
+#include <cstdio>
 #include <type_traits>
 
 namespace {
@@ -217,7 +218,7 @@ int launch512(const btk_fb* fb, const float* pcm, long nsamples, long pcm_stride
   // per launch: the attribute is per device, and one process may drive several GPUs (btk_set_device)
   BTK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const float gain = fb->gain_factor > 0 ? (float)fb->gain_factor : 1.0f;
-  static const int ablate = getenv("BTK_ANALYSIS512_ABLATE") ? atoi(getenv("BTK_ANALYSIS512_ABLATE")) : 0;   // diagnostics only
+  const int ablate = btk_switches().analysis512_ablate;                         // diagnostics only
   hipLaunchKernelGGL(kern, dim3((unsigned)nblocks), dim3(A_NT), lds, st, pcm, nsamples, pcm_stride, fb->d_proto, fb->d_tw,
                      fb->laN, gain, N, fb->kx1 - fb->kx0, X, T_stride, t0, tcount, ntiles, nruns, nchan, ablate, fb->kx0, fb->kx1);
   BTK_HIP_CHECK(hipGetLastError());
@@ -241,21 +242,23 @@ int launch512(const btk_fb* fb, const float* pcm, long nsamples, long pcm_stride
 // the FFT lane that holds Z_n[q] (q = j + 16 k2, registers k2 = 0..15) accumulates A[q] and B'[q] = B[(256-q) & 255]
 // straight from its registers: no FFT result goes back to LDS, no cross-lane partner is needed per channel.
 // Wq [Sw][N][WSTR] float4: entry i < 256 = (w[i], w[(256-i) & 255]), entry 256 = (w[256], 0, 0), the rest 0.
-template <int R, int VAR>
-__global__ __launch_bounds__(A_NT, 2)
+template <int R, int VAR, int TT = A_TT>       // TT frames per workgroup tile (16: four wavefronts; 8: two, four workgroups per CU)
+__global__ __launch_bounds__(TT * 16, 2)
 void analysis512_bfz_kernel(const float* __restrict__ pcm, long nsamples, long pcm_stride,
                             const float* __restrict__ proto, const float2* __restrict__ twg,
                             int laN, float gain, int N, int K, const float4* __restrict__ Wq, long w_stream_stride,
-                            float2* __restrict__ Y, long T_stride, long t0, long tcount, int ntiles, int tiles_per_xcd, int S)
+                            float2* __restrict__ Y, long T_stride, long t0, long tcount, int ntiles, int tiles_per_xcd, int S,
+                            unsigned long long* __restrict__ phase_cycles /* VAR & 512: diagnostics, else unused */)
 {
+  constexpr int NT = TT * 16, NWAVE = NT / 64;
   constexpr int D = A_M / R;
-  constexpr int SPAN = (A_TT - 1) * D + A_MT * A_M;
+  constexpr int SPAN = (TT - 1) * D + A_MT * A_M;
   // frame stride 272 = 16 (mod 32) float2: the four frames of a wavefront land on disjoint bank halves in both FFT passes
   // (with 273 the transposing writes of frames fl and fl+1 collide two-way)
   constexpr int FRZ = 272;
-  constexpr int FB_BYTES = A_TT * FRZ * 8;
+  constexpr int FB_BYTES = TT * FRZ * 8;
   constexpr int REG_U = (SPAN * 4 > FB_BYTES) ? SPAN * 4 : FB_BYTES;
-  constexpr int NV4 = (SPAN / 4 + A_NT - 1) / A_NT;
+  constexpr int NV4 = (SPAN / 4 + NT - 1) / NT;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   // PIPE: the PCM span has its own region and the weight pairs are double-buffered, so channel n+1 is staged into LDS
   // while channel n is transformed -- two workgroup barriers per channel instead of four.  Without it (R = 1: the span
@@ -279,7 +282,7 @@ void analysis512_bfz_kernel(const float* __restrict__ pcm, long nsamples, long p
   const int s = j0 / tiles_per_xcd;
   const int tile = xcd * tiles_per_xcd + j0 % tiles_per_xcd;
   if (s >= S || tile >= ntiles) return;
-  const long tt0 = (long)tile * A_TT;
+  const long tt0 = (long)tile * TT;
   const int fl = lane >> 4, j = lane & 15;
 
   const bool vec_ok = ((pcm_stride & 3) == 0) && ((reinterpret_cast<uintptr_t>(pcm) & 15) == 0);
@@ -287,7 +290,7 @@ void analysis512_bfz_kernel(const float* __restrict__ pcm, long nsamples, long p
   const bool inb = vec_ok && g0 >= 0 && g0 + SPAN <= nsamples;
   const float4* wts = Wq + (long)s * w_stream_stride;
   float4 pre[NV4];
-  float4 wpre;
+  float4 wpre[256 / NT];
   float2 w256pre;
   const float* pcm_e = pcm;                  // the edge path's own copies of the two base pointers: laundered through an
   const float4* wts_e = wts;                 // asm at its entry so that hipcc cannot hoist its loads above the branch
@@ -296,13 +299,13 @@ void analysis512_bfz_kernel(const float* __restrict__ pcm, long nsamples, long p
     if (inb) {
 #pragma unroll
       for (int q = 0; q < NV4; q++) {
-        const int l = (tid + q * A_NT) * 4;
+        const int l = (tid + q * NT) * 4;
         if (l < SPAN) pre[q] = *reinterpret_cast<const float4*>(src + g0 + l);
       }
     } else {
 #pragma unroll
       for (int q = 0; q < NV4; q++) {
-        const int l = (tid + q * A_NT) * 4;
+        const int l = (tid + q * NT) * 4;
         float v[4];
 #pragma unroll
         for (int e = 0; e < 4; e++) {
@@ -312,7 +315,8 @@ void analysis512_bfz_kernel(const float* __restrict__ pcm, long nsamples, long p
         pre[q] = make_float4(v[0], v[1], v[2], v[3]);
       }
     }
-    wpre = wts_e[(long)n * WSTR + tid];
+#pragma unroll
+    for (int q = 0; q < 256 / NT; q++) wpre[q] = wts_e[(long)n * WSTR + tid + q * NT];
     const float4 t = wts_e[(long)n * WSTR + 256];
     w256pre = make_float2(t.x, t.y);
   };
@@ -320,7 +324,7 @@ void analysis512_bfz_kernel(const float* __restrict__ pcm, long nsamples, long p
   // polyphase mapping: with D = M / R the windows of the pair indices n and n + D/2 are the same LDS words shifted by one
   // frame, so a thread takes G = 2 such indices (n0, n0 + 128) for half of the tile's frames and reads every word once
   constexpr int G = (R >= 2 && (VAR & 1)) ? 2 : 1;
-  constexpr int NPG = 256 / G, FPT = A_TT / G, CG = R / G;
+  constexpr int NPG = 256 / G, FPT = 16 / G, CG = R / G;            // FPT frames per thread; NT / NPG thread groups cover the tile
   constexpr int NWG = FPT + (A_MT - 1) * R + (G - 1) * CG;
   const int n0 = tid % NPG, fg = tid / NPG;
   float2 h[G][A_MT];
@@ -350,10 +354,11 @@ void analysis512_bfz_kernel(const float* __restrict__ pcm, long nsamples, long p
   auto stage = [&](int buf) {
 #pragma unroll
     for (int q = 0; q < NV4; q++) {
-      const int l = (tid + q * A_NT) * 4;
+      const int l = (tid + q * NT) * 4;
       if (l < SPAN) *reinterpret_cast<float4*>(xs + l) = pre[q];
     }
-    wq[buf * WSTR + tid] = wpre;
+#pragma unroll
+    for (int q = 0; q < 256 / NT; q++) wq[buf * WSTR + tid + q * NT] = wpre[q];
     if (tid == 0) wq[buf * WSTR + 256] = make_float4(w256pre.x, w256pre.y, 0.f, 0.f);
   };
   // PIPE: LDS-DMA (global_load_lds_dwordx4: 1 KiB per wave-instruction, lane-linear destination) of the span and the
@@ -372,10 +377,10 @@ void analysis512_bfz_kernel(const float* __restrict__ pcm, long nsamples, long p
       if constexpr (!GW) {
         const float* src = pcm + ((long)s * N + n) * pcm_stride + g0;
         constexpr int NCH = (SPAN * 4 + 1023) / 1024;
-        constexpr int NI = (NCH + 3) / 4;
+        constexpr int NI = (NCH + NWAVE - 1) / NWAVE;
 #pragma unroll
         for (int i = 0; i < NI; i++) {
-          const int c = wv + 4 * i;
+          const int c = wv + NWAVE * i;
           if (c < NCH) {
             const int l = c * 256 + lane * 4;
             if ((SPAN % 256) == 0 || l < SPAN) glds16s(src, (unsigned)l * 4u, xs_lds + c * 1024);
@@ -385,8 +390,8 @@ void analysis512_bfz_kernel(const float* __restrict__ pcm, long nsamples, long p
       const float4* wsrc = wts + (long)n * WSTR;
       const unsigned wq_lds = xs_lds + WQ_OFF + (n & 1) * (WSTR * 16);
 #pragma unroll
-      for (int i = 0; i < 2; i++) {
-        const int c = wv + 4 * i;
+      for (int i = 0; i < (WSTR / 64 + NWAVE - 1) / NWAVE; i++) {
+        const int c = wv + NWAVE * i;
         if (c < WSTR / 64) glds16s(wsrc, (unsigned)(c * 64 + lane) * 16u, wq_lds + c * 1024);
       }
     } else {
@@ -412,11 +417,20 @@ void analysis512_bfz_kernel(const float* __restrict__ pcm, long nsamples, long p
   // SHARED: the PCM span is staged through registers into the region the FFT frames overwrite (R = 1, and the edge
   // tiles of the GW form): four barriers per channel instead of two
   constexpr bool SHARED = !PIPE || (GW && !FAST);
+  // VAR & 512 (diagnostics, profiles/scripts/r02_phase_timing.sh): wave 0 of every workgroup adds up the shader-clock time it
+  // spends between the marks below (s_memtime; each mark drains lgkmcnt, which the surrounding code does anyway)
+  constexpr bool TIMED = (VAR & 512) != 0;
+  long long tm[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  long long tlast = TIMED ? clock64() : 0;
+  auto mark = [&](int i) { if constexpr (TIMED) { const long long c = clock64(); tm[i] += c - tlast; tlast = c; } };
   auto body = [&](int n, float2 (&win)[NWG]) {
+    mark(0);                                                         // (loop overhead / previous accumulate tail)
     // ---- phase 1: registers -> LDS (PCM span + weight pairs)
     if (SHARED) stage(PIPE ? (n & 1) : 0);
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // the LDS-DMA of channel n (and, GW, its window) has landed
+    mark(1);                                                         // wait for memory
     __syncthreads();
+    mark(2);                                                         // barrier A
     const int wbuf = PIPE ? (n & 1) : 0;
 
     // ---- phase 2: polyphase (sliding register window), frames overwrite the span after the barrier.
@@ -450,7 +464,9 @@ void analysis512_bfz_kernel(const float* __restrict__ pcm, long nsamples, long p
         for (int g = 0; g < FPT; g++) fbuf[(fg * FPT + g) * FRZ + zoff] = po[q][g];
       }
     }
+    mark(3);                                                         // polyphase (+ LDS window reads when staged)
     __syncthreads();
+    mark(4);                                                         // barrier B
     if (n + 1 < N) {
       if (SHARED) fetch(n + 1);           // lands under phases 3-4
       else {
@@ -459,6 +475,7 @@ void analysis512_bfz_kernel(const float* __restrict__ pcm, long nsamples, long p
       }
     }
 
+    mark(5);                                                         // issue of the next channel's loads
     // ---- phase 3: wave-private 256-point FFT of 4 frames; the result stays in registers
     f2 v[16];
     const f4* wl = reinterpret_cast<const f4*>(wq) + wbuf * WSTR + j;
@@ -468,6 +485,7 @@ void analysis512_bfz_kernel(const float* __restrict__ pcm, long nsamples, long p
 #pragma unroll
       for (int r = 0; r < 16; r++) v[r] = fb[r * 17 + j];
       dft16q(v);
+      if constexpr (TIMED) { asm volatile("" : "+v"(v[15])); mark(6); }   // first pass (reads + radix-16)
 #pragma unroll
       for (int k1 = 1; k1 < 16; k1++) v[k1] = cmulv(v[k1], twr[k1 - 1]);
 #pragma unroll
@@ -477,6 +495,7 @@ void analysis512_bfz_kernel(const float* __restrict__ pcm, long nsamples, long p
 #pragma unroll
       for (int q = 0; q < 4; q++) wg[0][q] = wl[q * 16];
       dft16q(v);                                                      // v[k2] = Z[j + 16 k2]
+      if constexpr (TIMED) { asm volatile("" : "+v"(v[15])); mark(7); }   // twiddles, exchange, second pass
     }
     // ---- phase 4: A[q] += conj(w[q]) Z[q],  B'[q] += conj(w[(256-q)&255]) conj(Z[q])
     {
@@ -499,12 +518,20 @@ void analysis512_bfz_kernel(const float* __restrict__ pcm, long nsamples, long p
       acc256.x = fmaf(w256.x, r, acc256.x);
       acc256.y = fmaf(-w256.y, r, acc256.y);
     }
+    if constexpr (TIMED) { asm volatile("" : "+v"(accA[15]), "+v"(accB[15])); mark(8); }   // beamformer sums
     if (SHARED) __syncthreads();                                      // frames and weight pairs consumed
   };
   if (SHARED) fetch(0);
   else dma(0, fast);
   if constexpr (GWF) wload(win, 0);
   for (int n = 0; n < N; n++) body(n, win);
+  if constexpr (TIMED && FAST) {
+    if (tid == 0) {
+#pragma unroll
+      for (int i = 0; i < 9; i++) atomicAdd(phase_cycles + i, (unsigned long long)tm[i]);
+      atomicAdd(phase_cycles + 9, 1ull);
+    }
+  }
   };
   if (PIPE && inb) channels(std::true_type{});
   else channels(std::false_type{});
@@ -535,7 +562,7 @@ void analysis512_bfz_kernel(const float* __restrict__ pcm, long nsamples, long p
   }
   __syncthreads();
   {
-    const int f = tid & 15, kq = tid >> 4;
+    const int f = tid % TT, kq = tid / TT;                 // NT / TT = 16 bin columns
     if (tt0 + f < tcount) {
       float2* yo = Y + (long)s * K * T_stride + tt0 + f;
       const float2* zf = fbuf + f * FRZ;
@@ -572,29 +599,52 @@ int launch512_bf(const btk_fb* fb, const float* pcm, long nsamples, long pcm_str
   constexpr int SPAN = (A_TT - 1) * D + A_MT * A_M;
   const int K = fb->K;
   const int Sw = per_stream ? S : 1;
-  const int ntiles = (int)((tcount + A_TT - 1) / A_TT);
-  const int tiles_per_xcd = (ntiles + 7) / 8;
-  const long nblocks = (long)8 * tiles_per_xcd * S;
   const float gain = fb->gain_factor > 0 ? (float)fb->gain_factor : 1.0f;
   float4* Wq = static_cast<float4*>(scratch);
   // BTK_FUSED_VAR (diagnostics, read once): 1 = register staging with the span and the frames sharing one LDS region (the only
   // form for R = 1, whose 38 KB span leaves no room for a separate region), 3 = LDS-DMA staging of the span,
   // 7 (default for R = 2) = polyphase window straight from HBM, only frames and weights in LDS
-  static const int var = getenv("BTK_FUSED_VAR") ? atoi(getenv("BTK_FUSED_VAR")) : (R == 2 ? 7 : 3);
+  const int var = btk_switches().fused_var >= 0 ? btk_switches().fused_var : (R == 2 ? 7 : 3);
   const bool pipe = (var & 2) && R >= 2;
   const bool gw = pipe && (var & 4) && R == 2;
-  const int fbz = A_TT * 272 * 8;
+  // (TT = 8 -- two wavefronts per workgroup, four workgroups per CU, the same occupancy with less barrier coupling -- measured
+  //  1.50 ms against 1.47 for the 16-frame tile: BTK_FUSED_VAR=1031 in profiles/scripts/r02_fused_ab.sh)
+  const bool t8 = gw && (var & 1024);
+  const int TTv = t8 ? 8 : A_TT;
+  const int ntiles = (int)((tcount + TTv - 1) / TTv);
+  const int tiles_per_xcd = (ntiles + 7) / 8;
+  const long nblocks = (long)8 * tiles_per_xcd * S;
+  const int fbz = TTv * 272 * 8;
   const int regz = SPAN * 4 > fbz ? SPAN * 4 : fbz;
   const size_t lds = pipe ? (size_t)(gw ? 0 : SPAN * 4) + fbz + sizeof(float4) * WSTR * 2 : (size_t)regz + sizeof(float4) * WSTR;
   const long nw = (long)Sw * N * WSTR;
   hipLaunchKernelGGL(pair_weights_kernel, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, st, W, Wq, K, N, Sw);
   auto kern = pipe ? analysis512_bfz_kernel<R, 3> : analysis512_bfz_kernel<R, 1>;
   if (gw) kern = analysis512_bfz_kernel<2, 7>;
+  if (t8) kern = analysis512_bfz_kernel<2, 7, 8>;
+  unsigned long long* phase = nullptr;
+  if (R == 2 && (var & 512)) {                       // diagnostics: per-phase shader cycles of wave 0, printed by every launch
+    kern = gw ? analysis512_bfz_kernel<2, 519> : analysis512_bfz_kernel<2, 515>;
+    static unsigned long long* dbuf = nullptr;
+    if (!dbuf) BTK_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&dbuf), 16 * sizeof(unsigned long long)));
+    BTK_HIP_CHECK(hipMemsetAsync(dbuf, 0, 16 * sizeof(unsigned long long), st));
+    phase = dbuf;
+  }
   // per launch: the attribute is per device, and one process may drive several GPUs (btk_set_device)
   BTK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(kern, dim3((unsigned)nblocks), dim3(A_NT), lds, st, pcm, nsamples, pcm_stride, fb->d_proto, fb->d_tw,
-                     fb->laN, gain, N, K, Wq, per_stream ? (long)N * WSTR : 0L, Y, T_stride, t0, tcount, ntiles, tiles_per_xcd, S);
+  hipLaunchKernelGGL(kern, dim3((unsigned)nblocks), dim3(TTv * 16), lds, st, pcm, nsamples, pcm_stride, fb->d_proto, fb->d_tw,
+                     fb->laN, gain, N, K, Wq, per_stream ? (long)N * WSTR : 0L, Y, T_stride, t0, tcount, ntiles, tiles_per_xcd, S, phase);
   BTK_HIP_CHECK(hipGetLastError());
+  if (phase) {
+    unsigned long long h[10];
+    BTK_HIP_CHECK(hipMemcpyAsync(h, phase, sizeof(h), hipMemcpyDeviceToHost, st));
+    BTK_HIP_CHECK(hipStreamSynchronize(st));
+    static const char* names[9] = {"loop", "wait_memory", "barrier_A", "polyphase", "barrier_B", "issue_loads", "fft_pass1", "fft_pass2", "beamformer_sums"};
+    double tot = 0; for (int i = 0; i < 9; i++) tot += (double)h[i];
+    fprintf(stderr, "fused kernel phases (wave 0 of %llu interior workgroups, %d channels): %.0f cycles per channel:", h[9], N, tot / (h[9] ? h[9] : 1) / N);
+    for (int i = 0; i < 9; i++) fprintf(stderr, " %s %.1f%%", names[i], 100.0 * h[i] / (tot > 0 ? tot : 1));
+    fprintf(stderr, "\n");
+  }
   return BTK_OK;
 }
 

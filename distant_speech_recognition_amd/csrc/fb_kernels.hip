@@ -335,12 +335,12 @@ int btk_fb_analysis(const btk_fb_t* fb, const float* pcm, long nsamples, long pc
   if (tcount == 0) return BTK_OK;
   hipStream_t st = as_stream(stream);
   float2* Xp = static_cast<float2*>(X);
-  static const bool no512 = getenv("BTK_DISABLE_ANALYSIS512") != nullptr;       // A/B switch for benchmarking
+  const bool no512 = btk_switches().disable_analysis512;                         // A/B switches of profiles/ (btk_internal.h)
   if (!no512) {
     const int rc = btk_analysis512_try(fb, pcm, nsamples, pcm_stride, S, N, X, T_stride, t0, tcount, st);
     if (rc != 0) return rc > 0 ? BTK_OK : rc;
   }
-  static const bool nofast = getenv("BTK_DISABLE_FAST") != nullptr;
+  const bool nofast = btk_switches().disable_fast;
   if (!nofast) {
     const int rc = btk_fast_analysis_try(fb, pcm, nsamples, pcm_stride, S, N, X, T_stride, t0, tcount, st);
     if (rc != 0) return rc > 0 ? BTK_OK : rc;
@@ -394,12 +394,12 @@ int btk_fb_synthesis(const btk_fb_t* fb, const void* Y, long nframes, long T_str
   if (bcount == 0) return BTK_OK;
   hipStream_t st = as_stream(stream);
   const float2* Yp = static_cast<const float2*>(Y);
-  static const bool no512 = getenv("BTK_DISABLE_SYNTHESIS512") != nullptr;      // A/B switch for benchmarking
+  const bool no512 = btk_switches().disable_synthesis512;
   if (!no512) {
     const int rc = btk_synthesis512_try(fb, Y, nframes, T_stride, S, out, out_stride, b0, bcount, st);
     if (rc != 0) return rc > 0 ? BTK_OK : rc;
   }
-  static const bool nofast = getenv("BTK_DISABLE_FAST") != nullptr;
+  const bool nofast = btk_switches().disable_fast;
   if (!nofast) {
     const int rc = btk_fast_synthesis_try(fb, Y, nframes, T_stride, S, out, out_stride, b0, bcount, st);
     if (rc != 0) return rc > 0 ? BTK_OK : rc;
@@ -434,7 +434,7 @@ int btk_fb_analysis_bf(const btk_fb_t* fb, const float* pcm, long nsamples, long
   const long Sw = per_stream_weights ? S : 1;
   const long wt_bytes = fuse512 ? (long)sizeof(float4) * Sw * 320 * N : fusefast ? (long)sizeof(float2) * Sw * fb->K * N : 0;
   hipStream_t st = as_stream(stream);
-  static const bool nofuse = getenv("BTK_DISABLE_FUSED") != nullptr;
+  const bool nofuse = btk_switches().disable_fused;
   if (!nofuse) {
     if ((fuse512 || fusefast) && scratch_bytes < wt_bytes)
       return btk_set_error(BTK_ERR_PARAMETER, "btk_fb_analysis_bf: scratch too small (%ld < %ld)", scratch_bytes, wt_bytes);
@@ -459,7 +459,7 @@ long btk_fb_analysis_bf_scratch_bytes(const btk_fb_t* fb, int S, int N, int per_
 {
   if (!fb) return -1;
   const bool rok = fb->R == 1 || fb->R == 2 || fb->R == 4;
-  const bool nofuse = getenv("BTK_DISABLE_FUSED") != nullptr;
+  const bool nofuse = btk_switches().disable_fused;
   if (!nofuse && rok && fb->m == 4 && fb->M == 512)
     return (long)sizeof(float4) * (per_stream_weights ? S : 1) * 320 * N;                // weight pairs [Sw][N][320], see fb_analysis512.hip
   if (!nofuse && rok && fb->m == 4 && fb->M == 256)

@@ -566,8 +566,8 @@ int btk_nlms_process_nc(const float* params /* host, 8 floats */, const void* vs
   const float2* VS = static_cast<const float2*>(vs);
   float2* Yp = static_cast<float2*>(Y);
   float2* U = static_cast<float2*>(u_state);
-  static const bool v1 = getenv("BTK_NLMS_V1") != nullptr;                       // A/B switches (benchmarking only)
-  static const int alt = getenv("BTK_NLMS_ALT") ? atoi(getenv("BTK_NLMS_ALT")) : 0;
+  const bool v1 = btk_switches().nlms_v1;                                        // A/B switches of profiles/ (btk_internal.h)
+  const int alt = btk_switches().nlms_alt;
   const bool vec_ok = (T_stride % 2 == 0) && ((reinterpret_cast<uintptr_t>(X) & 15) == 0);
   if (NC > 1) {
     if (!vec_ok) return btk_set_error(BTK_ERR_DIMENSION, "btk_nlms_process: Nc > 1 needs an even T_stride and a 16-byte aligned X");

@@ -359,7 +359,7 @@ int btk_bf_apply_stats2(const void* W, const void* D, int per_stream_weights, co
   dim3 grid((unsigned)((T + PF_NT - 1) / PF_NT), (unsigned)K, (unsigned)S);
   // rows of C per register block: 16 rows x two forms overflow the SGPR file (the C entries are scalar loads) and
   // N <= 8 wastes half of a 16-row block; measured in profiles/pf_ab.py.  BTK_PF_JB overrides (benchmarking only).
-  static const int jb_env = getenv("BTK_PF_JB") ? atoi(getenv("BTK_PF_JB")) : 0;
+  const int jb_env = btk_switches().pf_jb;
   const int jb = jb_env ? jb_env : (Cv ? 8 : (N <= 8 ? 8 : 16));
   if (Cv && jb == 16)
     hipLaunchKernelGGL((bf_apply_stats2_kernel<2, 16>), grid, dim3(PF_NT), 0, as_stream(stream),

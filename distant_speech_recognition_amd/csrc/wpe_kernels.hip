@@ -450,7 +450,7 @@ int btk_wpe_estimate(const void* X, int S, int K, int C, long T_stride, long T, 
   for (int it = 0; it < iterations; it++) {
     hipLaunchKernelGGL(wpe_predict_kernel, dim3((unsigned)((T + 255) / 256), (unsigned)K, (unsigned)(S * C)), dim3(256), 0, st,
                        Xp, Gp, g, 0, Winv, static_cast<float2*>(nullptr));
-    static const int skip = getenv("BTK_WPE_NOSKIP") ? 0 : 1;      // A/B switch (benchmarking only)
+    const int skip = btk_switches().wpe_noskip ? 0 : 1;            // A/B switch of profiles/ (btk_internal.h)
     const dim3 hgrid1((unsigned)(ntile * (ntile + 1) / 2), (unsigned)K, (unsigned)(S * C));
     if (C % 4 == 0)
       hipLaunchKernelGGL(wpe_herk_kernel<4>, dim3(hgrid1.x, hgrid1.y, (unsigned)(S * C / 4)), dim3(256), lds_herk, st, Xp, Winv, g, ntile, R, skip, nspan);
