@@ -1,0 +1,26 @@
+#!/bin/bash
+# Round-2 measurement set (one gpurun call): bench default, profiled bench (rocprofv3 --kernel-trace --stats), PMC traffic
+# passes (FETCH_SIZE / WRITE_SIZE separately), SQ counters + phase timing of the fused kernel, stage / config benches,
+# micro-benchmarks.  Everything lands under gpurun_out/r02/; the summaries that are committed go to profiles/r02_*.
+cd /tmp && export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r02; rm -rf $O; mkdir -p $O
+cd $R
+python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/smoke.log 2>&1
+python bench.py > $O/bench_default.json 2> $O/bench_default.err
+python bench_stages.py > $O/bench_stages.json 2> $O/bench_stages.err
+python bench_configs.py > $O/bench_configs.json 2> $O/bench_configs.err
+python bench_bin_sharded.py > $O/bench_bin_sharded.json 2> $O/bench_bin_sharded.err
+cd /tmp
+rocprofv3 --kernel-trace --stats -d $O/prof -o bench -- python $R/bench.py --no-cpu > $O/bench_profiled.json 2> $O/prof.err
+DB=$(find $O/prof -name "*.db" | head -1)
+[ -n "$DB" ] && python $R/profiles/summarize_rocpd.py $DB $O/bench_kernel_stats.txt > /dev/null 2>&1
+PMC_S=32 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -o p -- python $R/profiles/pmc_workload.py > $O/pmc_fetch.log 2>&1
+PMC_S=32 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -o p -- python $R/profiles/pmc_workload.py > $O/pmc_write.log 2>&1
+mkdir -p $O/pmc_rw && cp -r $O/pmc_fetch $O/pmc_rw/ && cp -r $O/pmc_write $O/pmc_rw/
+python $R/profiles/make_traffic_json.py $O/pmc_rw $O/pmc_traffic.json 32 4096 > /dev/null 2>&1
+cd $R
+BTK_FUSED_VAR=7 bash profiles/scripts/r02_pmc_fused.sh > $O/pmc_fused_sq.txt 2>&1
+for v in 519 515; do BTK_FUSED_VAR=$v python profiles/fused_ab.py 2>&1 | grep -E "phases|ms"; done > $O/fused_phase_timing.txt 2>&1
+VARS="7 3 1031" bash profiles/scripts/r02_fused_ab.sh > $O/fused_ab.txt 2>&1
+( cd profiles/ubench && for b in valu_rate vgpr_bank mfma_rate lds_rate; do /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -w -o /tmp/$b $b.hip && echo "== $b" && /tmp/$b; done ) > $O/ubench.txt 2>&1
+tail -1 $O/smoke.log; ls $O
