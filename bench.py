@@ -62,7 +62,7 @@ def synth_pcm_host(N, L, delays, seed):
 
 
 def _cpu_stream(a):
-    """one utterance stream through the oracle's frame-by-frame pull graph; returns (frames, seconds)"""
+    """one utterance stream through the oracle's frame-by-frame pull graph; returns (frames, seconds, t_start, t_end)"""
     N, M, m, r, dct, frames, seed = a
     from oracle import oracle as orc
     from distant_speech_recognition_amd import prototypes
@@ -73,9 +73,32 @@ def _cpu_stream(a):
     pcm = synth_pcm_host(N, frames * D, delays, seed)
     wq = orc.calc_mainlobe(M, N, FS, delays)
     wl = np.zeros((M, N), np.complex128)
+    w0 = time.time()                                      # wall clock: comparable across the pool's processes
     t0 = time.perf_counter()
     _, nbf = orc.pipeline_gsc(h, g, M, m, r, dct, pcm, wq, wl)
-    return nbf, time.perf_counter() - t0
+    dt = time.perf_counter() - t0
+    return nbf, dt, w0, w0 + dt
+
+
+def usable_cores():
+    """CPUs this process may really use: the affinity mask capped by the cgroup CPU quota (v2 cpu.max, v1 cfs_quota)"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = float(q) / float(per)
+    except (OSError, ValueError):
+        try:
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / per
+        except (OSError, ValueError):
+            pass
+    if quota is not None:
+        n = max(1, min(n, int(quota + 0.5)))
+    return n, quota
 
 
 def cpu_baseline(N, M, m, r, dct, frames, all_cores=True):
@@ -83,22 +106,22 @@ def cpu_baseline(N, M, m, r, dct, frames, all_cores=True):
     same workload: ONE host core (the reference is single-threaded: the faithful figure, `value`), and -- BASELINE.md
     section 2 item 2 -- one independent process per utterance stream on all cores the box gives this process."""
     D = M >> r
-    nbf, dt = _cpu_stream((N, M, m, r, dct, frames, 20260927))
+    nbf, dt, _, _ = _cpu_stream((N, M, m, r, dct, frames, 20260927))
     res = {"value": nbf / dt, "unit": "frames/s", "cores": 1, "kind": "port",
            "sample": "%d-mic %d-bin SubbandGSC chain, %d frames, 1 stream, oracle/btk_oracle.c -O3" % (N, M, nbf),
            "xRT": nbf / dt / (FS / D)}
     if all_cores:
         import multiprocessing as mp
-        cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-        per = max(frames // 4, 256)                       # keeps the whole baseline leg at ~2x the single-core time
+        cores, quota = usable_cores()
+        per = max(frames // 4, 256)                       # ~1/4 of the single-core sample per process
         with mp.get_context("fork").Pool(cores) as pool:
-            t0 = time.perf_counter()
-            outs = pool.map(_cpu_stream, [(N, M, m, r, dct, per, 20260927 + 1000 * i) for i in range(cores)])
-            wall = time.perf_counter() - t0
+            outs = pool.map(_cpu_stream, [(N, M, m, r, dct, per, 20260927 + 1000 * i) for i in range(cores)], chunksize=1)
         tot = sum(o[0] for o in outs)
+        wall = max(o[3] for o in outs) - min(o[2] for o in outs)        # first pull-graph start .. last end (input synthesis excluded)
         res["all_cores"] = {"value": tot / wall, "unit": "frames/s", "cores": cores, "kind": "port",
                             "sample": "%d independent streams (one process each) x %d frames" % (cores, outs[0][0]),
-                            "xRT": tot / wall / (FS / D)}
+                            "xRT": tot / wall / (FS / D), "cgroup_cpu_quota": quota,
+                            "per_process_frames_per_s": [min(o[0] / o[1] for o in outs), max(o[0] / o[1] for o in outs)]}
     return res
 
 
