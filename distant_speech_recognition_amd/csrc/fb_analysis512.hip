@@ -420,6 +420,11 @@ void analysis512_bfz_kernel(const float* __restrict__ pcm, long nsamples, long p
   // VAR & 512 (diagnostics, profiles/scripts/r02_phase_timing.sh): wave 0 of every workgroup adds up the shader-clock time it
   // spends between the marks below (s_memtime; each mark drains lgkmcnt, which the surrounding code does anyway)
   constexpr bool TIMED = (VAR & 512) != 0;
+  constexpr bool SPREAD = (VAR & 8) != 0;
+  // ABL (VAR bits 12-14, only built with -DBTK_FUSED_ABLATE; results are WRONG by design): what the kernel costs without ...
+  //   1 the LDS exchange between the FFT passes, 2 the weight-pair reads, 3 the frame writes and first-pass reads,
+  //   4 the window loads, 5 the two barriers, 6 the beamformer sums; 7 = window loads always from channel 0 (cache hits)
+  constexpr int ABL = (VAR >> 12) & 7;
   long long tm[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
   long long tlast = TIMED ? clock64() : 0;
   auto mark = [&](int i) { if constexpr (TIMED) { const long long c = clock64(); tm[i] += c - tlast; tlast = c; } };
@@ -429,7 +434,7 @@ void analysis512_bfz_kernel(const float* __restrict__ pcm, long nsamples, long p
     if (SHARED) stage(PIPE ? (n & 1) : 0);
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // the LDS-DMA of channel n (and, GW, its window) has landed
     mark(1);                                                         // wait for memory
-    __syncthreads();
+    if constexpr (ABL != 5) __syncthreads();
     mark(2);                                                         // barrier A
     const int wbuf = PIPE ? (n & 1) : 0;
 
@@ -461,19 +466,23 @@ void analysis512_bfz_kernel(const float* __restrict__ pcm, long nsamples, long p
         const int nn = n0 + q * NPG;
         const int zoff = (nn >> 4) * 17 + (nn & 15);
 #pragma unroll
-        for (int g = 0; g < FPT; g++) fbuf[(fg * FPT + g) * FRZ + zoff] = po[q][g];
+        for (int g = 0; g < FPT; g++) { if constexpr (ABL != 3) fbuf[(fg * FPT + g) * FRZ + zoff] = po[q][g]; else asm volatile("" :: "v"(po[q][g].x), "v"(po[q][g].y)); }
       }
     }
     mark(3);                                                         // polyphase (+ LDS window reads when staged)
-    __syncthreads();
+    if constexpr (ABL != 5) __syncthreads();
     mark(4);                                                         // barrier B
     if (n + 1 < N) {
       if (SHARED) fetch(n + 1);           // lands under phases 3-4
       else {
         dma(n + 1, fast);                 // every window read of channel n is behind the barrier; lands under phases 3-4
-        if constexpr (GWF) wload(win, n + 1);
+        if constexpr (GWF && !SPREAD) wload(win, n + 1);
       }
     }
+    // SPREAD: the window loads are unconditional (the last channel re-reads its own window) so that they share a basic
+    // block with the FFT, and the scheduling groups at the end of the body interleave them with its VALU work: four
+    // wavefronts issuing 15 loads back to back queue up behind the CU's one address path (~80 cycles per load and wave)
+    if constexpr (GWF && SPREAD && ABL != 4) wload(win, ABL == 7 ? 0 : (n + 1 < N ? n + 1 : n));     // ABL 7: always channel 0 (cache-resident)
 
     mark(5);                                                         // issue of the next channel's loads
     // ---- phase 3: wave-private 256-point FFT of 4 frames; the result stays in registers
@@ -483,17 +492,17 @@ void analysis512_bfz_kernel(const float* __restrict__ pcm, long nsamples, long p
     {
       f2* fb = reinterpret_cast<f2*>(fbuf) + (wave * 4 + fl) * FRZ;
 #pragma unroll
-      for (int r = 0; r < 16; r++) v[r] = fb[r * 17 + j];
+      for (int r = 0; r < 16; r++) { if constexpr (ABL != 3) v[r] = fb[r * 17 + j]; else { v[r] = f2{win[r % NWG].x, (float)r}; asm volatile("" : "+v"(v[r])); } }
       dft16q(v);
       if constexpr (TIMED) { asm volatile("" : "+v"(v[15])); mark(6); }   // first pass (reads + radix-16)
 #pragma unroll
       for (int k1 = 1; k1 < 16; k1++) v[k1] = cmulv(v[k1], twr[k1 - 1]);
 #pragma unroll
-      for (int k1 = 0; k1 < 16; k1++) fb[j * 17 + k1] = v[k1];
+      for (int k1 = 0; k1 < 16; k1++) { if constexpr (ABL != 1) fb[j * 17 + k1] = v[k1]; }
 #pragma unroll
-      for (int jp = 0; jp < 16; jp++) v[jp] = fb[jp * 17 + j];
+      for (int jp = 0; jp < 16; jp++) { if constexpr (ABL != 1) v[jp] = fb[jp * 17 + j]; else asm volatile("" : "+v"(v[jp])); }
 #pragma unroll
-      for (int q = 0; q < 4; q++) wg[0][q] = wl[q * 16];
+      for (int q = 0; q < 4; q++) { if constexpr (ABL == 2 || ABL == 6) { wg[0][q] = f4{1.f, 0.5f, 0.25f, 2.f}; wg[1][q] = wg[0][q]; asm volatile("" : "+v"(wg[0][q]), "+v"(wg[1][q])); } else wg[0][q] = wl[q * 16]; }
       dft16q(v);                                                      // v[k2] = Z[j + 16 k2]
       if constexpr (TIMED) { asm volatile("" : "+v"(v[15])); mark(7); }   // twiddles, exchange, second pass
     }
@@ -503,20 +512,35 @@ void analysis512_bfz_kernel(const float* __restrict__ pcm, long nsamples, long p
       for (int g = 0; g < 4; g++) {
         if (g < 3) {
 #pragma unroll
-          for (int q = 0; q < 4; q++) wg[(g + 1) & 1][q] = wl[((g + 1) * 4 + q) * 16];
+          for (int q = 0; q < 4; q++) { if constexpr (ABL != 2 && ABL != 6) wg[(g + 1) & 1][q] = wl[((g + 1) * 4 + q) * 16]; }
         }
 #pragma unroll
         for (int q = 0; q < 4; q++) {
           const int k2 = g * 4 + q;
           const f4 w4 = wg[g & 1][q];
-          acc_conjw_z(accA[k2], w4.xy, v[k2]);
-          acc_conjw_conjz(accB[k2], w4.zw, v[k2]);
+          if constexpr (ABL != 6) {
+            acc_conjw_z(accA[k2], w4.xy, v[k2]);
+            acc_conjw_conjz(accB[k2], w4.zw, v[k2]);
+          } else { accA[k2] += v[k2]; }
         }
       }
       const float r = v[0].x - v[0].y;                                // bin 256 (lanes j == 0): X = gain (Z0.re - Z0.im)
       const float4 w256 = wq[wbuf * WSTR + 256];
       acc256.x = fmaf(w256.x, r, acc256.x);
       acc256.y = fmaf(-w256.y, r, acc256.y);
+    }
+    if constexpr (GWF && SPREAD) {
+      constexpr int PAT = (VAR >> 4) & 1;
+#pragma unroll
+      for (int i = 0; i < NWG; i++) {
+        if constexpr (PAT == 0) {                               // measured 1.411 ms (VAR 15) against 1.463 unspread (VAR 7)
+          __builtin_amdgcn_sched_group_barrier(0x080, 3, 0);    // three LDS instructions (anchors: the FFT's data flow fixes their order) ...
+          __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);    // ... then one window load
+        } else {                                                // evenly between the VALU instructions: 1.420 ms (VAR 31)
+          __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);
+          __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        }
+      }
     }
     if constexpr (TIMED) { asm volatile("" : "+v"(accA[15]), "+v"(accB[15])); mark(8); }   // beamformer sums
     if (SHARED) __syncthreads();                                      // frames and weight pairs consumed
@@ -603,8 +627,9 @@ int launch512_bf(const btk_fb* fb, const float* pcm, long nsamples, long pcm_str
   float4* Wq = static_cast<float4*>(scratch);
   // BTK_FUSED_VAR (diagnostics, read once): 1 = register staging with the span and the frames sharing one LDS region (the only
   // form for R = 1, whose 38 KB span leaves no room for a separate region), 3 = LDS-DMA staging of the span,
-  // 7 (default for R = 2) = polyphase window straight from HBM, only frames and weights in LDS
-  const int var = btk_switches().fused_var >= 0 ? btk_switches().fused_var : (R == 2 ? 7 : 3);
+  // 7 = polyphase window straight from HBM, only frames and weights in LDS, 15 (default for R = 2) = 7 with the window loads
+  // interleaved with the FFT (31: the other interleaving pattern)
+  const int var = btk_switches().fused_var >= 0 ? btk_switches().fused_var : (R == 2 ? 15 : 3);
   const bool pipe = (var & 2) && R >= 2;
   const bool gw = pipe && (var & 4) && R == 2;
   // (TT = 8 -- two wavefronts per workgroup, four workgroups per CU, the same occupancy with less barrier coupling -- measured
@@ -622,6 +647,19 @@ int launch512_bf(const btk_fb* fb, const float* pcm, long nsamples, long pcm_str
   auto kern = pipe ? analysis512_bfz_kernel<R, 3> : analysis512_bfz_kernel<R, 1>;
   if (gw) kern = analysis512_bfz_kernel<2, 7>;
   if (t8) kern = analysis512_bfz_kernel<2, 7, 8>;
+  if (gw && !t8 && (var & 8)) kern = (var & 16) ? analysis512_bfz_kernel<2, 31> : analysis512_bfz_kernel<2, 15>;
+#ifdef BTK_FUSED_ABLATE
+  if (gw && !t8) switch ((var >> 12) & 7) {
+    case 1: kern = analysis512_bfz_kernel<2, 15 + 4096 * 1>; break;
+    case 2: kern = analysis512_bfz_kernel<2, 15 + 4096 * 2>; break;
+    case 3: kern = analysis512_bfz_kernel<2, 15 + 4096 * 3>; break;
+    case 4: kern = analysis512_bfz_kernel<2, 15 + 4096 * 4>; break;
+    case 5: kern = analysis512_bfz_kernel<2, 15 + 4096 * 5>; break;
+    case 6: kern = analysis512_bfz_kernel<2, 15 + 4096 * 6>; break;
+    case 7: kern = analysis512_bfz_kernel<2, 15 + 4096 * 7>; break;
+    default: break;
+  }
+#endif
   unsigned long long* phase = nullptr;
   if (R == 2 && (var & 512)) {                       // diagnostics: per-phase shader cycles of wave 0, printed by every launch
     kern = gw ? analysis512_bfz_kernel<2, 519> : analysis512_bfz_kernel<2, 515>;

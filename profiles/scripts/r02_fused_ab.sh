@@ -1,7 +1,7 @@
 #!/bin/bash
 # A/B of the fused analysis+beamform kernel forms (BTK_FUSED_VAR is read once per process): ROUNDS alternating passes over the
 # variants, best time per variant (clocks differ between boxes and drift within a call; only in-call comparisons count).
-#   3 = LDS-DMA staging of the PCM span, 7 = polyphase window straight from HBM, 15 = 7 + L2 touch two channels ahead
+#   3 = LDS-DMA staging of the PCM span, 7 = polyphase window straight from HBM, 15 = 7 + window loads interleaved with the LDS traffic of the FFT
 mkdir -p gpurun_out
 : > gpurun_out/r02_fused_ab.log
 for r in $(seq ${ROUNDS:-3}); do
