@@ -290,7 +290,11 @@ template <int GROUP> __device__ __forceinline__ float group_sum2(float v)
 // orthonormal vectors c_j (CX [K][NC-1][N], from btk_nlms_constraint_vectors).  Only Q x and |Q x|^2 change:
 //     Q x = x - vs Yc / |vs|^2 - sum_j c_j (c_j^H x),   |Q x|^2 = |x|^2 - |Yc|^2 / |vs|^2 - sum_j |c_j^H x|^2;
 // u Q x = u x still holds because u stays in the row space of B^T.
-template <int GROUP, int CPL, int TBF, int NC = 1>
+// NPF LDS tiles are fetched together: a tile of 8 frames takes 64 bytes of each of its 64 CPL snapshot rows, and visiting
+// thousands of rows 64 bytes at a time runs HBM at 2.8-3.6 TB/s whatever the kernel does with the data
+// (profiles/ubench/strided_rows.hip); requesting both halves of every 128-byte line back to back reads at 5.4-5.9 TB/s.
+// NPF = 2 keeps the 8-frame LDS tile (two wavefronts per SIMD) and holds the second half in registers until its turn.
+template <int GROUP, int CPL, int TBF, int NC = 1, int NPF = 1>
 __global__ __launch_bounds__(64)
 void nlms_bin2_kernel(const float2* __restrict__ X, const float2* __restrict__ VS, float2* __restrict__ Y,
                       int K, int N, long T_stride, long T, const float* __restrict__ ctrl,
@@ -341,43 +345,53 @@ void nlms_bin2_kernel(const float2* __restrict__ X, const float2* __restrict__ V
       }
   }
 
-  float4 pre[NPASS];
-  float creg = 0.f;
+  float4 pre[NPF][NPASS];
+  float creg[NPF];
   const int lrow = lane / LPR, lc4 = lane % LPR;
-  auto prefetch = [&](long t0) {
-    const long t = t0 + 2 * lc4;
+  auto prefetch = [&](long tp) {
 #pragma unroll
     for (int q = 0; q < NPASS; q++) {
       const int r = q * RPP + lrow;
       const int bl = r / NR, n = r % NR;
       const int kk = kb + bl;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (kk < K && n < N && t < T) {
-        const float2* src = X + (((long)s * K + kk) * N + n) * T_stride + t;
-        if (t + 1 < T) v = *reinterpret_cast<const float4*>(src);
-        else { const float2 a = src[0]; v = make_float4(a.x, a.y, 0.f, 0.f); }
+      const float2* row = X + (((long)s * K + kk) * N + n) * T_stride;
+#pragma unroll
+      for (int h = 0; h < NPF; h++) {                    // the tiles of a row back to back: one 128-byte line per NPF = 2
+        const long t = tp + h * TBF + 2 * lc4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (kk < K && n < N && t < T) {
+          if (t + 1 < T) v = *reinterpret_cast<const float4*>(row + t);
+          else { const float2 a = row[t]; v = make_float4(a.x, a.y, 0.f, 0.f); }
+        }
+        pre[h][q] = v;
       }
-      pre[q] = v;
     }
-    const long tc = t0 + (lane % TBF);
-    creg = tc < T ? ctrl[(long)s * T + tc] : 0.f;
+#pragma unroll
+    for (int h = 0; h < NPF; h++) {
+      const long tc = tp + h * TBF + (lane % TBF);
+      creg[h] = tc < T ? ctrl[(long)s * T + tc] : 0.f;
+    }
   };
-  auto commit = [&]() {
+  auto commit = [&](const float4 (&pr)[NPASS]) {
 #pragma unroll
     for (int q = 0; q < NPASS; q++) {
       float2* d = tile + (q * RPP + lrow) * LDWv + 2 * lc4;
-      d[0] = make_float2(pre[q].x, pre[q].y);
-      d[1] = make_float2(pre[q].z, pre[q].w);
+      d[0] = make_float2(pr[q].x, pr[q].y);
+      d[1] = make_float2(pr[q].z, pr[q].w);
     }
   };
 
   prefetch(0);
-  for (long t0 = 0; t0 < T; t0 += TBF) {
+  for (long tp = 0; tp < T; tp += NPF * TBF) {
+#pragma unroll
+  for (int h = 0; h < NPF; h++) {
+    const long t0 = tp + h * TBF;
+    if (h > 0 && t0 >= T) break;
     __syncthreads();
-    commit();
-    const float ctile = creg;
+    commit(pre[h]);
+    const float ctile = creg[h];
     __syncthreads();
-    if (t0 + TBF < T) prefetch(t0 + TBF);
+    if (h == NPF - 1 && tp + NPF * TBF < T) prefetch(tp + NPF * TBF);
     float2 yout = make_float2(0.f, 0.f);
     float uu = 0.f;
     const int nsteps = (T - t0) < TBF ? (int)(T - t0) : TBF;
@@ -465,6 +479,7 @@ void nlms_bin2_kernel(const float2* __restrict__ X, const float2* __restrict__ V
     if (GROUP >= TBF && kvalid && gl < nsteps)
       Y[((long)s * K + k) * T_stride + t0 + gl] = yout;
   }
+  }
   if (kvalid) {
 #pragma unroll
     for (int c = 0; c < CPL; c++) {
@@ -475,7 +490,7 @@ void nlms_bin2_kernel(const float2* __restrict__ X, const float2* __restrict__ V
   }
 }
 
-template <int GROUP, int CPL, int TBF, int NC = 1>
+template <int GROUP, int CPL, int TBF, int NC = 1, int NPF = 1>
 int launch_bin2(const float2* X, const float2* VS, float2* Y, int S, int K, int N, long T_stride, long T,
                 const float* ctrl, const double* state_before, NlmsParams p, float2* U, float* sigma2, hipStream_t st,
                 const float2* CX = nullptr)
@@ -483,7 +498,7 @@ int launch_bin2(const float2* X, const float2* VS, float2* Y, int S, int K, int 
   constexpr int BPW = 64 / GROUP;
   const size_t lds = sizeof(float2) * (size_t)64 * CPL * (TBF + 1);
   dim3 grid((unsigned)((K + BPW - 1) / BPW), (unsigned)S);
-  hipLaunchKernelGGL((nlms_bin2_kernel<GROUP, CPL, TBF, NC>), grid, dim3(64), lds, st, X, VS, Y, K, N, T_stride, T,
+  hipLaunchKernelGGL((nlms_bin2_kernel<GROUP, CPL, TBF, NC, NPF>), grid, dim3(64), lds, st, X, VS, Y, K, N, T_stride, T,
                      ctrl, state_before, p, U, sigma2, CX);
   BTK_HIP_CHECK(hipGetLastError());
   return BTK_OK;
@@ -590,10 +605,13 @@ int btk_nlms_process_nc(const float* params /* host, 8 floats */, const void* vs
     else if (N <= 64) {
       if (alt == 1) return launch_bin2<32, 2, 16>(Xp, VS, Yp, S, K, N, T_stride, T, ctrl, state_before, p, U, sigma2, st);
       if (alt == 2) return launch_bin2<8, 8, 8>(Xp, VS, Yp, S, K, N, T_stride, T, ctrl, state_before, p, U, sigma2, st);
-      return launch_bin2<16, 4, 8>(Xp, VS, Yp, S, K, N, T_stride, T, ctrl, state_before, p, U, sigma2, st);
+      if (alt == 3) return launch_bin2<16, 4, 16>(Xp, VS, Yp, S, K, N, T_stride, T, ctrl, state_before, p, U, sigma2, st);
+      if (alt == 4) return launch_bin2<32, 2, 16>(Xp, VS, Yp, S, K, N, T_stride, T, ctrl, state_before, p, U, sigma2, st);
+      if (alt == 6) return launch_bin2<16, 4, 8>(Xp, VS, Yp, S, K, N, T_stride, T, ctrl, state_before, p, U, sigma2, st);
+      return launch_bin2<16, 4, 8, 1, 2>(Xp, VS, Yp, S, K, N, T_stride, T, ctrl, state_before, p, U, sigma2, st);     // 6.49 -> 6.05 ms at 32 streams
     }
-    else if (N <= 128) return launch_bin2<32, 4, 8>(Xp, VS, Yp, S, K, N, T_stride, T, ctrl, state_before, p, U, sigma2, st);
-    return launch_bin2<64, 4, 8>(Xp, VS, Yp, S, K, N, T_stride, T, ctrl, state_before, p, U, sigma2, st);
+    else if (N <= 128) return launch_bin2<32, 4, 8, 1, 2>(Xp, VS, Yp, S, K, N, T_stride, T, ctrl, state_before, p, U, sigma2, st);
+    return launch_bin2<64, 4, 8, 1, 2>(Xp, VS, Yp, S, K, N, T_stride, T, ctrl, state_before, p, U, sigma2, st);
   }
   if (N <= 8)        return launch_bin<8, 1>(Xp, VS, Yp, S, K, N, T_stride, T, ctrl, state_before, p, U, sigma2, st);
   else if (N <= 16)  return launch_bin<16, 1>(Xp, VS, Yp, S, K, N, T_stride, T, ctrl, state_before, p, U, sigma2, st);
