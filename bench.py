@@ -130,7 +130,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--prewarm-ms", type=float, default=100.0,
+    ap.add_argument("--prewarm-ms", type=float, default=300.0,
                     help="untimed steps run before the warmup until this much wall time has passed: the host-side weight design "
                          "leaves the GPU idle for seconds and its clocks need tens of ms of load to come back up")
     ap.add_argument("--mics", type=int, default=64)
@@ -222,9 +222,10 @@ def main():
     prewarm_steps = 0
     t_pw = time.perf_counter()
     while (time.perf_counter() - t_pw) * 1e3 < args.prewarm_ms:
-        step()
+        for _ in range(8):                       # back to back: a host synchronisation after every step lets the clock sag
+            step()
         torch.cuda.synchronize()
-        prewarm_steps += 1
+        prewarm_steps += 8
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
@@ -247,12 +248,8 @@ def main():
 
     # per-stage reference measurements of the staged kernels (outside the timed region)
     def _time(fn, n=3):
-        fn(); torch.cuda.synchronize()
-        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        a.record()
-        for _ in range(n): fn()
-        b.record(); torch.cuda.synchronize()
-        return a.elapsed_time(b) * 1e-3 / n
+        from bench_util import gpu_time
+        return gpu_time(torch, fn, n=n)[0]
     if fused:
         t_ana = _time(lambda: afb.analysis(pcm, out=X))
         t_bf = _time(lambda: eng.bf_apply(W, X, out=Yc))

@@ -23,25 +23,10 @@ HBM = 8.0e12
 FS = 16000.0
 
 
-def timed(torch, fn, n=3, warm=1, prewarm_ms=40.0):
-    """(seconds per call, last result) after a wall-clock pre-warm: the GPU idles during the host-side set-up of a
-    stage and its clocks need tens of ms of load to come back up (same reason as bench.py --prewarm-ms)."""
-    import time
-    t0 = time.perf_counter()
-    r = None
-    while (time.perf_counter() - t0) * 1e3 < prewarm_ms:
-        r = fn()
-        torch.cuda.synchronize()
-    for _ in range(warm):
-        r = fn()
-    torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(n):
-        r = fn()
-    e1.record()
-    torch.cuda.synchronize()
-    return e0.elapsed_time(e1) * 1e-3 / n, r
+def timed(torch, fn, n=3, warm=1, prewarm_ms=250.0):
+    """(seconds per call, last result) at settled clocks (bench_util.gpu_time)"""
+    from bench_util import gpu_time
+    return gpu_time(torch, fn, n=n, prewarm_ms=prewarm_ms)
 
 
 def pcm_for(torch, dev, afb, S, N, T, D, seed):

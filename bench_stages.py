@@ -14,24 +14,10 @@ sys.path.insert(0, ROOT)
 HBM, FP32 = 8.0e12, 157.3e12
 
 
-def timeit(torch, fn, n=5, warm=2, prewarm_ms=40.0):
-    """HIP-event time per call after `warm` calls and a wall-clock pre-warm: host-side set-up between stages leaves the
-    GPU idle and its clocks need tens of ms of load to come back up (same reason as bench.py --prewarm-ms)."""
-    import time
-    t0 = time.perf_counter()
-    while (time.perf_counter() - t0) * 1e3 < prewarm_ms:
-        fn()
-        torch.cuda.synchronize()
-    for _ in range(warm):
-        fn()
-    torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(n):
-        fn()
-    e1.record()
-    torch.cuda.synchronize()
-    return e0.elapsed_time(e1) * 1e-3 / n
+def timeit(torch, fn, n=5, warm=2, prewarm_ms=250.0):
+    """HIP-event time per call at settled clocks (bench_util.gpu_time)"""
+    from bench_util import gpu_time
+    return gpu_time(torch, fn, n=n, prewarm_ms=prewarm_ms)[0]
 
 
 def main():

@@ -23,3 +23,28 @@ def ula_positions(N, pitch_mm=20.0):
 def la_delays(mpos, azimuth):
     """far-field linear-array delays (reference lib/pybeamformer.py:41-64)"""
     return calc_la_delays(mpos, azimuth)
+
+
+def gpu_time(torch, fn, n=3, prewarm_ms=250.0, min_ms=60.0, max_calls=40):
+    """(seconds per call by HIP events, last result).  The shader clock needs ~0.3 s of uninterrupted load to settle (idle
+    at ~150 MHz, ramping through ~2 GHz; profiles/clock_probe.py), and a host synchronisation between calls lets it fall
+    back: the pre-warm issues calls back to back for `prewarm_ms` of GPU time and the timed region covers at least `min_ms`
+    (at least n, at most max_calls calls each -- stateful stages such as the NLMS step-size schedule must not be run
+    hundreds of times)."""
+    r = fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    r = fn()
+    e1.record()
+    torch.cuda.synchronize()
+    t1 = max(e0.elapsed_time(e1), 1e-3)
+    for _ in range(int(min(max(prewarm_ms / t1, 1), max_calls))):
+        r = fn()
+    reps = int(min(max(min_ms / t1, n), max(max_calls, n)))
+    e0.record()
+    for _ in range(reps):
+        r = fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e-3 / reps, r

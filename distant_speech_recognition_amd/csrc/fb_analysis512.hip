@@ -32,7 +32,7 @@ constexpr int WSTR = 320;              // float4 per channel in the weight-pair 
 
 constexpr int A_RUN = 16;             // consecutive tiles (16 frames each) one workgroup walks through
 
-template <int R>     // R = M / D in {1, 2, 4}
+template <int R, bool SHARD>     // R = M / D in {1, 2, 4}; SHARD: only the bins [k0, k1) are stored
 __global__ __launch_bounds__(A_NT, 3)
 void analysis512_kernel(const float* __restrict__ pcm, long nsamples, long pcm_stride,
                         const float* __restrict__ proto, const float2* __restrict__ twg,
@@ -190,11 +190,11 @@ void analysis512_kernel(const float* __restrict__ pcm, long nsamples, long pcm_s
         const float2 w = tw[k];
         const float2 xv = make_float2(e.x + (w.x * o.x - w.y * o.y), e.y + (w.x * o.y + w.y * o.x));
         if (ablate == 1) { if (xv.x == 1.2345e33f) xo[0] = xv; }
-        else if (live && k >= k0 && k < k1) xo[(long)(16 * it - k0) * kstride] = xv;
+        else if (live && (!SHARD || (k >= k0 && k < k1))) xo[(long)(16 * it - (SHARD ? k0 : 0)) * kstride] = xv;
       }
-      if (tid < 16 && live && ablate != 1 && A_NF >= k0 && A_NF < k1) {   // k = 256: W^256 = -1, partner Z[0]
+      if (tid < 16 && live && ablate != 1 && (!SHARD || (A_NF >= k0 && A_NF < k1))) {   // k = 256: W^256 = -1, partner Z[0]
         const float2 z0 = zf[0];
-        X[((long)s * K * N + nch) * T_stride + tt0 + f + (long)(A_NF - k0) * kstride] = make_float2(gain * (z0.x - z0.y), 0.f);
+        X[((long)s * K * N + nch) * T_stride + tt0 + f + (long)(A_NF - (SHARD ? k0 : 0)) * kstride] = make_float2(gain * (z0.x - z0.y), 0.f);
       }
     }
     __syncthreads();                                         // frames consumed before the next span overwrites them
@@ -214,7 +214,8 @@ int launch512(const btk_fb* fb, const float* pcm, long nsamples, long pcm_stride
   const int ntiles = (int)((tcount + A_TT - 1) / A_TT);
   const int nruns = (ntiles + A_RUN - 1) / A_RUN;
   const long nblocks = (long)((nchan + 7) / 8) * nruns * 8;
-  auto kern = analysis512_kernel<R>;
+  const bool shard = !(fb->kx0 == 0 && fb->kx1 == fb->K);
+  auto kern = shard ? analysis512_kernel<R, true> : analysis512_kernel<R, false>;
   // per launch: the attribute is per device, and one process may drive several GPUs (btk_set_device)
   BTK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const float gain = fb->gain_factor > 0 ? (float)fb->gain_factor : 1.0f;

@@ -232,7 +232,7 @@ __device__ __forceinline__ void pp_emit(float2* __restrict__ fbuf, int tid, cons
 constexpr int F_RUN = 8;       // consecutive tiles a workgroup walks through
 
 // ------------------------------------------------------------------------------------------------ analysis
-template <int LOG2M, int R>
+template <int LOG2M, int R, bool SHARD>      // SHARD: only the bins [k0, k1) are stored (the full range needs no per-bin test)
 __global__ __launch_bounds__(F_NT, 2)
 void fast_analysis_kernel(const float* __restrict__ pcm, long nsamples, long pcm_stride,
                           const float* __restrict__ proto, const float2* __restrict__ twg,
@@ -335,12 +335,12 @@ void fast_analysis_kernel(const float* __restrict__ pcm, long nsamples, long pcm
         const float2 e = make_float2(hg * (zk.x + zq.x), hg * (zk.y - zq.y));
         const float2 o = make_float2(hg * (zk.y + zq.y), -hg * (zk.x - zq.x));
         const float2 w = twg[k];                                  // e^{+j 2 pi k / M}, L1-resident
-        if (live && k >= k0 && k < k1)
-          xo[(long)(k - k0) * kstride] = make_float2(e.x + (w.x * o.x - w.y * o.y), e.y + (w.x * o.y + w.y * o.x));
+        if (live && (!SHARD || (k >= k0 && k < k1)))
+          xo[(long)(k - (SHARD ? k0 : 0)) * kstride] = make_float2(e.x + (w.x * o.x - w.y * o.y), e.y + (w.x * o.y + w.y * o.x));
       }
-      if (kq == 0 && live && NF >= k0 && NF < k1) {
+      if (kq == 0 && live && (!SHARD || (NF >= k0 && NF < k1))) {
         const float2 z0 = zf[0];
-        xo[(long)(NF - k0) * kstride] = make_float2(gain * (z0.x - z0.y), 0.f);
+        xo[(long)(NF - (SHARD ? k0 : 0)) * kstride] = make_float2(gain * (z0.x - z0.y), 0.f);
       }
     }
     __syncthreads();
@@ -362,7 +362,8 @@ int launch_fast_analysis(const btk_fb* fb, const float* pcm, long nsamples, long
   const int ntiles = (int)((tcount + G::TT - 1) / G::TT);
   const int nruns = (ntiles + F_RUN - 1) / F_RUN;
   const long nblocks = (long)((nchan + 7) / 8) * nruns * 8;
-  auto kern = fast_analysis_kernel<LOG2M, R>;
+  const bool shard = !(fb->kx0 == 0 && fb->kx1 == fb->K);
+  auto kern = shard ? fast_analysis_kernel<LOG2M, R, true> : fast_analysis_kernel<LOG2M, R, false>;
   // per launch: the attribute is per device, and one process may drive several GPUs (btk_set_device)
   BTK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const float gain = fb->gain_factor > 0 ? (float)fb->gain_factor : 1.0f;
