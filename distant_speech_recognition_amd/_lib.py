@@ -90,6 +90,7 @@ SIGNATURES = {
     "btk_bin_range": (None, [_i, _i, _i, C.POINTER(_i), C.POINTER(_i)]),
     "btk_allgather_bins": (_i, [_vp, _vp, _vp, _i, _i, _l, _i, _i, _vp]),
     "btk_weights_mainlobe": (_i, [_i, _i, _f, _vp, _vp]),
+    "btk_weights_mainlobe_halfband": (_i, [_i, _i, _f, _vp, _vp]),
     "btk_weights_mainlobe_2": (_i, [_i, _i, _f, _vp, _vp, _vp]),
     "btk_weights_mainlobe_n": (_i, [_i, _i, _f, _vp, _vp, _i, _vp]),
     "btk_weights_blocking_matrix": (_i, [_vp, _i, _i, _vp]),

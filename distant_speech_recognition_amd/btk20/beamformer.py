@@ -50,8 +50,10 @@ class SnapShotArrayPtr(object):
 class _SubbandBeamformer(_BlockServedStream, VectorComplexFeatureStream):
     def __init__(self, fftlen, half_band_shift=False, nm="SubbandBeamformer"):
         _BlockServedStream.__init__(self, fftlen, nm)
-        if half_band_shift:
-            raise jallocation_error("halfBandShift==true is not yet supported\n")
+        # half_band_shift == true exists for SubbandDS and SubbandGSC with one constraint (beamformer.cc:1113-1128, 1276-1285);
+        # SubbandMVDR(GSC) refuse it in their constructors (:2283-2285) and SubbandGSCRLS in next() (:1528-1530)
+        self._half_band_shift = bool(half_band_shift)
+        self._Yfull = None        # half_band_shift: device output of all M bins [1][M][T]
         self._fftlen = int(fftlen)
         self._K = self._fftlen // 2 + 1
         self._channels = []
@@ -68,7 +70,7 @@ class _SubbandBeamformer(_BlockServedStream, VectorComplexFeatureStream):
     def clear_channel(self):
         self._channels = []
         self._snapshot_array = None
-        self._X = self._Y = self._Xhost = None
+        self._X = self._Y = self._Yfull = self._Xhost = None
 
     def chan_num(self):
         return len(self._channels)
@@ -141,15 +143,23 @@ class _SubbandBeamformer(_BlockServedStream, VectorComplexFeatureStream):
     def _compute_block(self):
         import torch
         X = self.device_snapshots()
-        W = torch.from_numpy(self.effective_weights()).to(device())
         try:
-            self._Y = engine.bf_apply(W, X)
+            if self._half_band_shift:
+                Wf = torch.from_numpy(self.effective_weights_all_bins().astype(np.complex64)).to(device())
+                self._Yfull = engine.bf_apply_all_bins(Wf, X)
+                self._Y = self._Yfull[:, : self._K]          # what a downstream synthesis bank reads (bins 0..M/2)
+            else:
+                W = torch.from_numpy(self.effective_weights()).to(device())
+                self._Y = engine.bf_apply(W, X)
         except _lib.BtkError as e:
             raise_from_code(e)
 
     def _prepare(self):
         Y = self.device_block()
-        self._frames = _mirror(Y[0].cpu().numpy(), self._fftlen)
+        if self._half_band_shift:
+            self._frames = self._Yfull[0].cpu().numpy().T.astype(np.complex128)      # every bin has its own output
+        else:
+            self._frames = _mirror(Y[0].cpu().numpy(), self._fftlen)
 
     def _output_version(self):
         return self._wversion
@@ -160,7 +170,7 @@ class _SubbandBeamformer(_BlockServedStream, VectorComplexFeatureStream):
         if self._Y is not None:
             done = self._frame_no + 1
             old, oldY = self._frames, self._Y
-            self._Y = None
+            self._Y = self._Yfull = None
             self._frames = None
             if done > 0:
                 self._compute_block()
@@ -175,15 +185,16 @@ class _SubbandBeamformer(_BlockServedStream, VectorComplexFeatureStream):
             c.reset()
         if self._snapshot_array is not None:
             self._snapshot_array.zero()
-        self._X = self._Y = self._Xhost = None
+        self._X = self._Y = self._Yfull = self._Xhost = None
         _BlockServedStream.reset(self)
 
 
 class _BeamformerWeights(object):
     """BeamformerWeights (beamformer.h:28-82, beamformer.cc:485-965): wq, B, wa, wl, ta host-side in float64."""
 
-    def __init__(self, fftlen, chan_num, NC=1):
+    def __init__(self, fftlen, chan_num, NC=1, half_band_shift=False):
         self.fftlen, self.chan_num, self.NC = fftlen, chan_num, NC
+        self.half_band_shift = bool(half_band_shift)
         self.wq = np.zeros((fftlen, chan_num), np.complex128)
         self.wl = np.zeros((fftlen, chan_num), np.complex128)
         self.ta = np.zeros((fftlen, chan_num), np.complex128)
@@ -196,7 +207,7 @@ class _BeamformerWeights(object):
             raise jdimension_error("Number of delays does not match number of channels (%d vs. %d).\n" % (delays.size, self.chan_num))
         if is_gsc and self.chan_num <= 1:
             raise jdimension_error("The number of channels must be > 1 but it is %d\n" % self.chan_num)
-        self.wq = engine.weights_mainlobe(self.fftlen, self.chan_num, samplerate, delays)
+        self.wq = engine.weights_mainlobe(self.fftlen, self.chan_num, samplerate, delays, self.half_band_shift)
         self.ta = self.wq.copy()                                           # setTimeAlignment
         if is_gsc:
             for k in range(self.fftlen):                                   # all M bins (beamformer.cc:557-563)
@@ -204,6 +215,8 @@ class _BeamformerWeights(object):
 
     def calc_mainlobe_2(self, samplerate, delays_t, delays_i, is_gsc):
         """calcMainlobe2 / calcMainlobeN with NC = 2 (beamformer.cc:572-721)."""
+        if self.half_band_shift:
+            raise j_error("halfBandShift==true with more than one constraint is not supported by this engine\n")
         delays_t, delays_i = np.asarray(delays_t, np.float64), np.asarray(delays_i, np.float64)
         if delays_i.size != self.chan_num:
             raise jdimension_error("The number of delays for an interference signal does not match number of channels (%d vs. %d).\n"
@@ -224,6 +237,8 @@ class _BeamformerWeights(object):
         """calcMainlobeN (beamformer.cc:600-721), NC >= 2."""
         if NC < 2 or NC > self.chan_num:
             raise jdimension_error("1 < the number of constraints %d <= the number of sensors %d.\n" % (NC, self.chan_num))
+        if self.half_band_shift:
+            raise j_error("halfBandShift==true with more than one constraint is not supported by this engine\n")
         delays_t = np.asarray(delays_t, np.float64)
         delays_is = np.asarray(delays_is, np.float64).reshape(-1, self.chan_num)
         if delays_t.size != self.chan_num:
@@ -255,7 +270,7 @@ class SubbandDSPtr(_SubbandBeamformer):
 
     def _alloc_bfweight(self, NC):
         # re-creates the BeamformerWeights object -> resets active weights and post-filter state (beamformer.cc:1082-1092)
-        self._bfw = [_BeamformerWeights(self._fftlen, self.chan_num(), NC)]
+        self._bfw = [_BeamformerWeights(self._fftlen, self.chan_num(), NC, self._half_band_shift)]
         self._weights_version = getattr(self, "_weights_version", 0) + 1
 
     def calc_array_manifold_vectors(self, samplerate, delays):
@@ -288,6 +303,11 @@ class SubbandDSPtr(_SubbandBeamformer):
     def effective_weights(self):
         self._check_weights()
         return engine.weights_gsc_effective(self._bfw[0].wq, None, self._fftlen)
+
+    def effective_weights_all_bins(self):
+        """half_band_shift: the weight vector of every one of the M bins, complex128 [M][N] (beamformer.cc:1113-1118)"""
+        self._check_weights()
+        return self._bfw[0].wq
 
     def alignment_vector(self, use_wq):
         self._check_weights()
@@ -366,6 +386,15 @@ class SubbandGSCPtr(SubbandDSPtr):
         self._dirty = False
         return engine.weights_gsc_effective(self._bfw[0].wq, self._bfw[0].wl, self._fftlen, self._normalize_weight)
 
+    def effective_weights_all_bins(self):
+        """half_band_shift: wq - wl of every bin, normalised like calc_gsc_output (beamformer.cc:1208-1243, 1276-1285)"""
+        self._check_weights()
+        self._dirty = False
+        w = self._bfw[0].wq - self._bfw[0].wl
+        if self._normalize_weight:
+            w = w / (np.linalg.norm(w, axis=1, keepdims=True) * self.chan_num())
+        return w
+
     def next(self, frame_no=-5):
         if getattr(self, "_dirty", False) and not (frame_no == self._frame_no and self._vector is not None):
             self._invalidate_output()
@@ -416,6 +445,8 @@ class SubbandGSCRLSPtr(SubbandGSCPtr):
     updateActiveWeightVecotrs, setQuadraticConstraint = update_active_weight_vecotrs, set_quadratic_constraint
 
     def _compute_block(self):
+        if self._half_band_shift:
+            raise j_error("not yet implemented\n")                      # beamformer.cc:1528-1530
         import torch
         self._check_weights()
         if self._p0 is None:
@@ -464,6 +495,8 @@ class SubbandMVDRPtr(SubbandDSPtr):
     """SubbandMVDR (beamformer.h:333-383, beamformer.cc:2280-2599)."""
 
     def __init__(self, fftlen, half_band_shift=False, nm="SubbandMVDR"):
+        if half_band_shift:
+            raise jallocation_error("halfBandShift==true is not yet supported\n")      # beamformer.cc:2283-2285
         SubbandDSPtr.__init__(self, fftlen, half_band_shift, nm)
         self._R = None            # device complex64 [K][N][N]
         self._wmvdr = None        # host complex128 [K][N]

@@ -163,6 +163,24 @@ int btk_weights_mainlobe(int M, int N, float samplerate, const double* delays, d
   return BTK_OK;
 }
 
+// BeamformerWeights::calcMainlobe with halfBandShift_ == true (beamformer.cc:515-527): bin k sits at (k + 0.5) fs / M, all M bins are
+// filled, and the conjugate partner of bin k is bin M - 1 - k (not M - k).
+int btk_weights_mainlobe_halfband(int M, int N, float samplerate, const double* delays, double* wq_out)
+{
+  if (M < 2 || N < 1 || !delays || !wq_out) return btk_set_error(BTK_ERR_PARAMETER, "btk_weights_mainlobe_halfband: bad argument");
+  cd* wq = reinterpret_cast<cd*>(wq_out);
+  const int half = M / 2;
+  const double dN = (double)N;
+  const float fshift = 0.5f;
+  for (int k = 0; k < half; k++)
+    for (int c = 0; c < N; c++) {
+      const double ph = -2.0 * M_PI * (fshift + k) * samplerate * delays[c] / M;
+      wq[(size_t)k * N + c] = std::polar(1.0, ph) / dN;
+      wq[(size_t)(M - 1 - k) * N + c] = std::polar(1.0, -ph) / dN;
+    }
+  return BTK_OK;
+}
+
 // calc_blocking_matrix_ (beamformer.cc:373-454): classical Gram-Schmidt over the first N-NC
 // columns of the projector I - conj(a) a^T / |a|^2.
 int btk_weights_blocking_matrix(const double* a_in, int N, int NC, double* B_out)

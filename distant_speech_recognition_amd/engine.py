@@ -204,15 +204,35 @@ def bf_apply(W, X, out=None):
     return out
 
 
+def bf_apply_all_bins(Wfull, X):
+    """half_band_shift == true (SubbandDS/GSC::next, beamformer.cc:1113-1128, 1276-1285): every one of the M bins has its
+    own weight vector, y_k = w_k^H x_k for k = 0..M-1, where the snapshots of the bins above M/2 are the conjugate mirrors
+    the analysis bank of a real signal produces, x_{M-k} = conj(x_k).  Wfull complex64 [M][N], X [S][K][N][T] ->
+    Y complex64 [S][M][T]:  y_{M-k} = conj((conj w_{M-k})^H x_k), i.e. two passes of the same apply kernel."""
+    _check(X, "X", torch.complex64, 4)
+    S, K, N, T = X.shape
+    M = 2 * (K - 1)
+    _check(Wfull, "W", torch.complex64, (M, N))
+    Y = torch.empty((S, M, T), dtype=torch.complex64, device=X.device)
+    lo = bf_apply(Wfull[:K].contiguous(), X)
+    Y[:, :K] = lo
+    W2 = torch.zeros((K, N), dtype=torch.complex64, device=X.device)
+    W2[1:K - 1] = torch.conj(Wfull[K:]).flip(0)              # row k' <- conj(w_{M-k'}), k' = 1 .. M/2-1
+    up = bf_apply(W2, X)
+    Y[:, K:] = torch.conj(up[:, 1:K - 1]).flip(1)
+    return Y
+
+
 # ---------------------------------------------------------------------------- host-side weight design
-def weights_mainlobe(M, N, samplerate, delays):
-    """BeamformerWeights::calcMainlobe -> wq complex128 [M][N]."""
+def weights_mainlobe(M, N, samplerate, delays, half_band_shift=False):
+    """BeamformerWeights::calcMainlobe -> wq complex128 [M][N] (half_band_shift: beamformer.cc:515-527)."""
     delays = np.ascontiguousarray(delays, np.float64)
     if delays.shape != (N,):
         raise _lib.BtkError(_lib.BTK_ERR_DIMENSION,
                             "Number of delays does not match number of channels (%d vs. %d)." % (delays.size, N))
     wq = np.zeros((M, N), np.complex128)
-    check(_lib.lib().btk_weights_mainlobe(M, N, float(samplerate), _np_ptr(delays), _np_ptr(wq)))
+    fn = _lib.lib().btk_weights_mainlobe_halfband if half_band_shift else _lib.lib().btk_weights_mainlobe
+    check(fn(M, N, float(samplerate), _np_ptr(delays), _np_ptr(wq)))
     return wq
 
 

@@ -309,6 +309,8 @@ int  btk_allgather_bins(void* nccl_comm, const void* Y_local, void* Y, int S, in
 /* ---- Host-side weight design (double precision, one-off per look direction) -------------
  * BeamformerWeights::calcMainlobe (beamformer.cc:502-565): wq [host] complex128 [M][N].     */
 int  btk_weights_mainlobe(int M, int N, float samplerate, const double* delays, double* wq);
+/* the same with halfBandShift == true (beamformer.cc:515-527): bin k at (k + 0.5) fs / M, partner of bin k is bin M-1-k */
+int  btk_weights_mainlobe_halfband(int M, int N, float samplerate, const double* delays, double* wq);
 /* LCMV quiescent weights with two constraints (target + one null): calcMainlobe2 / calcMainlobeN +
  * calc_null_beamformer_ + calc_inverse_22mat_ (beamformer.cc:181-221, 299-363, 572-721); wq [M][N].   */
 int  btk_weights_mainlobe_2(int M, int N, float samplerate, const double* delaysT, const double* delaysI, double* wq);

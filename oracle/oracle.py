@@ -151,6 +151,33 @@ def calc_mainlobe(M, N, samplerate, delays):
     return wq
 
 
+def calc_mainlobe_halfband(M, N, samplerate, delays):
+    """BeamformerWeights::calcMainlobe with halfBandShift_ == true (beamformer.cc:515-527): bins at (k + 0.5) fs / M, the
+    conjugate partner of bin k is bin M - 1 - k."""
+    delays = np.asarray(delays, np.float64)
+    wq = np.zeros((M, N), np.complex128)
+    fshift = np.float32(0.5)
+    for k in range(M // 2):
+        for c in range(N):
+            val = -2.0 * np.pi * float(fshift + k) * float(np.float32(samplerate)) * delays[c] / M
+            wq[k, c] = np.exp(1j * val) / N
+            wq[M - 1 - k, c] = np.exp(-1j * val) / N
+    return wq
+
+
+def gsc_frames_halfband(X, wq, wl, normalize=False):
+    """SubbandDS::next / SubbandGSC::next with halfBandShift_ == true (beamformer.cc:1113-1128, 1276-1285): every one of the
+    M bins is computed from its own snapshot and weights, nothing is mirrored.  X [T][N][M] (full spectra), wq, wl [M][N]."""
+    T, N, M = X.shape
+    Y = np.zeros((T, M), np.complex128)
+    for k in range(M):
+        w = wq[k] - wl[k]                                            # calc_gsc_output (:1208-1243)
+        if normalize:
+            w = w / (np.linalg.norm(w) * N)
+        Y[:, k] = X[:, :, k] @ np.conj(w)
+    return Y
+
+
 def calc_mainlobe_2(M, N, samplerate, delays_t, delays_i):
     """calcMainlobe2 / calcMainlobeN with NC = 2 (beamformer.cc:572-721): LCMV quiescent weights."""
     dt = np.ascontiguousarray(delays_t, np.float64)

@@ -40,6 +40,9 @@ def test_host_side_entry_points_without_gpu(orc):
     delays = la_delays(ula_positions(N), -1.306379)
     wq = engine.weights_mainlobe(M, N, 16000, delays)
     assert np.max(np.abs(wq - orc.calc_mainlobe(M, N, 16000, delays))) < 1e-15
+    wh = engine.weights_mainlobe(M, N, 16000, delays, half_band_shift=True)          # beamformer.cc:515-527
+    assert np.max(np.abs(wh - orc.calc_mainlobe_halfband(M, N, 16000, delays))) < 1e-15
+    assert np.max(np.abs(wh[M - 1] - np.conj(wh[0]))) == 0.0 and abs(np.angle(wh[0][0] * N) + np.pi * 16000 * delays[0] / M) < 1e-12
     for k in (0, 3, 32, 40):
         B = engine.weights_blocking_matrix(wq[k], 1)
         assert np.max(np.abs(B - orc.blocking_matrix(wq[k], 1))) < 1e-12
