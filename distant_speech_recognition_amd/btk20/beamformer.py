@@ -10,7 +10,7 @@ from .common import j_error, jallocation_error, jdimension_error, jiterator_erro
 from .modulated import OverSampledDFTAnalysisBankPtr, _mirror, _pull_all
 from .stream import VectorComplexFeatureStream, _BlockServedStream, device
 
-__all__ = ["SSPEED", "SnapShotArrayPtr", "SubbandDSPtr", "SubbandGSCPtr", "SubbandGSCRLSPtr", "SubbandMVDRPtr",
+__all__ = ["SSPEED", "SnapShotArrayPtr", "SpectralMatrixArrayPtr", "SubbandDSPtr", "SubbandGSCPtr", "SubbandGSCRLSPtr", "SubbandMVDRPtr",
            "SubbandMVDRGSCPtr", "SubbandDS", "SubbandGSC", "SubbandGSCRLS", "SubbandMVDR", "SubbandMVDRGSC",
            "calc_all_delays"]
 
@@ -45,6 +45,32 @@ class SnapShotArrayPtr(object):
     def zero(self):
         self._samples[:] = 0
         self._snapshots[:] = 0
+
+
+class SpectralMatrixArrayPtr(SnapShotArrayPtr):
+    """SpectralMatrixArray (beamformer/spectralinfoarray.h:43-64, beamformer.cc:97-143): a SnapShotArray that also keeps, per
+    bin, R_k <- mu R_k + (1 - mu) x_k x_k^T -- the outer product WITHOUT conjugation, as the reference writes it (:131-139).
+    Host container like SnapShotArray (the Hermitian covariance the beamformers use is btk_cov_accumulate on the device).
+    FBSpectralMatrixArray (:147-173) indexes the per-channel sample vectors with a bin number and is not mirrored."""
+
+    def __init__(self, fftLn, nChn, forgetFact=0.95):
+        SnapShotArrayPtr.__init__(self, fftLn, nChn)
+        self._mu = float(np.float32(forgetFact))
+        self._matrices = np.zeros((self._fftlen, self._chan_num, self._chan_num), np.complex128)
+
+    def matrix_f(self, idx):
+        return self._matrices[idx]
+
+    getSpecMatrix = matrix_f
+
+    def update(self):
+        SnapShotArrayPtr.update(self)
+        x = self._snapshots
+        self._matrices = self._mu * self._matrices + (1.0 - self._mu) * (x[:, :, None] * x[:, None, :])
+
+    def zero(self):
+        SnapShotArrayPtr.zero(self)
+        self._matrices[:] = 0
 
 
 class _SubbandBeamformer(_BlockServedStream, VectorComplexFeatureStream):

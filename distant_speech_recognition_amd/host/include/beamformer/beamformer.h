@@ -28,6 +28,25 @@ class SnapShotArray : public Countable {
 };
 typedef refcountable_ptr<SnapShotArray> SnapShotArrayPtr;
 
+// SnapShotArray that also keeps, per bin, the recursively averaged outer product of the snapshot with ITSELF -- without
+// conjugation, exactly as the reference writes it: R_k <- mu R_k + (1 - mu) x_k x_k^T (reference
+// beamformer/spectralinfoarray.h:43-64, beamformer.cc:97-143).  Host container like SnapShotArray; the Hermitian covariance the
+// beamformers need comes from btk_cov_accumulate on the device.  FBSpectralMatrixArray (:70-78, :147-173) indexes the
+// per-channel sample vectors with a bin number (out of bounds whenever fftLen > nChan) and is not mirrored.
+class SpectralMatrixArray : public SnapShotArray {
+ public:
+  SpectralMatrixArray(unsigned fftLn, unsigned nChn, float forgetFact = 0.95);
+  virtual ~SpectralMatrixArray();
+  gsl_matrix_complex* matrix_f(unsigned idx) const { return matrices_[idx]; }
+  virtual void update();
+  virtual void zero();
+  gsl_matrix_complex* getSpecMatrix(unsigned idx) { return matrix_f(idx); }
+ protected:
+  const double mu_;
+  gsl_matrix_complex** matrices_;
+};
+typedef refcountable_ptr<SpectralMatrixArray> SpectralMatrixArrayPtr;
+
 // Host-side weights (float64): wq, B, wa, wl, ta  (reference beamformer.h:28-82)
 class BeamformerWeights {
  public:

@@ -337,6 +337,43 @@ void SnapShotArray::update()
     }
 }
 
+// ================================================================================ SpectralMatrixArray
+SpectralMatrixArray::SpectralMatrixArray(unsigned fftLn, unsigned nChn, float forgetFact)
+    : SnapShotArray(fftLn, nChn), mu_((double)forgetFact)
+{
+  matrices_ = new gsl_matrix_complex*[fftLen_];
+  for (unsigned i = 0; i < fftLen_; i++) {
+    matrices_[i] = gsl_matrix_complex_alloc(nChan_, nChan_);
+    memset(matrices_[i]->data, 0, sizeof(double) * 2 * nChan_ * nChan_);
+  }
+}
+SpectralMatrixArray::~SpectralMatrixArray()
+{
+  for (unsigned i = 0; i < fftLen_; i++) gsl_matrix_complex_free(matrices_[i]);
+  delete[] matrices_;
+}
+void SpectralMatrixArray::zero()
+{
+  SnapShotArray::zero();
+  for (unsigned i = 0; i < fftLen_; i++) memset(matrices_[i]->data, 0, sizeof(double) * 2 * nChan_ * nChan_);
+}
+void SpectralMatrixArray::update()
+{
+  SnapShotArray::update();
+  const double alpha = 1.0 - mu_;
+  for (unsigned k = 0; k < fftLen_; k++) {
+    const double* x = snapshots_[k]->data;
+    double* R = matrices_[k]->data;
+    for (unsigned i = 0; i < nChan_; i++)
+      for (unsigned j = 0; j < nChan_; j++) {
+        const double pr = x[2 * i] * x[2 * j] - x[2 * i + 1] * x[2 * j + 1];          // x_i x_j, no conjugate (beamformer.cc:131-139)
+        const double pi = x[2 * i] * x[2 * j + 1] + x[2 * i + 1] * x[2 * j];
+        R[2 * (i * nChan_ + j)] = mu_ * R[2 * (i * nChan_ + j)] + alpha * pr;
+        R[2 * (i * nChan_ + j) + 1] = mu_ * R[2 * (i * nChan_ + j) + 1] + alpha * pi;
+      }
+  }
+}
+
 // ================================================================================ BeamformerWeights
 BeamformerWeights::BeamformerWeights(unsigned fftLen, unsigned chanN, bool, unsigned NC)
     : wq((size_t)fftLen * chanN), wl((size_t)fftLen * chanN), ta((size_t)fftLen * chanN),
