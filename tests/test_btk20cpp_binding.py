@@ -1,0 +1,133 @@
+"""The pybind11 binding of the C++ node layer (distant_speech_recognition_amd.btk20cpp): the reference's SWIG semantics --
+numpy views of the node's vector (include/vector.i:290-305), iterator protocol with StopIteration at jiterator_error,
+Python objects as source nodes (stream/pyStream.h:25-168), the j_error family -- and, on the GPU, the reference's D&S +
+Zelinski flow (unit_test/test_online_beamforming.py:51-116) through C++ nodes only."""
+import wave
+
+import numpy as np
+import pytest
+
+M, m, r, D, FS = 256, 4, 1, 128, 16000
+MPOS = [[-113.0, 0.0, 2.0], [36.0, 0.0, 2.0], [76.0, 0.0, 2.0], [113.0, 0.0, 2.0]]      # confs/ds.json:2-5
+AZIMUTH = -1.306379
+
+
+class _Source(object):
+    """what the reference's Python algorithm classes look like to a C++ node: size(), __iter__, next(), reset()"""
+
+    def __init__(self, frames):
+        self.frames, self.i, self.resets = frames, 0, 0
+
+    def size(self):
+        return self.frames.shape[1]
+
+    def __iter__(self):
+        return self
+
+    def next(self):
+        if self.i >= len(self.frames):
+            raise StopIteration
+        self.i += 1
+        return self.frames[self.i - 1]
+
+    __next__ = next
+
+    def reset(self):
+        self.i = 0
+        self.resets += 1
+
+
+def test_python_objects_source_cpp_nodes_and_views_are_zero_copy():
+    from distant_speech_recognition_amd import btk20cpp as B
+    fr = np.arange(12).reshape(3, 4) + 1j * np.arange(12).reshape(3, 4)[::-1]
+    src = _Source(fr)
+    s = B.PyVectorComplexFeatureStreamPtr(src)
+    assert s.size() == 4 and s.frame_no() == -1
+    a = s.next()
+    assert np.array_equal(a, fr[0]) and not a.flags.owndata and a.base is s          # a view of the node's vector_
+    assert np.shares_memory(a, s.next(0)) and s.frame_no() == 0                      # same frame -> same buffer, no pull
+    assert np.array_equal(s.current(), fr[0])
+    frames = [np.array(v) for v in s]                                                # __iter__ = reset() + self
+    assert src.resets == 1 and len(frames) == 3 and np.array_equal(frames[2], fr[2])
+    with pytest.raises(StopIteration):
+        s.next()
+    assert s.is_end()
+    # float streams and the block reader
+    f = B.PyVectorFloatFeatureStreamPtr(_Source(np.arange(6, dtype=np.float32).reshape(2, 3)))
+    assert [list(np.array(v)) for v in f] == [[0.0, 1.0, 2.0], [3.0, 4.0, 5.0]]
+    sf = B.SampleFeaturePtr(block_len=4, shift_len=4, pad_zeros=True)
+    sf.set_samples(np.arange(10, dtype=np.float32))
+    assert [list(np.array(v)) for v in sf] == [[0, 1, 2, 3], [4, 5, 6, 7], [8, 9, 0, 0]]
+    # a source that returns too short a vector is a dimension error, not a crash
+    bad = B.PyVectorComplexFeatureStreamPtr(_Source(np.zeros((1, 4), np.complex128)))
+    bad_src = _Source(np.zeros((1, 2), np.complex128)); bad_src.size = lambda: 4
+    with pytest.raises(B.jdimension_error):
+        B.PyVectorComplexFeatureStreamPtr(bad_src).next()
+    assert bad.size() == 4
+
+
+def test_exception_family_and_host_side_methods():
+    from distant_speech_recognition_amd import btk20cpp as B
+    from distant_speech_recognition_amd import engine
+    with pytest.raises(B.jallocation_error) as e:
+        B.SubbandMVDRPtr(fftlen=64, half_band_shift=True)                            # beamformer.cc:2283-2285
+    assert isinstance(e.value, B.j_error) and "halfBandShift" in str(e.value)
+    ds = B.SubbandDSPtr(fftlen=64)
+    with pytest.raises(B.j_error):
+        ds.next()                                                                    # no weights yet
+    # weights are host code: the node's quiescent vectors are the C-ABI's
+    chans = [B.PyVectorComplexFeatureStreamPtr(_Source(np.zeros((1, 64), np.complex128))) for _ in range(4)]
+    for c in chans:
+        ds.set_channel(c)
+    assert ds.chan_num() == 4 and ds.fftlen() == 64
+    delays = np.array([0.0, 1e-4, 2.5e-4, -1e-4])
+    ds.calc_array_manifold_vectors(16000.0, delays)
+    wq = engine.weights_mainlobe(64, 4, 16000.0, delays)
+    assert np.max(np.abs(np.stack([ds.get_weights(k) for k in range(64)]) - wq)) < 1e-15
+    arr = B.SpectralMatrixArrayPtr(8, 3, 0.9)
+    x = np.arange(8) + 1j
+    for c in range(3):
+        arr.set_samples(x * (c + 1), c)
+    arr.update()
+    assert np.allclose(arr.matrix_f(2), (1 - float(np.float32(0.9))) * np.outer(x[2] * np.arange(1, 4), x[2] * np.arange(1, 4)))
+
+
+@pytest.mark.gpu
+def test_ds_zelinski_flow_through_cpp_nodes(orc, dev, proto256, kinect_pcm, tmp_path):
+    from distant_speech_recognition_amd import btk20cpp as B
+    from distant_speech_recognition_amd.pybeamformer import calc_delays
+    h, g = proto256
+    afbs = []
+    for c in range(4):
+        p = str(tmp_path / ("c%d.wav" % c))
+        w = wave.open(p, "wb")
+        w.setnchannels(1); w.setsampwidth(2); w.setframerate(FS)
+        w.writeframes(kinect_pcm[c][:40000].astype(np.int16).tobytes())
+        w.close()
+        sf = B.SampleFeaturePtr(block_len=D, shift_len=D, pad_zeros=True)
+        sf.read(p, FS)
+        afbs.append(B.OverSampledDFTAnalysisBankPtr(sf, prototype=h, M=M, m=m, r=r, delay_compensation_type=2))
+    bf = B.SubbandGSCPtr(fftlen=M, half_band_shift=False)
+    for a in afbs:
+        bf.set_channel(a)
+    delays = calc_delays("linear", MPOS, [AZIMUTH, None, None])
+    bf.calc_gsc_weights(FS, delays)
+    pf = B.ZelinskiPostFilterPtr(bf, M, 0.7, 2)                                        # confs/ds_and_zelinski.json
+    pf.set_beamformer(bf)
+    sfb = B.OverSampledDFTSynthesisBankPtr(pf, prototype=g, M=M, m=m, r=r, delay_compensation_type=2)
+    out = np.concatenate([np.array(buf) for buf in sfb])
+    X = np.stack([orc.analysis(h, M, m, r, 2, kinect_pcm[c][:40000]) for c in range(4)], axis=1)
+    wq = orc.calc_mainlobe(M, 4, FS, delays)
+    Yf, _ = orc.zelinski_frames(X, orc.gsc_frames(X, wq, np.zeros_like(wq)), wq, 0.7, 2)
+    ref = orc.synthesis(g, M, m, r, 2, Yf)
+    assert out.shape == ref.shape == (313 * D,)
+    assert np.max(np.abs(out - ref)) < 0.5                                             # <= 0.5 LSB at int16 scale
+    with pytest.raises(StopIteration):
+        sfb.next()
+    # a Python object feeding a C++ node: the oracle's beamformed frames through the C++ synthesis bank
+    Yb = orc.gsc_frames(X, wq, np.zeros_like(wq))
+    py_src = B.PyVectorComplexFeatureStreamPtr(_Source(Yb))
+    sfb2 = B.OverSampledDFTSynthesisBankPtr(py_src, prototype=g, M=M, m=m, r=r, delay_compensation_type=2)
+    out2 = np.concatenate([np.array(buf) for buf in sfb2])
+    ref2 = orc.synthesis(g, M, m, r, 2, Yb)
+    assert out2.shape == ref2.shape and np.max(np.abs(out2 - ref2)) < 0.5
