@@ -21,6 +21,7 @@
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int WT_ = 32;                // frames per LDS tile
 
 struct WpeGeom { int K, C, L, lowerN, lower_bw, upper_bw; long T_stride, T; };
@@ -179,6 +180,104 @@ void wpe_herk_kernel(const float2* __restrict__ X, const float* __restrict__ Win
   }
 }
 
+// The same HERK with ONE wavefront per workgroup and one 32 x 32 block of the lower triangle per wavefront.  In the 64 x 64-tile form
+// a quarter of the wavefronts own a block the solver never reads (above the diagonal, or beyond P) and idle on their SIMD for the
+// whole launch (P = 264: 15 of 60; the MFMA pipes measured 51 % busy); here every launched wavefront multiplies.  The staging is
+// per wavefront (its two 32-row spans: <= 31/L + 2 channels each), the tile loop needs no workgroup barrier.
+template <int CB>
+__global__ __launch_bounds__(64)
+void wpe_herk32_kernel(const float2* __restrict__ X, const float* __restrict__ Winv, WpeGeom g, float2* __restrict__ R, int nspan)
+{
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int SPW = WT_ + g.L - 1;                                   // samples per channel span
+  float2* spanI = reinterpret_cast<float2*>(smem);                 // [nspan][SPW]
+  float2* spanJ = spanI + nspan * SPW;
+  float* wrow = reinterpret_cast<float*>(spanJ + nspan * SPW);     // [CB][WT_]
+  const int lane = threadIdx.x;
+  const int k = blockIdx.y;
+  if (!bin_active(g, k)) return;
+  const int ncg = g.C / CB;
+  const int s = blockIdx.z / ncg, c0 = (blockIdx.z % ncg) * CB;
+  const int P = g.C * g.L;
+  int bi = 0, rem = blockIdx.x;                                    // blockIdx.x -> (bi >= bj)
+  while (rem > bi) { rem -= bi + 1; bi++; }
+  const int bj = rem;
+  const float2* Xk = X + ((long)s * g.K + k) * g.C * g.T_stride;
+  f32x16 rr[CB], ri[CB];
+#pragma unroll
+  for (int cb = 0; cb < CB; cb++) { rr[cb] = f32x16{0}; ri[cb] = f32x16{0}; }
+  const int li = lane & 31, lk = lane >> 5;
+  const int chI0 = (bi * 32) / g.L, chJ0 = (bj * 32) / g.L;
+  const int pI = bi * 32 + li, pJ = bj * 32 + li;
+  const bool vI = pI < P, vJ = pJ < P;
+  const int offI = vI ? (pI / g.L - chI0) * SPW + (g.L - 1 - pI % g.L) : 0;
+  const int offJ = vJ ? (pJ / g.L - chJ0) * SPW + (g.L - 1 - pJ % g.L) : 0;
+  constexpr int WPF = 12;                                           // span elements a lane prefetches (L >= 6 at WT_ = 32)
+  const int nelem = 2 * nspan * SPW;
+  const bool use_pf = nelem <= WPF * 64;
+  float2 pf[WPF];
+  float wpf[(CB * WT_ + 63) / 64];
+  auto span_load = [&](int idx, long t0) -> float2 {
+    const int which = idx / (nspan * SPW), e = idx % (nspan * SPW);
+    const int ch = (which ? chJ0 : chI0) + e / SPW;
+    const long i = t0 - g.lowerN - (g.L - 1) + e % SPW;          // span element j holds sample i (zero outside [0, T))
+    return (ch < g.C && i >= 0 && i < g.T) ? Xk[(long)ch * g.T_stride + i] : make_float2(0.f, 0.f);
+  };
+  auto weight_load = [&](int idx, long t0) -> float {
+    const int cb = idx / WT_, tt = idx % WT_;
+    const long t = t0 + tt;
+    const float* w = Winv + (((long)s * g.C + c0 + cb) * g.K + k) * g.T_stride;
+    return (t < g.T && t >= g.lowerN) ? w[t] : 0.f;
+  };
+  auto prefetch = [&](long t0) {
+#pragma unroll
+    for (int q = 0; q < WPF; q++) { const int idx = lane + q * 64; if (idx < nelem) pf[q] = span_load(idx, t0); }
+#pragma unroll
+    for (int q = 0; q < (CB * WT_ + 63) / 64; q++) { const int idx = lane + q * 64; if (idx < CB * WT_) wpf[q] = weight_load(idx, t0); }
+  };
+  if (use_pf) prefetch(0);
+  for (long t0 = 0; t0 < g.T; t0 += WT_) {
+    __syncthreads();                                               // (one wavefront: orders the LDS reads of the last tile before the writes)
+    if (use_pf) {
+#pragma unroll
+      for (int q = 0; q < WPF; q++) { const int idx = lane + q * 64; if (idx < nelem) spanI[idx] = pf[q]; }
+#pragma unroll
+      for (int q = 0; q < (CB * WT_ + 63) / 64; q++) { const int idx = lane + q * 64; if (idx < CB * WT_) wrow[idx] = wpf[q]; }
+    } else {
+      for (int idx = lane; idx < nelem; idx += 64) spanI[idx] = span_load(idx, t0);
+      for (int idx = lane; idx < CB * WT_; idx += 64) wrow[idx] = weight_load(idx, t0);
+    }
+    __syncthreads();
+    if (use_pf && t0 + WT_ < g.T) prefetch(t0 + WT_);
+#pragma unroll 2
+    for (int kk = 0; kk < WT_; kk += 2) {
+      float2 a = spanI[offI + kk + lk];
+      float2 b = spanJ[offJ + kk + lk];
+      if (!vI) a = make_float2(0.f, 0.f);
+      if (!vJ) b = make_float2(0.f, 0.f);
+#pragma unroll
+      for (int cb = 0; cb < CB; cb++) {
+        const float wv = wrow[cb * WT_ + kk + lk];
+        const float bx = b.x * wv, by = b.y * wv;
+        rr[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, bx, rr[cb], 0, 0, 0);
+        rr[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, by, rr[cb], 0, 0, 0);
+        ri[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, bx, ri[cb], 0, 0, 0);
+        ri[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(-a.x, by, ri[cb], 0, 0, 0);
+      }
+    }
+  }
+#pragma unroll
+  for (int cb = 0; cb < CB; cb++) {
+    float2* Rk = R + (((long)s * g.C + c0 + cb) * g.K + k) * (long)P * P;
+#pragma unroll
+    for (int reg = 0; reg < 16; reg++) {
+      const int row = bi * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+      const int col = bj * 32 + (lane & 31);
+      if (row < P && col < P) Rk[(long)row * P + col] = make_float2(rr[cb][reg], ri[cb][reg]);
+    }
+  }
+}
+
 // r_c[p] = sum_t conj(y_c(t)) ybar_p(t) / theta_c(t)
 __global__ __launch_bounds__(256)
 void wpe_rvec_kernel(const float2* __restrict__ X, const float* __restrict__ Winv, WpeGeom g, float2* __restrict__ rvec)
@@ -228,11 +327,22 @@ void wpe_solve_kernel(float2* __restrict__ R, const float2* __restrict__ rvec, W
   float2* rhs = reinterpret_cast<float2*>(smem);                   // [Ppad]
   float* red = reinterpret_cast<float*>(rhs + Ppad);               // [512]
   float2* panel = reinterpret_cast<float2*>(red + 512);            // [P][CH_LD]
-  float2* chunk = panel + (long)P * CH_LD;                         // [P][CH_LD]
   float2* mat = R + ((long)sc * g.K + k) * (long)P * P;
   const int s = sc / g.C, c = sc % g.C;
   float2* gout = G + (((long)s * g.C + c) * g.K + k) * (long)P;
-  for (int p = tid; p < P; p += 256) rhs[p] = rvec[((long)sc * g.K + k) * P + p];
+  if (rvec) {
+    for (int p = tid; p < P; p += 256) rhs[p] = rvec[((long)sc * g.K + k) * P + p];
+  } else {
+    // lowerN == 0: y_c(t) is itself a row of the lag matrix (channel c, lag 0), so r_c[p] = sum_t ybar_p conj(y_c) / theta_c is column
+    // q = c L of the matrix the HERK just produced (lower triangle stored: R[p][q] for p >= q, conj(R[q][p]) above) -- read
+    // before the diagonal is biased and loaded
+    const int q = c * g.L;
+    for (int p = tid; p < P; p += 256) {
+      const float2 v = (p >= q) ? mat[(long)p * P + q] : mat[(long)q * P + p];
+      rhs[p] = (p >= q) ? v : make_float2(v.x, -v.y);
+    }
+    __syncthreads();
+  }
   // diagonal bias (dereverberation.cc:574-577) then load_R_ (:648-663)
   float mx = 0.f;
   for (int p = tid; p < P; p += 256) {
@@ -251,6 +361,8 @@ void wpe_solve_kernel(float2* __restrict__ R, const float2* __restrict__ rvec, W
   __syncthreads();
 
   bool bad = false;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int mi = lane & 15, mk = lane >> 4;                       // MFMA operand coordinates of this lane
   for (int jb = 0; jb < P && !bad; jb += CH_NB) {
     const int nb = (P - jb < CH_NB) ? P - jb : CH_NB;
     const int rows = P - jb;
@@ -259,67 +371,99 @@ void wpe_solve_kernel(float2* __restrict__ R, const float2* __restrict__ rvec, W
       const int r = idx / CH_NB, cc = idx % CH_NB;
       panel[r * CH_LD + cc] = (cc < nb) ? mat[(long)(jb + r) * P + jb + cc] : make_float2(0.f, 0.f);
     }
-    // ---- left-looking update: panel[r][cc] -= sum_{q<jb} L[jb+r][q] conj(L[jb+cc][q]), chunks of CH_NB previous columns
-    for (int r0 = 0; r0 < rows; r0 += 256) {
-      const int r = r0 + tid;
-      float2 acc[CH_NB];
+    __syncthreads();
+    // ---- left-looking update on the matrix cores: panel[r][cc] -= sum_{q<jb} L[jb+r][q] conj(L[jb+cc][q]).
+    //      A wavefront owns 16-row blocks; v_mfma_f32_16x16x4_f32 (exact fp32) takes A[i][k] from lane i + 16 k and B[k][j] from
+    //      lane j + 16 k, so a lane loads four consecutive columns of its row (q0 + 4 mk ..) for both operands and the four
+    //      k-steps of a 16-column chunk pair lane group mk with column q0 + 4 mk + step -- any pairing sums the same products.
+    //      Re(a conj b) = ar br + ai bi, Im = ai br - ar bi: four MFMAs per step.
+    if (jb > 0) {
+      const int nrb = (rows + 15) / 16;
+      const float2* brow = mat + (long)(jb + mi) * P;               // the panel's own rows jb + j (valid while j < nb)
+      const bool bok = mi < nb;
+      for (int rb = wave; rb < nrb; rb += 4) {
+        const int r = rb * 16 + mi;
+        const bool aok = r < rows;
+        const float2* arow = mat + (long)(jb + (aok ? r : 0)) * P;
+        f32x4 cr = {0.f, 0.f, 0.f, 0.f}, ci = {0.f, 0.f, 0.f, 0.f};
+        float2 av[4], bv[4], an[4], bn[4];
+        auto ld = [&](float2 (&a)[4], float2 (&b)[4], int q0) {
 #pragma unroll
-      for (int cc = 0; cc < CH_NB; cc++) acc[cc] = make_float2(0.f, 0.f);
-      for (int q0 = 0; q0 < jb; q0 += CH_NB) {
-        __syncthreads();
-        for (int idx = tid; idx < rows * CH_NB; idx += 256) {     // chunk <- L[jb.., q0..q0+CH_NB)  (64-byte row pieces)
-          const int rr = idx / CH_NB, qq = idx % CH_NB;
-          chunk[rr * CH_LD + qq] = mat[(long)(jb + rr) * P + q0 + qq];
-        }
-        __syncthreads();
-        if (r < rows) {
-#pragma unroll 4
-          for (int qq = 0; qq < CH_NB; qq++) {
-            const float2 a = chunk[r * CH_LD + qq];
-#pragma unroll
-            for (int cc = 0; cc < CH_NB; cc++) {
-              const float2 b = chunk[cc * CH_LD + qq];              // rows jb..jb+nb of the same chunk (broadcast)
-              acc[cc].x = fmaf(a.x, b.x, fmaf(a.y, b.y, acc[cc].x));
-              acc[cc].y = fmaf(a.y, b.x, fmaf(-a.x, b.y, acc[cc].y));
-            }
+          for (int e = 0; e < 4; e++) {
+            a[e] = aok ? arow[q0 + 4 * mk + e] : make_float2(0.f, 0.f);
+            b[e] = bok ? brow[q0 + 4 * mk + e] : make_float2(0.f, 0.f);
           }
-        }
-      }
-      __syncthreads();
-      if (r < rows) {
+        };
+        ld(av, bv, 0);
+        for (int q0 = 0; q0 < jb; q0 += 16) {
+          if (q0 + 16 < jb) ld(an, bn, q0 + 16);                   // the next chunk's loads fly under this chunk's MFMAs
 #pragma unroll
-        for (int cc = 0; cc < CH_NB; cc++) {
-          float2 v = panel[r * CH_LD + cc];
-          panel[r * CH_LD + cc] = make_float2(v.x - acc[cc].x, v.y - acc[cc].y);
+          for (int e = 0; e < 4; e++) {
+            cr = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e].x, bv[e].x, cr, 0, 0, 0);
+            cr = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e].y, bv[e].y, cr, 0, 0, 0);
+            ci = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e].y, bv[e].x, ci, 0, 0, 0);
+            ci = __builtin_amdgcn_mfma_f32_16x16x4f32(-av[e].x, bv[e].y, ci, 0, 0, 0);
+          }
+#pragma unroll
+          for (int e = 0; e < 4; e++) { av[e] = an[e]; bv[e] = bn[e]; }
+        }
+        // D[i][j]: register v of lane l holds row 4 (l / 16) + v, column l % 16
+#pragma unroll
+        for (int v = 0; v < 4; v++) {
+          const int rr = rb * 16 + 4 * mk + v;
+          if (rr < rows) {
+            float2 t = panel[rr * CH_LD + mi];
+            panel[rr * CH_LD + mi] = make_float2(t.x - cr[v], t.y - ci[v]);
+          }
         }
       }
     }
     __syncthreads();
-    // ---- factor the panel in LDS
-    for (int cc = 0; cc < nb; cc++) {
-      const float piv = panel[cc * CH_LD + cc].x;                  // final value: same for every thread
-      if (!(piv > 0.f)) { bad = true; break; }
-      const float d = sqrtf(piv), inv = 1.0f / d;
-      __syncthreads();
-      for (int r = tid; r < rows; r += 256) {
-        if (r == cc) panel[r * CH_LD + cc] = make_float2(d, 0.f);
-        else if (r > cc) { const float2 v = panel[r * CH_LD + cc]; panel[r * CH_LD + cc] = make_float2(v.x * inv, v.y * inv); }
-      }
-      __syncthreads();
-      for (int r = tid; r < rows; r += 256) {
-        if (r > cc) {
+    // ---- the 16 x 16 diagonal block: one wavefront, column by column (LDS accesses of one wavefront stay in program order)
+    if (wave == 0) {
+      int okflag = 1;
+      for (int cc = 0; cc < nb; cc++) {
+        const float piv = panel[cc * CH_LD + cc].x;
+        if (!(piv > 0.f)) { okflag = 0; break; }
+        const float d = sqrtf(piv), inv = 1.0f / d;
+        if (lane < nb && lane > cc) { const float2 v = panel[lane * CH_LD + cc]; panel[lane * CH_LD + cc] = make_float2(v.x * inv, v.y * inv); }
+        if (lane == cc) panel[cc * CH_LD + cc] = make_float2(d, 0.f);
+        __builtin_amdgcn_wave_barrier();
+        // trailing update of the block: rows r > cc, columns cc < c2 <= r; lane -> (r = lane % 16, c2 = cc + 1 + lane / 16 + 4 u)
+        const int r = lane & 15;
+        if (r > cc && r < nb) {
           const float2 a = panel[r * CH_LD + cc];
-          for (int c2 = cc + 1; c2 < nb; c2++) {
-            if (c2 <= r) {
-              const float2 t = cmul_conj_b(a, panel[c2 * CH_LD + cc]);
-              float2 v = panel[r * CH_LD + c2];
-              panel[r * CH_LD + c2] = make_float2(v.x - t.x, v.y - t.y);
-            }
+          for (int c2 = cc + 1 + (lane >> 4); c2 <= r; c2 += 4) {
+            const float2 t = cmul_conj_b(a, panel[c2 * CH_LD + cc]);
+            const float2 v = panel[r * CH_LD + c2];
+            panel[r * CH_LD + c2] = make_float2(v.x - t.x, v.y - t.y);
           }
         }
+        __builtin_amdgcn_wave_barrier();
       }
-      __syncthreads();
+      if (lane == 0) red[0] = okflag ? 1.f : 0.f;
     }
+    __syncthreads();
+    if (red[0] == 0.f) { bad = true; break; }
+    // ---- rows below the block: x L11^H = a, one thread per row, no barriers (L11 entries are LDS broadcasts)
+    for (int r = nb + tid; r < rows; r += 256) {
+      float2 x[CH_NB];
+#pragma unroll
+      for (int cc = 0; cc < CH_NB; cc++) {
+        if (cc < nb) {
+          float2 v = panel[r * CH_LD + cc];
+#pragma unroll
+          for (int c2 = 0; c2 < cc; c2++) {
+            const float2 t = cmul_conj_b(x[c2], panel[cc * CH_LD + c2]);
+            v.x -= t.x; v.y -= t.y;
+          }
+          const float inv = 1.0f / panel[cc * CH_LD + cc].x;
+          x[cc] = make_float2(v.x * inv, v.y * inv);
+          panel[r * CH_LD + cc] = x[cc];
+        }
+      }
+    }
+    __syncthreads();
     if (bad) break;
     // ---- write the factored panel back, forward substitution for its columns: L y = r
     for (int idx = tid; idx < rows * CH_NB; idx += 256) {
@@ -442,7 +586,7 @@ int btk_wpe_estimate(const void* X, int S, int K, int C, long T_stride, long T, 
   const int nspan = 63 / g.L + 2;                                  // channels a 64-row tile can touch
   const size_t lds_herk = sizeof(float2) * 2 * (size_t)nspan * (WT_ + g.L - 1) + sizeof(float) * 4 * WT_;
   const float load_factor = (float)pow(10.0, load_db / 10.0);
-  const size_t lds_solve = sizeof(float2) * ((P + 1) & ~1L) + sizeof(float) * 512 + sizeof(float2) * 2 * (size_t)P * CH_LD;
+  const size_t lds_solve = sizeof(float2) * ((P + 1) & ~1L) + sizeof(float) * 512 + sizeof(float2) * (size_t)P * CH_LD;
   if (lds_solve > 160 * 1024)
     return btk_set_error(BTK_ERR_DIMENSION, "btk_wpe_estimate: C*(upperN-lowerN+1) = %ld taps exceed the LDS-resident solver (max ~560)", P);
   if (lds_solve > 64 * 1024)
@@ -452,15 +596,26 @@ int btk_wpe_estimate(const void* X, int S, int K, int C, long T_stride, long T, 
                        Xp, Gp, g, 0, Winv, static_cast<float2*>(nullptr));
     const int skip = btk_switches().wpe_noskip ? 0 : 1;            // A/B switch of profiles/ (btk_internal.h)
     const dim3 hgrid1((unsigned)(ntile * (ntile + 1) / 2), (unsigned)K, (unsigned)(S * C));
-    if (C % 4 == 0)
+    const int nb32 = (int)((P + 31) / 32);
+    const unsigned nblk = (unsigned)(nb32 * (nb32 + 1) / 2);          // 32 x 32 blocks of the lower triangle
+    const int nspan32 = 31 / g.L + 2;
+    const size_t lds32 = sizeof(float2) * 2 * (size_t)nspan32 * (WT_ + g.L - 1) + sizeof(float) * 4 * WT_;
+    if (skip && C % 4 == 0)
+      hipLaunchKernelGGL(wpe_herk32_kernel<4>, dim3(nblk, (unsigned)K, (unsigned)(S * C / 4)), dim3(64), lds32, st, Xp, Winv, g, R, nspan32);
+    else if (skip && C % 2 == 0)
+      hipLaunchKernelGGL(wpe_herk32_kernel<2>, dim3(nblk, (unsigned)K, (unsigned)(S * C / 2)), dim3(64), lds32, st, Xp, Winv, g, R, nspan32);
+    else if (skip)
+      hipLaunchKernelGGL(wpe_herk32_kernel<1>, dim3(nblk, (unsigned)K, (unsigned)(S * C)), dim3(64), lds32, st, Xp, Winv, g, R, nspan32);
+    else if (C % 4 == 0)
       hipLaunchKernelGGL(wpe_herk_kernel<4>, dim3(hgrid1.x, hgrid1.y, (unsigned)(S * C / 4)), dim3(256), lds_herk, st, Xp, Winv, g, ntile, R, skip, nspan);
     else if (C % 2 == 0)
       hipLaunchKernelGGL(wpe_herk_kernel<2>, dim3(hgrid1.x, hgrid1.y, (unsigned)(S * C / 2)), dim3(256), lds_herk, st, Xp, Winv, g, ntile, R, skip, nspan);
     else
       hipLaunchKernelGGL(wpe_herk_kernel<1>, hgrid1, dim3(256), lds_herk, st, Xp, Winv, g, ntile, R, skip, nspan);
-    hipLaunchKernelGGL(wpe_rvec_kernel, dim3((unsigned)K, (unsigned)(S * C)), dim3(256), 0, st, Xp, Winv, g, rvec);
+    const bool rvec_from_R = (lowerN == 0) && skip;            // the lag-0 row of the target channel is y_c itself
+    if (!rvec_from_R) hipLaunchKernelGGL(wpe_rvec_kernel, dim3((unsigned)K, (unsigned)(S * C)), dim3(256), 0, st, Xp, Winv, g, rvec);
     hipLaunchKernelGGL(wpe_solve_kernel, dim3((unsigned)K, (unsigned)(S * C)), dim3(256), lds_solve, st,
-                       R, rvec, g, load_factor, (float)diagonal_bias, Gp, fail_count);
+                       R, rvec_from_R ? static_cast<const float2*>(nullptr) : rvec, g, load_factor, (float)diagonal_bias, Gp, fail_count);
     BTK_HIP_CHECK(hipGetLastError());
   }
   return BTK_OK;
