@@ -313,10 +313,13 @@ constexpr int CH_NB = 16;              // panel width
 constexpr int CH_LD = CH_NB + 1;       // padded row (float2): conflict-free row-per-lane access
 
 __device__ __forceinline__ float2 cmul_conj_b(float2 a, float2 b) { return make_float2(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y); }
+// value of lane `l` (compile-time) broadcast to the wavefront through an SGPR
+__device__ __forceinline__ float lane_value(float x, int l) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), l)); }
 
 __global__ __launch_bounds__(256)
 void wpe_solve_kernel(float2* __restrict__ R, const float2* __restrict__ rvec, WpeGeom g, float load_factor,
-                      float diagonal_bias, float2* __restrict__ G, int* __restrict__ fail_count)
+                      float diagonal_bias, float2* __restrict__ G, int* __restrict__ fail_count,
+                      unsigned long long* __restrict__ phase_cycles /* BTK_WPE_TIMING diagnostics, else null */)
 {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int k = blockIdx.x, sc = blockIdx.y;
@@ -362,6 +365,12 @@ void wpe_solve_kernel(float2* __restrict__ R, const float2* __restrict__ rvec, W
 
   bool bad = false;
   const int lane = tid & 63, wave = tid >> 6;
+  // the single-wavefront phases rotate over the four wavefronts (= SIMDs) with the panel and the workgroup: with every workgroup
+  // using its wavefront 0, the four resident workgroups of a CU queue up on one SIMD while three idle
+  const int wrot = blockIdx.x + blockIdx.y;
+  long long tm[7] = {0, 0, 0, 0, 0, 0, 0};
+  long long tlast = phase_cycles ? clock64() : 0;
+  auto mark = [&](int i) { if (phase_cycles) { const long long c = clock64(); tm[i] += c - tlast; tlast = c; } };
   const int mi = lane & 15, mk = lane >> 4;                       // MFMA operand coordinates of this lane
   for (int jb = 0; jb < P && !bad; jb += CH_NB) {
     const int nb = (P - jb < CH_NB) ? P - jb : CH_NB;
@@ -372,6 +381,7 @@ void wpe_solve_kernel(float2* __restrict__ R, const float2* __restrict__ rvec, W
       panel[r * CH_LD + cc] = (cc < nb) ? mat[(long)(jb + r) * P + jb + cc] : make_float2(0.f, 0.f);
     }
     __syncthreads();
+    mark(0);                                                         // panel load
     // ---- left-looking update on the matrix cores: panel[r][cc] -= sum_{q<jb} L[jb+r][q] conj(L[jb+cc][q]).
     //      A wavefront owns 16-row blocks; v_mfma_f32_16x16x4_f32 (exact fp32) takes A[i][k] from lane i + 16 k and B[k][j] from
     //      lane j + 16 k, so a lane loads four consecutive columns of its row (q0 + 4 mk ..) for both operands and the four
@@ -419,32 +429,44 @@ void wpe_solve_kernel(float2* __restrict__ R, const float2* __restrict__ rvec, W
       }
     }
     __syncthreads();
+    mark(1);                                                         // MFMA update
     // ---- the 16 x 16 diagonal block: one wavefront, column by column (LDS accesses of one wavefront stay in program order)
-    if (wave == 0) {
+    if (wave == ((wrot + (jb >> 4)) & 3)) {
+      // lane r < 16 holds row r of the block in registers; the pivot and the column entries L[c2][cc] travel through SGPRs
+      // (v_readlane): the serial chain is register arithmetic, not LDS round trips (19 k -> a few k cycles per panel)
       int okflag = 1;
-      for (int cc = 0; cc < nb; cc++) {
-        const float piv = panel[cc * CH_LD + cc].x;
-        if (!(piv > 0.f)) { okflag = 0; break; }
-        const float d = sqrtf(piv), inv = 1.0f / d;
-        if (lane < nb && lane > cc) { const float2 v = panel[lane * CH_LD + cc]; panel[lane * CH_LD + cc] = make_float2(v.x * inv, v.y * inv); }
-        if (lane == cc) panel[cc * CH_LD + cc] = make_float2(d, 0.f);
-        __builtin_amdgcn_wave_barrier();
-        // trailing update of the block: rows r > cc, columns cc < c2 <= r; lane -> (r = lane % 16, c2 = cc + 1 + lane / 16 + 4 u)
-        const int r = lane & 15;
-        if (r > cc && r < nb) {
-          const float2 a = panel[r * CH_LD + cc];
-          for (int c2 = cc + 1 + (lane >> 4); c2 <= r; c2 += 4) {
-            const float2 t = cmul_conj_b(a, panel[c2 * CH_LD + cc]);
-            const float2 v = panel[r * CH_LD + c2];
-            panel[r * CH_LD + c2] = make_float2(v.x - t.x, v.y - t.y);
+      const int r = lane & 15;
+      float2 row[CH_NB];
+#pragma unroll
+      for (int c2 = 0; c2 < CH_NB; c2++) row[c2] = panel[r * CH_LD + c2];
+#pragma unroll
+      for (int cc = 0; cc < CH_NB; cc++) {
+        if (cc < nb && okflag) {
+          const float piv = lane_value(row[cc].x, cc);
+          if (!(piv > 0.f)) { okflag = 0; }
+          else {
+            const float d = sqrtf(piv), inv = 1.0f / d;
+            if (r == cc) row[cc] = make_float2(d, 0.f);
+            else if (r > cc) row[cc] = make_float2(row[cc].x * inv, row[cc].y * inv);
+#pragma unroll
+            for (int c2 = cc + 1; c2 < CH_NB; c2++) {
+              if (c2 < nb) {
+                const float2 lc = make_float2(lane_value(row[cc].x, c2), lane_value(row[cc].y, c2));    // L[c2][cc]
+                if (r >= c2) { const float2 t = cmul_conj_b(row[cc], lc); row[c2].x -= t.x; row[c2].y -= t.y; }
+              }
+            }
           }
         }
-        __builtin_amdgcn_wave_barrier();
+      }
+      if (lane < nb) {
+#pragma unroll
+        for (int c2 = 0; c2 < CH_NB; c2++) panel[lane * CH_LD + c2] = row[c2];
       }
       if (lane == 0) red[0] = okflag ? 1.f : 0.f;
     }
     __syncthreads();
     if (red[0] == 0.f) { bad = true; break; }
+    mark(2);                                                         // diagonal block
     // ---- rows below the block: x L11^H = a, one thread per row, no barriers (L11 entries are LDS broadcasts)
     for (int r = nb + tid; r < rows; r += 256) {
       float2 x[CH_NB];
@@ -464,23 +486,30 @@ void wpe_solve_kernel(float2* __restrict__ R, const float2* __restrict__ rvec, W
       }
     }
     __syncthreads();
+    mark(3);                                                         // rows below the block
     if (bad) break;
     // ---- write the factored panel back, forward substitution for its columns: L y = r
     for (int idx = tid; idx < rows * CH_NB; idx += 256) {
       const int r = idx / CH_NB, cc = idx % CH_NB;
       if (cc < nb && cc <= r) mat[(long)(jb + r) * P + jb + cc] = panel[r * CH_LD + cc];
     }
-    if (tid == 0) {
-      for (int cc = 0; cc < nb; cc++) {
-        float2 y = rhs[jb + cc];
-        for (int c2 = 0; c2 < cc; c2++) {
-          const float2 l = panel[cc * CH_LD + c2], yy = rhs[jb + c2];
-          y.x -= l.x * yy.x - l.y * yy.y;
-          y.y -= l.x * yy.y + l.y * yy.x;
+    if (wave == ((wrot + (jb >> 4) + 1) & 3)) {
+      // L11 y = r for the panel's own entries: lane r holds y_r and row r of L11, column by column through SGPR broadcasts
+      const int r = lane & 15;
+      float2 lr[CH_NB];
+#pragma unroll
+      for (int c2 = 0; c2 < CH_NB; c2++) lr[c2] = panel[r * CH_LD + c2];
+      float2 y = (lane < nb) ? rhs[jb + lane] : make_float2(0.f, 0.f);
+#pragma unroll
+      for (int c2 = 0; c2 < CH_NB; c2++) {
+        if (c2 < nb) {
+          const float dinv = 1.0f / lane_value(lr[c2].x, c2);
+          const float2 yc = make_float2(lane_value(y.x, c2) * dinv, lane_value(y.y, c2) * dinv);
+          if (r == c2) y = yc;
+          else if (r > c2) { y.x -= lr[c2].x * yc.x - lr[c2].y * yc.y; y.y -= lr[c2].x * yc.y + lr[c2].y * yc.x; }
         }
-        const float inv = 1.0f / panel[cc * CH_LD + cc].x;
-        rhs[jb + cc] = make_float2(y.x * inv, y.y * inv);
       }
+      if (lane < nb) rhs[jb + lane] = y;
     }
     __syncthreads();
     for (int r = nb + tid; r < rows; r += 256) {
@@ -493,6 +522,7 @@ void wpe_solve_kernel(float2* __restrict__ R, const float2* __restrict__ rvec, W
       rhs[jb + r] = y;
     }
     __syncthreads();
+    mark(4);                                                         // write-back + forward substitution
   }
   if (bad) { if (tid == 0) atomicAdd(fail_count, 1); return; }
   // ---- back substitution L^H g = y, panels in reverse order
@@ -528,22 +558,36 @@ void wpe_solve_kernel(float2* __restrict__ R, const float2* __restrict__ rvec, W
       if ((tid & 63) == 0) { red[((tid >> 6) * CH_NB + cc) * 2] = px; red[((tid >> 6) * CH_NB + cc) * 2 + 1] = py; }
     }
     __syncthreads();
-    if (tid == 0) {
-      for (int cc = nb - 1; cc >= 0; cc--) {
-        float2 z = rhs[jb + cc];
-        for (int wv = 0; wv < 4; wv++) { z.x -= red[(wv * CH_NB + cc) * 2]; z.y -= red[(wv * CH_NB + cc) * 2 + 1]; }
-        for (int c2 = cc + 1; c2 < nb; c2++) {
-          const float2 l = panel[c2 * CH_LD + cc], gg = rhs[jb + c2];
-          z.x -= l.x * gg.x + l.y * gg.y;
-          z.y -= l.x * gg.y - l.y * gg.x;
-        }
-        const float inv = 1.0f / panel[cc * CH_LD + cc].x;
-        rhs[jb + cc] = make_float2(z.x * inv, z.y * inv);
+    if (wave == ((wrot + pb) & 3)) {
+      // L11^H g = z for the panel's own entries: lane cc holds z_cc and column cc of L11
+      const int cc = lane & 15;
+      float2 lc[CH_NB];
+#pragma unroll
+      for (int c2 = 0; c2 < CH_NB; c2++) lc[c2] = panel[c2 * CH_LD + cc];            // L[c2][cc] (zero above the diagonal)
+      float2 z = make_float2(0.f, 0.f);
+      if (lane < nb) {
+        z = rhs[jb + lane];
+        for (int wv = 0; wv < 4; wv++) { z.x -= red[(wv * CH_NB + lane) * 2]; z.y -= red[(wv * CH_NB + lane) * 2 + 1]; }
       }
+#pragma unroll
+      for (int c2 = CH_NB - 1; c2 >= 0; c2--) {
+        if (c2 < nb) {
+          const float dinv = 1.0f / lane_value(lc[c2].x, c2);
+          const float2 gg = make_float2(lane_value(z.x, c2) * dinv, lane_value(z.y, c2) * dinv);
+          if (cc == c2) z = gg;
+          else if (cc < c2) { z.x -= lc[c2].x * gg.x + lc[c2].y * gg.y; z.y -= lc[c2].x * gg.y - lc[c2].y * gg.x; }     // conj(l) g
+        }
+      }
+      if (lane < nb) rhs[jb + lane] = z;
     }
     __syncthreads();
   }
   for (int p = tid; p < P; p += 256) gout[p] = rhs[p];
+  mark(5);                                                           // back substitution
+  if (phase_cycles && tid == 0) {
+    for (int i = 0; i < 6; i++) atomicAdd(phase_cycles + i, (unsigned long long)tm[i]);
+    atomicAdd(phase_cycles + 6, 1ull);
+  }
 }
 
 WpeGeom make_geom(int K, int C, int lowerN, int upperN, int lower_bw, int upper_bw, long T_stride, long T)
@@ -591,6 +635,13 @@ int btk_wpe_estimate(const void* X, int S, int K, int C, long T_stride, long T, 
     return btk_set_error(BTK_ERR_DIMENSION, "btk_wpe_estimate: C*(upperN-lowerN+1) = %ld taps exceed the LDS-resident solver (max ~560)", P);
   if (lds_solve > 64 * 1024)
     BTK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(wpe_solve_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_solve));
+  unsigned long long* phase = nullptr;                              // BTK_WPE_TIMING=1: shader cycles per phase of the solver, printed per call
+  if (btk_switches().wpe_timing) {
+    static unsigned long long* dbuf = nullptr;
+    if (!dbuf) BTK_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&dbuf), 8 * sizeof(unsigned long long)));
+    BTK_HIP_CHECK(hipMemsetAsync(dbuf, 0, 8 * sizeof(unsigned long long), st));
+    phase = dbuf;
+  }
   for (int it = 0; it < iterations; it++) {
     hipLaunchKernelGGL(wpe_predict_kernel, dim3((unsigned)((T + 255) / 256), (unsigned)K, (unsigned)(S * C)), dim3(256), 0, st,
                        Xp, Gp, g, 0, Winv, static_cast<float2*>(nullptr));
@@ -615,8 +666,18 @@ int btk_wpe_estimate(const void* X, int S, int K, int C, long T_stride, long T, 
     const bool rvec_from_R = (lowerN == 0) && skip;            // the lag-0 row of the target channel is y_c itself
     if (!rvec_from_R) hipLaunchKernelGGL(wpe_rvec_kernel, dim3((unsigned)K, (unsigned)(S * C)), dim3(256), 0, st, Xp, Winv, g, rvec);
     hipLaunchKernelGGL(wpe_solve_kernel, dim3((unsigned)K, (unsigned)(S * C)), dim3(256), lds_solve, st,
-                       R, rvec_from_R ? static_cast<const float2*>(nullptr) : rvec, g, load_factor, (float)diagonal_bias, Gp, fail_count);
+                       R, rvec_from_R ? static_cast<const float2*>(nullptr) : rvec, g, load_factor, (float)diagonal_bias, Gp, fail_count, phase);
     BTK_HIP_CHECK(hipGetLastError());
+  }
+  if (phase) {
+    unsigned long long h[8];
+    BTK_HIP_CHECK(hipMemcpyAsync(h, phase, sizeof(h), hipMemcpyDeviceToHost, st));
+    BTK_HIP_CHECK(hipStreamSynchronize(st));
+    static const char* names[6] = {"panel_load", "mfma_update", "diagonal_block", "row_solves", "writeback_forward", "back_substitution"};
+    double tot = 0; for (int i = 0; i < 6; i++) tot += (double)h[i];
+    fprintf(stderr, "wpe_solve phases (%llu systems, P = %ld): %.0f cycles per system:", h[6], P, tot / (h[6] ? h[6] : 1));
+    for (int i = 0; i < 6; i++) fprintf(stderr, " %s %.1f%%", names[i], 100.0 * h[i] / (tot > 0 ? tot : 1));
+    fprintf(stderr, "\n");
   }
   return BTK_OK;
 }
