@@ -22,6 +22,8 @@ import types
 
 import numpy as np
 
+sys.dont_write_bytecode = True          # the reference tree is read-only: importing its designer must not leave a __pycache__ there
+
 REF = "/root/reference/btk20_src"
 HERE = os.path.dirname(os.path.abspath(__file__))
 OUT = os.path.join(os.path.dirname(os.path.dirname(HERE)), "distant_speech_recognition_amd", "prototypes", "nyquist_m4_r1.npz")
