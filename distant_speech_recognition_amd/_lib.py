@@ -68,6 +68,8 @@ SIGNATURES = {
     "btk_lefkimmiatis_process": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _l, _l, _d, _i, _i, _l, _vp, _vp, _vp, _vp]),
     "btk_mvdr_lambda": (_i, [_vp, _vp, _vp, _i, _i, _f, _vp, _vp, _vp]),
     "btk_frame_energy": (_i, [_vp, _i, _i, _i, _l, _l, _vp, _l, _vp]),
+    "btk_pcm_i16_to_f32": (_i, [_vp, _vp, _l, _vp]),
+    "btk_pcm_f32_to_i16": (_i, [_vp, _vp, _l, _vp]),
     "btk_cov_frame_gate": (_i, [_vp, _vp, _i, _l, _l, _f, _vp, _vp, _vp]),
     "btk_cov_accumulate": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _l, _l, _i, _vp]),
     "btk_cov_finalize": (_i, [_vp, _vp, _i, _i, _i, _i, _f, _vp]),

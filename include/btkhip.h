@@ -84,6 +84,14 @@ int  btk_fb_analysis_polyphase(const btk_fb_t* fb, const float* pcm, long nsampl
 int  btk_fb_synthesis(const btk_fb_t* fb, const void* Y, long nframes, long T_stride, int S,
                       float* out, long out_stride, long b0, long bcount, void* stream);
 
+/* ---- Sample formats on either side of the path ------------------------------------------------
+ * SampleFeature hands the analysis bank UN-NORMALISED floats of 16-bit PCM (feature/feature.cc:265-269) and the reference's
+ * scripts write the synthesis output back as int16 (numpy.array(buf, numpy.int16): toward zero,
+ * unit_test/test_online_beamforming.py:209).  Utterances cross PCIe as int16 and are widened / narrowed on the device.
+ * in, out [dev], n samples.                                                                                            */
+int  btk_pcm_i16_to_f32(const short* in, float* out, long n, void* stream);
+int  btk_pcm_f32_to_i16(const float* in, short* out, long n, void* stream);
+
 /* ---- Fixed-weight beamformer apply ------------------------------------------------------
  * SubbandDS::next (beamformer/beamformer.cc:1095-1157), SubbandGSC::next + calc_gsc_output
  * (:1208-1316), SubbandMVDR::next (:2537-2587), SubbandMVDRGSC::next (:2720-2773):

@@ -1,0 +1,62 @@
+"""GPU: the host-to-host serving pipeline (distant_speech_recognition_amd/serving.py): int16 PCM over PCIe, three HIP streams,
+`depth` buffer sets -- must give bit for bit what the same chain gives on resident float PCM, for every batch including the
+ragged last one, with the output narrowed like the reference scripts' numpy.array(buf, numpy.int16)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("int16_in,int16_out,depth", [(True, False, 3), (True, True, 2), (False, False, 1)])
+def test_pipeline_equals_resident_chain(dev, int16_in, int16_out, depth):
+    import torch
+    from distant_speech_recognition_amd import engine as eng
+    from distant_speech_recognition_amd.serving import BatchBeamformerPipeline
+    from tests.util import design_prototype, ula_positions, la_delays
+    N, M, m, r, S, B = 6, 512, 4, 1, 7, 3
+    D = M >> r
+    afb = eng.FilterBank(design_prototype(M, m), M, m, r, 2)
+    sfb = eng.FilterBank(design_prototype(M, m, "g"), M, m, r, 2, synthesis=True)
+    L = 45 * D
+    rng = np.random.default_rng(8)
+    host = rng.integers(-20000, 20000, size=(S, N, L)).astype(np.int16)
+    delays = la_delays(ula_positions(N), 0.6)
+    wq = eng.weights_mainlobe(M, N, 16000.0, delays)
+    W = torch.from_numpy(eng.weights_gsc_effective(wq, np.zeros_like(wq), M)).to(dev)
+    pipe = BatchBeamformerPipeline(afb, sfb, W, N, L, streams_per_batch=B, depth=depth, int16_in=int16_in, int16_out=int16_out)
+    src = torch.from_numpy(host if int16_in else host.astype(np.float32))
+    got = pipe.run(src)
+    got2 = pipe.run(src)                                            # buffer sets and events are reusable
+    # the resident chain on the same samples
+    pcm = torch.from_numpy(host.astype(np.float32)).to(dev)
+    Y = afb.analysis_beamform(pcm, W)
+    ref = sfb.synthesize(Y).cpu().numpy()
+    if int16_out:
+        ref = ref.astype(np.int16)                                  # numpy.array(buf, numpy.int16): toward zero
+    assert got.shape == ref.shape and got.dtype == ref.dtype
+    assert np.array_equal(got, ref) and np.array_equal(got2, ref)
+    assert np.abs(ref.astype(np.float64)).max() > 100.0
+
+
+def test_pcm_format_kernels(dev):
+    import ctypes
+    import torch
+    from distant_speech_recognition_amd import _lib
+    rng = np.random.default_rng(1)
+    for n in (0, 1, 7, 8, 2048, 2049 + 5):
+        a = rng.integers(-32768, 32768, size=n).astype(np.int16)
+        d = torch.from_numpy(a).to(dev)
+        f = torch.empty(n, dtype=torch.float32, device=dev)
+        _lib.check(_lib.lib().btk_pcm_i16_to_f32(d.data_ptr(), f.data_ptr(), n, None))
+        assert np.array_equal(f.cpu().numpy(), a.astype(np.float32))
+        x = (rng.standard_normal(n) * 9000).astype(np.float32)
+        o = torch.empty(n, dtype=torch.int16, device=dev)
+        _lib.check(_lib.lib().btk_pcm_f32_to_i16(torch.from_numpy(x).to(dev).data_ptr(), o.data_ptr(), n, None))
+        # toward zero; beyond the int16 range a C cast through int wraps, which is what numpy.array(buf, numpy.int16) does on x86
+        assert np.array_equal(o.cpu().numpy(), x.astype(np.int32).astype(np.int16))
+    # an unaligned view takes the scalar path
+    a = rng.integers(-32768, 32768, size=4099).astype(np.int16)
+    d = torch.from_numpy(a).to(dev)[1:]
+    f = torch.empty(4098, dtype=torch.float32, device=dev)
+    _lib.check(_lib.lib().btk_pcm_i16_to_f32(d.data_ptr(), f.data_ptr(), 4098, None))
+    assert np.array_equal(f.cpu().numpy(), a[1:].astype(np.float32))
