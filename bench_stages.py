@@ -48,6 +48,17 @@ def main():
     t = timeit(torch, lambda: eng.nlms_process(vd, X2, st2, out=Y2))
     out["nlms_c0_128streams"] = {"ms": t * 1e3, "frames_per_s": S2 * T2 / t, "GBps": b / t / 1e9, "hbm_frac": b / t / HBM}
     del X2, Y2
+    # the same two kernels on row-padded snapshots (analysis(pad_rows=True): rows 48 frames wider than the 32 KiB power of two)
+    Xp = eng.padded_rows((S, K, N, T), torch.complex64, dev)
+    Xp.copy_(X)
+    stp = eng.NLMSState(S, M, N, dev)
+    t = timeit(torch, lambda: eng.nlms_process(vd, Xp, stp))
+    out["nlms_c0_padded_rows"] = {"ms": t * 1e3, "frames_per_s": S * T / t, "GBps": b / t / 1e9, "hbm_frac": b / t / HBM}
+    t = timeit(torch, lambda: eng.bf_apply(vd, X))
+    out["apply_c0"] = {"ms": t * 1e3, "frames_per_s": S * T / t, "GBps": b / t / 1e9, "hbm_frac": b / t / HBM}
+    t = timeit(torch, lambda: eng.bf_apply(vd, Xp))
+    out["apply_c0_padded_rows"] = {"ms": t * 1e3, "frames_per_s": S * T / t, "GBps": b / t / 1e9, "hbm_frac": b / t / HBM}
+    del Xp
     zs = eng.ZelinskiState(S, K, dev)
     t = timeit(torch, lambda: eng.bf_apply_zelinski(vd, vd, X, zs, alpha=0.7, out=Y))
     out["apply_zelinski_c0"] = {"ms": t * 1e3, "frames_per_s": S * T / t, "GBps": b / t / 1e9, "hbm_frac": b / t / HBM}

@@ -34,10 +34,15 @@ def _need_cuda(t, name):
         raise ValueError("%s must be contiguous" % name)
 
 
-def _check(t, name, dtype, shape):
+def _check(t, name, dtype, shape, rows=False):
     """The C-ABI sees raw pointers: dtype, residency, contiguity and shape are checked here.  shape: an int (number of
-    dimensions) or a tuple whose None entries are free."""
-    _need_cuda(t, name)
+    dimensions) or a tuple whose None entries are free.  rows=True admits a [..., :T] view of a buffer with padded rows
+    (padded_rows) and returns the row stride in elements, for the entry points whose T_stride the caller may choose."""
+    if rows:
+        ts = _row_stride(t, name)
+    else:
+        _need_cuda(t, name)
+        ts = t.shape[-1] if t.dim() else 0
     if t.dtype != dtype:
         raise _lib.BtkError(_lib.BTK_ERR_DIMENSION, "%s must be %s, got %s" % (name, dtype, t.dtype))
     if isinstance(shape, int):
@@ -46,6 +51,17 @@ def _check(t, name, dtype, shape):
         ok = t.dim() == len(shape) and all(e is None or int(e) == int(g) for e, g in zip(shape, t.shape))
     if not ok:
         raise _lib.BtkError(_lib.BTK_ERR_DIMENSION, "%s has shape %s, expected %s" % (name, tuple(t.shape), shape))
+    return ts
+
+
+def rows_like(X, shape, dtype=torch.complex64):
+    """Tensor of `shape` [..., T] whose rows are spaced like the rows of X (the C-ABI's per-frame outputs share the snapshots'
+    T_stride): contiguous for contiguous X, a [..., :T] view of a padded buffer for row-padded X."""
+    ts = X.stride(-2) if X.dim() >= 2 else X.shape[-1]
+    T = shape[-1]
+    if ts == T:
+        return torch.empty(shape, dtype=dtype, device=X.device)
+    return torch.empty(tuple(shape[:-1]) + (ts,), dtype=dtype, device=X.device)[..., :T]
 
 
 def _row_stride(t, name):
@@ -53,6 +69,8 @@ def _row_stride(t, name):
     tensor or a [..., :T] view of a buffer with padded rows (the C-ABI takes T_stride >= T everywhere)."""
     if not t.is_cuda:
         raise ValueError("%s must live in HBM (cuda tensor); the engine has no CPU path" % name)
+    if t.numel() == 0:                          # an empty bin shard: nothing is read or written, any stride will do
+        return max(int(t.shape[-1]), 1) if t.dim() else 1
     if t.dim() < 2 or t.stride(-1) != 1 or t.stride(-2) < t.shape[-1]:
         raise ValueError("%s: rows must be contiguous" % name)
     for i in range(t.dim() - 3, -1, -1):
@@ -104,9 +122,11 @@ class FilterBank:
     def num_frames(self, nsamples):
         return _lib.lib().btk_fb_analysis_num_frames(self._h, nsamples)
 
-    def analysis(self, pcm, nsamples=None, t0=0, tcount=None, out=None, bins=None):
+    def analysis(self, pcm, nsamples=None, t0=0, tcount=None, out=None, bins=None, pad_rows=False):
         """pcm float32 [S][N][L] (cuda) -> X complex64 [S][K][N][T]; bins = (k0, k1): only that bin range is computed
-        into X [S][k1-k0][N][T] (the bin shard of one rank, sharding.py)."""
+        into X [S][k1-k0][N][T] (the bin shard of one rank, sharding.py).  pad_rows: allocate X with padded rows
+        (padded_rows: power-of-two row pitches put a tile's rows on the same HBM channels) -- bf_apply and nlms_process
+        accept such a view, the other consumers want contiguous snapshots; `out` may itself be a row-padded view."""
         _check(pcm, "pcm", torch.float32, 3)
         S, N, L = pcm.shape
         nsamples = L if nsamples is None else nsamples
@@ -116,14 +136,15 @@ class FilterBank:
         if not (0 <= k0 <= k1 <= self.K):
             raise _lib.BtkError(_lib.BTK_ERR_DIMENSION, "bin range [%d, %d) outside [0, %d]" % (k0, k1, self.K))
         if out is None:
-            out = torch.empty((S, k1 - k0, N, tcount), dtype=torch.complex64, device=pcm.device)
-        _check(out, "X", torch.complex64, (S, k1 - k0, N, None))
+            out = (padded_rows((S, k1 - k0, N, tcount), torch.complex64, pcm.device) if pad_rows
+                   else torch.empty((S, k1 - k0, N, tcount), dtype=torch.complex64, device=pcm.device))
+        ts = _check(out, "X", torch.complex64, (S, k1 - k0, N, None), rows=True)
         if out.shape[3] < tcount:
             raise _lib.BtkError(_lib.BTK_ERR_DIMENSION, "X holds %d frames, %d requested" % (out.shape[3], tcount))
         if bins is None:
-            check(_lib.lib().btk_fb_analysis(self._h, _ptr(pcm), nsamples, L, S, N, _ptr(out), out.shape[3], t0, tcount, _stream()))
+            check(_lib.lib().btk_fb_analysis(self._h, _ptr(pcm), nsamples, L, S, N, _ptr(out), ts, t0, tcount, _stream()))
         else:
-            check(_lib.lib().btk_fb_analysis_bins(self._h, _ptr(pcm), nsamples, L, S, N, _ptr(out), out.shape[3], t0, tcount,
+            check(_lib.lib().btk_fb_analysis_bins(self._h, _ptr(pcm), nsamples, L, S, N, _ptr(out), ts, t0, tcount,
                                                   k0, k1, _stream()))
         return out
 
@@ -187,8 +208,9 @@ class FilterBank:
 
 
 def bf_apply(W, X, out=None):
-    """y_k[t] = w_k^H x_k[t].  W complex64 [S|1][K][N], X complex64 [S][K][N][T] -> Y [S][K][T]."""
-    _check(X, "X", torch.complex64, 4)
+    """y_k[t] = w_k^H x_k[t].  W complex64 [S|1][K][N], X complex64 [S][K][N][T] -> Y [S][K][T].  X may be a row-padded view
+    (analysis(pad_rows=True)); Y then shares its row stride (the C-ABI has one T_stride for both)."""
+    ts = _check(X, "X", torch.complex64, 4, rows=True)
     S, K, N, T = X.shape
     if W.dim() == 2:
         W = W.unsqueeze(0)
@@ -196,11 +218,12 @@ def bf_apply(W, X, out=None):
     if W.shape[1:] != (K, N) or W.shape[0] not in (1, S):
         raise _lib.BtkError(_lib.BTK_ERR_DIMENSION, "weights %s do not match X %s" % (tuple(W.shape), tuple(X.shape)))
     if out is None:
-        out = torch.empty((S, K, T), dtype=torch.complex64, device=X.device)
-    _check(out, "Y", torch.complex64, (S, K, T))
+        out = rows_like(X, (S, K, T))
+    if _check(out, "Y", torch.complex64, (S, K, T), rows=True) != ts and K * T:
+        raise _lib.BtkError(_lib.BTK_ERR_DIMENSION, "Y rows are %d frames apart, X rows %d: they share T_stride" % (out.stride(-2), ts))
     if K == 0 or T == 0:                       # the empty bin shard of a trailing rank: nothing to launch
         return out
-    check(_lib.lib().btk_bf_apply(_ptr(W), int(W.shape[0] == S and S > 1), _ptr(X), _ptr(out), S, K, N, T, T, _stream()))
+    check(_lib.lib().btk_bf_apply(_ptr(W), int(W.shape[0] == S and S > 1), _ptr(X), _ptr(out), S, K, N, ts, T, _stream()))
     return out
 
 
@@ -338,15 +361,17 @@ class NLMSState:
 
 
 def nlms_process(vs, X, state, out=None):
-    """Adaptive GSC over a block: vs complex64 [K][N] (cuda), X [S][K][N][T] -> Y [S][K][T]; state updated in place."""
-    _check(X, "X", torch.complex64, 4)
+    """Adaptive GSC over a block: vs complex64 [K][N] (cuda), X [S][K][N][T] -> Y [S][K][T]; state updated in place.
+    X may be a row-padded view (analysis(pad_rows=True)); Y then shares its row stride."""
+    ts = _check(X, "X", torch.complex64, 4, rows=True)
     S, K, N, T = X.shape
     _check(vs, "vs", torch.complex64, (K, N))
     if (S, K, N) != (state.S, state.K, state.N):
         raise _lib.BtkError(_lib.BTK_ERR_DIMENSION, "nlms_process: shapes do not match the state")
     if out is None:
-        out = torch.empty((S, K, T), dtype=torch.complex64, device=X.device)
-    _check(out, "Y", torch.complex64, (S, K, T))
+        out = rows_like(X, (S, K, T))
+    if _check(out, "Y", torch.complex64, (S, K, T), rows=True) != ts:
+        raise _lib.BtkError(_lib.BTK_ERR_DIMENSION, "Y rows are %d frames apart, X rows %d: they share T_stride" % (out.stride(-2), ts))
     params = state.params_array()
     ws = state.workspace(T)
     Nc = getattr(state, "Nc", 1)
@@ -356,7 +381,7 @@ def nlms_process(vs, X, state, out=None):
             raise _lib.BtkError(_lib.BTK_ERR_PARAMETER, "nlms_process: Nc = %d needs state.set_constraints(vs) first" % Nc)
         _check(cx, "cextra", torch.complex64, (K, Nc - 1, N))
     check(_lib.lib().btk_nlms_process_nc(_np_ptr(params), _ptr(vs), _ptr(state.cextra) if Nc > 1 else None, Nc, _ptr(X), _ptr(out),
-                                         S, state.M, N, T, T, _ptr(state.u), _ptr(state.sigma2), _ptr(state.stream_state),
+                                         S, state.M, N, ts, T, _ptr(state.u), _ptr(state.sigma2), _ptr(state.stream_state),
                                          _ptr(ws), _stream()))
     return out
 

@@ -208,3 +208,35 @@ def test_fused_default_geometry_m256(orc, dev, N, r, S, T):
     Yo = np.einsum("kn,tnk->kt", np.conj(Wn[0].astype(np.complex128)), Xo[t0:t0 + 16, :, :K])
     g = got[0, :, t0:t0 + 16].cpu().numpy()
     assert np.max(np.abs(g - Yo)) <= 4e-6 * np.sqrt(N) * np.max(np.abs(Yo))
+
+
+def test_row_padded_snapshots_give_identical_results(dev):
+    """analysis(pad_rows=True) spaces the snapshot rows 48 frames wider when a row is a multiple of 4 KiB (engine.padded_rows);
+    bf_apply and nlms_process take such a view (the C-ABI's T_stride) and their outputs share the row stride -- bit for bit
+    the contiguous results."""
+    import torch
+    from distant_speech_recognition_amd import engine as eng
+    from tests.util import design_prototype, ula_positions, la_delays
+    N, M, S, T = 8, 512, 2, 512                                   # T * 8 B = 4 KiB rows -> padded
+    D = M // 2
+    afb = eng.FilterBank(design_prototype(M, 4), M, 4, 1, 2)
+    L = (T - afb.processing_delay + afb.lookahead) * D
+    g = torch.Generator(device=dev).manual_seed(2)
+    pcm = (torch.randn((S, N, L), device=dev, generator=g) * 1000.0).round_()
+    Xc = afb.analysis(pcm)
+    Xp = afb.analysis(pcm, pad_rows=True)
+    assert Xc.is_contiguous() and not Xp.is_contiguous() and Xp.stride(-2) == T + 48
+    assert torch.equal(Xc, Xp)
+    delays = la_delays(ula_positions(N), 0.4)
+    wq = eng.weights_mainlobe(M, N, 16000.0, delays)
+    W = torch.from_numpy(eng.weights_gsc_effective(wq, np.zeros_like(wq), M)).to(dev)
+    Yc, Yp = eng.bf_apply(W, Xc), eng.bf_apply(W, Xp)
+    assert Yp.stride(-2) == T + 48 and torch.equal(Yc, Yp)
+    vs = torch.from_numpy(wq[: M // 2 + 1].astype(np.complex64)).to(dev)
+    sc, sp = eng.NLMSState(S, M, N, dev), eng.NLMSState(S, M, N, dev)
+    Zc, Zp = eng.nlms_process(vs, Xc, sc), eng.nlms_process(vs, Xp, sp)
+    assert torch.equal(Zc, Zp) and torch.equal(sc.u, sp.u)
+    with pytest.raises(Exception):
+        eng.bf_apply(W, Xp, out=torch.empty_like(Yc))             # a contiguous Y cannot share the padded T_stride
+    with pytest.raises(Exception):
+        eng.cov_accumulate(Xp)                                    # the other consumers want contiguous snapshots
