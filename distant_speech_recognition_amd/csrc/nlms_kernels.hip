@@ -349,6 +349,20 @@ void nlms_bin2_kernel(const float2* __restrict__ X, const float2* __restrict__ V
   float creg[NPF];
   const int lrow = lane / LPR, lc4 = lane % LPR;
   auto prefetch = [&](long tp) {
+    // whole tiles of whole bins with N == NR channels (the C0 shape): rows kb N .. (kb + BPW) N - 1 of the stream are consecutive
+    // and every load is in range -- one uniform test instead of three per load
+    if (N == NR && kb + BPW <= K && tp + NPF * TBF <= T) {
+      const float2* base = X + (((long)s * K + kb) * N + lrow) * T_stride + tp + 2 * lc4;
+#pragma unroll
+      for (int q = 0; q < NPASS; q++) {
+#pragma unroll
+        for (int h = 0; h < NPF; h++)
+          pre[h][q] = *reinterpret_cast<const float4*>(base + (long)(q * RPP) * T_stride + h * TBF);
+      }
+#pragma unroll
+      for (int h = 0; h < NPF; h++) creg[h] = ctrl[(long)s * T + tp + h * TBF + (lane % TBF)];
+      return;
+    }
 #pragma unroll
     for (int q = 0; q < NPASS; q++) {
       const int r = q * RPP + lrow;
