@@ -278,6 +278,100 @@ void wpe_herk32_kernel(const float2* __restrict__ X, const float* __restrict__ W
   }
 }
 
+// The rows beyond the last full 32-row block (P = 264: rows 256..263) as a 16-row strip on v_mfma_f32_16x16x4_f32: padding them to
+// a ninth 32-row block row costs 9 blocks of which a quarter is used (15 % of the launch's MFMA work); a strip of 16 x 16 tiles
+// costs 4.25 block equivalents.  One wavefront owns the strip rows against 64 columns (four tiles): A[i][k] comes from lane
+// i + 16 k, B[k][j] from lane j + 16 k (k = four consecutive frames), D[i][j] lands in register v of lane l with i = 4 (l / 16) + v,
+// j = l % 16.  Same staging and arithmetic as wpe_herk32_kernel.
+template <int CB>
+__global__ __launch_bounds__(64)
+void wpe_herk16_kernel(const float2* __restrict__ X, const float* __restrict__ Winv, WpeGeom g, float2* __restrict__ R, int nspan, int row0)
+{
+  constexpr int CT = 4;                                            // 16-column tiles per wavefront
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int SPW = WT_ + g.L - 1;
+  float2* spanI = reinterpret_cast<float2*>(smem);                 // [nspan][SPW]
+  float2* spanJ = spanI + nspan * SPW;
+  float* wrow = reinterpret_cast<float*>(spanJ + nspan * SPW);     // [CB][WT_]
+  const int lane = threadIdx.x;
+  const int k = blockIdx.y;
+  if (!bin_active(g, k)) return;
+  const int ncg = g.C / CB;
+  const int s = blockIdx.z / ncg, c0 = (blockIdx.z % ncg) * CB;
+  const int P = g.C * g.L;
+  const int col0 = blockIdx.x * (16 * CT);
+  const float2* Xk = X + ((long)s * g.K + k) * g.C * g.T_stride;
+  f32x4 rr[CT][CB], ri[CT][CB];
+#pragma unroll
+  for (int ct = 0; ct < CT; ct++)
+#pragma unroll
+    for (int cb = 0; cb < CB; cb++) { rr[ct][cb] = f32x4{0.f, 0.f, 0.f, 0.f}; ri[ct][cb] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+  const int li = lane & 15, lk = lane >> 4;
+  const int chI0 = row0 / g.L, chJ0 = col0 / g.L;
+  const int pI = row0 + li;
+  const bool vI = pI < P;
+  const int offI = vI ? (pI / g.L - chI0) * SPW + (g.L - 1 - pI % g.L) : 0;
+  int offJ[CT]; bool vJ[CT];
+#pragma unroll
+  for (int ct = 0; ct < CT; ct++) {
+    const int pJ = col0 + 16 * ct + li;
+    vJ[ct] = pJ < P;
+    offJ[ct] = vJ[ct] ? (pJ / g.L - chJ0) * SPW + (g.L - 1 - pJ % g.L) : 0;
+  }
+  const int nelem = 2 * nspan * SPW;
+  auto span_load = [&](int idx, long t0) -> float2 {
+    const int which = idx / (nspan * SPW), e = idx % (nspan * SPW);
+    const int ch = (which ? chJ0 : chI0) + e / SPW;
+    const long i = t0 - g.lowerN - (g.L - 1) + e % SPW;
+    return (ch < g.C && i >= 0 && i < g.T) ? Xk[(long)ch * g.T_stride + i] : make_float2(0.f, 0.f);
+  };
+  auto weight_load = [&](int idx, long t0) -> float {
+    const int cb = idx / WT_, tt = idx % WT_;
+    const long t = t0 + tt;
+    const float* w = Winv + (((long)s * g.C + c0 + cb) * g.K + k) * g.T_stride;
+    return (t < g.T && t >= g.lowerN) ? w[t] : 0.f;
+  };
+  for (long t0 = 0; t0 < g.T; t0 += WT_) {
+    __syncthreads();
+    for (int idx = lane; idx < nelem; idx += 64) spanI[idx] = span_load(idx, t0);
+    for (int idx = lane; idx < CB * WT_; idx += 64) wrow[idx] = weight_load(idx, t0);
+    __syncthreads();
+#pragma unroll 2
+    for (int kk = 0; kk < WT_; kk += 4) {
+      float2 a = spanI[offI + kk + lk];
+      if (!vI) a = make_float2(0.f, 0.f);
+      float wv[CB];
+#pragma unroll
+      for (int cb = 0; cb < CB; cb++) wv[cb] = wrow[cb * WT_ + kk + lk];
+#pragma unroll
+      for (int ct = 0; ct < CT; ct++) {
+        float2 b = spanJ[offJ[ct] + kk + lk];
+        if (!vJ[ct]) b = make_float2(0.f, 0.f);
+#pragma unroll
+        for (int cb = 0; cb < CB; cb++) {
+          const float bx = b.x * wv[cb], by = b.y * wv[cb];
+          rr[ct][cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, bx, rr[ct][cb], 0, 0, 0);
+          rr[ct][cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, by, rr[ct][cb], 0, 0, 0);
+          ri[ct][cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, bx, ri[ct][cb], 0, 0, 0);
+          ri[ct][cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(-a.x, by, ri[ct][cb], 0, 0, 0);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int cb = 0; cb < CB; cb++) {
+    float2* Rk = R + (((long)s * g.C + c0 + cb) * g.K + k) * (long)P * P;
+#pragma unroll
+    for (int ct = 0; ct < CT; ct++)
+#pragma unroll
+      for (int v = 0; v < 4; v++) {
+        const int row = row0 + 4 * lk + v;
+        const int col = col0 + 16 * ct + li;
+        if (row < P && col < P) Rk[(long)row * P + col] = make_float2(rr[ct][cb][v], ri[ct][cb][v]);
+      }
+  }
+}
+
 // r_c[p] = sum_t conj(y_c(t)) ybar_p(t) / theta_c(t)
 __global__ __launch_bounds__(256)
 void wpe_rvec_kernel(const float2* __restrict__ X, const float* __restrict__ Winv, WpeGeom g, float2* __restrict__ rvec)
@@ -647,16 +741,25 @@ int btk_wpe_estimate(const void* X, int S, int K, int C, long T_stride, long T, 
                        Xp, Gp, g, 0, Winv, static_cast<float2*>(nullptr));
     const int skip = btk_switches().wpe_noskip ? 0 : 1;            // A/B switch of profiles/ (btk_internal.h)
     const dim3 hgrid1((unsigned)(ntile * (ntile + 1) / 2), (unsigned)K, (unsigned)(S * C));
-    const int nb32 = (int)((P + 31) / 32);
+    // up to 16 rows beyond the last full 32-row block go to the 16-row strip kernel instead of a padded block row
+    const int rem = (int)(P % 32);
+    const bool strip = rem > 0 && rem <= 16 && P >= 32;
+    const int nb32 = strip ? (int)(P / 32) : (int)((P + 31) / 32);
     const unsigned nblk = (unsigned)(nb32 * (nb32 + 1) / 2);          // 32 x 32 blocks of the lower triangle
-    const int nspan32 = 31 / g.L + 2;
+    const int nspan32 = 31 / g.L + 2, nspan64 = 63 / g.L + 2;
     const size_t lds32 = sizeof(float2) * 2 * (size_t)nspan32 * (WT_ + g.L - 1) + sizeof(float) * 4 * WT_;
-    if (skip && C % 4 == 0)
+    const size_t lds16 = sizeof(float2) * 2 * (size_t)nspan64 * (WT_ + g.L - 1) + sizeof(float) * 4 * WT_;
+    const unsigned nstrip = (unsigned)((P + 63) / 64);
+    if (skip && C % 4 == 0) {
       hipLaunchKernelGGL(wpe_herk32_kernel<4>, dim3(nblk, (unsigned)K, (unsigned)(S * C / 4)), dim3(64), lds32, st, Xp, Winv, g, R, nspan32);
-    else if (skip && C % 2 == 0)
+      if (strip) hipLaunchKernelGGL(wpe_herk16_kernel<4>, dim3(nstrip, (unsigned)K, (unsigned)(S * C / 4)), dim3(64), lds16, st, Xp, Winv, g, R, nspan64, nb32 * 32);
+    } else if (skip && C % 2 == 0) {
       hipLaunchKernelGGL(wpe_herk32_kernel<2>, dim3(nblk, (unsigned)K, (unsigned)(S * C / 2)), dim3(64), lds32, st, Xp, Winv, g, R, nspan32);
-    else if (skip)
+      if (strip) hipLaunchKernelGGL(wpe_herk16_kernel<2>, dim3(nstrip, (unsigned)K, (unsigned)(S * C / 2)), dim3(64), lds16, st, Xp, Winv, g, R, nspan64, nb32 * 32);
+    } else if (skip) {
       hipLaunchKernelGGL(wpe_herk32_kernel<1>, dim3(nblk, (unsigned)K, (unsigned)(S * C)), dim3(64), lds32, st, Xp, Winv, g, R, nspan32);
+      if (strip) hipLaunchKernelGGL(wpe_herk16_kernel<1>, dim3(nstrip, (unsigned)K, (unsigned)(S * C)), dim3(64), lds16, st, Xp, Winv, g, R, nspan64, nb32 * 32);
+    }
     else if (C % 4 == 0)
       hipLaunchKernelGGL(wpe_herk_kernel<4>, dim3(hgrid1.x, hgrid1.y, (unsigned)(S * C / 4)), dim3(256), lds_herk, st, Xp, Winv, g, ntile, R, skip, nspan);
     else if (C % 2 == 0)
