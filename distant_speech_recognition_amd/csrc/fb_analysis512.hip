@@ -761,11 +761,15 @@ void synthesis512_kernel(const float2* __restrict__ Y, long nframes, long T_stri
     return make_float2(sm.x - t.y, sm.y + t.x);
   };
   prefetch(f_lo + HALO - 16);
+  // ring slot of frame f is (f - f_lo) mod NRING; s0 = slot of the chunk's first frame, carried from chunk to chunk (a 64-bit
+  // modulo by 24 per ring access was a thousand scalar instructions per chunk)
+  auto wrap = [](int v) { return v >= NRING ? v - NRING : (v < 0 ? v + NRING : v); };
+  int s0 = wrap(HALO - 16 + NRING);                              // (fc0 - f_lo) mod NRING for the history chunk, fc0 - f_lo = HALO - 16 < 0
   // chunk c covers frames fc0 .. fc0+15; chunk -1 is the history (only its last HALO frames matter)
-  for (long fc0 = f_lo + HALO - 16; fc0 < bend + pd; fc0 += 16) {
+  for (long fc0 = f_lo + HALO - 16; fc0 < bend + pd; fc0 += 16, s0 = wrap(s0 + 16)) {
     {
       const long f = fc0 + fi;
-      const int slot = (int)(((f - f_lo) % NRING + NRING) % NRING);
+      const int slot = wrap(s0 + fi);
       float2* zf = ring + slot * FRS;
       if (f >= f_lo) {
 #pragma unroll
@@ -789,7 +793,7 @@ void synthesis512_kernel(const float2* __restrict__ Y, long nframes, long T_stri
       const int fl = lane >> 4, j = lane & 15;
       const long f = fc0 + wave * 4 + fl;
       if (f >= f_lo) {
-        const int slot = (int)(((f - f_lo) % NRING + NRING) % NRING);
+        const int slot = wrap(s0 + wave * 4 + fl);
         f2* fb = reinterpret_cast<f2*>(ring) + slot * FRS;
         const f2* twq = reinterpret_cast<const f2*>(twj);
         f2 v[16];
@@ -822,8 +826,7 @@ void synthesis512_kernel(const float2* __restrict__ Y, long nframes, long T_stri
             const int zi = ((i >> 1) >> 4) * 17 + ((i >> 1) & 15);
 #pragma unroll
             for (int wdx = 0; wdx < 16 + HALO; wdx++) {
-              const long f = fc0 - HALO + wdx;
-              const int slot = (int)((f - f_lo) % NRING);
+              const int slot = wrap(s0 - HALO + wdx);          // frame fc0 - HALO + wdx
               const float2 zz = ring[slot * FRS + zi];
               win[j][wdx] = (i & 1) ? zz.y : zz.x;
             }

@@ -670,11 +670,15 @@ void fast_synthesis_kernel(const float2* __restrict__ Y, long nframes, long T_st
     return make_float2(sm.x - t.y, sm.y + t.x);
   };
   prefetch(f_lo + HALO - TT);
-  for (long fc0 = f_lo + HALO - TT; fc0 < bend + pd; fc0 += TT) {
+  // ring slot of frame f is (f - f_lo) mod NRING; s0 = slot of the chunk's first frame, carried from chunk to chunk: the 64-bit
+  // modulo per ring access (per lane in phases A and B) cost hundreds of instructions per chunk
+  auto wrap = [](int v) { return v >= NRING ? v - NRING : (v < 0 ? v + NRING : v); };
+  int s0 = wrap(HALO - TT + NRING);
+  for (long fc0 = f_lo + HALO - TT; fc0 < bend + pd; fc0 += TT, s0 = wrap(s0 + TT)) {
     {
       const long f = fc0 + fi;
       if (f >= f_lo) {
-        float2* zf = ring + (int)((f - f_lo) % NRING) * FRS;
+        float2* zf = ring + wrap(s0 + fi) * FRS;
 #pragma unroll
         for (int it = 0; it < NPAIR; it++) {
           const int k = kq + KQ * it;
@@ -706,7 +710,7 @@ void fast_synthesis_kernel(const float2* __restrict__ Y, long nframes, long T_st
           const int fl = lane / P2, j = lane % P2;
           const long f = fw0 + rd * GG::FP1 + fl;
           if (f >= f_lo) {
-            float2* fb = ring + (int)((f - f_lo) % NRING) * FRS;
+            float2* fb = ring + wrap(s0 + wave * GG::FPW + rd * GG::FP1 + fl) * FRS;
             float2 v[P1];
 #pragma unroll
             for (int r = 0; r < P1; r++) v[r] = cconjf(fb[r * LA + j]);
@@ -722,7 +726,7 @@ void fast_synthesis_kernel(const float2* __restrict__ Y, long nframes, long T_st
           const int fl = lane / P1, k1 = lane % P1;
           const long f = fw0 + rd * GG::FP2 + fl;
           if (f >= f_lo) {
-            float2* fb = ring + (int)((f - f_lo) % NRING) * FRS;
+            float2* fb = ring + wrap(s0 + wave * GG::FPW + rd * GG::FP2 + fl) * FRS;
             float2 v[P2];
 #pragma unroll
             for (int jp = 0; jp < P2; jp++) v[jp] = fb[jp * LB + k1];
@@ -753,8 +757,7 @@ void fast_synthesis_kernel(const float2* __restrict__ Y, long nframes, long T_st
           const int zi = zidx<LOG2M>(i >> 1);
 #pragma unroll
           for (int wdx = 0; wdx < BPT + HALO; wdx++) {
-            const long f = fc0 + bb0 - HALO + wdx;
-            const float2 zz = ring[(int)((f - f_lo) % NRING) * FRS + zi];
+            const float2 zz = ring[wrap(s0 + bb0 - HALO + wdx) * FRS + zi];          // frame fc0 + bb0 - HALO + wdx
             win[j][wdx] = (i & 1) ? zz.y : zz.x;
           }
         }
