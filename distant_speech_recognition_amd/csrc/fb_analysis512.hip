@@ -37,7 +37,7 @@ __global__ __launch_bounds__(A_NT, 3)
 void analysis512_kernel(const float* __restrict__ pcm, long nsamples, long pcm_stride,
                         const float* __restrict__ proto, const float2* __restrict__ twg,
                         int laN, float gain, int N, int K, float2* __restrict__ X,
-                        long T_stride, long t0, long tcount, int ntiles, int nruns, int nchan, int ablate, int k0, int k1)
+                        long T_stride, long t0, long tcount, int ntiles, int nruns, int nchan, int k0, int k1)
 {
   // X [S][K][N][T_stride] holds the bins [k0, k1) of the plan (K = k1 - k0; the whole range for an unsharded plan)
   constexpr int D = A_M / R;
@@ -129,7 +129,7 @@ void analysis512_kernel(const float* __restrict__ pcm, long nsamples, long pcm_s
 #pragma unroll
       for (int i = 0; i < NWG; i++) win[i] = *reinterpret_cast<const float2*>(wbase + i * D);
       __syncthreads();
-      if (ablate != 2) {
+      {
 #pragma unroll
         for (int q = 0; q < G; q++) {
           const int nn = n0 + q * NPG;
@@ -151,7 +151,7 @@ void analysis512_kernel(const float* __restrict__ pcm, long nsamples, long pcm_s
     __syncthreads();
 
     // ---- phase 3: wave-private 256-point FFT of 4 frames (no workgroup barrier inside)
-    if (ablate != 2) {
+    {
       const int fl = lane >> 4, j = lane & 15;
       f2* fb = reinterpret_cast<f2*>(fbuf) + (wave * 4 + fl) * FRS;
       const f2* twq = reinterpret_cast<const f2*>(twj);
@@ -176,11 +176,9 @@ void analysis512_kernel(const float* __restrict__ pcm, long nsamples, long pcm_s
     //      thread (kq = tid>>4, f = tid&15) walks k = kq, kq+16, ..., kq+240; bin 256 is handled by tid < 16
     {
       const int f = tid & 15, kq = tid >> 4;
-      const bool live = tt0 + f < tcount;
       const float2* zf = fbuf + f * FRS;
       float2* xo = X + ((long)s * K * N + nch) * T_stride + tt0 + f + (long)kq * kstride;
-#pragma unroll 4
-      for (int it = 0; it < 16; it++) {
+      auto post = [&](int it) {
         const int k = kq + 16 * it;
         const int kp = (A_NF - k) & 255;
         const float2 zk = zf[it * 17 + kq];
@@ -188,13 +186,29 @@ void analysis512_kernel(const float* __restrict__ pcm, long nsamples, long pcm_s
         const float2 e = make_float2(hg * (zk.x + zq.x), hg * (zk.y - zq.y));
         const float2 o = make_float2(hg * (zk.y + zq.y), -hg * (zk.x - zq.x));   // -j (Z[k] - conj Z[256-k]) / 2
         const float2 w = tw[k];
-        const float2 xv = make_float2(e.x + (w.x * o.x - w.y * o.y), e.y + (w.x * o.y + w.y * o.x));
-        if (ablate == 1) { if (xv.x == 1.2345e33f) xo[0] = xv; }
-        else if (live && (!SHARD || (k >= k0 && k < k1))) xo[(long)(16 * it - (SHARD ? k0 : 0)) * kstride] = xv;
-      }
-      if (tid < 16 && live && ablate != 1 && (!SHARD || (A_NF >= k0 && A_NF < k1))) {   // k = 256: W^256 = -1, partner Z[0]
-        const float2 z0 = zf[0];
-        X[((long)s * K * N + nch) * T_stride + tt0 + f + (long)(A_NF - (SHARD ? k0 : 0)) * kstride] = make_float2(gain * (z0.x - z0.y), 0.f);
+        return make_float2(e.x + (w.x * o.x - w.y * o.y), e.y + (w.x * o.y + w.y * o.x));
+      };
+      // whole tiles of an unsharded plan store unconditionally: a per-store test costs the store stream -- what bounds this
+      // kernel -- two branches each
+      if (!SHARD && tt0 + A_TT <= tcount) {
+#pragma unroll 4
+        for (int it = 0; it < 16; it++) xo[(long)(16 * it) * kstride] = post(it);
+        if (tid < 16) {                                                    // k = 256: W^256 = -1, partner Z[0]
+          const float2 z0 = zf[0];
+          X[((long)s * K * N + nch) * T_stride + tt0 + f + (long)A_NF * kstride] = make_float2(gain * (z0.x - z0.y), 0.f);
+        }
+      } else {
+        const bool live = tt0 + f < tcount;
+#pragma unroll 4
+        for (int it = 0; it < 16; it++) {
+          const int k = kq + 16 * it;
+          const float2 xv = post(it);
+          if (live && (!SHARD || (k >= k0 && k < k1))) xo[(long)(16 * it - (SHARD ? k0 : 0)) * kstride] = xv;
+        }
+        if (tid < 16 && live && (!SHARD || (A_NF >= k0 && A_NF < k1))) {
+          const float2 z0 = zf[0];
+          X[((long)s * K * N + nch) * T_stride + tt0 + f + (long)(A_NF - (SHARD ? k0 : 0)) * kstride] = make_float2(gain * (z0.x - z0.y), 0.f);
+        }
       }
     }
     __syncthreads();                                         // frames consumed before the next span overwrites them
@@ -219,9 +233,8 @@ int launch512(const btk_fb* fb, const float* pcm, long nsamples, long pcm_stride
   // per launch: the attribute is per device, and one process may drive several GPUs (btk_set_device)
   BTK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const float gain = fb->gain_factor > 0 ? (float)fb->gain_factor : 1.0f;
-  const int ablate = btk_switches().analysis512_ablate;                         // diagnostics only
   hipLaunchKernelGGL(kern, dim3((unsigned)nblocks), dim3(A_NT), lds, st, pcm, nsamples, pcm_stride, fb->d_proto, fb->d_tw,
-                     fb->laN, gain, N, fb->kx1 - fb->kx0, X, T_stride, t0, tcount, ntiles, nruns, nchan, ablate, fb->kx0, fb->kx1);
+                     fb->laN, gain, N, fb->kx1 - fb->kx0, X, T_stride, t0, tcount, ntiles, nruns, nchan, fb->kx0, fb->kx1);
   BTK_HIP_CHECK(hipGetLastError());
   return BTK_OK;
 }
