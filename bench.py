@@ -194,12 +194,14 @@ def main():
         wl[k] = eng.weights_sidelobe(B, (rng.normal(size=N - 1) + 1j * rng.normal(size=N - 1)) * 0.01)
     W = torch.from_numpy(eng.weights_gsc_effective(wq, wl, M)).to(dev)
 
-    X = torch.empty((S, K, N, T), dtype=torch.complex64, device=dev)
-    # the chain's Y [S][K][T]: rows 48 frames apart from contiguous when a row is a multiple of 4 KiB (power-of-two row strides
-    # put the 257 bin rows of a tile on the same HBM channels; the C-ABI takes any T_stride >= T); the staged stages below
-    # share X's T_stride and use their own contiguous block
-    Y = eng.padded_rows((S, K, T), torch.complex64, dev) if not args.staged else torch.empty((S, K, T), dtype=torch.complex64, device=dev)
-    Yc = Y if Y.is_contiguous() else torch.empty((S, K, T), dtype=torch.complex64, device=dev)
+    # snapshots and beamformed block with padded rows (engine.padded_rows: 48 frames wider whenever a contiguous row would be a
+    # multiple of 4 KiB -- power-of-two row pitches put the 257 bin rows of a tile on the same HBM channels; the C-ABI takes any
+    # T_stride >= T).  The staged stages' Y shares the snapshots' row stride (one T_stride in btk_bf_apply / btk_nlms_process).
+    X = eng.padded_rows((S, K, N, T), torch.complex64, dev)
+    Y = eng.padded_rows((S, K, T), torch.complex64, dev)
+    Yc = eng.rows_like(X, (S, K, T))
+    if args.staged:
+        Y = Yc
     nblk = sfb.num_blocks(T)
     out = torch.empty((S, nblk * D), dtype=torch.float32, device=dev)
 
