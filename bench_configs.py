@@ -88,7 +88,7 @@ def main():
     afb = eng.FilterBank(design_prototype(M, 4), M, 4, 1, 2)
     sfb = eng.FilterBank(design_prototype(M, 4, "g"), M, 4, 1, 2, synthesis=True)
     pcm, _ = pcm_for(torch, dev, afb, S, N, T, D, 2)
-    X = torch.empty((S, K, N, T), dtype=torch.complex64, device=dev)
+    X = eng.padded_rows((S, K, N, T), torch.complex64, dev)          # row-padded snapshots (engine.padded_rows); Y shares the row stride
     t_a, _ = timed(torch, lambda: afb.analysis(pcm, out=X))
     R = torch.zeros((S, K, N, N), dtype=torch.complex64, device=dev)
 
@@ -102,7 +102,7 @@ def main():
     delays = la_delays(ula_positions(N), -1.306379)
     wqd = torch.from_numpy(eng.weights_mainlobe(M, N, FS, delays)[:K].astype(np.complex64)).to(dev)
     t_m, (Wm, nfb) = timed(torch, lambda: eng.mvdr_weights(R[0], wqd))
-    Y = torch.empty((S, K, T), dtype=torch.complex64, device=dev)
+    Y = eng.rows_like(X, (S, K, T))
     t_b, _ = timed(torch, lambda: eng.bf_apply(Wm, X, out=Y))
     t_s, _ = timed(torch, lambda: sfb.synthesize(Y))
     tot = t_a + t_c + t_m * S + t_b + t_s
@@ -154,7 +154,7 @@ def main():
     afb = eng.FilterBank(design_prototype(M, 4), M, 4, 1, 2)
     sfb = eng.FilterBank(design_prototype(M, 4, "g"), M, 4, 1, 2, synthesis=True)
     pcm, _ = pcm_for(torch, dev, afb, S, N, T, D, 4)
-    X = torch.empty((S, K, N, T), dtype=torch.complex64, device=dev)
+    X = eng.padded_rows((S, K, N, T), torch.complex64, dev)          # row-padded snapshots (engine.padded_rows); Y shares the row stride
     t_a, _ = timed(torch, lambda: afb.analysis(pcm, out=X))
     mpos = ula_positions(N, 10.0)
     delays = la_delays(mpos, 0.8)
@@ -165,7 +165,7 @@ def main():
         eng.mvdr_diagonal_loading(Rd, 0.01)
         return eng.mvdr_weights(Rd, wqd)
     t_m, (Wm, nfb) = timed(torch, design, n=2, warm=1)
-    Y = torch.empty((S, K, T), dtype=torch.complex64, device=dev)
+    Y = eng.rows_like(X, (S, K, T))
     t_b, _ = timed(torch, lambda: eng.bf_apply(Wm, X, out=Y))
     t_s, _ = timed(torch, lambda: sfb.synthesize(Y))
     tot = t_a + t_b + t_s

@@ -656,14 +656,19 @@ def cov_frame_gate(energy, label, threshold, count=None):
 
 
 def cov_accumulate(X, R=None, tf_weights=None, frame_weights=None, use_mfma=True):
-    """R[s][k] += sum_t tf[s][k][t] fw[s][t] x x^H.  X [S][K][N][T] -> R complex64 [S][K][N][N]."""
-    _need_cuda(X, "X")
+    """R[s][k] += sum_t tf[s][k][t] fw[s][t] x x^H.  X [S][K][N][T] -> R complex64 [S][K][N][N].  X may be a row-padded view
+    (analysis(pad_rows=True)); the per-frame weights, if any, then need the same row stride (rows_like(X, ...))."""
+    ts = _check(X, "X", torch.complex64, 4, rows=True)
     S, K, N, T = X.shape
     if R is None:
         R = torch.zeros((S, K, N, N), dtype=torch.complex64, device=X.device)
+    _check(R, "R", torch.complex64, (S, K, N, N))
+    for w, name, shape in ((tf_weights, "tf_weights", (S, K, T)), (frame_weights, "frame_weights", (S, T))):
+        if w is not None and _check(w, name, torch.float32, shape, rows=True) != ts:
+            raise _lib.BtkError(_lib.BTK_ERR_DIMENSION, "%s rows are %d frames apart, X rows %d: they share T_stride" % (name, w.stride(-2), ts))
     check(_lib.lib().btk_cov_accumulate(_ptr(X), None if tf_weights is None else _ptr(tf_weights),
                                         None if frame_weights is None else _ptr(frame_weights), _ptr(R),
-                                        S, K, N, T, T, int(use_mfma), _stream()))
+                                        S, K, N, ts, T, int(use_mfma), _stream()))
     return R
 
 

@@ -314,3 +314,24 @@ def test_lefkimmiatis_matches_oracle(orc, dev, N, M, T, type_, minf, x1):
         wl = st.w_last.cpu().numpy()[s]
         assert np.max(np.abs(wl - Wref[-1, :K].real)) <= 1e-3
     assert 1.5e-4 < np.mean(Wref.real[:, :K]) < 0.999          # neither clamped to the floor nor to 1 everywhere
+
+
+def test_cov_accumulate_on_row_padded_snapshots(dev):
+    """cov_accumulate takes row-padded snapshots (engine.padded_rows) and per-frame weights of the same row stride: identical
+    to the contiguous result for the MFMA, VALU and small-N kernels."""
+    import torch
+    from distant_speech_recognition_amd import engine as eng
+    for N in (4, 64):
+        S, K, T = 2, 5, 512                                   # 512 frames x 8 B = 4 KiB rows -> padded
+        g = torch.Generator(device=dev).manual_seed(N)
+        Xc = (torch.randn((S, K, N, T), device=dev, generator=g) + 1j * torch.randn((S, K, N, T), device=dev, generator=g)).to(torch.complex64)
+        Xp = eng.padded_rows((S, K, N, T), torch.complex64, dev)
+        Xp.copy_(Xc)
+        assert not Xp.is_contiguous()
+        for mf in (True, False):
+            assert torch.equal(eng.cov_accumulate(Xc, use_mfma=mf), eng.cov_accumulate(Xp, use_mfma=mf))
+        fw = torch.rand((S, T), device=dev, generator=g)
+        fwp = eng.rows_like(Xp, (S, T), dtype=torch.float32); fwp.copy_(fw)
+        assert torch.equal(eng.cov_accumulate(Xc, frame_weights=fw), eng.cov_accumulate(Xp, frame_weights=fwp))
+        with pytest.raises(Exception):
+            eng.cov_accumulate(Xp, frame_weights=fw)             # contiguous weights cannot share the padded T_stride
