@@ -238,5 +238,6 @@ def test_row_padded_snapshots_give_identical_results(dev):
     assert torch.equal(Zc, Zp) and torch.equal(sc.u, sp.u)
     with pytest.raises(Exception):
         eng.bf_apply(W, Xp, out=torch.empty_like(Yc))             # a contiguous Y cannot share the padded T_stride
+    assert torch.equal(eng.cov_accumulate(Xc), eng.cov_accumulate(Xp))
     with pytest.raises(Exception):
-        eng.cov_accumulate(Xp)                                    # the other consumers want contiguous snapshots
+        eng.frame_energy(Xp, M)                                   # the remaining consumers want contiguous snapshots
