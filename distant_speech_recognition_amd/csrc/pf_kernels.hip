@@ -181,12 +181,20 @@ void bf_apply_stats2_kernel(const float2* __restrict__ W, long w_stream_stride, 
 {
   const int k = blockIdx.y, s = blockIdx.z;
   const long t = (long)blockIdx.x * PF_NT + threadIdx.x;
+  const float2* cs = Cs + (long)k * N * N;
+  const float2* cv = (NQ == 2) ? Cv + (long)k * N * N : nullptr;
+  // A diffuse-field coherence matrix is real (sinc of the distances), and so are the pair weights built from it: half of the
+  // multiply-adds of the complex form would multiply zeros.  One scan of the bin's coefficients decides per workgroup.
+  int im = 0;
+  for (int idx = threadIdx.x; idx < N * N; idx += PF_NT) {
+    im |= (cs[idx].y != 0.f);
+    if (NQ == 2) im |= (cv[idx].y != 0.f);
+  }
+  const bool complex_c = __syncthreads_or(im) != 0;
   if (t >= T) return;
   const float2* w = W + s * w_stream_stride + (long)k * N;
   const float2* d = Dv + s * w_stream_stride + (long)k * N;
   const float2* x = X + ((long)s * K + k) * N * T_stride + t;
-  const float2* cs = Cs + (long)k * N * N;
-  const float2* cv = (NQ == 2) ? Cv + (long)k * N * N : nullptr;
   float yr = 0.f, yi = 0.f, e = 0.f;
 #pragma unroll 8
   for (int n = 0; n < N; n++) {
@@ -203,20 +211,40 @@ void bf_apply_stats2_kernel(const float2* __restrict__ W, long w_stream_stride, 
 #pragma unroll
     for (int jj = 0; jj < PF_JB; jj++) { ar[jj] = ai[jj] = 0.f; br[jj] = bi[jj] = 0.f; }
     const int iend = (jb + PF_JB < N) ? jb + PF_JB : N;
-    for (int i = 0; i < iend; i++) {
-      const float2 xv = x[(long)i * T_stride];
-      const float2 dn = d[i];
-      const float xr = fmaf(dn.x, xv.x, dn.y * xv.y), xi = fmaf(dn.x, xv.y, -dn.y * xv.x);   // x'_i = conj(d_i) x_i
+    if (complex_c) {
+      for (int i = 0; i < iend; i++) {
+        const float2 xv = x[(long)i * T_stride];
+        const float2 dn = d[i];
+        const float xr = fmaf(dn.x, xv.x, dn.y * xv.y), xi = fmaf(dn.x, xv.y, -dn.y * xv.x);   // x'_i = conj(d_i) x_i
 #pragma unroll
-      for (int jj = 0; jj < PF_JB; jj++) {
-        const int j = (jb + jj < N) ? jb + jj : N - 1;            // clamped rows are never used
-        const float2 c = cs[(long)j * N + i];                     // wave-uniform
-        ar[jj] = fmaf(c.x, xr, fmaf(-c.y, xi, ar[jj]));
-        ai[jj] = fmaf(c.x, xi, fmaf(c.y, xr, ai[jj]));
-        if (NQ == 2) {
-          const float2 c2 = cv[(long)j * N + i];
-          br[jj] = fmaf(c2.x, xr, fmaf(-c2.y, xi, br[jj]));
-          bi[jj] = fmaf(c2.x, xi, fmaf(c2.y, xr, bi[jj]));
+        for (int jj = 0; jj < PF_JB; jj++) {
+          const int j = (jb + jj < N) ? jb + jj : N - 1;            // clamped rows are never used
+          const float2 c = cs[(long)j * N + i];                     // wave-uniform
+          ar[jj] = fmaf(c.x, xr, fmaf(-c.y, xi, ar[jj]));
+          ai[jj] = fmaf(c.x, xi, fmaf(c.y, xr, ai[jj]));
+          if (NQ == 2) {
+            const float2 c2 = cv[(long)j * N + i];
+            br[jj] = fmaf(c2.x, xr, fmaf(-c2.y, xi, br[jj]));
+            bi[jj] = fmaf(c2.x, xi, fmaf(c2.y, xr, bi[jj]));
+          }
+        }
+      }
+    } else {
+      for (int i = 0; i < iend; i++) {
+        const float2 xv = x[(long)i * T_stride];
+        const float2 dn = d[i];
+        const float xr = fmaf(dn.x, xv.x, dn.y * xv.y), xi = fmaf(dn.x, xv.y, -dn.y * xv.x);
+#pragma unroll
+        for (int jj = 0; jj < PF_JB; jj++) {
+          const int j = (jb + jj < N) ? jb + jj : N - 1;
+          const float c = cs[(long)j * N + i].x;
+          ar[jj] = fmaf(c, xr, ar[jj]);
+          ai[jj] = fmaf(c, xi, ai[jj]);
+          if (NQ == 2) {
+            const float c2 = cv[(long)j * N + i].x;
+            br[jj] = fmaf(c2, xr, br[jj]);
+            bi[jj] = fmaf(c2, xi, bi[jj]);
+          }
         }
       }
     }
