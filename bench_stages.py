@@ -58,6 +58,9 @@ def main():
     out["apply_c0"] = {"ms": t * 1e3, "frames_per_s": S * T / t, "GBps": b / t / 1e9, "hbm_frac": b / t / HBM}
     t = timeit(torch, lambda: eng.bf_apply(vd, Xp))
     out["apply_c0_padded_rows"] = {"ms": t * 1e3, "frames_per_s": S * T / t, "GBps": b / t / 1e9, "hbm_frac": b / t / HBM}
+    zsp = eng.ZelinskiState(S, K, dev)
+    t = timeit(torch, lambda: eng.bf_apply_zelinski(vd, vd, Xp, zsp, alpha=0.7))
+    out["apply_zelinski_c0_padded_rows"] = {"ms": t * 1e3, "frames_per_s": S * T / t, "GBps": b / t / 1e9, "hbm_frac": b / t / HBM}
     del Xp
     zs = eng.ZelinskiState(S, K, dev)
     t = timeit(torch, lambda: eng.bf_apply_zelinski(vd, vd, X, zs, alpha=0.7, out=Y))

@@ -528,8 +528,9 @@ class ZelinskiState:
 
 def bf_apply_zelinski(W, D, X, state, alpha=0.6, type_=2, min_frames=0, out=None):
     """Beamform + Zelinski post-filter over a block (ZelinskiPostFilter over SubbandDS/GSC/MVDR).
-    W, D complex64 [S|1][K][N]; X [S][K][N][T] -> Y [S][K][T] (post-filtered)."""
-    _check(X, "X", torch.complex64, 4)
+    W, D complex64 [S|1][K][N]; X [S][K][N][T] -> Y [S][K][T] (post-filtered).  X may be a row-padded view
+    (analysis(pad_rows=True)); Y and the per-frame statistics then share its row stride."""
+    ts = _check(X, "X", torch.complex64, 4, rows=True)
     S, K, N, T = X.shape
     if W.dim() == 2:
         W, D = W.unsqueeze(0), D.unsqueeze(0)
@@ -537,14 +538,15 @@ def bf_apply_zelinski(W, D, X, state, alpha=0.6, type_=2, min_frames=0, out=None
     if W.shape[0] not in (1, S):
         raise _lib.BtkError(_lib.BTK_ERR_DIMENSION, "weights %s do not match X %s" % (tuple(W.shape), tuple(X.shape)))
     if out is None:
-        out = torch.empty((S, K, T), dtype=torch.complex64, device=X.device)
-    _check(out, "Y", torch.complex64, (S, K, T))
-    Cc = torch.empty((S, K, T), dtype=torch.complex64, device=X.device)
-    Ee = torch.empty((S, K, T), dtype=torch.float32, device=X.device)
+        out = rows_like(X, (S, K, T))
+    if _check(out, "Y", torch.complex64, (S, K, T), rows=True) != ts:
+        raise _lib.BtkError(_lib.BTK_ERR_DIMENSION, "Y rows are %d frames apart, X rows %d: they share T_stride" % (out.stride(-2), ts))
+    Cc = rows_like(X, (S, K, T))
+    Ee = rows_like(X, (S, K, T), dtype=torch.float32)
     L = _lib.lib()
     check(L.btk_bf_apply_stats(_ptr(W), _ptr(D), int(W.shape[0] == S and S > 1), _ptr(X), _ptr(out), _ptr(Cc), _ptr(Ee),
-                               S, K, N, T, T, _stream()))
-    check(L.btk_zelinski_process(_ptr(out), _ptr(Cc), _ptr(Ee), S, K, N, T, T, float(alpha), int(type_), int(min_frames),
+                               S, K, N, ts, T, _stream()))
+    check(L.btk_zelinski_process(_ptr(out), _ptr(Cc), _ptr(Ee), S, K, N, ts, T, float(alpha), int(type_), int(min_frames),
                                  state.frames_done, _ptr(state.phi), _ptr(state.psi), _ptr(state.w_last), _stream()))
     state.frames_done += T
     return out

@@ -239,5 +239,7 @@ def test_row_padded_snapshots_give_identical_results(dev):
     with pytest.raises(Exception):
         eng.bf_apply(W, Xp, out=torch.empty_like(Yc))             # a contiguous Y cannot share the padded T_stride
     assert torch.equal(eng.cov_accumulate(Xc), eng.cov_accumulate(Xp))
+    zc, zp = eng.ZelinskiState(S, M // 2 + 1, dev), eng.ZelinskiState(S, M // 2 + 1, dev)
+    assert torch.equal(eng.bf_apply_zelinski(W, W, Xc, zc, alpha=0.7), eng.bf_apply_zelinski(W, W, Xp, zp, alpha=0.7))
     with pytest.raises(Exception):
         eng.frame_energy(Xp, M)                                   # the remaining consumers want contiguous snapshots
