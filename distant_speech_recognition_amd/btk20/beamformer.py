@@ -6,7 +6,7 @@ analysis + beamform pass on the device and serves frames; weights are designed h
 import numpy as np
 
 from .. import _lib, engine
-from .common import j_error, jallocation_error, jdimension_error, jiterator_error, raise_from_code
+from .common import j_error, jallocation_error, jdimension_error, raise_from_code
 from .modulated import OverSampledDFTAnalysisBankPtr, _mirror, _pull_all
 from .stream import VectorComplexFeatureStream, _BlockServedStream, device
 

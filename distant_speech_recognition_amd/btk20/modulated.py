@@ -3,7 +3,7 @@ modulated/modulated.i:124-140): same constructors and kwargs, GPU compute throug
 import numpy as np
 
 from .. import _lib, engine
-from .common import jconsistency_error, jdimension_error, jiterator_error, raise_from_code
+from .common import jconsistency_error, jdimension_error, raise_from_code
 from .stream import VectorComplexFeatureStream, VectorFloatFeatureStream, _BlockServedStream, device
 
 __all__ = ["OverSampledDFTAnalysisBankPtr", "OverSampledDFTSynthesisBankPtr",

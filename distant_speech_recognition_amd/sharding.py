@@ -8,7 +8,6 @@ The path shards two ways:
     bin (`for fbinX` loops, beamformer.cc:1298, postfilter.cc:184, pybeamformer.py:674): rank g owns a
     contiguous bin range, and ONE all-gather of the beamformed block Y[K_g][T] precedes synthesis.
 """
-import numpy as np
 
 
 def streams_for_rank(num_streams, rank, world):
