@@ -5,6 +5,7 @@ utterances start and end in pinned host memory.  Reports, for the same utterance
   f32_serial    float32 samples uploaded, transformed and downloaded one batch after the other on one stream,
   f32_pipelined float32 samples, three streams (upload / compute / download) and three buffer sets,
   i16_pipelined int16 samples over the link, widened on the device (what SampleFeature's 16-bit WAVs are), int16 output,
+  i16_interleaved_pipelined  the same with the samples as a multi-channel WAV stores them ([L][N] frames), de-interleaved on the device,
 and the raw pinned host-to-device copy rate, which is what bounds the last two.  Not the driver's bench (bench.py is)."""
 import argparse
 import json
@@ -75,8 +76,12 @@ def main():
             hout.copy_(out, non_blocking=True)
     t = wall(serial)
     res["f32_serial"] = {"frames_per_s": frames / t, "ms": t * 1e3}
+    host16il = host16.permute(0, 2, 1).contiguous().pin_memory()            # [S][L][N]: the frames of a multi-channel WAV as stored
+    t0 = time.perf_counter(); _ = np.ascontiguousarray(np.transpose(host16il.numpy()[:4], (0, 2, 1))); t_host_tr = (time.perf_counter() - t0) / 4
+    res["host_side_deinterleave_ms_per_utterance"] = t_host_tr * 1e3  # what numpy needs to do the same on one core
     for name, kw, src in (("f32_pipelined", dict(int16_in=False, int16_out=False), host32),
-                          ("i16_pipelined", dict(int16_in=True, int16_out=True), host16)):
+                          ("i16_pipelined", dict(int16_in=True, int16_out=True), host16),
+                          ("i16_interleaved_pipelined", dict(int16_in=True, int16_out=True, interleaved=True), host16il)):
         pipe = BatchBeamformerPipeline(afb, sfb, W, N, L, streams_per_batch=B, depth=3, **kw)
         o = np.empty((S, pipe.out_len), np.int16 if kw["int16_out"] else np.float32)
         t = wall(lambda: pipe.run(src, out=o))

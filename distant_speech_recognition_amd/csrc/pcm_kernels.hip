@@ -32,7 +32,42 @@ void pcm_f32_to_i16_kernel(const float* __restrict__ in, short* __restrict__ out
   for (long i = i0; i < n && i < i0 + 8; i++) out[i] = (short)(int)in[i];       // numpy's float -> int16 cast: toward zero
 }
 
+// A multi-channel recording is stored frame by frame, in[l][c] (what libsndfile hands SampleFeature::read, which then copies out
+// channel chX with stride chN: feature/feature.cc:333-334, once per channel node).  One pass de-interleaves ALL channels:
+// 64 x 64 tiles through LDS, reads coalesced along c, writes coalesced along l.  out[c][l] float32, rows out_stride apart.
+__global__ __launch_bounds__(256)
+void pcm_i16_deinterleave_kernel(const short* __restrict__ in, float* __restrict__ out, long L, int N, long out_stride)
+{
+  __shared__ float tile[64][65];
+  const long l0 = (long)blockIdx.x * 64;
+  const int c0 = blockIdx.y * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;          // 64 x 4
+#pragma unroll
+  for (int r = 0; r < 16; r++) {
+    const long l = l0 + ty + 4 * r;
+    const int c = c0 + tx;
+    tile[ty + 4 * r][tx] = (l < L && c < N) ? (float)in[l * N + c] : 0.f;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < 16; r++) {
+    const int c = c0 + ty + 4 * r;
+    const long l = l0 + tx;
+    if (c < N && l < L) out[(long)c * out_stride + l] = tile[tx][ty + 4 * r];
+  }
+}
+
 }  // namespace
+
+extern "C" int btk_pcm_i16_deinterleave(const short* in, float* out, long L, int N, long out_stride, void* stream)
+{
+  if (L < 0 || N <= 0 || out_stride < L || (L > 0 && (!in || !out))) return btk_set_error(BTK_ERR_PARAMETER, "btk_pcm_i16_deinterleave: bad argument");
+  if (L == 0) return BTK_OK;
+  hipLaunchKernelGGL(pcm_i16_deinterleave_kernel, dim3((unsigned)((L + 63) / 64), (unsigned)((N + 63) / 64)), dim3(256), 0, as_stream(stream),
+                     in, out, L, N, out_stride);
+  BTK_HIP_CHECK(hipGetLastError());
+  return BTK_OK;
+}
 
 extern "C" int btk_pcm_i16_to_f32(const short* in, float* out, long n, void* stream)
 {

@@ -30,13 +30,17 @@ class BatchBeamformerPipeline:
     N          channels per utterance, L samples per channel and utterance (shorter utterances are zero-padded by the caller)
     streams_per_batch   utterances transformed by one launch of the chain
     depth      device buffer sets in flight (>= 2 overlaps the three stages)
-    int16_out  narrow the output on the device and download int16 (the reference scripts' WAV samples)"""
+    int16_out  narrow the output on the device and download int16 (the reference scripts' WAV samples)
+    interleaved  host PCM is [S][L][N] int16, the frames of a multi-channel WAV as stored; de-interleaved on the device"""
 
-    def __init__(self, afb, sfb, W, N, L, streams_per_batch=8, depth=3, int16_in=True, int16_out=False, device=None):
+    def __init__(self, afb, sfb, W, N, L, streams_per_batch=8, depth=3, int16_in=True, int16_out=False, interleaved=False, device=None):
         self.afb, self.sfb, self.N, self.L, self.B, self.depth = afb, sfb, int(N), int(L), int(streams_per_batch), int(depth)
         self.dev = W.device if device is None else device
         self.W = W if W.dim() == 3 else W.unsqueeze(0)
         self.int16_in, self.int16_out = bool(int16_in), bool(int16_out)
+        self.interleaved = bool(interleaved)               # host PCM as stored in a multi-channel WAV: [S][L][N] int16
+        if self.interleaved and not self.int16_in:
+            raise _lib.BtkError(_lib.BTK_ERR_PARAMETER, "interleaved input is int16 (the frames of a multi-channel WAV)")
         self.T = afb.num_frames(self.L)
         self.nblk = sfb.num_blocks(self.T)
         self.out_len = self.nblk * sfb.D
@@ -45,7 +49,8 @@ class BatchBeamformerPipeline:
         self.sets = []
         for _ in range(self.depth):
             st = {
-                "raw": torch.empty((self.B, self.N, self.L), dtype=torch.int16 if self.int16_in else torch.float32, device=self.dev),
+                "raw": torch.empty((self.B, self.L, self.N) if self.interleaved else (self.B, self.N, self.L),
+                                   dtype=torch.int16 if self.int16_in else torch.float32, device=self.dev),
                 "pcm": torch.empty((self.B, self.N, self.L), dtype=torch.float32, device=self.dev) if self.int16_in else None,
                 "Y": engine.padded_rows((self.B, K, self.T), torch.complex64, self.dev),
                 "out": torch.empty((self.B, self.out_len), dtype=torch.float32, device=self.dev),
@@ -67,8 +72,12 @@ class BatchBeamformerPipeline:
         with torch.cuda.stream(self.s_cmp):
             self.s_cmp.wait_event(st["uploaded"])
             self.s_cmp.wait_event(st["downloaded"])                # the set's previous output has left `out`
-            if self.int16_in:
+            if self.interleaved:
+                for u in range(nb):                                # [L][N] frames -> planar float channels, all channels per launch
+                    check(_lib.lib().btk_pcm_i16_deinterleave(_ptr(st["raw"][u]), _ptr(st["pcm"][u]), self.L, self.N, self.L, self.s_cmp.cuda_stream))
+            elif self.int16_in:
                 check(_lib.lib().btk_pcm_i16_to_f32(_ptr(st["raw"]), _ptr(st["pcm"]), nb * self.N * self.L, self.s_cmp.cuda_stream))
+            if self.int16_in:
                 pcm = st["pcm"][:nb]
                 st["free"].record(self.s_cmp)                      # `raw` may be overwritten by the next upload once widened ...
             else:
@@ -96,9 +105,10 @@ class BatchBeamformerPipeline:
         if not torch.is_tensor(host_pcm):
             host_pcm = torch.from_numpy(np.ascontiguousarray(host_pcm))
         want = torch.int16 if self.int16_in else torch.float32
-        if host_pcm.dtype != want or tuple(host_pcm.shape[1:]) != (self.N, self.L):
+        shape = (self.L, self.N) if self.interleaved else (self.N, self.L)
+        if host_pcm.dtype != want or tuple(host_pcm.shape[1:]) != shape:
             raise _lib.BtkError(_lib.BTK_ERR_DIMENSION, "host PCM must be %s [S][%d][%d], got %s %s"
-                                % (want, self.N, self.L, host_pcm.dtype, tuple(host_pcm.shape)))
+                                % (want, shape[0], shape[1], host_pcm.dtype, tuple(host_pcm.shape)))
         if not host_pcm.is_pinned():
             host_pcm = host_pcm.pin_memory()                       # pageable memory would serialise the copies
         S = host_pcm.shape[0]

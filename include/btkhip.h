@@ -91,6 +91,9 @@ int  btk_fb_synthesis(const btk_fb_t* fb, const void* Y, long nframes, long T_st
  * in, out [dev], n samples.                                                                                            */
 int  btk_pcm_i16_to_f32(const short* in, float* out, long n, void* stream);
 int  btk_pcm_f32_to_i16(const float* in, short* out, long n, void* stream);
+/* A multi-channel recording as stored (frame by frame): in [dev] int16 [L][N] -> out [dev] float32 [N][out_stride], all channels in
+ * one pass (SampleFeature::read copies channel chX out of the interleaved frames, once per channel node: feature/feature.cc:333-334). */
+int  btk_pcm_i16_deinterleave(const short* in, float* out, long L, int N, long out_stride, void* stream);
 
 /* ---- Fixed-weight beamformer apply ------------------------------------------------------
  * SubbandDS::next (beamformer/beamformer.cc:1095-1157), SubbandGSC::next + calc_gsc_output

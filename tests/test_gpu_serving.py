@@ -7,8 +7,8 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("int16_in,int16_out,depth", [(True, False, 3), (True, True, 2), (False, False, 1)])
-def test_pipeline_equals_resident_chain(dev, int16_in, int16_out, depth):
+@pytest.mark.parametrize("int16_in,int16_out,depth,interleaved", [(True, False, 3, False), (True, True, 2, False), (False, False, 1, False), (True, True, 3, True)])
+def test_pipeline_equals_resident_chain(dev, int16_in, int16_out, depth, interleaved):
     import torch
     from distant_speech_recognition_amd import engine as eng
     from distant_speech_recognition_amd.serving import BatchBeamformerPipeline
@@ -23,8 +23,11 @@ def test_pipeline_equals_resident_chain(dev, int16_in, int16_out, depth):
     delays = la_delays(ula_positions(N), 0.6)
     wq = eng.weights_mainlobe(M, N, 16000.0, delays)
     W = torch.from_numpy(eng.weights_gsc_effective(wq, np.zeros_like(wq), M)).to(dev)
-    pipe = BatchBeamformerPipeline(afb, sfb, W, N, L, streams_per_batch=B, depth=depth, int16_in=int16_in, int16_out=int16_out)
+    pipe = BatchBeamformerPipeline(afb, sfb, W, N, L, streams_per_batch=B, depth=depth, int16_in=int16_in, int16_out=int16_out,
+                                   interleaved=interleaved)
     src = torch.from_numpy(host if int16_in else host.astype(np.float32))
+    if interleaved:                                                 # the frames of a multi-channel WAV as stored: [S][L][N]
+        src = torch.from_numpy(np.ascontiguousarray(np.transpose(host, (0, 2, 1))))
     got = pipe.run(src)
     got2 = pipe.run(src)                                            # buffer sets and events are reusable
     # the resident chain on the same samples
@@ -60,3 +63,18 @@ def test_pcm_format_kernels(dev):
     f = torch.empty(4098, dtype=torch.float32, device=dev)
     _lib.check(_lib.lib().btk_pcm_i16_to_f32(d.data_ptr(), f.data_ptr(), 4098, None))
     assert np.array_equal(f.cpu().numpy(), a[1:].astype(np.float32))
+
+
+def test_pcm_deinterleave_kernel(dev):
+    """btk_pcm_i16_deinterleave: int16 frames [L][N] -> planar float32 [N][stride] for sizes around the 64 x 64 tile"""
+    import torch
+    from distant_speech_recognition_amd import _lib
+    rng = np.random.default_rng(2)
+    for L, N, pad in ((1, 1, 0), (63, 5, 3), (64, 64, 0), (130, 65, 7), (1000, 8, 0)):
+        a = rng.integers(-32768, 32768, size=(L, N)).astype(np.int16)
+        d = torch.from_numpy(a).to(dev)
+        o = torch.full((N, L + pad), -7.0, dtype=torch.float32, device=dev)
+        _lib.check(_lib.lib().btk_pcm_i16_deinterleave(d.data_ptr(), o.data_ptr(), L, N, L + pad, None))
+        got = o.cpu().numpy()
+        assert np.array_equal(got[:, :L], a.T.astype(np.float32))
+        assert np.all(got[:, L:] == -7.0)                           # the padding of a row is not touched
