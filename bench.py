@@ -128,7 +128,7 @@ def cpu_baseline(N, M, m, r, dct, frames, all_cores=True):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--steps", type=int, default=600)       # ~1.8 s of timed GPU work at C0
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--prewarm-ms", type=float, default=300.0,
                     help="untimed steps run before the warmup until this much wall time has passed: the host-side weight design "
