@@ -435,6 +435,7 @@ void analysis512_bfz_kernel(const float* __restrict__ pcm, long nsamples, long p
   // spends between the marks below (s_memtime; each mark drains lgkmcnt, which the surrounding code does anyway)
   constexpr bool TIMED = (VAR & 512) != 0;
   constexpr bool SPREAD = (VAR & 8) != 0;
+  constexpr bool XSWAP = (VAR & 64) != 0;      // polyphase products with op_sel-crossed halves (no v_pk_mov swap per output)
   // ABL (VAR bits 12-14, only built with -DBTK_FUSED_ABLATE; results are WRONG by design): what the kernel costs without ...
   //   1 the LDS exchange between the FFT passes, 2 the weight-pair reads, 3 the frame writes and first-pass reads,
   //   4 the window loads, 5 the two barriers, 6 the beamformer sums; 7 = window loads always from channel 0 (cache hits)
@@ -464,23 +465,33 @@ void analysis512_bfz_kernel(const float* __restrict__ pcm, long nsamples, long p
         else __builtin_amdgcn_sched_barrier(0);          // keep the window reads back to back (one LDS latency, not NWG)
       }
       // tap-major order: consecutive FMAs belong to different outputs (no dependent back-to-back packed FMAs)
-      float2 po[G][FPT];
+      // z = (h.x x.y, h.y x.x) summed over the taps: one packed multiply-add per tap with the halves of x crossed by op_sel
+      f2 po[G][FPT];
 #pragma unroll
       for (int k = 0; k < A_MT; k++)
 #pragma unroll
         for (int q = 0; q < G; q++)
 #pragma unroll
           for (int g = 0; g < FPT; g++) {
-            const float2 x = win[g + R * (A_MT - 1 - k) + (G - 1 - q) * CG];
-            po[q][g].x = (k == 0) ? h[q][k].x * x.y : fmaf(h[q][k].x, x.y, po[q][g].x);
-            po[q][g].y = (k == 0) ? h[q][k].y * x.x : fmaf(h[q][k].y, x.x, po[q][g].y);
+            const float2 xw = win[g + R * (A_MT - 1 - k) + (G - 1 - q) * CG];
+            const f2 x = f2{xw.x, xw.y}, hk = f2{h[q][k].x, h[q][k].y};
+            if constexpr (XSWAP) {
+              if (k == 0) po[q][g] = pk_mul_xswap(hk, x);
+              else pk_fma_xswap(po[q][g], hk, x);
+            } else {
+              po[q][g].x = (k == 0) ? hk.x * x.y : fmaf(hk.x, x.y, po[q][g].x);
+              po[q][g].y = (k == 0) ? hk.y * x.x : fmaf(hk.y, x.x, po[q][g].y);
+            }
           }
 #pragma unroll
       for (int q = 0; q < G; q++) {
         const int nn = n0 + q * NPG;
         const int zoff = (nn >> 4) * 17 + (nn & 15);
 #pragma unroll
-        for (int g = 0; g < FPT; g++) { if constexpr (ABL != 3) fbuf[(fg * FPT + g) * FRZ + zoff] = po[q][g]; else asm volatile("" :: "v"(po[q][g].x), "v"(po[q][g].y)); }
+        for (int g = 0; g < FPT; g++) {
+          if constexpr (ABL != 3) fbuf[(fg * FPT + g) * FRZ + zoff] = make_float2(po[q][g].x, po[q][g].y);
+          else asm volatile("" :: "v"(po[q][g]));
+        }
       }
     }
     mark(3);                                                         // polyphase (+ LDS window reads when staged)
@@ -641,9 +652,9 @@ int launch512_bf(const btk_fb* fb, const float* pcm, long nsamples, long pcm_str
   float4* Wq = static_cast<float4*>(scratch);
   // BTK_FUSED_VAR (diagnostics, read once): 1 = register staging with the span and the frames sharing one LDS region (the only
   // form for R = 1, whose 38 KB span leaves no room for a separate region), 3 = LDS-DMA staging of the span,
-  // 7 = polyphase window straight from HBM, only frames and weights in LDS, 15 (default for R = 2) = 7 with the window loads
-  // interleaved with the FFT (31: the other interleaving pattern)
-  const int var = btk_switches().fused_var >= 0 ? btk_switches().fused_var : (R == 2 ? 15 : 3);
+  // 7 = polyphase window straight from HBM, only frames and weights in LDS, 15 = 7 with the window loads interleaved with the FFT
+  // (31: the other interleaving pattern), 79 (default for R = 2) = 15 with the polyphase products' halves crossed by op_sel
+  const int var = btk_switches().fused_var >= 0 ? btk_switches().fused_var : (R == 2 ? 79 : 3);
   const bool pipe = (var & 2) && R >= 2;
   const bool gw = pipe && (var & 4) && R == 2;
   // (TT = 8 -- two wavefronts per workgroup, four workgroups per CU, the same occupancy with less barrier coupling -- measured
@@ -661,7 +672,7 @@ int launch512_bf(const btk_fb* fb, const float* pcm, long nsamples, long pcm_str
   auto kern = pipe ? analysis512_bfz_kernel<R, 3> : analysis512_bfz_kernel<R, 1>;
   if (gw) kern = analysis512_bfz_kernel<2, 7>;
   if (t8) kern = analysis512_bfz_kernel<2, 7, 8>;
-  if (gw && !t8 && (var & 8)) kern = (var & 16) ? analysis512_bfz_kernel<2, 31> : analysis512_bfz_kernel<2, 15>;
+  if (gw && !t8 && (var & 8)) kern = (var & 16) ? analysis512_bfz_kernel<2, 31> : ((var & 64) ? analysis512_bfz_kernel<2, 79> : analysis512_bfz_kernel<2, 15>);
 #ifdef BTK_FUSED_ABLATE
   if (gw && !t8) switch ((var >> 12) & 7) {
     case 1: kern = analysis512_bfz_kernel<2, 15 + 4096 * 1>; break;

@@ -29,6 +29,18 @@ __device__ __forceinline__ f2 cmulv(f2 a, f2 w)       // a w
   asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]" : "=v"(r) : "v"(a), "v"(w), "v"(t));   // + (-a.y w.y, a.y w.x)
   return r;
 }
+// polyphase product of a tap pair with a sample pair: (lo, hi) = (h.lo x.hi, h.hi x.lo) -- the low result takes the HIGH half of x and
+// vice versa through op_sel, so no v_pk_mov swap is needed afterwards (hipcc emits one per output otherwise)
+__device__ __forceinline__ f2 pk_mul_xswap(f2 h, f2 x)
+{
+  f2 r;
+  asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0]" : "=v"(r) : "v"(h), "v"(x));
+  return r;
+}
+__device__ __forceinline__ void pk_fma_xswap(f2& acc, f2 h, f2 x)
+{
+  asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,0,1]" : "+v"(acc) : "v"(h), "v"(x));
+}
 __device__ __forceinline__ f2 cmulc(f2 a, f2 w) { return __builtin_elementwise_fma(a.yy, f2{-w.y, w.x}, a.xx * w); }   // constant w
 __device__ __forceinline__ void acc_conjw_z(f2& A, f2 w, f2 z)          // A += conj(w) z
 {

@@ -19,11 +19,11 @@ PMC_S=32 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc
 mkdir -p $O/pmc_rw && cp -r $O/pmc_fetch $O/pmc_rw/ && cp -r $O/pmc_write $O/pmc_rw/
 python $R/profiles/make_traffic_json.py $O/pmc_rw $O/pmc_traffic.json 32 4096 > /dev/null 2>&1
 cd $R
-BTK_FUSED_VAR=15 bash profiles/scripts/r02_pmc_fused.sh > $O/pmc_fused_sq.txt 2>&1
+BTK_FUSED_VAR=79 bash profiles/scripts/r02_pmc_fused.sh > $O/pmc_fused_sq.txt 2>&1
 for v in 519 515; do BTK_FUSED_VAR=$v python profiles/fused_ab.py 2>&1 | grep -E "phases|ms"; done > $O/fused_phase_timing.txt 2>&1
-VARS="15 7 3 31" bash profiles/scripts/r02_fused_ab.sh > $O/fused_ab.txt 2>&1
+VARS="79 15 7 3" bash profiles/scripts/r02_fused_ab.sh > $O/fused_ab.txt 2>&1
 ( cd profiles/ubench && for b in valu_rate vgpr_bank mfma_rate lds_rate strided_rows; do /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -w -o /tmp/$b $b.hip && echo "== $b" && /tmp/$b; done ) > $O/ubench.txt 2>&1
-for v in 15; do BTK_FUSED_VAR=$v PROBE_SECONDS=6 python profiles/clock_probe.py 2>/dev/null | tail -1; done > $O/clock_probe.txt
+for v in 79; do BTK_FUSED_VAR=$v PROBE_SECONDS=6 python profiles/clock_probe.py 2>/dev/null | tail -1; done > $O/clock_probe.txt
 PROBE_WORK=nlms PROBE_S=32 PROBE_SECONDS=5 python profiles/clock_probe.py 2>/dev/null | tail -1 >> $O/clock_probe.txt
 NLMS_S=32 bash profiles/scripts/r02_pmc_nlms.sh > $O/pmc_nlms_sq.txt 2>&1
 WPE_S=2 bash profiles/scripts/r02_wpe_profile.sh > $O/wpe_profile.txt 2>&1
