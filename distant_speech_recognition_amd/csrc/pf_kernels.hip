@@ -271,6 +271,186 @@ void bf_apply_stats2_kernel(const float2* __restrict__ W, long w_stream_stride, 
   Ee[o] = e;
 }
 
+// ------------------------------------------------------------------------------------------------
+// 4b. bf_apply_stats2_mfma_kernel (N = 32 or 64): the inner products a_j = sum_{i<=j} C[j][i] x'_i of the quadratic forms
+// are a matrix product per bin -- C (N x N, lower triangle, constant) times the snapshots x' (N x frames) -- and run on the
+// fp32 matrix cores (v_mfma_f32_16x16x4_f32: exact fp32 products, fp32 accumulation, as the fmaf chains of the VALU kernel).
+//   rows of a 16x16 block = j, columns = 16 consecutive frames, the contraction runs over the channels i, four per
+//   instruction; real and imaginary parts of x' are two B operands against the same A (a real C, the diffuse-field case: two
+//   instructions per four channels and block; a complex C adds the two cross products).  Only the 10 of 16 blocks on or below
+//   the diagonal are computed (N = 64).
+// The contraction order is free, so the channel a lane feeds into step m is chosen as i(m, g) = 16 (m / 4) + 4 g + m % 4 with
+// g = lane / 16: these are exactly the rows j = 16 jb + 4 g + v the lane receives in accumulator register v of block jb
+// (m = 4 jb + v).  A lane therefore already holds x'_j for every a_j it gets back: the outer sums u = sum_j conj(x'_j) a_j
+// (float64, as in the VALU kernel) need no exchange but two adds across the four lane groups, and the snapshot goes HBM ->
+// registers -> matrix core without touching LDS.  LDS holds the bin's coefficients, transposed and split ([i][j] real /
+// imaginary planes, row stride N + 4: the four rows an operand read touches fall on disjoint bank halves), upper triangle zeroed.
+// A workgroup = MF_NW wavefronts = one (stream, bin) and MF_TPW x MF_NW tiles of 16 frames (the coefficients are staged once per
+// workgroup); the other wavefronts of a SIMD load their tiles while one feeds the matrix core.
+constexpr int MF_TPW = 4;      // tiles per wavefront
+// wavefronts per workgroup (the coefficient planes allow two workgroups per CU): one form = 8, four wavefronts per SIMD in 128
+// VGPRs (2.46 ms against 2.69 with 4 at the C0 shape); two forms = 4, two per SIMD in 232 VGPRs (4.0 ms; with 8 the kernel spills,
+// 4.85 ms, one form after the other 7.1 ms, and six wavefronts land 2-2-1-1 on the SIMDs, 5.9 ms)
+constexpr int mf_nw(int nq) { return nq == 1 ? 8 : 4; }
+
+template <int NQ, int NB /* N / 16 */>
+__global__ __launch_bounds__(64 * mf_nw(NQ), mf_nw(NQ) / 2)       // (HIP: the second number is wavefronts per SIMD)
+void bf_apply_stats2_mfma_kernel(const float2* __restrict__ W, long w_stream_stride, const float2* __restrict__ Dv,
+                                 const float2* __restrict__ X, float2* __restrict__ Y,
+                                 const float2* __restrict__ Cs, const float2* __restrict__ Cv,
+                                 float2* __restrict__ U, float2* __restrict__ V, float* __restrict__ Ee,
+                                 int K, long T_stride, long T)
+{
+  typedef float v4f __attribute__((ext_vector_type(4)));
+  typedef float v2f __attribute__((ext_vector_type(2)));
+  constexpr int N = 16 * NB, LD = N + 4, M4 = N / 4, MF_NW = mf_nw(NQ);
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* ctr = reinterpret_cast<float*>(smem);                  // [NQ][N][LD] real parts, [i][j]
+  float* cti = ctr + NQ * N * LD;                               // [NQ][N][LD] imaginary parts
+  float2* ws = reinterpret_cast<float2*>(cti + NQ * N * LD);    // [N] beamformer weights
+  float2* ds = ws + N;                                          // [N] alignment vector
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int k = blockIdx.y, s = blockIdx.z;
+  const int n = lane & 15, g = lane >> 4;
+
+  int im = 0;
+#pragma unroll
+  for (int q = 0; q < NQ; q++) {
+    const float2* c = (q == 0 ? Cs : Cv) + (long)k * N * N;
+    for (int idx = tid; idx < N * N; idx += 64 * MF_NW) {
+      const int j = idx / N, i = idx % N;                       // C[j][i], i <= j used (the reference reads nothing else of a row either)
+      float2 v = c[idx];
+      if (i > j) v = make_float2(0.f, 0.f);
+      im |= (v.y != 0.f);
+      ctr[(q * N + i) * LD + j] = v.x;
+      cti[(q * N + i) * LD + j] = v.y;
+    }
+  }
+  if (tid < N) {
+    ws[tid] = W[s * w_stream_stride + (long)k * N + tid];
+    ds[tid] = Dv[s * w_stream_stride + (long)k * N + tid];
+  }
+  const bool complex_c = __syncthreads_or(im) != 0;
+
+  const float2* xk = X + ((long)s * K + k) * N * T_stride;
+  const long f0 = (long)blockIdx.x * (MF_NW * MF_TPW * 16);
+  auto chan = [&](int m) { return 16 * (m >> 2) + 4 * g + (m & 3); };
+  float2 xv[M4];
+  long t0 = f0 + __builtin_amdgcn_readfirstlane(wave) * 16;
+#pragma unroll 1
+  for (int q = 0; q < MF_TPW && t0 < T; q++, t0 += MF_NW * 16) {
+    {
+      // row pointers are wave-uniform (SGPR pair), the lane adds one 32-bit byte offset (its group's 4 rows and its frame,
+      // clamped into the block for a ragged last tile: those columns are never stored): global_load with an SGPR base from
+      // inline asm -- hipcc builds per-lane 64-bit addresses for the same loads.  The loads are invisible to hipcc's
+      // counters: every value passes through an asm behind the wait.
+      const long tl = (t0 + n < T) ? n : (T - 1 - t0);
+      const unsigned vb = ((unsigned)(4 * g) * (unsigned)T_stride + (unsigned)tl) * 8u;
+      v2f raw[M4];
+#pragma unroll
+      for (int m = 0; m < M4; m++) {
+        const float2* rowp = xk + (long)(16 * (m >> 2) + (m & 3)) * T_stride + t0;
+        asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(raw[m]) : "v"(vb), "s"(rowp) : "memory");
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int m = 0; m < M4; m++) { asm volatile("" : "+v"(raw[m])); xv[m] = make_float2(raw[m].x, raw[m].y); }
+    }
+    // (the weights and coefficients in LDS do not change from tile to tile: an opaque zero in their addresses keeps hipcc
+    //  from hoisting the loop-invariant LDS reads out of the tile loop and spilling them)
+    int lo = 0;
+    asm volatile("" : "+s"(lo));
+    // y = w^H x, x' = conj(d) x, e = sum |x'|^2 over this lane group's channels
+    float yr = 0.f, yi = 0.f, e = 0.f;
+#pragma unroll
+    for (int m = 0; m < M4; m++) {
+      const int i = chan(m) + lo;
+      const float2 wn = ws[i], dn = ds[i], v = xv[m];
+      yr = fmaf(wn.x, v.x, fmaf(wn.y, v.y, yr));
+      yi = fmaf(wn.x, v.y, fmaf(-wn.y, v.x, yi));
+      const float ar = fmaf(dn.x, v.x, dn.y * v.y), ai = fmaf(dn.x, v.y, -dn.y * v.x);
+      e = fmaf(ar, ar, fmaf(ai, ai, e));
+      xv[m] = make_float2(ar, ai);
+      // four channels' weights in flight, not all of them: the sums are pinned here, or hipcc parks the weights in scratch
+      // and forms y after the matrix instructions
+      if ((m & 3) == 3) asm volatile("" : "+v"(yr), "+v"(yi), "+v"(e));
+    }
+    double ur = 0.0, ui = 0.0, vr = 0.0, vi = 0.0;
+#pragma unroll
+    for (int jb = 0; jb < NB; jb++) {
+      v4f are[NQ], aim[NQ];
+#pragma unroll
+      for (int f = 0; f < NQ; f++) { are[f] = v4f{0.f, 0.f, 0.f, 0.f}; aim[f] = v4f{0.f, 0.f, 0.f, 0.f}; }
+      const int mend = 4 * (jb + 1);                           // channels i < 16 (jb + 1): the blocks right of the diagonal are zero
+      if (!complex_c) {
+#pragma unroll
+        for (int m = 0; m < mend; m++) {
+          const int off = chan(m) * LD + jb * 16 + n + lo;
+#pragma unroll
+          for (int f = 0; f < NQ; f++) {
+            const float a = ctr[f * N * LD + off];
+            are[f] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, xv[m].x, are[f], 0, 0, 0);
+            aim[f] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, xv[m].y, aim[f], 0, 0, 0);
+          }
+        }
+      } else {
+#pragma unroll
+        for (int m = 0; m < mend; m++) {
+          const int off = chan(m) * LD + jb * 16 + n + lo;
+#pragma unroll
+          for (int f = 0; f < NQ; f++) {
+            const float a = ctr[f * N * LD + off], b = cti[f * N * LD + off];
+            are[f] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, xv[m].x, are[f], 0, 0, 0);
+            aim[f] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, xv[m].y, aim[f], 0, 0, 0);
+            are[f] = __builtin_amdgcn_mfma_f32_16x16x4f32(b, -xv[m].y, are[f], 0, 0, 0);
+            aim[f] = __builtin_amdgcn_mfma_f32_16x16x4f32(b, xv[m].x, aim[f], 0, 0, 0);
+          }
+        }
+      }
+#pragma unroll
+      for (int v = 0; v < 4; v++) {
+        const double xr = xv[4 * jb + v].x, xi = xv[4 * jb + v].y;         // x'_j of accumulator row v (see the channel map)
+        ur = fma(xr, (double)are[0][v], fma(xi, (double)aim[0][v], ur));           // += conj(x'_j) a_j, two chained multiply-adds per part
+        ui = fma(xr, (double)aim[0][v], fma(-xi, (double)are[0][v], ui));
+        if (NQ == 2) {
+          vr = fma(xr, (double)are[NQ - 1][v], fma(xi, (double)aim[NQ - 1][v], vr));
+          vi = fma(xr, (double)aim[NQ - 1][v], fma(-xi, (double)are[NQ - 1][v], vi));
+        }
+      }
+    }
+#pragma unroll
+    for (int sh = 16; sh <= 32; sh *= 2) {
+      yr += __shfl_xor(yr, sh, 64); yi += __shfl_xor(yi, sh, 64); e += __shfl_xor(e, sh, 64);
+      ur += __shfl_xor(ur, sh, 64); ui += __shfl_xor(ui, sh, 64);
+      if (NQ == 2) { vr += __shfl_xor(vr, sh, 64); vi += __shfl_xor(vi, sh, 64); }
+    }
+    const long t = t0 + n;
+    if (g == 0 && t < T) {
+      const long o = ((long)s * K + k) * T_stride + t;
+      Y[o] = make_float2(yr, yi);
+      U[o] = make_float2((float)ur, (float)ui);
+      if (NQ == 2) V[o] = make_float2((float)vr, (float)vi);
+      Ee[o] = e;
+    }
+  }
+}
+
+template <int NQ, int NB>
+int launch_stats2_mfma(const float2* W, long wss, const float2* D, const float2* X, float2* Y, const float2* Cs, const float2* Cv,
+                       float2* U, float2* V, float* E, int S, int K, long T_stride, long T, hipStream_t st)
+{
+  constexpr int N = 16 * NB;
+  const size_t lds = sizeof(float) * 2 * NQ * N * (N + 4) + sizeof(float2) * 2 * N;
+  auto kern = bf_apply_stats2_mfma_kernel<NQ, NB>;
+  BTK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  constexpr int MF_NW = mf_nw(NQ);
+  const long per_wg = (long)MF_NW * MF_TPW * 16;
+  hipLaunchKernelGGL(kern, dim3((unsigned)((T + per_wg - 1) / per_wg), (unsigned)K, (unsigned)S), dim3(64 * MF_NW), lds, st,
+                     W, wss, D, X, Y, Cs, Cv, U, V, E, K, T_stride, T);
+  BTK_HIP_CHECK(hipGetLastError());
+  return BTK_OK;
+}
+
 // One wavefront per (s,k): W = g(U) / (g(U) + g(V) / Lambda_k), Lambda_k = 1 for k < fbinX1 (postfilter.cc:1122-1135)
 __global__ __launch_bounds__(64)
 void lefkimmiatis_iir_kernel(float2* __restrict__ Y, const float2* __restrict__ Uc, const float2* __restrict__ Vc,
@@ -388,6 +568,17 @@ int btk_bf_apply_stats2(const void* W, const void* D, int per_stream_weights, co
   // rows of C per register block: 16 rows x two forms overflow the SGPR file (the C entries are scalar loads) and
   // N <= 8 wastes half of a 16-row block; measured in profiles/pf_ab.py.  BTK_PF_JB overrides (benchmarking only).
   const int jb_env = btk_switches().pf_jb;
+  // N = 32 / 64: the coefficient products on the matrix cores (BTK_PF_JB set = the VALU kernel, for the A/B in profiles/)
+  if (!jb_env && (N == 32 || N == 64) && (long)N * T_stride * 8 < (1L << 31)) {
+    const float2 *Wp = static_cast<const float2*>(W), *Dp = static_cast<const float2*>(D), *Xp = static_cast<const float2*>(X);
+    const float2 *Csp = static_cast<const float2*>(Cs), *Cvp = static_cast<const float2*>(Cv);
+    float2 *Yp = static_cast<float2*>(Y), *Up = static_cast<float2*>(U), *Vp = static_cast<float2*>(V);
+    hipStream_t st = as_stream(stream);
+    if (Cv) return N == 64 ? launch_stats2_mfma<2, 4>(Wp, wss, Dp, Xp, Yp, Csp, Cvp, Up, Vp, E, S, K, T_stride, T, st)
+                           : launch_stats2_mfma<2, 2>(Wp, wss, Dp, Xp, Yp, Csp, Cvp, Up, Vp, E, S, K, T_stride, T, st);
+    return N == 64 ? launch_stats2_mfma<1, 4>(Wp, wss, Dp, Xp, Yp, Csp, Cvp, Up, Vp, E, S, K, T_stride, T, st)
+                   : launch_stats2_mfma<1, 2>(Wp, wss, Dp, Xp, Yp, Csp, Cvp, Up, Vp, E, S, K, T_stride, T, st);
+  }
   const int jb = jb_env ? jb_env : (Cv ? 8 : (N <= 8 ? 8 : 16));
   if (Cv && jb == 16)
     hipLaunchKernelGGL((bf_apply_stats2_kernel<2, 16>), grid, dim3(PF_NT), 0, as_stream(stream),

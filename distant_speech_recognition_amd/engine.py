@@ -593,44 +593,51 @@ class CoherencePostFilterState:
         return int(fb.item())
 
 
-def bf_apply_mccowan(W, D, X, state, alpha=0.6, type_=2, min_frames=0, out=None):
-    """Beamform + McCowan post-filter over a block.  W, D complex64 [S|1][K][N]; X [S][K][N][T] -> Y [S][K][T]."""
-    _need_cuda(W, "W"); _need_cuda(D, "D"); _need_cuda(X, "X")
+def _pf_args(W, D, X, out):
+    """Shape / dtype / row-stride checks shared by the coherence post-filters; returns (T_stride, S, K, N, T, W, D, out)."""
+    ts = _check(X, "X", torch.complex64, 4, rows=True)
     S, K, N, T = X.shape
-    if state.Cs is None:
-        raise _lib.BtkError(_lib.BTK_ERR_PARAMETER, "McCowanPostFilter:  construct/set a noise coherence matrix")
     if W.dim() == 2:
         W, D = W.unsqueeze(0), D.unsqueeze(0)
+    _check(W, "W", torch.complex64, (None, K, N)); _check(D, "D", torch.complex64, tuple(W.shape))
+    if W.shape[0] not in (1, S):
+        raise _lib.BtkError(_lib.BTK_ERR_DIMENSION, "weights %s do not match X %s" % (tuple(W.shape), tuple(X.shape)))
     if out is None:
-        out = torch.empty((S, K, T), dtype=torch.complex64, device=X.device)
-    U = torch.empty((S, K, T), dtype=torch.complex64, device=X.device)
-    Ee = torch.empty((S, K, T), dtype=torch.float32, device=X.device)
+        out = rows_like(X, (S, K, T))
+    if _check(out, "Y", torch.complex64, (S, K, T), rows=True) != ts:
+        raise _lib.BtkError(_lib.BTK_ERR_DIMENSION, "Y rows are %d frames apart, X rows %d: they share T_stride" % (out.stride(-2), ts))
+    return ts, S, K, N, T, W, D, out
+
+
+def bf_apply_mccowan(W, D, X, state, alpha=0.6, type_=2, min_frames=0, out=None):
+    """Beamform + McCowan post-filter over a block.  W, D complex64 [S|1][K][N]; X [S][K][N][T] -> Y [S][K][T].  X may be a
+    row-padded view (analysis(pad_rows=True)); Y and the per-frame statistics then share its row stride."""
+    ts, S, K, N, T, W, D, out = _pf_args(W, D, X, out)
+    if state.Cs is None:
+        raise _lib.BtkError(_lib.BTK_ERR_PARAMETER, "McCowanPostFilter:  construct/set a noise coherence matrix")
+    U = rows_like(X, (S, K, T))
+    Ee = rows_like(X, (S, K, T), dtype=torch.float32)
     L = _lib.lib()
     check(L.btk_bf_apply_stats2(_ptr(W), _ptr(D), int(W.shape[0] == S and S > 1), _ptr(X), _ptr(out), _ptr(state.Cs), None,
-                                _ptr(U), None, _ptr(Ee), S, K, N, T, T, _stream()))
-    check(L.btk_zelinski_process(_ptr(out), _ptr(U), _ptr(Ee), S, K, N, T, T, float(alpha), int(type_) & 3, int(min_frames),
+                                _ptr(U), None, _ptr(Ee), S, K, N, ts, T, _stream()))
+    check(L.btk_zelinski_process(_ptr(out), _ptr(U), _ptr(Ee), S, K, N, ts, T, float(alpha), int(type_) & 3, int(min_frames),
                                  state.frames_done, _ptr(state.u), _ptr(state.psi), _ptr(state.w_last), _stream()))
     state.frames_done += T
     return out
 
 
 def bf_apply_lefkimmiatis(W, D, X, state, fbin_x1=0, alpha=0.6, type_=2, min_frames=0, out=None):
-    """Beamform + Lefkimmiatis post-filter over a block (D = array manifold)."""
-    _need_cuda(W, "W"); _need_cuda(D, "D"); _need_cuda(X, "X")
-    S, K, N, T = X.shape
+    """Beamform + Lefkimmiatis post-filter over a block (D = array manifold); X may be a row-padded view as for McCowan."""
+    ts, S, K, N, T, W, D, out = _pf_args(W, D, X, out)
     if state.Cs is None or state.Cv is None or state.lam is None:
         raise _lib.BtkError(_lib.BTK_ERR_PARAMETER, "LefkimmiatisPostFilter:  construct/set a noise coherence matrix")
-    if W.dim() == 2:
-        W, D = W.unsqueeze(0), D.unsqueeze(0)
-    if out is None:
-        out = torch.empty((S, K, T), dtype=torch.complex64, device=X.device)
-    U = torch.empty((S, K, T), dtype=torch.complex64, device=X.device)
-    V = torch.empty((S, K, T), dtype=torch.complex64, device=X.device)
-    Ee = torch.empty((S, K, T), dtype=torch.float32, device=X.device)
+    U = rows_like(X, (S, K, T))
+    V = rows_like(X, (S, K, T))
+    Ee = rows_like(X, (S, K, T), dtype=torch.float32)
     L = _lib.lib()
     check(L.btk_bf_apply_stats2(_ptr(W), _ptr(D), int(W.shape[0] == S and S > 1), _ptr(X), _ptr(out), _ptr(state.Cs),
-                                _ptr(state.Cv), _ptr(U), _ptr(V), _ptr(Ee), S, K, N, T, T, _stream()))
-    check(L.btk_lefkimmiatis_process(_ptr(out), _ptr(U), _ptr(V), _ptr(state.lam), int(fbin_x1), S, K, N, T, T, float(alpha),
+                                _ptr(state.Cv), _ptr(U), _ptr(V), _ptr(Ee), S, K, N, ts, T, _stream()))
+    check(L.btk_lefkimmiatis_process(_ptr(out), _ptr(U), _ptr(V), _ptr(state.lam), int(fbin_x1), S, K, N, ts, T, float(alpha),
                                      int(type_), int(min_frames), state.frames_done, _ptr(state.u), _ptr(state.v),
                                      _ptr(state.w_last), _stream()))
     state.frames_done += T

@@ -240,7 +240,7 @@ def _coherent_snapshots(rng, S, K, N, T):
 
 
 @pytest.mark.parametrize("N,M,T,type_,minf,load", [(4, 256, 120, 2, 0, 0.01), (8, 64, 70, 1, 0, 0.01), (64, 64, 40, 2, 5, 0.0),
-                                                  (5, 128, 90, 10, 0, 0.05), (20, 64, 50, 2, 0, 0.01)])
+                                                  (5, 128, 90, 10, 0, 0.05), (20, 64, 50, 2, 0, 0.01), (32, 64, 45, 2, 0, 0.01)])
 def test_mccowan_matches_oracle(orc, dev, N, M, T, type_, minf, load):
     """McCowanPostFilter (postfilter.cc:798-935) over a delay-and-sum beamformer, diffuse-noise coherence
     (confs/sd_and_mccowan.json shape), two consecutive blocks."""
@@ -279,7 +279,7 @@ def test_mccowan_matches_oracle(orc, dev, N, M, T, type_, minf, load):
 
 
 @pytest.mark.parametrize("N,M,T,type_,minf,x1", [(4, 256, 120, 2, 0, 100), (8, 64, 70, 1, 0, 10), (33, 64, 40, 2, 3, 0),
-                                                (6, 128, 90, 2, 0, 200)])
+                                                (6, 128, 90, 2, 0, 200), (64, 64, 40, 2, 0, 5), (32, 64, 50, 2, 2, 5)])
 def test_lefkimmiatis_matches_oracle(orc, dev, N, M, T, type_, minf, x1):
     """LefkimmiatisPostFilter (postfilter.cc:967-1190), confs/sd_and_lefkimmiatis.json shape (alpha 0.8, min_sv 1e-4)."""
     import torch
@@ -335,3 +335,83 @@ def test_cov_accumulate_on_row_padded_snapshots(dev):
         assert torch.equal(eng.cov_accumulate(Xc, frame_weights=fw), eng.cov_accumulate(Xp, frame_weights=fwp))
         with pytest.raises(Exception):
             eng.cov_accumulate(Xp, frame_weights=fw)             # contiguous weights cannot share the padded T_stride
+
+
+@pytest.mark.parametrize("N,T,nq,cplx,pad", [(64, 37, 1, False, False), (64, 530, 2, False, True), (32, 100, 2, False, False),
+                                             (64, 75, 2, True, True), (32, 16, 1, True, False), (20, 50, 2, True, False)])
+def test_stats2_quadratic_forms_against_their_definition(dev, N, T, nq, cplx, pad):
+    """btk_bf_apply_stats2 (the per-frame sums behind McCowan / Lefkimmiatis, postfilter.cc:798-829, 1041-1077) against
+    u_t = sum_{i<=j} Cs[j][i] x'_i conj(x'_j) evaluated in float64: the matrix-core kernel (N = 32, 64; real and complex
+    pair weights, one and two forms, ragged tiles, row-padded snapshots) and the VALU kernel (other N)."""
+    import torch
+    from distant_speech_recognition_amd import _lib, engine as eng
+    rng = np.random.default_rng(N * 7 + T + nq)
+    S, K = 2, 5
+    Xh = ((rng.normal(size=(S, K, N, T)) + 1j * rng.normal(size=(S, K, N, T))) * 1500.0).astype(np.complex64)
+    Xh += ((rng.normal(size=(S, K, 1, T)) + 1j * rng.normal(size=(S, K, 1, T))) * 2500.0).astype(np.complex64)
+    if pad:
+        X = torch.zeros((S, K, N, T + 48), dtype=torch.complex64, device=dev)[..., :T]      # rows as engine.padded_rows lays them out
+        X.copy_(torch.from_numpy(Xh))
+    else:
+        X = torch.from_numpy(Xh).to(dev)
+    Ts = X.stride(2)
+    W = (rng.normal(size=(1, K, N)) + 1j * rng.normal(size=(1, K, N))).astype(np.complex64) / N
+    D = np.exp(1j * rng.uniform(0, 2 * np.pi, size=(1, K, N))).astype(np.complex64)
+    # pair weights as btk_pf_coherence_coeffs lays them out: row j holds i <= j, zeros right of the diagonal
+    C = [np.tril(rng.normal(size=(K, N, N)) + (1j * rng.normal(size=(K, N, N)) if cplx else 0)).astype(np.complex64) for _ in range(nq)]
+    Wd, Dd = torch.from_numpy(W).to(dev), torch.from_numpy(D).to(dev)
+    Cd = [torch.from_numpy(c).to(dev) for c in C]
+    Y = torch.zeros((S, K, Ts), dtype=torch.complex64, device=dev)
+    U = torch.zeros_like(Y)
+    V = torch.zeros_like(Y) if nq == 2 else None
+    E = torch.zeros((S, K, Ts), dtype=torch.float32, device=dev)
+    p = lambda t: None if t is None else t.data_ptr()
+    _lib.check(_lib.lib().btk_bf_apply_stats2(p(Wd), p(Dd), 0, p(X), p(Y), p(Cd[0]), p(Cd[1]) if nq == 2 else None, p(U), p(V), p(E),
+                                              S, K, N, Ts, T, torch.cuda.current_stream().cuda_stream))
+    torch.cuda.synchronize()
+    X64 = Xh.astype(np.complex128)
+    xp = np.conj(D[0].astype(np.complex128))[None, :, :, None] * X64                         # x' = conj(d) x
+    yref = np.einsum("kn,sknt->skt", np.conj(W[0].astype(np.complex128)), X64)
+    eref = np.sum(np.abs(xp) ** 2, axis=2)
+    assert np.max(np.abs(Y.cpu().numpy()[..., :T] - yref)) <= 2e-6 * np.sqrt(N) * np.max(np.abs(yref))
+    assert np.max(np.abs(E.cpu().numpy()[..., :T] - eref)) <= 1e-5 * np.max(eref)
+    for got, c in zip((U, V), C):
+        L = np.tril(c.astype(np.complex128))                                                 # row j holds i <= j
+        ref = np.einsum("skjt,kji,skit->skt", np.conj(xp), L, xp)
+        # fp32 inner products of N terms of magnitude |C| |x'|^2, float64 outer sums
+        scale = np.max(np.einsum("skjt,kji,skit->skt", np.abs(xp), np.abs(L), np.abs(xp)))
+        assert np.max(np.abs(got.cpu().numpy()[..., :T] - ref)) <= 1e-6 * scale
+    if Ts > T:
+        assert float(torch.abs(U[..., T:]).max()) == 0.0                                     # nothing written past the last frame
+
+
+@pytest.mark.parametrize("N", [8, 64])
+def test_coherence_postfilters_on_row_padded_snapshots(dev, N):
+    """bf_apply_mccowan / bf_apply_lefkimmiatis take row-padded snapshots (engine.padded_rows, analysis(pad_rows=True)): the same
+    numbers as on contiguous rows, Y sharing the row stride of X."""
+    import torch
+    from distant_speech_recognition_amd import engine as eng
+    rng = np.random.default_rng(99 + N)
+    S, M, T = 2, 64, 512                                     # 512 frames x 8 B = 4 KiB rows: padded_rows pads them
+    K = M // 2 + 1
+    Xh = _coherent_snapshots(rng, S, K, N, T)
+    Xc = torch.from_numpy(Xh).to(dev)
+    Xp = eng.padded_rows((S, K, N, T), torch.complex64, dev)
+    assert Xp.stride(2) > T
+    Xp.copy_(Xc)
+    mpos = ula_positions(N, 40.0)
+    d = torch.from_numpy(np.exp(-2j * np.pi * rng.uniform(size=(K, N))).astype(np.complex64) / N).to(dev)
+    R = eng.mvdr_diffuse_model(mpos, M, 16000.0, device=dev)
+    eng.mvdr_diagonal_loading(R, 0.05)
+    for lef in (False, True):
+        outs = []
+        for X in (Xc, Xp):
+            st = eng.CoherencePostFilterState(S, K, N, dev, lefkimmiatis=lef)
+            st.set_coherence(R, 0.99)
+            if lef:
+                st.set_lambda(R, d, 1.0e-4)
+                outs.append(eng.bf_apply_lefkimmiatis(d, d, X, st, fbin_x1=3, alpha=0.8))
+            else:
+                outs.append(eng.bf_apply_mccowan(d, d, X, st, alpha=0.7))
+        assert outs[1].stride(1) == Xp.stride(2) and outs[0].is_contiguous()
+        assert torch.equal(outs[0], outs[1])
