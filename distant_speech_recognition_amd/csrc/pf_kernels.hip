@@ -343,7 +343,7 @@ void bf_apply_stats2_mfma_kernel(const float2* __restrict__ W, long w_stream_str
       // row pointers are wave-uniform (SGPR pair), the lane adds one 32-bit byte offset (its group's 4 rows and its frame,
       // clamped into the block for a ragged last tile: those columns are never stored): global_load with an SGPR base from
       // inline asm -- hipcc builds per-lane 64-bit addresses for the same loads.  The loads are invisible to hipcc's
-      // counters: every value passes through an asm behind the wait.
+      // counters, hence the explicit wait below.
       const long tl = (t0 + n < T) ? n : (T - 1 - t0);
       const unsigned vb = ((unsigned)(4 * g) * (unsigned)T_stride + (unsigned)tl) * 8u;
       v2f raw[M4];
@@ -352,9 +352,17 @@ void bf_apply_stats2_mfma_kernel(const float2* __restrict__ W, long w_stream_str
         const float2* rowp = xk + (long)(16 * (m >> 2) + (m & 3)) * T_stride + t0;
         asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(raw[m]) : "v"(vb), "s"(rowp) : "memory");
       }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      // every loaded value is an in/out operand of the wait: its register carries it across, hipcc cannot read it earlier
+      static_assert(M4 == 8 || M4 == 16, "operand lists below");
+      if constexpr (M4 == 16)
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(raw[0]), "+v"(raw[1]), "+v"(raw[2]), "+v"(raw[3]), "+v"(raw[4]), "+v"(raw[5]), "+v"(raw[6]),
+                     "+v"(raw[7]), "+v"(raw[8]), "+v"(raw[9]), "+v"(raw[10]), "+v"(raw[11]), "+v"(raw[12]), "+v"(raw[13]), "+v"(raw[14]),
+                     "+v"(raw[15]) :: "memory");
+      else
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(raw[0]), "+v"(raw[1]), "+v"(raw[2]), "+v"(raw[3]), "+v"(raw[4]), "+v"(raw[5]), "+v"(raw[6]),
+                     "+v"(raw[7]) :: "memory");
 #pragma unroll
-      for (int m = 0; m < M4; m++) { asm volatile("" : "+v"(raw[m])); xv[m] = make_float2(raw[m].x, raw[m].y); }
+      for (int m = 0; m < M4; m++) xv[m] = make_float2(raw[m].x, raw[m].y);
     }
     // (the weights and coefficients in LDS do not change from tile to tile: an opaque zero in their addresses keeps hipcc
     //  from hoisting the loop-invariant LDS reads out of the tile loop and spilling them)
