@@ -24,6 +24,7 @@ const btk_switches_t& btk_switches()
     s.nlms_v1 = flag("BTK_NLMS_V1"); s.wpe_noskip = flag("BTK_WPE_NOSKIP"); s.wpe_timing = flag("BTK_WPE_TIMING");
     s.nlms_alt = num("BTK_NLMS_ALT", 0); s.fused_var = num("BTK_FUSED_VAR", -1);
     s.pf_jb = num("BTK_PF_JB", 0);
+    s.pf_tpw = num("BTK_PF_TPW", 0);
     return s;
   }();                                                   // C++11 magic static: initialised once, thread-safe
   return sw;

@@ -287,7 +287,7 @@ void bf_apply_stats2_kernel(const float2* __restrict__ W, long w_stream_stride, 
 // imaginary planes, row stride N + 4: the four rows an operand read touches fall on disjoint bank halves), upper triangle zeroed.
 // A workgroup = MF_NW wavefronts = one (stream, bin) and MF_TPW x MF_NW tiles of 16 frames (the coefficients are staged once per
 // workgroup); the other wavefronts of a SIMD load their tiles while one feeds the matrix core.
-constexpr int MF_TPW = 4;      // tiles per wavefront
+constexpr int MF_TPW = 8;      // tiles per wavefront: 4 / 8 / 16 / 32 -> 2.61 / 2.51 / 2.54 / 2.55 ms (one form), 4.42 / 4.11 / 4.08 / 4.11 (two); BTK_PF_TPW overrides
 // wavefronts per workgroup (the coefficient planes allow two workgroups per CU): one form = 8, four wavefronts per SIMD in 128
 // VGPRs (2.46 ms against 2.69 with 4 at the C0 shape); two forms = 4, two per SIMD in 232 VGPRs (4.0 ms; with 8 the kernel spills,
 // 4.85 ms, one form after the other 7.1 ms, and six wavefronts land 2-2-1-1 on the SIMDs, 5.9 ms)
@@ -299,7 +299,7 @@ void bf_apply_stats2_mfma_kernel(const float2* __restrict__ W, long w_stream_str
                                  const float2* __restrict__ X, float2* __restrict__ Y,
                                  const float2* __restrict__ Cs, const float2* __restrict__ Cv,
                                  float2* __restrict__ U, float2* __restrict__ V, float* __restrict__ Ee,
-                                 int K, long T_stride, long T)
+                                 int K, long T_stride, long T, int tpw)
 {
   typedef float v4f __attribute__((ext_vector_type(4)));
   typedef float v2f __attribute__((ext_vector_type(2)));
@@ -333,12 +333,12 @@ void bf_apply_stats2_mfma_kernel(const float2* __restrict__ W, long w_stream_str
   const bool complex_c = __syncthreads_or(im) != 0;
 
   const float2* xk = X + ((long)s * K + k) * N * T_stride;
-  const long f0 = (long)blockIdx.x * (MF_NW * MF_TPW * 16);
+  const long f0 = (long)blockIdx.x * (MF_NW * tpw * 16);
   auto chan = [&](int m) { return 16 * (m >> 2) + 4 * g + (m & 3); };
   float2 xv[M4];
   long t0 = f0 + __builtin_amdgcn_readfirstlane(wave) * 16;
 #pragma unroll 1
-  for (int q = 0; q < MF_TPW && t0 < T; q++, t0 += MF_NW * 16) {
+  for (int q = 0; q < tpw && t0 < T; q++, t0 += MF_NW * 16) {
     {
       // row pointers are wave-uniform (SGPR pair), the lane adds one 32-bit byte offset (its group's 4 rows and its frame,
       // clamped into the block for a ragged last tile: those columns are never stored): global_load with an SGPR base from
@@ -452,9 +452,10 @@ int launch_stats2_mfma(const float2* W, long wss, const float2* D, const float2*
   auto kern = bf_apply_stats2_mfma_kernel<NQ, NB>;
   BTK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   constexpr int MF_NW = mf_nw(NQ);
-  const long per_wg = (long)MF_NW * MF_TPW * 16;
+  const int tpw = btk_switches().pf_tpw > 0 ? btk_switches().pf_tpw : MF_TPW;
+  const long per_wg = (long)MF_NW * tpw * 16;
   hipLaunchKernelGGL(kern, dim3((unsigned)((T + per_wg - 1) / per_wg), (unsigned)K, (unsigned)S), dim3(64 * MF_NW), lds, st,
-                     W, wss, D, X, Y, Cs, Cv, U, V, E, K, T_stride, T);
+                     W, wss, D, X, Y, Cs, Cv, U, V, E, K, T_stride, T, tpw);
   BTK_HIP_CHECK(hipGetLastError());
   return BTK_OK;
 }
