@@ -272,7 +272,7 @@ void bf_apply_stats2_kernel(const float2* __restrict__ W, long w_stream_stride, 
 }
 
 // ------------------------------------------------------------------------------------------------
-// 4b. bf_apply_stats2_mfma_kernel (N = 32 or 64): the inner products a_j = sum_{i<=j} C[j][i] x'_i of the quadratic forms
+// 4b. bf_apply_stats2_mfma_kernel (N = 16, 32, 48, 64): the inner products a_j = sum_{i<=j} C[j][i] x'_i of the quadratic forms
 // are a matrix product per bin -- C (N x N, lower triangle, constant) times the snapshots x' (N x frames) -- and run on the
 // fp32 matrix cores (v_mfma_f32_16x16x4_f32: exact fp32 products, fp32 accumulation, as the fmaf chains of the VALU kernel).
 //   rows of a 16x16 block = j, columns = 16 consecutive frames, the contraction runs over the channels i, four per
@@ -352,15 +352,13 @@ void bf_apply_stats2_mfma_kernel(const float2* __restrict__ W, long w_stream_str
         const float2* rowp = xk + (long)(16 * (m >> 2) + (m & 3)) * T_stride + t0;
         asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(raw[m]) : "v"(vb), "s"(rowp) : "memory");
       }
-      // every loaded value is an in/out operand of the wait: its register carries it across, hipcc cannot read it earlier
-      static_assert(M4 == 8 || M4 == 16, "operand lists below");
-      if constexpr (M4 == 16)
-        asm volatile("s_waitcnt vmcnt(0)" : "+v"(raw[0]), "+v"(raw[1]), "+v"(raw[2]), "+v"(raw[3]), "+v"(raw[4]), "+v"(raw[5]), "+v"(raw[6]),
-                     "+v"(raw[7]), "+v"(raw[8]), "+v"(raw[9]), "+v"(raw[10]), "+v"(raw[11]), "+v"(raw[12]), "+v"(raw[13]), "+v"(raw[14]),
-                     "+v"(raw[15]) :: "memory");
-      else
-        asm volatile("s_waitcnt vmcnt(0)" : "+v"(raw[0]), "+v"(raw[1]), "+v"(raw[2]), "+v"(raw[3]), "+v"(raw[4]), "+v"(raw[5]), "+v"(raw[6]),
-                     "+v"(raw[7]) :: "memory");
+      // every loaded value is an in/out operand of the wait (of an empty asm right behind it from the fifth on; volatile asms keep
+      // their order): its register carries it across, hipcc has no use of it that could be scheduled earlier
+#pragma unroll
+      for (int c = 0; c < NB; c++) {
+        if (c == 0) asm volatile("s_waitcnt vmcnt(0)" : "+v"(raw[0]), "+v"(raw[1]), "+v"(raw[2]), "+v"(raw[3]) :: "memory");
+        else asm volatile("" : "+v"(raw[4 * c]), "+v"(raw[4 * c + 1]), "+v"(raw[4 * c + 2]), "+v"(raw[4 * c + 3]) :: "memory");
+      }
 #pragma unroll
       for (int m = 0; m < M4; m++) xv[m] = make_float2(raw[m].x, raw[m].y);
     }
@@ -577,16 +575,22 @@ int btk_bf_apply_stats2(const void* W, const void* D, int per_stream_weights, co
   // rows of C per register block: 16 rows x two forms overflow the SGPR file (the C entries are scalar loads) and
   // N <= 8 wastes half of a 16-row block; measured in profiles/pf_ab.py.  BTK_PF_JB overrides (benchmarking only).
   const int jb_env = btk_switches().pf_jb;
-  // N = 32 / 64: the coefficient products on the matrix cores (BTK_PF_JB set = the VALU kernel, for the A/B in profiles/)
-  if (!jb_env && (N == 32 || N == 64) && (long)N * T_stride * 8 < (1L << 31)) {
+  // N = 16, 32, 48, 64: the coefficient products on the matrix cores (BTK_PF_JB set = the VALU kernel, for the A/B in profiles/)
+  if (!jb_env && N % 16 == 0 && N <= 64 && (long)N * T_stride * 8 < (1L << 31)) {
     const float2 *Wp = static_cast<const float2*>(W), *Dp = static_cast<const float2*>(D), *Xp = static_cast<const float2*>(X);
     const float2 *Csp = static_cast<const float2*>(Cs), *Cvp = static_cast<const float2*>(Cv);
     float2 *Yp = static_cast<float2*>(Y), *Up = static_cast<float2*>(U), *Vp = static_cast<float2*>(V);
     hipStream_t st = as_stream(stream);
-    if (Cv) return N == 64 ? launch_stats2_mfma<2, 4>(Wp, wss, Dp, Xp, Yp, Csp, Cvp, Up, Vp, E, S, K, T_stride, T, st)
-                           : launch_stats2_mfma<2, 2>(Wp, wss, Dp, Xp, Yp, Csp, Cvp, Up, Vp, E, S, K, T_stride, T, st);
-    return N == 64 ? launch_stats2_mfma<1, 4>(Wp, wss, Dp, Xp, Yp, Csp, Cvp, Up, Vp, E, S, K, T_stride, T, st)
-                   : launch_stats2_mfma<1, 2>(Wp, wss, Dp, Xp, Yp, Csp, Cvp, Up, Vp, E, S, K, T_stride, T, st);
+#define BTK_PF_MFMA(NQ_)                                                                                                         \
+    switch (N / 16) {                                                                                                              \
+      case 1: return launch_stats2_mfma<NQ_, 1>(Wp, wss, Dp, Xp, Yp, Csp, Cvp, Up, Vp, E, S, K, T_stride, T, st);                  \
+      case 2: return launch_stats2_mfma<NQ_, 2>(Wp, wss, Dp, Xp, Yp, Csp, Cvp, Up, Vp, E, S, K, T_stride, T, st);                  \
+      case 3: return launch_stats2_mfma<NQ_, 3>(Wp, wss, Dp, Xp, Yp, Csp, Cvp, Up, Vp, E, S, K, T_stride, T, st);                  \
+      default: return launch_stats2_mfma<NQ_, 4>(Wp, wss, Dp, Xp, Yp, Csp, Cvp, Up, Vp, E, S, K, T_stride, T, st);                 \
+    }
+    if (Cv) { BTK_PF_MFMA(2) }
+    BTK_PF_MFMA(1)
+#undef BTK_PF_MFMA
   }
   const int jb = jb_env ? jb_env : (Cv ? 8 : (N <= 8 ? 8 : 16));
   if (Cv && jb == 16)

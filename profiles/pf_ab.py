@@ -5,7 +5,7 @@ import numpy as np, torch
 from distant_speech_recognition_amd import engine as eng
 from bench_util import ula_positions, la_delays
 dev = torch.device("cuda:0")
-for N in (8, 64):
+for N in [int(v) for v in os.environ.get("PF_NS", "8,64").split(",")]:
     S, M, T = 16, 512, 4096
     K = M // 2 + 1
     X = (torch.randn((S, K, N, T), device=dev) + 1j * torch.randn((S, K, N, T), device=dev)).to(torch.complex64) * 2000

@@ -240,7 +240,7 @@ def _coherent_snapshots(rng, S, K, N, T):
 
 
 @pytest.mark.parametrize("N,M,T,type_,minf,load", [(4, 256, 120, 2, 0, 0.01), (8, 64, 70, 1, 0, 0.01), (64, 64, 40, 2, 5, 0.0),
-                                                  (5, 128, 90, 10, 0, 0.05), (20, 64, 50, 2, 0, 0.01), (32, 64, 45, 2, 0, 0.01)])
+                                                  (5, 128, 90, 10, 0, 0.05), (20, 64, 50, 2, 0, 0.01), (32, 64, 45, 2, 0, 0.01), (16, 64, 60, 2, 0, 0.01)])
 def test_mccowan_matches_oracle(orc, dev, N, M, T, type_, minf, load):
     """McCowanPostFilter (postfilter.cc:798-935) over a delay-and-sum beamformer, diffuse-noise coherence
     (confs/sd_and_mccowan.json shape), two consecutive blocks."""
@@ -338,10 +338,11 @@ def test_cov_accumulate_on_row_padded_snapshots(dev):
 
 
 @pytest.mark.parametrize("N,T,nq,cplx,pad", [(64, 37, 1, False, False), (64, 530, 2, False, True), (32, 100, 2, False, False),
-                                             (64, 75, 2, True, True), (32, 16, 1, True, False), (20, 50, 2, True, False)])
+                                             (64, 75, 2, True, True), (32, 16, 1, True, False), (20, 50, 2, True, False),
+                                             (16, 40, 2, True, False), (48, 100, 1, False, True), (48, 33, 2, True, False)])
 def test_stats2_quadratic_forms_against_their_definition(dev, N, T, nq, cplx, pad):
     """btk_bf_apply_stats2 (the per-frame sums behind McCowan / Lefkimmiatis, postfilter.cc:798-829, 1041-1077) against
-    u_t = sum_{i<=j} Cs[j][i] x'_i conj(x'_j) evaluated in float64: the matrix-core kernel (N = 32, 64; real and complex
+    u_t = sum_{i<=j} Cs[j][i] x'_i conj(x'_j) evaluated in float64: the matrix-core kernel (N = 16, 32, 48, 64; real and complex
     pair weights, one and two forms, ragged tiles, row-padded snapshots) and the VALU kernel (other N)."""
     import torch
     from distant_speech_recognition_amd import _lib, engine as eng
