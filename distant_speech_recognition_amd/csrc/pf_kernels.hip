@@ -23,6 +23,7 @@
 namespace {
 
 constexpr int PF_NT = 256;
+constexpr int PF_UNROLL = 16;
 
 __global__ __launch_bounds__(PF_NT)
 void bf_apply_stats_kernel(const float2* __restrict__ W, long w_stream_stride,
@@ -38,9 +39,7 @@ void bf_apply_stats_kernel(const float2* __restrict__ W, long w_stream_stride,
   const float2* d = Dv + s * w_stream_stride + (long)k * N;
   const float2* x = X + ((long)s * K + k) * N * T_stride + t;
   float yr = 0.f, yi = 0.f, pr = 0.f, pi = 0.f, cr = 0.f, ci = 0.f, e = 0.f;
-#pragma unroll 8
-  for (int n = 0; n < N; n++) {
-    const float2 v = x[(long)n * T_stride];
+  auto step = [&](int n, float2 v) {
     const float2 wn = w[n], dn = d[n];
     yr = fmaf(wn.x, v.x, fmaf(wn.y, v.y, yr));                  // conj(w) x
     yi = fmaf(wn.x, v.y, fmaf(-wn.y, v.x, yi));
@@ -50,7 +49,18 @@ void bf_apply_stats_kernel(const float2* __restrict__ W, long w_stream_stride,
     ci = fmaf(pi, ar, fmaf(-pr, ai, ci));
     pr += ar; pi += ai;
     e = fmaf(ar, ar, fmaf(ai, ai, e));
+  };
+  // the loads of PF_UNROLL channels are issued before the first of them is consumed (as bf_apply_kernel does): the prefix
+  // sums make every step depend on the previous one, and hipcc keeps load and use together otherwise
+  int n = 0;
+  for (; n + PF_UNROLL <= N; n += PF_UNROLL) {
+    float2 v[PF_UNROLL];
+#pragma unroll
+    for (int u = 0; u < PF_UNROLL; u++) v[u] = x[(long)(n + u) * T_stride];
+#pragma unroll
+    for (int u = 0; u < PF_UNROLL; u++) step(n + u, v[u]);
   }
+  for (; n < N; n++) step(n, x[(long)n * T_stride]);
   const long o = ((long)s * K + k) * T_stride + t;
   Y[o] = make_float2(yr, yi);
   Cc[o] = make_float2(cr, ci);
