@@ -299,7 +299,7 @@ void bf_apply_stats2_kernel(const float2* __restrict__ W, long w_stream_stride, 
 // workgroup); the other wavefronts of a SIMD load their tiles while one feeds the matrix core.
 constexpr int MF_TPW = 8;      // tiles per wavefront: 4 / 8 / 16 / 32 -> 2.61 / 2.51 / 2.54 / 2.55 ms (one form), 4.42 / 4.11 / 4.08 / 4.11 (two); BTK_PF_TPW overrides
 // wavefronts per workgroup (the coefficient planes allow two workgroups per CU): one form = 8, four wavefronts per SIMD in 128
-// VGPRs (2.46 ms against 2.69 with 4 at the C0 shape); two forms = 4, two per SIMD in 232 VGPRs (4.0 ms; with 8 the kernel spills,
+// VGPRs (2.46 ms against 2.69 with 4 at the C0 shape); two forms = 4, two per SIMD in 172 VGPRs (4.0 ms; with 8 the kernel spills,
 // 4.85 ms, one form after the other 7.1 ms, and six wavefronts land 2-2-1-1 on the SIMDs, 5.9 ms)
 constexpr int mf_nw(int nq) { return nq == 1 ? 8 : 4; }
 
