@@ -82,6 +82,12 @@ void zelinski_iir_kernel(float2* __restrict__ Y, const float2* __restrict__ Cc, 
   float psi_c = Psi[row];
   float wlast = Wlast[row];
   const float scale = 2.0f / ((float)N - 1.0f);
+  // the statistics (and the beamformer output the gain scales) of chunk i + 1 are requested before chunk i is scanned: the
+  // 24 dependent cross-lane steps of a scan and the latency of a chunk's loads no longer add up
+  const bool scales = type != 0;
+  float2 cn = (lane < T) ? Cc[row * T_stride + lane] : make_float2(0.f, 0.f);
+  float en = (lane < T) ? Ee[row * T_stride + lane] : 0.f;
+  float2 yn = (scales && lane < T) ? Y[row * T_stride + lane] : make_float2(0.f, 0.f);
   for (long t0 = 0; t0 < T; t0 += 64) {
     const long t = t0 + lane;
     const bool ok = t < T;
@@ -89,8 +95,15 @@ void zelinski_iir_kernel(float2* __restrict__ Y, const float2* __restrict__ Cc, 
     float a = ok ? ((g >= 2) ? alpha : 0.f) : 1.f;              // identity element beyond the end
     const float bsc = (g >= 2 && alpha > 0.f) ? 1.f - alpha : 1.f;
     if (alpha <= 0.f) a = ok ? 0.f : 1.f;                       // calc_CSD_: alpha <= 0 -> no memory
-    float2 c = ok ? Cc[row * T_stride + t] : make_float2(0.f, 0.f);
-    float e = ok ? Ee[row * T_stride + t] : 0.f;
+    const float2 c = cn, y = yn;
+    const float e = en;
+    {
+      const long tn = t + 64;
+      const bool okn = tn < T;
+      cn = okn ? Cc[row * T_stride + tn] : make_float2(0.f, 0.f);
+      en = okn ? Ee[row * T_stride + tn] : 0.f;
+      yn = (scales && okn) ? Y[row * T_stride + tn] : make_float2(0.f, 0.f);
+    }
     float br = ok ? bsc * c.x : 0.f, bi = ok ? bsc * c.y : 0.f, be = ok ? bsc * e : 0.f;
     // inclusive scan of the affine maps v -> a v + b
 #pragma unroll
@@ -110,10 +123,8 @@ void zelinski_iir_kernel(float2* __restrict__ Y, const float2* __restrict__ Cc, 
       float Wf = (num / ps) * scale;
       if (Wf >= 1.0f) Wf = 1.0f;
       if (Wf < 1.0e-4f) Wf = 1.0e-4f;
-      if (apply && type != 0) {                                 // NO_USE_POST_FILTER: the CSDs are just updated (postfilter.cc:197-199)
-        float2 y = Y[row * T_stride + t];
+      if (apply && type != 0)                                   // NO_USE_POST_FILTER: the CSDs are just updated (postfilter.cc:197-199)
         Y[row * T_stride + t] = make_float2(Wf * y.x, Wf * y.y);
-      }
       wlast = Wf;
     }
     // carry = state after the last valid frame of the chunk
