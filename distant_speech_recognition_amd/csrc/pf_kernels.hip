@@ -67,6 +67,37 @@ void bf_apply_stats_kernel(const float2* __restrict__ W, long w_stream_stride,
   Ee[o] = e;
 }
 
+// Inclusive wave-wide scan of the affine maps v -> a v + b[i] (one multiplier, NB offsets) in the DPP network: four row_shr steps
+// inside the 16-lane rows, then the row totals travel with row_bcast:15 (into rows 1 and 3) and row_bcast:31 (into rows 2 and 3).
+// Lanes without a source keep the identity map (`old` operand), so no lane tests are needed.  The shuffle form of the same
+// scan was 30 dependent ds_bpermute round trips per 64-frame chunk.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_or(float identity, float v)
+{
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, identity), __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xF, false));
+}
+template <int NB, int CTRL, int ROW_MASK>
+__device__ __forceinline__ void affine_scan_step(float& a, float (&b)[NB])
+{
+  const float a2 = dpp_or<CTRL, ROW_MASK>(1.f, a);
+  float p[NB];
+#pragma unroll
+  for (int i = 0; i < NB; i++) p[i] = dpp_or<CTRL, ROW_MASK>(0.f, b[i]);
+#pragma unroll
+  for (int i = 0; i < NB; i++) b[i] = fmaf(a, p[i], b[i]);     // (this o earlier)(v) = a (a2 v + p) + b
+  a *= a2;
+}
+template <int NB>
+__device__ __forceinline__ void affine_scan(float& a, float (&b)[NB])
+{
+  affine_scan_step<NB, 0x111, 0xF>(a, b);      // row_shr:1
+  affine_scan_step<NB, 0x112, 0xF>(a, b);      // row_shr:2
+  affine_scan_step<NB, 0x114, 0xF>(a, b);      // row_shr:4
+  affine_scan_step<NB, 0x118, 0xF>(a, b);      // row_shr:8
+  affine_scan_step<NB, 0x142, 0xA>(a, b);      // row_bcast:15 -> rows 1, 3
+  affine_scan_step<NB, 0x143, 0xC>(a, b);      // row_bcast:31 -> rows 2, 3
+}
+
 // One wavefront per (s,k).  frame_base = number of frames this post-filter has already produced
 // (ZelinskiPostFilter::frame_no_ + 1).
 __global__ __launch_bounds__(64)
@@ -104,18 +135,9 @@ void zelinski_iir_kernel(float2* __restrict__ Y, const float2* __restrict__ Cc, 
       en = okn ? Ee[row * T_stride + tn] : 0.f;
       yn = (scales && okn) ? Y[row * T_stride + tn] : make_float2(0.f, 0.f);
     }
-    float br = ok ? bsc * c.x : 0.f, bi = ok ? bsc * c.y : 0.f, be = ok ? bsc * e : 0.f;
-    // inclusive scan of the affine maps v -> a v + b
-#pragma unroll
-    for (int dlt = 1; dlt < 64; dlt <<= 1) {
-      const float a2 = __shfl_up(a, dlt, 64);
-      const float r2 = __shfl_up(br, dlt, 64), i2 = __shfl_up(bi, dlt, 64), e2 = __shfl_up(be, dlt, 64);
-      if (lane >= dlt) {
-        br = fmaf(a, r2, br); bi = fmaf(a, i2, bi); be = fmaf(a, e2, be);
-        a *= a2;
-      }
-    }
-    const float phr = fmaf(a, phi_c.x, br), phim = fmaf(a, phi_c.y, bi), ps = fmaf(a, psi_c, be);
+    float bb[3] = {ok ? bsc * c.x : 0.f, ok ? bsc * c.y : 0.f, ok ? bsc * e : 0.f};
+    affine_scan<3>(a, bb);                                      // inclusive scan of the affine maps v -> a v + b
+    const float phr = fmaf(a, phi_c.x, bb[0]), phim = fmaf(a, phi_c.y, bb[1]), ps = fmaf(a, psi_c, bb[2]);
     if (ok) {
       const bool apply = (g - 1) >= (long)min_frames;           // frame_no_ (= g-1, pre-increment) < min_frames -> NO_USE_POST_FILTER
       const int pft = apply ? type : 0;
@@ -503,17 +525,9 @@ void lefkimmiatis_iir_kernel(float2* __restrict__ Y, const float2* __restrict__ 
     if (alpha <= 0.f) a = ok ? 0.f : 1.f;
     const float2 cu = ok ? Uc[row * T_stride + t] : make_float2(0.f, 0.f);
     const float2 cvv = ok ? Vc[row * T_stride + t] : make_float2(0.f, 0.f);
-    float b0 = ok ? bsc * cu.x : 0.f, b1 = ok ? bsc * cu.y : 0.f, b2 = ok ? bsc * cvv.x : 0.f, b3 = ok ? bsc * cvv.y : 0.f;
-#pragma unroll
-    for (int dlt = 1; dlt < 64; dlt <<= 1) {
-      const float a2 = __shfl_up(a, dlt, 64);
-      const float p0 = __shfl_up(b0, dlt, 64), p1 = __shfl_up(b1, dlt, 64), p2 = __shfl_up(b2, dlt, 64), p3 = __shfl_up(b3, dlt, 64);
-      if (lane >= dlt) {
-        b0 = fmaf(a, p0, b0); b1 = fmaf(a, p1, b1); b2 = fmaf(a, p2, b2); b3 = fmaf(a, p3, b3);
-        a *= a2;
-      }
-    }
-    const float u0 = fmaf(a, u_c.x, b0), u1 = fmaf(a, u_c.y, b1), v0 = fmaf(a, v_c.x, b2), v1 = fmaf(a, v_c.y, b3);
+    float bb[4] = {ok ? bsc * cu.x : 0.f, ok ? bsc * cu.y : 0.f, ok ? bsc * cvv.x : 0.f, ok ? bsc * cvv.y : 0.f};
+    affine_scan<4>(a, bb);
+    const float u0 = fmaf(a, u_c.x, bb[0]), u1 = fmaf(a, u_c.y, bb[1]), v0 = fmaf(a, v_c.x, bb[2]), v1 = fmaf(a, v_c.y, bb[3]);
     if (ok) {
       const float gs = (type & 1) ? u0 : sqrtf(u0 * u0 + u1 * u1);
       const float gv = (type & 1) ? v0 : sqrtf(v0 * v0 + v1 * v1);
