@@ -1,5 +1,6 @@
-"""Staged analysis bank at the C0 shape (16 streams x 64 mics x 4096 frames, M = 512, r = 1), row-padded snapshots:
-BTK_FUSED_VAR=2127 selects the fused kernel's front end with a per-channel store (analysis512_bfz_kernel, XOUT form)."""
+"""Staged analysis bank at the C0 shape (16 streams x 64 mics x 4096 frames, M = 512, r = 1), row-padded snapshots, at settled
+clocks.  (Used for the A/B of an experimental form -- the fused kernel's front end with a per-channel store, DESIGN.md section 8 --
+that was selected by BTK_FUSED_VAR and is not in the tree.)"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
