@@ -136,14 +136,16 @@ void analysis512_kernel(const float* __restrict__ pcm, long nsamples, long pcm_s
           const int zoff = (nn >> 4) * 17 + (nn & 15);
 #pragma unroll
           for (int g = 0; g < FPT; g++) {
-            float p0 = 0.f, p1 = 0.f;
+            // (h.x x.y, h.y x.x) summed over the taps: one packed multiply-add per tap, the halves of x crossed by op_sel
+            f2 po;
 #pragma unroll
             for (int k = 0; k < A_MT; k++) {
-              const float2 x = win[g + R * (A_MT - 1 - k) + (G - 1 - q) * CG];
-              p0 = fmaf(h[q][k].x, x.y, p0);
-              p1 = fmaf(h[q][k].y, x.x, p1);
+              const float2 xw = win[g + R * (A_MT - 1 - k) + (G - 1 - q) * CG];
+              const f2 x = f2{xw.x, xw.y}, hk = f2{h[q][k].x, h[q][k].y};
+              if (k == 0) po = pk_mul_xswap(hk, x);
+              else pk_fma_xswap(po, hk, x);
             }
-            fbuf[(fg * FPT + g) * FRS + zoff] = make_float2(p0, p1);      // frame f -> wave f/4, slot f%4
+            fbuf[(fg * FPT + g) * FRS + zoff] = make_float2(po.x, po.y);  // frame f -> wave f/4, slot f%4
           }
         }
       }
