@@ -723,7 +723,7 @@ int launch512_bf(const btk_fb* fb, const float* pcm, long nsamples, long pcm_str
 //   B. wave-private 256-point FFT (two in-register radix-16 passes; forward sign through conjugation),
 //   C. polyphase + overlap-add with a register window: thread d reads each of the 16 + m R - 1 frames
 //      once at i = d and i = d + jD and produces 16 output samples; float32 running sum in the reference's order.
-constexpr int S_RUN = 128;
+constexpr int S_RUN = 256;
 
 template <int R>
 __global__ __launch_bounds__(A_NT, 2)
