@@ -616,7 +616,7 @@ int fast_analysis_bf_r(const btk_fb* fb, const float* pcm, long nsamples, long p
 // blocks of one stream; the real sequences v_f live in a ring of TT + m R frame buffers; every iteration adds
 // TT frames (Hermitian pre-pass from Y, wave-private forward FFT through conjugation) and emits TT blocks
 // (register-window polyphase + overlap-add, float32 running sum in the reference's order).
-constexpr int F_SRUN = 128;
+constexpr int F_SRUN = 256;
 
 template <int LOG2M, int R>
 __global__ __launch_bounds__(F_NT, 1)
