@@ -1,7 +1,7 @@
 """Fused analysis + apply at the reference's default geometry (M = 256, m = 4, r = 1) against the staged pair."""
 import os, sys, json
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import numpy as np, torch
+import torch
 from distant_speech_recognition_amd import engine as eng
 from bench_util import design_prototype
 dev = torch.device("cuda:0")

@@ -1,6 +1,6 @@
 """Does the k-stride of the snapshot block (N * T_stride * 8 B = 2 MiB at T_stride = 4096) hot-spot HBM channels?
 Same analysis / apply launches with the time axis padded by a few frames."""
-import os, sys, torch, numpy as np
+import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from distant_speech_recognition_amd import engine as eng
 from bench_util import design_prototype

@@ -4,7 +4,7 @@ analysis+apply kernels at bench.py's default launch size (16 streams x 64 mics x
 per-launch counter values compare directly with bench.py's roofline.bytes_per_launch.  PMC_S / PMC_T override."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import numpy as np, torch
+import torch
 from distant_speech_recognition_amd import engine as eng
 from bench_util import design_prototype
 
