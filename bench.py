@@ -25,6 +25,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK = 8.0e12          # B/s, MI355X spec (MI355X_MICROARCH.md)
+TRAFFIC_JSON = "r03_pmc_traffic.json"      # profiles/: PMC traffic of the kernels below, with the launch size and kernel-source hash it holds for
 FS = 16000.0
 
 
@@ -270,18 +271,30 @@ def main():
         b_bf = 8 * K * (N + 1) * S * T                 # beamformer apply
         b_syn = (8 * K + 4 * D) * S * T
         b_fused_hbm = (4 * D * N + 8 * K) * S * T      # what the fused kernel actually has to move
+        from bench_util import kernel_source_sha
+        traffic_note = {}
         def pmc_traffic(kernel_substr):
-            """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/make_traffic_json.py), only if
-            they were taken at this launch size"""
+            """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/make_traffic_json.py) -- refused (null,
+            with the reason in traffic_source) unless they were taken at this launch size AND on the kernel sources of this
+            checkout (sha256 of fb_analysis512.hip + fft_packed.h stored with the counters)"""
+            path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", TRAFFIC_JSON)
             try:
-                j = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_pmc_traffic.json")))
-                if (j["S"], j["T"], j["N"], j["M"]) != (S, T, N, M):
-                    return None
-                for kname, e in j["kernels"].items():
-                    if kernel_substr in kname and "traffic_bytes" in e:
-                        return e["traffic_bytes"]
-            except (OSError, ValueError, KeyError):
-                pass
+                j = json.load(open(path))
+            except (OSError, ValueError):
+                traffic_note["why"] = "no PMC passes committed (profiles/%s missing)" % TRAFFIC_JSON
+                return None
+            if (j.get("S"), j.get("T"), j.get("N"), j.get("M")) != (S, T, N, M):
+                traffic_note["why"] = "profiles/%s was taken at another launch size: refused" % TRAFFIC_JSON
+                return None
+            if j.get("kernel_source_sha256") != kernel_source_sha():
+                traffic_note["why"] = "profiles/%s was taken on other kernel sources (sha256 differs): refused as stale" % TRAFFIC_JSON
+                return None
+            for kname, e in j.get("kernels", {}).items():
+                if kernel_substr in kname and "traffic_bytes" in e:
+                    traffic_note["why"] = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of profiles/pmc_workload.py at this launch size and "
+                                           "on these kernel sources (profiles/%s, kernel %s; gfx950 correction 2 x FETCH_SIZE)" % (TRAFFIC_JSON, kname))
+                    return e["traffic_bytes"]
+            traffic_note["why"] = "profiles/%s holds no kernel named *%s*: refused" % (TRAFFIC_JSON, kernel_substr)
             return None
         if fused:
             # algorithmic bytes of the FUSED operator: every PCM sample in once, every beamformed bin out once (4 D N + 8 K
@@ -289,9 +302,7 @@ def main():
             roof = {"bound": "hbm", "kernel": "analysis512_bfz_kernel (fused analysis bank + SubbandGSC apply)",
                     "achieved": b_fused_hbm / t_a / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                     "frac": b_fused_hbm / t_a / HBM_PEAK, "frac_survey_8d": (b_ana + b_bf) / t_a / HBM_PEAK,
-                    "traffic": pmc_traffic("analysis512_bfz_kernel"),
-                    "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of profiles/pmc_workload.py at this launch "
-                                      "size (profiles/r02_pmc_traffic.json; gfx950 correction 2 x FETCH_SIZE)",
+                    "traffic": pmc_traffic("analysis512_bfz_kernel"), "traffic_source": None,
                     "bytes_per_launch": b_fused_hbm, "avg_launch_ms": t_a * 1e3,
                     "staged_equivalent": {"bytes_per_launch": b_ana + b_bf, "GBps": (b_ana + b_bf) / t_a / 1e9,
                                           "frac": (b_ana + b_bf) / t_a / HBM_PEAK},
@@ -302,8 +313,8 @@ def main():
         else:
             roof = {"bound": "hbm", "kernel": "analysis512_kernel", "achieved": b_ana / t_ana / 1e9, "peak": HBM_PEAK / 1e9,
                     "unit": "GB/s", "frac": b_ana / t_ana / HBM_PEAK, "traffic": pmc_traffic("analysis512_kernel"),
-                    "traffic_source": "rocprofv3 --pmc passes, profiles/r02_pmc_traffic.json (2 x FETCH_SIZE + WRITE_SIZE)",
-                    "bytes_per_launch": b_ana, "avg_launch_ms": t_ana * 1e3}
+                    "traffic_source": None, "bytes_per_launch": b_ana, "avg_launch_ms": t_ana * 1e3}
+        roof["traffic_source"] = traffic_note.get("why")
         res = {
             "metric": "beamformed subband frames/sec, 64-mic 512-bin SubbandGSC",
             "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

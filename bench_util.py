@@ -1,11 +1,24 @@
 """Helpers shared by the benchmark scripts (bench.py, bench_stages.py, bench_configs.py, bench_bin_sharded.py, profiles/*.py):
 the designed Nyquist(M) prototypes, the array geometry and the synthetic PCM of SURVEY 8(d).  Nothing here touches tests/."""
+import hashlib
+import os
+
 import numpy as np
 
 from distant_speech_recognition_amd import prototypes
 from distant_speech_recognition_amd.pybeamformer import calc_la_delays
 
 FS = 16000.0
+
+
+def kernel_source_sha(files=("fb_analysis512.hip", "fft_packed.h")):
+    """sha256 over the sources of the headline kernel: PMC traffic figures (profiles/*_pmc_traffic.json) carry it, and bench.py
+    quotes them only while it still matches -- a changed kernel silently keeping an old traffic number was possible before"""
+    h = hashlib.sha256()
+    d = os.path.join(os.path.dirname(os.path.abspath(__file__)), "distant_speech_recognition_amd", "csrc")
+    for f in files:
+        h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()
 
 
 def design_prototype(M, m=4, kind="h", r=1):

@@ -4,8 +4,10 @@ launch in bytes, corrected as /opt/skills/guides/MI355X_MICROARCH.md "HBM [CDNA4
 FETCH_SIZE (KiB) is doubled for wide coalesced streaming reads (128-B requests tallied at 64 B); WRITE_SIZE (KiB) is
 used as reported (calibrated here: analysis512_kernel writes exactly its 8*K*N*S*T snapshot bytes).
 Usage: make_traffic_json.py <pmc_dir> <out.json> S T"""
-import csv, glob, json, os, sys
+import csv, glob, hashlib, json, os, sys
 from collections import defaultdict
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bench_util import kernel_source_sha
 
 d, out, S, T = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4])
 acc = defaultdict(lambda: defaultdict(list))
@@ -13,7 +15,8 @@ for f in sorted(glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), rec
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"].replace("void (anonymous namespace)::", "").split("(")[0]
         acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
-res = {"S": S, "T": T, "N": 64, "M": 512, "correction": "read = 2 * FETCH_SIZE KiB * 1024; write = WRITE_SIZE KiB * 1024", "kernels": {}}
+# bench.py only quotes these numbers while the kernel sources are the ones they were measured on
+res = {"S": S, "T": T, "N": 64, "M": 512, "kernel_source_sha256": kernel_source_sha(), "correction": "read = 2 * FETCH_SIZE KiB * 1024; write = WRITE_SIZE KiB * 1024", "kernels": {}}
 for k, c in acc.items():
     if not any(s in k for s in ("analysis", "bf_apply", "synthesis")):
         continue

@@ -147,12 +147,19 @@ def test_fused_interior_tiles_lds_dma_path(orc, dev, N, r, S, T):
         got = fb.analysis_beamform(p, W)
         scale = float(ref.abs().max())
         assert float((got - ref).abs().max()) <= 2e-6 * np.sqrt(N) * scale + 1e-6 * scale
-    # oracle on frames 100..115 of stream 1 (an interior tile), shared weights Wn[1]
-    Xo = np.stack([orc.analysis(h, M, m, r, 2, pcm[1, n]) for n in range(N)], axis=1)      # [T][N][M]
-    t0 = 96
-    Yo = np.einsum("kn,tnk->kt", np.conj(Wn[1].astype(np.complex128)), Xo[t0:t0 + 16, :, :K])
-    g = got[1, :, t0:t0 + 16].cpu().numpy()
-    assert np.max(np.abs(g - Yo)) <= 4e-6 * np.sqrt(N) * np.max(np.abs(Yo))
+    # oracle on whole 16-frame tiles of BOTH streams: the first tile (its span starts before the recording: edge path), interior
+    # tiles (LDS-DMA / direct-window path), the last, ragged tile (edge path), per-stream weights for stream 0 and shared ones for 1
+    gotp = fb.analysis_beamform(p, torch.from_numpy(Wn).to(dev)).cpu().numpy()
+    gots = got.cpu().numpy()
+    tiles = sorted({0, 16 * (T // 32), 96 if T > 112 else 16, 16 * ((T - 1) // 16)})
+    for s_, cases in ((0, ((Wn[0], gotp),)), (1, ((Wn[1], gots), (Wn[1], gotp)))):
+        Xo = np.stack([orc.analysis(h, M, m, r, 2, pcm[s_, n]) for n in range(N)], axis=1)      # [T][N][M]
+        assert Xo.shape[0] == T
+        for Wo, G in cases:
+            for t0 in tiles:
+                t1 = min(t0 + 16, T)
+                Yo = np.einsum("kn,tnk->kt", np.conj(Wo.astype(np.complex128)), Xo[t0:t1, :, :K])
+                assert np.max(np.abs(G[s_, :, t0:t1] - Yo)) <= 4e-6 * np.sqrt(N) * np.max(np.abs(Yo)), (s_, t0)
 
 
 def test_fused_chain_with_row_padded_output(dev):

@@ -1,5 +1,6 @@
 """GPU: size-independent properties at BASELINE's full launch sizes (the float64 oracle cannot run these in seconds):
-C0 = 16 streams x 64 mics x 4096 frames at M = 512, and a 256-mic / 2048-bin C4 launch."""
+C0 = 32 streams x 64 mics x 4096 frames at M = 512 (exactly the launch bench.py times: 8 192 workgroups of the fused kernel), and a
+256-mic / 2048-bin C4 launch."""
 import numpy as np
 import pytest
 
@@ -11,7 +12,7 @@ pytestmark = pytest.mark.gpu
 def test_c0_full_launch_properties(dev):
     import torch
     from distant_speech_recognition_amd import engine as eng
-    S, N, M, m, r, T = 16, 64, 512, 4, 1, 4096
+    S, N, M, m, r, T = 32, 64, 512, 4, 1, 4096            # bench.py's launch (streams_per_gpu = 32)
     D, K = M >> r, M // 2 + 1
     afb = eng.FilterBank(design_prototype(M, m), M, m, r, 2)
     sfb = eng.FilterBank(design_prototype(M, m, "g"), M, m, r, 2, synthesis=True)
@@ -27,7 +28,7 @@ def test_c0_full_launch_properties(dev):
     scale = float(Ys.abs().max())
     assert float((Yf - Ys).abs().max()) <= 2e-6 * np.sqrt(N) * scale + 1e-6 * scale
     # 2. streams are independent: a stream computed alone equals its slice of the batched launch, bit for bit
-    for s in (0, 7, 15):
+    for s in (0, 7, 31):
         assert torch.equal(afb.analysis(pcm[s:s + 1].contiguous()), X[s:s + 1])
         assert torch.equal(afb.analysis_beamform(pcm[s:s + 1].contiguous(), W), Yf[s:s + 1])
     # 3. Hermitian symmetry of a real input: bins 0 and M/2 are real (up to the FFT's rounding)
