@@ -178,6 +178,23 @@ def main():
         "chain_without_design": {"ms": tot * 1e3, "frames_per_s": S * T / tot, "xRT": S * T / tot / (FS / D)},
         "allgather_bytes_if_bin_sharded": 8 * K * T * S,
     }
+    del X, pcm, Y
+
+    # ------------------------------------------------------------------ pseudo-inverse fall-back (a12)
+    # SMI-MVDR covariances from fewer frames than microphones (unit_test/confs/smimvdr.json): every bin fails the Cholesky solve
+    # and takes the reference's float32-SVD pseudo-inverse rule -- the batched GPU Jacobi solve (pinv_kernels.hip)
+    def pinv_case(N, K, T, seed):
+        g = torch.Generator(device=dev).manual_seed(seed)
+        Xs = (torch.randn((K, N, T), device=dev, generator=g) + 1j * torch.randn((K, N, T), device=dev, generator=g)).to(torch.complex64) * 1000.0
+        Rs = torch.einsum("knt,kmt->knm", Xs, Xs.conj()) / T
+        Rs = Rs + 1.0e-4 * torch.diag_embed(torch.diagonal(Rs, dim1=1, dim2=2).real.mean(dim=1, keepdim=True).expand(K, N)).to(torch.complex64)
+        dq = torch.polar(torch.full((K, N), 1.0 / N, device=dev), torch.rand((K, N), device=dev, generator=g) * 6.2831853).to(torch.complex64)
+        eng.mvdr_weights(Rs, dq)                                   # warm-up
+        t, (Wp, nid) = timed(torch, lambda: eng.mvdr_weights(Rs, dq), n=2, warm=1, prewarm_ms=0.0)
+        return {"N": N, "bins": K, "frames_in_covariance": T, "ms_cholesky_attempt_plus_pinv_all_bins": t * 1e3, "identity_fallbacks": nid,
+                "us_per_bin": t / K * 1e6}
+    out["pinv_fallback_all_bins"] = {"N64_513bins": pinv_case(64, 513, 40, 11), "N256_1025bins_C4_size": pinv_case(256, 1025, 128, 12),
+                                     "note": "round 2 (host Jacobi, one thread): 15 ms per 64 x 64 bin, 1.74 s per 256 x 256 bin"}
     print(json.dumps(out, indent=1))
 
 

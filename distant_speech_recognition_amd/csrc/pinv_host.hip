@@ -1,12 +1,13 @@
-// pinv_host.hip -- the reference's pseudo-inverse semantics on the host, for the bins the batched Cholesky solve
-// (mvdr_kernels.hip) cannot handle and for the NC > 2 LCMV constraint Gram matrix.
+// pinv_host.hip -- the reference's pseudo-inverse semantics on the host: btk_pinv for the NC > 2 LCMV constraint Gram matrix
+// (a handful of NC x NC matrices per design) and as the checker of the batched GPU solve (pinv_kernels.hip), which serves the
+// bins the Cholesky kernel (mvdr_kernels.hip) flags; btk_mvdr_pinv_fallback_host is that solve bin by bin on one host thread
+// (15 ms per 64 x 64, 1.7 s per 256 x 256 matrix) -- kept for tests and A/B timing only, no product path calls it.
 //
 // Reference: pseudoinverse() (beamformer/beamformer.cc:232-289) casts the matrix to complex<float>, takes its SVD with
 // LINPACK csvdc (matrix/linpack_c.cc:9516), replaces singular values below dThreshold by 0 (AND reports failure, upon
 // which calc_mvdr_weights substitutes the identity, :2381-2383), inverts the others and forms V S^-1 U^H.
 // The pseudo-inverse of a matrix is unique, so any accurate SVD reproduces it: here a one-sided Jacobi (Hestenes) SVD of
 // the float32-rounded matrix in float64 arithmetic -- what the reference's float32 Householder/QR iteration approximates.
-// Host code only: O(N^3) per sweep, used for a handful of bins (the GPU Cholesky path serves every well-posed bin).
 #include "btk_internal.h"
 #include <cmath>
 #include <complex>
@@ -92,11 +93,11 @@ int btk_pinv(const double* A, int M, int N, float threshold, double* invA, int* 
 
 // calc_mvdr_weights for the flagged bins, literally (beamformer.cc:2372-2397): invR = pinv(R_k) or the identity when
 // pseudoinverse() reports failure; tmpH = invR^H d; w = tmpH / (N d^H... zdotc(tmpH, d)).  Synchronises the stream.
-int btk_mvdr_pinv_fallback(const void* R, const void* wq, void* W, int K, int N, int first_bin, float threshold,
+int btk_mvdr_pinv_fallback_host(const void* R, const void* wq, void* W, int K, int N, int first_bin, float threshold,
                            const int* fail_flags, int* identity_count, void* stream)
 {
-  if (!R || !wq || !W || !fail_flags) return btk_set_error(BTK_ERR_PARAMETER, "btk_mvdr_pinv_fallback: null argument");
-  if (K < 1 || N < 1) return btk_set_error(BTK_ERR_DIMENSION, "btk_mvdr_pinv_fallback: bad sizes");
+  if (!R || !wq || !W || !fail_flags) return btk_set_error(BTK_ERR_PARAMETER, "btk_mvdr_pinv_fallback_host: null argument");
+  if (K < 1 || N < 1) return btk_set_error(BTK_ERR_DIMENSION, "btk_mvdr_pinv_fallback_host: bad sizes");
   hipStream_t st = as_stream(stream);
   std::vector<int> flags(K);
   BTK_HIP_CHECK(hipMemcpyAsync(flags.data(), fail_flags, sizeof(int) * K, hipMemcpyDeviceToHost, st));

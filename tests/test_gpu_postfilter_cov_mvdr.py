@@ -200,6 +200,100 @@ def test_mvdr_pinv_fallback_matches_oracle(orc, dev, N):
     assert np.allclose(W[3], d[3] / (N * np.vdot(d[3], d[3])), atol=1e-6)   # invR = I
 
 
+def _pinv_fallback_both(eng, R, d, threshold, first_bin=0):
+    """(W_gpu, nident_gpu, ms_gpu), (W_host, nident_host): every bin flagged, the batched GPU Jacobi solve against the
+    bin-by-bin host solve (btk_mvdr_pinv_fallback_host, the round-2 product path, itself pinned by the compiled csvdc)"""
+    import ctypes as C
+    import torch
+    from distant_speech_recognition_amd import _lib
+    L = _lib.lib()
+    K, N, _ = R.shape
+    flags = torch.ones(K, dtype=torch.int32, device=R.device)
+    Wg = torch.zeros((K, N), dtype=torch.complex64, device=R.device)
+    Wh = torch.zeros_like(Wg)
+    cnt = torch.zeros(1, dtype=torch.int32, device=R.device)
+    sb = L.btk_mvdr_pinv_scratch_bytes(K, N)
+    scratch = torch.empty(max(sb, 16), dtype=torch.uint8, device=R.device)
+    st = torch.cuda.current_stream().cuda_stream
+    args = (R.data_ptr(), d.data_ptr(), Wg.data_ptr(), K, N, first_bin, threshold, flags.data_ptr(), cnt.data_ptr(),
+            scratch.data_ptr() if sb else None, st)
+    _lib.check(L.btk_mvdr_pinv_fallback_async(*args))                      # warm-up (module load, attribute)
+    torch.cuda.synchronize()
+    cnt.zero_()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    _lib.check(L.btk_mvdr_pinv_fallback_async(*args))
+    e1.record()
+    torch.cuda.synchronize()
+    ni = C.c_int(0)
+    _lib.check(L.btk_mvdr_pinv_fallback_host(R.data_ptr(), d.data_ptr(), Wh.data_ptr(), K, N, first_bin, threshold,
+                                             flags.data_ptr(), C.byref(ni), st))
+    return (Wg.cpu().numpy(), int(cnt.item()), e0.elapsed_time(e1)), (Wh.cpu().numpy(), ni.value)
+
+
+def test_mvdr_pinv_gpu_all_bins_rank_deficient_n64(orc, dev):
+    """an SMI-MVDR covariance from fewer than N frames (unit_test/confs/smimvdr.json, barely loaded) sends
+    ALL K = 513 bins of a 64-mic array to the pseudo-inverse.  The batched GPU Jacobi solve does them in < 50 ms (the host
+    loop needed 15 ms per bin = 8 s) and agrees with the host solve and, on sampled bins, with the oracle's compiled-csvdc path."""
+    import torch
+    from distant_speech_recognition_amd import engine as eng
+    N, K, T = 64, 513, 40
+    rng = np.random.default_rng(64)
+    X = (rng.normal(size=(K, N, T)) + 1j * rng.normal(size=(K, N, T))) * 1000.0
+    R = (np.einsum("knt,kmt->knm", X, X.conj()) / T)
+    R[:, np.arange(N), np.arange(N)] += 1.0e-4 * np.trace(R, axis1=1, axis2=2).real[:, None] / N     # mu = 1e-4 loading
+    R[7] = 0.0                                                              # an empty bin: sigma = 0 -> identity
+    R[9][:, 0] = 0; R[9][0, :] = 0                                          # a dead channel: identity
+    R = R.astype(np.complex64)
+    d = (np.exp(-2j * np.pi * rng.uniform(size=(K, N))) / N).astype(np.complex64)
+    Rd, dd = torch.from_numpy(R).to(dev), torch.from_numpy(d).to(dev)
+    (Wg, nig, ms), (Wh, nih) = _pinv_fallback_both(eng, Rd, dd, 1.0e-8)
+    assert ms < 50.0, ms
+    assert nig == nih == 2
+    assert np.allclose(Wg[0], 0.0) and np.allclose(Wh[0], 0.0)              # global bin 0 is not touched (all-ones set by the solve kernel)
+    for k in range(1, K):
+        assert np.linalg.norm(Wg[k] - Wh[k]) <= 2e-6 * np.linalg.norm(Wh[k]), k
+    for k in (7, 9):
+        assert np.allclose(Wg[k], d[k] / (N * np.vdot(d[k], d[k])), atol=1e-6)       # invR = I
+    for k in (1, 2, 256, 512):
+        ref = _oracle_mvdr_bin(orc, R[k].astype(np.complex128), d[k].astype(np.complex128))
+        if ref is not None:
+            cond = np.linalg.cond(R[k].astype(np.complex128))
+            assert np.linalg.norm(Wg[k] - ref) <= (2e-6 * cond + 1e-5) * np.linalg.norm(ref), (k, cond)
+    # and through the product entry: the Cholesky kernel takes what it can, the rest goes to the GPU fall-back
+    W, nident = eng.mvdr_weights(Rd, dd)
+    W = W.cpu().numpy()
+    assert nident == 2 and np.allclose(W[0], 1.0)
+    for k in range(1, K):
+        assert np.linalg.norm(W[k] - Wh[k]) <= (2e-6 * np.linalg.cond(R[k].astype(np.complex128)) + 1e-5) * np.linalg.norm(Wh[k]) or k in (7, 9), k
+
+
+@pytest.mark.parametrize("N,K", [(1, 3), (2, 4), (3, 5), (8, 9), (33, 5), (65, 4), (100, 3), (256, 2)])
+def test_mvdr_pinv_gpu_sizes(dev, N, K):
+    """every storage form of the GPU pseudo-inverse solve (LDS up to N = 64, global scratch above; odd N: the tournament's dummy
+    player) against the host solve: indefinite, positive definite, rank-deficient and zero matrices"""
+    import torch
+    from distant_speech_recognition_amd import engine as eng
+    rng = np.random.default_rng(1000 + N)
+    R = np.zeros((K, N, N), np.complex64)
+    for k in range(K):
+        H = rng.normal(size=(N, N)) + 1j * rng.normal(size=(N, N))
+        if k % 3 == 0:
+            R[k] = ((H + H.conj().T) / 2).astype(np.complex64)               # indefinite
+        elif k % 3 == 1:
+            R[k] = (H @ H.conj().T / N + 0.01 * np.eye(N)).astype(np.complex64)
+        else:
+            Hr = H[:, : max(N // 2, 1)]
+            R[k] = (Hr @ Hr.conj().T).astype(np.complex64) if N > 1 else 0   # exactly rank deficient in float64; float32 rounding noise decides
+    d = (np.exp(-2j * np.pi * rng.uniform(size=(K, N))) / N).astype(np.complex64)
+    (Wg, nig, ms), (Wh, nih) = _pinv_fallback_both(eng, torch.from_numpy(R).to(dev), torch.from_numpy(d).to(dev), 1.0e-8, first_bin=1)
+    assert nig == nih
+    for k in range(K):
+        cond = min(np.linalg.cond(R[k].astype(np.complex128)), 1e7) if N > 1 and np.any(R[k]) else 1.0
+        assert np.all(np.isfinite(Wg[k]))
+        assert np.linalg.norm(Wg[k] - Wh[k]) <= (1e-9 * cond + 2e-6) * np.linalg.norm(Wh[k]), (k, cond)
+
+
 def test_mvdr_divide_nondiagonal(orc, dev):
     """divide_all_nondiagonal_elements (beamformer.h:357-362) on the diffuse model, then MVDR == the oracle's pinned path"""
     import torch
