@@ -7,10 +7,14 @@ MI355X through the C-ABI (include/btkhip.h): a node pulls its finite upstream on
 whole block through the HIP kernels and then serves frames from a host mirror, so `next()`
 keeps the reference's per-frame semantics (node-owned buffer, same-frame caching, end-of-stream).
 """
-from .common import *      # noqa: F401,F403
-from .stream import *      # noqa: F401,F403
-from .feature import *     # noqa: F401,F403
-from .modulated import *   # noqa: F401,F403
-from .beamformer import *  # noqa: F401,F403
-from .postfilter import *  # noqa: F401,F403
-from .dereverberation import *  # noqa: F401,F403
+import os as _os
+if _os.environ.get("BTK20_BACKEND") == "cpp":
+    from ..btk20cpp import *   # noqa: F401,F403
+else:
+    from .common import *      # noqa: F401,F403
+    from .stream import *      # noqa: F401,F403
+    from .feature import *     # noqa: F401,F403
+    from .modulated import *   # noqa: F401,F403
+    from .beamformer import *  # noqa: F401,F403
+    from .postfilter import *  # noqa: F401,F403
+    from .dereverberation import *  # noqa: F401,F403

@@ -880,14 +880,190 @@ void synthesis512_kernel(const float2* __restrict__ Y, long nframes, long T_stri
   }
 }
 
+// ---- round 3: the same schedule with wide memory instructions (R = 1, 2; aligned launches).  s_memtime marks on the kernel above
+// (profiles/r03_synthesis_phases.txt) showed 18 800 cycles per 16-frame chunk: 9 000 in the overlap-add (46 ds_read_b64 of which
+// each lane used half, sixteen 4-byte stores per lane), 3 300 issuing the 17 strided 8-byte loads of the next chunk, 3 000 in the
+// FFT, 2 400 in the pre-pass.  Here
+//   * the overlap-add lane owns FOUR consecutive output samples of BPG consecutive blocks: its window is read with ds_read2_b64
+//     (every byte used), and a block leaves as one 16-byte store per lane -- 1 KiB per wave-instruction, a quarter of the stores;
+//   * the pre-pass lane owns TWO consecutive frames of a bin pair: 16-byte loads, half the load instructions;
+//   * the ring has 32 slots (a mask instead of compare-and-subtract chains), the inter-pass twiddles live in registers.
+// Arithmetic and summation order per output sample are those of the kernel above (the two agree to 2 ulp: the compiler contracts
+// the multiply-adds of the two bodies differently).  C0 bench launch: 0.156 -> 0.123 ms (0.32 -> 0.41 of the HBM roofline);
+// placing the next chunk's loads one by one between the FFT's LDS operations (as the fused analysis kernel does) measured 0.128 ms
+// and was not kept (profiles/r03_synthesis_ab.txt).
+template <int R>
+__global__ __launch_bounds__(A_NT, 2)
+void synthesis512w_kernel(const float2* __restrict__ Y, long nframes, long T_stride, int K,
+                          const float* __restrict__ proto, const float2* __restrict__ twg,
+                          int pd, float gain, float* __restrict__ out, long out_stride, long b0, long bcount, int srun)
+{
+  constexpr int D = A_M / R;
+  constexpr int HALO = A_MT * R - 1;
+  constexpr int NRING = 32;
+  constexpr int NQ = D / 4, NBG = A_NT / NQ, BPG = 16 / NBG;   // sample quads per block, block groups, blocks per group
+  constexpr int NWF = BPG + HALO;                              // frames in a lane's window
+  static_assert(NRING >= 16 + HALO + 1 && NBG * BPG == 16, "geometry");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float2* ring = reinterpret_cast<float2*>(smem);             // [NRING][FRS]
+  float2* tw = ring + NRING * FRS;                            // [257]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int s = blockIdx.y;
+  const long bt0 = b0 + (long)blockIdx.x * srun;
+  const long bend = (bt0 + srun < b0 + bcount) ? bt0 + srun : b0 + bcount;
+  const float2* Ys = Y + (long)s * K * T_stride;
+  float* os = out + (long)s * out_stride;
+
+  for (int j = tid; j <= A_NF; j += A_NT) tw[j] = twg[j];
+  const int fl = lane >> 4, jj = lane & 15;
+  f2 twr[15];                                                 // W_256^{j k1}, k1 = 1..15
+#pragma unroll
+  for (int k1 = 1; k1 < 16; k1++) { const float2 t = twg[(2 * jj * k1) & 511]; twr[k1 - 1] = f2{t.x, t.y}; }
+
+  const int dq = tid % NQ, bg = tid / NQ, d0 = 4 * dq;
+  float gco[4][R][A_MT];                                      // g[M-1-(d+jD)+M k], d = d0 + dd
+#pragma unroll
+  for (int dd = 0; dd < 4; dd++)
+#pragma unroll
+    for (int j = 0; j < R; j++)
+#pragma unroll
+      for (int k = 0; k < A_MT; k++) gco[dd][j][k] = proto[(A_M - 1 - (d0 + dd + j * D)) + A_M * k];
+  __syncthreads();
+
+  const long f_lo = bt0 + pd - HALO;
+  // A. pre-pass lane: frames fc0 + 2 fp, + 1; bin pairs (k, 256 - k), k = kq + 32 it
+  const int fp = tid & 7, kq = tid >> 3;
+  float4 pa[4], pb[4], p128 = make_float4(0.f, 0.f, 0.f, 0.f);
+  auto prefetch = [&](long fc0) {
+    const long fA = fc0 + 2 * fp;
+    const bool okA = fA >= f_lo && fA >= 0 && fA < nframes, okB = fA + 1 >= f_lo && fA + 1 >= 0 && fA + 1 < nframes;
+    if (okA && okB) {                                          // 16-byte loads: fA is even and the rows are 16-byte aligned (launch check)
+#pragma unroll
+      for (int it = 0; it < 4; it++) {
+        const int k = kq + 32 * it;
+        pa[it] = *reinterpret_cast<const float4*>(Ys + (long)k * T_stride + fA);
+        pb[it] = *reinterpret_cast<const float4*>(Ys + (long)(A_NF - k) * T_stride + fA);
+      }
+      if (kq == 0) p128 = *reinterpret_cast<const float4*>(Ys + (long)128 * T_stride + fA);
+    } else {
+      auto ld = [&](int k) {
+        const float2 a = okA ? Ys[(long)k * T_stride + fA] : make_float2(0.f, 0.f);
+        const float2 b = okB ? Ys[(long)k * T_stride + fA + 1] : make_float2(0.f, 0.f);
+        return make_float4(a.x, a.y, b.x, b.y);
+      };
+#pragma unroll
+      for (int it = 0; it < 4; it++) { const int k = kq + 32 * it; pa[it] = ld(k); pb[it] = ld(A_NF - k); }
+      if (kq == 0) p128 = ld(128);
+    }
+  };
+  auto zc = [&](float2 a, float2 bq, int k) {                 // Zc[k] from Y[k] = a, Y[256-k] = bq
+    const float2 sm = make_float2(a.x + bq.x, a.y - bq.y), df = make_float2(a.x - bq.x, a.y + bq.y);
+    const float2 w = tw[k];
+    const float2 t = make_float2(w.x * df.x + w.y * df.y, w.x * df.y - w.y * df.x);     // conj(W^k) * df
+    return make_float2(sm.x - t.y, sm.y + t.x);
+  };
+  prefetch(f_lo + HALO - 16);
+  int s0 = (HALO - 16) & (NRING - 1);                         // ring slot of the chunk's first frame: (fc0 - f_lo) mod 32
+  for (long fc0 = f_lo + HALO - 16; fc0 < bend + pd; fc0 += 16, s0 = (s0 + 16) & (NRING - 1)) {
+    // ---- A. Hermitian pre-pass of the two frames of this lane
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+      const long f = fc0 + 2 * fp + h;
+      if (f >= f_lo) {
+        float2* zf = ring + ((s0 + 2 * fp + h) & (NRING - 1)) * FRS;
+#pragma unroll
+        for (int it = 0; it < 4; it++) {
+          const int k = kq + 32 * it;
+          float2 a = h ? make_float2(pa[it].z, pa[it].w) : make_float2(pa[it].x, pa[it].y);
+          float2 bq = h ? make_float2(pb[it].z, pb[it].w) : make_float2(pb[it].x, pb[it].y);
+          if (k == 0) { a.y = 0.f; bq.y = 0.f; }               // imaginary parts of bins 0 and M/2 are ignored
+          zf[(k >> 4) * 17 + (k & 15)] = zc(a, bq, k);
+          if (k > 0) {
+            const int kk = A_NF - k;                           // 129 .. 255
+            zf[(kk >> 4) * 17 + (kk & 15)] = zc(bq, a, kk);
+          }
+        }
+        if (kq == 0) { const float2 c = h ? make_float2(p128.z, p128.w) : make_float2(p128.x, p128.y); zf[8 * 17] = zc(c, c, 128); }
+      }
+    }
+    __syncthreads();
+    if (fc0 + 16 < bend + pd) prefetch(fc0 + 16);             // lands under B and C
+    // ---- B. forward FFT of the 16 new frames (4 per wavefront): conj -> positive-exponent passes -> conj
+    {
+      const long f = fc0 + wave * 4 + fl;
+      if (f >= f_lo) {
+        f2* fb = reinterpret_cast<f2*>(ring) + ((s0 + wave * 4 + fl) & (NRING - 1)) * FRS;
+        f2 v[16];
+#pragma unroll
+        for (int r = 0; r < 16; r++) { const f2 z = fb[r * 17 + jj]; v[r] = f2{z.x, -z.y}; }
+        dft16q(v);
+#pragma unroll
+        for (int k1 = 1; k1 < 16; k1++) v[k1] = cmulv(v[k1], twr[k1 - 1]);
+#pragma unroll
+        for (int k1 = 0; k1 < 16; k1++) fb[jj * 17 + k1] = v[k1];
+#pragma unroll
+        for (int jp = 0; jp < 16; jp++) v[jp] = fb[jp * 17 + jj];
+        dft16q(v);
+#pragma unroll
+        for (int k2 = 0; k2 < 16; k2++) fb[k2 * 17 + jj] = f2{v[k2].x, -v[k2].y};     // z[n]: v[2n] = Re, v[2n+1] = Im
+      }
+    }
+    __syncthreads();
+    // ---- C. polyphase + overlap-add: samples d0 .. d0+3 of the blocks fc0 + bg BPG + b - pd, b < BPG
+    if (fc0 >= f_lo + HALO) {
+      // window: frames fc0 - HALO + bg BPG + w, w < NWF, at i = d0 + dd + j D  ->  two float2 at (d0 + j D) / 2
+      float win[R][NWF][4];
+#pragma unroll
+      for (int j = 0; j < R; j++) {
+        const int h = (d0 + j * D) >> 1;
+        const int zi = (h >> 4) * 17 + (h & 15);
+#pragma unroll
+        for (int w = 0; w < NWF; w++) {
+          const float2* zr = ring + ((s0 - HALO + bg * BPG + w) & (NRING - 1)) * FRS + zi;
+          const float2 z0 = zr[0], z1 = zr[1];
+          win[j][w][0] = z0.x; win[j][w][1] = z0.y; win[j][w][2] = z1.x; win[j][w][3] = z1.y;
+        }
+      }
+#pragma unroll
+      for (int b = 0; b < BPG; b++) {
+        const long bglob = fc0 + bg * BPG + b - pd;
+        float acc[4];
+#pragma unroll
+        for (int dd = 0; dd < 4; dd++) {
+          float a = 0.f;
+#pragma unroll
+          for (int j = 0; j < R; j++) {
+            float sv = 0.f;
+#pragma unroll
+            for (int k = 0; k < A_MT; k++) sv = fmaf(gco[dd][j][k], win[j][b + HALO - (R - 1 - j) - R * k][dd], sv);
+            if (bglob - (R - 1 - j) >= 0) a += sv;             // gsi_ is still zero before block 0 (modulated.cc:574-578,600)
+          }
+          if (gain > 0.f) a *= gain;
+          acc[dd] = a;
+        }
+        if (bglob >= bt0 && bglob < bend)
+          *reinterpret_cast<float4*>(os + (bglob - b0) * D + (D - 4 - d0)) = make_float4(acc[3], acc[2], acc[1], acc[0]);
+      }
+    }
+    __syncthreads();
+  }
+}
+
 template <int R>
 int launch_syn512(const btk_fb* fb, const float2* Y, long nframes, long T_stride, int S, float* out, long out_stride,
                   long b0, long bcount, hipStream_t st)
 {
   constexpr int HALO = A_MT * R - 1;
   constexpr int NRING = 16 + HALO + 1;
-  const size_t lds = sizeof(float2) * ((size_t)NRING * FRS + A_NF + 1 + 256);
+  size_t lds = sizeof(float2) * ((size_t)NRING * FRS + A_NF + 1 + 256);
   auto kern = synthesis512_kernel<R>;
+  // the wide form needs 16-byte rows on both sides: even frame index of every chunk start (b0 + pd even; runs are multiples of 16),
+  // Y rows and output blocks 16-byte aligned
+  const bool wide = R <= 2 && !btk_switches().syn_narrow && ((b0 + fb->pd) & 1) == 0 && (T_stride & 1) == 0 && (out_stride & 3) == 0 &&
+                    (reinterpret_cast<uintptr_t>(Y) & 15) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0;
+  if constexpr (R <= 2) {
+    if (wide) { kern = synthesis512w_kernel<R>; lds = sizeof(float2) * ((size_t)32 * FRS + A_NF + 1); }
+  }
   // per launch: the attribute is per device, and one process may drive several GPUs (btk_set_device)
   BTK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   // run length: S_RUN blocks amortise the m R - 1 frame ring priming best, but few streams need shorter runs to fill
