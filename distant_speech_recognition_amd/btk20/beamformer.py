@@ -80,6 +80,7 @@ class _SubbandBeamformer(_BlockServedStream, VectorComplexFeatureStream):
         # SubbandMVDR(GSC) refuse it in their constructors (:2283-2285) and SubbandGSCRLS in next() (:1528-1530)
         self._half_band_shift = bool(half_band_shift)
         self._Yfull = None        # half_band_shift: device output of all M bins [1][M][T]
+        self._Xfull = None        # half_band_shift over pulled (non-analysis-bank) sources: all M snapshot bins [1][M][N][T]
         self._fftlen = int(fftlen)
         self._K = self._fftlen // 2 + 1
         self._channels = []
@@ -96,7 +97,7 @@ class _SubbandBeamformer(_BlockServedStream, VectorComplexFeatureStream):
     def clear_channel(self):
         self._channels = []
         self._snapshot_array = None
-        self._X = self._Y = self._Yfull = self._Xhost = None
+        self._X = self._Y = self._Yfull = self._Xhost = self._Xfull = None
 
     def chan_num(self):
         return len(self._channels)
@@ -152,8 +153,15 @@ class _SubbandBeamformer(_BlockServedStream, VectorComplexFeatureStream):
             else:
                 frames = [_pull_all(c) for c in chans]
                 T = min(len(f) for f in frames)
-                Xh = np.stack([np.stack(f[:T])[:, : self._K] for f in frames])         # [N][T][K]
-                self._X = torch.from_numpy(np.ascontiguousarray(np.transpose(Xh, (2, 0, 1))[None]).astype(np.complex64)).to(device())
+                Xa = np.stack([np.stack(f[:T]) for f in frames])                         # [N][T][M]
+                if self._half_band_shift:
+                    # halfBandShift: the reference dots every one of the M snapshots as supplied (beamformer.cc:1113-1128); a
+                    # generic source owes no conjugate symmetry between its bins, so all M bins go to the device
+                    self._Xfull = torch.from_numpy(np.ascontiguousarray(np.transpose(Xa, (2, 0, 1))[None]).astype(np.complex64)).to(device())
+                    self._X = self._Xfull[:, : self._K].contiguous()
+                else:
+                    Xh = Xa[:, :, : self._K]                                             # [N][T][K]
+                    self._X = torch.from_numpy(np.ascontiguousarray(np.transpose(Xh, (2, 0, 1))[None]).astype(np.complex64)).to(device())
             self._Xhost = None
         return self._X
 
@@ -172,7 +180,8 @@ class _SubbandBeamformer(_BlockServedStream, VectorComplexFeatureStream):
         try:
             if self._half_band_shift:
                 Wf = torch.from_numpy(self.effective_weights_all_bins().astype(np.complex64)).to(device())
-                self._Yfull = engine.bf_apply_all_bins(Wf, X)
+                # analysis-bank channels: bins above M/2 are the conjugate mirrors; pulled sources: every bin as supplied
+                self._Yfull = engine.bf_apply_all_bins(Wf, X) if self._Xfull is None else engine.bf_apply(Wf, self._Xfull)
                 self._Y = self._Yfull[:, : self._K]          # what a downstream synthesis bank reads (bins 0..M/2)
             else:
                 W = torch.from_numpy(self.effective_weights()).to(device())
@@ -211,7 +220,7 @@ class _SubbandBeamformer(_BlockServedStream, VectorComplexFeatureStream):
             c.reset()
         if self._snapshot_array is not None:
             self._snapshot_array.zero()
-        self._X = self._Y = self._Yfull = self._Xhost = None
+        self._X = self._Y = self._Yfull = self._Xhost = self._Xfull = None
         _BlockServedStream.reset(self)
 
 

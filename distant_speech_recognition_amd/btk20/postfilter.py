@@ -49,6 +49,10 @@ class ZelinskiPostFilterPtr(_BlockServedStream, VectorComplexFeatureStream):
             bf = src.python_object().beamformer() if hasattr(src, "python_object") and hasattr(src.python_object(), "beamformer") else None
         if bf is None:
             raise j_error("set beamformer's weights \n")
+        if getattr(bf, "_half_band_shift", False):
+            # the reference runs its post-filters over all fftLen bins of a half-band-shifted beamformer (postfilter.cc:170-182);
+            # this engine's post-filter kernels work on the M/2+1 bins of a non-shifted bank: refuse instead of filtering wrongly
+            raise j_error("post-filters over a beamformer with halfBandShift==true are not supported by this engine\n")
         return bf
 
     def _bf_or_none(self):

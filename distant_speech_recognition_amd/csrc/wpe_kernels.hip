@@ -16,6 +16,7 @@
 //   wpe_rvec_kernel    : r_c
 //   wpe_solve_kernel   : diagonal bias + loading + in-place Cholesky (matrix in global memory / L2) + solves
 #include "btk_internal.h"
+#include "chol_blocked.h"
 #include <cstdlib>
 
 namespace {
@@ -398,18 +399,7 @@ void wpe_rvec_kernel(const float2* __restrict__ X, const float* __restrict__ Win
   }
 }
 
-// One workgroup per (sc,k): blocked left-looking Cholesky, 16-column panels factored in LDS.
-// The unblocked version swept the trailing matrix in global memory once per column (P = 264: ~100 MB of traffic per
-// matrix, 2056 matrices -> 51 ms, bandwidth-bound); here every panel is read once, updated from the already
-// factored columns staged through LDS in 16-column chunks, factored in LDS and written back once (< 1 MB per matrix).
-// Forward substitution rides along with the panels; back substitution re-reads them in reverse order.
-constexpr int CH_NB = 16;              // panel width
-constexpr int CH_LD = CH_NB + 1;       // padded row (float2): conflict-free row-per-lane access
-
-__device__ __forceinline__ float2 cmul_conj_b(float2 a, float2 b) { return make_float2(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y); }
-// value of lane `l` (compile-time) broadcast to the wavefront through an SGPR
-__device__ __forceinline__ float lane_value(float x, int l) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), l)); }
-
+// One workgroup per (sc,k): diagonal bias + loading, then the blocked Cholesky solve of chol_blocked.h.
 __global__ __launch_bounds__(256)
 void wpe_solve_kernel(float2* __restrict__ R, const float2* __restrict__ rvec, WpeGeom g, float load_factor,
                       float diagonal_bias, float2* __restrict__ G, int* __restrict__ fail_count,
@@ -423,7 +413,7 @@ void wpe_solve_kernel(float2* __restrict__ R, const float2* __restrict__ rvec, W
   const int Ppad = (P + 1) & ~1;
   float2* rhs = reinterpret_cast<float2*>(smem);                   // [Ppad]
   float* red = reinterpret_cast<float*>(rhs + Ppad);               // [512]
-  float2* panel = reinterpret_cast<float2*>(red + 512);            // [P][CH_LD]
+  float2* panel = reinterpret_cast<float2*>(red + 512);            // [P][cholb::CH_LD]
   float2* mat = R + ((long)sc * g.K + k) * (long)P * P;
   const int s = sc / g.C, c = sc % g.C;
   float2* gout = G + (((long)s * g.C + c) * g.K + k) * (long)P;
@@ -457,225 +447,11 @@ void wpe_solve_kernel(float2* __restrict__ R, const float2* __restrict__ rvec, W
   for (int p = tid; p < P; p += 256) mat[(long)p * P + p].x += load;
   __syncthreads();
 
-  bool bad = false;
-  const int lane = tid & 63, wave = tid >> 6;
-  // the single-wavefront phases rotate over the four wavefronts (= SIMDs) with the panel and the workgroup: with every workgroup
-  // using its wavefront 0, the four resident workgroups of a CU queue up on one SIMD while three idle
   const int wrot = blockIdx.x + blockIdx.y;
   long long tm[7] = {0, 0, 0, 0, 0, 0, 0};
   long long tlast = phase_cycles ? clock64() : 0;
   auto mark = [&](int i) { if (phase_cycles) { const long long c = clock64(); tm[i] += c - tlast; tlast = c; } };
-  const int mi = lane & 15, mk = lane >> 4;                       // MFMA operand coordinates of this lane
-  for (int jb = 0; jb < P && !bad; jb += CH_NB) {
-    const int nb = (P - jb < CH_NB) ? P - jb : CH_NB;
-    const int rows = P - jb;
-    // ---- panel <- A[jb.., jb..jb+nb)
-    for (int idx = tid; idx < rows * CH_NB; idx += 256) {
-      const int r = idx / CH_NB, cc = idx % CH_NB;
-      panel[r * CH_LD + cc] = (cc < nb) ? mat[(long)(jb + r) * P + jb + cc] : make_float2(0.f, 0.f);
-    }
-    __syncthreads();
-    mark(0);                                                         // panel load
-    // ---- left-looking update on the matrix cores: panel[r][cc] -= sum_{q<jb} L[jb+r][q] conj(L[jb+cc][q]).
-    //      A wavefront owns 16-row blocks; v_mfma_f32_16x16x4_f32 (exact fp32) takes A[i][k] from lane i + 16 k and B[k][j] from
-    //      lane j + 16 k, so a lane loads four consecutive columns of its row (q0 + 4 mk ..) for both operands and the four
-    //      k-steps of a 16-column chunk pair lane group mk with column q0 + 4 mk + step -- any pairing sums the same products.
-    //      Re(a conj b) = ar br + ai bi, Im = ai br - ar bi: four MFMAs per step.
-    if (jb > 0) {
-      const int nrb = (rows + 15) / 16;
-      const float2* brow = mat + (long)(jb + mi) * P;               // the panel's own rows jb + j (valid while j < nb)
-      const bool bok = mi < nb;
-      for (int rb = wave; rb < nrb; rb += 4) {
-        const int r = rb * 16 + mi;
-        const bool aok = r < rows;
-        const float2* arow = mat + (long)(jb + (aok ? r : 0)) * P;
-        f32x4 cr = {0.f, 0.f, 0.f, 0.f}, ci = {0.f, 0.f, 0.f, 0.f};
-        float2 av[4], bv[4], an[4], bn[4];
-        auto ld = [&](float2 (&a)[4], float2 (&b)[4], int q0) {
-#pragma unroll
-          for (int e = 0; e < 4; e++) {
-            a[e] = aok ? arow[q0 + 4 * mk + e] : make_float2(0.f, 0.f);
-            b[e] = bok ? brow[q0 + 4 * mk + e] : make_float2(0.f, 0.f);
-          }
-        };
-        ld(av, bv, 0);
-        for (int q0 = 0; q0 < jb; q0 += 16) {
-          if (q0 + 16 < jb) ld(an, bn, q0 + 16);                   // the next chunk's loads fly under this chunk's MFMAs
-#pragma unroll
-          for (int e = 0; e < 4; e++) {
-            cr = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e].x, bv[e].x, cr, 0, 0, 0);
-            cr = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e].y, bv[e].y, cr, 0, 0, 0);
-            ci = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e].y, bv[e].x, ci, 0, 0, 0);
-            ci = __builtin_amdgcn_mfma_f32_16x16x4f32(-av[e].x, bv[e].y, ci, 0, 0, 0);
-          }
-#pragma unroll
-          for (int e = 0; e < 4; e++) { av[e] = an[e]; bv[e] = bn[e]; }
-        }
-        // D[i][j]: register v of lane l holds row 4 (l / 16) + v, column l % 16
-#pragma unroll
-        for (int v = 0; v < 4; v++) {
-          const int rr = rb * 16 + 4 * mk + v;
-          if (rr < rows) {
-            float2 t = panel[rr * CH_LD + mi];
-            panel[rr * CH_LD + mi] = make_float2(t.x - cr[v], t.y - ci[v]);
-          }
-        }
-      }
-    }
-    __syncthreads();
-    mark(1);                                                         // MFMA update
-    // ---- the 16 x 16 diagonal block: one wavefront, column by column (LDS accesses of one wavefront stay in program order)
-    if (wave == ((wrot + (jb >> 4)) & 3)) {
-      // lane r < 16 holds row r of the block in registers; the pivot and the column entries L[c2][cc] travel through SGPRs
-      // (v_readlane): the serial chain is register arithmetic, not LDS round trips (19 k -> a few k cycles per panel)
-      int okflag = 1;
-      const int r = lane & 15;
-      float2 row[CH_NB];
-#pragma unroll
-      for (int c2 = 0; c2 < CH_NB; c2++) row[c2] = panel[r * CH_LD + c2];
-#pragma unroll
-      for (int cc = 0; cc < CH_NB; cc++) {
-        if (cc < nb && okflag) {
-          const float piv = lane_value(row[cc].x, cc);
-          if (!(piv > 0.f)) { okflag = 0; }
-          else {
-            const float d = sqrtf(piv), inv = 1.0f / d;
-            if (r == cc) row[cc] = make_float2(d, 0.f);
-            else if (r > cc) row[cc] = make_float2(row[cc].x * inv, row[cc].y * inv);
-#pragma unroll
-            for (int c2 = cc + 1; c2 < CH_NB; c2++) {
-              if (c2 < nb) {
-                const float2 lc = make_float2(lane_value(row[cc].x, c2), lane_value(row[cc].y, c2));    // L[c2][cc]
-                if (r >= c2) { const float2 t = cmul_conj_b(row[cc], lc); row[c2].x -= t.x; row[c2].y -= t.y; }
-              }
-            }
-          }
-        }
-      }
-      if (lane < nb) {
-#pragma unroll
-        for (int c2 = 0; c2 < CH_NB; c2++) panel[lane * CH_LD + c2] = row[c2];
-      }
-      if (lane == 0) red[0] = okflag ? 1.f : 0.f;
-    }
-    __syncthreads();
-    if (red[0] == 0.f) { bad = true; break; }
-    mark(2);                                                         // diagonal block
-    // ---- rows below the block: x L11^H = a, one thread per row, no barriers (L11 entries are LDS broadcasts)
-    for (int r = nb + tid; r < rows; r += 256) {
-      float2 x[CH_NB];
-#pragma unroll
-      for (int cc = 0; cc < CH_NB; cc++) {
-        if (cc < nb) {
-          float2 v = panel[r * CH_LD + cc];
-#pragma unroll
-          for (int c2 = 0; c2 < cc; c2++) {
-            const float2 t = cmul_conj_b(x[c2], panel[cc * CH_LD + c2]);
-            v.x -= t.x; v.y -= t.y;
-          }
-          const float inv = 1.0f / panel[cc * CH_LD + cc].x;
-          x[cc] = make_float2(v.x * inv, v.y * inv);
-          panel[r * CH_LD + cc] = x[cc];
-        }
-      }
-    }
-    __syncthreads();
-    mark(3);                                                         // rows below the block
-    if (bad) break;
-    // ---- write the factored panel back, forward substitution for its columns: L y = r
-    for (int idx = tid; idx < rows * CH_NB; idx += 256) {
-      const int r = idx / CH_NB, cc = idx % CH_NB;
-      if (cc < nb && cc <= r) mat[(long)(jb + r) * P + jb + cc] = panel[r * CH_LD + cc];
-    }
-    if (wave == ((wrot + (jb >> 4) + 1) & 3)) {
-      // L11 y = r for the panel's own entries: lane r holds y_r and row r of L11, column by column through SGPR broadcasts
-      const int r = lane & 15;
-      float2 lr[CH_NB];
-#pragma unroll
-      for (int c2 = 0; c2 < CH_NB; c2++) lr[c2] = panel[r * CH_LD + c2];
-      float2 y = (lane < nb) ? rhs[jb + lane] : make_float2(0.f, 0.f);
-#pragma unroll
-      for (int c2 = 0; c2 < CH_NB; c2++) {
-        if (c2 < nb) {
-          const float dinv = 1.0f / lane_value(lr[c2].x, c2);
-          const float2 yc = make_float2(lane_value(y.x, c2) * dinv, lane_value(y.y, c2) * dinv);
-          if (r == c2) y = yc;
-          else if (r > c2) { y.x -= lr[c2].x * yc.x - lr[c2].y * yc.y; y.y -= lr[c2].x * yc.y + lr[c2].y * yc.x; }
-        }
-      }
-      if (lane < nb) rhs[jb + lane] = y;
-    }
-    __syncthreads();
-    for (int r = nb + tid; r < rows; r += 256) {
-      float2 y = rhs[jb + r];
-      for (int cc = 0; cc < nb; cc++) {
-        const float2 l = panel[r * CH_LD + cc], yy = rhs[jb + cc];
-        y.x -= l.x * yy.x - l.y * yy.y;
-        y.y -= l.x * yy.y + l.y * yy.x;
-      }
-      rhs[jb + r] = y;
-    }
-    __syncthreads();
-    mark(4);                                                         // write-back + forward substitution
-  }
-  if (bad) { if (tid == 0) atomicAdd(fail_count, 1); return; }
-  // ---- back substitution L^H g = y, panels in reverse order
-  const int npan = (P + CH_NB - 1) / CH_NB;
-  for (int pb = npan - 1; pb >= 0; pb--) {
-    const int jb = pb * CH_NB;
-    const int nb = (P - jb < CH_NB) ? P - jb : CH_NB;
-    const int rows = P - jb;
-    __syncthreads();
-    for (int idx = tid; idx < rows * CH_NB; idx += 256) {
-      const int r = idx / CH_NB, cc = idx % CH_NB;
-      panel[r * CH_LD + cc] = (cc < nb && cc <= r) ? mat[(long)(jb + r) * P + jb + cc] : make_float2(0.f, 0.f);
-    }
-    __syncthreads();
-    // contributions of the rows below the diagonal block: sum_r conj(L[r][cc]) g[r], r >= nb
-    float2 part[CH_NB];
-#pragma unroll
-    for (int cc = 0; cc < CH_NB; cc++) part[cc] = make_float2(0.f, 0.f);
-    for (int r = nb + tid; r < rows; r += 256) {
-      const float2 gr = rhs[jb + r];
-#pragma unroll
-      for (int cc = 0; cc < CH_NB; cc++) {
-        const float2 l = panel[r * CH_LD + cc];
-        part[cc].x += l.x * gr.x + l.y * gr.y;                     // conj(l) * g
-        part[cc].y += l.x * gr.y - l.y * gr.x;
-      }
-    }
-    // reduce the 16 partial sums over the workgroup: wave shuffles, then 4 waves through LDS
-#pragma unroll
-    for (int cc = 0; cc < CH_NB; cc++) {
-      float px = part[cc].x, py = part[cc].y;
-      for (int o = 32; o > 0; o >>= 1) { px += __shfl_xor(px, o, 64); py += __shfl_xor(py, o, 64); }
-      if ((tid & 63) == 0) { red[((tid >> 6) * CH_NB + cc) * 2] = px; red[((tid >> 6) * CH_NB + cc) * 2 + 1] = py; }
-    }
-    __syncthreads();
-    if (wave == ((wrot + pb) & 3)) {
-      // L11^H g = z for the panel's own entries: lane cc holds z_cc and column cc of L11
-      const int cc = lane & 15;
-      float2 lc[CH_NB];
-#pragma unroll
-      for (int c2 = 0; c2 < CH_NB; c2++) lc[c2] = panel[c2 * CH_LD + cc];            // L[c2][cc] (zero above the diagonal)
-      float2 z = make_float2(0.f, 0.f);
-      if (lane < nb) {
-        z = rhs[jb + lane];
-        for (int wv = 0; wv < 4; wv++) { z.x -= red[(wv * CH_NB + lane) * 2]; z.y -= red[(wv * CH_NB + lane) * 2 + 1]; }
-      }
-#pragma unroll
-      for (int c2 = CH_NB - 1; c2 >= 0; c2--) {
-        if (c2 < nb) {
-          const float dinv = 1.0f / lane_value(lc[c2].x, c2);
-          const float2 gg = make_float2(lane_value(z.x, c2) * dinv, lane_value(z.y, c2) * dinv);
-          if (cc == c2) z = gg;
-          else if (cc < c2) { z.x -= lc[c2].x * gg.x + lc[c2].y * gg.y; z.y -= lc[c2].x * gg.y - lc[c2].y * gg.x; }     // conj(l) g
-        }
-      }
-      if (lane < nb) rhs[jb + lane] = z;
-    }
-    __syncthreads();
-  }
+  if (!cholb::solve(mat, P, rhs, red, panel, 0.f, wrot, mark)) { if (tid == 0) atomicAdd(fail_count, 1); return; }
   for (int p = tid; p < P; p += 256) gout[p] = rhs[p];
   mark(5);                                                           // back substitution
   if (phase_cycles && tid == 0) {
@@ -724,7 +500,7 @@ int btk_wpe_estimate(const void* X, int S, int K, int C, long T_stride, long T, 
   const int nspan = 63 / g.L + 2;                                  // channels a 64-row tile can touch
   const size_t lds_herk = sizeof(float2) * 2 * (size_t)nspan * (WT_ + g.L - 1) + sizeof(float) * 4 * WT_;
   const float load_factor = (float)pow(10.0, load_db / 10.0);
-  const size_t lds_solve = sizeof(float2) * ((P + 1) & ~1L) + sizeof(float) * 512 + sizeof(float2) * (size_t)P * CH_LD;
+  const size_t lds_solve = sizeof(float2) * ((P + 1) & ~1L) + sizeof(float) * 512 + sizeof(float2) * (size_t)P * cholb::CH_LD;
   if (lds_solve > 160 * 1024)
     return btk_set_error(BTK_ERR_DIMENSION, "btk_wpe_estimate: C*(upperN-lowerN+1) = %ld taps exceed the LDS-resident solver (max ~560)", P);
   if (lds_solve > 64 * 1024)

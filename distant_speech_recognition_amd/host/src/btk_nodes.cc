@@ -792,6 +792,7 @@ void SubbandMVDR::divide_all_nondiagonal_elements(float mu)
 void SubbandMVDR::divide_nondiagonal_elements(unsigned fbinX, float mu)
 {
   if (!dR_) throw j_error("Construct first a noise covariance matrix\n");
+  if (fbinX > fftLen2_) throw jindex_error("frequency bin %d is out of range: the matrices exist for bins 0..%d\n", (int)fbinX, (int)fftLen2_);
   const unsigned N = chanN();
   check_abi(btk_mvdr_divide_nondiagonal(static_cast<float*>(dR_) + (size_t)fbinX * 2 * N * N, 1, (int)N, mu, NULL));
 }
@@ -799,6 +800,7 @@ void SubbandMVDR::divide_nondiagonal_elements(unsigned fbinX, float mu)
 const gsl_matrix_complex* SubbandMVDR::noise_spatial_spectral_matrix(unsigned fbinX)
 {
   if (!dR_) return NULL;                                       // the reference returns its NULL R_[fbinX]
+  if (fbinX > fftLen2_) throw jindex_error("frequency bin %d is out of range: the matrices exist for bins 0..%d\n", (int)fbinX, (int)fftLen2_);
   const unsigned N = chanN();
   if (!R_view_ || R_view_->size1 != N) { gsl_matrix_complex_free(R_view_); R_view_ = gsl_matrix_complex_alloc(N, N); }
   std::vector<float> r((size_t)2 * N * N);
@@ -822,6 +824,7 @@ bool SubbandMVDR::set_noise_spatial_spectral_matrix(unsigned fbinX, gsl_matrix_c
   const unsigned N = chanN();
   if (Rnn->size1 != N) { fprintf(stderr, "The number of the rows of the matrix must be %d but it is %lu\n", N, (unsigned long)Rnn->size1); return false; }
   if (Rnn->size2 != N) { fprintf(stderr, "The number of the columns of the matrix must be %d but it is %lu\n", N, (unsigned long)Rnn->size2); return false; }
+  if (fbinX > fftLen2_) throw jindex_error("frequency bin %d is out of range: the matrices exist for bins 0..%d\n", (int)fbinX, (int)fftLen2_);
   alloc_R_();
   std::vector<float> r((size_t)2 * N * N);
   for (unsigned a = 0; a < N; a++)
@@ -858,6 +861,7 @@ void SubbandMVDR::set_all_diagonal_loading(float diagonalWeight)
 void SubbandMVDR::set_diagonal_looading(unsigned fbinX, float diagonalWeight)
 {
   if (!dR_) throw j_error("Construct first a noise covariance matrix\n");
+  if (fbinX > fftLen2_) throw jindex_error("frequency bin %d is out of range: the matrices exist for bins 0..%d\n", (int)fbinX, (int)fftLen2_);
   const unsigned N = chanN();
   check_abi(btk_mvdr_diagonal_loading(static_cast<float*>(dR_) + (size_t)fbinX * 2 * N * N, 1, (int)N, diagonalWeight, NULL));
 }
@@ -1117,6 +1121,7 @@ void McCowanPostFilter::push_R_()
 const gsl_matrix_complex* McCowanPostFilter::noise_spatial_spectral_matrix(unsigned fbinX)
 {
   if (!dR_) return NULL;
+  if (fbinX > fftLen_ / 2) throw jindex_error("frequency bin %d is out of range: the matrices exist for bins 0..%d\n", (int)fbinX, (int)(fftLen_ / 2));
   fetch_R_();
   const unsigned N = nChanR_;
   if (Rview_ && Rview_->size1 != N) { gsl_matrix_complex_free(Rview_); Rview_ = NULL; }
@@ -1128,6 +1133,7 @@ const gsl_matrix_complex* McCowanPostFilter::noise_spatial_spectral_matrix(unsig
 bool McCowanPostFilter::set_noise_spatial_spectral_matrix(unsigned fbinX, gsl_matrix_complex* Rnn)
 {
   if (Rnn->size1 != Rnn->size2) { fprintf(stderr, "The noise coherence matrix should be the square matrix\n"); return false; }
+  if (fbinX > fftLen_ / 2) throw jindex_error("frequency bin %d is out of range: the matrices exist for bins 0..%d\n", (int)fbinX, (int)(fftLen_ / 2));
   const unsigned K = fftLen_ / 2 + 1, N = (unsigned)Rnn->size1;
   if (!dR_ || nChanR_ != N) {
     dev_free(dR_);
@@ -1174,6 +1180,7 @@ void McCowanPostFilter::set_all_diagonal_loading(float diagonalWeight)
 void McCowanPostFilter::set_diagonal_looading(unsigned fbinX, float diagonalWeight)
 {
   if (!dR_) throw j_error("Construct/set first a noise coherence matrix\n");
+  if (fbinX > fftLen_ / 2) throw jindex_error("frequency bin %d is out of range: the matrices exist for bins 0..%d\n", (int)fbinX, (int)(fftLen_ / 2));
   check_abi(btk_mvdr_diagonal_loading(static_cast<float*>(dR_) + (size_t)2 * fbinX * nChanR_ * nChanR_, 1, (int)nChanR_,
                                       diagonalWeight, NULL));
   invR_computed_ = false;
@@ -1183,6 +1190,7 @@ void McCowanPostFilter::set_diagonal_looading(unsigned fbinX, float diagonalWeig
 void McCowanPostFilter::divide_nondiagonal_elements(unsigned fbinX, float mu)
 {
   if (!dR_) throw j_error("Construct/set first a noise coherence matrix\n");
+  if (fbinX > fftLen_ / 2) throw jindex_error("frequency bin %d is out of range: the matrices exist for bins 0..%d\n", (int)fbinX, (int)(fftLen_ / 2));
   fetch_R_();
   const unsigned N = nChanR_;
   for (unsigned a = 0; a < N; a++)

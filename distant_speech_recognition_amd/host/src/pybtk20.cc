@@ -301,7 +301,8 @@ PYBIND11_MODULE(_btk20cpp, m)
       .def("mvdr_weights", [](SubbandMVDR& b, unsigned fbinX) { return copy_of(b.mvdr_weights(fbinX)); })
       .def("set_noise_spatial_spectral_matrix", [](SubbandMVDR& b, unsigned fbinX, py::array_t<cd, py::array::c_style | py::array::forcecast> Rnn) {
              GslCMat M(Rnn); return b.set_noise_spatial_spectral_matrix(fbinX, M.m); })
-      .def("noise_spatial_spectral_matrix", [](SubbandMVDR& b, unsigned fbinX) { return copy_of(b.noise_spatial_spectral_matrix(fbinX)); })
+      .def("noise_spatial_spectral_matrix", [](SubbandMVDR& b, unsigned fbinX) -> py::object {      // None while no matrix is set (the reference returns NULL)
+             const gsl_matrix_complex* m = b.noise_spatial_spectral_matrix(fbinX); return m ? py::object(copy_of(m)) : py::object(py::none()); })
       .def("set_diffuse_noise_model", [](SubbandMVDR& b, py::array_t<double, py::array::c_style | py::array::forcecast> mpos, float fs, float sspeed) {
              GslMat M(mpos); return b.set_diffuse_noise_model(M.m, fs, sspeed); }, py::arg("mic_positions"), py::arg("samplerate"), py::arg("sspeed") = 343740.0f)
       .def("set_all_diagonal_loading", &SubbandMVDR::set_all_diagonal_loading)
@@ -342,8 +343,11 @@ PYBIND11_MODULE(_btk20cpp, m)
              GslMat M(mpos); return f.set_diffuse_noise_model(M.m, fs, sspeed); }, py::arg("mic_positions"), py::arg("samplerate"), py::arg("sspeed") = 343740.0)
       .def("set_noise_spatial_spectral_matrix", [](McCowanPostFilter& f, unsigned fbinX, py::array_t<cd, py::array::c_style | py::array::forcecast> Rnn) {
              GslCMat M(Rnn); return f.set_noise_spatial_spectral_matrix(fbinX, M.m); })
-      .def("noise_spatial_spectral_matrix", [](McCowanPostFilter& f, unsigned fbinX) { return copy_of(f.noise_spatial_spectral_matrix(fbinX)); })
+      .def("noise_spatial_spectral_matrix", [](McCowanPostFilter& f, unsigned fbinX) -> py::object {
+             const gsl_matrix_complex* m = f.noise_spatial_spectral_matrix(fbinX); return m ? py::object(copy_of(m)) : py::object(py::none()); })
       .def("set_all_diagonal_loading", &McCowanPostFilter::set_all_diagonal_loading)
+      .def("set_diagonal_looading", &McCowanPostFilter::set_diagonal_looading)
+      .def("divide_nondiagonal_elements", &McCowanPostFilter::divide_nondiagonal_elements)
       .def("divide_all_nondiagonal_elements", &McCowanPostFilter::divide_all_nondiagonal_elements);
   py::class_<LefkimmiatisPostFilter, McCowanPostFilter, cref<LefkimmiatisPostFilter>>(m, "LefkimmiatisPostFilterPtr")
       .def(py::init([](VectorComplexFeatureStream* output, unsigned fftlen, double min_sv, unsigned fbin_x1, double alpha, int type, int min_frames,

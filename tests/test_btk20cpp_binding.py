@@ -90,6 +90,8 @@ def test_exception_family_and_host_side_methods():
         arr.set_samples(x * (c + 1), c)
     arr.update()
     assert np.allclose(arr.matrix_f(2), (1 - float(np.float32(0.9))) * np.outer(x[2] * np.arange(1, 4), x[2] * np.arange(1, 4)))
+    # no noise matrix yet: None like the reference's NULL R_[fbinX] (the binding once dereferenced it)
+    assert B.SubbandMVDRPtr(fftlen=64).noise_spatial_spectral_matrix(3) is None
 
 
 @pytest.mark.gpu
@@ -131,3 +133,33 @@ def test_ds_zelinski_flow_through_cpp_nodes(orc, dev, proto256, kinect_pcm, tmp_
     out2 = np.concatenate([np.array(buf) for buf in sfb2])
     ref2 = orc.synthesis(g, M, m, r, 2, Yb)
     assert out2.shape == ref2.shape and np.max(np.abs(out2 - ref2)) < 0.5
+
+
+@pytest.mark.gpu
+def test_noise_matrix_accessors_are_range_checked(dev):
+    """set / get / load / divide of one bin's noise matrix: bins beyond M/2 are jindex_error, not device memory beyond the
+    allocation (advisor finding, round 2); unset matrices read as None"""
+    from distant_speech_recognition_amd import btk20cpp as B
+    Mh, N = 64, 4
+    mv = B.SubbandMVDRPtr(fftlen=Mh)
+    for _ in range(N):
+        mv.set_channel(B.PyVectorComplexFeatureStreamPtr(_Source(np.zeros((1, Mh), np.complex128))))
+    R = np.eye(N, dtype=np.complex128) * 2.0
+    assert mv.set_noise_spatial_spectral_matrix(Mh // 2, R)
+    assert np.allclose(mv.noise_spatial_spectral_matrix(Mh // 2), R) and np.allclose(mv.noise_spatial_spectral_matrix(1), 0.0)
+    mv.set_diagonal_looading(Mh // 2, 0.5)
+    mv.divide_nondiagonal_elements(Mh // 2, 1.0)
+    assert np.allclose(mv.noise_spatial_spectral_matrix(Mh // 2), np.eye(N) * 2.5)
+    for call in (lambda: mv.noise_spatial_spectral_matrix(Mh // 2 + 1), lambda: mv.set_diagonal_looading(Mh, 0.1),
+                 lambda: mv.divide_nondiagonal_elements(Mh // 2 + 1, 0.1), lambda: mv.set_noise_spatial_spectral_matrix(Mh, R)):
+        with pytest.raises(B.jindex_error):
+            call()
+    src = B.PyVectorComplexFeatureStreamPtr(_Source(np.zeros((1, Mh), np.complex128)))
+    pf = B.McCowanPostFilterPtr(src, Mh)
+    assert pf.noise_spatial_spectral_matrix(0) is None
+    assert pf.set_noise_spatial_spectral_matrix(3, R)
+    assert np.allclose(pf.noise_spatial_spectral_matrix(3), R)
+    for call in (lambda: pf.noise_spatial_spectral_matrix(Mh // 2 + 1), lambda: pf.set_diagonal_looading(Mh, 0.1),
+                 lambda: pf.divide_nondiagonal_elements(Mh, 0.1), lambda: pf.set_noise_spatial_spectral_matrix(Mh // 2 + 1, R)):
+        with pytest.raises(B.jindex_error):
+            call()

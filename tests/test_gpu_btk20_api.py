@@ -469,3 +469,60 @@ def test_half_band_shift_ds_and_gsc(orc, dev, proto256, kinect_pcm, wavs):
     rls.init_precision_matrix(0.01)
     with pytest.raises(j_error):
         rls.next()
+
+
+class _FrameSource(object):
+    """a Python algorithm object as the reference's C++ nodes see it: size(), __iter__, next(), reset()"""
+
+    def __init__(self, frames):
+        self.frames, self.i = frames, 0
+
+    def size(self):
+        return self.frames.shape[1]
+
+    def __iter__(self):
+        self.i = 0
+        return self
+
+    def next(self):
+        if self.i >= len(self.frames):
+            raise StopIteration
+        self.i += 1
+        return self.frames[self.i - 1]
+
+    __next__ = next
+
+    def reset(self):
+        self.i = 0
+
+
+def test_half_band_shift_over_generic_sources_and_postfilter_guard(orc, dev):
+    """halfBandShift over sources that are NOT analysis banks (PyVectorComplexFeatureStream): the reference dots every one of the
+    M snapshots as supplied (beamformer.cc:1113-1128) -- no conjugate symmetry between bins may be assumed -- and a post-filter
+    over such a beamformer is refused (this engine's post-filters work on the M/2+1 bins of a non-shifted bank)."""
+    from distant_speech_recognition_amd.btk20 import (PyVectorComplexFeatureStreamPtr, SubbandGSCPtr, ZelinskiPostFilterPtr, j_error)
+    from distant_speech_recognition_amd.pybeamformer import calc_delays
+    Mh, N, T = 64, 4, 37
+    rng = np.random.default_rng(99)
+    X = (rng.standard_normal((T, N, Mh)) + 1j * rng.standard_normal((T, N, Mh))) * 1000.0        # no symmetry between bins k and M-1-k
+    delays = calc_delays("linear", MPOS, [AZIMUTH, None, None])
+    wq = orc.calc_mainlobe_halfband(Mh, N, FS, delays)
+    gsc = SubbandGSCPtr(fftlen=Mh, half_band_shift=True)
+    for n in range(N):
+        gsc.set_channel(PyVectorComplexFeatureStreamPtr(_FrameSource(X[:, n, :])))
+    gsc.calc_gsc_weights(FS, delays)
+    wl = np.zeros_like(wq)
+    for k in range(Mh):
+        wa = (rng.standard_normal(N - 1) + 1j * rng.standard_normal(N - 1)) * 0.05
+        packed = np.empty(2 * (N - 1)); packed[0::2] = wa.real; packed[1::2] = wa.imag
+        gsc.set_active_weights_f(k, packed)
+        wl[k] = orc.blocking_matrix(wq[k], 1) @ wa
+    out = np.stack([np.array(v) for v in gsc])
+    ref = orc.gsc_frames_halfband(X, wq, wl)
+    assert out.shape == ref.shape == (T, Mh)
+    assert np.max(np.abs(out - ref)) < 2e-5 * np.max(np.abs(ref))
+    assert np.max(np.abs(out[:, Mh // 2 + 1:] - ref[:, Mh // 2 + 1:])) < 2e-5 * np.max(np.abs(ref))     # the bins a mirror would get wrong
+    pf = ZelinskiPostFilterPtr(gsc, Mh, 0.7, 2)
+    pf.set_beamformer(gsc)
+    with pytest.raises(j_error):
+        pf.next()
