@@ -78,7 +78,25 @@ def main():
         Wf = torch.randn((K, N), dtype=torch.complex64, device=dev)
         t_bf_full = _t(lambda: eng.bf_apply(Wf, Xf))
         t_bf_shard = _t(lambda: eng.bf_apply(Wf[a8:b8].contiguous(), Xs))
-        shard_probe = {"analysis_all_bins_ms": t_full, "analysis_one_of_8_bin_shards_ms": t_shard,
+        # option (iii) of SURVEY 8(e): the rank's K/8 bins as a pruned DFT = GEMM (K/8 x M) . (M x N T) on the polyphase outputs.
+        # Priced here with the vendor fp32 GEMM (torch.matmul -> hipBLASLt; a measurement proxy, not a product path): the cos and
+        # sin planes of the rank's rows against the real polyphase block, 4 (K/8) M N T flop
+        Pm = torch.randn((M, N * T), dtype=torch.float32, device=dev)
+        Cm = torch.randn((2 * (b8 - a8), M), dtype=torch.float32, device=dev)
+        t_gemm = _t(lambda: torch.matmul(Cm, Pm))
+        gemm_flop = 2.0 * 2 * (b8 - a8) * M * N * T
+        t_poly = _t(lambda: afb.analysis_polyphase(pcm))      # the polyphase stage that would still precede the GEMM
+        # option (ii): every rank transforms N/8 channels completely, then an all-to-all hands each rank its bins of all channels:
+        # volume per block 8 K N T bytes in total, 7/8 of a rank's 1/8 leaves it over its 7 xGMI links (153 GB/s each, MI355X guide)
+        X8 = torch.empty((S, K, N // 8, T), dtype=torch.complex64, device=dev)
+        t_ana8 = _t(lambda: afb.analysis(pcm[:, : N // 8].contiguous(), out=X8))
+        a2a_bytes_per_link = 8.0 * K * N * T * S / 8 / 8
+        del Pm, Cm, X8
+        shard_probe = {"option_iii_pruned_dft_gemm_ms": t_gemm, "option_iii_gemm_TFLOPs": gemm_flop / t_gemm / 1e9,
+                       "option_iii_polyphase_stage_ms": t_poly,
+                       "option_ii_analysis_of_N_over_8_channels_ms": t_ana8, "option_ii_all_to_all_bytes_per_link": a2a_bytes_per_link,
+                       "option_ii_all_to_all_ms_at_153GBps_per_link": a2a_bytes_per_link / 153e9 * 1e3,
+                       "analysis_all_bins_ms": t_full, "analysis_one_of_8_bin_shards_ms": t_shard,
                        "slice_copy_the_round1_path_needed_ms": t_slice, "bf_apply_all_bins_ms": t_bf_full,
                        "bf_apply_one_shard_ms": t_bf_shard,
                        "note": "rank-side cost of option (i) (replicated PCM + FFT, only the rank's bins stored) on one GPU"}

@@ -95,6 +95,8 @@ SIGNATURES = {
     "btk_wpe_apply": (_i, [_vp, _vp, _vp, _i, _i, _i, _l, _l, _i, _i, _i, _i, _vp]),
     "btk_bin_range": (None, [_i, _i, _i, C.POINTER(_i), C.POINTER(_i)]),
     "btk_allgather_bins": (_i, [_vp, _vp, _vp, _i, _i, _l, _i, _i, _vp]),
+    "btk_bin_rows_padded": (_i, [_i, _i]),
+    "btk_allgather_bins_inplace": (_i, [_vp, _vp, _i, _i, _l, _i, _i, _vp]),
     "btk_weights_mainlobe": (_i, [_i, _i, _f, _vp, _vp]),
     "btk_weights_mainlobe_halfband": (_i, [_i, _i, _f, _vp, _vp]),
     "btk_weights_mainlobe_2": (_i, [_i, _i, _f, _vp, _vp, _vp]),

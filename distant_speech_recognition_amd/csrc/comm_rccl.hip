@@ -10,30 +10,40 @@
 #include "btk_internal.h"
 #include <dlfcn.h>
 #include <cstddef>
+#include <mutex>
 
 namespace {
 typedef int (*nccl_group_fn)();
 typedef int (*nccl_bcast_fn)(const void*, void*, size_t, int, int, void*, hipStream_t);
+typedef int (*nccl_allgather_fn)(const void*, void*, size_t, int, void*, hipStream_t);
 typedef const char* (*nccl_errstr_fn)(int);
-struct Rccl { nccl_group_fn start = nullptr, end = nullptr; nccl_bcast_fn bcast = nullptr; nccl_errstr_fn errstr = nullptr; bool tried = false; };
+struct Rccl { nccl_group_fn start = nullptr, end = nullptr; nccl_bcast_fn bcast = nullptr; nccl_allgather_fn allgather = nullptr; nccl_errstr_fn errstr = nullptr; };
 Rccl g_rccl;
+std::once_flag g_rccl_once;
 
+// Bound once per process (std::call_once: a second thread waits for the first instead of seeing a half-filled table).  Order:
+// symbols already visible in the process; an RCCL the host program loaded RTLD_LOCAL (torch does) through RTLD_NOLOAD -- the SAME
+// instance, a communicator must not cross library instances --; only then a fresh dlopen.
 bool bind_rccl()
 {
-  if (g_rccl.tried) return g_rccl.bcast != nullptr;
-  g_rccl.tried = true;
-  void* h = RTLD_DEFAULT;
-  if (!dlsym(h, "ncclBroadcast")) {
-    h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
-    if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
-    if (!h) return false;
-  }
-  g_rccl.start = reinterpret_cast<nccl_group_fn>(dlsym(h, "ncclGroupStart"));
-  g_rccl.end = reinterpret_cast<nccl_group_fn>(dlsym(h, "ncclGroupEnd"));
-  g_rccl.bcast = reinterpret_cast<nccl_bcast_fn>(dlsym(h, "ncclBroadcast"));
-  g_rccl.errstr = reinterpret_cast<nccl_errstr_fn>(dlsym(h, "ncclGetErrorString"));
-  if (!g_rccl.start || !g_rccl.end || !g_rccl.bcast) { g_rccl.bcast = nullptr; return false; }
-  return true;
+  std::call_once(g_rccl_once, [] {
+    void* h = RTLD_DEFAULT;
+    if (!dlsym(h, "ncclAllGather")) {
+      h = dlopen("librccl.so", RTLD_NOLOAD | RTLD_NOW);
+      if (!h) h = dlopen("librccl.so.1", RTLD_NOLOAD | RTLD_NOW);
+      if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+      if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+      if (!h) return;
+    }
+    Rccl r;
+    r.start = reinterpret_cast<nccl_group_fn>(dlsym(h, "ncclGroupStart"));
+    r.end = reinterpret_cast<nccl_group_fn>(dlsym(h, "ncclGroupEnd"));
+    r.bcast = reinterpret_cast<nccl_bcast_fn>(dlsym(h, "ncclBroadcast"));
+    r.allgather = reinterpret_cast<nccl_allgather_fn>(dlsym(h, "ncclAllGather"));
+    r.errstr = reinterpret_cast<nccl_errstr_fn>(dlsym(h, "ncclGetErrorString"));
+    if (r.start && r.end && r.bcast && r.allgather) g_rccl = r;
+  });
+  return g_rccl.bcast != nullptr;
 }
 constexpr int kNcclFloat = 7;           // ncclFloat32 (rccl.h)
 }  // namespace
@@ -78,6 +88,33 @@ int btk_allgather_bins(void* nccl_comm, const void* Y_local, void* Y, int S, int
   const int rc2 = g_rccl.end();
   if (rc == 0) rc = rc2;
   if (rc != 0) return btk_set_error(BTK_ERR_HIP, "btk_allgather_bins: RCCL error %d (%s)", rc, g_rccl.errstr ? g_rccl.errstr(rc) : "?");
+  return BTK_OK;
+}
+
+// rows per stream of a buffer the in-place all-gather can run in: world x ceil(K / world) >= K (the last shard padded)
+int btk_bin_rows_padded(int K, int world) { return (K < 1 || world < 1) ? 0 : world * ((K + world - 1) / world); }
+
+// The even form: Y [S][Kp][T_stride], Kp = btk_bin_rows_padded(K, world); every rank has ALREADY written its beamformed bins at
+// rows [rank per, ...) of each stream (per = ceil(K / world); the apply kernel writes there directly), so the exchange is ONE
+// in-place ncclAllGather per stream -- for the single-stream large-array case of SURVEY 8(e) literally a single all-gather, no
+// staging copy on either side.  Rows >= K are padding.
+int btk_allgather_bins_inplace(void* nccl_comm, void* Y, int S, int K, long T_stride, int rank, int world, void* stream)
+{
+  if (!nccl_comm || !Y) return btk_set_error(BTK_ERR_PARAMETER, "btk_allgather_bins_inplace: null argument");
+  if (S < 1 || K < 1 || T_stride < 1 || world < 1 || rank < 0 || rank >= world)
+    return btk_set_error(BTK_ERR_DIMENSION, "btk_allgather_bins_inplace: bad sizes S=%d K=%d T_stride=%ld rank=%d world=%d", S, K, T_stride, rank, world);
+  if (!bind_rccl()) return btk_set_error(BTK_ERR_PARAMETER, "btk_allgather_bins_inplace: RCCL (librccl.so) is not available in this process");
+  const int per = (K + world - 1) / world;
+  const size_t count = (size_t)per * T_stride * 2, rows = (size_t)per * world;
+  float* base = static_cast<float*>(Y);
+  int rc = 0;
+  if (S > 1) rc = g_rccl.start();
+  for (int s = 0; s < S && rc == 0; s++) {
+    float* recv = base + (size_t)s * rows * T_stride * 2;
+    rc = g_rccl.allgather(recv + (size_t)rank * count, recv, count, kNcclFloat, nccl_comm, as_stream(stream));
+  }
+  if (S > 1) { const int rc2 = g_rccl.end(); if (rc == 0) rc = rc2; }
+  if (rc != 0) return btk_set_error(BTK_ERR_HIP, "btk_allgather_bins_inplace: RCCL error %d (%s)", rc, g_rccl.errstr ? g_rccl.errstr(rc) : "?");
   return BTK_OK;
 }
 

@@ -182,10 +182,16 @@ class FilterBank:
             raise _lib.BtkError(_lib.BTK_ERR_DIMENSION, "Y must be complex64 [%d][%d][>=%d], got %s %s"
                                 % (S, self.K, tcount, out.dtype, tuple(out.shape)))
         nb = _lib.lib().btk_fb_analysis_bf_scratch_bytes(self._h, S, N, per_stream, tcount)
-        if getattr(self, "_bf_scratch", None) is None or self._bf_scratch.numel() < nb:
-            self._bf_scratch = torch.empty(nb, dtype=torch.uint8, device=pcm.device)
+        # the weight-pair scratch is written by a kernel of THIS launch's stream: one buffer per (device, stream), so that a plan
+        # shared by several streams (serving.BatchBeamformerPipeline next to a caller's own stream) never has two launches
+        # re-packing weights into the same bytes
+        key = (pcm.device.index, int(torch.cuda.current_stream().cuda_stream))
+        cache = self.__dict__.setdefault("_bf_scratch", {})
+        buf = cache.get(key)
+        if buf is None or buf.numel() < nb:
+            buf = cache[key] = torch.empty(nb, dtype=torch.uint8, device=pcm.device)
         check(_lib.lib().btk_fb_analysis_bf(self._h, _ptr(pcm), nsamples, L, S, N, _ptr(W), per_stream, _ptr(out), t_stride,
-                                            t0, tcount, _ptr(self._bf_scratch), self._bf_scratch.numel(), _stream()))
+                                            t0, tcount, _ptr(buf), buf.numel(), _stream()))
         return out
 
     # ---- synthesis

@@ -10,7 +10,11 @@ synthesis) runs 50x faster than PCIe can feed it -- so the
   * utterance streams are independent (unit_test/test_online_beamforming.py:80-88 builds one graph per utterance), so a batch is
     any `streams_per_batch` of them; with several GPUs each rank runs its own pipeline over its share (sharding.streams_for_rank).
 
-PyTorch supplies pinned memory, streams and events; every computation is a C-ABI call on the compute stream."""
+PyTorch supplies pinned memory, streams and events; every computation is a C-ABI call on the compute stream.
+
+Sharing: the plans keep one weight-pair scratch per (device, stream), so `afb` / `sfb` may also be used from the caller's own stream
+while run() is in flight.  run() returns HOST results only: device-side state a caller wants to read afterwards (the buffer sets)
+must be ordered behind the pipeline's streams by the caller (`torch.cuda.current_stream().wait_stream(pipe.s_cmp)`)."""
 import numpy as np
 import torch
 

@@ -44,6 +44,33 @@ def allgather_bins(Y_local, K, group=None):
     return full.contiguous()
 
 
+def padded_bin_rows(K, world):
+    """rows per stream of a buffer the in-place all-gather runs in: world * ceil(K / world) >= K (btk_bin_rows_padded)"""
+    return world * (-(-K // world))
+
+
+def allgather_bins_inplace(Y, K, group=None):
+    """north_star's "single all-gather": Y complex [S][Kp][T], Kp = padded_bin_rows(K, world), holds this rank's beamformed bins at
+    rows [rank * per, ...) of every stream (the apply kernel wrote them there); ONE in-place all-gather per stream -- a single
+    collective for the one-stream large-array case -- completes it on every rank without a staging copy (the C-ABI form is
+    btk_allgather_bins_inplace).  Returns the [S][K][T] view."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    per = -(-K // world)
+    S, Kp, T = Y.shape
+    assert Kp == per * world and Y.is_contiguous(), "Y must be contiguous [S][%d][T]" % (per * world)
+    Yr = torch.view_as_real(Y)                                            # [S][Kp][T][2]
+    for s in range(S):
+        out = Yr[s].view(world * per * T * 2)
+        chunk = out[rank * per * T * 2: (rank + 1) * per * T * 2]
+        if dist.get_backend(group) != "nccl":
+            chunk = chunk.clone()                                           # gloo (CPU tests) does not promise in-place aliasing
+        dist.all_gather_into_tensor(out, chunk, group=group)
+    return Y[:, :K]
+
+
 def max_over_ranks(value, device, group=None):
     """MAX-reduce a host scalar (step time) over ranks."""
     import torch
@@ -73,6 +100,18 @@ def pipeline_bin_sharded(afb, sfb, pcm, W_local, K, rank, world, group=None, syn
     # full-size X nor a slice copy exists (an empty trailing shard launches nothing)
     X_local = afb.analysis(pcm, bins=(k0, k1))              # [S][K_g][N][T]
     from . import engine
-    Y = bf_apply_bin_sharded(W_local, X_local, K, group) if world > 1 else engine.bf_apply(W_local, X_local)
+    S, T = X_local.shape[0], X_local.shape[-1]
+    if world > 1 and S == 1:
+        # one stream (the large-array case this sharding exists for): the apply kernel writes this rank's bins in place into the
+        # padded block and a SINGLE in-place all-gather completes it -- no staging buffer, no copy
+        import torch
+        Yp = torch.zeros((1, padded_bin_rows(K, world), T), dtype=torch.complex64, device=X_local.device)
+        if k1 > k0:
+            engine.bf_apply(W_local, X_local, out=Yp[:, k0:k1])
+        Y = allgather_bins_inplace(Yp, K, group)
+    elif world > 1:
+        Y = bf_apply_bin_sharded(W_local, X_local, K, group)
+    else:
+        Y = engine.bf_apply(W_local, X_local)
     out = sfb.synthesize(Y) if (synth_rank is None or synth_rank == rank) else None
     return out, Y

@@ -326,6 +326,13 @@ int  btk_wpe_apply(const void* X, const void* G, void* OUT, int S, int K, int C,
 void btk_bin_range(int K, int rank, int world, int* k0, int* k1);
 int  btk_allgather_bins(void* nccl_comm, const void* Y_local, void* Y, int S, int K, long T_stride, int rank, int world,
                         void* stream);
+/* The even form -- north_star's "single RCCL all-gather": Y [dev] complex64 [S][Kp][T_stride] with
+ * Kp = btk_bin_rows_padded(K, world) = world ceil(K / world) rows per stream (rows >= K are padding); every rank has written its
+ * beamformed bins in place at rows [rank ceil(K/world), ...) (btk_bf_apply straight into that view), and ONE in-place
+ * ncclAllGather per stream completes Y on every rank: no staging buffer, no copy.  btk_allgather_bins (grouped broadcasts) remains
+ * for callers whose Y has exactly K rows.                                                                                  */
+int  btk_bin_rows_padded(int K, int world);
+int  btk_allgather_bins_inplace(void* nccl_comm, void* Y, int S, int K, long T_stride, int rank, int world, void* stream);
 
 /* ---- Host-side weight design (double precision, one-off per look direction) -------------
  * BeamformerWeights::calcMainlobe (beamformer.cc:502-565): wq [host] complex128 [M][N].     */

@@ -155,6 +155,17 @@ assert np.array_equal(out, Yl)
 k0, k1 = C.c_int(), C.c_int()
 lib.btk_bin_range(33, 7, 8, C.byref(k0), C.byref(k1)); assert (k0.value, k1.value) == (33, 33)
 lib.btk_bin_range(33, 6, 8, C.byref(k0), C.byref(k1)); assert (k0.value, k1.value) == (30, 33)
+# the even form: ONE in-place ncclAllGather per stream on the padded block (world 1: the rank's rows are the whole block)
+assert lib.btk_bin_rows_padded(33, 8) == 40 and lib.btk_bin_rows_padded(1025, 8) == 1032 and lib.btk_bin_rows_padded(33, 1) == 33
+lib.btk_allgather_bins_inplace.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_long, C.c_int, C.c_int, C.c_void_p]
+for s_n in (1, S):
+    hip.hipMemcpy(dy, Yl.ctypes.data_as(C.c_void_p), C.c_size_t(Yl.nbytes), 1)
+    rc = lib.btk_allgather_bins_inplace(comm, dy, s_n, K, T, 0, 1, None)
+    assert rc == 0, lib.btk_last_error()
+    hip.hipDeviceSynchronize()
+    hip.hipMemcpy(out.ctypes.data_as(C.c_void_p), dy, C.c_size_t(Yl.nbytes), 2)
+    assert np.array_equal(out, Yl)
+assert lib.btk_allgather_bins_inplace(comm, dy, 1, K, T, 3, 2, None) != 0           # rank outside the world: refused
 rccl.ncclCommDestroy(comm)
 print("ok")
 ''' % os.path.join(root, "distant_speech_recognition_amd", "csrc", "libbtkhip.so")

@@ -30,6 +30,12 @@ def _worker(rank, world, port, K, ret):
         k0, k1 = sharding.bin_range_for_rank(K, rank, world)
         got = sharding.allgather_bins(full[:, k0:k1].contiguous(), K)
         assert torch.equal(got, full)
+        # the even form: every rank's bins already in place in the padded block, one in-place all-gather per stream
+        Yp = torch.zeros((S, sharding.padded_bin_rows(K, world), T), dtype=full.dtype)
+        Yp[:, k0:k1] = full[:, k0:k1]
+        got2 = sharding.allgather_bins_inplace(Yp, K)
+        assert got2.shape == full.shape and torch.equal(got2, full)
+        assert sharding.padded_bin_rows(K, world) % world == 0 and 0 <= sharding.padded_bin_rows(K, world) - K < world
         t = sharding.max_over_ranks(1.0 + rank, torch.device("cpu"))
         assert t == float(world)
         mine = sharding.streams_for_rank(7, rank, world)
