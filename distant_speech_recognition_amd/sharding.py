@@ -71,6 +71,49 @@ def allgather_bins_inplace(Y, K, group=None):
     return Y[:, :K]
 
 
+def exchange_channels_for_bins(X_chan, K, N, group=None):
+    """Option (ii) of SURVEY 8(e) for the analysis side of a bin-sharded run: every rank has transformed ITS channels completely
+    (X_chan complex [S][K][N_r][T], channel range bin_range_for_rank(N, rank, world)) and one all-to-all hands every rank its bin
+    range of ALL channels: -> X_bins [S][K_r][N][T].  Per block 8 K N T S bytes cross the fabric in total, 7/8 of a rank's eighth over
+    its seven xGMI links (C5: 16.8 MB per link, 0.11 ms at 153 GB/s) -- against option (i), where every rank transforms all N
+    channels (0.40 ms at C5) and exchanges nothing.  RCCL: one all_to_all_single with uneven splits; other backends (CPU tests):
+    an all-gather of the padded blocks."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    S, Kx, Nr, T = X_chan.shape
+    c0, c1 = bin_range_for_rank(N, rank, world)
+    assert Kx == K and Nr == c1 - c0, "X_chan must hold all K bins of this rank's channel range"
+    k0, k1 = bin_range_for_rank(K, rank, world)
+    Kr = k1 - k0
+    chans = [bin_range_for_rank(N, q, world) for q in range(world)]
+    bins = [bin_range_for_rank(K, q, world) for q in range(world)]
+    X_bins = torch.empty((S, Kr, N, T), dtype=X_chan.dtype, device=X_chan.device)
+    if dist.get_backend(group) == "nccl":
+        send = torch.cat([torch.view_as_real(X_chan[:, a:b].contiguous()).reshape(-1) for a, b in bins])
+        in_split = [S * (b - a) * Nr * T * 2 for a, b in bins]
+        out_split = [S * Kr * (b - a) * T * 2 for a, b in chans]
+        recv = torch.empty(sum(out_split), dtype=send.dtype, device=send.device)
+        dist.all_to_all_single(recv, send, output_split_sizes=out_split, input_split_sizes=in_split, group=group)
+        off = 0
+        for (a, b), n in zip(chans, out_split):
+            if n:
+                X_bins[:, :, a:b] = torch.view_as_complex(recv[off: off + n].view(S, Kr, b - a, T, 2))
+            off += n
+    else:
+        per = -(-N // world)
+        pad = torch.zeros((S, K, per, T), dtype=X_chan.dtype, device=X_chan.device)
+        pad[:, :, :Nr] = X_chan
+        buf = torch.view_as_real(pad).contiguous()
+        out = [torch.empty_like(buf) for _ in range(world)]
+        dist.all_gather(out, buf, group=group)
+        for (a, b), o in zip(chans, out):
+            if b > a:
+                X_bins[:, :, a:b] = torch.view_as_complex(o)[:, k0:k1, : b - a]
+    return X_bins
+
+
 def max_over_ranks(value, device, group=None):
     """MAX-reduce a host scalar (step time) over ranks."""
     import torch
@@ -88,17 +131,23 @@ def bf_apply_bin_sharded(W_local, X_local, K, group=None):
     return allgather_bins(Y_local, K, group)
 
 
-def pipeline_bin_sharded(afb, sfb, pcm, W_local, K, rank, world, group=None, synth_rank=None):
+def pipeline_bin_sharded(afb, sfb, pcm, W_local, K, rank, world, group=None, synth_rank=None, analysis_input="replicated"):
     """BASELINE config C5 end to end on `world` GPUs: every rank analyses the SAME multichannel PCM (the analysis FFT
     yields all bins of a channel, so the PCM -- N*D*4 bytes per frame -- is what is replicated), stores only its bin range
     of the snapshots (btk_fb_analysis_bins), beamforms it, ONE all-gather assembles Y [S][K][T], and the synthesis bank runs on `synth_rank`
     (every rank if None).  afb / sfb: engine.FilterBank analysis / synthesis plans; W_local complex64 [K_g][N].
+    analysis_input = "replicated" (option (i) of SURVEY 8(e), the default: no exchange before the beamformer) or "channels"
+    (option (ii): pcm holds only this rank's channel range bin_range_for_rank(N, rank, world); the ranks transform disjoint
+    channels and one all-to-all regroups the snapshots by bin -- measured / predicted in DESIGN.md section 6).
     Returns (pcm_out or None, Y)."""
     k0, k1 = bin_range_for_rank(K, rank, world)
     # every channel is transformed on every rank (the FFT yields all bins), but only this rank's bins are stored: the
     # snapshot write -- 8 K N bytes per frame, the dominant cost of the analysis bank -- shrinks by `world`, and no
     # full-size X nor a slice copy exists (an empty trailing shard launches nothing)
-    X_local = afb.analysis(pcm, bins=(k0, k1))              # [S][K_g][N][T]
+    if analysis_input == "channels" and world > 1:
+        X_local = exchange_channels_for_bins(afb.analysis(pcm), K, W_local.shape[-1], group)
+    else:
+        X_local = afb.analysis(pcm, bins=(k0, k1))          # [S][K_g][N][T]
     from . import engine
     S, T = X_local.shape[0], X_local.shape[-1]
     if world > 1 and S == 1:

@@ -49,6 +49,11 @@ def _worker(rank, world, port, ret):
             assert torch.equal(out, sfb.synthesize(ref_Y))
         else:
             assert out is None
+        # option (ii): every rank transforms only ITS channels, the exchange regroups the snapshots by bin -- same Y
+        c0, c1 = sharding.bin_range_for_rank(N, rank, world)
+        out2, Y2 = sharding.pipeline_bin_sharded(afb, sfb, pcm[:, c0:c1].contiguous(), W_local, K, rank, world, synth_rank=0,
+                                                 analysis_input="channels")
+        assert torch.equal(Y2, ref_Y)
         # stream sharding: each rank runs its streams, no collective on the data path
         mine = sharding.streams_for_rank(S, rank, world)
         Ym = afb.analysis_beamform(pcm[mine].contiguous(), W_full)

@@ -36,6 +36,12 @@ def _worker(rank, world, port, K, ret):
         got2 = sharding.allgather_bins_inplace(Yp, K)
         assert got2.shape == full.shape and torch.equal(got2, full)
         assert sharding.padded_bin_rows(K, world) % world == 0 and 0 <= sharding.padded_bin_rows(K, world) - K < world
+        # option (ii) of the analysis input: channel-sharded transforms regrouped by bin (uneven channel and bin shards)
+        N = 5
+        Xall = torch.view_as_complex(torch.randn((S, K, N, T, 2), generator=g))      # same on every rank
+        c0, c1 = sharding.bin_range_for_rank(N, rank, world)
+        Xb = sharding.exchange_channels_for_bins(Xall[:, :, c0:c1].contiguous(), K, N)
+        assert Xb.shape == (S, k1 - k0, N, T) and torch.equal(Xb, Xall[:, k0:k1])
         t = sharding.max_over_ranks(1.0 + rank, torch.device("cpu"))
         assert t == float(world)
         mine = sharding.streams_for_rank(7, rank, world)
