@@ -25,6 +25,7 @@ const btk_switches_t& btk_switches()
     s.nlms_alt = num("BTK_NLMS_ALT", 0); s.fused_var = num("BTK_FUSED_VAR", -1);
     s.pf_jb = num("BTK_PF_JB", 0);
     s.pf_tpw = num("BTK_PF_TPW", 0);
+    s.pf_mfma_min = num("BTK_PF_MFMA_MIN", 8);
     return s;
   }();                                                   // C++11 magic static: initialised once, thread-safe
   return sw;

@@ -334,19 +334,22 @@ constexpr int MF_TPW = 8;      // tiles per wavefront: 4 / 8 / 16 / 32 -> 2.61 /
 // wavefronts per workgroup (the coefficient planes allow two workgroups per CU): one form = 8, four wavefronts per SIMD in 128
 // VGPRs (2.46 ms against 2.69 with 4 at the C0 shape); two forms = 4, two per SIMD in 172 VGPRs (4.0 ms; with 8 the kernel spills,
 // 4.85 ms, one form after the other 7.1 ms, and six wavefronts land 2-2-1-1 on the SIMDs, 5.9 ms)
-constexpr int mf_nw(int nq) { return nq == 1 ? 8 : 4; }
+constexpr int mf_nw(int nq, int nb = 4) { return (nq == 1 && nb <= 4) ? 8 : 4; }     // more than 64 channels: 4 wavefronts, 256 VGPRs each
 
-template <int NQ, int NB /* N / 16 */>
-__global__ __launch_bounds__(64 * mf_nw(NQ), mf_nw(NQ) / 2)       // (HIP: the second number is wavefronts per SIMD)
+// Round 3: any channel count.  NB = ceil(NR / 16) blocks; the channels NR .. 16 NB - 1 are padding: their weights, alignment entries
+// and coefficient rows / columns are zero in LDS, so x' = conj(d) x, y, e and every a_j they touch vanish by themselves; only the
+// snapshot loads of the last block need care (a clamped per-lane row instead of the wave-uniform row pointer) to stay inside X.
+template <int NQ, int NB /* ceil(NR / 16) */, bool PAD /* NR < 16 NB */>
+__global__ __launch_bounds__(64 * mf_nw(NQ, NB), mf_nw(NQ, NB) / 2)       // (HIP: the second number is wavefronts per SIMD)
 void bf_apply_stats2_mfma_kernel(const float2* __restrict__ W, long w_stream_stride, const float2* __restrict__ Dv,
                                  const float2* __restrict__ X, float2* __restrict__ Y,
                                  const float2* __restrict__ Cs, const float2* __restrict__ Cv,
                                  float2* __restrict__ U, float2* __restrict__ V, float* __restrict__ Ee,
-                                 int K, long T_stride, long T, int tpw)
+                                 int K, long T_stride, long T, int tpw, int NR /* real channel count, 16 (NB - 1) < NR <= 16 NB */)
 {
   typedef float v4f __attribute__((ext_vector_type(4)));
   typedef float v2f __attribute__((ext_vector_type(2)));
-  constexpr int N = 16 * NB, LD = N + 4, M4 = N / 4, MF_NW = mf_nw(NQ);
+  constexpr int N = 16 * NB, LD = N + 4, M4 = N / 4, MF_NW = mf_nw(NQ, NB);
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* ctr = reinterpret_cast<float*>(smem);                  // [NQ][N][LD] real parts, [i][j]
   float* cti = ctr + NQ * N * LD;                               // [NQ][N][LD] imaginary parts
@@ -359,23 +362,22 @@ void bf_apply_stats2_mfma_kernel(const float2* __restrict__ W, long w_stream_str
   int im = 0;
 #pragma unroll
   for (int q = 0; q < NQ; q++) {
-    const float2* c = (q == 0 ? Cs : Cv) + (long)k * N * N;
+    const float2* c = (q == 0 ? Cs : Cv) + (long)k * NR * NR;
     for (int idx = tid; idx < N * N; idx += 64 * MF_NW) {
       const int j = idx / N, i = idx % N;                       // C[j][i], i <= j used (the reference reads nothing else of a row either)
-      float2 v = c[idx];
-      if (i > j) v = make_float2(0.f, 0.f);
+      float2 v = (j < NR && i <= j) ? c[j * NR + i] : make_float2(0.f, 0.f);
       im |= (v.y != 0.f);
       ctr[(q * N + i) * LD + j] = v.x;
       cti[(q * N + i) * LD + j] = v.y;
     }
   }
   if (tid < N) {
-    ws[tid] = W[s * w_stream_stride + (long)k * N + tid];
-    ds[tid] = Dv[s * w_stream_stride + (long)k * N + tid];
+    ws[tid] = tid < NR ? W[s * w_stream_stride + (long)k * NR + tid] : make_float2(0.f, 0.f);
+    ds[tid] = tid < NR ? Dv[s * w_stream_stride + (long)k * NR + tid] : make_float2(0.f, 0.f);
   }
   const bool complex_c = __syncthreads_or(im) != 0;
 
-  const float2* xk = X + ((long)s * K + k) * N * T_stride;
+  const float2* xk = X + ((long)s * K + k) * NR * T_stride;
   const long f0 = (long)blockIdx.x * (MF_NW * tpw * 16);
   auto chan = [&](int m) { return 16 * (m >> 2) + 4 * g + (m & 3); };
   float2 xv[M4];
@@ -392,8 +394,15 @@ void bf_apply_stats2_mfma_kernel(const float2* __restrict__ W, long w_stream_str
       v2f raw[M4];
 #pragma unroll
       for (int m = 0; m < M4; m++) {
-        const float2* rowp = xk + (long)(16 * (m >> 2) + (m & 3)) * T_stride + t0;
-        asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(raw[m]) : "v"(vb), "s"(rowp) : "memory");
+        if (PAD && m >= M4 - 4) {
+          // last block of a padded channel count: the lane's own row, clamped to the last real channel (its x' is zeroed by d = 0)
+          const int ch = chan(m) < NR ? chan(m) : NR - 1;
+          const float2 v = xk[(long)ch * T_stride + t0 + tl];
+          raw[m] = v2f{v.x, v.y};
+        } else {
+          const float2* rowp = xk + (long)(16 * (m >> 2) + (m & 3)) * T_stride + t0;
+          asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(raw[m]) : "v"(vb), "s"(rowp) : "memory");
+        }
       }
       // every loaded value is an in/out operand of the wait (of an empty asm right behind it from the fifth on; volatile asms keep
       // their order): its register carries it across, hipcc has no use of it that could be scheduled earlier
@@ -484,19 +493,19 @@ void bf_apply_stats2_mfma_kernel(const float2* __restrict__ W, long w_stream_str
   }
 }
 
-template <int NQ, int NB>
+template <int NQ, int NB, bool PAD>
 int launch_stats2_mfma(const float2* W, long wss, const float2* D, const float2* X, float2* Y, const float2* Cs, const float2* Cv,
-                       float2* U, float2* V, float* E, int S, int K, long T_stride, long T, hipStream_t st)
+                       float2* U, float2* V, float* E, int S, int K, long T_stride, long T, hipStream_t st, int NR)
 {
   constexpr int N = 16 * NB;
   const size_t lds = sizeof(float) * 2 * NQ * N * (N + 4) + sizeof(float2) * 2 * N;
-  auto kern = bf_apply_stats2_mfma_kernel<NQ, NB>;
+  auto kern = bf_apply_stats2_mfma_kernel<NQ, NB, PAD>;
   BTK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  constexpr int MF_NW = mf_nw(NQ);
+  constexpr int MF_NW = mf_nw(NQ, NB);
   const int tpw = btk_switches().pf_tpw > 0 ? btk_switches().pf_tpw : MF_TPW;
   const long per_wg = (long)MF_NW * tpw * 16;
   hipLaunchKernelGGL(kern, dim3((unsigned)((T + per_wg - 1) / per_wg), (unsigned)K, (unsigned)S), dim3(64 * MF_NW), lds, st,
-                     W, wss, D, X, Y, Cs, Cv, U, V, E, K, T_stride, T, tpw);
+                     W, wss, D, X, Y, Cs, Cv, U, V, E, K, T_stride, T, tpw, NR);
   BTK_HIP_CHECK(hipGetLastError());
   return BTK_OK;
 }
@@ -610,22 +619,29 @@ int btk_bf_apply_stats2(const void* W, const void* D, int per_stream_weights, co
   // rows of C per register block: 16 rows x two forms overflow the SGPR file (the C entries are scalar loads) and
   // N <= 8 wastes half of a 16-row block; measured in profiles/pf_ab.py.  BTK_PF_JB overrides (benchmarking only).
   const int jb_env = btk_switches().pf_jb;
-  // N = 16, 32, 48, 64: the coefficient products on the matrix cores (BTK_PF_JB set = the VALU kernel, for the A/B in profiles/)
-  if (!jb_env && N % 16 == 0 && N <= 64 && (long)N * T_stride * 8 < (1L << 31)) {
+  // The coefficient products on the matrix cores (BTK_PF_JB set = the VALU kernel, for the A/B in profiles/): any N up to 64 (two
+  // forms in one pass) or 128 (one form per pass), padded to a multiple of 16 inside the kernel.  Below BTK_PF_MFMA_MIN channels
+  // (default 8: at N = 8 the matrix cores still win, 0.55 against 0.58 ms; smaller arrays are mostly padding) the VALU kernel stays.
+  if (!jb_env && N >= btk_switches().pf_mfma_min && N <= 128 && (long)N * T_stride * 8 < (1L << 31)) {
     const float2 *Wp = static_cast<const float2*>(W), *Dp = static_cast<const float2*>(D), *Xp = static_cast<const float2*>(X);
     const float2 *Csp = static_cast<const float2*>(Cs), *Cvp = static_cast<const float2*>(Cv);
     float2 *Yp = static_cast<float2*>(Y), *Up = static_cast<float2*>(U), *Vp = static_cast<float2*>(V);
     hipStream_t st = as_stream(stream);
-#define BTK_PF_MFMA(NQ_)                                                                                                         \
-    switch (N / 16) {                                                                                                              \
-      case 1: return launch_stats2_mfma<NQ_, 1>(Wp, wss, Dp, Xp, Yp, Csp, Cvp, Up, Vp, E, S, K, T_stride, T, st);                  \
-      case 2: return launch_stats2_mfma<NQ_, 2>(Wp, wss, Dp, Xp, Yp, Csp, Cvp, Up, Vp, E, S, K, T_stride, T, st);                  \
-      case 3: return launch_stats2_mfma<NQ_, 3>(Wp, wss, Dp, Xp, Yp, Csp, Cvp, Up, Vp, E, S, K, T_stride, T, st);                  \
-      default: return launch_stats2_mfma<NQ_, 4>(Wp, wss, Dp, Xp, Yp, Csp, Cvp, Up, Vp, E, S, K, T_stride, T, st);                 \
+#define BTK_PF_CASE(NQ_, NB_) case NB_: return (N % 16) ? launch_stats2_mfma<NQ_, NB_, true>(Wp, wss, Dp, Xp, Yp, Csp, Cvp, Up, Vp, E, S, K, T_stride, T, st, N) \
+                                                         : launch_stats2_mfma<NQ_, NB_, false>(Wp, wss, Dp, Xp, Yp, Csp, Cvp, Up, Vp, E, S, K, T_stride, T, st, N);
+    if (Cv && N > 64) {
+      // two forms of more than 64 channels: their coefficient planes do not fit the LDS together -- one pass per form (the second
+      // recomputes y and e: the same values), still 1.8 x the VALU kernel at N = 100 (profiles/r03_pf_ab.txt)
+      const int rc = btk_bf_apply_stats2(W, D, per_stream_weights, X, Y, Cs, nullptr, U, nullptr, E, S, K, N, T_stride, T, stream);
+      if (rc != BTK_OK) return rc;
+      return btk_bf_apply_stats2(W, D, per_stream_weights, X, Y, Cv, nullptr, V, nullptr, E, S, K, N, T_stride, T, stream);
     }
-    if (Cv) { BTK_PF_MFMA(2) }
-    BTK_PF_MFMA(1)
-#undef BTK_PF_MFMA
+    if (Cv) {
+      switch ((N + 15) / 16) { BTK_PF_CASE(2, 1) BTK_PF_CASE(2, 2) BTK_PF_CASE(2, 3) BTK_PF_CASE(2, 4) }
+    } else {
+      switch ((N + 15) / 16) { BTK_PF_CASE(1, 1) BTK_PF_CASE(1, 2) BTK_PF_CASE(1, 3) BTK_PF_CASE(1, 4) BTK_PF_CASE(1, 5) BTK_PF_CASE(1, 6) BTK_PF_CASE(1, 7) BTK_PF_CASE(1, 8) }
+    }
+#undef BTK_PF_CASE
   }
   const int jb = jb_env ? jb_env : (Cv ? 8 : (N <= 8 ? 8 : 16));
   if (Cv && jb == 16)

@@ -334,7 +334,8 @@ def _coherent_snapshots(rng, S, K, N, T):
 
 
 @pytest.mark.parametrize("N,M,T,type_,minf,load", [(4, 256, 120, 2, 0, 0.01), (8, 64, 70, 1, 0, 0.01), (64, 64, 40, 2, 5, 0.0),
-                                                  (5, 128, 90, 10, 0, 0.05), (20, 64, 50, 2, 0, 0.01), (32, 64, 45, 2, 0, 0.01), (16, 64, 60, 2, 0, 0.01)])
+                                                  (5, 128, 90, 10, 0, 0.05), (20, 64, 50, 2, 0, 0.01), (32, 64, 45, 2, 0, 0.01), (16, 64, 60, 2, 0, 0.01),
+                                                  (100, 32, 30, 2, 0, 0.01), (12, 64, 40, 2, 0, 0.01)])
 def test_mccowan_matches_oracle(orc, dev, N, M, T, type_, minf, load):
     """McCowanPostFilter (postfilter.cc:798-935) over a delay-and-sum beamformer, diffuse-noise coherence
     (confs/sd_and_mccowan.json shape), two consecutive blocks."""
@@ -373,7 +374,8 @@ def test_mccowan_matches_oracle(orc, dev, N, M, T, type_, minf, load):
 
 
 @pytest.mark.parametrize("N,M,T,type_,minf,x1", [(4, 256, 120, 2, 0, 100), (8, 64, 70, 1, 0, 10), (33, 64, 40, 2, 3, 0),
-                                                (6, 128, 90, 2, 0, 200), (64, 64, 40, 2, 0, 5), (32, 64, 50, 2, 2, 5)])
+                                                (6, 128, 90, 2, 0, 200), (64, 64, 40, 2, 0, 5), (32, 64, 50, 2, 2, 5),
+                                                (100, 32, 25, 2, 0, 3), (20, 64, 40, 2, 0, 5)])
 def test_lefkimmiatis_matches_oracle(orc, dev, N, M, T, type_, minf, x1):
     """LefkimmiatisPostFilter (postfilter.cc:967-1190), confs/sd_and_lefkimmiatis.json shape (alpha 0.8, min_sv 1e-4)."""
     import torch
@@ -433,11 +435,15 @@ def test_cov_accumulate_on_row_padded_snapshots(dev):
 
 @pytest.mark.parametrize("N,T,nq,cplx,pad", [(64, 37, 1, False, False), (64, 530, 2, False, True), (32, 100, 2, False, False),
                                              (64, 75, 2, True, True), (32, 16, 1, True, False), (20, 50, 2, True, False),
-                                             (16, 40, 2, True, False), (48, 100, 1, False, True), (48, 33, 2, True, False)])
+                                             (16, 40, 2, True, False), (48, 100, 1, False, True), (48, 33, 2, True, False),
+                                             # round 3: any channel count on the matrix cores (padded blocks, > 64 channels in one or two passes)
+                                             (8, 70, 2, True, False), (12, 33, 1, False, True), (21, 50, 2, True, True), (63, 40, 2, False, False),
+                                             (100, 45, 1, True, False), (100, 36, 2, False, True), (128, 20, 2, True, False), (7, 60, 2, True, False),
+                                             (130, 18, 1, False, False)])
 def test_stats2_quadratic_forms_against_their_definition(dev, N, T, nq, cplx, pad):
     """btk_bf_apply_stats2 (the per-frame sums behind McCowan / Lefkimmiatis, postfilter.cc:798-829, 1041-1077) against
-    u_t = sum_{i<=j} Cs[j][i] x'_i conj(x'_j) evaluated in float64: the matrix-core kernel (N = 16, 32, 48, 64; real and complex
-    pair weights, one and two forms, ragged tiles, row-padded snapshots) and the VALU kernel (other N)."""
+    u_t = sum_{i<=j} Cs[j][i] x'_i conj(x'_j) evaluated in float64: the matrix-core kernel (8 <= N <= 128, any N: real and complex
+    pair weights, one and two forms, ragged tiles, row-padded snapshots, channel counts padded to 16) and the VALU kernel (N < 8, N > 128)."""
     import torch
     from distant_speech_recognition_amd import _lib, engine as eng
     rng = np.random.default_rng(N * 7 + T + nq)
