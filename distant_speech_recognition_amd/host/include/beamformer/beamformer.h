@@ -66,20 +66,34 @@ class BeamformerWeights {
   void setSidelobeCanceller_f(unsigned fbinX, gsl_vector_complex* wl_f);
   void setQuiescentVector(unsigned fbinX, gsl_vector_complex* wq_f, bool isGSC = false);
   void setQuiescentVectorAll(gsl_complex z, bool isGSC = false);
-  void setTimeAlignment() { ta = wq; }
-  // gsl views of one bin (copies refreshed at every call, owned by this object)
-  gsl_vector_complex* wq_f(unsigned fbinX);
-  gsl_vector_complex* wl_f(unsigned fbinX);
-  gsl_matrix_complex* B_f(unsigned fbinX);
+  void setTimeAlignment() { ta_v = wq_v; }
+  // The reference's accessors (beamformer/beamformer.h:53-67), same names and return types.  The gsl objects ALIAS this object's
+  // storage (owner = 0): what a caller writes through wq()[k], B()[k], wa()[k] is what the nodes compute with, as in the
+  // reference.  CSDs(): the reference's post-filters keep the N x N auto / cross spectral densities of every bin here; this engine
+  // keeps only the recursively averaged SUMS the gains depend on, on the device, so these vectors exist,
+  // zeroed, for callers that index them, and are never updated.  wp1(): the post-filter gains of the last served frame, mirrored
+  // from the post-filter node that is bound to this weight object (ZelinskiPostFilter::postfilter_weights()).
+  bool isHalfBandShift() const { return halfBandShift_; }
+  gsl_vector_complex** arrayManifold() const { return ta_views_; }
+  gsl_vector_complex* wq_f(unsigned fbinX) const { return wq_views_[fbinX]; }
+  gsl_vector_complex* wl_f(unsigned fbinX) const { return wl_views_[fbinX]; }
+  gsl_matrix_complex* B_f(unsigned fbinX) const { return B_views_ ? B_views_[fbinX] : NULL; }
+  gsl_vector_complex** wq() const { return wq_views_; }
+  gsl_matrix_complex** B() const { return B_views_; }
+  gsl_vector_complex** wa() const { return wa_views_; }
+  gsl_vector_complex** CSDs() const { return CSDs_; }
+  gsl_vector_complex* wp1() const { return wp1_; }
   unsigned fftLen() const { return fftLen_; }
   unsigned chanN() const { return chanN_; }
   unsigned NC() const { return NC_; }
-  bool isHalfBandShift() const { return false; }
-  std::vector<std::complex<double> > wq, wl, ta, wa, B;   // [M][N], [M][N], [M][N], [M][N-NC], [M][N][N-NC]
+  // storage behind the views: [M][N], [M][N], [M][N], [M][N-NC], [M][N][N-NC]  (round 2 exposed these as wq / wl / ta / wa / B)
+  std::vector<std::complex<double> > wq_v, wl_v, ta_v, wa_v, B_v;
  private:
   unsigned fftLen_, chanN_, NC_;
-  gsl_vector_complex *wq_view_, *wl_view_;
-  gsl_matrix_complex* B_view_;
+  bool halfBandShift_;
+  gsl_vector_complex **wq_views_, **wl_views_, **ta_views_, **wa_views_, **CSDs_;
+  gsl_matrix_complex** B_views_;
+  gsl_vector_complex* wp1_;
 };
 
 class SubbandBeamformer : public VectorComplexFeatureStream {
@@ -101,11 +115,16 @@ class SubbandBeamformer : public VectorComplexFeatureStream {
   void clearChannel() { clear_channel(); }
   const gsl_vector_complex* snapShotArray_f(unsigned fbinX) { return snapshot_array_f(fbinX); }
   SnapShotArrayPtr getSnapShotArray() { return snapshot_array(); }
+  bool is_half_band_shift() const { return halfBandShift_; }
+  bool isHalfBandShift() const { return halfBandShift_; }
   // device hooks
   void* device_snapshots();       // complex64 [1][K][N][T] on the device
+  void* device_snapshots_all_bins() { device_snapshots(); return dXfull_; }   // halfBandShift over pulled sources: [1][M][N][T], else NULL
   long num_frames() { device_snapshots(); return T_; }
  protected:
   void free_device_();
+  bool halfBandShift_;
+  void* dXfull_;
   typedef std::list<VectorComplexFeatureStreamPtr> ChannelList_;
   ChannelList_ channelList_;
   SnapShotArrayPtr snapshot_array_;
@@ -135,6 +154,8 @@ class SubbandDS : public SubbandBeamformer {
   void calcArrayManifoldVectorsN(float sampleRate, const gsl_vector* delaysT, const gsl_matrix* delaysJ, unsigned NC = 2) { calc_array_manifold_vectors_n(sampleRate, delaysT, delaysJ, NC); }
   // engine hooks for downstream GPU nodes (post-filter, synthesis)
   virtual void effective_weights(std::vector<float>& w);   // complex64 [K][N]
+  // halfBandShift == true (reference beamformer.cc:1113-1128, 1276-1285): the weight vector of every one of the M bins, complex64 [M][N]
+  virtual void effective_weights_all_bins(std::vector<float>& w);
   void alignment_vector(bool use_wq, std::vector<float>& d);
   unsigned long weights_version() const { return weights_version_; }
  protected:
@@ -171,6 +192,7 @@ class SubbandGSC : public SubbandDS {
   bool writeFIRCoeff(const String& fn, unsigned winType = 1) { return write_fir_coeff(fn, winType); }
   gsl_matrix_complex* getBlockingMatrix(unsigned srcX, unsigned fbinX) { return blocking_matrix(srcX, fbinX); }
   virtual void effective_weights(std::vector<float>& w);
+  virtual void effective_weights_all_bins(std::vector<float>& w);
  protected:
   virtual const char* need_weights_msg_() const { return "call calc_gsc_weights_X() once\n"; }
   bool normalize_weight_;

@@ -63,6 +63,26 @@ void serve_frame(const std::vector<float>& Y, long T, unsigned M, long t, gsl_ve
   }
 }
 
+// halfBandShift: every bin has its own output, nothing is mirrored.  Y [M][T] complex64
+void serve_frame_all_bins(const std::vector<float>& Y, long T, unsigned M, long t, gsl_vector_complex* out)
+{
+  for (unsigned k = 0; k < M; k++) { out->data[2 * k] = Y[2 * ((size_t)k * T + t)]; out->data[2 * k + 1] = Y[2 * ((size_t)k * T + t) + 1]; }
+}
+
+// drain a complex node keeping all M bins: frames [T][M] complex64 (halfBandShift over sources that are not analysis banks)
+long drain_complex_all_bins(VectorComplexFeatureStreamPtr& src, unsigned M, std::vector<float>& frames)
+{
+  long T = 0;
+  for (;;) {
+    const gsl_vector_complex* v;
+    try { v = src->next(); } catch (jiterator_error&) { break; }
+    frames.resize((size_t)(T + 1) * M * 2);
+    for (unsigned k = 0; k < 2 * M; k++) frames[2 * (size_t)T * M + k] = (float)v->data[k];
+    T++;
+  }
+  return T;
+}
+
 // drain a complex node: frames [T][K] complex64 (bins 0..M/2)
 long drain_complex(VectorComplexFeatureStreamPtr& src, unsigned M, std::vector<float>& frames)
 {
@@ -375,32 +395,58 @@ void SpectralMatrixArray::update()
 }
 
 // ================================================================================ BeamformerWeights
-BeamformerWeights::BeamformerWeights(unsigned fftLen, unsigned chanN, bool, unsigned NC)
-    : wq((size_t)fftLen * chanN), wl((size_t)fftLen * chanN), ta((size_t)fftLen * chanN),
-      wa(chanN > NC ? (size_t)fftLen * (chanN - NC) : 0), B(chanN > NC ? (size_t)fftLen * chanN * (chanN - NC) : 0),
-      fftLen_(fftLen), chanN_(chanN), NC_(NC), wq_view_(gsl_vector_complex_calloc(chanN)), wl_view_(gsl_vector_complex_calloc(chanN)),
-      B_view_(gsl_matrix_complex_alloc(chanN, chanN > NC ? chanN - NC : 0)) {}
+namespace {
+gsl_vector_complex* alias_vector(std::complex<double>* p, size_t n)
+{
+  gsl_vector_complex* v = (gsl_vector_complex*)malloc(sizeof(gsl_vector_complex));
+  v->size = n; v->stride = 1; v->data = reinterpret_cast<double*>(p); v->block = NULL; v->owner = 0;
+  return v;
+}
+gsl_matrix_complex* alias_matrix(std::complex<double>* p, size_t n1, size_t n2)
+{
+  gsl_matrix_complex* m = (gsl_matrix_complex*)malloc(sizeof(gsl_matrix_complex));
+  m->size1 = n1; m->size2 = n2; m->tda = n2; m->data = reinterpret_cast<double*>(p); m->block = NULL; m->owner = 0;
+  return m;
+}
+}  // namespace
+
+BeamformerWeights::BeamformerWeights(unsigned fftLen, unsigned chanN, bool halfBandShift, unsigned NC)
+    : wq_v((size_t)fftLen * chanN), wl_v((size_t)fftLen * chanN), ta_v((size_t)fftLen * chanN),
+      wa_v(chanN > NC ? (size_t)fftLen * (chanN - NC) : 0), B_v(chanN > NC ? (size_t)fftLen * chanN * (chanN - NC) : 0),
+      fftLen_(fftLen), chanN_(chanN), NC_(NC), halfBandShift_(halfBandShift), wa_views_(NULL), B_views_(NULL)
+{
+  // the vectors never change size: the views below stay valid for the life of the object
+  const unsigned bs = chanN > NC ? chanN - NC : 0;
+  wq_views_ = (gsl_vector_complex**)malloc(sizeof(gsl_vector_complex*) * fftLen);
+  wl_views_ = (gsl_vector_complex**)malloc(sizeof(gsl_vector_complex*) * fftLen);
+  ta_views_ = (gsl_vector_complex**)malloc(sizeof(gsl_vector_complex*) * fftLen);
+  CSDs_ = (gsl_vector_complex**)malloc(sizeof(gsl_vector_complex*) * fftLen);
+  if (bs) {
+    wa_views_ = (gsl_vector_complex**)malloc(sizeof(gsl_vector_complex*) * fftLen);
+    B_views_ = (gsl_matrix_complex**)malloc(sizeof(gsl_matrix_complex*) * fftLen);
+  }
+  for (unsigned k = 0; k < fftLen; k++) {
+    wq_views_[k] = alias_vector(&wq_v[(size_t)k * chanN], chanN);
+    wl_views_[k] = alias_vector(&wl_v[(size_t)k * chanN], chanN);
+    ta_views_[k] = alias_vector(&ta_v[(size_t)k * chanN], chanN);
+    CSDs_[k] = gsl_vector_complex_calloc((size_t)chanN * chanN);
+    if (bs) {
+      wa_views_[k] = alias_vector(&wa_v[(size_t)k * bs], bs);
+      B_views_[k] = alias_matrix(&B_v[(size_t)k * chanN * bs], chanN, bs);
+    }
+  }
+  wp1_ = gsl_vector_complex_calloc(fftLen);
+}
 
 BeamformerWeights::~BeamformerWeights()
 {
-  gsl_vector_complex_free(wq_view_); gsl_vector_complex_free(wl_view_); gsl_matrix_complex_free(B_view_);
-}
-
-gsl_vector_complex* BeamformerWeights::wq_f(unsigned fbinX)
-{
-  memcpy(wq_view_->data, &wq[(size_t)fbinX * chanN_], sizeof(double) * 2 * chanN_);
-  return wq_view_;
-}
-gsl_vector_complex* BeamformerWeights::wl_f(unsigned fbinX)
-{
-  memcpy(wl_view_->data, &wl[(size_t)fbinX * chanN_], sizeof(double) * 2 * chanN_);
-  return wl_view_;
-}
-gsl_matrix_complex* BeamformerWeights::B_f(unsigned fbinX)
-{
-  const unsigned bs = chanN_ - NC_;
-  if (bs) memcpy(B_view_->data, &B[(size_t)fbinX * chanN_ * bs], sizeof(double) * 2 * chanN_ * bs);
-  return B_view_;
+  for (unsigned k = 0; k < fftLen_; k++) {
+    free(wq_views_[k]); free(wl_views_[k]); free(ta_views_[k]); gsl_vector_complex_free(CSDs_[k]);
+    if (wa_views_) free(wa_views_[k]);
+    if (B_views_) free(B_views_[k]);
+  }
+  free(wq_views_); free(wl_views_); free(ta_views_); free(CSDs_); free(wa_views_); free(B_views_);
+  gsl_vector_complex_free(wp1_);
 }
 
 void BeamformerWeights::calcMainlobe2(float samplerate, const gsl_vector* delaysT, const gsl_vector* delaysI, bool isGSC)
@@ -422,13 +468,14 @@ void BeamformerWeights::calcMainlobeN(float samplerate, const gsl_vector* delays
   if (delaysT->size != chanN_)
     throw jdimension_error("The number of delays does not match number of channels (%d vs. %d).\n", (int)delaysT->size, chanN_);
   if (NC != NC_) throw jdimension_error("The weight object was allocated for %d constraints, not %d\n", NC_, NC);
+  if (halfBandShift_) throw j_error("halfBandShift==true with more than one constraint is not supported by this engine\n");
   std::vector<double> dt(chanN_), di((size_t)(NC - 1) * chanN_);
   for (unsigned c = 0; c < chanN_; c++) dt[c] = gsl_vector_get(delaysT, c);
   for (unsigned n = 0; n + 1 < NC; n++)
     for (unsigned c = 0; c < chanN_; c++) di[(size_t)n * chanN_ + c] = gsl_matrix_get(delaysIs, n, c);
-  check_abi(btk_weights_mainlobe_n((int)fftLen_, (int)chanN_, samplerate, dt.data(), di.data(), (int)NC, reinterpret_cast<double*>(wq.data())));
+  check_abi(btk_weights_mainlobe_n((int)fftLen_, (int)chanN_, samplerate, dt.data(), di.data(), (int)NC, reinterpret_cast<double*>(wq_v.data())));
   // ta_ keeps the plain look-direction manifold calcMainlobe copied before the constraints were applied (beamformer.cc:562)
-  check_abi(btk_weights_mainlobe((int)fftLen_, (int)chanN_, samplerate, dt.data(), reinterpret_cast<double*>(ta.data())));
+  check_abi(btk_weights_mainlobe((int)fftLen_, (int)chanN_, samplerate, dt.data(), reinterpret_cast<double*>(ta_v.data())));
   if (isGSC)
     for (unsigned k = 0; k < fftLen_; k++) calcBlockingMatrix(k);
 }
@@ -444,25 +491,25 @@ void BeamformerWeights::calcSidelobeCancellerU_f(unsigned fbinX, const gsl_vecto
 
 void BeamformerWeights::setSidelobeCanceller_f(unsigned fbinX, gsl_vector_complex* wl_in)
 {
-  memcpy(static_cast<void*>(&wl[(size_t)fbinX * chanN_]), wl_in->data, sizeof(double) * 2 * chanN_);
+  memcpy(static_cast<void*>(&wl_v[(size_t)fbinX * chanN_]), wl_in->data, sizeof(double) * 2 * chanN_);
 }
 
 void BeamformerWeights::setQuiescentVector(unsigned fbinX, gsl_vector_complex* wq_in, bool isGSC)
 {
-  for (unsigned c = 0; c < chanN_; c++) { const gsl_complex z = gsl_vector_complex_get(wq_in, c); wq[(size_t)fbinX * chanN_ + c] = cd(GSL_REAL(z), GSL_IMAG(z)); }
+  for (unsigned c = 0; c < chanN_; c++) { const gsl_complex z = gsl_vector_complex_get(wq_in, c); wq_v[(size_t)fbinX * chanN_ + c] = cd(GSL_REAL(z), GSL_IMAG(z)); }
   if (isGSC) calcBlockingMatrix(fbinX);
 }
 
 void BeamformerWeights::setQuiescentVectorAll(gsl_complex z, bool isGSC)
 {
   for (unsigned k = 0; k < fftLen_; k++) {
-    for (unsigned c = 0; c < chanN_; c++) wq[(size_t)k * chanN_ + c] = cd(GSL_REAL(z), GSL_IMAG(z));
+    for (unsigned c = 0; c < chanN_; c++) wq_v[(size_t)k * chanN_ + c] = cd(GSL_REAL(z), GSL_IMAG(z));
     if (isGSC) calcBlockingMatrix(k);
   }
 }
 
 // reference beamformer.cc:775-828.  The inverse DFT (gsl_fft_complex_radix2_inverse: e^{+j 2 pi k n / M} / M) of the
-// Hermitian-extended sequence val[k] = e^{j pi (k+1)} conj(wq[k] - wl[k]) is taken directly: M^2 / 2 operations per
+// Hermitian-extended sequence val[k] = e^{j pi (k+1)} conj(wq_v[k] - wl_v[k]) is taken directly: M^2 / 2 operations per
 // channel, one-off.
 bool BeamformerWeights::write_fir_coeff(const String& fn, unsigned winType)
 {
@@ -478,7 +525,7 @@ bool BeamformerWeights::write_fir_coeff(const String& fn, unsigned winType)
   for (unsigned c = 0; c < chanN_; c++) {
     std::fill(val.begin(), val.end(), cd(0, 0));
     for (unsigned k = 0; k <= M2; k++) {
-      const cd wH = std::conj(wq[(size_t)k * chanN_ + c] - wl[(size_t)k * chanN_ + c]);
+      const cd wH = std::conj(wq_v[(size_t)k * chanN_ + c] - wl_v[(size_t)k * chanN_ + c]);
       const cd v = std::polar(1.0, M_PI * (k + 1)) * wH;                       // shift fftLen/2
       val[k] = v;
       if (k > 0 && k < M2) val[M - k] = std::conj(v);
@@ -504,8 +551,10 @@ void BeamformerWeights::calcMainlobe(float samplerate, const gsl_vector* delays,
   if (isGSC && chanN_ <= 1) throw jdimension_error("The number of channels must be > 1 but it is %d\n", chanN_);
   std::vector<double> d(chanN_);
   for (unsigned c = 0; c < chanN_; c++) d[c] = gsl_vector_get(delays, c);
-  check_abi(btk_weights_mainlobe((int)fftLen_, (int)chanN_, samplerate, d.data(), reinterpret_cast<double*>(wq.data())));
-  ta = wq;                                                   // setTimeAlignment
+ // halfBandShift: bin k sits at (k + 0.5) fs / M and every one of the M bins has its own vector (beamformer.cc:515-527)
+  if (halfBandShift_) check_abi(btk_weights_mainlobe_halfband((int)fftLen_, (int)chanN_, samplerate, d.data(), reinterpret_cast<double*>(wq_v.data())));
+  else check_abi(btk_weights_mainlobe((int)fftLen_, (int)chanN_, samplerate, d.data(), reinterpret_cast<double*>(wq_v.data())));
+  ta_v = wq_v;                                                   // setTimeAlignment
   if (isGSC)
     for (unsigned k = 0; k < fftLen_; k++) calcBlockingMatrix(k);
 }
@@ -513,18 +562,18 @@ void BeamformerWeights::calcMainlobe(float samplerate, const gsl_vector* delays,
 void BeamformerWeights::calcBlockingMatrix(unsigned fbinX)
 {
   const unsigned bs = chanN_ - NC_;
-  check_abi(btk_weights_blocking_matrix(reinterpret_cast<const double*>(&wq[(size_t)fbinX * chanN_]), (int)chanN_, (int)NC_,
-                                        reinterpret_cast<double*>(&B[(size_t)fbinX * chanN_ * bs])));
+  check_abi(btk_weights_blocking_matrix(reinterpret_cast<const double*>(&wq_v[(size_t)fbinX * chanN_]), (int)chanN_, (int)NC_,
+                                        reinterpret_cast<double*>(&B_v[(size_t)fbinX * chanN_ * bs])));
 }
 
 void BeamformerWeights::calcSidelobeCancellerU_f(unsigned fbinX, const cd* w)
 {
   if (fbinX >= fftLen_) throw jdimension_error("Must be a frequency bin %d < the length of FFT %d\n", fbinX, fftLen_);
   const unsigned bs = chanN_ - NC_;
-  for (unsigned i = 0; i < bs; i++) wa[(size_t)fbinX * bs + i] = w[i];
-  check_abi(btk_weights_sidelobe(reinterpret_cast<const double*>(&B[(size_t)fbinX * chanN_ * bs]),
-                                 reinterpret_cast<const double*>(&wa[(size_t)fbinX * bs]), (int)chanN_, (int)NC_,
-                                 reinterpret_cast<double*>(&wl[(size_t)fbinX * chanN_])));
+  for (unsigned i = 0; i < bs; i++) wa_v[(size_t)fbinX * bs + i] = w[i];
+  check_abi(btk_weights_sidelobe(reinterpret_cast<const double*>(&B_v[(size_t)fbinX * chanN_ * bs]),
+                                 reinterpret_cast<const double*>(&wa_v[(size_t)fbinX * bs]), (int)chanN_, (int)NC_,
+                                 reinterpret_cast<double*>(&wl_v[(size_t)fbinX * chanN_])));
 }
 
 void BeamformerWeights::calcSidelobeCancellerP_f(unsigned fbinX, const gsl_vector* packedWeight)
@@ -539,12 +588,10 @@ void BeamformerWeights::calcSidelobeCancellerP_f(unsigned fbinX, const gsl_vecto
 
 // ================================================================================ SubbandBeamformer
 SubbandBeamformer::SubbandBeamformer(unsigned fftLen, bool halfBandShift, const String& nm)
-    : VectorComplexFeatureStream(fftLen, nm), snapshot_array_(NULL), fftLen_(fftLen), fftLen2_(fftLen / 2), dX_(NULL), T_(0)
-{
-  if (halfBandShift) throw jallocation_error("halfBandShift==true is not yet supported\n");
-}
+    : VectorComplexFeatureStream(fftLen, nm), snapshot_array_(NULL), halfBandShift_(halfBandShift), dXfull_(NULL), fftLen_(fftLen),
+      fftLen2_(fftLen / 2), dX_(NULL), T_(0) {}
 SubbandBeamformer::~SubbandBeamformer() { free_device_(); }
-void SubbandBeamformer::free_device_() { dev_free(dX_); dX_ = NULL; T_ = 0; Xhost_.clear(); }
+void SubbandBeamformer::free_device_() { dev_free(dX_); dX_ = NULL; dev_free(dXfull_); dXfull_ = NULL; T_ = 0; Xhost_.clear(); }
 void SubbandBeamformer::set_channel(VectorComplexFeatureStreamPtr& chan) { channelList_.push_back(chan); }
 void SubbandBeamformer::clear_channel() { channelList_.clear(); snapshot_array_ = NULL; free_device_(); }
 
@@ -582,6 +629,27 @@ void* SubbandBeamformer::device_snapshots()
     check_abi(btk_fb_analysis(banks[0]->plan(), (const float*)dp, L, L ? L : 1, 1, (int)N, dX_, T_, 0, T_, NULL));
     check_abi(btk_synchronize(NULL));
     dev_free(dp);
+  } else if (halfBandShift_) {
+    // the reference dots every one of the M snapshots as supplied (beamformer.cc:1113-1128): a generic source owes no conjugate
+    // symmetry between its bins, so all M bins go to the device; dX_ keeps the usual bins 0..M/2 for the other consumers
+    const unsigned M = fftLen_;
+    std::vector<std::vector<float> > fr(N);
+    long T = -1; unsigned c = 0;
+    for (ChannelList_::iterator it = channelList_.begin(); it != channelList_.end(); ++it, ++c) {
+      const long t = drain_complex_all_bins(*it, M, fr[c]);
+      if (T < 0 || t < T) T = t;
+    }
+    T_ = T;
+    std::vector<float> Xf((size_t)2 * M * N * T_);
+    for (unsigned k = 0; k < M; k++)
+      for (unsigned n = 0; n < N; n++)
+        for (long t = 0; t < T_; t++) {
+          Xf[2 * (((size_t)k * N + n) * T_ + t)] = fr[n][2 * ((size_t)t * M + k)];
+          Xf[2 * (((size_t)k * N + n) * T_ + t) + 1] = fr[n][2 * ((size_t)t * M + k) + 1];
+        }
+    dXfull_ = dev_alloc(sizeof(float) * (Xf.empty() ? 2 : Xf.size()));
+    dX_ = dev_alloc(sizeof(float) * 2 * K * N * (T_ ? T_ : 1));
+    if (!Xf.empty()) { h2d(dXfull_, Xf.data(), sizeof(float) * Xf.size()); h2d(dX_, Xf.data(), sizeof(float) * 2 * K * N * T_); }
   } else {
     std::vector<std::vector<float> > fr(N);
     long T = -1; unsigned c = 0;
@@ -632,7 +700,7 @@ void SubbandDS::alloc_bfweight_(int NC)
 {
   // re-creates the weight object: active weights and post-filter state start over (reference beamformer.cc:1082-1092)
   delete bfweight_;
-  bfweight_ = new BeamformerWeights(fftLen_, chanN(), false, (unsigned)NC);
+  bfweight_ = new BeamformerWeights(fftLen_, chanN(), halfBandShift_, (unsigned)NC);
   weights_version_++;
 }
 
@@ -659,7 +727,7 @@ const gsl_vector_complex* SubbandDS::get_weights(unsigned fbinX)
   const unsigned N = chanN();
   gsl_vector_complex_free(wq_view_);
   wq_view_ = gsl_vector_complex_calloc(N);
-  memcpy(wq_view_->data, &bfweight_->wq[(size_t)fbinX * N], sizeof(double) * 2 * N);
+  memcpy(wq_view_->data, &bfweight_->wq_v[(size_t)fbinX * N], sizeof(double) * 2 * N);
   return wq_view_;
 }
 
@@ -667,34 +735,83 @@ void SubbandDS::effective_weights(std::vector<float>& w)
 {
   if (!bfweight_) throw j_error("%s", need_weights_msg_());
   w.resize((size_t)2 * (fftLen2_ + 1) * chanN());
-  check_abi(btk_weights_gsc_effective(reinterpret_cast<const double*>(bfweight_->wq.data()), NULL, (int)fftLen_, (int)chanN(), 0, w.data()));
+  check_abi(btk_weights_gsc_effective(reinterpret_cast<const double*>(bfweight_->wq_v.data()), NULL, (int)fftLen_, (int)chanN(), 0, w.data()));
+}
+
+void SubbandDS::effective_weights_all_bins(std::vector<float>& w)
+{
+  if (!bfweight_) throw j_error("%s", need_weights_msg_());
+  const size_t n = (size_t)fftLen_ * chanN();
+  w.resize(2 * n);
+  for (size_t i = 0; i < n; i++) { w[2 * i] = (float)bfweight_->wq_v[i].real(); w[2 * i + 1] = (float)bfweight_->wq_v[i].imag(); }
 }
 
 void SubbandDS::alignment_vector(bool use_wq, std::vector<float>& d)
 {
   if (!bfweight_) throw j_error("%s", need_weights_msg_());
   const unsigned N = chanN(), K = fftLen2_ + 1;
-  const std::vector<cd>& src = use_wq ? bfweight_->wq : bfweight_->ta;
+  const std::vector<cd>& src = use_wq ? bfweight_->wq_v : bfweight_->ta_v;
   d.resize((size_t)2 * K * N);
   for (size_t i = 0; i < (size_t)K * N; i++) { d[2 * i] = (float)src[i].real(); d[2 * i + 1] = (float)src[i].imag(); }
 }
 
 void SubbandDS::compute_output_(long from_frame)
 {
-  const unsigned N = chanN(), K = fftLen2_ + 1;
+  const unsigned N = chanN(), K = fftLen2_ + 1, M = fftLen_;
   void* dX = device_snapshots();
-  std::vector<float> w;
-  effective_weights(w);
-  void* dW = dev_alloc(sizeof(float) * w.size());
-  void* dY = dev_alloc(sizeof(float) * 2 * K * (T_ ? T_ : 1));
-  h2d(dW, w.data(), sizeof(float) * w.size());
-  check_abi(btk_bf_apply(dW, 0, dX, dY, 1, (int)K, (int)N, T_, T_, NULL));
-  check_abi(btk_synchronize(NULL));
-  std::vector<float> Ynew((size_t)2 * K * T_);
-  if (T_) d2h(Ynew.data(), dY, sizeof(float) * Ynew.size());
-  dev_free(dW); dev_free(dY);
+  const unsigned rows = halfBandShift_ ? M : K;                  // halfBandShift: every bin has its own output (Yhost_ [M][T])
+  std::vector<float> Ynew((size_t)2 * rows * T_);
+  if (!halfBandShift_) {
+    std::vector<float> w;
+    effective_weights(w);
+    void* dW = dev_alloc(sizeof(float) * w.size());
+    void* dY = dev_alloc(sizeof(float) * 2 * K * (T_ ? T_ : 1));
+    h2d(dW, w.data(), sizeof(float) * w.size());
+    check_abi(btk_bf_apply(dW, 0, dX, dY, 1, (int)K, (int)N, T_, T_, NULL));
+    check_abi(btk_synchronize(NULL));
+    if (T_) d2h(Ynew.data(), dY, sizeof(float) * Ynew.size());
+    dev_free(dW); dev_free(dY);
+  } else {
+    // reference beamformer.cc:1113-1128 / 1276-1285: y_k = w_k^H x_k for k = 0..M-1.
+    std::vector<float> wf;
+    effective_weights_all_bins(wf);                              // [M][N]
+    void* dY = dev_alloc(sizeof(float) * 2 * M * (T_ ? T_ : 1));
+    if (dXfull_) {                                               // pulled sources: all M snapshot bins as supplied, one pass
+      void* dW = dev_alloc(sizeof(float) * wf.size());
+      h2d(dW, wf.data(), sizeof(float) * wf.size());
+      check_abi(btk_bf_apply(dW, 0, dXfull_, dY, 1, (int)M, (int)N, T_, T_, NULL));
+      check_abi(btk_synchronize(NULL));
+      if (T_) d2h(Ynew.data(), dY, sizeof(float) * Ynew.size());
+      dev_free(dW);
+    } else {
+      // analysis banks of a real signal: x_{M-k} = conj(x_k), so y_{M-k} = conj((conj w_{M-k})^H x_k): a second pass of the same
+      // kernel over bins 1 .. M/2-1 with the conjugated upper weights
+      std::vector<float> w2((size_t)2 * K * N, 0.f), up((size_t)2 * K * T_);
+      for (unsigned k = 1; k + 1 < K; k++)
+        for (unsigned c = 0; c < N; c++) {
+          w2[2 * ((size_t)k * N + c)] = wf[2 * ((size_t)(M - k) * N + c)];
+          w2[2 * ((size_t)k * N + c) + 1] = -wf[2 * ((size_t)(M - k) * N + c) + 1];
+        }
+      void* dW = dev_alloc(sizeof(float) * 2 * K * N);
+      h2d(dW, wf.data(), sizeof(float) * 2 * K * N);
+      check_abi(btk_bf_apply(dW, 0, dX, dY, 1, (int)K, (int)N, T_, T_, NULL));
+      check_abi(btk_synchronize(NULL));
+      if (T_) d2h(Ynew.data(), dY, sizeof(float) * 2 * K * T_);
+      h2d(dW, w2.data(), sizeof(float) * 2 * K * N);
+      check_abi(btk_bf_apply(dW, 0, dX, dY, 1, (int)K, (int)N, T_, T_, NULL));
+      check_abi(btk_synchronize(NULL));
+      if (T_) d2h(up.data(), dY, sizeof(float) * up.size());
+      for (unsigned k = 1; k + 1 < K; k++)
+        for (long t = 0; t < T_; t++) {
+          Ynew[2 * ((size_t)(M - k) * T_ + t)] = up[2 * ((size_t)k * T_ + t)];
+          Ynew[2 * ((size_t)(M - k) * T_ + t) + 1] = -up[2 * ((size_t)k * T_ + t) + 1];
+        }
+      dev_free(dW);
+    }
+    dev_free(dY);
+  }
   if (Yhost_.size() == Ynew.size() && from_frame > 0) {
-    for (unsigned k = 0; k < K; k++)                        // frames already served keep their values
+    for (unsigned k = 0; k < rows; k++)                     // frames already served keep their values
       memcpy(&Ynew[2 * ((size_t)k * T_)], &Yhost_[2 * ((size_t)k * T_)], sizeof(float) * 2 * (size_t)from_frame);
   }
   Yhost_.swap(Ynew);
@@ -708,7 +825,8 @@ const gsl_vector_complex* SubbandDS::next(int frame_no)
   if (Yhost_.empty() || output_version_ != weights_version_) compute_output_(frame_no_ + 1);
   const long idx = frame_no_ + 1;
   if (idx >= T_) { is_end_ = true; throw jiterator_error("end of samples!"); }
-  serve_frame(Yhost_, T_, fftLen_, idx, vector_);
+  if (halfBandShift_) serve_frame_all_bins(Yhost_, T_, fftLen_, idx, vector_);
+  else serve_frame(Yhost_, T_, fftLen_, idx, vector_);
   increment_();
   return vector_;
 }
@@ -749,7 +867,7 @@ gsl_matrix_complex* SubbandGSC::blocking_matrix(unsigned srcX, unsigned fbinX)
 void SubbandGSC::set_quiescent_weights_f(unsigned fbinX, const gsl_vector_complex* srcWq)
 {
   alloc_bfweight_(1);
-  memcpy(static_cast<void*>(&bfweight_->wq[(size_t)fbinX * chanN()]), srcWq->data, sizeof(double) * 2 * chanN());
+  memcpy(static_cast<void*>(&bfweight_->wq_v[(size_t)fbinX * chanN()]), srcWq->data, sizeof(double) * 2 * chanN());
   bfweight_->calcBlockingMatrix(fbinX);
 }
 
@@ -772,15 +890,38 @@ void SubbandGSC::effective_weights(std::vector<float>& w)
 {
   if (!bfweight_) throw j_error("%s", need_weights_msg_());
   w.resize((size_t)2 * (fftLen2_ + 1) * chanN());
-  check_abi(btk_weights_gsc_effective(reinterpret_cast<const double*>(bfweight_->wq.data()),
-                                      reinterpret_cast<const double*>(bfweight_->wl.data()), (int)fftLen_, (int)chanN(),
+  check_abi(btk_weights_gsc_effective(reinterpret_cast<const double*>(bfweight_->wq_v.data()),
+                                      reinterpret_cast<const double*>(bfweight_->wl_v.data()), (int)fftLen_, (int)chanN(),
                                       normalize_weight_ ? 1 : 0, w.data()));
+}
+
+void SubbandGSC::effective_weights_all_bins(std::vector<float>& w)
+{
+  // wq - wl of every bin, normalised like calc_gsc_output (reference beamformer.cc:1208-1243, 1276-1285)
+  if (!bfweight_) throw j_error("%s", need_weights_msg_());
+  const unsigned N = chanN();
+  w.resize((size_t)2 * fftLen_ * N);
+  for (unsigned k = 0; k < fftLen_; k++) {
+    double nn = 0.0;
+    for (unsigned c = 0; c < N; c++) nn += std::norm(bfweight_->wq_v[(size_t)k * N + c] - bfweight_->wl_v[(size_t)k * N + c]);
+    const double sc = normalize_weight_ ? 1.0 / (std::sqrt(nn) * N) : 1.0;
+    for (unsigned c = 0; c < N; c++) {
+      const cd v = (bfweight_->wq_v[(size_t)k * N + c] - bfweight_->wl_v[(size_t)k * N + c]) * sc;
+      w[2 * ((size_t)k * N + c)] = (float)v.real(); w[2 * ((size_t)k * N + c) + 1] = (float)v.imag();
+    }
+  }
 }
 
 // ================================================================================ SubbandMVDR
 SubbandMVDR::SubbandMVDR(unsigned fftLen, bool halfBandShift, const String& nm)
     : SubbandDS(fftLen, halfBandShift, nm), dR_(NULL), have_mvdr_(false), fallbacks_(0), wm_view_(gsl_vector_complex_calloc(1)),
-      R_view_(NULL) {}
+      R_view_(NULL)
+{
+  if (halfBandShift) {                                       // reference beamformer.cc:2283-2285
+    gsl_vector_complex_free(wm_view_);
+    throw jallocation_error("halfBandShift==true is not yet supported\n");
+  }
+}
 SubbandMVDR::~SubbandMVDR() { dev_free(dR_); gsl_vector_complex_free(wm_view_); gsl_matrix_complex_free(R_view_); }
 
 void SubbandMVDR::divide_all_nondiagonal_elements(float mu)
@@ -947,7 +1088,7 @@ bool SubbandMVDRGSC::calc_blocking_matrix2()
   const unsigned N = chanN();
   for (unsigned k = 1; k <= fftLen2_; k++) {
     for (unsigned c = 0; c < N; c++)
-      bfweight_->wq[(size_t)k * N + c] = cd(wmvdr_[2 * ((size_t)k * N + c)], wmvdr_[2 * ((size_t)k * N + c) + 1]);
+      bfweight_->wq_v[(size_t)k * N + c] = cd(wmvdr_[2 * ((size_t)k * N + c)], wmvdr_[2 * ((size_t)k * N + c) + 1]);
     bfweight_->calcBlockingMatrix(k);
   }
   return true;
@@ -960,9 +1101,9 @@ void SubbandMVDRGSC::upgrade_blocking_matrix()
   const unsigned N = chanN(), bs = N - bfweight_->NC();
   std::vector<cd> w(N);
   for (unsigned k = 1; k < fftLen_; k++) {
-    for (unsigned c = 0; c < N; c++) w[c] = bfweight_->wq[(size_t)k * N + c] - bfweight_->wl[(size_t)k * N + c];
+    for (unsigned c = 0; c < N; c++) w[c] = bfweight_->wq_v[(size_t)k * N + c] - bfweight_->wl_v[(size_t)k * N + c];
     check_abi(btk_weights_blocking_matrix(reinterpret_cast<const double*>(w.data()), (int)N, (int)bfweight_->NC(),
-                                          reinterpret_cast<double*>(&bfweight_->B[(size_t)k * N * bs])));
+                                          reinterpret_cast<double*>(&bfweight_->B_v[(size_t)k * N * bs])));
   }
 }
 
@@ -977,7 +1118,7 @@ const gsl_vector_complex* SubbandMVDRGSC::blocking_matrix_output(int outChanX)
     const gsl_vector_complex* x = snaps->snapshot(k);
     cd acc(0.0, 0.0);
     for (unsigned c = 0; c < N; c++)
-      acc += std::conj(bfweight_->B[((size_t)k * N + c) * bs + outChanX]) * cd(x->data[2 * c], x->data[2 * c + 1]);
+      acc += std::conj(bfweight_->B_v[((size_t)k * N + c) * bs + outChanX]) * cd(x->data[2 * c], x->data[2 * c + 1]);
     vector_->data[2 * k] = acc.real(); vector_->data[2 * k + 1] = acc.imag();
   }
   return vector_;
@@ -991,7 +1132,7 @@ void SubbandMVDRGSC::effective_weights(std::vector<float>& w)
   std::vector<cd> wq((size_t)fftLen_ * N, cd(0.0, 0.0));
   for (size_t i = 0; i < (size_t)K * N; i++) wq[i] = cd(wmvdr_[2 * i], wmvdr_[2 * i + 1]);
   w.resize((size_t)2 * K * N);
-  check_abi(btk_weights_gsc_effective(reinterpret_cast<const double*>(wq.data()), reinterpret_cast<const double*>(bfweight_->wl.data()),
+  check_abi(btk_weights_gsc_effective(reinterpret_cast<const double*>(wq.data()), reinterpret_cast<const double*>(bfweight_->wl_v.data()),
                                       (int)fftLen_, (int)N, normalize_weight_ ? 1 : 0, w.data()));
 }
 
@@ -1013,6 +1154,9 @@ void ZelinskiPostFilter::compute_(long from_frame)
 {
   if (!has_bf_ptr_) throw j_error("set beamformer's weights \n");
   SubbandDS* bf = bf_ptr_.operator->();
+  // the reference runs its post-filters over all fftLen bins of a half-band-shifted beamformer (postfilter.cc:170-182); this
+  // engine's post-filter kernels work on the M/2+1 bins of a non-shifted bank: refuse instead of filtering wrongly
+  if (bf->is_half_band_shift()) throw j_error("post-filters over a beamformer with halfBandShift==true are not supported by this engine\n");
   const unsigned N = bf->chanN(), K = fftLen_ / 2 + 1;
   void* dX = bf->device_snapshots();
   T_ = bf->num_frames();
@@ -1082,6 +1226,9 @@ const gsl_vector_complex* ZelinskiPostFilter::postfilter_weights()
     wp1_->data[2 * k] = wl[k]; wp1_->data[2 * k + 1] = 0.0;
     if (k > 0 && k < fftLen_ / 2) { wp1_->data[2 * (fftLen_ - k)] = wl[k]; wp1_->data[2 * (fftLen_ - k) + 1] = 0.0; }
   }
+  // the reference keeps these gains in the beamformer's weight object (BeamformerWeights::wp1(), postfilter.cc:447): mirror them
+  if (has_bf_ptr_ && bf_ptr_->beamformer_weight_object() && bf_ptr_->beamformer_weight_object()->fftLen() == fftLen_)
+    memcpy(bf_ptr_->beamformer_weight_object()->wp1()->data, wp1_->data, sizeof(double) * 2 * fftLen_);
   return wp1_;
 }
 
@@ -1305,7 +1452,7 @@ void SubbandGSCRLS::alloc_state_()
   dV_ = dev_alloc(sizeof(double) * 2 * K * N);
   dSS_ = dev_alloc(sizeof(double) * 4);
   check_hip(hipMemset(dSS_, 0, sizeof(double) * 4), "hipMemset");
-  h2d(dV_, bfweight_->wq.data(), sizeof(double) * 2 * K * N);                 // bins 0..M/2 of wq [M][N]
+  h2d(dV_, bfweight_->wq_v.data(), sizeof(double) * 2 * K * N);                 // bins 0..M/2 of wq [M][N]
 }
 
 void SubbandGSCRLS::init_precision_matrix(float sigma2)
@@ -1315,7 +1462,7 @@ void SubbandGSCRLS::init_precision_matrix(float sigma2)
   const float p0 = 1 / sigma2;                                                // float division, beamformer.cc:1491
   check_abi(btk_rls_init(0, dV_, 0, (double)p0, 1, (int)K, (int)N, dP_, dW_, NULL));
   // the active weights kept in the weight object are the starting point (zeros after calc_gsc_weights)
-  h2d(dW_, bfweight_->wl.data(), sizeof(double) * 2 * K * N);
+  h2d(dW_, bfweight_->wl_v.data(), sizeof(double) * 2 * K * N);
   have_P_ = true;
   Yhost_.clear();
 }
@@ -1326,14 +1473,14 @@ void SubbandGSCRLS::set_precision_matrix(unsigned fbinX, gsl_matrix_complex* Pz)
     alloc_state_();
     const unsigned N = chanN(), K = fftLen2_ + 1;
     check_hip(hipMemset(dP_, 0, sizeof(double) * 2 * K * N * N), "hipMemset");
-    h2d(dW_, bfweight_->wl.data(), sizeof(double) * 2 * K * N);
+    h2d(dW_, bfweight_->wl_v.data(), sizeof(double) * 2 * K * N);
     have_P_ = true;
   }
   const unsigned N = chanN(), bs = N - 1;
   if (fbinX > fftLen2_) return;                                               // only bins 1..M/2 are ever used
   if (Pz->size1 < bs || Pz->size2 < bs) throw jdimension_error("the precision matrix must be at least %dx%d\n", bs, bs);
   // engine basis: P = B Pz B^H
-  const cd* B = &bfweight_->B[(size_t)fbinX * N * bs];
+  const cd* B = &bfweight_->B_v[(size_t)fbinX * N * bs];
   std::vector<cd> T((size_t)N * bs), P((size_t)N * N);
   for (unsigned a = 0; a < N; a++)
     for (unsigned j = 0; j < bs; j++) {
@@ -1372,12 +1519,12 @@ void SubbandGSCRLS::run_block_()
   d2h(wl.data(), dW_, sizeof(double) * 2 * K * N);
   const unsigned bs = N - 1;
   for (unsigned k = 1; k < K; k++) {
-    const cd* B = &bfweight_->B[(size_t)k * N * bs];
-    for (unsigned c = 0; c < N; c++) bfweight_->wl[(size_t)k * N + c] = wl[(size_t)k * N + c];
+    const cd* B = &bfweight_->B_v[(size_t)k * N * bs];
+    for (unsigned c = 0; c < N; c++) bfweight_->wl_v[(size_t)k * N + c] = wl[(size_t)k * N + c];
     for (unsigned i = 0; i < bs; i++) {
       cd acc(0, 0);
       for (unsigned c = 0; c < N; c++) acc += std::conj(B[(size_t)c * bs + i]) * wl[(size_t)k * N + c];
-      bfweight_->wa[(size_t)k * bs + i] = acc;
+      bfweight_->wa_v[(size_t)k * bs + i] = acc;
     }
   }
   output_version_ = weights_version_;
@@ -1388,6 +1535,7 @@ const gsl_vector_complex* SubbandGSCRLS::next(int frame_no)
   if (frame_no == frame_no_) return vector_;
   if (!bfweight_) throw j_error("call calc_gsc_weights_x() once\n");
   if (!have_P_) throw j_error("set the precision matrix with init_precision_matrix() or set_precision_matrix()\n");
+  if (halfBandShift_) throw j_error("halfBandShift==true is not yet supported\n");          // reference beamformer.cc:1528-1530
   if (Yhost_.empty()) run_block_();
   const long idx = frame_no_ + 1;
   if (idx >= T_) { is_end_ = true; throw jiterator_error("end of samples!"); }

@@ -250,6 +250,7 @@ PYBIND11_MODULE(_btk20cpp, m)
       .def("fftLen", &SubbandBeamformer::fftLen)
       .def("dim", &SubbandBeamformer::dim)
       .def("num_frames", &SubbandBeamformer::num_frames)
+      .def("is_half_band_shift", &SubbandBeamformer::is_half_band_shift)
       .def("snapshot_array_f", [](SubbandBeamformer& b, unsigned fbinX) { return copy_of(b.snapshot_array_f(fbinX)); });
 
   py::class_<SubbandDS, SubbandBeamformer, cref<SubbandDS>>(m, "SubbandDSPtr")

@@ -163,3 +163,78 @@ def test_noise_matrix_accessors_are_range_checked(dev):
                  lambda: pf.divide_nondiagonal_elements(Mh, 0.1), lambda: pf.set_noise_spatial_spectral_matrix(Mh // 2 + 1, R)):
         with pytest.raises(B.jindex_error):
             call()
+
+
+@pytest.mark.gpu
+def test_half_band_shift_through_cpp_nodes(orc, dev, proto256, kinect_pcm, tmp_path):
+    """halfBandShift == true in the C++ node layer (SubbandDS / SubbandGSC with one constraint, reference beamformer.cc:515-527,
+    1113-1128, 1276-1285): analysis-bank channels (conjugate-mirrored upper bins) and generic sources (all M bins as supplied);
+    SubbandMVDR refuses it in the constructor, SubbandGSCRLS in next(), post-filters when bound."""
+    from distant_speech_recognition_amd import btk20cpp as B
+    from distant_speech_recognition_amd.pybeamformer import calc_delays
+    h, _ = proto256
+    delays = calc_delays("linear", MPOS, [AZIMUTH, None, None])
+
+    def banks():
+        afbs = []
+        for c in range(4):
+            p = str(tmp_path / ("h%d.wav" % c))
+            w = wave.open(p, "wb")
+            w.setnchannels(1); w.setsampwidth(2); w.setframerate(FS)
+            w.writeframes(kinect_pcm[c][:40000].astype(np.int16).tobytes())
+            w.close()
+            sf = B.SampleFeaturePtr(block_len=D, shift_len=D, pad_zeros=True)
+            sf.read(p, FS)
+            afbs.append(B.OverSampledDFTAnalysisBankPtr(sf, prototype=h, M=M, m=m, r=r, delay_compensation_type=2))
+        return afbs
+    X = np.stack([orc.analysis(h, M, m, r, 2, kinect_pcm[c][:40000]) for c in range(4)], axis=1)      # [T][N][M]
+    wq = orc.calc_mainlobe_halfband(M, 4, FS, delays)
+    ds = B.SubbandDSPtr(fftlen=M, half_band_shift=True)
+    assert ds.is_half_band_shift()
+    for a in banks():
+        ds.set_channel(a)
+    ds.calc_array_manifold_vectors(FS, delays)
+    assert np.max(np.abs(np.stack([ds.get_weights(k) for k in range(M)]) - wq)) < 1e-15
+    out = np.stack([np.array(v) for v in ds])
+    ref = orc.gsc_frames_halfband(X, wq, np.zeros_like(wq))
+    assert out.shape == ref.shape and np.max(np.abs(out - ref)) < 2e-5 * np.max(np.abs(ref))
+    gsc = B.SubbandGSCPtr(fftlen=M, half_band_shift=True)
+    for a in banks():
+        gsc.set_channel(a)
+    gsc.calc_gsc_weights(FS, delays)
+    gsc.normalize_weight(True)
+    rng = np.random.default_rng(5)
+    wl = np.zeros_like(wq)
+    for k in range(M):
+        wa = (rng.standard_normal(3) + 1j * rng.standard_normal(3)) * 0.05
+        packed = np.empty(6); packed[0::2] = wa.real; packed[1::2] = wa.imag
+        gsc.set_active_weights_f(k, packed)
+        wl[k] = orc.blocking_matrix(wq[k], 1) @ wa
+    out = np.stack([np.array(v) for v in gsc])
+    ref = orc.gsc_frames_halfband(X, wq, wl, normalize=True)
+    assert np.max(np.abs(out - ref)) < 2e-5 * np.max(np.abs(ref))
+    # generic sources: no symmetry between the bins, every bin as supplied
+    Mh, T = 64, 29
+    Xg = (rng.standard_normal((T, 4, Mh)) + 1j * rng.standard_normal((T, 4, Mh))) * 1000.0
+    wqh = orc.calc_mainlobe_halfband(Mh, 4, FS, delays)
+    g2 = B.SubbandGSCPtr(fftlen=Mh, half_band_shift=True)
+    for n in range(4):
+        g2.set_channel(B.PyVectorComplexFeatureStreamPtr(_Source(Xg[:, n, :])))
+    g2.calc_gsc_weights(FS, delays)
+    out = np.stack([np.array(v) for v in g2])
+    ref = orc.gsc_frames_halfband(Xg, wqh, np.zeros_like(wqh))
+    assert out.shape == ref.shape == (T, Mh) and np.max(np.abs(out - ref)) < 2e-5 * np.max(np.abs(ref))
+    # the classes that refuse it
+    with pytest.raises(B.jallocation_error):
+        B.SubbandMVDRPtr(fftlen=M, half_band_shift=True)
+    rls = B.SubbandGSCRLSPtr(fftlen=M, half_band_shift=True, mu=0.9)
+    for a in banks():
+        rls.set_channel(a)
+    rls.calc_gsc_weights(FS, delays)
+    rls.init_precision_matrix(0.01)
+    with pytest.raises(B.j_error):
+        rls.next()
+    pf = B.ZelinskiPostFilterPtr(g2, Mh, 0.7, 2)
+    pf.set_beamformer(g2)
+    with pytest.raises(B.j_error):
+        pf.next()
