@@ -134,7 +134,7 @@ class SubbandBeamformer : public VectorComplexFeatureStream {
   std::vector<float> Xhost_;      // lazily fetched host copy for snapshot_array()
 };
 
-class SubbandDS : public SubbandBeamformer {
+class SubbandDS : public SubbandBeamformer, public BlockSource {
  public:
   SubbandDS(unsigned fftLen = 512, bool halfBandShift = false, const String& nm = "SubbandDS");
   ~SubbandDS();
@@ -158,6 +158,10 @@ class SubbandDS : public SubbandBeamformer {
   virtual void effective_weights_all_bins(std::vector<float>& w);
   void alignment_vector(bool use_wq, std::vector<float>& d);
   unsigned long weights_version() const { return weights_version_; }
+  // BlockSource (modulated/modulated.h): the whole beamformed utterance for a batching consumer, weight changes mid-stream
+  virtual unsigned long block_version() { return weights_version_; }
+  virtual const std::vector<float>& block(long& T);
+  virtual void advance_to(long frame_idx);
  protected:
   void alloc_bfweight_(int NC);
   void compute_output_(long from_frame);
@@ -209,6 +213,7 @@ class SubbandGSCRLS : public SubbandGSC {
                 const String& nm = "SubbandGSCRLS");
   ~SubbandGSCRLS();
   virtual const gsl_vector_complex* next(int frame_no = -5);
+  virtual const std::vector<float>& block(long& T);          // the adaptive recursion of the whole utterance (not the static apply)
   void init_precision_matrix(float sigma2 = 0.01);
   void set_precision_matrix(unsigned fbinX, gsl_matrix_complex* Pz);
   void update_active_weight_vecotrs(bool flag) { is_wa_updated_ = flag; }   // sic (reference spelling)

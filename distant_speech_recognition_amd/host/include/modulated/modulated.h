@@ -3,6 +3,22 @@
 #pragma once
 #include <vector>
 #include "stream/stream.h"
+#include <vector>
+
+// Virtual-pull protocol between the engine's nodes (not part of the reference's interface, which stays in stream/stream.h).  A
+// reference node hands over one frame per next(); an engine node computes the whole utterance in one launch.  To keep the
+// per-frame MEANING when weights change between two next() calls (the moving look direction of
+// unit_test/test_online_beamforming.py:209-226), a consumer that batches -- the synthesis bank -- asks a producer that
+// implements this interface for its whole block instead of draining it through next(), tells it after every block it serves how
+// far a per-frame graph would have pulled (advance_to), and re-fetches the block when block_version() changes: the producer
+// recomputes only the frames beyond that mark with the new weights, everything already handed over keeps its value.
+class BlockSource {
+ public:
+  virtual ~BlockSource() {}
+  virtual unsigned long block_version() = 0;                 // changes whenever the frames not yet handed over may have changed
+  virtual const std::vector<float>& block(long& T) = 0;      // complex64 [>= K rows][T], row k = bin k, frames <= the mark unchanged
+  virtual void advance_to(long frame_idx) = 0;               // a per-frame graph would have pulled frames 0 .. frame_idx by now
+};
 #include "btkhip.h"
 
 class OverSampledDFTAnalysisBank : public VectorComplexFeatureStream {
@@ -47,6 +63,7 @@ class OverSampledDFTSynthesisBank : public VectorFloatFeatureStream {
   virtual void reset();
  private:
   void prepare_();
+  void synthesize_(const std::vector<float>& Yk, long T, long keep_blocks);
   VectorComplexFeatureStreamPtr samp_;
   unsigned M_, m_, r_, D_;
   int gain_;
@@ -54,5 +71,7 @@ class OverSampledDFTSynthesisBank : public VectorFloatFeatureStream {
   std::vector<float> blocks_;                           // [B][D]
   long nblocks_;
   bool prepared_;
+  BlockSource* bsrc_;                                   // samp_ seen as a block source (NULL: drained through next())
+  unsigned long src_version_;
 };
 typedef Inherit<OverSampledDFTSynthesisBank, VectorFloatFeatureStreamPtr> OverSampledDFTSynthesisBankPtr;

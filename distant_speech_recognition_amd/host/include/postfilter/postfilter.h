@@ -6,7 +6,7 @@
 typedef enum { TYPE_ZELINSKI1_REAL = 0x01, TYPE_ZELINSKI1_ABS = 0x02, TYPE_APAB = 0x04, TYPE_ZELINSKI2 = 0x08,
                NO_USE_POST_FILTER = 0x00 } PostfilterType;
 
-class ZelinskiPostFilter : public VectorComplexFeatureStream {
+class ZelinskiPostFilter : public VectorComplexFeatureStream, public BlockSource {
  public:
   ZelinskiPostFilter(VectorComplexFeatureStreamPtr& output, unsigned fftLen, double alpha = 0.6, int type = 2,
                      int minFrames = 0, const String& nm = "ZelinskPostFilter");
@@ -16,6 +16,10 @@ class ZelinskiPostFilter : public VectorComplexFeatureStream {
   void set_beamformer(SubbandDSPtr& beamformer);
   void setBeamformer(SubbandDSPtr& beamformer) { set_beamformer(beamformer); }
   const gsl_vector_complex* postfilter_weights();
+  // BlockSource: see modulated/modulated.h
+  virtual unsigned long block_version() { return has_bf_ptr_ ? bf_ptr_->weights_version() : 0; }
+  virtual const std::vector<float>& block(long& T);
+  virtual void advance_to(long frame_idx);
  protected:
   virtual void compute_(long from_frame);
   void merge_output_(std::vector<float>& Ynew, long from_frame);

@@ -270,7 +270,7 @@ OverSampledDFTSynthesisBank::OverSampledDFTSynthesisBank(VectorComplexFeatureStr
                                                          unsigned m, unsigned r, unsigned delayCompensationType, int gainFactor,
                                                          const String& nm)
     : VectorFloatFeatureStream(M >> r, nm), samp_(samp), M_(M), m_(m), r_(r), D_(M >> r), gain_(gainFactor), plan_(NULL),
-      nblocks_(0), prepared_(false)
+      nblocks_(0), prepared_(false), bsrc_(NULL), src_version_(0)
 {
   if (prototype->size != (size_t)M * m)
     throw jconsistency_error("Prototype sizes do not match (%d vs. %d).", (int)prototype->size, (int)(M * m));
@@ -281,39 +281,61 @@ OverSampledDFTSynthesisBank::OverSampledDFTSynthesisBank(VectorComplexFeatureStr
 
 OverSampledDFTSynthesisBank::~OverSampledDFTSynthesisBank() { btk_fb_destroy(plan_); }
 
-void OverSampledDFTSynthesisBank::prepare_()
+// Yk complex64 [>= K rows][T] -> blocks_; the first keep_blocks blocks (already handed over) keep their values
+void OverSampledDFTSynthesisBank::synthesize_(const std::vector<float>& Yk, long T, long keep_blocks)
 {
   const unsigned K = M_ / 2 + 1;
-  std::vector<float> fr;                       // [T][K]
-  const long T = drain_complex(samp_, M_, fr);
+  std::vector<float> old;
+  if (keep_blocks > 0) old.assign(blocks_.begin(), blocks_.begin() + (size_t)std::min<long>(keep_blocks, nblocks_) * D_);
   nblocks_ = btk_fb_synthesis_num_blocks(plan_, T);
   blocks_.assign((size_t)nblocks_ * D_, 0.f);
   if (nblocks_ > 0) {
-    std::vector<float> Yk((size_t)2 * K * T);  // [K][T]
-    for (long t = 0; t < T; t++)
-      for (unsigned k = 0; k < K; k++) {
-        Yk[2 * ((size_t)k * T + t)] = fr[2 * ((size_t)t * K + k)];
-        Yk[2 * ((size_t)k * T + t) + 1] = fr[2 * ((size_t)t * K + k) + 1];
-      }
-    void* dY = dev_alloc(sizeof(float) * Yk.size());
+    void* dY = dev_alloc(sizeof(float) * 2 * K * T);
     void* dO = dev_alloc(sizeof(float) * blocks_.size());
-    h2d(dY, Yk.data(), sizeof(float) * Yk.size());
+    h2d(dY, Yk.data(), sizeof(float) * 2 * K * T);
     check_abi(btk_fb_synthesis(plan_, dY, T, T, 1, (float*)dO, nblocks_ * D_, 0, nblocks_, NULL));
     check_abi(btk_synchronize(NULL));
     d2h(blocks_.data(), dO, sizeof(float) * blocks_.size());
     dev_free(dY); dev_free(dO);
     if (gain_ > 1) for (size_t i = 0; i < blocks_.size(); i++) blocks_[i] *= (float)gain_;
   }
+  if (!old.empty()) memcpy(blocks_.data(), old.data(), sizeof(float) * std::min(old.size(), blocks_.size()));
+}
+
+void OverSampledDFTSynthesisBank::prepare_()
+{
+  const unsigned K = M_ / 2 + 1;
+  bsrc_ = dynamic_cast<BlockSource*>(samp_.operator->());
+  if (bsrc_) {
+    // an engine node upstream: take its whole block (it is not advanced), keep what was already served; next() tells it after
+    // every block how far a per-frame graph would have pulled, so that a later weight change touches only the frames beyond
+    long T = 0;
+    const std::vector<float>& Yk = bsrc_->block(T);
+    src_version_ = bsrc_->block_version();
+    synthesize_(Yk, T, frame_no_ + 1);
+  } else {
+    std::vector<float> fr;                       // [T][K]
+    const long T = drain_complex(samp_, M_, fr);
+    std::vector<float> Yk((size_t)2 * K * T);    // [K][T]
+    for (long t = 0; t < T; t++)
+      for (unsigned k = 0; k < K; k++) {
+        Yk[2 * ((size_t)k * T + t)] = fr[2 * ((size_t)t * K + k)];
+        Yk[2 * ((size_t)k * T + t) + 1] = fr[2 * ((size_t)t * K + k) + 1];
+      }
+    synthesize_(Yk, T, 0);
+  }
   prepared_ = true;
 }
 
 const gsl_vector_float* OverSampledDFTSynthesisBank::next(int frame_no)
 {
-  if (!prepared_) prepare_();
+  if (!prepared_ || (bsrc_ && bsrc_->block_version() != src_version_)) prepare_();
   const long idx = frame_no_ + 1;
   if (idx >= nblocks_) { is_end_ = true; throw jiterator_error("end of samples!"); }
   memcpy(vector_->data, blocks_.data() + (size_t)idx * D_, sizeof(float) * D_);
   increment_();
+  // block idx of a per-frame graph has pulled the frames 0 .. pd + idx (the priming of modulated.cc:574-578 included)
+  if (bsrc_) bsrc_->advance_to((long)btk_fb_processing_delay(plan_) + idx);
   return vector_;
 }
 
@@ -321,7 +343,7 @@ void OverSampledDFTSynthesisBank::reset()
 {
   samp_->reset();
   VectorFloatFeatureStream::reset();
-  prepared_ = false; blocks_.clear(); nblocks_ = 0;
+  prepared_ = false; blocks_.clear(); nblocks_ = 0; bsrc_ = NULL; src_version_ = 0;
 }
 
 // ================================================================================ SnapShotArray
@@ -833,6 +855,21 @@ const gsl_vector_complex* SubbandDS::next(int frame_no)
 
 void SubbandDS::reset() { SubbandBeamformer::reset(); Yhost_.clear(); }
 
+const std::vector<float>& SubbandDS::block(long& T)
+{
+  if (!bfweight_) throw j_error("%s", need_weights_msg_());
+  if (Yhost_.empty() || output_version_ != weights_version_) compute_output_(frame_no_ + 1);
+  T = T_;
+  return Yhost_;
+}
+
+void SubbandDS::advance_to(long frame_idx)
+{
+  // frames 0 .. frame_idx count as handed over: a weight change from now on recomputes only the frames beyond
+  if (frame_idx >= T_) frame_idx = T_ - 1;
+  if (frame_idx > frame_no_) frame_no_ = (int)frame_idx;
+}
+
 // ================================================================================ SubbandGSC
 void SubbandGSC::calc_gsc_weights(float samplerate, const gsl_vector* delaysT)
 {
@@ -1216,6 +1253,21 @@ const gsl_vector_complex* ZelinskiPostFilter::next(int frame_no)
   return vector_;
 }
 
+const std::vector<float>& ZelinskiPostFilter::block(long& T)
+{
+  if (!has_bf_ptr_) throw j_error("set beamformer's weights \n");
+  if (!prepared_ || bf_version_ != bf_ptr_->weights_version()) compute_(frame_no_ + 1);
+  T = T_;
+  return Yhost_;
+}
+
+void ZelinskiPostFilter::advance_to(long frame_idx)
+{
+  if (frame_idx >= T_) frame_idx = T_ - 1;
+  if (frame_idx > frame_no_) frame_no_ = (int)frame_idx;
+  if (has_bf_ptr_) bf_ptr_->advance_to(frame_idx);
+}
+
 const gsl_vector_complex* ZelinskiPostFilter::postfilter_weights()
 {
   if (!dWl_) return NULL;
@@ -1528,6 +1580,16 @@ void SubbandGSCRLS::run_block_()
     }
   }
   output_version_ = weights_version_;
+}
+
+const std::vector<float>& SubbandGSCRLS::block(long& T)
+{
+  if (!bfweight_) throw j_error("call calc_gsc_weights_x() once\n");
+  if (!have_P_) throw j_error("set the precision matrix with init_precision_matrix() or set_precision_matrix()\n");
+  if (halfBandShift_) throw j_error("halfBandShift==true is not yet supported\n");
+  if (Yhost_.empty()) run_block_();
+  T = T_;
+  return Yhost_;
 }
 
 const gsl_vector_complex* SubbandGSCRLS::next(int frame_no)

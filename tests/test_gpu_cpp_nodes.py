@@ -285,3 +285,75 @@ def test_write_fir_coeff_matches_reference_formula(orc, dev, tmp_path, proto256,
                 val[M - k] = np.conj(v)
         want[c] = win * np.real(np.fft.ifft(val))                              # gsl_fft_complex_radix2_inverse: e^{+j}, 1/M
     assert got.shape == want.shape and np.max(np.abs(got - want)) < 1e-6 * np.max(np.abs(want)) + 1e-12
+
+
+def test_moving_look_direction_through_cpp_nodes(orc, dev, proto256, kinect_pcm, tmp_path):
+    """The look direction changes between two output blocks (unit_test/test_online_beamforming.py:209-226) with C++ nodes only:
+    frames the synthesis bank of a per-frame graph had already pulled (pd + block + 1, modulated.cc:574-578) keep the old weights,
+    later frames use the new ones -- the BlockSource protocol between the engine's batching nodes (modulated/modulated.h)."""
+    import wave
+    from distant_speech_recognition_amd import btk20cpp as B
+    from distant_speech_recognition_amd.pybeamformer import calc_delays
+    M, m, r, D, FS = 256, 4, 1, 128, 16000
+    MPOS = [[-113.0, 0.0, 2.0], [36.0, 0.0, 2.0], [76.0, 0.0, 2.0], [113.0, 0.0, 2.0]]
+    h, g = proto256
+    L = 40000
+
+    def graph(with_pf):
+        afbs = []
+        for c in range(4):
+            p = str(tmp_path / ("m%d.wav" % c))
+            w = wave.open(p, "wb")
+            w.setnchannels(1); w.setsampwidth(2); w.setframerate(FS)
+            w.writeframes(kinect_pcm[c][:L].astype(np.int16).tobytes())
+            w.close()
+            sf = B.SampleFeaturePtr(block_len=D, shift_len=D, pad_zeros=True)
+            sf.read(p, FS)
+            afbs.append(B.OverSampledDFTAnalysisBankPtr(sf, prototype=h, M=M, m=m, r=r, delay_compensation_type=2))
+        bf = B.SubbandDSPtr(fftlen=M)
+        for a in afbs:
+            bf.set_channel(a)
+        top = bf
+        if with_pf:
+            top = B.ZelinskiPostFilterPtr(bf, M, 0.7, 2)
+            top.set_beamformer(bf)
+        return bf, B.OverSampledDFTSynthesisBankPtr(top, prototype=g, M=M, m=m, r=r, delay_compensation_type=2)
+
+    dA = calc_delays("linear", MPOS, [-1.306379, None, None])
+    dB = calc_delays("linear", MPOS, [0.4, None, None])
+    b_switch, pd_syn = 60, 4
+    bf, sfb = graph(False)
+    bf.calc_array_manifold_vectors(FS, dA)
+    blocks = []
+    for b in range(b_switch + 1):
+        blocks.append(np.array(sfb.next()))
+    bf.calc_array_manifold_vectors(FS, dB)                              # between block b_switch and b_switch + 1
+    while True:
+        try:
+            blocks.append(np.array(sfb.next()))
+        except StopIteration:
+            break
+    out = np.concatenate(blocks)
+    X = np.stack([orc.analysis(h, M, m, r, 2, kinect_pcm[c][:L]) for c in range(4)], axis=1)
+    wa, wb = orc.calc_mainlobe(M, 4, FS, dA), orc.calc_mainlobe(M, 4, FS, dB)
+    Ya, Yb = orc.gsc_frames(X, wa, np.zeros_like(wa)), orc.gsc_frames(X, wb, np.zeros_like(wb))
+    n_old = pd_syn + b_switch + 1
+    ref = orc.synthesis(g, M, m, r, 2, np.concatenate([Ya[:n_old], Yb[n_old:]]))
+    assert out.shape == ref.shape and np.max(np.abs(out - ref)) < 0.5
+    assert np.max(np.abs(orc.synthesis(g, M, m, r, 2, Ya) - ref)) > 5.0          # the switch is visible in the expectation itself
+    # with a post-filter between beamformer and synthesis: the blocks before the switch equal the static run bit for bit
+    bf2, sfb2 = graph(True)
+    bf2.calc_array_manifold_vectors(FS, dA)
+    stat = np.concatenate([np.array(v) for v in sfb2])
+    bf3, sfb3 = graph(True)
+    bf3.calc_array_manifold_vectors(FS, dA)
+    mv = [np.array(sfb3.next()) for _ in range(b_switch + 1)]
+    bf3.calc_array_manifold_vectors(FS, dB)
+    while True:
+        try:
+            mv.append(np.array(sfb3.next()))
+        except StopIteration:
+            break
+    mv = np.concatenate(mv)
+    nb = (b_switch + 1) * D
+    assert mv.shape == stat.shape and np.array_equal(mv[:nb], stat[:nb]) and np.max(np.abs(mv[nb:] - stat[nb:])) > 5.0
