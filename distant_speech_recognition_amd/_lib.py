@@ -61,6 +61,8 @@ SIGNATURES = {
     "btk_rls_workspace_bytes": (_l, [_i, _l]),
     "btk_rls_init": (_i, [_i, _vp, _i, _d, _i, _i, _i, _vp, _vp, _vp]),
     "btk_rls_process": (_i, [_i, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _l, _l, _vp, _vp, _vp, _vp, _vp]),
+    "btk_rls_init_nc": (_i, [_i, _vp, _i, _vp, _i, _d, _i, _i, _i, _vp, _vp, _vp]),
+    "btk_rls_process_nc": (_i, [_i, _vp, _vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _l, _l, _vp, _vp, _vp, _vp, _vp]),
     "btk_bf_apply_stats": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _l, _l, _vp]),
     "btk_zelinski_process": (_i, [_vp, _vp, _vp, _i, _i, _i, _l, _l, _d, _i, _i, _l, _vp, _vp, _vp, _vp]),
     "btk_pf_coherence_coeffs": (_i, [_vp, _f, _i, _i, _vp, _vp, _vp]),

@@ -489,12 +489,10 @@ class SubbandGSCRLSPtr(SubbandGSCPtr):
         X = self.device_snapshots()
         bw = self._bfw[0]
         K, N = self._K, self.chan_num()
-        if bw.NC != 1:
-            raise jdimension_error("the GPU RLS canceller supports NC = 1 constraint (got %d)\n" % bw.NC)
         try:
             if self._rls is None:
                 wq = torch.from_numpy(np.ascontiguousarray(bw.wq[:K]).astype(np.complex128)).to(device())
-                self._rls = engine.RLSState(0, 1, self._fftlen, N, wq)
+                self._rls = engine.RLSState(0, 1, self._fftlen, N, wq, Nc=bw.NC)      # NC > 1: after calc_gsc_weights_2 / _n
                 self._rls.init_precision_matrix(self._p0)
                 if self._Pz_user or np.any(bw.wl[:K] != 0):
                     P = self._rls.P.cpu().numpy()

@@ -111,10 +111,11 @@ void rls_control_kernel(const float* __restrict__ energy, long T, double beta, d
 
 // P = p0 (I - v v^H / |v|^2) (mode 1) or p0 (I - conj(v) v^T / |v|^2) (mode 0), w = 0
 __global__ void rls_init_kernel(const zd* __restrict__ V, int per_stream, int conj_v, double p0, int K, int N,
-                                zd* __restrict__ P, zd* __restrict__ Wst)
+                                zd* __restrict__ P, zd* __restrict__ Wst, const zd* __restrict__ CX, int NC)
 {
   const int k = blockIdx.x, s = blockIdx.y;
   const zd* v = V + ((long)(per_stream ? s : 0) * K + k) * N;
+  const zd* cx = (NC > 1) ? CX + ((long)(per_stream ? s : 0) * K + k) * (NC - 1) * N : nullptr;
   double vv = 0.0;
   for (int i = 0; i < N; i++) vv += v[i].x * v[i].x + v[i].y * v[i].y;
   const double iv = vv > 0.0 ? 1.0 / vv : 0.0;
@@ -122,6 +123,7 @@ __global__ void rls_init_kernel(const zd* __restrict__ V, int per_stream, int co
   for (int e = threadIdx.x; e < N * N; e += blockDim.x) {
     const int i = e / N, j = e % N;
     zd q = zscale(conj_v ? zmul(zconj(v[i]), v[j]) : zmul(v[i], zconj(v[j])), -iv);
+    for (int d = 0; d + 1 < NC; d++) q = zsub(q, zmul(cx[d * N + i], zconj(cx[d * N + j])));     // further blocked directions (NC > 1)
     if (i == j) q.x += 1.0;
     Pk[e] = zscale(q, p0);
   }
@@ -417,6 +419,286 @@ int launch_rls(const float2* X, const zd* V, int per_stream, float2* Y, int S, i
 }
 
 
+
+// ------------------------------------------------------------------------------------------------
+// Round 3: more than 64 channels, and more than one constraint (SubbandGSCRLSBeamformer(..., Nc), lib/pybeamformer.py:784-797; the
+// C++ SubbandGSCRLS after calc_gsc_weights_2 / _n).  One 256-thread workgroup per (stream, bin); P lives in LDS as the PACKED lower
+// triangle of a Hermitian matrix (N (N + 1) / 2 complex128: 81 KB at N = 100, 132 KB at N = 128).  The recursion keeps P Hermitian
+// in exact arithmetic -- x^H P = (P x)^H and the gain denominator mu + x^H P x is real -- so one matrix-vector product a = P x per
+// frame serves both sides of the reference's update and P <- (P - a a^H / den) / mu touches every stored entry once (the register
+// kernel above carries row AND column copies and reproduces the reference's two products separately; the two agree to rounding).
+// With NC > 1 constraints the blocking matrix spans the complement of conj(v) AND of NC - 1 further orthonormal directions c_j
+// (btk_nlms_constraint_vectors, as in the NLMS canceller): conj(B) B^T = I - v v^H / |v|^2 - sum_j c_j c_j^H is the initial
+// projector, the projector of the norm-reset branch, and what the per-tile leak removal projects with, direction by direction.
+struct RlsLds {
+  zd* P;        // packed lower triangle: (i, j <= i) at i (i + 1) / 2 + j
+  zd *xv, *av, *wv, *nv, *vv, *dv, *cx;      // [N] each (dv: the blocked direction, v in mode 1, conj(v) in mode 0), cx [NC-1][N]
+  double* red;  // [4 waves][8]
+  float2* xt;   // [2][N][RLD]
+};
+
+__device__ __forceinline__ zd pk_get(const zd* P, int i, int j) { return (j <= i) ? P[i * (i + 1) / 2 + j] : zconj(P[j * (j + 1) / 2 + i]); }
+
+// sums of up to 6 doubles over the 256 threads; every thread gets the totals (two barriers)
+template <int NV>
+__device__ __forceinline__ void block_sums(double (&v)[NV], double* red)
+{
+  const int tid = threadIdx.x;
+#pragma unroll
+  for (int q = 0; q < NV; q++) {
+    double x = v[q];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o, 64);
+    if ((tid & 63) == 0) red[(tid >> 6) * 8 + q] = x;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < NV; q++) v[q] = red[q] + red[8 + q] + red[16 + q] + red[24 + q];
+  __syncthreads();
+}
+
+// out_i = sum_j P_ij in_j (CONJ_IN: in_j conjugated), Hermitian packed; two lanes per row (even / odd j), N <= 128
+template <bool CONJ_IN>
+__device__ __forceinline__ void pk_matvec(const zd* P, const zd* in, zd* out, int N)
+{
+  const int tid = threadIdx.x, i = tid >> 1, h = tid & 1;
+  zd acc = zmk(0.0, 0.0);
+  if (i < N) {
+    for (int j = h; j < N; j += 2) {
+      const zd pij = pk_get(P, i, j);
+      acc = zfma(pij, CONJ_IN ? zconj(in[j]) : in[j], acc);
+    }
+  }
+  acc.x += __shfl_xor(acc.x, 1, 64); acc.y += __shfl_xor(acc.y, 1, 64);
+  if (i < N && h == 0) out[i] = acc;
+  __syncthreads();
+}
+
+// P <- sc (P - g a^H)  on the stored triangle (g = a den_inv with a real den_inv keeps it Hermitian); two lanes per row
+__device__ __forceinline__ void pk_rank1(zd* P, const zd* a, double den_inv, double sc, int N)
+{
+  const int tid = threadIdx.x, i = tid >> 1, h = tid & 1;
+  if (i < N) {
+    const zd gi = zscale(a[i], den_inv);
+    zd* row = P + i * (i + 1) / 2;
+    for (int j = h; j <= i; j += 2) {
+      zd e = zscale(zsub(row[j], zmul(gi, zconj(a[j]))), sc);
+      // the diagonal of a Hermitian matrix is real: an imaginary rounding residue there is divided by mu every frame and nothing
+      // in the recursion damps it (0.97^-1200 = 7e15: it reached O(1) after 1 200 frames before this line existed)
+      if (j == i) e.y = 0.0;
+      row[j] = e;
+    }
+  }
+  __syncthreads();
+}
+
+// P <- p0 (I - sum_d n_d n_d^H) with the orthonormal directions n_0 = vdir / |vdir| and c_j
+__device__ __forceinline__ void pk_set_projector(zd* P, const zd* vdir, double inv_vv, const zd* cx, int NC, double p0, int N)
+{
+  const int tid = threadIdx.x, i = tid >> 1, h = tid & 1;
+  if (i < N) {
+    zd* row = P + i * (i + 1) / 2;
+    for (int j = h; j <= i; j += 2) {
+      zd q = zscale(zmul(vdir[i], zconj(vdir[j])), -inv_vv);
+      for (int d = 0; d + 1 < NC; d++) q = zsub(q, zmul(cx[d * N + i], zconj(cx[d * N + j])));
+      if (i == j) { q.x += 1.0; q.y = 0.0; }
+      row[j] = zscale(q, p0);
+    }
+  }
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(256)
+void rls_packed_kernel(const float2* __restrict__ X, const zd* __restrict__ V, int per_stream, const zd* __restrict__ CX, int NC,
+                       float2* __restrict__ Y, int K, int N, long T_stride, long T, const float* __restrict__ ctrl,
+                       const double* __restrict__ state_before, RlsParams p, zd* __restrict__ Pst, zd* __restrict__ Wst,
+                       int rtb /* frames per snapshot tile: 16, double-buffered; 8, single buffer, when the LDS is short (N > 112) */)
+{
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int s = blockIdx.y, k = blockIdx.x;
+  const int rld = rtb + 1, nbuf = rtb == RTB ? 2 : 1;
+  const long sk = (long)s * K + k;
+  const int NP = N * (N + 1) / 2;
+  RlsLds L;
+  L.P = reinterpret_cast<zd*>(smem);
+  L.xv = L.P + NP; L.av = L.xv + N; L.wv = L.av + N; L.nv = L.wv + N; L.vv = L.nv + N; L.dv = L.vv + N; L.cx = L.dv + N;
+  L.red = reinterpret_cast<double*>(L.cx + (NC > 1 ? (NC - 1) * N : 0));
+  L.xt = reinterpret_cast<float2*>(L.red + 32);
+  float2* yout = L.xt + nbuf * N * rld;
+  const zd* v = V + ((long)(per_stream ? s : 0) * K + k) * N;
+  zd* Pk = Pst + sk * N * N;
+  zd* wk = Wst + sk * N;
+  const float2* xk = X + sk * N * T_stride;
+
+  for (int e = tid; e < NP; e += 256) {                     // lower triangle of the exported [N][N] state
+    int i = (int)((sqrt(8.0 * e + 1.0) - 1.0) * 0.5);
+    while (i * (i + 1) / 2 > e) i--;
+    while ((i + 1) * (i + 2) / 2 <= e) i++;
+    const int j = e - i * (i + 1) / 2;
+    L.P[e] = Pk[(long)i * N + j];
+    if (i == j) L.P[e].y = 0.0;
+  }
+  // v as it enters the projector: mode 1 v = vs; mode 0 the blocked direction is conj(wq)
+  for (int n = tid; n < N; n += 256) { L.vv[n] = v[n]; L.dv[n] = (p.mode == 0) ? zconj(v[n]) : v[n]; L.wv[n] = wk[n]; }
+  for (int e = tid; e < (NC - 1) * N; e += 256) L.cx[e] = CX[((long)(per_stream ? s : 0) * K + k) * (NC - 1) * N + e];
+  __syncthreads();
+  double vs2[1] = {0.0};
+  for (int n = tid; n < N; n += 256) vs2[0] += L.vv[n].x * L.vv[n].x + L.vv[n].y * L.vv[n].y;
+  block_sums<1>(vs2, L.red);
+  const double inv_vv = vs2[0] > 0.0 ? 1.0 / vs2[0] : 0.0;
+  // the direction the projector removes, as a vector in LDS: mode 1 vs, mode 0 conj(wq); kept in nv during the leak step only
+  const long isamp0 = (long)state_before[4 * s + 2];
+  const double inv_mu = 1.0 / p.mu;
+  const bool commit = (p.mode == 1) || k > 0;               // beamformer.cc:1589 starts at bin 1
+
+  auto stage = [&](int buf, long t0) {
+    for (int e = tid; e < N * rtb; e += 256) {
+      const int n = e / rtb, f = e % rtb;
+      const long t = t0 + f;
+      L.xt[(buf * N + n) * rld + f] = (t < T) ? xk[(long)n * T_stride + t] : make_float2(0.f, 0.f);
+    }
+  };
+  if (nbuf == 2) stage(0, 0);
+  __syncthreads();
+  int buf = 0;
+  for (long t0 = 0; t0 < T; t0 += rtb, buf = (nbuf == 2) ? buf ^ 1 : 0) {
+    if (nbuf == 2) { if (t0 + rtb < T) stage(buf ^ 1, t0 + rtb); }      // the other buffer: last read a tile ago
+    else { stage(0, t0); __syncthreads(); }                                 // one buffer: the previous tile ended with a barrier
+    const int nt = (T - t0 < rtb) ? (int)(T - t0) : rtb;
+    for (int tt = 0; tt < nt; tt++) {
+      const bool adapt = (p.mode == 0) ? (p.update != 0) : (ctrl[(long)s * T + t0 + tt] != 0.f);
+      for (int n = tid; n < N; n += 256) { const float2 xf = L.xt[(buf * N + n) * rld + tt]; L.xv[n] = zmk((double)xf.x, (double)xf.y); }
+      __syncthreads();
+      // Yc = v^H x, canceller output with the current weights, |v - w|^2 (mode 0 normalisation)
+      double r5[5] = {0, 0, 0, 0, 0};
+      for (int n = tid; n < N; n += 256) {
+        const zd x = L.xv[n], vq = L.vv[n], wq = L.wv[n];
+        const zd a = zfmac(vq, x, zmk(0, 0));
+        const zd b = (p.mode == 1) ? zfma(wq, x, zmk(0, 0)) : zfmac(wq, x, zmk(0, 0));
+        const zd d = zsub(vq, wq);
+        r5[0] += a.x; r5[1] += a.y; r5[2] += b.x; r5[3] += b.y; r5[4] += d.x * d.x + d.y * d.y;
+      }
+      block_sums<5>(r5, L.red);
+      const zd Yc = zmk(r5[0], r5[1]);
+      zd Wx = zmk(r5[2], r5[3]);
+      zd y;
+      if (p.mode == 0) {
+        y = (k == 0) ? Yc : zsub(Yc, Wx);                                    // beamformer.cc:1540-1558
+        if (p.normalize && k > 0) y = zscale(y, 1.0 / (sqrt(r5[4]) * (double)N));   // calc_gsc_output :1229-1237
+      } else {
+        y = Yc;
+      }
+      if (adapt) {                                                           // (workgroup-uniform)
+        pk_matvec<false>(L.P, L.xv, L.av, N);                                // a = P x;  x^H P = a^H
+        double ipr[1] = {0.0};
+        for (int n = tid; n < N; n += 256) { const zd x = L.xv[n], a = L.av[n]; ipr[0] += x.x * a.x + x.y * a.y; }   // Re(x^H a)
+        block_sums<1>(ipr, L.red);
+        // mode 1: g = a / (mu + x^H P x) (pybeamformer.py:840); mode 0: g = a / (mu (1 + x^H P x / mu)) (beamformer.cc:1598-1606)
+        double den_inv = 1.0 / (p.mu + ipr[0]);
+        if (!commit) den_inv = 0.0;
+        pk_rank1(L.P, L.av, den_inv, commit ? inv_mu : 1.0, N);              // P <- (P - g a^H) / mu
+        // regularisation mat-vec with the OLD weights and the NEW P: mode 0 (P wl), mode 1 (P conj(u))
+        const bool need_rr = (p.mode == 1) ? (p.reg > 0.0) : (p.diag_w != 0.0);
+        if (need_rr) { if (p.mode == 1) pk_matvec<true>(L.P, L.wv, L.nv, N); else pk_matvec<false>(L.P, L.wv, L.nv, N); }
+        double n2s[1] = {0.0};
+        for (int n = tid; n < N; n += 256) {
+          const zd g = zscale(L.av[n], den_inv), w_n = L.wv[n];
+          const zd rr = need_rr ? L.nv[n] : zmk(0.0, 0.0);
+          zd wn;
+          if (p.mode == 1) {
+            const zd ep = zsub(Yc, Wx);                                      // :845
+            wn = zadd(w_n, zmul(zscale(zconj(g), p.gamma), ep));             // :846
+            if (p.reg > 0.0) wn = zsub(wn, zscale(zconj(rr), p.reg));        // :848-849
+          } else {
+            wn = zadd(zsub(w_n, zscale(rr, p.diag_w)), zmul(g, zconj(y)));   // :1620-1630
+          }
+          L.xv[n] = wn;                                                      // x is dead from here on: xv holds the candidate
+          n2s[0] += wn.x * wn.x + wn.y * wn.y;
+        }
+        __syncthreads();                                                     // (nv was read above, xv written: order both)
+        block_sums<1>(n2s, L.red);
+        double n2 = n2s[0];
+        double scale_w = 1.0;
+        if (p.mode == 0) {
+          if (p.qctype == 1 || (p.qctype == 2 && n2 >= p.alpha)) scale_w = p.alpha / sqrt(n2);       // :1631-1641
+        } else if (p.copt > 0) {
+          const bool quad = (p.copt == 1 || p.copt == 3) && n2 > p.alpha2;   // :853-866
+          if (quad) {
+            pk_matvec<true>(L.P, L.xv, L.nv, N);                             // va = P conj(waHK)
+            double q2[2] = {0.0, 0.0};
+            for (int n = tid; n < N; n += 256) {
+              const zd va = L.nv[n], nq = L.xv[n];
+              q2[0] += va.x * va.x + va.y * va.y;
+              q2[1] += va.x * nq.x - va.y * nq.y;                            // Re(conj(va) . waK), waK = conj(waHK)
+            }
+            block_sums<2>(q2, L.red);
+            const double a = q2[0], b = -2.0 * q2[1], cq = n2 - p.alpha2;
+            const double arg = b * b - 4.0 * a * cq;
+            const double betaK = (arg > 0.0) ? -(b + sqrt(arg)) / (2.0 * a) : -b / (2.0 * a);
+            for (int n = tid; n < N; n += 256) L.xv[n] = zsub(L.xv[n], zscale(zconj(L.nv[n]), betaK));
+            __syncthreads();
+          }
+          if (p.copt >= 2 && n2 > p.max_norm) {                              // :867-870 (n2 of the unconstrained candidate)
+            scale_w = sqrt(p.max_norm / n2);
+            pk_set_projector(L.P, L.dv, inv_vv, L.cx, NC, 1.0 / p.init_load, N);
+          }
+        }
+        if (commit) for (int n = tid; n < N; n += 256) L.wv[n] = zscale(L.xv[n], scale_w);
+        __syncthreads();
+        if (p.mode == 1) {                                                   // output with the updated weights
+          for (int n = tid; n < N; n += 256) { const float2 xf = L.xt[(buf * N + n) * rld + tt]; L.xv[n] = zmk((double)xf.x, (double)xf.y); }
+          __syncthreads();
+          double w2[2] = {0.0, 0.0};
+          for (int n = tid; n < N; n += 256) { const zd t = zfma(L.wv[n], L.xv[n], zmk(0, 0)); w2[0] += t.x; w2[1] += t.y; }
+          block_sums<2>(w2, L.red);
+          Wx = zmk(w2[0], w2[1]);
+        }
+      }
+      if (p.mode == 1 && isamp0 + t0 + tt >= p.min_frames) y = zsub(Yc, Wx);   // pybeamformer.py:894-897
+      if (tid == 0) yout[tt] = make_float2((float)y.x, (float)y.y);
+      __syncthreads();
+    }
+    if (tid < nt) Y[sk * T_stride + t0 + tid] = yout[tid];
+    // ---- once per tile: P <- Q P Q, Q = I - n n^H for every blocked direction n (v / |v| resp. conj(wq) / |wq|, then the c_j):
+    // in exact arithmetic P n = 0 for ever; in floating point that component is multiplied by 1 / mu per frame
+    for (int d = 0; d < NC; d++) {
+      for (int n = tid; n < N; n += 256) {
+        L.xv[n] = (d == 0) ? zscale(L.dv[n], sqrt(inv_vv)) : L.cx[(d - 1) * N + n];
+      }
+      __syncthreads();
+      pk_matvec<false>(L.P, L.xv, L.av, N);                                  // a = P n
+      double sv[1] = {0.0};
+      for (int n = tid; n < N; n += 256) { const zd nd = L.xv[n], a = L.av[n]; sv[0] += nd.x * a.x + nd.y * a.y; }   // n^H P n (real)
+      block_sums<1>(sv, L.red);
+      const int i = tid >> 1, h = tid & 1;
+      if (i < N) {
+        zd* row = L.P + i * (i + 1) / 2;
+        const zd ai = L.av[i], ni = L.xv[i];
+        for (int j = h; j <= i; j += 2) {
+          const zd aj = L.av[j], nj = L.xv[j];
+          zd dlt = zadd(zmul(ai, zconj(nj)), zmul(ni, zconj(aj)));
+          dlt = zsub(dlt, zscale(zmul(ni, zconj(nj)), sv[0]));
+          zd e = zsub(row[j], dlt);
+          if (j == i) e.y = 0.0;                                              // (see pk_rank1)
+          row[j] = e;
+        }
+      }
+      __syncthreads();
+    }
+  }
+  // export: both triangles of P [N][N], w [N]
+  for (int e = tid; e < N * N; e += 256) { const int i = e / N, j = e % N; Pk[e] = pk_get(L.P, i, j); }
+  for (int n = tid; n < N; n += 256) wk[n] = L.wv[n];
+}
+
+inline size_t rls_packed_lds(int N, int NC, int rtb)
+{
+  return sizeof(zd) * ((size_t)N * (N + 1) / 2 + 6 * (size_t)N + (size_t)(NC > 1 ? NC - 1 : 0) * N) + sizeof(double) * 32 +
+         sizeof(float2) * ((rtb == RTB ? 2 : 1) * (size_t)N * (rtb + 1) + RTB);
+}
+inline int rls_packed_rtb(int N, int NC) { return rls_packed_lds(N, NC, RTB) <= 160 * 1024 - 256 ? RTB : 8; }
+
 }  // namespace
 
 extern "C" {
@@ -426,28 +708,47 @@ long btk_rls_workspace_bytes(int S, long T)
   return (long)sizeof(float) * 2 * S * T + (long)sizeof(double) * 4 * S + 64;
 }
 
-int btk_rls_init(int mode, const void* v, int per_stream, double p0, int S, int K, int N, void* P_state, void* w_state,
-                 void* stream)
+int btk_rls_init_nc(int mode, const void* v, int per_stream, const void* cx, int NC, double p0, int S, int K, int N, void* P_state,
+                    void* w_state, void* stream)
 {
   if (mode != 0 && mode != 1) return btk_set_error(BTK_ERR_PARAMETER, "btk_rls_init: mode must be 0 or 1");
   if (!v || !P_state || !w_state) return btk_set_error(BTK_ERR_PARAMETER, "btk_rls_init: null argument");
   if (S <= 0 || K <= 0 || N < 2) return btk_set_error(BTK_ERR_DIMENSION, "btk_rls_init: bad sizes S=%d K=%d N=%d", S, K, N);
+  if (NC < 1 || NC >= N || (NC > 1 && !cx)) return btk_set_error(BTK_ERR_DIMENSION, "btk_rls_init: NC=%d constraints with N=%d channels", NC, N);
   hipLaunchKernelGGL(rls_init_kernel, dim3((unsigned)K, (unsigned)S), dim3(256), 0, as_stream(stream),
-                     static_cast<const zd*>(v), per_stream, mode == 0 ? 1 : 0, p0, K, N, static_cast<zd*>(P_state), static_cast<zd*>(w_state));
+                     static_cast<const zd*>(v), per_stream, mode == 0 ? 1 : 0, p0, K, N, static_cast<zd*>(P_state), static_cast<zd*>(w_state),
+                     static_cast<const zd*>(cx), NC);
   BTK_HIP_CHECK(hipGetLastError());
   return BTK_OK;
+}
+
+int btk_rls_init(int mode, const void* v, int per_stream, double p0, int S, int K, int N, void* P_state, void* w_state,
+                 void* stream)
+{
+  return btk_rls_init_nc(mode, v, per_stream, nullptr, 1, p0, S, K, N, P_state, w_state, stream);
 }
 
 int btk_rls_process(int mode, const double* params /* host, 10 doubles */, const void* v, int per_stream,
                     const void* X, void* Y, int S, int M, int N, long T_stride, long T,
                     void* P_state, void* w_state, double* stream_state, void* workspace, void* stream)
 {
+  return btk_rls_process_nc(mode, params, v, per_stream, nullptr, 1, X, Y, S, M, N, T_stride, T, P_state, w_state, stream_state, workspace, stream);
+}
+
+int btk_rls_process_nc(int mode, const double* params /* host, 10 doubles */, const void* v, int per_stream, const void* cx, int NC,
+                       const void* X, void* Y, int S, int M, int N, long T_stride, long T,
+                       void* P_state, void* w_state, double* stream_state, void* workspace, void* stream)
+{
   if (!params || !v || !X || !Y || !P_state || !w_state || !stream_state || !workspace)
     return btk_set_error(BTK_ERR_PARAMETER, "btk_rls_process: null argument");
   if (mode != 0 && mode != 1) return btk_set_error(BTK_ERR_PARAMETER, "btk_rls_process: mode must be 0 or 1");
   if (S <= 0 || N < 2 || M < 2 || T < 0 || T_stride < T)
     return btk_set_error(BTK_ERR_DIMENSION, "btk_rls_process: bad sizes S=%d N=%d M=%d T=%ld", S, N, M, T);
-  if (N > 64) return btk_set_error(BTK_ERR_DIMENSION, "btk_rls_process: N=%d > 64 channels not supported", N);
+  if (NC < 1 || NC >= N || (NC > 1 && !cx)) return btk_set_error(BTK_ERR_DIMENSION, "btk_rls_process: NC=%d constraints with N=%d channels", NC, N);
+  // register kernel: N <= 64 with one constraint; packed-Hermitian LDS kernel: anything else that fits the LDS (N <= 128)
+  const bool packed = N > 64 || NC > 1 || btk_switches().rls_packed;
+  if (packed && (N > 128 /* two lanes per matrix row in a 256-thread workgroup */ || rls_packed_lds(N, NC, rls_packed_rtb(N, NC)) > 160 * 1024 - 256))
+    return btk_set_error(BTK_ERR_DIMENSION, "btk_rls_process: N=%d channels (NC=%d) exceed the LDS-resident precision matrix (N <= 128)", N, NC);
   if (T == 0) return BTK_OK;
   const int K = M / 2 + 1;
   RlsParams p = {};
@@ -477,6 +778,15 @@ int btk_rls_process(int mode, const double* params /* host, 10 doubles */, const
   float2* Yp = static_cast<float2*>(Y);
   zd* P = static_cast<zd*>(P_state);
   zd* Wst = static_cast<zd*>(w_state);
+  if (packed) {
+    const int rtb = rls_packed_rtb(N, NC);
+    const size_t lds = rls_packed_lds(N, NC, rtb);
+    BTK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(rls_packed_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(rls_packed_kernel, dim3((unsigned)K, (unsigned)S), dim3(256), lds, st, Xp, V, per_stream, static_cast<const zd*>(cx), NC,
+                       Yp, K, N, T_stride, T, ctrl, state_before, p, P, Wst, rtb);
+    BTK_HIP_CHECK(hipGetLastError());
+    return BTK_OK;
+  }
   if (N <= 4)       return launch_rls<4>(Xp, V, per_stream, Yp, S, K, N, T_stride, T, ctrl, state_before, p, P, Wst, st);
   else if (N <= 8)  return launch_rls<8>(Xp, V, per_stream, Yp, S, K, N, T_stride, T, ctrl, state_before, p, P, Wst, st);
   else if (N <= 16) return launch_rls<16>(Xp, V, per_stream, Yp, S, K, N, T_stride, T, ctrl, state_before, p, P, Wst, st);

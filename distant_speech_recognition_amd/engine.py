@@ -392,16 +392,21 @@ def nlms_process(vs, X, state, out=None):
     return out
 
 
-def nlms_constraint_vectors(vs, Nc):
-    """The Nc - 1 extra orthonormal directions the Nc-constraint canceller's projector loses per bin (include/btkhip.h):
-    vs complex [K][N] (host) -> complex64 [K][Nc-1][N] (host)."""
+def constraint_vectors(vs, Nc):
+    """The Nc - 1 extra orthonormal directions the Nc-constraint cancellers' projector loses per bin (include/btkhip.h):
+    vs complex [K][N] (host) -> complex128 [K][Nc-1][N] (host)."""
     vs = np.ascontiguousarray(vs, np.complex128)
     K, N = vs.shape
     out = np.zeros((K, Nc - 1, N), np.complex128)
     for k in range(K):
         B = weights_blocking_matrix(vs[k], Nc)
         check(_lib.lib().btk_nlms_constraint_vectors(_np_ptr(vs[k]), _np_ptr(B), N, Nc, _np_ptr(out[k])))
-    return out.astype(np.complex64)
+    return out
+
+
+def nlms_constraint_vectors(vs, Nc):
+    """constraint_vectors in the NLMS kernel's element type: complex64 [K][Nc-1][N] (host)"""
+    return constraint_vectors(vs, Nc).astype(np.complex64)
 
 
 def nlms_u_to_wa(u, B):
@@ -435,10 +440,12 @@ class RLSState:
     mode 1: SubbandGSCRLSBeamformer (lib/pybeamformer.py:765-928); mode 0: SubbandGSCRLS (beamformer.cc:1447-1645).
     v complex128 [K][N] or [S][K][N] (cuda): vs resp. wq of bins 0..M/2."""
 
-    def __init__(self, mode, S, M, N, v, **kw):
+    def __init__(self, mode, S, M, N, v, Nc=1, **kw):
         if mode not in (0, 1):
             raise _lib.BtkError(_lib.BTK_ERR_PARAMETER, "RLSState: mode must be 0 or 1")
         self.mode = mode
+        self.Nc = int(Nc)
+        self.cx = None                         # Nc > 1: complex128 [K][Nc-1][N] on the device, the further blocked directions
         self.p = dict(RLS_PY_DEFAULTS if mode == 1 else RLS_CC_DEFAULTS)
         unknown = set(kw) - set(self.p)
         if unknown:
@@ -455,14 +462,20 @@ class RLSState:
         self.w = torch.empty((S, self.K, N), dtype=torch.complex128, device=dev)
         self.stream_state = torch.zeros((S, 4), dtype=torch.float64, device=dev)
         self._ws = None
+        if self.Nc > 1:
+            if self.per_stream:
+                raise _lib.BtkError(_lib.BTK_ERR_PARAMETER, "RLSState: Nc > 1 takes one v [K][N] for all streams")
+            # conj(B) B^T = I - v v^H/|v|^2 - sum_j c_j c_j^H (mode 1); mode 0: B B^H, i.e. the complex conjugates (include/btkhip.h)
+            cx = constraint_vectors(self.v.cpu().numpy(), self.Nc)
+            self.cx = torch.from_numpy(np.conj(cx) if mode == 0 else cx).to(dev).contiguous()
         if mode == 1:
             self.reset_stats()
 
     def init_precision_matrix(self, p0):
         """P = p0 B B^H (mode 0) / p0 conj(B) B^T (mode 1), w = 0 (init_precision_matrix with p0 = 1/sigma2,
         beamformer.cc:1482-1494)"""
-        check(_lib.lib().btk_rls_init(self.mode, _ptr(self.v), self.per_stream, float(p0), self.S, self.K, self.N,
-                                      _ptr(self.P), _ptr(self.w), _stream()))
+        check(_lib.lib().btk_rls_init_nc(self.mode, _ptr(self.v), self.per_stream, None if self.cx is None else _ptr(self.cx), self.Nc,
+                                         float(p0), self.S, self.K, self.N, _ptr(self.P), _ptr(self.w), _stream()))
 
     def reset_stats(self):
         """pybeamformer.py:913-925"""
@@ -496,15 +509,16 @@ def rls_process(X, state, out=None):
         out = torch.empty((S, K, T), dtype=torch.complex64, device=X.device)
     params = state.params_array()
     ws = state.workspace(T)
-    check(_lib.lib().btk_rls_process(state.mode, _np_ptr(params), _ptr(state.v), state.per_stream, _ptr(X), _ptr(out),
-                                     S, state.M, N, T, T, _ptr(state.P), _ptr(state.w), _ptr(state.stream_state),
-                                     _ptr(ws), _stream()))
+    check(_lib.lib().btk_rls_process_nc(state.mode, _np_ptr(params), _ptr(state.v), state.per_stream,
+                                        None if state.cx is None else _ptr(state.cx), state.Nc, _ptr(X), _ptr(out),
+                                        S, state.M, N, T, T, _ptr(state.P), _ptr(state.w), _ptr(state.stream_state),
+                                        _ptr(ws), _stream()))
     return out
 
 
 def rls_state_to_reference(mode, P, w, B):
-    """Host change of basis for one bin: engine (P [N][N], w [N]) -> reference (Pz [N-1][N-1], wa resp. waH [N-1])
-    with the bin's blocking matrix B [N][N-1] (orthonormal columns)."""
+    """Host change of basis for one bin: engine (P [N][N], w [N]) -> reference (Pz [N-Nc][N-Nc], wa resp. waH [N-Nc])
+    with the bin's blocking matrix B [N][N-Nc] (orthonormal columns)."""
     P = np.asarray(P, np.complex128)
     w = np.asarray(w, np.complex128)
     B = np.asarray(B, np.complex128)

@@ -229,6 +229,7 @@ class SubbandGSCRLS : public SubbandGSC {
   QuadraticConstraintType qctype_;
   bool is_wa_updated_, have_P_;
   void *dP_, *dW_, *dV_, *dSS_;     // device: P complex128 [K][N][N], w complex128 [K][N], wq complex128 [K][N], stream state
+  void* dCx_;                       // NC > 1: the further blocked directions, complex128 [K][NC-1][N] (btk_rls_*_nc)
 };
 typedef Inherit<SubbandGSCRLS, SubbandGSCPtr> SubbandGSCRLSPtr;
 

@@ -1489,16 +1489,29 @@ void LefkimmiatisPostFilter::calc_inverse_noise_spatial_spectral_matrix()
 // ================================================================================ SubbandGSCRLS
 SubbandGSCRLS::SubbandGSCRLS(unsigned fftLen, bool halfBandShift, float mu, float sigma2, const String& nm)
     : SubbandGSC(fftLen, halfBandShift, nm), mu_(mu), diagonal_weight_(sigma2), alpha_(-1.0f), qctype_(NO_QUADRATIC_CONSTRAINT),
-      is_wa_updated_(true), have_P_(false), dP_(NULL), dW_(NULL), dV_(NULL), dSS_(NULL) {}
+      is_wa_updated_(true), have_P_(false), dP_(NULL), dW_(NULL), dV_(NULL), dSS_(NULL), dCx_(NULL) {}
 
-SubbandGSCRLS::~SubbandGSCRLS() { dev_free(dP_); dev_free(dW_); dev_free(dV_); dev_free(dSS_); }
+SubbandGSCRLS::~SubbandGSCRLS() { dev_free(dP_); dev_free(dW_); dev_free(dV_); dev_free(dSS_); dev_free(dCx_); }
 
 void SubbandGSCRLS::alloc_state_()
 {
   if (!bfweight_) throw j_error("call calc_gsc_weights_x() once\n");
-  if (bfweight_->NC() != 1) throw jdimension_error("the GPU RLS canceller supports NC = 1 constraint (got %d)\n", bfweight_->NC());
-  const unsigned N = chanN(), K = fftLen2_ + 1;
-  dev_free(dP_); dev_free(dW_); dev_free(dV_); dev_free(dSS_);
+  const unsigned N = chanN(), K = fftLen2_ + 1, NC = bfweight_->NC();
+  dev_free(dP_); dev_free(dW_); dev_free(dV_); dev_free(dSS_); dev_free(dCx_); dCx_ = NULL;
+  if (NC > 1) {
+    // the blocking matrix of calc_gsc_weights_2 / _n keeps N - NC columns: B B^H = I - conj(wq) wq^T / |wq|^2 - sum_j c_j c_j^H;
+    // btk_nlms_constraint_vectors returns the directions of conj(B) B^T, i.e. the complex conjugates (include/btkhip.h)
+    const unsigned bs = N - NC;
+    std::vector<cd> cx((size_t)K * (NC - 1) * N);
+    for (unsigned k = 0; k < K; k++) {
+      check_abi(btk_nlms_constraint_vectors(reinterpret_cast<const double*>(&bfweight_->wq_v[(size_t)k * N]),
+                                            reinterpret_cast<const double*>(&bfweight_->B_v[(size_t)k * N * bs]), (int)N, (int)NC,
+                                            reinterpret_cast<double*>(&cx[(size_t)k * (NC - 1) * N])));
+    }
+    for (size_t i = 0; i < cx.size(); i++) cx[i] = std::conj(cx[i]);
+    dCx_ = dev_alloc(sizeof(double) * 2 * cx.size());
+    h2d(dCx_, cx.data(), sizeof(double) * 2 * cx.size());
+  }
   dP_ = dev_alloc(sizeof(double) * 2 * K * N * N);
   dW_ = dev_alloc(sizeof(double) * 2 * K * N);
   dV_ = dev_alloc(sizeof(double) * 2 * K * N);
@@ -1512,7 +1525,7 @@ void SubbandGSCRLS::init_precision_matrix(float sigma2)
   alloc_state_();
   const unsigned N = chanN(), K = fftLen2_ + 1;
   const float p0 = 1 / sigma2;                                                // float division, beamformer.cc:1491
-  check_abi(btk_rls_init(0, dV_, 0, (double)p0, 1, (int)K, (int)N, dP_, dW_, NULL));
+  check_abi(btk_rls_init_nc(0, dV_, 0, dCx_, (int)bfweight_->NC(), (double)p0, 1, (int)K, (int)N, dP_, dW_, NULL));
   // the active weights kept in the weight object are the starting point (zeros after calc_gsc_weights)
   h2d(dW_, bfweight_->wl_v.data(), sizeof(double) * 2 * K * N);
   have_P_ = true;
@@ -1528,7 +1541,7 @@ void SubbandGSCRLS::set_precision_matrix(unsigned fbinX, gsl_matrix_complex* Pz)
     h2d(dW_, bfweight_->wl_v.data(), sizeof(double) * 2 * K * N);
     have_P_ = true;
   }
-  const unsigned N = chanN(), bs = N - 1;
+  const unsigned N = chanN(), bs = N - bfweight_->NC();
   if (fbinX > fftLen2_) return;                                               // only bins 1..M/2 are ever used
   if (Pz->size1 < bs || Pz->size2 < bs) throw jdimension_error("the precision matrix must be at least %dx%d\n", bs, bs);
   // engine basis: P = B Pz B^H
@@ -1561,7 +1574,7 @@ void SubbandGSCRLS::run_block_()
   const double params[6] = { (double)mu_, (double)diagonal_weight_, (double)(int)qctype_, (double)alpha_,
                              normalize_weight_ ? 1.0 : 0.0, is_wa_updated_ ? 1.0 : 0.0 };
   void* ws = dev_alloc((size_t)btk_rls_workspace_bytes(1, T_ ? T_ : 1));
-  check_abi(btk_rls_process(0, params, dV_, 0, dX, dY, 1, (int)fftLen_, (int)N, T_, T_, dP_, dW_, (double*)dSS_, ws, NULL));
+  check_abi(btk_rls_process_nc(0, params, dV_, 0, dCx_, (int)bfweight_->NC(), dX, dY, 1, (int)fftLen_, (int)N, T_, T_, dP_, dW_, (double*)dSS_, ws, NULL));
   check_abi(btk_synchronize(NULL));
   Yhost_.assign((size_t)2 * K * T_, 0.f);
   if (T_) d2h(Yhost_.data(), dY, sizeof(float) * Yhost_.size());
@@ -1569,7 +1582,7 @@ void SubbandGSCRLS::run_block_()
   // export wl / wa of bins 1..M/2 as calcSidelobeCancellerU_f leaves them (beamformer.cc:1643)
   std::vector<cd> wl((size_t)K * N);
   d2h(wl.data(), dW_, sizeof(double) * 2 * K * N);
-  const unsigned bs = N - 1;
+  const unsigned bs = N - bfweight_->NC();
   for (unsigned k = 1; k < K; k++) {
     const cd* B = &bfweight_->B_v[(size_t)k * N * bs];
     for (unsigned c = 0; c < N; c++) bfweight_->wl_v[(size_t)k * N + c] = wl[(size_t)k * N + c];

@@ -297,9 +297,7 @@ class SubbandGSCRLSBeamformer(SubbandBeamformer):
                  regularization_param=1.0E-2, sil_thresh=1.0E+8, constraint_option=3, alpha2=10.0,
                  max_wa_l2norm=100.0, min_frames=128, slowdown_after=4096, Nc=1):
         SubbandBeamformer.__init__(self, spec_sources)
-        if Nc != 1:
-            raise NotImplementedError("the GPU canceller supports Nc = 1 (see DESIGN.md)")
-        self._Nc = Nc
+        self._Nc = int(Nc)
         self._front = SubbandGSCPtr(fftlen=self._fftlen, half_band_shift=False)   # owns channels + device snapshots
         for source in self._spec_sources:
             self._front.set_channel(source)
@@ -337,7 +335,7 @@ class SubbandGSCRLSBeamformer(SubbandBeamformer):
             X = self._front.device_snapshots()
             if self._state is None:
                 self._state = engine.RLSState(1, 1, self._fftlen, self._chan_num,
-                                              torch.from_numpy(np.ascontiguousarray(self._vs)).to(device()), **self._params)
+                                              torch.from_numpy(np.ascontiguousarray(self._vs)).to(device()), Nc=self._Nc, **self._params)
             self._Y = engine.rls_process(X, self._state)
         return self._Y
 
@@ -357,7 +355,7 @@ class SubbandGSCRLSBeamformer(SubbandBeamformer):
     @property
     def _waH(self):
         if self._state is None or self._vs is None:
-            return np.zeros((self._fftlen2 + 1, self._chan_num - 1), complex)
+            return np.zeros((self._fftlen2 + 1, self._chan_num - self._Nc), complex)
         return np.stack([e[1] for e in self._export()])
 
     @_waH.setter
@@ -367,7 +365,7 @@ class SubbandGSCRLSBeamformer(SubbandBeamformer):
     @property
     def _Pz(self):
         if self._state is None or self._vs is None:
-            n = self._chan_num - 1
+            n = self._chan_num - self._Nc
             return [np.identity(n) / self._params["init_diagonal_load"] for _ in range(self._fftlen2 + 1)]
         return [e[0] for e in self._export()]
 

@@ -161,13 +161,25 @@ int  btk_nlms_u_to_wa(const double* u, const double* B, int N, double* waH);
  *   stream_state float64 [S][4]     = {_energy, -, _isamp, _ttl_updates} (mode 1; untouched in mode 0)
  * btk_rls_init writes P = p0 B B^H resp. p0 conj(B) B^T (closed form from v), w = 0  == init_precision_matrix (p0 = 1/sigma2,
  * beamformer.cc:1482-1494) resp. reset_stats (p0 = 1/init_diagonal_load, pybeamformer.py:921-925).
- * N <= 64.  workspace [dev] btk_rls_workspace_bytes(S,T) bytes.  Y [dev] complex64 [S][K][T_stride].     */
+ * workspace [dev] btk_rls_workspace_bytes(S,T) bytes.  Y [dev] complex64 [S][K][T_stride].
+ * N <= 64 with one constraint: P in registers (row and column copies, the reference's two products separately); otherwise, up to
+ * N = 128: P as a packed Hermitian matrix in LDS (rls_kernels.hip).
+ * btk_rls_init_nc / btk_rls_process_nc: NC >= 1 constraints (SubbandGSCRLSBeamformer(..., Nc), pybeamformer.py:784-797;
+ *   SubbandGSCRLS after calc_gsc_weights_2 / _n): cx [dev] complex128 [Sv][K][NC-1][N], the orthonormal directions the blocking
+ *   matrix removes besides the one implied by v -- mode 1: btk_nlms_constraint_vectors(vs, B) (conj(B) B^T = I - vs vs^H/|vs|^2 -
+ *   sum_j c_j c_j^H), mode 0: their complex conjugates taken with vs = wq (B B^H = I - conj(wq) wq^T/|wq|^2 - sum_j c_j c_j^H).
+ *   NC = 1: cx may be NULL (== btk_rls_init / btk_rls_process).                                                               */
 long btk_rls_workspace_bytes(int S, long T);
 int  btk_rls_init(int mode, const void* v, int per_stream_v, double p0, int S, int K, int N,
                   void* P_state, void* w_state, void* stream);
 int  btk_rls_process(int mode, const double* params, const void* v, int per_stream_v,
                      const void* X, void* Y, int S, int M, int N, long T_stride, long T,
                      void* P_state, void* w_state, double* stream_state, void* workspace, void* stream);
+int  btk_rls_init_nc(int mode, const void* v, int per_stream_v, const void* cx, int NC, double p0, int S, int K, int N,
+                     void* P_state, void* w_state, void* stream);
+int  btk_rls_process_nc(int mode, const double* params, const void* v, int per_stream_v, const void* cx, int NC,
+                        const void* X, void* Y, int S, int M, int N, long T_stride, long T,
+                        void* P_state, void* w_state, double* stream_state, void* workspace, void* stream);
 
 /* ---- Zelinski post-filter -------------------------------------------------------------------
  * Replaces ZelinskiFilter_f / ZelinskiFilter / ZelinskiPostFilter::next

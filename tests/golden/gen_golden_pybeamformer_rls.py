@@ -8,7 +8,10 @@ Pinned: SubbandGSCRLSBeamformer.__iter__ / calc_beamformer_weights / reset_stats
 with its default hyper-parameters (= confs/gscrls.json) and with a configuration that exercises the
 quadratic constraint and the norm reset.
 
-Run:  python tests/golden/gen_golden_pybeamformer_rls.py
+Round 3: the same recursion with Nc = 2 constraints (SubbandGSCRLSBeamformer(..., Nc), :784-797: the blocking matrix keeps
+N - Nc columns) -> tests/golden/pybeamformer_rls_nc_golden.npz.
+
+Run:  python tests/golden/gen_golden_pybeamformer_rls.py        (writes both files)
 """
 import os
 import sys
@@ -27,7 +30,14 @@ CASES = (
 )
 
 
-def main():
+NC_CASES = (
+    ("rlsnc2_default", dict(min_frames=16)),
+    ("rlsnc2_constrained", dict(min_frames=8, gamma=0.5, alpha2=1.0e-3, max_wa_l2norm=4.0e-3, init_diagonal_load=1.0e3,
+                                sil_thresh=1.0e2)),
+)
+
+
+def main(cases=CASES, Nc=1, outfile="pybeamformer_rls_golden.npz"):
     sys.path.insert(0, ROOT)
     from oracle import oracle as orc
     ref = load_reference_module()
@@ -38,13 +48,13 @@ def main():
     mpos = np.array([[-113.0, 0.0, 2.0], [36.0, 0.0, 2.0], [76.0, 0.0, 2.0], [113.0, 0.0, 2.0]])
     delays = ref.calc_la_delays(mpos, -1.306379)
     out = {"meta_T": np.array([T])}
-    for tag, kw in CASES:
+    for tag, kw in cases:
         cls = ref.SubbandGSCRLSBeamformer
         bf = cls.__new__(cls)
         bf._array_source = NumpySnapshotSource(X)
-        bf._chan_num, bf._fftlen, bf._fftlen2, bf._shiftlen, bf._Nc = 4, M, M // 2, 128, 1
+        bf._chan_num, bf._fftlen, bf._fftlen2, bf._shiftlen, bf._Nc = 4, M, M // 2, 128, Nc
         bf._wqH = np.ones((M // 2 + 1, 4), complex)
-        bf._BmH = [np.zeros((3, 4), complex) for _ in range(M // 2 + 1)]
+        bf._BmH = [np.zeros((4 - Nc, 4), complex) for _ in range(M // 2 + 1)]
         p = dict(beta=0.97, gamma=0.04, mu=0.97, init_diagonal_load=1.0e6, regularization_param=1.0e-2, sil_thresh=1.0e8,
                  constraint_option=3, alpha2=10.0, max_wa_l2norm=100.0, min_frames=128, slowdown_after=4096)
         p.update(kw)
@@ -69,9 +79,11 @@ def main():
         nrm = np.abs(np.sum(np.array(bf._waH) * np.conj(np.array(bf._waH)), axis=1))
         print(tag, "ttl_updates", bf._ttl_updates, "max|wa|^2", nrm.max(), "Pz resets",
               int(np.sum(np.abs(np.array(bf._Pz)[:, 0, 0] - 1.0 / p["init_diagonal_load"]) < 1e-30)))
-    np.savez_compressed(os.path.join(HERE, "pybeamformer_rls_golden.npz"), **out)
+    out["meta_Nc"] = np.array([Nc])
+    np.savez_compressed(os.path.join(HERE, outfile), **out)
     print({k: v.shape for k, v in out.items()})
 
 
 if __name__ == "__main__":
     main()
+    main(NC_CASES, 2, "pybeamformer_rls_nc_golden.npz")

@@ -238,3 +238,34 @@ def test_half_band_shift_through_cpp_nodes(orc, dev, proto256, kinect_pcm, tmp_p
     pf.set_beamformer(g2)
     with pytest.raises(B.j_error):
         pf.next()
+
+
+@pytest.mark.gpu
+def test_cpp_gscrls_with_two_constraints(orc, dev):
+    """C++ SubbandGSCRLS after calc_gsc_weights_2 (look direction + one null: the blocking matrix keeps N - 2 columns): the
+    recursion of btk_rls_process_nc (mode 0, the further blocked direction from btk_nlms_constraint_vectors) against the oracle's
+    frame-by-frame restatement of beamformer.cc:1514-1645 run on the same LCMV quiescent weights."""
+    from distant_speech_recognition_amd import btk20cpp as B
+    from distant_speech_recognition_amd.pybeamformer import calc_delays
+    Mh, N, T = 32, 6, 70
+    K = Mh // 2 + 1
+    rng = np.random.default_rng(321)
+    X = (rng.standard_normal((T, N, Mh)) + 1j * rng.standard_normal((T, N, Mh))) * 0.5
+    X[:, :, 0] = X[:, :, 0].real; X[:, :, Mh // 2] = X[:, :, Mh // 2].real
+    X[:, :, K:] = np.conj(X[:, :, Mh // 2 - 1:0:-1])
+    mpos = [[-100.0 + 40.0 * i, 0.0, 2.0] for i in range(N)]
+    dT, dJ = calc_delays("linear", mpos, [-1.0, None, None]), calc_delays("linear", mpos, [0.5, None, None])
+    rls = B.SubbandGSCRLSPtr(fftlen=Mh, half_band_shift=False, mu=0.9, sigma2=0.01)
+    for n in range(N):
+        rls.set_channel(B.PyVectorComplexFeatureStreamPtr(_Source(X[:, n, :])))
+    rls.calc_gsc_weights_2(FS, dT, dJ)
+    rls.init_precision_matrix(0.01)
+    out = np.stack([np.array(v) for v in rls])
+    o = orc.RLSCc(Mh, N, dT, FS, mu=0.9, sigma2=0.01, Nc=2)
+    o.wq = orc.calc_mainlobe_2(Mh, N, FS, dT, dJ)                                   # the node's LCMV quiescent weights
+    for k in range(Mh):
+        o.B[k] = orc.blocking_matrix(o.wq[k], 2)
+    o.init_precision_matrix(0.01)
+    ref = o.run(X)
+    assert out.shape == ref.shape
+    assert np.max(np.abs(out[:, :K] - ref[:, :K])) <= 1e-4 * np.max(np.abs(ref))
