@@ -97,6 +97,20 @@ def main():
     t = timeit(torch, lambda: eng.rls_process(X8, rs, out=Y8), n=3, warm=1)
     out["rls_8mic"] = {"ms": t * 1e3, "frames_per_s": S * T / t, "bin_frames_per_s": S * K * T / t,
                        "GFLOPs_f64": 8.0 * 5 * N8 * N8 * S * K * T / t / 1e9}
+    # round 3: the packed-Hermitian LDS form: two constraints at 8 mics, and a 100-microphone array (one stream, 1024 frames)
+    rs2 = eng.RLSState(1, S, M, N8, vs8, Nc=2, min_frames=0)
+    t = timeit(torch, lambda: eng.rls_process(X8, rs2, out=Y8), n=2, warm=1)
+    out["rls_8mic_nc2_packed"] = {"ms": t * 1e3, "frames_per_s": S * T / t, "bin_frames_per_s": S * K * T / t}
+    N100, T100 = 100, 1024
+    X100 = (torch.randn((1, K, N100, T100), device=dev) + 1j * torch.randn((1, K, N100, T100), device=dev)).to(torch.complex64) * 2000
+    d100 = la_delays(ula_positions(N100), -1.306379)
+    vs100 = torch.from_numpy(np.stack([np.exp(-2j * np.pi * k * (16000.0 / M) * d100) / N100 for k in range(K)])).to(dev)
+    rs100 = eng.RLSState(1, 1, M, N100, vs100, min_frames=0)
+    t = timeit(torch, lambda: eng.rls_process(X100, rs100), n=2, warm=1)
+    out["rls_100mic_packed"] = {"ms": t * 1e3, "frames_per_s": T100 / t, "bin_frames_per_s": K * T100 / t,
+                                "GFLOPs_f64": 8.0 * 3 * N100 * N100 * K * T100 / t / 1e9,
+                                "note": "one workgroup per bin, P packed in 81 KB of LDS: 257 workgroups on 256 CUs, sequential in t"}
+    del X100
     st8 = eng.NLMSState(S, M, N8, dev)
     v8c = vs8.to(torch.complex64)
     t = timeit(torch, lambda: eng.nlms_process(v8c, X8, st8, out=Y8))
