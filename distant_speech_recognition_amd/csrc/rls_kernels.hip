@@ -439,8 +439,8 @@ struct RlsLds {
 
 __device__ __forceinline__ zd pk_get(const zd* P, int i, int j) { return (j <= i) ? P[i * (i + 1) / 2 + j] : zconj(P[j * (j + 1) / 2 + i]); }
 
-// sums of up to 6 doubles over the 256 threads; every thread gets the totals (two barriers)
-template <int NV>
+// sums of up to 6 doubles over the NT threads; every thread gets the totals (two barriers; none in a one-wave workgroup)
+template <int NV, int NT>
 __device__ __forceinline__ void block_sums(double (&v)[NV], double* red)
 {
   const int tid = threadIdx.x;
@@ -449,12 +449,20 @@ __device__ __forceinline__ void block_sums(double (&v)[NV], double* red)
     double x = v[q];
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o, 64);
-    if ((tid & 63) == 0) red[(tid >> 6) * 8 + q] = x;
+    if constexpr (NT == 64) v[q] = x;
+    else if ((tid & 63) == 0) red[(tid >> 6) * 8 + q] = x;
   }
-  __syncthreads();
+  if constexpr (NT > 64) {
+    __syncthreads();
 #pragma unroll
-  for (int q = 0; q < NV; q++) v[q] = red[q] + red[8 + q] + red[16 + q] + red[24 + q];
-  __syncthreads();
+    for (int q = 0; q < NV; q++) {
+      double x = red[q];
+#pragma unroll
+      for (int w = 1; w < NT / 64; w++) x += red[8 * w + q];
+      v[q] = x;
+    }
+    __syncthreads();
+  }
 }
 
 // out_i = sum_j P_ij in_j (CONJ_IN: in_j conjugated), Hermitian packed; two lanes per row (even / odd j), N <= 128
@@ -508,7 +516,8 @@ __device__ __forceinline__ void pk_set_projector(zd* P, const zd* vdir, double i
   __syncthreads();
 }
 
-__global__ __launch_bounds__(256)
+template <int NT>
+__global__ __launch_bounds__(NT)
 void rls_packed_kernel(const float2* __restrict__ X, const zd* __restrict__ V, int per_stream, const zd* __restrict__ CX, int NC,
                        float2* __restrict__ Y, int K, int N, long T_stride, long T, const float* __restrict__ ctrl,
                        const double* __restrict__ state_before, RlsParams p, zd* __restrict__ Pst, zd* __restrict__ Wst,
@@ -531,7 +540,7 @@ void rls_packed_kernel(const float2* __restrict__ X, const zd* __restrict__ V, i
   zd* wk = Wst + sk * N;
   const float2* xk = X + sk * N * T_stride;
 
-  for (int e = tid; e < NP; e += 256) {                     // lower triangle of the exported [N][N] state
+  for (int e = tid; e < NP; e += NT) {                     // lower triangle of the exported [N][N] state
     int i = (int)((sqrt(8.0 * e + 1.0) - 1.0) * 0.5);
     while (i * (i + 1) / 2 > e) i--;
     while ((i + 1) * (i + 2) / 2 <= e) i++;
@@ -540,12 +549,12 @@ void rls_packed_kernel(const float2* __restrict__ X, const zd* __restrict__ V, i
     if (i == j) L.P[e].y = 0.0;
   }
   // v as it enters the projector: mode 1 v = vs; mode 0 the blocked direction is conj(wq)
-  for (int n = tid; n < N; n += 256) { L.vv[n] = v[n]; L.dv[n] = (p.mode == 0) ? zconj(v[n]) : v[n]; L.wv[n] = wk[n]; }
-  for (int e = tid; e < (NC - 1) * N; e += 256) L.cx[e] = CX[((long)(per_stream ? s : 0) * K + k) * (NC - 1) * N + e];
+  for (int n = tid; n < N; n += NT) { L.vv[n] = v[n]; L.dv[n] = (p.mode == 0) ? zconj(v[n]) : v[n]; L.wv[n] = wk[n]; }
+  for (int e = tid; e < (NC - 1) * N; e += NT) L.cx[e] = CX[((long)(per_stream ? s : 0) * K + k) * (NC - 1) * N + e];
   __syncthreads();
   double vs2[1] = {0.0};
-  for (int n = tid; n < N; n += 256) vs2[0] += L.vv[n].x * L.vv[n].x + L.vv[n].y * L.vv[n].y;
-  block_sums<1>(vs2, L.red);
+  for (int n = tid; n < N; n += NT) vs2[0] += L.vv[n].x * L.vv[n].x + L.vv[n].y * L.vv[n].y;
+  block_sums<1, NT>(vs2, L.red);
   const double inv_vv = vs2[0] > 0.0 ? 1.0 / vs2[0] : 0.0;
   // the direction the projector removes, as a vector in LDS: mode 1 vs, mode 0 conj(wq); kept in nv during the leak step only
   const long isamp0 = (long)state_before[4 * s + 2];
@@ -553,7 +562,7 @@ void rls_packed_kernel(const float2* __restrict__ X, const zd* __restrict__ V, i
   const bool commit = (p.mode == 1) || k > 0;               // beamformer.cc:1589 starts at bin 1
 
   auto stage = [&](int buf, long t0) {
-    for (int e = tid; e < N * rtb; e += 256) {
+    for (int e = tid; e < N * rtb; e += NT) {
       const int n = e / rtb, f = e % rtb;
       const long t = t0 + f;
       L.xt[(buf * N + n) * rld + f] = (t < T) ? xk[(long)n * T_stride + t] : make_float2(0.f, 0.f);
@@ -568,18 +577,18 @@ void rls_packed_kernel(const float2* __restrict__ X, const zd* __restrict__ V, i
     const int nt = (T - t0 < rtb) ? (int)(T - t0) : rtb;
     for (int tt = 0; tt < nt; tt++) {
       const bool adapt = (p.mode == 0) ? (p.update != 0) : (ctrl[(long)s * T + t0 + tt] != 0.f);
-      for (int n = tid; n < N; n += 256) { const float2 xf = L.xt[(buf * N + n) * rld + tt]; L.xv[n] = zmk((double)xf.x, (double)xf.y); }
+      for (int n = tid; n < N; n += NT) { const float2 xf = L.xt[(buf * N + n) * rld + tt]; L.xv[n] = zmk((double)xf.x, (double)xf.y); }
       __syncthreads();
       // Yc = v^H x, canceller output with the current weights, |v - w|^2 (mode 0 normalisation)
       double r5[5] = {0, 0, 0, 0, 0};
-      for (int n = tid; n < N; n += 256) {
+      for (int n = tid; n < N; n += NT) {
         const zd x = L.xv[n], vq = L.vv[n], wq = L.wv[n];
         const zd a = zfmac(vq, x, zmk(0, 0));
         const zd b = (p.mode == 1) ? zfma(wq, x, zmk(0, 0)) : zfmac(wq, x, zmk(0, 0));
         const zd d = zsub(vq, wq);
         r5[0] += a.x; r5[1] += a.y; r5[2] += b.x; r5[3] += b.y; r5[4] += d.x * d.x + d.y * d.y;
       }
-      block_sums<5>(r5, L.red);
+      block_sums<5, NT>(r5, L.red);
       const zd Yc = zmk(r5[0], r5[1]);
       zd Wx = zmk(r5[2], r5[3]);
       zd y;
@@ -592,8 +601,8 @@ void rls_packed_kernel(const float2* __restrict__ X, const zd* __restrict__ V, i
       if (adapt) {                                                           // (workgroup-uniform)
         pk_matvec<false>(L.P, L.xv, L.av, N);                                // a = P x;  x^H P = a^H
         double ipr[1] = {0.0};
-        for (int n = tid; n < N; n += 256) { const zd x = L.xv[n], a = L.av[n]; ipr[0] += x.x * a.x + x.y * a.y; }   // Re(x^H a)
-        block_sums<1>(ipr, L.red);
+        for (int n = tid; n < N; n += NT) { const zd x = L.xv[n], a = L.av[n]; ipr[0] += x.x * a.x + x.y * a.y; }   // Re(x^H a)
+        block_sums<1, NT>(ipr, L.red);
         // mode 1: g = a / (mu + x^H P x) (pybeamformer.py:840); mode 0: g = a / (mu (1 + x^H P x / mu)) (beamformer.cc:1598-1606)
         double den_inv = 1.0 / (p.mu + ipr[0]);
         if (!commit) den_inv = 0.0;
@@ -602,7 +611,7 @@ void rls_packed_kernel(const float2* __restrict__ X, const zd* __restrict__ V, i
         const bool need_rr = (p.mode == 1) ? (p.reg > 0.0) : (p.diag_w != 0.0);
         if (need_rr) { if (p.mode == 1) pk_matvec<true>(L.P, L.wv, L.nv, N); else pk_matvec<false>(L.P, L.wv, L.nv, N); }
         double n2s[1] = {0.0};
-        for (int n = tid; n < N; n += 256) {
+        for (int n = tid; n < N; n += NT) {
           const zd g = zscale(L.av[n], den_inv), w_n = L.wv[n];
           const zd rr = need_rr ? L.nv[n] : zmk(0.0, 0.0);
           zd wn;
@@ -617,7 +626,7 @@ void rls_packed_kernel(const float2* __restrict__ X, const zd* __restrict__ V, i
           n2s[0] += wn.x * wn.x + wn.y * wn.y;
         }
         __syncthreads();                                                     // (nv was read above, xv written: order both)
-        block_sums<1>(n2s, L.red);
+        block_sums<1, NT>(n2s, L.red);
         double n2 = n2s[0];
         double scale_w = 1.0;
         if (p.mode == 0) {
@@ -627,16 +636,16 @@ void rls_packed_kernel(const float2* __restrict__ X, const zd* __restrict__ V, i
           if (quad) {
             pk_matvec<true>(L.P, L.xv, L.nv, N);                             // va = P conj(waHK)
             double q2[2] = {0.0, 0.0};
-            for (int n = tid; n < N; n += 256) {
+            for (int n = tid; n < N; n += NT) {
               const zd va = L.nv[n], nq = L.xv[n];
               q2[0] += va.x * va.x + va.y * va.y;
               q2[1] += va.x * nq.x - va.y * nq.y;                            // Re(conj(va) . waK), waK = conj(waHK)
             }
-            block_sums<2>(q2, L.red);
+            block_sums<2, NT>(q2, L.red);
             const double a = q2[0], b = -2.0 * q2[1], cq = n2 - p.alpha2;
             const double arg = b * b - 4.0 * a * cq;
             const double betaK = (arg > 0.0) ? -(b + sqrt(arg)) / (2.0 * a) : -b / (2.0 * a);
-            for (int n = tid; n < N; n += 256) L.xv[n] = zsub(L.xv[n], zscale(zconj(L.nv[n]), betaK));
+            for (int n = tid; n < N; n += NT) L.xv[n] = zsub(L.xv[n], zscale(zconj(L.nv[n]), betaK));
             __syncthreads();
           }
           if (p.copt >= 2 && n2 > p.max_norm) {                              // :867-870 (n2 of the unconstrained candidate)
@@ -644,14 +653,14 @@ void rls_packed_kernel(const float2* __restrict__ X, const zd* __restrict__ V, i
             pk_set_projector(L.P, L.dv, inv_vv, L.cx, NC, 1.0 / p.init_load, N);
           }
         }
-        if (commit) for (int n = tid; n < N; n += 256) L.wv[n] = zscale(L.xv[n], scale_w);
+        if (commit) for (int n = tid; n < N; n += NT) L.wv[n] = zscale(L.xv[n], scale_w);
         __syncthreads();
         if (p.mode == 1) {                                                   // output with the updated weights
-          for (int n = tid; n < N; n += 256) { const float2 xf = L.xt[(buf * N + n) * rld + tt]; L.xv[n] = zmk((double)xf.x, (double)xf.y); }
+          for (int n = tid; n < N; n += NT) { const float2 xf = L.xt[(buf * N + n) * rld + tt]; L.xv[n] = zmk((double)xf.x, (double)xf.y); }
           __syncthreads();
           double w2[2] = {0.0, 0.0};
-          for (int n = tid; n < N; n += 256) { const zd t = zfma(L.wv[n], L.xv[n], zmk(0, 0)); w2[0] += t.x; w2[1] += t.y; }
-          block_sums<2>(w2, L.red);
+          for (int n = tid; n < N; n += NT) { const zd t = zfma(L.wv[n], L.xv[n], zmk(0, 0)); w2[0] += t.x; w2[1] += t.y; }
+          block_sums<2, NT>(w2, L.red);
           Wx = zmk(w2[0], w2[1]);
         }
       }
@@ -663,14 +672,14 @@ void rls_packed_kernel(const float2* __restrict__ X, const zd* __restrict__ V, i
     // ---- once per tile: P <- Q P Q, Q = I - n n^H for every blocked direction n (v / |v| resp. conj(wq) / |wq|, then the c_j):
     // in exact arithmetic P n = 0 for ever; in floating point that component is multiplied by 1 / mu per frame
     for (int d = 0; d < NC; d++) {
-      for (int n = tid; n < N; n += 256) {
+      for (int n = tid; n < N; n += NT) {
         L.xv[n] = (d == 0) ? zscale(L.dv[n], sqrt(inv_vv)) : L.cx[(d - 1) * N + n];
       }
       __syncthreads();
       pk_matvec<false>(L.P, L.xv, L.av, N);                                  // a = P n
       double sv[1] = {0.0};
-      for (int n = tid; n < N; n += 256) { const zd nd = L.xv[n], a = L.av[n]; sv[0] += nd.x * a.x + nd.y * a.y; }   // n^H P n (real)
-      block_sums<1>(sv, L.red);
+      for (int n = tid; n < N; n += NT) { const zd nd = L.xv[n], a = L.av[n]; sv[0] += nd.x * a.x + nd.y * a.y; }   // n^H P n (real)
+      block_sums<1, NT>(sv, L.red);
       const int i = tid >> 1, h = tid & 1;
       if (i < N) {
         zd* row = L.P + i * (i + 1) / 2;
@@ -688,8 +697,8 @@ void rls_packed_kernel(const float2* __restrict__ X, const zd* __restrict__ V, i
     }
   }
   // export: both triangles of P [N][N], w [N]
-  for (int e = tid; e < N * N; e += 256) { const int i = e / N, j = e % N; Pk[e] = pk_get(L.P, i, j); }
-  for (int n = tid; n < N; n += 256) wk[n] = L.wv[n];
+  for (int e = tid; e < N * N; e += NT) { const int i = e / N, j = e % N; Pk[e] = pk_get(L.P, i, j); }
+  for (int n = tid; n < N; n += NT) wk[n] = L.wv[n];
 }
 
 inline size_t rls_packed_lds(int N, int NC, int rtb)
@@ -698,6 +707,18 @@ inline size_t rls_packed_lds(int N, int NC, int rtb)
          sizeof(float2) * ((rtb == RTB ? 2 : 1) * (size_t)N * (rtb + 1) + RTB);
 }
 inline int rls_packed_rtb(int N, int NC) { return rls_packed_lds(N, NC, RTB) <= 160 * 1024 - 256 ? RTB : 8; }
+
+
+template <int NT>
+int launch_rls_packed(const float2* X, const zd* V, int per_stream, const zd* cx, int NC, float2* Y, int S, int K, int N, long T_stride, long T,
+                      const float* ctrl, const double* state_before, const RlsParams& p, zd* P, zd* W, int rtb, size_t lds, hipStream_t st)
+{
+  BTK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(rls_packed_kernel<NT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(rls_packed_kernel<NT>, dim3((unsigned)K, (unsigned)S), dim3(NT), lds, st, X, V, per_stream, cx, NC, Y, K, N, T_stride, T,
+                     ctrl, state_before, p, P, W, rtb);
+  BTK_HIP_CHECK(hipGetLastError());
+  return BTK_OK;
+}
 
 }  // namespace
 
@@ -781,11 +802,11 @@ int btk_rls_process_nc(int mode, const double* params /* host, 10 doubles */, co
   if (packed) {
     const int rtb = rls_packed_rtb(N, NC);
     const size_t lds = rls_packed_lds(N, NC, rtb);
-    BTK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(rls_packed_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(rls_packed_kernel, dim3((unsigned)K, (unsigned)S), dim3(256), lds, st, Xp, V, per_stream, static_cast<const zd*>(cx), NC,
-                       Yp, K, N, T_stride, T, ctrl, state_before, p, P, Wst, rtb);
-    BTK_HIP_CHECK(hipGetLastError());
-    return BTK_OK;
+    // two lanes per matrix row: a 64-thread (one wave, barrier-free sums) workgroup up to N = 32, 128 threads up to 64 -- small
+    // arrays then keep 4x / 2x as many bins resident per CU as the 256-thread form
+    if (N <= 32)      return launch_rls_packed<64>(Xp, V, per_stream, static_cast<const zd*>(cx), NC, Yp, S, K, N, T_stride, T, ctrl, state_before, p, P, Wst, rtb, lds, st);
+    else if (N <= 64) return launch_rls_packed<128>(Xp, V, per_stream, static_cast<const zd*>(cx), NC, Yp, S, K, N, T_stride, T, ctrl, state_before, p, P, Wst, rtb, lds, st);
+    return launch_rls_packed<256>(Xp, V, per_stream, static_cast<const zd*>(cx), NC, Yp, S, K, N, T_stride, T, ctrl, state_before, p, P, Wst, rtb, lds, st);
   }
   if (N <= 4)       return launch_rls<4>(Xp, V, per_stream, Yp, S, K, N, T_stride, T, ctrl, state_before, p, P, Wst, st);
   else if (N <= 8)  return launch_rls<8>(Xp, V, per_stream, Yp, S, K, N, T_stride, T, ctrl, state_before, p, P, Wst, st);
