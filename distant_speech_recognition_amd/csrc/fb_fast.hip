@@ -782,6 +782,196 @@ void fast_synthesis_kernel(const float2* __restrict__ Y, long nframes, long T_st
   }
 }
 
+
+// ---- round 3: M = 1024 / 2048 (R = 1, 2; aligned launches).  The ring form above needs TT + m R frame buffers of M/2 complex words: 87 KB at
+// M = 1024 and 101-135 KB at M = 2048 -> ONE four-wave workgroup per CU, 4-byte stores, every ds_read_b64 of the overlap-add half used.
+// Here the overlap-add lane owns FOUR consecutive samples (a "quad") of all its blocks and carries the m R - 1 history frames of its quad
+// in REGISTERS from chunk to chunk, so LDS holds only the TT frames of the current chunk (68-70 KB: two workgroups per CU); window reads
+// are two adjacent complex words per frame, a block leaves as one 16-byte store per lane, the pre-pass lane owns two consecutive frames
+// of a bin pair (16-byte loads), the FFT is the packed wave-private one of the analysis kernels (fft_packed.h).
+template <int LOG2M, int R>
+__global__ __launch_bounds__(F_NT, 2)
+void fast_synthesis_w_kernel(const float2* __restrict__ Y, long nframes, long T_stride, int K,
+                             const float* __restrict__ proto, const float2* __restrict__ twg,
+                             int pd, float gain, float* __restrict__ out, long out_stride, long b0, long bcount, int srun)
+{
+  using G = FG<LOG2M>;
+  constexpr int M = G::M, NF = G::NF, TT = G::TT, FRS = G::FRS, P2 = G::P2;
+  constexpr int D = M / R;
+  constexpr int HALO = F_MT * R - 1;
+  constexpr int SPL = (D / 4 >= F_NT) ? 4 : 2;                 // consecutive samples per overlap-add lane (16- or 8-byte stores)
+  constexpr int NQ = D / SPL;                                  // lanes' sample groups per block
+  constexpr int QPT = NQ / F_NT;                               // groups per thread
+  constexpr int BPG = TT;
+  constexpr int NWF = BPG + HALO;
+  static_assert(NQ % F_NT == 0 && HALO <= BPG && (TT & 1) == 0, "geometry");
+  constexpr int FP = TT / 2, KQW = F_NT / FP, NPW = NF / 2 / KQW;      // frame pairs, bin lanes, bin pairs per lane
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float2* frm = reinterpret_cast<float2*>(smem);               // [TT][FRS]
+  float2* twj = frm + TT * FRS;                                // [NF]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int s = blockIdx.y;
+  const long bt0 = b0 + (long)blockIdx.x * srun;
+  const long bend = (bt0 + srun < b0 + bcount) ? bt0 + srun : b0 + bcount;
+  const float2* Ys = Y + (long)s * K * T_stride;
+  float* os = out + (long)s * out_stride;
+
+  for (int i = tid; i < NF; i += F_NT) twj[i] = twg[(2 * (i % P2) * (i / P2)) & (M - 1)];
+
+  const int qd = tid;
+  float hist[QPT][R][HALO][SPL];                                 // the quad's samples of the HALO frames before the chunk
+#pragma unroll
+  for (int q = 0; q < QPT; q++)
+#pragma unroll
+    for (int j = 0; j < R; j++)
+#pragma unroll
+      for (int w = 0; w < HALO; w++)
+#pragma unroll
+        for (int dd = 0; dd < SPL; dd++) hist[q][j][w][dd] = 0.f;
+
+  const long f_lo = bt0 + pd - HALO;
+  // A. pre-pass lane: frames fc0 + 2 fp, + 1; bin pairs (k, NF - k), k = kq + KQW it < NF / 2; the kq == 0 lanes also own bin NF / 2
+  const int fp = tid % FP, kq = tid / FP;
+  const float2 twm = twg[NF / 2];
+  float4 pa[NPW], pb[NPW], pmid = make_float4(0.f, 0.f, 0.f, 0.f);
+  auto prefetch = [&](long fc0) {
+    const long fA = fc0 + 2 * fp;
+    const bool okA = fA >= 0 && fA < nframes, okB = fA + 1 >= 0 && fA + 1 < nframes;
+    if (okA && okB) {                                          // 16-byte loads: fA is even and the rows are 16-byte aligned (launch check)
+#pragma unroll
+      for (int it = 0; it < NPW; it++) {
+        const int k = kq + KQW * it;
+        pa[it] = *reinterpret_cast<const float4*>(Ys + (long)k * T_stride + fA);
+        pb[it] = *reinterpret_cast<const float4*>(Ys + (long)(NF - k) * T_stride + fA);
+      }
+      if (kq == 0) pmid = *reinterpret_cast<const float4*>(Ys + (long)(NF / 2) * T_stride + fA);
+    } else {
+      auto ld = [&](int k) {
+        const float2 a = okA ? Ys[(long)k * T_stride + fA] : make_float2(0.f, 0.f);
+        const float2 b = okB ? Ys[(long)k * T_stride + fA + 1] : make_float2(0.f, 0.f);
+        return make_float4(a.x, a.y, b.x, b.y);
+      };
+#pragma unroll
+      for (int it = 0; it < NPW; it++) { const int k = kq + KQW * it; pa[it] = ld(k); pb[it] = ld(NF - k); }
+      if (kq == 0) pmid = ld(NF / 2);
+    }
+  };
+  auto zc = [&](float2 a, float2 bq, float2 w) {              // Zc[k] from Y[k] = a, Y[NF-k] = bq, w = W_M^k
+    const float2 sm = make_float2(a.x + bq.x, a.y - bq.y), df = make_float2(a.x - bq.x, a.y + bq.y);
+    const float2 t = make_float2(w.x * df.x + w.y * df.y, w.x * df.y - w.y * df.x);
+    return make_float2(sm.x - t.y, sm.y + t.x);
+  };
+  __syncthreads();
+  for (long fc0 = f_lo + HALO - TT; fc0 < bend + pd; fc0 += TT) {
+    // the 32-point passes of B leave no room to carry the next chunk's 64 registers of bins through B and C (the form with the loads a
+    // phase ahead spills 18-255 registers); the second workgroup of the CU covers this one's load latency instead.  Pulling the next
+    // chunk into L2 with one discarded dword per 16-byte piece made it SLOWER (M = 2048: 0.57 -> 0.98 ms): the pre-pass is bound by
+    // the number of load instructions and the 16 rows each of them touches, not by latency
+    prefetch(fc0);
+    // ---- A. Hermitian pre-pass of this lane's two frames
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+      float2* zf = frm + (2 * fp + h) * FRS;
+#pragma unroll
+      for (int it = 0; it < NPW; it++) {
+        const int k = kq + KQW * it;
+        float2 a = h ? make_float2(pa[it].z, pa[it].w) : make_float2(pa[it].x, pa[it].y);
+        float2 bq = h ? make_float2(pb[it].z, pb[it].w) : make_float2(pb[it].x, pb[it].y);
+        if (k == 0) { a.y = 0.f; bq.y = 0.f; }                 // imaginary parts of bins 0 and M/2 are ignored
+        const float2 w = twg[k];                               // W_M^k (L1-resident); W_M^{NF-k} = (-x, y)
+        zf[(k / P2) * G::LA + (k % P2)] = zc(a, bq, w);        // input layout of pass 1: n = P2 r + j
+        if (k > 0) {
+          const int kk = NF - k;
+          zf[(kk / P2) * G::LA + (kk % P2)] = zc(bq, a, make_float2(-w.x, w.y));
+        }
+      }
+      if (kq == 0) { const float2 c = h ? make_float2(pmid.z, pmid.w) : make_float2(pmid.x, pmid.y); zf[((NF / 2) / P2) * G::LA + ((NF / 2) % P2)] = zc(c, c, twm); }
+    }
+    __syncthreads();
+    // ---- B. forward FFT of this wave's FPW frames: conj -> positive-exponent passes -> conj
+    wave_fft<LOG2M, true>(frm + wave * G::FPW * FRS, twj, lane);
+    __syncthreads();
+    // ---- C. polyphase + overlap-add: sample groups qd (+ q 256), blocks fc0 + b - pd, b < TT, in sub-chunks of SB blocks so that only
+    //         SB + HALO frames of the window are live at a time (the scheduler would otherwise hoist all TT + HALO frame reads to the top)
+    const bool emit = fc0 >= f_lo + HALO;
+    constexpr int SB = 4;
+#pragma unroll
+    for (int q = 0; q < QPT; q++) {
+      const int d0 = SPL * (qd + q * F_NT);
+      int zi[R];
+#pragma unroll
+      for (int j = 0; j < R; j++) zi[j] = zidx<LOG2M>((d0 + j * D) >> 1);
+      auto rd = [&](int fr, int j, float (&o)[SPL]) {
+        const float2* zr = frm + fr * FRS + zi[j];
+        const float2 z0 = zr[0];
+        o[0] = z0.x; o[1] = z0.y;
+        if constexpr (SPL == 4) { const float2 z1 = zr[1]; o[2] = z1.x; o[3] = z1.y; }
+      };
+      float win[R][NWF][SPL];
+#pragma unroll
+      for (int j = 0; j < R; j++)
+#pragma unroll
+        for (int w = 0; w < HALO; w++)
+#pragma unroll
+          for (int dd = 0; dd < SPL; dd++) win[j][w][dd] = hist[q][j][w][dd];
+      float gco[SPL][R][F_MT];                                 // g[M-1-(d+jD)+M k], d = d0 + dd: one reversed wide load per (j, k)
+#pragma unroll
+      for (int j = 0; j < R; j++)
+#pragma unroll
+        for (int k = 0; k < F_MT; k++) {
+          if constexpr (SPL == 4) {
+            const float4 g4 = *reinterpret_cast<const float4*>(proto + (M - 4 - (d0 + j * D)) + M * k);
+            gco[0][j][k] = g4.w; gco[1][j][k] = g4.z; gco[2][j][k] = g4.y; gco[3][j][k] = g4.x;
+          } else {
+            const float2 g2 = *reinterpret_cast<const float2*>(proto + (M - 2 - (d0 + j * D)) + M * k);
+            gco[0][j][k] = g2.y; gco[1][j][k] = g2.x;
+          }
+        }
+#pragma unroll
+      for (int sb = 0; sb < BPG; sb += SB) {
+#pragma unroll
+        for (int j = 0; j < R; j++)
+#pragma unroll
+          for (int i = 0; i < SB; i++) rd(sb + i, j, win[j][HALO + sb + i]);
+        if (emit) {
+#pragma unroll
+          for (int b = sb; b < sb + SB; b++) {
+            const long bglob = fc0 + b - pd;
+            float acc[SPL];
+#pragma unroll
+            for (int dd = 0; dd < SPL; dd++) {
+              float a = 0.f;
+#pragma unroll
+              for (int j = 0; j < R; j++) {
+                float sv = 0.f;
+#pragma unroll
+                for (int k = 0; k < F_MT; k++) sv = fmaf(gco[dd][j][k], win[j][b + HALO - (R - 1 - j) - R * k][dd], sv);
+                if (bglob - (R - 1 - j) >= 0) a += sv;         // gsi_ is still zero before block 0 (modulated.cc:574-578,600)
+              }
+              if (gain > 0.f) a *= gain;
+              acc[dd] = a;
+            }
+            if (bglob >= bt0 && bglob < bend) {
+              float* o = os + (bglob - b0) * D + (D - SPL - d0);
+              if constexpr (SPL == 4) *reinterpret_cast<float4*>(o) = make_float4(acc[3], acc[2], acc[1], acc[0]);
+              else *reinterpret_cast<float2*>(o) = make_float2(acc[1], acc[0]);
+            }
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      // history for the next chunk: the last HALO frames of this one
+#pragma unroll
+      for (int j = 0; j < R; j++)
+#pragma unroll
+        for (int w = 0; w < HALO; w++)
+#pragma unroll
+          for (int dd = 0; dd < SPL; dd++) hist[q][j][w][dd] = win[j][BPG + w][dd];
+    }
+    __syncthreads();
+  }
+}
+
 template <int LOG2M, int R>
 int launch_fast_synthesis(const btk_fb* fb, const float2* Y, long nframes, long T_stride, int S, float* out, long out_stride,
                           long b0, long bcount, hipStream_t st)
@@ -789,9 +979,16 @@ int launch_fast_synthesis(const btk_fb* fb, const float2* Y, long nframes, long 
   using G = FG<LOG2M>;
   constexpr int HALO = F_MT * R - 1;
   constexpr int NRING = G::TT + HALO + 1;
-  const size_t lds = sizeof(float2) * ((size_t)NRING * G::FRS + G::NF);
+  size_t lds = sizeof(float2) * ((size_t)NRING * G::FRS + G::NF);
   if (lds > 160 * 1024) return 0;
   auto kern = fast_synthesis_kernel<LOG2M, R>;
+  // the register-history form (M >= 1024): 16-byte rows on both sides -- even frame index of every chunk start (b0 + pd even; runs are
+  // multiples of TT), Y rows and output blocks 16-byte aligned
+  if constexpr (LOG2M >= 10 && R <= 2) {
+    const bool wide = !btk_switches().syn_narrow && ((b0 + fb->pd) & 1) == 0 && (T_stride & 1) == 0 && (out_stride & 3) == 0 &&
+                      (reinterpret_cast<uintptr_t>(Y) & 15) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0;
+    if (wide) { kern = fast_synthesis_w_kernel<LOG2M, R>; lds = sizeof(float2) * ((size_t)G::TT * G::FRS + G::NF); }
+  }
   // per launch: the attribute is per device, and one process may drive several GPUs (btk_set_device)
   BTK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   // shorter runs when few streams would leave the chip empty (see synthesis512): multiples of TT, aiming at >= 512 runs

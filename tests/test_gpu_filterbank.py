@@ -83,7 +83,8 @@ def test_analysis_chunked_equals_whole(dev):
 
 
 @pytest.mark.parametrize("M,m,r,dct", [(256, 4, 1, 2), (256, 4, 1, 0), (512, 4, 1, 2), (64, 4, 1, 1),
-                                       (128, 2, 2, 2), (1024, 4, 1, 2), (2048, 4, 1, 0), (512, 4, 0, 0), (512, 4, 2, 1), (512, 3, 1, 2), (256, 4, 0, 1), (256, 4, 2, 2), (1024, 4, 2, 0), (2048, 4, 2, 0), (2048, 4, 2, 2), (2048, 2, 2, 1)])
+                                       (128, 2, 2, 2), (1024, 4, 1, 2), (2048, 4, 1, 0), (512, 4, 0, 0), (512, 4, 2, 1), (512, 3, 1, 2), (256, 4, 0, 1), (256, 4, 2, 2), (1024, 4, 2, 0), (2048, 4, 2, 0), (2048, 4, 2, 2), (2048, 2, 2, 1),
+                                       (1024, 4, 0, 2), (1024, 4, 1, 0), (2048, 4, 0, 0), (2048, 4, 0, 2), (2048, 4, 1, 2)])
 def test_synthesis_matches_oracle(orc, dev, M, m, r, dct):
     import torch
     eng = _eng()
