@@ -373,6 +373,185 @@ void wpe_herk16_kernel(const float2* __restrict__ X, const float* __restrict__ W
   }
 }
 
+// ---- round 3: the normal equations as LAG PRODUCTS.  Entry [(c1,l1)][(c2,l2)] of R_c is, with u = t - lowerN - l1 and d = l1 - l2,
+//   sum_u  w_c(u + lowerN + l1) * [ y_c1(u) conj(y_c2(u + d)) ]:
+// the bracket does not depend on the target channel c nor on l1, only on (c1, c2, d).  The block HERK above recomputes that complex
+// product for every one of the L - |d| entries of a diagonal and for each of the C target channels (four real matrix instructions per
+// complex block product).  Here the products are formed on the vector ALU -- exactly, in fp32 -- and the matrix cores only apply the
+// REAL weights: a real GEMM
+//   Out[(l1, c)] [(c1, c2, re|im)] = sum_u  Wh[(l1, c)][u] * Pd[u][(c1, c2, re|im)],     Wh[(l1, c)][u] = w_c(u + lowerN + l1)
+// per lag difference d >= 0 (entries with d < 0 are the conjugates of the swapped ordered pair, so all C^2 ordered pairs with d >= 0
+// cover the lower triangle once; d = 0 is computed for both orders and stored from one).  Rows: 32 / C consecutive l1 x C target
+// channels per 32-row block, blocks counted down from l1 = L - 1 so that only the last one is partial; columns: 2 C^2 = 128 at C = 8 =
+// four 32-column blocks.  P = 264: 612 block products of ONE real matrix instruction per two frames against 36 x 8 complex block
+// products of FOUR (1 152): 0.53 x the matrix-core work, no strip kernel, no wasted upper halves of diagonal blocks.
+// One wavefront per workgroup; a task is (d, up to four row blocks): the wavefront holds up to 4 x 4 accumulator blocks (256 AGPRs, one
+// wavefront per SIMD) so that every product feeds four matrix instructions -- on this chip a vector instruction between matrix
+// instructions is not free: profiles/ubench/mfma_war.hip measures 145 TFLOP/s for v_mfma_f32_32x32x2_f32 alone with ONE wavefront per
+// SIMD and 98-107 with two vector instructions per matrix instruction (the one-row-block form of this kernel, 3.5 other instructions per
+// matrix instruction, kept the pipe 52 % busy).  Spans of the C snapshot rows and weight rows of a 64-frame tile are staged per
+// wavefront (register prefetch one tile ahead), operands of frame group g + 1 are read from LDS before the matrix instructions of g.
+constexpr int LP_WT = 64, LP_RMAX = 4;
+
+template <int C, int NR>
+__device__ __forceinline__ void lagprod_task(const float2* __restrict__ Xk, const float* __restrict__ Wk, const WpeGeom& g, float2* __restrict__ R,
+                                             int ys_ld, int ws_ld, int d, int la, int s, int k, float2* ys, float* ws)
+{
+  constexpr int NCB = 2 * C * C / 32;                              // 32-column blocks: col = 2 (c1 C + c2) + (0 re | 1 im)
+  constexpr int RL = 32 / C;                                       // l1 values per 32-row block: row m of block j -> (l1 = la + RL j + m / C, c = m % C)
+  const int lane = threadIdx.x;
+  const int L = g.L, P = C * L;
+  const int YN = LP_WT + L - 1;                                    // samples per channel span (<= 128: L <= 65)
+  constexpr int WN = LP_WT + RL * NR - 1;                          // weights per target-channel span (<= 128)
+  // staging: lane e (and e + 64) of every channel row -- no index arithmetic per element (a flat index over the C x YN tile costs an
+  // integer division by YN per element and tile: a quarter of the tile's cycles at one wavefront per SIMD)
+  float2 ypf[C][2];
+  float wpf[C][2];
+  auto prefetch = [&](long u0) {
+#pragma unroll
+    for (int c = 0; c < C; c++)
+#pragma unroll
+      for (int q = 0; q < 2; q++) {
+        const int e = lane + 64 * q;
+        const long u = u0 + e;
+        ypf[c][q] = (e < YN && u < g.T) ? Xk[(long)c * g.T_stride + u] : make_float2(0.f, 0.f);
+        const long t = u0 + g.lowerN + la + e;
+        wpf[c][q] = (e < WN && t >= g.lowerN && t < g.T) ? Wk[(long)c * g.K * g.T_stride + t] : 0.f;
+      }
+  };
+  f32x16 acc[NR][NCB];
+#pragma unroll
+  for (int j = 0; j < NR; j++)
+#pragma unroll
+    for (int cb = 0; cb < NCB; cb++) acc[j][cb] = f32x16{0};
+  const int m = lane & 31, lk = lane >> 5;
+  // frames of a 4-frame group: lane half lk multiplies frames 4 g + 2 lk + h in the two matrix instructions h = 0, 1, so that its
+  // two operands of a group are ADJACENT in LDS: the first factors come as one 16-byte read
+  const int aoff = (m % C) * ws_ld + m / C + 2 * lk;               // A of block j: Wh[(la + RL j + m / C, m % C)][u0 + 4 g + 2 lk + h] at + RL j
+  const bool im = lane & 1;
+  // B: x = y_c1(u), y = y_c2(u + d), pair = 16 cb + (lane & 31) / 2 = c1 C + c2; 16 % C == 0: c2 = (m / 2) % C for every cb
+  int boffx[NCB];
+#pragma unroll
+  for (int cb = 0; cb < NCB; cb++) boffx[cb] = (((16 * cb + (m >> 1)) / C) * ys_ld) / 2 + lk;       // in float4 units (ys_ld is even)
+  const int boffy = ((m >> 1) % C) * ys_ld + 2 * lk + d;
+  static_assert(16 % C == 0, "the second factor's channel must not depend on the column block");
+  prefetch(0);
+  for (long u0 = 0; u0 < g.T; u0 += LP_WT) {
+    __syncthreads();                                               // (one wavefront: orders the LDS reads of the last tile before the writes)
+#pragma unroll
+    for (int c = 0; c < C; c++)
+#pragma unroll
+      for (int q = 0; q < 2; q++) {
+        const int e = lane + 64 * q;
+        if (e < YN) ys[c * ys_ld + e] = ypf[c][q];
+        if (e < WN) ws[c * ws_ld + e] = wpf[c][q];
+      }
+    __syncthreads();
+    if (u0 + LP_WT < g.T) prefetch(u0 + LP_WT);
+    struct Ops { float a[NR][2]; float2 y[2]; float2 x[NCB][2]; };
+    auto fetch = [&](Ops& o, int kk) {
+#pragma unroll
+      for (int h = 0; h < 2; h++) {
+#pragma unroll
+        for (int j = 0; j < NR; j++) o.a[j][h] = ws[aoff + RL * j + kk + h];
+        o.y[h] = ys[boffy + kk + h];                             // (odd d: not 16-byte aligned)
+      }
+#pragma unroll
+      for (int cb = 0; cb < NCB; cb++) {
+        const float4 x4 = reinterpret_cast<const float4*>(ys)[boffx[cb] + kk / 2];
+        o.x[cb][0] = make_float2(x4.x, x4.y); o.x[cb][1] = make_float2(x4.z, x4.w);
+      }
+    };
+    auto mult = [&](const Ops& o) {
+#pragma unroll
+      for (int h = 0; h < 2; h++) {
+        // x conj(y): re = x.x y.x + x.y y.y, im = x.y y.x - x.x y.y
+        const float p = im ? -o.y[h].y : o.y[h].x, q = im ? o.y[h].x : o.y[h].y;
+#pragma unroll
+        for (int cb = 0; cb < NCB; cb++) {
+          const float b = fmaf(o.x[cb][h].x, p, o.x[cb][h].y * q);
+#pragma unroll
+          for (int j = 0; j < NR; j++) acc[j][cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(o.a[j][h], b, acc[j][cb], 0, 0, 0);
+        }
+      }
+    };
+    Ops o0, o1;
+    fetch(o0, 0);
+#pragma unroll
+    for (int kk = 0; kk < LP_WT; kk += 8) {
+      fetch(o1, kk + 4);
+      __builtin_amdgcn_sched_barrier(0);                            // (the scheduler otherwise sinks the reads to their first use)
+      mult(o0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (kk + 8 < LP_WT) fetch(o0, kk + 8);
+      __builtin_amdgcn_sched_barrier(0);
+      mult(o1);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  // ---- store: register r of lane -> row (r & 3) + 8 (r >> 2) + 4 lk, column lane & 31.  With p = c1 L + l1, q = c2 L + l1 - d the
+  // entry goes to [p][q] when c1 >= c2 and, conjugated, to [q][p] otherwise; both offsets are  const(c1, c2, d) + l1 (P + 1)
+  static_assert(C == 8 || C == 4, "row -> (l1, c) below");
+  const int c1c2 = m >> 1;
+  float* Rc[4];                                                    // matrices of the target channels of this lane's rows
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const int c = (C == 8) ? i + 4 * lk : i;                       // row % C for row = i + 8 (r >> 2) + 4 lk
+    Rc[i] = reinterpret_cast<float*>(R + (((long)s * C + c) * g.K + k) * (long)P * P) + (im ? 1 : 0);
+  }
+#pragma unroll
+  for (int cb = 0; cb < NCB; cb++) {
+    const int pair = 16 * cb + c1c2, c1 = pair / C, c2 = pair % C;
+    const bool lower = c1 >= c2;
+    const bool skip = (d == 0 && c1 < c2);                         // the swapped pair stores this entry
+    const long off0 = lower ? (long)c1 * L * P + (long)c2 * L - d : ((long)c2 * L - d) * P + (long)c1 * L;
+    const float sgn = (!lower && im) ? -1.f : 1.f;
+#pragma unroll
+    for (int j = 0; j < NR; j++) {
+#pragma unroll
+      for (int reg = 0; reg < 16; reg++) {
+        const int row = (reg & 3) + 8 * (reg >> 2) + 4 * lk;
+        const int l1 = la + RL * j + row / C;                      // C = 8: la + 4 j + (reg >> 2); C = 4: la + 8 j + 2 (reg >> 2) + lk
+        if (l1 < d || skip) continue;                              // (also l1 < 0: la < 0 only in the partial block)
+        Rc[reg & 3][2 * (off0 + (long)l1 * (P + 1))] = sgn * acc[j][cb][reg];
+      }
+      __builtin_amdgcn_sched_barrier(0);                            // (one accumulator block at a time out of the AGPRs)
+    }
+  }
+}
+
+template <int C>
+__global__ __launch_bounds__(64)
+void wpe_lagprod_kernel(const float2* __restrict__ X, const float* __restrict__ Winv, WpeGeom g, float2* __restrict__ R, int ys_ld, int ws_ld)
+{
+  constexpr int RL = 32 / C;
+  static_assert(2 * C * C / 32 >= 1 && 2 * C * C / 32 <= 4 && 32 % C == 0, "C in {4, 8}");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float2* ys = reinterpret_cast<float2*>(smem);                    // [C][ys_ld]: sample u0 + e of channel c'
+  float* ws = reinterpret_cast<float*>(ys + C * ys_ld);            // [C][ws_ld]: w_c(u0 + lowerN + la + e)
+  const int k = blockIdx.y, s = blockIdx.z;
+  if (!bin_active(g, k)) return;
+  const int L = g.L;
+  // task -> (d, group of up to LP_RMAX row blocks counted down from l1 = L - 1)
+  int d = 0, grp = blockIdx.x;
+  auto nblk = [&](int dd) { return (L - dd + RL - 1) / RL; };
+  auto ngrp = [&](int dd) { return (nblk(dd) + LP_RMAX - 1) / LP_RMAX; };
+  while (grp >= ngrp(d)) { grp -= ngrp(d); d++; }
+  // the row blocks of d are spread evenly over its groups (9 -> 3 + 3 + 3, 5 -> 3 + 2): a one-block task runs at half the efficiency
+  const int nbd = nblk(d), ng = ngrp(d), base = nbd / ng, extra = nbd % ng;
+  const int nb = base + (grp < extra ? 1 : 0);
+  const int first = grp * base + (grp < extra ? grp : extra);      // row blocks above this group (counted down from l1 = L - 1)
+  const int la = L - RL * (first + nb);                            // lowest l1 of the task (rows with l1 < d are not stored)
+  const float2* Xk = X + ((long)s * g.K + k) * C * g.T_stride;
+  const float* Wk = Winv + ((long)s * C * g.K + k) * g.T_stride;   // + c K T_stride
+  switch (nb) {
+    case 4: lagprod_task<C, 4>(Xk, Wk, g, R, ys_ld, ws_ld, d, la, s, k, ys, ws); break;
+    case 3: lagprod_task<C, 3>(Xk, Wk, g, R, ys_ld, ws_ld, d, la, s, k, ys, ws); break;
+    case 2: lagprod_task<C, 2>(Xk, Wk, g, R, ys_ld, ws_ld, d, la, s, k, ys, ws); break;
+    default: lagprod_task<C, 1>(Xk, Wk, g, R, ys_ld, ws_ld, d, la, s, k, ys, ws); break;
+  }
+}
+
 // r_c[p] = sum_t conj(y_c(t)) ybar_p(t) / theta_c(t)
 __global__ __launch_bounds__(256)
 void wpe_rvec_kernel(const float2* __restrict__ X, const float* __restrict__ Winv, WpeGeom g, float2* __restrict__ rvec)
@@ -526,7 +705,18 @@ int btk_wpe_estimate(const void* X, int S, int K, int C, long T_stride, long T, 
     const size_t lds32 = sizeof(float2) * 2 * (size_t)nspan32 * (WT_ + g.L - 1) + sizeof(float) * 4 * WT_;
     const size_t lds16 = sizeof(float2) * 2 * (size_t)nspan64 * (WT_ + g.L - 1) + sizeof(float) * 4 * WT_;
     const unsigned nstrip = (unsigned)((P + 63) / 64);
-    if (skip && C % 4 == 0) {
+    const bool lagprod = skip && !btk_switches().wpe_herk_blocks && (C == 8 || C == 4) && g.L <= 65 && g.L >= 32 / C;
+    if (lagprod) {
+      // tasks: for every lag difference d the row blocks of l1 = d .. L-1 in groups of LP_RMAX
+      const int RL = 32 / C;
+      unsigned ntask = 0;
+      for (int d = 0; d < g.L; d++) ntask += (unsigned)(((g.L - d + RL - 1) / RL + LP_RMAX - 1) / LP_RMAX);
+      int ys_ld = LP_WT + g.L - 1; while (ys_ld % 32 != 4) ys_ld++;          // float2 row pitch: channel rows 8 banks apart (16-byte reads of the two lane halves 4 apart)
+      int ws_ld = LP_WT + RL * LP_RMAX - 1; while (ws_ld % 64 != (C == 8 ? 8 : 16)) ws_ld++;    // weight rows 8 / 16 banks apart: a wavefront's read2 touches 7 / 13 consecutive words per row
+      const size_t lds_lp = sizeof(float2) * (size_t)C * ys_ld + sizeof(float) * (size_t)C * ws_ld;
+      if (C == 8) hipLaunchKernelGGL(wpe_lagprod_kernel<8>, dim3(ntask, (unsigned)K, (unsigned)S), dim3(64), lds_lp, st, Xp, Winv, g, R, ys_ld, ws_ld);
+      else        hipLaunchKernelGGL(wpe_lagprod_kernel<4>, dim3(ntask, (unsigned)K, (unsigned)S), dim3(64), lds_lp, st, Xp, Winv, g, R, ys_ld, ws_ld);
+    } else if (skip && C % 4 == 0) {
       hipLaunchKernelGGL(wpe_herk32_kernel<4>, dim3(nblk, (unsigned)K, (unsigned)(S * C / 4)), dim3(64), lds32, st, Xp, Winv, g, R, nspan32);
       if (strip) hipLaunchKernelGGL(wpe_herk16_kernel<4>, dim3(nstrip, (unsigned)K, (unsigned)(S * C / 4)), dim3(64), lds16, st, Xp, Winv, g, R, nspan64, nb32 * 32);
     } else if (skip && C % 2 == 0) {

@@ -15,7 +15,7 @@ for r in csv.DictReader(open(sys.argv[1])):
     dur[(k, r["Dispatch_Id"])] = (float(r["End_Timestamp"]) - float(r["Start_Timestamp"])) / 1e3
 lines = ["# MFMA counters per dispatch (mean), %s" % sys.argv[1]]
 for k in rows:
-    if not any(s in k for s in ("cov_mfma", "wpe_herk")):
+    if not any(s in k for s in ("cov_mfma", "wpe_herk", "wpe_lagprod", "wpe_solve")):
         continue
     c = {a: sum(v) / len(v) for a, v in rows[k].items()}
     d = [v for (kk, _), v in dur.items() if kk == k]
