@@ -8,8 +8,13 @@ whole block through the HIP kernels and then serves frames from a host mirror, s
 keeps the reference's per-frame semantics (node-owned buffer, same-frame caching, end-of-stream).
 """
 import os as _os
-if _os.environ.get("BTK20_BACKEND") == "cpp":
+BACKEND = _os.environ.get("BTK20_BACKEND", "cpp")
+if BACKEND == "cpp":
+    # the C++ node layer (host/, pybind11): the default.  BTK20_BACKEND=python selects the ctypes mirror below, which is kept as the
+    # executable specification the C++ nodes are tested against (same tests, both backends)
     from ..btk20cpp import *   # noqa: F401,F403
+elif BACKEND != "python":
+    raise ImportError("BTK20_BACKEND must be 'cpp' or 'python', got %r" % BACKEND)
 else:
     from .common import *      # noqa: F401,F403
     from .stream import *      # noqa: F401,F403

@@ -411,8 +411,11 @@ class SubbandGSCPtr(SubbandDSPtr):
         self._bfw[0].wl[:] = 0
         self._invalidate_output()
 
-    def blocking_matrix(self, fbin_no):
-        return self._bfw[0].B[fbin_no]
+    def blocking_matrix(self, srcX, fbin_no=None):
+        """blocking_matrix(srcX, fbinX) (beamformer.h:186); the one-argument form of earlier rounds means source 0."""
+        if fbin_no is None:
+            srcX, fbin_no = 0, srcX
+        return self._bfw[srcX].B[fbin_no]
 
     calcGSCWeights, setActiveWeights_f, getBlockingMatrix = calc_gsc_weights, set_active_weights_f, blocking_matrix
 

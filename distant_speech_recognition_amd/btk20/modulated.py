@@ -21,13 +21,7 @@ def _pull_all(src):
     return out
 
 
-def _mirror(Yk, M):
-    """[K][T] bins 0..M/2 -> [T][M] complex128 with conjugate mirror bins."""
-    K, T = Yk.shape
-    full = np.empty((T, M), np.complex128)
-    full[:, :K] = Yk.T
-    full[:, K:] = np.conj(full[:, M // 2 - 1:0:-1])
-    return full
+from .._hostutil import mirror_bins as _mirror  # noqa: E402
 
 
 class OverSampledDFTAnalysisBankPtr(_BlockServedStream, VectorComplexFeatureStream):

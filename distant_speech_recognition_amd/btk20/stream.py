@@ -7,18 +7,7 @@ from .common import jconsistency_error, jiterator_error, raise_from_code
 __all__ = ["FeatureStream", "VectorFloatFeatureStream", "VectorComplexFeatureStream",
            "PyVectorFloatFeatureStreamPtr", "PyVectorComplexFeatureStreamPtr", "device"]
 
-_DEVICE = None
-
-
-def device():
-    """The HIP device every node of this process uses (one process per GPU)."""
-    global _DEVICE
-    if _DEVICE is None:
-        import torch
-        if not torch.cuda.is_available():
-            raise RuntimeError("btk20 nodes compute on an MI355X: no HIP device visible (there is no CPU fallback)")
-        _DEVICE = torch.device("cuda", torch.cuda.current_device())
-    return _DEVICE
+from .._hostutil import device  # noqa: E402,F401  (one device per process, shared with the C++ node layer)
 
 
 class FeatureStream(object):

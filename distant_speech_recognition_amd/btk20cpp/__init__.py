@@ -22,3 +22,115 @@ _spec.loader.exec_module(_mod)
 
 globals().update({k: v for k, v in vars(_mod).items() if not k.startswith("_")})
 __all__ = [k for k in vars(_mod) if not k.startswith("_")]
+
+# ---- the part of the module surface that is not a C++ class
+from .._hostutil import device, device_tensor  # noqa: E402
+
+j_error = _mod.j_error
+SSPEED = 343740.0                              # beamformer/beamformer.h:26
+TYPE_ZELINSKI1_REAL, TYPE_ZELINSKI1_ABS, TYPE_APAB, TYPE_ZELINSKI2, NO_USE_POST_FILTER = 0x01, 0x02, 0x04, 0x08, 0x00   # postfilter.h:18-24
+
+
+class jarithmetic_error(j_error, ArithmeticError):
+    pass
+
+
+class jinitialization_error(j_error):
+    pass
+
+
+class jkey_error(j_error, KeyError):
+    pass
+
+
+class jparse_error(j_error):
+    pass
+
+
+class jtype_error(j_error, TypeError):
+    pass
+
+
+jiterator_error = StopIteration               # jexception.i:20-29 maps it there; the binding raises StopIteration directly
+
+
+def calc_all_delays(x, y, z, mpos):
+    """calc_all_delays (beamformer.cc:1172-1189)."""
+    import numpy as np
+    mpos = np.asarray(mpos, np.float64)
+    d = np.sqrt(np.sum(mpos[:, :3] ** 2, axis=1)) / SSPEED
+    return d - d[len(d) // 2]
+
+
+def _device_snapshots(self):
+    """X complex64 [1][K][N][T] on the device, a torch view of the node's own block (no copy)."""
+    ptr, K, N, T = self._device_snapshots_info()
+    return device_tensor(ptr, (1, K, N, T), self)
+
+
+_mod.SubbandBeamformer.device_snapshots = _device_snapshots
+
+def _set_noise_spatial_spectral_matrices(self, R):
+    """All bins at once from a [K][N][N] array or device tensor: set_noise_spatial_spectral_matrix per bin (beamformer.h:331)."""
+    import numpy as np
+    Rh = R.detach().cpu().numpy() if hasattr(R, "detach") else np.asarray(R)
+    for k in range(Rh.shape[0]):
+        self.set_noise_spatial_spectral_matrix(k, np.ascontiguousarray(Rh[k]).astype(np.complex128))
+
+
+_mod.SubbandMVDRPtr.set_noise_spatial_spectral_matrices = _set_noise_spatial_spectral_matrices
+
+
+# ---- keyword names and legacy aliases of the SWIG interface (see _signatures.py)
+def _with_names(f, params, what):
+    names = [p for p, _ in params]
+
+    def call(self, *args, **kw):
+        if kw:
+            args = list(args)
+            for p, dflt in params[len(args):]:
+                if p in kw:
+                    args.append(kw.pop(p))
+                elif kw and dflt is not None:
+                    args.append(dflt)
+                else:
+                    break
+            if kw:
+                raise TypeError("%s() got an unexpected keyword argument %r (parameters: %s)" % (what, sorted(kw)[0], ", ".join(names)))
+        return f(self, *args)
+    call.__name__ = getattr(f, "__name__", what)
+    call.__doc__ = getattr(f, "__doc__", None)
+    return call
+
+
+def _apply_signatures():
+    from . import _signatures as S
+    for cname, cls in vars(_mod).items():
+        if not isinstance(cls, type):
+            continue
+        for mname in list(vars(cls)):
+            params = S.CLASS_METHOD_KWARGS.get(cname, {}).get(mname) or S.METHOD_KWARGS.get(mname)
+            if params and callable(vars(cls)[mname]):
+                setattr(cls, mname, _with_names(vars(cls)[mname], params, "%s.%s" % (cname, mname)))
+        if cname in S.CTOR_KWARGS:
+            cls.__init__ = _with_names(cls.__init__, S.CTOR_KWARGS[cname], cname)
+    for cname, table in S.ALIASES.items():
+        cls = getattr(_mod, cname)
+        for alias, target in table.items():
+            if not hasattr(cls, alias):
+                setattr(cls, alias, getattr(cls, target))
+
+
+_apply_signatures()
+
+# the reference exports every class under both names (X and XPtr, modulated.i:124-140 etc.)
+SampleFeature = _mod.SampleFeaturePtr
+OverSampledDFTAnalysisBank, OverSampledDFTSynthesisBank = _mod.OverSampledDFTAnalysisBankPtr, _mod.OverSampledDFTSynthesisBankPtr
+SubbandDS, SubbandGSC, SubbandGSCRLS = _mod.SubbandDSPtr, _mod.SubbandGSCPtr, _mod.SubbandGSCRLSPtr
+SubbandMVDR, SubbandMVDRGSC = _mod.SubbandMVDRPtr, _mod.SubbandMVDRGSCPtr
+ZelinskiPostFilter, McCowanPostFilter, LefkimmiatisPostFilter = _mod.ZelinskiPostFilterPtr, _mod.McCowanPostFilterPtr, _mod.LefkimmiatisPostFilterPtr
+
+__all__ += ["device", "SSPEED", "TYPE_ZELINSKI1_REAL", "TYPE_ZELINSKI1_ABS", "TYPE_APAB", "TYPE_ZELINSKI2", "NO_USE_POST_FILTER",
+            "jarithmetic_error", "jinitialization_error", "jkey_error", "jparse_error", "jtype_error", "jiterator_error", "calc_all_delays",
+            "SampleFeature", "OverSampledDFTAnalysisBank", "OverSampledDFTSynthesisBank", "SubbandDS", "SubbandGSC", "SubbandGSCRLS",
+            "SubbandMVDR", "SubbandMVDRGSC", "ZelinskiPostFilter", "McCowanPostFilter", "LefkimmiatisPostFilter"]

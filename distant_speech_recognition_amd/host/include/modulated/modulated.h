@@ -18,6 +18,7 @@ class BlockSource {
   virtual unsigned long block_version() = 0;                 // changes whenever the frames not yet handed over may have changed
   virtual const std::vector<float>& block(long& T) = 0;      // complex64 [>= K rows][T], row k = bin k, frames <= the mark unchanged
   virtual void advance_to(long frame_idx) = 0;               // a per-frame graph would have pulled frames 0 .. frame_idx by now
+  virtual bool has_block() { return true; }                  // a wrapper around a foreign object (pyStream) may have no block to offer: drain next()
 };
 #include "btkhip.h"
 

@@ -306,6 +306,7 @@ void OverSampledDFTSynthesisBank::prepare_()
 {
   const unsigned K = M_ / 2 + 1;
   bsrc_ = dynamic_cast<BlockSource*>(samp_.operator->());
+  if (bsrc_ && !bsrc_->has_block()) bsrc_ = NULL;
   if (bsrc_) {
     // an engine node upstream: take its whole block (it is not advanced), keep what was already served; next() tells it after
     // every block how far a per-frame graph would have pulled, so that a later weight change touches only the frames beyond

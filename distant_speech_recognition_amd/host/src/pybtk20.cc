@@ -96,7 +96,7 @@ py::array copy_of(const gsl_matrix_complex* m) {
 
 // ---- a Python object as a source node (reference stream/pyStream.h:25-168)
 template <class Base, class VecT, class T>
-class PyStream : public Base {
+class PyStream : public Base, public BlockSource {
  public:
   PyStream(py::object c, const String& nm) : Base(size_of_(c), nm), cont_(c), iter_(c.attr("__iter__")()) {}
   ~PyStream() { py::gil_scoped_acquire g; cont_ = py::object(); iter_ = py::object(); }
@@ -122,12 +122,59 @@ class PyStream : public Base {
     iter_ = cont_.attr("__iter__")();
     Base::reset();
   }
+  py::object python_object() const { return cont_; }
+  // BlockSource: a GPU-backed Python beamformer (pybeamformer.*, or anything with device_block() -> complex [.. K][T], optionally
+  // _output_version() / _advance_to(idx)) hands its whole block to a batching C++ consumer; plain iterators have none and are drained
+  bool has_block() override { py::gil_scoped_acquire g; return py::hasattr(cont_, "device_block"); }
+  unsigned long block_version() override {
+    py::gil_scoped_acquire g;
+    return py::hasattr(cont_, "_output_version") ? cont_.attr("_output_version")().template cast<unsigned long>() : 0ul;
+  }
+  const std::vector<float>& block(long& Tn) override {
+    py::gil_scoped_acquire g;
+    py::object b = cont_.attr("device_block")();
+    if (py::hasattr(b, "detach")) b = b.attr("detach")().attr("cpu")().attr("numpy")();      // a torch tensor
+    py::array_t<std::complex<float>, py::array::c_style | py::array::forcecast> a(b);
+    if (a.ndim() < 2) throw jdimension_error("device_block() must return [.. K][T], got %d-d", (int)a.ndim());
+    const size_t K = (size_t)a.shape(a.ndim() - 2);
+    Tn = (long)a.shape(a.ndim() - 1);
+    blk_.resize(2 * K * (size_t)Tn);
+    memcpy(blk_.data(), a.data(), sizeof(float) * blk_.size());
+    return blk_;
+  }
+  void advance_to(long idx) override {
+    py::gil_scoped_acquire g;
+    if (py::hasattr(cont_, "_advance_to")) cont_.attr("_advance_to")(idx);
+  }
  private:
   static unsigned size_of_(const py::object& c) { return c.attr("size")().cast<unsigned>(); }
   py::object cont_, iter_;
+  std::vector<float> blk_;
 };
 typedef PyStream<VectorFloatFeatureStream, gsl_vector_float, float> PyVectorFloatFeatureStream;
 typedef PyStream<VectorComplexFeatureStream, gsl_vector_complex, cd> PyVectorComplexFeatureStream;
+
+// a bound node is used as it is; any other Python object with size() / __iter__ / next() / reset() becomes a source node (the
+// reference wants the explicit PyVector*FeatureStreamPtr(obj) wrapper, stream/pyStream.h:25-168; both spellings work here)
+VectorComplexFeatureStreamPtr as_cstream(const py::object& o)
+{
+  if (py::isinstance<VectorComplexFeatureStream>(o)) return VectorComplexFeatureStreamPtr(o.cast<VectorComplexFeatureStream*>());
+  return VectorComplexFeatureStreamPtr(new PyVectorComplexFeatureStream(o, "PyVectorComplexFeatureStream"));
+}
+VectorFloatFeatureStreamPtr as_fstream(const py::object& o)
+{
+  if (py::isinstance<VectorFloatFeatureStream>(o)) return VectorFloatFeatureStreamPtr(o.cast<VectorFloatFeatureStream*>());
+  return VectorFloatFeatureStreamPtr(new PyVectorFloatFeatureStream(o, "PyVectorFloatFeatureStream"));
+}
+py::array block_of(BlockSource& b)
+{
+  long T = 0;
+  const std::vector<float>& y = b.block(T);
+  const py::ssize_t K = T > 0 ? (py::ssize_t)(y.size() / 2 / (size_t)T) : 0;
+  py::array_t<std::complex<float>> a({(py::ssize_t)1, K, (py::ssize_t)T});
+  if (T > 0) memcpy(static_cast<void*>(a.mutable_data()), y.data(), sizeof(float) * 2 * (size_t)K * (size_t)T);
+  return std::move(a);
+}
 
 template <class S, class C>
 void bind_stream_methods(C& cls)
@@ -183,9 +230,11 @@ PYBIND11_MODULE(_btk20cpp, m)
   bind_stream_methods<VectorComplexFeatureStream>(vc);
 
   py::class_<PyVectorFloatFeatureStream, VectorFloatFeatureStream, cref<PyVectorFloatFeatureStream>>(m, "PyVectorFloatFeatureStreamPtr")
-      .def(py::init([](py::object c, const std::string& nm) { return new PyVectorFloatFeatureStream(c, nm); }), py::arg("c"), py::arg("nm") = "PyVectorFloatFeatureStream");
+      .def(py::init([](py::object c, const std::string& nm) { return new PyVectorFloatFeatureStream(c, nm); }), py::arg("c"), py::arg("nm") = "PyVectorFloatFeatureStream")
+      .def("python_object", &PyVectorFloatFeatureStream::python_object);
   py::class_<PyVectorComplexFeatureStream, VectorComplexFeatureStream, cref<PyVectorComplexFeatureStream>>(m, "PyVectorComplexFeatureStreamPtr")
-      .def(py::init([](py::object c, const std::string& nm) { return new PyVectorComplexFeatureStream(c, nm); }), py::arg("c"), py::arg("nm") = "PyVectorComplexFeatureStream");
+      .def(py::init([](py::object c, const std::string& nm) { return new PyVectorComplexFeatureStream(c, nm); }), py::arg("c"), py::arg("nm") = "PyVectorComplexFeatureStream")
+      .def("python_object", &PyVectorComplexFeatureStream::python_object);
 
   // ---- feature/feature.h
   py::class_<SampleFeature, VectorFloatFeatureStream, cref<SampleFeature>>(m, "SampleFeaturePtr")
@@ -203,9 +252,9 @@ PYBIND11_MODULE(_btk20cpp, m)
 
   // ---- modulated/modulated.h
   py::class_<OverSampledDFTAnalysisBank, VectorComplexFeatureStream, cref<OverSampledDFTAnalysisBank>>(m, "OverSampledDFTAnalysisBankPtr")
-      .def(py::init([](VectorFloatFeatureStream* samp, py::array_t<double, py::array::c_style | py::array::forcecast> prototype, unsigned M, unsigned mm,
+      .def(py::init([](py::object samp, py::array_t<double, py::array::c_style | py::array::forcecast> prototype, unsigned M, unsigned mm,
                        unsigned r, unsigned dct, const std::string& nm) {
-             VectorFloatFeatureStreamPtr sp(samp);
+             VectorFloatFeatureStreamPtr sp = as_fstream(samp);
              GslVec h(prototype);
              return new OverSampledDFTAnalysisBank(sp, h.v, M, mm, r, dct, nm);
            }), py::arg("samp"), py::arg("prototype"), py::arg("M"), py::arg("m"), py::arg("r"), py::arg("delay_compensation_type") = 0,
@@ -214,9 +263,9 @@ PYBIND11_MODULE(_btk20cpp, m)
       .def("fftLen", &OverSampledDFTAnalysisBank::fftlen)
       .def("shiftlen", &OverSampledDFTAnalysisBank::shiftlen);
   py::class_<OverSampledDFTSynthesisBank, VectorFloatFeatureStream, cref<OverSampledDFTSynthesisBank>>(m, "OverSampledDFTSynthesisBankPtr")
-      .def(py::init([](VectorComplexFeatureStream* samp, py::array_t<double, py::array::c_style | py::array::forcecast> prototype, unsigned M, unsigned mm,
+      .def(py::init([](py::object samp, py::array_t<double, py::array::c_style | py::array::forcecast> prototype, unsigned M, unsigned mm,
                        unsigned r, unsigned dct, int gain_factor, const std::string& nm) {
-             VectorComplexFeatureStreamPtr sp(samp);
+             VectorComplexFeatureStreamPtr sp = as_cstream(samp);
              GslVec g(prototype);
              return new OverSampledDFTSynthesisBank(sp, g.v, M, mm, r, dct, gain_factor, nm);
            }), py::arg("samp"), py::arg("prototype"), py::arg("M"), py::arg("m"), py::arg("r") = 0, py::arg("delay_compensation_type") = 0,
@@ -240,8 +289,11 @@ PYBIND11_MODULE(_btk20cpp, m)
       .def("getSpecMatrix", [](SpectralMatrixArray& a, unsigned idx) { return copy_of(a.matrix_f(idx)); });
 
   py::class_<SubbandBeamformer, VectorComplexFeatureStream, cref<SubbandBeamformer>>(m, "SubbandBeamformer")
-      .def("set_channel", [](SubbandBeamformer& b, VectorComplexFeatureStream* chan) { VectorComplexFeatureStreamPtr p(chan); b.set_channel(p); })
-      .def("setChannel", [](SubbandBeamformer& b, VectorComplexFeatureStream* chan) { VectorComplexFeatureStreamPtr p(chan); b.set_channel(p); })
+      .def("set_channel", [](SubbandBeamformer& b, py::object chan) { VectorComplexFeatureStreamPtr p = as_cstream(chan); b.set_channel(p); })
+      .def("setChannel", [](SubbandBeamformer& b, py::object chan) { VectorComplexFeatureStreamPtr p = as_cstream(chan); b.set_channel(p); })
+      .def("_device_snapshots_info", [](SubbandBeamformer& b) {      // (device pointer, K, N, T) of the complex64 [K][N][T] snapshot block
+             void* p = b.device_snapshots();
+             return py::make_tuple((size_t)reinterpret_cast<uintptr_t>(p), (long)(b.fftLen() / 2 + 1), (long)b.chanN(), b.num_frames()); })
       .def("clear_channel", [](SubbandBeamformer& b) { b.clear_channel(); })
       .def("clearChannel", [](SubbandBeamformer& b) { b.clear_channel(); })
       .def("chan_num", &SubbandBeamformer::chanN)
@@ -252,6 +304,30 @@ PYBIND11_MODULE(_btk20cpp, m)
       .def("num_frames", &SubbandBeamformer::num_frames)
       .def("is_half_band_shift", &SubbandBeamformer::is_half_band_shift)
       .def("snapshot_array_f", [](SubbandBeamformer& b, unsigned fbinX) { return copy_of(b.snapshot_array_f(fbinX)); });
+
+  // BeamformerWeights (beamformer.h:26-97), owned by its beamformer node: whole-array views of the reference's per-bin accessors
+  py::class_<BeamformerWeights, std::unique_ptr<BeamformerWeights, py::nodelete>>(m, "BeamformerWeights")
+      .def("fftLen", &BeamformerWeights::fftLen)
+      .def("chanN", &BeamformerWeights::chanN)
+      .def("NC", &BeamformerWeights::NC)
+      .def("isHalfBandShift", &BeamformerWeights::isHalfBandShift)
+      .def("wq_f", [](BeamformerWeights& w, unsigned fbinX) { if (fbinX >= w.fftLen()) throw jindex_error("bin %d of %d", (int)fbinX, (int)w.fftLen()); return copy_of(w.wq_f(fbinX)); })
+      .def("wl_f", [](BeamformerWeights& w, unsigned fbinX) { if (fbinX >= w.fftLen()) throw jindex_error("bin %d of %d", (int)fbinX, (int)w.fftLen()); return copy_of(w.wl_f(fbinX)); })
+      .def_property_readonly("wq", [](BeamformerWeights& w) {
+             py::array_t<cd> a({(py::ssize_t)w.fftLen(), (py::ssize_t)w.chanN()});
+             memcpy(static_cast<void*>(a.mutable_data()), w.wq_v.data(), sizeof(cd) * w.wq_v.size()); return a; })
+      .def_property_readonly("wl", [](BeamformerWeights& w) {
+             py::array_t<cd> a({(py::ssize_t)w.fftLen(), (py::ssize_t)w.chanN()});
+             memcpy(static_cast<void*>(a.mutable_data()), w.wl_v.data(), sizeof(cd) * w.wl_v.size()); return a; })
+      .def_property_readonly("ta", [](BeamformerWeights& w) {
+             py::array_t<cd> a({(py::ssize_t)w.fftLen(), (py::ssize_t)w.chanN()});
+             memcpy(static_cast<void*>(a.mutable_data()), w.ta_v.data(), sizeof(cd) * w.ta_v.size()); return a; })
+      .def_property_readonly("wa", [](BeamformerWeights& w) {
+             py::array_t<cd> a({(py::ssize_t)w.fftLen(), (py::ssize_t)(w.chanN() - w.NC())});
+             memcpy(static_cast<void*>(a.mutable_data()), w.wa_v.data(), sizeof(cd) * w.wa_v.size()); return a; })
+      .def_property_readonly("B", [](BeamformerWeights& w) {
+             py::array_t<cd> a({(py::ssize_t)w.fftLen(), (py::ssize_t)w.chanN(), (py::ssize_t)(w.chanN() - w.NC())});
+             memcpy(static_cast<void*>(a.mutable_data()), w.B_v.data(), sizeof(cd) * w.B_v.size()); return a; });
 
   py::class_<SubbandDS, SubbandBeamformer, cref<SubbandDS>>(m, "SubbandDSPtr")
       .def(py::init([](unsigned fftlen, bool half_band_shift, const std::string& nm) { return new SubbandDS(fftlen, half_band_shift, nm); }),
@@ -265,7 +341,14 @@ PYBIND11_MODULE(_btk20cpp, m)
                                                py::array_t<double, py::array::c_style | py::array::forcecast> djs, unsigned NC) {
              GslVec a(dt); GslMat c(djs); b.calc_array_manifold_vectors_n(fs, a.v, c.m, NC); }, py::arg("samplerate"), py::arg("delays_t"), py::arg("delays_js"), py::arg("NC") = 2)
       .def("get_weights", [](SubbandDS& b, unsigned fbinX) { return copy_of(b.get_weights(fbinX)); })
-      .def("getWeights", [](SubbandDS& b, unsigned fbinX) { return copy_of(b.get_weights(fbinX)); });
+      .def("getWeights", [](SubbandDS& b, unsigned fbinX) { return copy_of(b.get_weights(fbinX)); })
+      .def("beamformer_weight_object", [](SubbandDS& b, unsigned srcX) -> py::object {
+             BeamformerWeights* w = b.beamformer_weight_object(srcX);
+             return w ? py::cast(w, py::return_value_policy::reference) : py::object(py::none()); }, py::arg("srcX") = 0, py::keep_alive<0, 1>())
+      // the block protocol a batching consumer uses (modulated/modulated.h BlockSource), under the names of the Python-side protocol
+      .def("device_block", [](SubbandDS& b) { return block_of(b); })
+      .def("_output_version", [](SubbandDS& b) { return b.block_version(); })
+      .def("_advance_to", [](SubbandDS& b, long idx) { b.advance_to(idx); });
 
   py::class_<SubbandGSC, SubbandDS, cref<SubbandGSC>>(m, "SubbandGSCPtr")
       .def(py::init([](unsigned fftlen, bool half_band_shift, const std::string& nm) { return new SubbandGSC(fftlen, half_band_shift, nm); }),
@@ -327,16 +410,19 @@ PYBIND11_MODULE(_btk20cpp, m)
 
   // ---- postfilter/postfilter.h
   py::class_<ZelinskiPostFilter, VectorComplexFeatureStream, cref<ZelinskiPostFilter>>(m, "ZelinskiPostFilterPtr")
-      .def(py::init([](VectorComplexFeatureStream* output, unsigned fftlen, double alpha, int type, int min_frames, const std::string& nm) {
-             VectorComplexFeatureStreamPtr p(output);
+      .def(py::init([](py::object output, unsigned fftlen, double alpha, int type, int min_frames, const std::string& nm) {
+             VectorComplexFeatureStreamPtr p = as_cstream(output);
              return new ZelinskiPostFilter(p, fftlen, alpha, type, min_frames, nm);
            }), py::arg("output"), py::arg("fftlen"), py::arg("alpha") = 0.6, py::arg("type") = 2, py::arg("min_frames") = 0, py::arg("nm") = "ZelinskPostFilter")
       .def("set_beamformer", [](ZelinskiPostFilter& f, SubbandDS* bf) { SubbandDSPtr p(bf); f.set_beamformer(p); })
       .def("setBeamformer", [](ZelinskiPostFilter& f, SubbandDS* bf) { SubbandDSPtr p(bf); f.set_beamformer(p); })
-      .def("postfilter_weights", [](ZelinskiPostFilter& f) { return copy_of(f.postfilter_weights()); });
+      .def("postfilter_weights", [](ZelinskiPostFilter& f) { return copy_of(f.postfilter_weights()); })
+      .def("device_block", [](ZelinskiPostFilter& f) { return block_of(f); })
+      .def("_output_version", [](ZelinskiPostFilter& f) { return f.block_version(); })
+      .def("_advance_to", [](ZelinskiPostFilter& f, long idx) { f.advance_to(idx); });
   py::class_<McCowanPostFilter, ZelinskiPostFilter, cref<McCowanPostFilter>>(m, "McCowanPostFilterPtr")
-      .def(py::init([](VectorComplexFeatureStream* output, unsigned fftlen, double alpha, int type, int min_frames, float threshold, const std::string& nm) {
-             VectorComplexFeatureStreamPtr p(output);
+      .def(py::init([](py::object output, unsigned fftlen, double alpha, int type, int min_frames, float threshold, const std::string& nm) {
+             VectorComplexFeatureStreamPtr p = as_cstream(output);
              return new McCowanPostFilter(p, fftlen, alpha, type, min_frames, threshold, nm);
            }), py::arg("output"), py::arg("fftlen"), py::arg("alpha") = 0.6, py::arg("type") = 2, py::arg("min_frames") = 0, py::arg("threshold") = 0.99f,
            py::arg("nm") = "McCowanPostFilter")
@@ -351,9 +437,9 @@ PYBIND11_MODULE(_btk20cpp, m)
       .def("divide_nondiagonal_elements", &McCowanPostFilter::divide_nondiagonal_elements)
       .def("divide_all_nondiagonal_elements", &McCowanPostFilter::divide_all_nondiagonal_elements);
   py::class_<LefkimmiatisPostFilter, McCowanPostFilter, cref<LefkimmiatisPostFilter>>(m, "LefkimmiatisPostFilterPtr")
-      .def(py::init([](VectorComplexFeatureStream* output, unsigned fftlen, double min_sv, unsigned fbin_x1, double alpha, int type, int min_frames,
+      .def(py::init([](py::object output, unsigned fftlen, double min_sv, unsigned fbin_x1, double alpha, int type, int min_frames,
                        float threshold, const std::string& nm) {
-             VectorComplexFeatureStreamPtr p(output);
+             VectorComplexFeatureStreamPtr p = as_cstream(output);
              return new LefkimmiatisPostFilter(p, fftlen, min_sv, fbin_x1, alpha, type, min_frames, threshold, nm);
            }), py::arg("output"), py::arg("fftlen"), py::arg("min_sv") = 1.0E-8, py::arg("fbin_x1") = 0, py::arg("alpha") = 0.6, py::arg("type") = 2,
            py::arg("min_frames") = 0, py::arg("threshold") = 0.99f, py::arg("nm") = "LefkimmiatisPostFilter")
@@ -368,10 +454,11 @@ PYBIND11_MODULE(_btk20cpp, m)
            py::arg("load_db") = -20.0, py::arg("band_width") = 0.0, py::arg("diagonal_bias") = 0.0, py::arg("samplerate") = 16000.0)
       .def("size", &MultiChannelWPEDereverberation::size)
       .def("reset", &MultiChannelWPEDereverberation::reset)
-      .def("set_input", [](MultiChannelWPEDereverberation& w, VectorComplexFeatureStream* s) { VectorComplexFeatureStreamPtr p(s); w.set_input(p); })
+      .def("set_input", [](MultiChannelWPEDereverberation& w, py::object s) { VectorComplexFeatureStreamPtr p = as_cstream(s); w.set_input(p); })
       .def("estimate_filter", &MultiChannelWPEDereverberation::estimate_filter, py::arg("start_frame_no") = 0, py::arg("frame_num") = -1)
       .def("reset_filter", &MultiChannelWPEDereverberation::reset_filter)
       .def("next_speaker", &MultiChannelWPEDereverberation::next_speaker)
+      .def("print_objective_func", &MultiChannelWPEDereverberation::print_objective_func)
       .def("frame_no", &MultiChannelWPEDereverberation::frame_no);
   py::class_<MultiChannelWPEDereverberationFeature, VectorComplexFeatureStream, cref<MultiChannelWPEDereverberationFeature>>(m, "MultiChannelWPEDereverberationFeaturePtr")
       .def(py::init([](MultiChannelWPEDereverberation* source, unsigned channel_no, unsigned primary_channel_no, const std::string& nm) {
@@ -379,13 +466,14 @@ PYBIND11_MODULE(_btk20cpp, m)
              return new MultiChannelWPEDereverberationFeature(p, channel_no, primary_channel_no, nm);
            }), py::arg("source"), py::arg("channel_no"), py::arg("primary_channel_no") = 0, py::arg("nm") = "MultiChannelWPEDereverberationFeature");
   py::class_<SingleChannelWPEDereverberationFeature, VectorComplexFeatureStream, cref<SingleChannelWPEDereverberationFeature>>(m, "SingleChannelWPEDereverberationFeaturePtr")
-      .def(py::init([](VectorComplexFeatureStream* samples, unsigned lower_num, unsigned upper_num, unsigned iterations_num, double load_db, double band_width,
+      .def(py::init([](py::object samples, unsigned lower_num, unsigned upper_num, unsigned iterations_num, double load_db, double band_width,
                        double samplerate, const std::string& nm) {
-             VectorComplexFeatureStreamPtr p(samples);
+             VectorComplexFeatureStreamPtr p = as_cstream(samples);
              return new SingleChannelWPEDereverberationFeature(p, lower_num, upper_num, iterations_num, load_db, band_width, samplerate, nm);
            }), py::arg("samples"), py::arg("lower_num"), py::arg("upper_num"), py::arg("iterations_num") = 2, py::arg("load_db") = -20.0,
            py::arg("band_width") = 0.0, py::arg("samplerate") = 16000.0, py::arg("nm") = "SingleChannelWPEDereverberationFeature")
       .def("estimate_filter", &SingleChannelWPEDereverberationFeature::estimate_filter, py::arg("start_frame_no") = 0, py::arg("frame_num") = -1)
       .def("reset_filter", &SingleChannelWPEDereverberationFeature::reset_filter)
-      .def("next_speaker", &SingleChannelWPEDereverberationFeature::next_speaker);
+      .def("next_speaker", &SingleChannelWPEDereverberationFeature::next_speaker)
+      .def("print_objective_func", &SingleChannelWPEDereverberationFeature::print_objective_func);
 }

@@ -13,9 +13,8 @@ iterator behaviour; the per-frame / per-bin numpy loops are replaced by HIP kern
 import numpy as np
 
 from . import engine
-from .btk20.beamformer import SSPEED, SubbandDSPtr, SubbandGSCPtr, SubbandMVDRGSCPtr
-from .btk20.modulated import _mirror
-from .btk20.stream import device
+from .btk20 import SSPEED, SubbandDSPtr, SubbandGSCPtr, SubbandMVDRGSCPtr      # whichever host layer btk20 resolves to
+from ._hostutil import mirror_bins as _mirror, device
 
 
 # ------------------------------------------------------------------ delays (pybeamformer.py:41-153)

@@ -222,7 +222,7 @@ def test_subband_gscrls_node(orc, dev, proto256, kinect_pcm, wavs):
     ref = o.run(X)
     assert frames.shape == ref.shape
     assert np.max(np.abs(frames - ref)) <= 1e-4 * np.max(np.abs(ref))
-    assert np.max(np.abs(bf._bfw[0].wl[: M // 2 + 1] - o.wl[: M // 2 + 1])) <= 1e-4 * max(np.max(np.abs(o.wl)), 1e-30)
+    assert np.max(np.abs(bf.beamformer_weight_object(0).wl[: M // 2 + 1] - o.wl[: M // 2 + 1])) <= 1e-4 * max(np.max(np.abs(o.wl)), 1e-30)
 
 
 def test_smimvdr_batch_flow(orc, dev, proto256, kinect_pcm, wavs):
@@ -392,7 +392,7 @@ def test_subband_mvdrgsc_node(orc, dev, proto256, kinect_pcm, wavs, bm):
         assert np.max(np.abs(v - want)) < 1e-5 * np.max(np.abs(X[t]))
     # upgrade_blocking_matrix: B_k <- calc_blocking_matrix_(wq_k - wl_k) (wq = the weight object's quiescent vector)
     bf.upgrade_blocking_matrix()
-    bw = bf._bfw[0]
+    bw = bf.beamformer_weight_object(0)
     # (calc_blocking_matrix2 leaves wq = 0 above M/2: the reference's -1/|w|^2 projector turns those bins into NaN there too)
     for k in (1, 17, M // 2) + ((M - 3,) if bm == 1 else ()):
         wk = bw.wq[k] - bw.wl[k]

@@ -23,7 +23,7 @@ def test_sample_feature_block_reader(tmp_path):
     """SampleFeature::next (feature/feature.cc:605-649): un-normalised int16 -> float, pad_zeros, the `cur + size >= total`
     end rule (a last block that fits exactly is treated as the padded tail), explicit frame numbers, end of samples."""
     from distant_speech_recognition_amd.btk20 import SampleFeaturePtr
-    from distant_speech_recognition_amd.btk20.common import jindex_error
+    from distant_speech_recognition_amd.btk20 import jindex_error
     x = (np.arange(1000) - 500).astype(np.int16)
     p = tmp_path / "a.wav"
     _wav(p, x)
