@@ -261,7 +261,9 @@ PYBIND11_MODULE(_btk20cpp, m)
            py::arg("nm") = "OverSampledDFTAnalysisBank")
       .def("fftlen", &OverSampledDFTAnalysisBank::fftlen)
       .def("fftLen", &OverSampledDFTAnalysisBank::fftlen)
-      .def("shiftlen", &OverSampledDFTAnalysisBank::shiftlen);
+      .def("shiftlen", &OverSampledDFTAnalysisBank::shiftlen)
+      .def("nBlocks", &OverSampledDFTAnalysisBank::nBlocks)
+      .def("subSampRate", &OverSampledDFTAnalysisBank::subSampRate);
   py::class_<OverSampledDFTSynthesisBank, VectorFloatFeatureStream, cref<OverSampledDFTSynthesisBank>>(m, "OverSampledDFTSynthesisBankPtr")
       .def(py::init([](py::object samp, py::array_t<double, py::array::c_style | py::array::forcecast> prototype, unsigned M, unsigned mm,
                        unsigned r, unsigned dct, int gain_factor, const std::string& nm) {
@@ -303,7 +305,9 @@ PYBIND11_MODULE(_btk20cpp, m)
       .def("dim", &SubbandBeamformer::dim)
       .def("num_frames", &SubbandBeamformer::num_frames)
       .def("is_half_band_shift", &SubbandBeamformer::is_half_band_shift)
-      .def("snapshot_array_f", [](SubbandBeamformer& b, unsigned fbinX) { return copy_of(b.snapshot_array_f(fbinX)); });
+      .def("snapshot_array_f", [](SubbandBeamformer& b, unsigned fbinX) { return copy_of(b.snapshot_array_f(fbinX)); })
+      .def("snapshot_array", [](SubbandBeamformer& b) { SnapShotArrayPtr a = b.snapshot_array(); return cref<SnapShotArray>(a.operator->()); })
+      .def("getSnapShotArray", [](SubbandBeamformer& b) { SnapShotArrayPtr a = b.snapshot_array(); return cref<SnapShotArray>(a.operator->()); });
 
   // BeamformerWeights (beamformer.h:26-97), owned by its beamformer node: whole-array views of the reference's per-bin accessors
   py::class_<BeamformerWeights, std::unique_ptr<BeamformerWeights, py::nodelete>>(m, "BeamformerWeights")

@@ -1,2 +1,2 @@
 mkdir -p gpurun_out/cpp
-timeout 1500 python -m pytest tests/ -m gpu -q --tb=short --deselect tests/test_gpu_fullsize_properties.py 2>&1 | grep -v "^E   *$" | tail -150 > gpurun_out/cpp/test.txt
+timeout 1500 python -m pytest tests/ -m gpu -q --tb=short 2>&1 | grep -v "^E   *$" | tail -150 > gpurun_out/cpp/test.txt
