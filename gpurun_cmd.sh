@@ -1,2 +1,3 @@
-mkdir -p gpurun_out/cpp
-timeout 1500 python -m pytest tests/ -m gpu -q --tb=short 2>&1 | grep -v "^E   *$" | tail -150 > gpurun_out/cpp/test.txt
+mkdir -p gpurun_out/bench
+python bench.py > gpurun_out/bench/bench.json 2> gpurun_out/bench/bench.err
+python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > gpurun_out/bench/smoke.txt 2>&1
