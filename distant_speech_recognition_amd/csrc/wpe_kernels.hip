@@ -477,7 +477,7 @@ __device__ __forceinline__ void lagprod_task(const float2* __restrict__ Xk, cons
     };
     Ops o0, o1;
     fetch(o0, 0);
-#pragma unroll
+#pragma unroll 1
     for (int kk = 0; kk < LP_WT; kk += 8) {
       fetch(o1, kk + 4);
       __builtin_amdgcn_sched_barrier(0);                            // (the scheduler otherwise sinks the reads to their first use)

@@ -1,3 +1,2 @@
-mkdir -p gpurun_out/bench
-python bench.py > gpurun_out/bench/bench.json 2> gpurun_out/bench/bench.err
-python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > gpurun_out/bench/smoke.txt 2>&1
+mkdir -p gpurun_out/wpe
+timeout 900 python -m pytest tests/test_gpu_wpe.py -m gpu -q 2>&1 | grep -E "passed|failed|FAILED|Error" > gpurun_out/wpe/test.txt

@@ -21,7 +21,10 @@ def _reverberant(rng, T, C, M):
     return Y
 
 
-@pytest.mark.parametrize("C,M,T,lower,upper,iters", [(2, 64, 120, 0, 5, 2), (3, 64, 90, 1, 4, 2), (4, 64, 150, 0, 15, 1), (1, 64, 100, 2, 6, 2)])
+@pytest.mark.parametrize("C,M,T,lower,upper,iters", [(2, 64, 120, 0, 5, 2), (3, 64, 90, 1, 4, 2), (4, 64, 150, 0, 15, 1), (1, 64, 100, 2, 6, 2),
+                                                    # the lag-product kernel (4 / 8 channels): delayed prediction (own r-vector kernel), lag counts that leave partial row
+                                                    # blocks, frame counts that are not a multiple of its 64-frame tile
+                                                    (8, 32, 200, 1, 10, 2), (4, 64, 130, 2, 11, 2), (8, 16, 331, 0, 12, 1)])
 def test_wpe_matches_oracle(orc, dev, C, M, T, lower, upper, iters):
     import torch
     from distant_speech_recognition_amd import engine as eng
