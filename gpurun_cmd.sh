@@ -1,2 +1,2 @@
 mkdir -p gpurun_out/wpe
-timeout 900 python -m pytest tests/test_gpu_wpe.py -m gpu -q 2>&1 | grep -E "passed|failed|FAILED|Error" > gpurun_out/wpe/test.txt
+cd profiles/ubench && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -w -o /tmp/mfma_war mfma_war.hip && /tmp/mfma_war > ../../gpurun_out/wpe/mfma_war.txt 2>&1

@@ -97,8 +97,75 @@ void run16(int wg)
   hipFree(out);
 }
 
+// the inner loop of wpe_lagprod_kernel in isolation: sixteen accumulator blocks, per two frames four products formed from LDS operands
+// MODE bit 0: B operands come from vector instructions (mul + fma + select), bit 1: operands are re-read from LDS every step
+template <int MODE>
+__global__ __launch_bounds__(64) void k16m(float* out, int iters, float seed)
+{
+  __shared__ float4 lds[1024];
+  for (int i = threadIdx.x; i < 1024; i += 64) lds[i] = make_float4(seed + i, seed - i, 0.5f * i, 1.0f);
+  __syncthreads();
+  f32x16 c[16];
+#pragma unroll
+  for (int i = 0; i < 16; i++) c[i] = f32x16{0};
+  const int lane = threadIdx.x;
+  float4 x[4]; float4 y; float a[4];
+#pragma unroll
+  for (int q = 0; q < 4; q++) { x[q] = lds[(lane + 17 * q) & 1023]; a[q] = seed + q; }
+  y = lds[(lane * 3) & 1023];
+  const bool im = lane & 1;
+  for (int i = 0; i < iters; i++) {
+    if (MODE & 2) {
+#pragma unroll
+      for (int q = 0; q < 4; q++) x[q] = lds[(lane + 17 * q + 4 * i) & 1023];
+      y = lds[(lane * 3 + i) & 1023];
+      const float4 aa = lds[(lane + 7 * i) & 1023];
+      a[0] = aa.x; a[1] = aa.y; a[2] = aa.z; a[3] = aa.w;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+      const float yx = h ? y.z : y.x, yy = h ? y.w : y.y;
+      const float p = im ? -yy : yx, q2 = im ? yx : yy;
+#pragma unroll
+      for (int cb = 0; cb < 4; cb++) {
+        const float xx = h ? x[cb].z : x[cb].x, xy = h ? x[cb].w : x[cb].y;
+        float b = (MODE & 1) ? fmaf(xx, p, xy * q2) : xx;
+#pragma unroll
+        for (int j = 0; j < 4; j++) c[4 * j + cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], b, c[4 * j + cb], 0, 0, 0);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (!(MODE & 2)) asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(y.x), "+v"(y.y), "+v"(y.z), "+v"(y.w));
+  }
+  float s = 0;
+#pragma unroll
+  for (int i = 0; i < 16; i++)
+    for (int r = 0; r < 16; r++) s += c[i][r];
+  out[blockIdx.x * 64 + threadIdx.x] = s;
+}
+
+template <int MODE> void run16m(const char* name, int wg, int iters)
+{
+  float* out; hipMalloc(&out, sizeof(float) * 64 * wg);
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  hipLaunchKernelGGL(k16m<MODE>, dim3(wg), dim3(64), 0, 0, out, 100, 1.0f);
+  hipEventRecord(e0);
+  hipLaunchKernelGGL(k16m<MODE>, dim3(wg), dim3(64), 0, 0, out, iters, 1.0f);
+  hipEventRecord(e1); hipEventSynchronize(e1);
+  float ms; hipEventElapsedTime(&ms, e0, e1);
+  printf("%-58s %5d wavefronts x %5d steps: %8.3f ms -> %.1f TFLOP/s\n", name, wg, iters, ms, (double)wg * iters * 32 * 4096 / ms / 1e9);
+  hipFree(out);
+}
+
 int main()
 {
+  for (int it : {2000, 20000}) {
+    run16m<0>("lagprod loop: matrix instructions only", 1024, it);
+    run16m<1>("lagprod loop: + vector products", 1024, it);
+    run16m<2>("lagprod loop: + LDS operand reads", 1024, it);
+    run16m<3>("lagprod loop: + both", 1024, it);
+  }
   run16(1024); run16(2048); run16(4096);
   for (int wg : {1024, 2048, 4096}) {
     run<0>("matrix instructions only", wg);
