@@ -1,2 +1,2 @@
-mkdir -p gpurun_out/wpe
-cd profiles/ubench && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -w -o /tmp/mfma_war mfma_war.hip && /tmp/mfma_war > ../../gpurun_out/wpe/mfma_war.txt 2>&1
+mkdir -p gpurun_out/syn
+timeout 900 python -m pytest tests/test_gpu_fullsize_properties.py -m gpu -q 2>&1 | grep -E "passed|failed|FAILED|Error|assert" > gpurun_out/syn/test.txt

@@ -70,6 +70,35 @@ def test_reconstruction_at_scale_reference_prototypes(dev, proto256):
     assert float(snr.min()) > 50.0, snr
 
 
+@pytest.mark.parametrize("M,S,N,T", [(1024, 16, 4, 2048), (2048, 8, 4, 1024)])
+def test_reconstruction_at_scale_designed_prototypes(dev, M, S, N, T):
+    """The same identity for the BASELINE geometries M = 1024 / 2048 (prototypes of the reference's designer, shipped as data) at a
+    launch that fills the chip: analysis -> pick one channel -> synthesis (the register-history synthesis kernel of round 3) gives the
+    input back at lag 0 for every stream, and a stream synthesised alone equals its rows of the batched launch."""
+    import torch
+    from distant_speech_recognition_amd import engine as eng, prototypes
+    h, g = prototypes.load(M, 4, 1)
+    D, K = M // 2, M // 2 + 1
+    afb = eng.FilterBank(h, M, 4, 1, 2)
+    sfb = eng.FilterBank(g, M, 4, 1, 2, synthesis=True)
+    L = (T - afb.processing_delay + afb.lookahead) * D
+    gen = torch.Generator(device=dev).manual_seed(M)
+    noise = torch.randn((S, N, L + 7), device=dev, generator=gen) * 3000
+    pcm = noise.unfold(-1, 8, 1).mean(dim=-1).round_().contiguous()           # smoothed noise at int16 scale (the designer's stop band is finite)
+    X = afb.analysis(pcm)
+    W = torch.zeros((K, N), dtype=torch.complex64, device=dev)
+    W[:, 1] = 1.0                                                              # pick channel 1
+    Y = eng.bf_apply(W, X)
+    y = sfb.synthesize(Y)
+    n = min(y.shape[1], L)
+    a, b = 8 * M, n - 8 * M
+    x = pcm[:, 1, a:b]
+    err = y[:, a:b] - x
+    snr = 10 * torch.log10((x ** 2).sum(dim=1) / (err ** 2).sum(dim=1))
+    assert float(snr.min()) > 45.0, snr
+    assert torch.equal(sfb.synthesize(Y[2:3].contiguous()), y[2:3])
+
+
 def test_c4_full_launch_properties(dev):
     """256 mics, 2048 bins: apply is linear, the all-ones/N weight returns the channel mean, bin shards tile the launch"""
     import torch
