@@ -7,7 +7,8 @@ cp $R/pmc_fused_sq.txt profiles/r03_pmc_fused_sq.txt; cp $R/fused_ab.txt profile
 cp $R/bench_stages.json profiles/r03_bench_stages.json; cp $R/bench_configs.json profiles/r03_bench_configs.json
 cp $R/bench_bin_sharded.json profiles/r03_bench_bin_sharded.json
 (head -3 $R/fused_phase_timing.txt; echo "..."; tail -4 $R/fused_phase_timing.txt) > profiles/r03_fused_phase_timing.txt
-cp $R/wpe_profile.txt profiles/r03_wpe_kernel_stats.txt; cp $R/fb_ab.txt profiles/r03_fb_ab.txt; cp $R/mvdr_solve.json profiles/r03_mvdr_solve.json
+cp $R/mvdr_solve.json profiles/r03_mvdr_solve.json
+# (profiles/r03_wpe_kernel_stats.txt, r03_fb_ab.txt, r03_pinv_bench.txt are curated by hand from wpe_profile.txt, fb_ab*.txt, pinv_bench.txt of the runs that produced them)
 python - <<'PY'
 import json, csv, collections
 out = []

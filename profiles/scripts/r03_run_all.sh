@@ -26,5 +26,8 @@ for v in 79; do BTK_FUSED_VAR=$v PROBE_SECONDS=6 python profiles/clock_probe.py 
 WPE_S=2 bash profiles/scripts/r02_wpe_profile.sh > $O/wpe_profile.txt 2>&1
 BTK_WPE_TIMING=1 WPE_S=2 python profiles/wpe_one.py 2>&1 | grep -E "phases|wpe_estimate" | tail -2 >> $O/wpe_profile.txt
 python profiles/fb_ab.py 2>/dev/null | tail -4 > $O/fb_ab.txt
+BTK_SYN_NARROW=1 python profiles/fb_ab.py 2>/dev/null | tail -4 > $O/fb_ab_round2_synthesis.txt
+BTK_WPE_HERK_BLOCKS=1 WPE_S=2 python profiles/wpe_one.py 2>&1 | grep wpe_estimate | tail -1 > $O/wpe_round2_herk.txt
+python profiles/pinv_bench.py > $O/pinv_bench.txt 2>/dev/null
 python profiles/mvdr256_time.py 2>/dev/null | tail -1 > $O/mvdr_solve.json
 tail -1 $O/smoke.log; ls $O
