@@ -32,8 +32,14 @@ constexpr int WSTR = 320;              // float4 per channel in the weight-pair 
 
 constexpr int A_RUN = 16;             // consecutive tiles (16 frames each) one workgroup walks through
 
+// Round 3: FOUR workgroups per CU instead of three.  The PCM span of the next tile is no longer carried in registers through the tile
+// (24 VGPRs; the kernel now fits 126) but fetched at the top of its own tile, where the other three workgroups of the CU cover its
+// latency: 5.70 -> 5.06 ms per 32 streams x 64 channels x 4096 frames on row-padded snapshots (0.57 -> 0.64 of the HBM roofline),
+// 1.72 -> 1.35 ms in profiles/fb_ab.py.
+constexpr int ANA512_WGS = 4;
+constexpr bool ANA512_PREFETCH = false;
 template <int R, bool SHARD>     // R = M / D in {1, 2, 4}; SHARD: only the bins [k0, k1) are stored
-__global__ __launch_bounds__(A_NT, 3)
+__global__ __launch_bounds__(A_NT, ANA512_WGS)
 void analysis512_kernel(const float* __restrict__ pcm, long nsamples, long pcm_stride,
                         const float* __restrict__ proto, const float2* __restrict__ twg,
                         int laN, float gain, int N, int K, float2* __restrict__ X,
@@ -104,9 +110,10 @@ void analysis512_kernel(const float* __restrict__ pcm, long nsamples, long pcm_s
   const long kstride = (long)N * T_stride;
   const float hg = 0.5f * gain;
 
-  fetch(tile_first);
+  if (ANA512_PREFETCH) fetch(tile_first);
   for (int tile = tile_first; tile < tile_end; tile++) {
     const long tt0 = (long)tile * A_TT;
+    if (!ANA512_PREFETCH) fetch(tile);
     // ---- phase 1: registers -> LDS span, then start fetching the next tile
 #pragma unroll
     for (int q = 0; q < NV4; q++) {
@@ -114,7 +121,7 @@ void analysis512_kernel(const float* __restrict__ pcm, long nsamples, long pcm_s
       if (l < SPAN) *reinterpret_cast<float4*>(xs + l) = pre[q];
     }
     __syncthreads();
-    if (tile + 1 < tile_end) fetch(tile + 1);
+    if (ANA512_PREFETCH && tile + 1 < tile_end) fetch(tile + 1);
 
     // ---- phase 2: polyphase with a sliding register window.  With D = M / R the windows of the pair indices n and
     //      n + D/2 are the same LDS words shifted by one frame, so a thread takes G = 2 such indices (n0, n0 + 128)

@@ -296,16 +296,21 @@ void fast_analysis_kernel(const float* __restrict__ pcm, long nsamples, long pcm
   const long kstride = (long)N * T_stride;
   const float hg = 0.5f * gain;
 
-  fetch(tile_first);
+  // Round 3: the span of the next tile is NOT carried in registers through the FFT passes any more (6-15 float4 per thread; at
+  // M = 2048 that spilled 56-63 registers at two workgroups per CU): it is fetched at the top of its own tile and the other
+  // workgroups of the CU cover the latency.  profiles/fb_ab.py: M = 256 1.84 -> 1.65 ms, M = 1024 1.73 -> 1.56, M = 2048 2.13 -> 1.92
+  constexpr bool PREFETCH = false;
+  if (PREFETCH) fetch(tile_first);
   for (int tile = tile_first; tile < tile_end; tile++) {
     const long tt0 = (long)tile * TT;
+    if (!PREFETCH) fetch(tile);
 #pragma unroll
     for (int q = 0; q < NV4; q++) {
       const int l = (tid + q * F_NT) * 4;
       if (l < SPAN) *reinterpret_cast<float4*>(xs + l) = pre[q];
     }
     __syncthreads();
-    if (tile + 1 < tile_end) fetch(tile + 1);
+    if (PREFETCH && tile + 1 < tile_end) fetch(tile + 1);
 
     // ---- polyphase with register windows (all windows are pulled before the frames overwrite the span)
     {
@@ -485,7 +490,8 @@ void fast_analysis_bf_kernel(const float* __restrict__ pcm, long nsamples, long 
   for (int it = 0; it < NIT; it++) acc[it] = make_float2(0.f, 0.f);
   float2 accN = make_float2(0.f, 0.f);                          // bin NF = M/2 (kq == 0 threads)
 
-  // M >= 1024: the span prefetch (12-24 float4 per thread) does not fit next to the accumulators -> fetched at the top
+  // M >= 1024: the span prefetch (12-24 float4 per thread) does not fit next to the accumulators -> fetched at the top.  (Unlike the
+  // staged analysis kernel above, this one keeps its prefetch at M = 256: without it 2.86 -> 3.08 ms, profiles/fused256_ab.py.)
   constexpr bool PREFETCH = LOG2M <= 9;
   if (PREFETCH) fetch(0);
   for (int n = 0; n < N; n++) {
