@@ -1,2 +1,2 @@
-mkdir -p gpurun_out/cpp
-timeout 1500 python -m pytest tests/ -m gpu -q --tb=short 2>&1 | grep -v "^E   *$" | tail -50 > gpurun_out/cpp/test.txt
+mkdir -p gpurun_out/bench
+python bench.py > gpurun_out/bench/bench.json 2> gpurun_out/bench/bench.err
