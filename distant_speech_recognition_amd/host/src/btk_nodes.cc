@@ -611,7 +611,7 @@ void BeamformerWeights::calcSidelobeCancellerP_f(unsigned fbinX, const gsl_vecto
 
 // ================================================================================ SubbandBeamformer
 SubbandBeamformer::SubbandBeamformer(unsigned fftLen, bool halfBandShift, const String& nm)
-    : VectorComplexFeatureStream(fftLen, nm), snapshot_array_(NULL), halfBandShift_(halfBandShift), dXfull_(NULL), fftLen_(fftLen),
+    : VectorComplexFeatureStream(fftLen, nm), halfBandShift_(halfBandShift), dXfull_(NULL), snapshot_array_(NULL), fftLen_(fftLen),
       fftLen2_(fftLen / 2), dX_(NULL), T_(0) {}
 SubbandBeamformer::~SubbandBeamformer() { free_device_(); }
 void SubbandBeamformer::free_device_() { dev_free(dX_); dX_ = NULL; dev_free(dXfull_); dXfull_ = NULL; T_ = 0; Xhost_.clear(); }
