@@ -71,6 +71,91 @@ void wpe_predict_kernel(const float2* __restrict__ X, const float2* __restrict__
 }
 
 
+// ---- round 3: the prediction y_c(t) - g_c^H ybar(t) on the matrix cores (C >= 4 channels).  Per stream and bin it is a complex GEMM
+// [C x P] . [P x T]: the C target channels share the lag matrix.  The vector kernel above spends 264 dependent multiply-adds per
+// output (15 TFLOP/s, 4.7 ms per call at 16 streams -- twice per estimate and once per apply).  Here a workgroup of four wavefronts owns
+// 256 frames of one (stream, bin): conj(G) [C][P] and the C channel spans are staged in LDS once, a wavefront multiplies its 64 frames
+// (four 16 x 16 tiles) on v_mfma_f32_16x16x4_f32: rows = target channel (C <= 16 of 16 used), columns = frames, four taps per step.
+// A[i][k] comes from lane i + 16 k (G), B[k][j] from lane j + 16 k (the sample y_c'(t_j - lowerN - l) of tap p = 4 q + k = c' L + l),
+// D[i][j] lands in register v of lane l with i = 4 (l / 16) + v, j = l % 16.
+constexpr int PM_FW = 64, PM_FG = 4 * PM_FW;                       // frames per wavefront / workgroup
+__global__ __launch_bounds__(256)
+void wpe_predict_mfma_kernel(const float2* __restrict__ X, const float2* __restrict__ G, WpeGeom g, int mode,
+                             float* __restrict__ Winv, float2* __restrict__ OUT, int g_ld, int sp_ld)
+{
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float2* gs = reinterpret_cast<float2*>(smem);                    // [C][g_ld]: conj-ready filter taps (zero where a tap does not apply)
+  float2* sp = gs + g.C * g_ld;                                    // [C][sp_ld]: samples t0 - lowerN - (L - 1) .. t0 + PM_FG - 1 - lowerN of every channel
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int k = blockIdx.y, s = blockIdx.z;
+  const long t0 = (long)blockIdx.x * PM_FG;
+  const int C = g.C, L = g.L, P = C * L;
+  const float2* Xk = X + ((long)s * g.K + k) * C * g.T_stride;
+  const bool active = bin_active(g, k);
+  // apply-time ring (dereverberation.cc:471-480): only the last L frames exist, i.e. taps l > L - 1 - lowerN never apply
+  const int lmax = (mode == 1) ? L - 1 - g.lowerN : L - 1;
+  for (int idx = tid; idx < C * g_ld; idx += 256) {
+    const int c = idx / g_ld, p = idx - c * g_ld;
+    float2 v = make_float2(0.f, 0.f);
+    if (active && p < P && (p % L) <= lmax) v = G[(((long)s * C + c) * g.K + k) * (long)P + p];
+    gs[idx] = v;
+  }
+  const int SPW = PM_FG + L - 1;
+  for (int idx = tid; idx < C * SPW; idx += 256) {
+    const int c = idx / SPW, e = idx - c * SPW;
+    const long i = t0 - g.lowerN - (L - 1) + e;
+    sp[c * sp_ld + e] = (i >= 0 && i < g.T) ? Xk[(long)c * g.T_stride + i] : make_float2(0.f, 0.f);
+  }
+  __syncthreads();
+  const int mi = lane & 15, mk = lane >> 4;
+  f32x4 dr[4], di[4];
+#pragma unroll
+  for (int cb = 0; cb < 4; cb++) { dr[cb] = f32x4{0.f, 0.f, 0.f, 0.f}; di[cb] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+  // tap of this lane group in step q: p = 4 q + mk = cp L + l
+  int cp = mk / L, l = mk % L;
+  const int fbase = wave * PM_FW + mi + (L - 1);                   // span index of frame (wave, tile 0, column mi) at lag 0
+  const int nstep = (P + 3) / 4;
+  for (int q = 0; q < nstep; q++) {
+    const float2 gv = (mi < C && 4 * q + mk < P) ? gs[mi * g_ld + 4 * q + mk] : make_float2(0.f, 0.f);
+    const float ngi = -gv.y;
+    const bool pv = cp < C;
+    const float2* row = sp + (pv ? cp : 0) * sp_ld + fbase - l;
+#pragma unroll
+    for (int cb = 0; cb < 4; cb++) {
+      float2 y = row[16 * cb];
+      if (!pv) y = make_float2(0.f, 0.f);
+      // conj(g) y = (gr yr + gi yi) + i (gr yi - gi yr)
+      dr[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(gv.x, y.x, dr[cb], 0, 0, 0);
+      dr[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(gv.y, y.y, dr[cb], 0, 0, 0);
+      di[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(gv.x, y.y, di[cb], 0, 0, 0);
+      di[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(ngi, y.x, di[cb], 0, 0, 0);
+    }
+    l += 4;
+    while (l >= L) { l -= L; cp++; }
+  }
+  // ---- epilogue: rows c = 4 mk + v < C, frame t = t0 + 64 wave + 16 cb + mi
+#pragma unroll
+  for (int cb = 0; cb < 4; cb++) {
+    const long t = t0 + wave * PM_FW + 16 * cb + mi;
+    if (t >= g.T) continue;
+#pragma unroll
+    for (int v = 0; v < 4; v++) {
+      const int c = 4 * mk + v;
+      if (c >= C) continue;
+      const float2 y = sp[c * sp_ld + wave * PM_FW + 16 * cb + mi + (L - 1) + g.lowerN];       // y_c(t): the span starts lowerN + L - 1 before t0
+      const bool pred = t >= g.lowerN;
+      const float drr = y.x - (pred ? dr[cb][v] : 0.f), dii = y.y - (pred ? di[cb][v] : 0.f);
+      if (mode == 0) {
+        float th = sqrtf(drr * drr + dii * dii);
+        if (th < 1.0e-3f) th = 1.0e-3f;                               // subband_floor_
+        Winv[(((long)s * C + c) * g.K + k) * g.T_stride + t] = 1.0f / (th * th);
+      } else {
+        OUT[(((long)s * g.K + k) * C + c) * g.T_stride + t] = make_float2(drr, dii);
+      }
+    }
+  }
+}
+
 // grid: (lower-triangle tile pairs, K, S*C/CB).  The lag matrix is the same for all target channels -- only the weights
 // 1/theta_c differ -- so one workgroup accumulates the tiles of CB channels from ONE staging of the lag rows.
 // Staging: row (c', l) of the lag matrix is the snapshot row of channel c' shifted by l, so a 64-row tile x WT_ frames
@@ -647,6 +732,29 @@ WpeGeom make_geom(int K, int C, int lowerN, int upperN, int lower_bw, int upper_
   return g;
 }
 
+
+// prediction pass: matrix-core kernel for 4..16 channels, the vector kernel otherwise (and with BTK_WPE_PREDICT_VALU set)
+int launch_wpe_predict(const float2* X, const float2* G, const WpeGeom& g, int S, int mode, float* Winv, float2* OUT, hipStream_t st)
+{
+  const int C = g.C, K = g.K;
+  const long T = g.T;
+  const int P = C * g.L;
+  if (C >= 4 && C <= 16 && g.L >= 1 && !btk_switches().wpe_predict_valu) {
+    int g_ld = P; while (g_ld % 32 != 4) g_ld++;                   // filter rows 8 banks apart
+    const int sp_ld = PM_FG + g.L - 1;
+    const size_t lds = sizeof(float2) * ((size_t)C * g_ld + (size_t)C * sp_ld);
+    if (lds <= 64 * 1024) {
+      hipLaunchKernelGGL(wpe_predict_mfma_kernel, dim3((unsigned)((T + PM_FG - 1) / PM_FG), (unsigned)K, (unsigned)S), dim3(256), lds, st,
+                         X, G, g, mode, Winv, OUT, g_ld, sp_ld);
+      BTK_HIP_CHECK(hipGetLastError());
+      return BTK_OK;
+    }
+  }
+  hipLaunchKernelGGL(wpe_predict_kernel, dim3((unsigned)((T + 255) / 256), (unsigned)K, (unsigned)(S * C)), dim3(256), 0, st, X, G, g, mode, Winv, OUT);
+  BTK_HIP_CHECK(hipGetLastError());
+  return BTK_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -692,8 +800,7 @@ int btk_wpe_estimate(const void* X, int S, int K, int C, long T_stride, long T, 
     phase = dbuf;
   }
   for (int it = 0; it < iterations; it++) {
-    hipLaunchKernelGGL(wpe_predict_kernel, dim3((unsigned)((T + 255) / 256), (unsigned)K, (unsigned)(S * C)), dim3(256), 0, st,
-                       Xp, Gp, g, 0, Winv, static_cast<float2*>(nullptr));
+    { const int rc = launch_wpe_predict(Xp, Gp, g, S, 0, Winv, static_cast<float2*>(nullptr), st); if (rc != BTK_OK) return rc; }
     const int skip = btk_switches().wpe_noskip ? 0 : 1;            // A/B switch of profiles/ (btk_internal.h)
     const dim3 hgrid1((unsigned)(ntile * (ntile + 1) / 2), (unsigned)K, (unsigned)(S * C));
     // up to 16 rows beyond the last full 32-row block go to the 16-row strip kernel instead of a padded block row
@@ -759,11 +866,8 @@ int btk_wpe_apply(const void* X, const void* G, void* OUT, int S, int K, int C, 
     return btk_set_error(BTK_ERR_DIMENSION, "btk_wpe_apply: bad sizes");
   if (T == 0) return BTK_OK;
   const WpeGeom g = make_geom(K, C, lowerN, upperN, lower_bw, upper_bw, T_stride, T);
-  hipLaunchKernelGGL(wpe_predict_kernel, dim3((unsigned)((T + 255) / 256), (unsigned)K, (unsigned)(S * C)), dim3(256), 0,
-                     as_stream(stream), static_cast<const float2*>(X), static_cast<const float2*>(G), g, 1,
-                     static_cast<float*>(nullptr), static_cast<float2*>(OUT));
-  BTK_HIP_CHECK(hipGetLastError());
-  return BTK_OK;
+  return launch_wpe_predict(static_cast<const float2*>(X), static_cast<const float2*>(G), g, S, 1, static_cast<float*>(nullptr),
+                            static_cast<float2*>(OUT), as_stream(stream));
 }
 
 }  // extern "C"
