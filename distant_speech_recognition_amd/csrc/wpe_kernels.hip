@@ -85,7 +85,7 @@ void wpe_predict_mfma_kernel(const float2* __restrict__ X, const float2* __restr
 {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float2* gs = reinterpret_cast<float2*>(smem);                    // [C][g_ld]: conj-ready filter taps (zero where a tap does not apply)
-  float2* sp = gs + g.C * g_ld;                                    // [C][sp_ld]: samples t0 - lowerN - (L - 1) .. t0 + PM_FG - 1 - lowerN of every channel
+  float2* sp = gs + g.C * g_ld;                                    // [C][sp_ld]: samples t0 - lowerN - (L - 1) .. t0 + PM_FG - 1 of every channel
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int k = blockIdx.y, s = blockIdx.z;
   const long t0 = (long)blockIdx.x * PM_FG;
@@ -100,7 +100,7 @@ void wpe_predict_mfma_kernel(const float2* __restrict__ X, const float2* __restr
     if (active && p < P && (p % L) <= lmax) v = G[(((long)s * C + c) * g.K + k) * (long)P + p];
     gs[idx] = v;
   }
-  const int SPW = PM_FG + L - 1;
+  const int SPW = PM_FG + L - 1 + g.lowerN;                        // ... up to sample t0 + PM_FG - 1: y_c(t) itself is read from the span too
   for (int idx = tid; idx < C * SPW; idx += 256) {
     const int c = idx / SPW, e = idx - c * SPW;
     const long i = t0 - g.lowerN - (L - 1) + e;
@@ -741,7 +741,7 @@ int launch_wpe_predict(const float2* X, const float2* G, const WpeGeom& g, int S
   const int P = C * g.L;
   if (C >= 4 && C <= 16 && g.L >= 1 && !btk_switches().wpe_predict_valu) {
     int g_ld = P; while (g_ld % 32 != 4) g_ld++;                   // filter rows 8 banks apart
-    const int sp_ld = PM_FG + g.L - 1;
+    const int sp_ld = PM_FG + g.L - 1 + g.lowerN;
     const size_t lds = sizeof(float2) * ((size_t)C * g_ld + (size_t)C * sp_ld);
     if (lds <= 64 * 1024) {
       hipLaunchKernelGGL(wpe_predict_mfma_kernel, dim3((unsigned)((T + PM_FG - 1) / PM_FG), (unsigned)K, (unsigned)S), dim3(256), lds, st,

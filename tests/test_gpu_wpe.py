@@ -24,7 +24,9 @@ def _reverberant(rng, T, C, M):
 @pytest.mark.parametrize("C,M,T,lower,upper,iters", [(2, 64, 120, 0, 5, 2), (3, 64, 90, 1, 4, 2), (4, 64, 150, 0, 15, 1), (1, 64, 100, 2, 6, 2),
                                                     # the lag-product kernel (4 / 8 channels): delayed prediction (own r-vector kernel), lag counts that leave partial row
                                                     # blocks, frame counts that are not a multiple of its 64-frame tile
-                                                    (8, 32, 200, 1, 10, 2), (4, 64, 130, 2, 11, 2), (8, 16, 331, 0, 12, 1)])
+                                                    (8, 32, 200, 1, 10, 2), (4, 64, 130, 2, 11, 2), (8, 16, 331, 0, 12, 1),
+                                                    # the matrix-core prediction kernel with a channel count that is not a multiple of four (block HERK + MFMA prediction)
+                                                    (5, 32, 300, 1, 6, 2), (12, 16, 270, 0, 4, 1), (8, 16, 530, 3, 9, 1)])
 def test_wpe_matches_oracle(orc, dev, C, M, T, lower, upper, iters):
     import torch
     from distant_speech_recognition_amd import engine as eng
