@@ -4,8 +4,11 @@
 StopIteration, and `PyVectorComplexFeatureStreamPtr(obj)` / `PyVectorFloatFeatureStreamPtr(obj)` turn any Python object with
 size() / __iter__ / next() / reset() into a source node that C++ nodes pull from (reference stream/pyStream.h:25-168).
 
-`distant_speech_recognition_amd.btk20` is the pure-Python mirror of the same classes (ctypes over the C-ABI) with the
-virtual-pull protocol for moving look directions; both sit on the same kernels and are tested against the same oracle."""
+`distant_speech_recognition_amd.btk20` (and the top-level `btk20`) are the reference's import names for THIS module: there is one
+host layer, the C++ nodes; the extension must be built (`make -C distant_speech_recognition_amd/host`, done by
+`__graft_entry__.build()`), importing it without the built file raises ImportError with that instruction.
+End of stream: the binding raises StopIteration itself (jexception.i:20-29 maps jiterator_error there); `jiterator_error` is
+exported as that class, so `except jiterator_error` works but `except j_error` does not see the end of a stream."""
 import importlib.util
 import os
 import sysconfig
@@ -81,40 +84,59 @@ def _set_noise_spatial_spectral_matrices(self, R):
 _mod.SubbandMVDRPtr.set_noise_spatial_spectral_matrices = _set_noise_spatial_spectral_matrices
 
 
-# ---- keyword names and legacy aliases of the SWIG interface (see _signatures.py)
-def _with_names(f, params, what):
-    names = [p for p, _ in params]
-
+# ---- keyword names and legacy aliases of the SWIG interface.  _signatures.py is GENERATED from the reference's .i files (the
+# names a script written against the SWIG module may use); _signatures_alt.py holds the spellings earlier versions of this
+# package used.  A call with keywords is matched against those tables in that order; keywords none of them knows go to the
+# pybind11 callable unchanged (its own py::arg names), so nothing that worked positionally or with the binding's names breaks.
+def _with_names(f, tables, what):
     def call(self, *args, **kw):
-        if kw:
-            args = list(args)
-            for p, dflt in params[len(args):]:
-                if p in kw:
-                    args.append(kw.pop(p))
-                elif kw and dflt is not None:
-                    args.append(dflt)
-                else:
+        if not kw:
+            return f(self, *args)
+        for params in tables:
+            names = [p for p, _ in params]
+            if not all(k in names for k in kw) or any(k in names[:len(args)] for k in kw):
+                continue
+            a, left, ok = list(args), dict(kw), True
+            for p, dflt in params[len(a):]:
+                if p in left:
+                    a.append(left.pop(p))
+                elif not left:
                     break
-            if kw:
-                raise TypeError("%s() got an unexpected keyword argument %r (parameters: %s)" % (what, sorted(kw)[0], ", ".join(names)))
-        return f(self, *args)
+                elif isinstance(dflt, str) and dflt == "required" or dflt is Ellipsis:
+                    ok = False                      # a gap the table cannot fill: let the binding decide
+                    break
+                else:
+                    a.append(dflt)
+            if ok and not left:
+                return f(self, *a)
+        return f(self, *args, **kw)
     call.__name__ = getattr(f, "__name__", what)
     call.__doc__ = getattr(f, "__doc__", None)
     return call
 
 
 def _apply_signatures():
-    from . import _signatures as S
+    from . import _signatures as S, _signatures_alt as A
+
+    def alt(params):        # the older tables mark "required" with None
+        return [(p, "required" if d is None else d) for p, d in params]
     for cname, cls in vars(_mod).items():
         if not isinstance(cls, type):
             continue
+        mro = [c.__name__ for c in cls.__mro__]
         for mname in list(vars(cls)):
-            params = S.CLASS_METHOD_KWARGS.get(cname, {}).get(mname) or S.METHOD_KWARGS.get(mname)
-            if params and callable(vars(cls)[mname]):
-                setattr(cls, mname, _with_names(vars(cls)[mname], params, "%s.%s" % (cname, mname)))
-        if cname in S.CTOR_KWARGS:
-            cls.__init__ = _with_names(cls.__init__, S.CTOR_KWARGS[cname], cname)
-    for cname, table in S.ALIASES.items():
+            if mname.startswith("__") or not callable(vars(cls)[mname]):
+                continue
+            tables = [S.METHODS[c][mname] for c in mro if mname in S.METHODS.get(c, {})]
+            old = A.CLASS_METHOD_KWARGS.get(cname, {}).get(mname) or A.METHOD_KWARGS.get(mname)
+            if old:
+                tables.append(alt(old))
+            if tables:
+                setattr(cls, mname, _with_names(vars(cls)[mname], tables, "%s.%s" % (cname, mname)))
+        tables = ([S.CTORS[cname]] if cname in S.CTORS else []) + ([alt(A.CTOR_KWARGS[cname])] if cname in A.CTOR_KWARGS else [])
+        if tables:
+            cls.__init__ = _with_names(cls.__init__, tables, cname)
+    for cname, table in A.ALIASES.items():
         cls = getattr(_mod, cname)
         for alias, target in table.items():
             if not hasattr(cls, alias):

@@ -357,7 +357,12 @@ void analysis512_bfz_kernel(const float* __restrict__ pcm, long nsamples, long p
     for (int k = 0; k < A_MT; k++) h[q][k] = *reinterpret_cast<const float2*>(proto + 2 * (n0 + q * NPG) + A_M * k);
   f2 twr[15];                                                                 // W_256^{j k1}, k1 = 1..15
 #pragma unroll
-  for (int k1 = 1; k1 < 16; k1++) { const float2 t = twg[(2 * j * k1) & 511]; twr[k1 - 1] = f2{t.x, t.y}; }
+  for (int k1 = 1; k1 < 16; k1++) { const float2 t = twg[(2 * j * k1) & 511]; twr[k1 - 1] = (VAR & 128) ? tw_tangent(t.x, t.y) : f2{t.x, t.y}; }
+  // TAN (VAR & 128, round 4): folded-constant radix-16 passes (fft_packed.h: a twiddle is one rotation FMA, its cosine rides in
+  // the next butterfly): twr holds (cos, tan) and is applied behind the LDS exchange (W_256^{j k1} is symmetric in lane and
+  // register index).  296 instead of 316 packed instructions per wavefront and channel; measured -1.0 % (profiles/r04_fused_ab.txt)
+  constexpr bool TAN = (VAR & 128) != 0;
+  const f2 k_hc = f2{0.70710678118654752f, 0.92387953251128674f}, k_t1 = f2{0.41421356237309503f, 0.41421356237309503f};
   // The taps and twiddles are first used inside the channel loop; without a use in front of it hipcc keeps their
   // s_waitcnt vmcnt(k) inside the loop, where every iteration it also waits for the LDS-DMA of the NEXT channel that
   // was issued a few instructions earlier (vector-memory counters retire in order): the latency the DMA is meant
@@ -527,17 +532,19 @@ void analysis512_bfz_kernel(const float* __restrict__ pcm, long nsamples, long p
       f2* fb = reinterpret_cast<f2*>(fbuf) + (wave * 4 + fl) * FRZ;
 #pragma unroll
       for (int r = 0; r < 16; r++) { if constexpr (ABL != 3) v[r] = fb[r * 17 + j]; else { v[r] = f2{win[r % NWG].x, (float)r}; asm volatile("" : "+v"(v[r])); } }
-      dft16q(v);
+      if constexpr (TAN) dft16t(v, k_hc, k_t1); else dft16q(v);
       if constexpr (TIMED) { asm volatile("" : "+v"(v[15])); mark(6); }   // first pass (reads + radix-16)
+      if constexpr (!TAN) {
 #pragma unroll
-      for (int k1 = 1; k1 < 16; k1++) v[k1] = cmulv(v[k1], twr[k1 - 1]);
+        for (int k1 = 1; k1 < 16; k1++) v[k1] = cmulv(v[k1], twr[k1 - 1]);
+      }
 #pragma unroll
       for (int k1 = 0; k1 < 16; k1++) { if constexpr (ABL != 1) fb[j * 17 + k1] = v[k1]; }
 #pragma unroll
       for (int jp = 0; jp < 16; jp++) { if constexpr (ABL != 1) v[jp] = fb[jp * 17 + j]; else asm volatile("" : "+v"(v[jp])); }
 #pragma unroll
       for (int q = 0; q < 4; q++) { if constexpr (ABL == 2 || ABL == 6) { wg[0][q] = f4{1.f, 0.5f, 0.25f, 2.f}; wg[1][q] = wg[0][q]; asm volatile("" : "+v"(wg[0][q]), "+v"(wg[1][q])); } else wg[0][q] = wl[q * 16]; }
-      dft16q(v);                                                      // v[k2] = Z[j + 16 k2]
+      if constexpr (TAN) dft16t_tw(v, twr, k_hc, k_t1); else dft16q(v);   // v[k2] = Z[j + 16 k2]
       if constexpr (TIMED) { asm volatile("" : "+v"(v[15])); mark(7); }   // twiddles, exchange, second pass
     }
     // ---- phase 4: A[q] += conj(w[q]) Z[q],  B'[q] += conj(w[(256-q)&255]) conj(Z[q])
@@ -662,8 +669,9 @@ int launch512_bf(const btk_fb* fb, const float* pcm, long nsamples, long pcm_str
   // BTK_FUSED_VAR (diagnostics, read once): 1 = register staging with the span and the frames sharing one LDS region (the only
   // form for R = 1, whose 38 KB span leaves no room for a separate region), 3 = LDS-DMA staging of the span,
   // 7 = polyphase window straight from HBM, only frames and weights in LDS, 15 = 7 with the window loads interleaved with the FFT
-  // (31: the other interleaving pattern), 79 (default for R = 2) = 15 with the polyphase products' halves crossed by op_sel
-  const int var = btk_switches().fused_var >= 0 ? btk_switches().fused_var : (R == 2 ? 79 : 3);
+  // (31: the other interleaving pattern), 79 = 15 with the polyphase products' halves crossed by op_sel, 207 (default for R = 2) =
+  // 79 with the folded-constant radix-16 passes
+  const int var = btk_switches().fused_var >= 0 ? btk_switches().fused_var : (R == 2 ? 207 : 3);
   const bool pipe = (var & 2) && R >= 2;
   const bool gw = pipe && (var & 4) && R == 2;
   // (TT = 8 -- two wavefronts per workgroup, four workgroups per CU, the same occupancy with less barrier coupling -- measured
@@ -681,7 +689,7 @@ int launch512_bf(const btk_fb* fb, const float* pcm, long nsamples, long pcm_str
   auto kern = pipe ? analysis512_bfz_kernel<R, 3> : analysis512_bfz_kernel<R, 1>;
   if (gw) kern = analysis512_bfz_kernel<2, 7>;
   if (t8) kern = analysis512_bfz_kernel<2, 7, 8>;
-  if (gw && !t8 && (var & 8)) kern = (var & 16) ? analysis512_bfz_kernel<2, 31> : ((var & 64) ? analysis512_bfz_kernel<2, 79> : analysis512_bfz_kernel<2, 15>);
+  if (gw && !t8 && (var & 8)) kern = (var & 16) ? analysis512_bfz_kernel<2, 31> : ((var & 64) ? ((var & 128) ? analysis512_bfz_kernel<2, 207> : analysis512_bfz_kernel<2, 79>) : analysis512_bfz_kernel<2, 15>);
 #ifdef BTK_FUSED_ABLATE
   if (gw && !t8) switch ((var >> 12) & 7) {
     case 1: kern = analysis512_bfz_kernel<2, 15 + 4096 * 1>; break;
@@ -696,7 +704,7 @@ int launch512_bf(const btk_fb* fb, const float* pcm, long nsamples, long pcm_str
 #endif
   unsigned long long* phase = nullptr;
   if (R == 2 && (var & 512)) {                       // diagnostics: per-phase shader cycles of wave 0, printed by every launch
-    kern = gw ? analysis512_bfz_kernel<2, 519> : analysis512_bfz_kernel<2, 515>;
+    kern = gw ? analysis512_bfz_kernel<2, 719> : analysis512_bfz_kernel<2, 515>;   // 719 = the default form (207) with the marks
     static unsigned long long* dbuf = nullptr;
     if (!dbuf) BTK_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&dbuf), 16 * sizeof(unsigned long long)));
     BTK_HIP_CHECK(hipMemsetAsync(dbuf, 0, 16 * sizeof(unsigned long long), st));

@@ -3,6 +3,7 @@
 // beamformer/spectralinfoarray.h:6-36), computed through libbtkhip.
 #pragma once
 #include <complex>
+#include <functional>
 #include <list>
 #include <vector>
 #include "stream/stream.h"
@@ -69,9 +70,11 @@ class BeamformerWeights {
   void setTimeAlignment() { ta_v = wq_v; }
   // The reference's accessors (beamformer/beamformer.h:53-67), same names and return types.  The gsl objects ALIAS this object's
   // storage (owner = 0): what a caller writes through wq()[k], B()[k], wa()[k] is what the nodes compute with, as in the
-  // reference.  CSDs(): the reference's post-filters keep the N x N auto / cross spectral densities of every bin here; this engine
-  // keeps only the recursively averaged SUMS the gains depend on, on the device, so these vectors exist,
-  // zeroed, for callers that index them, and are never updated.  wp1(): the post-filter gains of the last served frame, mirrored
+  // reference.  CSDs(): the reference's post-filters keep the N x N auto / cross spectral densities of every bin here (upper triangle
+  // i < j and the diagonal, postfilter.cc:77-116); this engine keeps only the recursively averaged SUMS the gains depend on, on the
+  // device, and REBUILDS the matrices when CSDs() is called: the post-filter bound to this object installs
+  // a provider that runs one exponentially weighted covariance launch over the frames it has served (ZelinskiPostFilter::fill_csds_).
+  // Without a post-filter the vectors are what the reference's are at that point: zero.  wp1(): the post-filter gains of the last served frame, mirrored
   // from the post-filter node that is bound to this weight object (ZelinskiPostFilter::postfilter_weights()).
   bool isHalfBandShift() const { return halfBandShift_; }
   gsl_vector_complex** arrayManifold() const { return ta_views_; }
@@ -81,7 +84,8 @@ class BeamformerWeights {
   gsl_vector_complex** wq() const { return wq_views_; }
   gsl_matrix_complex** B() const { return B_views_; }
   gsl_vector_complex** wa() const { return wa_views_; }
-  gsl_vector_complex** CSDs() const { return CSDs_; }
+  gsl_vector_complex** CSDs() const { if (csd_provider_) csd_provider_(CSDs_); return CSDs_; }
+  void set_csd_provider(const std::function<void(gsl_vector_complex**)>& f) { csd_provider_ = f; }
   gsl_vector_complex* wp1() const { return wp1_; }
   unsigned fftLen() const { return fftLen_; }
   unsigned chanN() const { return chanN_; }
@@ -94,6 +98,7 @@ class BeamformerWeights {
   gsl_vector_complex **wq_views_, **wl_views_, **ta_views_, **wa_views_, **CSDs_;
   gsl_matrix_complex** B_views_;
   gsl_vector_complex* wp1_;
+  std::function<void(gsl_vector_complex**)> csd_provider_;
 };
 
 class SubbandBeamformer : public VectorComplexFeatureStream {

@@ -59,10 +59,22 @@ class OverSampledDFTSynthesisBank : public VectorFloatFeatureStream {
   OverSampledDFTSynthesisBank(VectorComplexFeatureStreamPtr& samp, gsl_vector* prototype, unsigned M, unsigned m, unsigned r = 0,
                               unsigned delayCompensationType = 0, int gainFactor = 1,
                               const String& nm = "OverSampledDFTSynthesisBank");
+  // source-less form (reference modulated/modulated.h:320-334, modulated.cc:500-518): the caller pushes one subband frame with
+  // input_source_vector() and pulls one block with next(); the block is synthesised on the device from the ring of the last
+  // m R + R frames.  A per-frame graph pushes exactly one frame per next(); any other pattern (whose ring the batch kernel's
+  // frame sequence cannot express) raises jconsistency_error instead of returning a different signal.
+  OverSampledDFTSynthesisBank(gsl_vector* prototype, unsigned M, unsigned m, unsigned r = 0, unsigned delayCompensationType = 0,
+                              int gainFactor = 1, const String& nm = "OverSampledDFTSynthesisBank");
   ~OverSampledDFTSynthesisBank();
   virtual const gsl_vector_float* next(int frame_no = -5);
   virtual void reset();
+  void input_source_vector(const gsl_vector_complex* block);
+  void no_stream_feature(bool flag = true) { no_stream_feature_ = flag; }
+  void inputSourceVector(const gsl_vector_complex* block) { input_source_vector(block); }          // ENABLE_LEGACY_BTK_API aliases
+  void doNotUseStreamFeature(bool flag = true) { no_stream_feature(flag); }
  private:
+  void init_(gsl_vector* prototype, unsigned dct);
+  const gsl_vector_float* next_pushed_();
   void prepare_();
   void synthesize_(const std::vector<float>& Yk, long T, long keep_blocks);
   VectorComplexFeatureStreamPtr samp_;
@@ -74,5 +86,9 @@ class OverSampledDFTSynthesisBank : public VectorFloatFeatureStream {
   bool prepared_;
   BlockSource* bsrc_;                                   // samp_ seen as a block source (NULL: drained through next())
   unsigned long src_version_;
+  bool no_stream_feature_;
+  std::vector<float> ring_;                             // pushed frames, complex64 [W][K], oldest first (W = m R + R)
+  long npushed_, npushed_at_next_;
+  void *dWin_, *dBlk_;                                  // device window [K][W] complex64 and one output block
 };
 typedef Inherit<OverSampledDFTSynthesisBank, VectorFloatFeatureStreamPtr> OverSampledDFTSynthesisBankPtr;

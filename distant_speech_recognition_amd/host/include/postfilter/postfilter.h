@@ -14,8 +14,18 @@ class ZelinskiPostFilter : public VectorComplexFeatureStream, public BlockSource
   virtual const gsl_vector_complex* next(int frame_no = -5);
   virtual void reset();
   void set_beamformer(SubbandDSPtr& beamformer);
-  void setBeamformer(SubbandDSPtr& beamformer) { set_beamformer(beamformer); }
+  // without a beamformer object (reference postfilter.h:83-84, postfilter.cc:384-421): the caller keeps a SnapShotArray current
+  // (set_samples() + update() per frame) and gives the alignment vector of every bin; next() then filters samp_'s frame with
+  // the statistics of the snapshot of that moment -- one small launch per frame, state on the device
+  void set_snapshot_array(SnapShotArrayPtr& snapShotArray);
+  void set_array_manifold_vector(unsigned fbinX, gsl_vector_complex* arrayManifoldVector, bool halfBandShift, unsigned NC = 1);
+  void setBeamformer(SubbandDSPtr& beamformer) { set_beamformer(beamformer); }                       // ENABLE_LEGACY_BTK_API aliases
+  void setSnapShotArray(SnapShotArrayPtr& snapShotArray) { set_snapshot_array(snapShotArray); }
+  void setArrayManifoldVector(unsigned fbinX, gsl_vector_complex* v, bool halfBandShift, unsigned NC = 1) { set_array_manifold_vector(fbinX, v, halfBandShift, NC); }
+  const gsl_vector_complex* getPostFilterWeights() { return postfilter_weights(); }
   const gsl_vector_complex* postfilter_weights();
+  // bf_weights_ of the reference (postfilter.h:104): the beamformer's weight object, or the one set_array_manifold_vector() made
+  BeamformerWeights* weights_object() const { return has_bf_ptr_ ? bf_ptr_->beamformer_weight_object() : own_weights_; }
   // BlockSource: see modulated/modulated.h
   virtual unsigned long block_version() { return has_bf_ptr_ ? bf_ptr_->weights_version() : 0; }
   virtual const std::vector<float>& block(long& T);
@@ -23,6 +33,13 @@ class ZelinskiPostFilter : public VectorComplexFeatureStream, public BlockSource
  protected:
   virtual void compute_(long from_frame);
   void merge_output_(std::vector<float>& Ynew, long from_frame);
+  const gsl_vector_complex* next_manual_(int frame_no);
+  // the reference keeps the N x N spectral densities of every bin in BeamformerWeights::CSDs(); this engine keeps only their
+  // sums on the device and rebuilds the matrices on demand: one weighted covariance launch over the frames served so far
+  void bind_csd_provider_();
+  void fill_csds_(gsl_vector_complex** out);
+  virtual bool align_with_wq_() const { return (type_ & TYPE_ZELINSKI2) != 0; }     // postfilter.cc:452-457
+  virtual bool lefkimmiatis_or_mccowan_() const { return false; }
   unsigned fftLen_;
   VectorComplexFeatureStreamPtr samp_;
   PostfilterType type_;
@@ -36,6 +53,11 @@ class ZelinskiPostFilter : public VectorComplexFeatureStream, public BlockSource
   unsigned long bf_version_;
   void *dPhi_, *dPsi_, *dWl_;
   gsl_vector_complex* wp1_;
+  long hist_start_;                         // frame at which the density history last restarted (weights recomputed)
+  SnapShotArrayPtr snapshot_array_;         // manual mode: multi-channel input kept current by the caller
+  BeamformerWeights* own_weights_;          // manual mode: created by set_array_manifold_vector
+  std::vector<float> Xhist_;                // manual mode: the snapshots seen so far, complex64 [T][K][N] (for CSDs())
+  long manual_frames_;
 };
 typedef Inherit<ZelinskiPostFilter, VectorComplexFeatureStreamPtr> ZelinskiPostFilterPtr;
 
@@ -58,6 +80,8 @@ class McCowanPostFilter : public ZelinskiPostFilter {
  protected:
   virtual void compute_(long from_frame);
   virtual bool lefkimmiatis_() const { return false; }
+  virtual bool lefkimmiatis_or_mccowan_() const { return true; }
+  virtual bool align_with_wq_() const { return !lefkimmiatis_() && (type_ & TYPE_ZELINSKI2) != 0; }   // postfilter.cc:858-863 vs :1098
   virtual const char* no_R_msg_() const { return "McCowanPostFilter:  construct/set a noise coherence matrix\n"; }
   void fetch_R_();
   void push_R_();

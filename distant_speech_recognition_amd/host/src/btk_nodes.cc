@@ -10,6 +10,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <ctime>
 
 #include "feature/feature.h"
 #include "modulated/modulated.h"
@@ -105,15 +106,24 @@ long drain_complex(VectorComplexFeatureStreamPtr& src, unsigned M, std::vector<f
 
 // ================================================================================ SampleFeature
 SampleFeature::SampleFeature(const String& fn, unsigned blockLen, unsigned shiftLen, bool padZeros, const String& nm)
-    : VectorFloatFeatureStream(blockLen, nm), have_samples_(false), shiftLen_(shiftLen), cur_(0), pad_zeros_(padZeros),
-      samplerate_(0)
+    : VectorFloatFeatureStream(blockLen, nm), have_samples_(false), norm_(0.0f), shiftLen_(shiftLen), cur_(0),
+      pad_zeros_(padZeros), samplerate_(0), nChan_(1), format_(sndfile::SF_FORMAT_WAV | sndfile::SF_FORMAT_PCM_16),
+      copy_fsamples_(NULL), copy_dsamples_(NULL)
 {
   if (fn != "") read(fn);
   is_end_ = false;
 }
 
+SampleFeature::~SampleFeature()
+{
+  if (copy_fsamples_) gsl_vector_float_free(copy_fsamples_);
+  if (copy_dsamples_) gsl_vector_free(copy_dsamples_);
+}
+
 unsigned SampleFeature::read(const String& fn, int, int, int chX, int, int cfrom, int to, int, float norm)
 {
+  norm_ = norm;
+  samples_.clear(); have_samples_ = false;
   FILE* fp = fopen(fn.c_str(), "rb");
   if (!fp) throw jio_error("Could not open file %s.", fn.c_str());
   unsigned char hdr[12];
@@ -145,17 +155,49 @@ unsigned SampleFeature::read(const String& fn, int, int, int chX, int, int cfrom
   }
   fclose(fp);
   if (fmt != 1 || bits != 16) throw jio_error("Only 16-bit PCM WAV is supported (%s)", fn.c_str());
+  nChan_ = channels;
+  const long nfr = (long)(raw.size() / channels);
+  if (to < 0 || to >= nfr) to = (int)nfr - 1;                       // feature.cc:286-293
+  if (cfrom < 0) cfrom = 0;
+  if (cfrom > to || cfrom > nfr) throw jio_error("Cannot load samples from %d to %d.", cfrom, to);
   if (chX > channels || chX < 1) {
     if (chX == 0) throw jconsistency_error("Multi-channel read is not yet supported.");
     throw jconsistency_error("Selected channel out of range of available channels.");
   }
-  const size_t nfr = raw.size() / channels;
-  size_t first = cfrom > 0 ? (size_t)cfrom : 0, last = (to > 0 && (size_t)to < nfr) ? (size_t)to + 1 : nfr;
-  std::vector<float> s;
-  for (size_t i = first; i < last; i++) s.push_back((float)raw[i * channels + (chX - 1)]);   // un-normalised
-  if (norm != 1.0f && norm != 0.0f) for (size_t i = 0; i < s.size(); i++) s[i] *= norm;
+  // norm == 0: un-normalised (int16-scale) floats; otherwise libsndfile's normalised floats (x / 32768) times norm
+  const float scale = (norm == 0.0f) ? 1.0f : (1.0f / 32768.0f) * (norm != 1.0f ? norm : 1.0f);
+  std::vector<float> s((size_t)(to - cfrom + 1));
+  for (long i = cfrom; i <= to; i++) s[(size_t)(i - cfrom)] = (float)raw[(size_t)i * channels + (chX - 1)] * scale;
+  format_ = sndfile::SF_FORMAT_WAV | sndfile::SF_FORMAT_PCM_16;
   set_samples(s.data(), s.size());
   return (unsigned)samples_.size();
+}
+
+void SampleFeature::write(const String& fn, int format, int sampleRate)
+{
+  if (format != (sndfile::SF_FORMAT_WAV | sndfile::SF_FORMAT_PCM_16))
+    throw jio_error("Error opening file %s: only SF_FORMAT_WAV|SF_FORMAT_PCM_16 is written (format 0x%x asked).", fn.c_str(), format);
+  (void)sampleRate;                                                  // no SRCONV: the file keeps samplerate_ (feature.cc:439-443)
+  FILE* fp = fopen(fn.c_str(), "wb");
+  if (!fp) throw jio_error("Error opening file %s.", fn.c_str());
+  const size_t n = samples_.size();
+  std::vector<short> pcm(n);
+  // norm_ == 0: un-normalised floats are int16 values; else samples / norm_ are [-1, 1) values scaled by 0x7FFF (libsndfile's
+  // float -> short conversion with SFC_SET_NORM_FLOAT on); rounding lrintf as libsndfile does, clipped instead of wrapped
+  const float k = (norm_ == 0.0f) ? 1.0f : 32767.0f / ((norm_ != 1.0f) ? norm_ : 1.0f);
+  for (size_t i = 0; i < n; i++) {
+    long v = lrintf(samples_[i] * k);
+    pcm[i] = (short)(v < -32768 ? -32768 : (v > 32767 ? 32767 : v));
+  }
+  const unsigned rate = (unsigned)(samplerate_ > 0 ? samplerate_ : 16000), bytes = (unsigned)(2 * n);
+  unsigned char h[44];
+  auto le32 = [&](int o, unsigned v) { h[o] = v & 255; h[o + 1] = (v >> 8) & 255; h[o + 2] = (v >> 16) & 255; h[o + 3] = (v >> 24) & 255; };
+  auto le16 = [&](int o, unsigned v) { h[o] = v & 255; h[o + 1] = (v >> 8) & 255; };
+  memcpy(h, "RIFF", 4); le32(4, 36 + bytes); memcpy(h + 8, "WAVEfmt ", 8); le32(16, 16); le16(20, 1); le16(22, 1);
+  le32(24, rate); le32(28, rate * 2); le16(32, 2); le16(34, 16); memcpy(h + 36, "data", 4); le32(40, bytes);
+  const bool ok = fwrite(h, 1, 44, fp) == 44 && fwrite(pcm.data(), 2, n, fp) == n;
+  fclose(fp);
+  if (!ok) fprintf(stderr, "unable to write all samples to %s\n", fn.c_str());
 }
 
 void SampleFeature::set_samples(const float* samples, size_t n)
@@ -165,6 +207,118 @@ void SampleFeature::set_samples(const float* samples, size_t n)
   cur_ = 0;
   reset();
   is_end_ = false;
+}
+
+void SampleFeature::setSamples(const gsl_vector* samples, unsigned sampleRate)      // feature.cc:669-679
+{
+  samplerate_ = (int)sampleRate;
+  samples_.resize(samples->size);
+  for (size_t i = 0; i < samples->size; i++) samples_[i] = (float)gsl_vector_get(samples, i);
+  have_samples_ = true;
+  reset();
+}
+
+void SampleFeature::copySamples(SampleFeaturePtr& src, unsigned cfrom, unsigned to)  // feature.cc:651-667
+{
+  size_t n;
+  if (to == 0) {
+    n = src->samples_.size();
+  } else {
+    if (to <= cfrom) throw jindex_error("cfrom = %d and to = %d are inconsistent.", cfrom, to);
+    if (to >= src->samples_.size()) to = (unsigned)src->samples_.size() - 1;
+    n = to - cfrom;
+  }
+  if ((size_t)cfrom + n > src->samples_.size()) throw jindex_error("cfrom = %d and to = %d are inconsistent.", cfrom, to);
+  std::vector<float> tmp(src->samples_.begin() + cfrom, src->samples_.begin() + cfrom + n);
+  samples_.swap(tmp);
+  have_samples_ = true;
+}
+
+const gsl_vector_float* SampleFeature::data()
+{
+  if (copy_fsamples_) gsl_vector_float_free(copy_fsamples_);
+  copy_fsamples_ = gsl_vector_float_calloc(samples_.size());
+  for (size_t i = 0; i < samples_.size(); i++) gsl_vector_float_set(copy_fsamples_, i, samples_[i]);
+  return copy_fsamples_;
+}
+
+const gsl_vector* SampleFeature::dataDouble()
+{
+  if (copy_dsamples_) gsl_vector_free(copy_dsamples_);
+  copy_dsamples_ = gsl_vector_calloc(samples_.size());
+  for (size_t i = 0; i < samples_.size(); i++) gsl_vector_set(copy_dsamples_, i, samples_[i]);
+  return copy_dsamples_;
+}
+
+void SampleFeature::zeroMean()                                       // feature.cc:556-570: truncation toward zero after the int16 clamp
+{
+  if (!have_samples_) throw jconsistency_error("Must first load data before setting mean to zero.");
+  double mean = 0.0;
+  for (size_t i = 0; i < samples_.size(); i++) mean += samples_[i];
+  mean /= (double)samples_.size();
+  for (size_t i = 0; i < samples_.size(); i++) {
+    const double x = samples_[i] - mean;
+    samples_[i] = (float)(int)(x < -32768.0 ? -32768.0 : (x < 32767.0 ? x : 32767.0));
+  }
+}
+
+void SampleFeature::cut(unsigned cfrom, unsigned cto)                // feature.cc:572-586 (both bounds inclusive)
+{
+  if (cfrom >= cto) throw j_error("Cut bounds (%d,%d) do not match.", cfrom, cto);
+  if (cto >= samples_.size()) throw j_error("Do not have enough samples (%d,%d).", cto, (int)samples_.size());
+  std::vector<float> tmp(samples_.begin() + cfrom, samples_.begin() + cto + 1);
+  samples_.swap(tmp);
+}
+
+// feature.cc:589-603: gsl_rng_default (mt19937, default seed: GSL turns seed 0 into 4357) and gsl_ran_gaussian (polar
+// Box-Muller over gsl_rng_uniform_pos-style uniforms: x, y = -1 + 2 u), restated from GSL's published sources; the reference
+// hands sigma2 to it as the standard deviation
+void SampleFeature::randomize(int startX, int endX, double sigma2)
+{
+  printf("Randomizing from %6.2f to %6.2f\n", startX / 16000.0, endX / 16000.0);
+  unsigned long mt[624];
+  int mti = 624;
+  mt[0] = 4357UL;
+  for (int i = 1; i < 624; i++) mt[i] = (1812433253UL * (mt[i - 1] ^ (mt[i - 1] >> 30)) + (unsigned long)i) & 0xffffffffUL;
+  auto next_u32 = [&]() -> unsigned long {
+    if (mti >= 624) {
+      for (int kk = 0; kk < 624; kk++) {
+        const unsigned long y = (mt[kk] & 0x80000000UL) | (mt[(kk + 1) % 624] & 0x7fffffffUL);
+        mt[kk] = mt[(kk + 397) % 624] ^ (y >> 1) ^ ((y & 1UL) ? 0x9908b0dfUL : 0UL);
+      }
+      mti = 0;
+    }
+    unsigned long k = mt[mti++];
+    k ^= (k >> 11); k ^= (k << 7) & 0x9d2c5680UL; k ^= (k << 15) & 0xefc60000UL; k ^= (k >> 18);
+    return k & 0xffffffffUL;
+  };
+  auto uniform = [&]() { return (double)next_u32() / 4294967296.0; };
+  for (int n = startX; n <= endX; n++) {
+    if (n < 0 || (size_t)n >= samples_.size()) throw jindex_error("randomize: sample %d outside of the %d loaded", n, (int)samples_.size());
+    double x, y, r2;
+    do { x = -1 + 2 * uniform(); y = -1 + 2 * uniform(); r2 = x * x + y * y; } while (r2 > 1.0 || r2 == 0);
+    samples_[(size_t)n] = (float)(sigma2 * y * sqrt(-2.0 * log(r2) / r2));
+  }
+}
+
+// feature.cc:391-427, literally: the noise is drawn into SHORT integers (rand() truncated, then (x / max - 0.5) truncated
+// again), so every noise sample is 0 or -(desired level / mean |noise|) -- kept as the reference computes it, time-seeded
+void SampleFeature::addWhiteNoise(float snr)
+{
+  const size_t n = samples_.size();
+  if (n == 0) return;
+  std::vector<short> noise(n);
+  double avgSig = 0.0, avgNoi = 0.0;
+  int max = -2147483647 - 1;
+  for (size_t i = 0; i < n; i++) avgSig += fabsf(samples_[i]);
+  avgSig /= (double)n;
+  srand((unsigned)time(NULL));
+  for (size_t i = 0; i < n; i++) { noise[i] = (short)rand(); if (noise[i] > max) max = noise[i]; }
+  for (size_t i = 0; i < n; i++) { noise[i] = (short)((noise[i] / (float)max) - 0.5); avgNoi += std::abs((int)noise[i]); }
+  avgNoi /= (double)n;
+  const double desiredNoA = avgSig / pow(10.0, snr / 20.0);
+  for (size_t i = 0; i < n; i++) noise[i] = (short)(desiredNoA * noise[i] / avgNoi);
+  for (size_t i = 0; i < n; i++) samples_[i] += noise[i];
 }
 
 const gsl_vector_float* SampleFeature::next(int frame_no)
@@ -270,16 +424,31 @@ OverSampledDFTSynthesisBank::OverSampledDFTSynthesisBank(VectorComplexFeatureStr
                                                          unsigned m, unsigned r, unsigned delayCompensationType, int gainFactor,
                                                          const String& nm)
     : VectorFloatFeatureStream(M >> r, nm), samp_(samp), M_(M), m_(m), r_(r), D_(M >> r), gain_(gainFactor), plan_(NULL),
-      nblocks_(0), prepared_(false), bsrc_(NULL), src_version_(0)
+      nblocks_(0), prepared_(false), bsrc_(NULL), src_version_(0), no_stream_feature_(false), npushed_(0), npushed_at_next_(0),
+      dWin_(NULL), dBlk_(NULL)
 {
-  if (prototype->size != (size_t)M * m)
-    throw jconsistency_error("Prototype sizes do not match (%d vs. %d).", (int)prototype->size, (int)(M * m));
-  std::vector<double> g(prototype->size);
-  for (size_t i = 0; i < g.size(); i++) g[i] = gsl_vector_get(prototype, i);
-  check_abi(btk_fb_create(&plan_, (int)M, (int)m, (int)r, (int)delayCompensationType, 1, g.data()));
+  init_(prototype, delayCompensationType);
 }
 
-OverSampledDFTSynthesisBank::~OverSampledDFTSynthesisBank() { btk_fb_destroy(plan_); }
+OverSampledDFTSynthesisBank::OverSampledDFTSynthesisBank(gsl_vector* prototype, unsigned M, unsigned m, unsigned r,
+                                                         unsigned delayCompensationType, int gainFactor, const String& nm)
+    : VectorFloatFeatureStream(M >> r, nm), samp_(NULL), M_(M), m_(m), r_(r), D_(M >> r), gain_(gainFactor), plan_(NULL),
+      nblocks_(0), prepared_(false), bsrc_(NULL), src_version_(0), no_stream_feature_(true), npushed_(0), npushed_at_next_(0),
+      dWin_(NULL), dBlk_(NULL)
+{
+  init_(prototype, delayCompensationType);
+}
+
+void OverSampledDFTSynthesisBank::init_(gsl_vector* prototype, unsigned delayCompensationType)
+{
+  if (prototype->size != (size_t)M_ * m_)
+    throw jconsistency_error("Prototype sizes do not match (%d vs. %d).", (int)prototype->size, (int)(M_ * m_));
+  std::vector<double> g(prototype->size);
+  for (size_t i = 0; i < g.size(); i++) g[i] = gsl_vector_get(prototype, i);
+  check_abi(btk_fb_create(&plan_, (int)M_, (int)m_, (int)r_, (int)delayCompensationType, 1, g.data()));
+}
+
+OverSampledDFTSynthesisBank::~OverSampledDFTSynthesisBank() { btk_fb_destroy(plan_); dev_free(dWin_); dev_free(dBlk_); }
 
 // Yk complex64 [>= K rows][T] -> blocks_; the first keep_blocks blocks (already handed over) keep their values
 void OverSampledDFTSynthesisBank::synthesize_(const std::vector<float>& Yk, long T, long keep_blocks)
@@ -328,8 +497,55 @@ void OverSampledDFTSynthesisBank::prepare_()
   prepared_ = true;
 }
 
+// update_buf_ of the source-less form (modulated.cc:551-567): one more subband frame enters the ring
+void OverSampledDFTSynthesisBank::input_source_vector(const gsl_vector_complex* block)
+{
+  if (!block || block->size != M_) throw jdimension_error("Input block length (%d) != fftLen (%d)\n", block ? (int)block->size : 0, M_);
+  const unsigned K = M_ / 2 + 1, W = m_ * (1u << r_) + (1u << r_);
+  if (ring_.size() >= (size_t)2 * K * W) ring_.erase(ring_.begin(), ring_.begin() + 2 * K);
+  for (unsigned k = 0; k < K; k++) {
+    ring_.push_back((float)block->data[2 * k * block->stride]);
+    ring_.push_back((float)block->data[2 * k * block->stride + 1]);
+  }
+  npushed_++;
+}
+
+// next() of the source-less form: block j of the stream "pd zero frames, then the pushed frames" -- the ring of a per-frame
+// graph after j + 1 pushes (update_buffer_ is a no-op and nothing is primed, modulated.cc:536-549, 574-578) -- computed from
+// the last m R + R virtual frames, which is everything the polyphase sums of the R overlapping blocks reach
+const gsl_vector_float* OverSampledDFTSynthesisBank::next_pushed_()
+{
+  if (npushed_ - npushed_at_next_ != 1)
+    throw jconsistency_error("OverSampledDFTSynthesisBank without a source: exactly one input_source_vector() per next() "
+                             "(%ld since the last one)\n", npushed_ - npushed_at_next_);
+  const unsigned K = M_ / 2 + 1, R = 1u << r_, W = m_ * R + R;
+  const long pd = btk_fb_processing_delay(plan_), Tv = pd + npushed_, Lw = Tv < (long)W ? Tv : (long)W;
+  const long nring = (long)(ring_.size() / (2 * K));
+  std::vector<float> win((size_t)2 * K * Lw, 0.f);                 // [K][Lw]
+  for (long i = 0; i < Lw; i++) {
+    const long p = Tv - Lw + i - pd;                               // pushed-frame index of virtual frame Tv - Lw + i
+    const long q = p - (npushed_ - nring);                         // its slot in the ring
+    if (p < 0 || q < 0) continue;
+    for (unsigned k = 0; k < K; k++) {
+      win[2 * ((size_t)k * Lw + i)] = ring_[2 * ((size_t)q * K + k)];
+      win[2 * ((size_t)k * Lw + i) + 1] = ring_[2 * ((size_t)q * K + k) + 1];
+    }
+  }
+  if (!dWin_) { dWin_ = dev_alloc(sizeof(float) * 2 * K * W); dBlk_ = dev_alloc(sizeof(float) * D_); }
+  h2d(dWin_, win.data(), sizeof(float) * win.size());
+  check_abi(btk_fb_synthesis(plan_, dWin_, Lw, Lw, 1, (float*)dBlk_, D_, Lw - 1 - pd, 1, NULL));
+  check_abi(btk_synchronize(NULL));
+  d2h(vector_->data, dBlk_, sizeof(float) * D_);
+  if (gain_ > 1) for (unsigned i = 0; i < D_; i++) vector_->data[i] *= (float)gain_;
+  npushed_at_next_ = npushed_;
+  increment_();
+  return vector_;
+}
+
 const gsl_vector_float* OverSampledDFTSynthesisBank::next(int frame_no)
 {
+  if (no_stream_feature_) return next_pushed_();
+  if (samp_.is_null()) throw jconsistency_error("OverSampledDFTSynthesisBank: no source stream (no_stream_feature(false) on a source-less bank)\n");
   if (!prepared_ || (bsrc_ && bsrc_->block_version() != src_version_)) prepare_();
   const long idx = frame_no_ + 1;
   if (idx >= nblocks_) { is_end_ = true; throw jiterator_error("end of samples!"); }
@@ -342,9 +558,10 @@ const gsl_vector_float* OverSampledDFTSynthesisBank::next(int frame_no)
 
 void OverSampledDFTSynthesisBank::reset()
 {
-  samp_->reset();
+  if (!no_stream_feature_ && !samp_.is_null()) samp_->reset();
   VectorFloatFeatureStream::reset();
   prepared_ = false; blocks_.clear(); nblocks_ = 0; bsrc_ = NULL; src_version_ = 0;
+  ring_.clear(); npushed_ = 0; npushed_at_next_ = 0;      // buffer_.zero() (modulated.cc:614-622)
 }
 
 // ================================================================================ SnapShotArray
@@ -1179,14 +1396,165 @@ ZelinskiPostFilter::ZelinskiPostFilter(VectorComplexFeatureStreamPtr& output, un
                                        int minFrames, const String& nm)
     : VectorComplexFeatureStream(fftLen, nm), fftLen_(fftLen), samp_(output), type_((PostfilterType)type), alpha_(alpha),
       min_frames_(minFrames), has_bf_ptr_(false), T_(0), prepared_(false), bf_version_(0), dPhi_(NULL), dPsi_(NULL), dWl_(NULL),
-      wp1_(gsl_vector_complex_calloc(fftLen))
+      wp1_(gsl_vector_complex_calloc(fftLen)), hist_start_(0), own_weights_(NULL), manual_frames_(0)
 {
   if (output->size() != fftLen) throw jdimension_error("Input block length (%d) != fftLen (%d)\n", output->size(), fftLen);
 }
 
-ZelinskiPostFilter::~ZelinskiPostFilter() { dev_free(dPhi_); dev_free(dPsi_); dev_free(dWl_); gsl_vector_complex_free(wp1_); }
+ZelinskiPostFilter::~ZelinskiPostFilter()
+{
+  if (has_bf_ptr_ && bf_ptr_->beamformer_weight_object()) bf_ptr_->beamformer_weight_object()->set_csd_provider(nullptr);
+  dev_free(dPhi_); dev_free(dPsi_); dev_free(dWl_); gsl_vector_complex_free(wp1_);
+  delete own_weights_;
+}
 
-void ZelinskiPostFilter::set_beamformer(SubbandDSPtr& bfptr) { has_bf_ptr_ = true; bf_ptr_ = bfptr; }
+void ZelinskiPostFilter::set_beamformer(SubbandDSPtr& bfptr)
+{
+  if (!has_bf_ptr_ && own_weights_) { delete own_weights_; own_weights_ = NULL; }      // postfilter.cc:373-382
+  has_bf_ptr_ = true;
+  bf_ptr_ = bfptr;
+}
+
+void ZelinskiPostFilter::set_snapshot_array(SnapShotArrayPtr& snapShotArray) { snapshot_array_ = snapShotArray; }
+
+// postfilter.cc:393-415: the vector goes into wq (type & TYPE_ZELINSKI2) or the array manifold of a weight object this
+// post-filter owns
+void ZelinskiPostFilter::set_array_manifold_vector(unsigned fbinX, gsl_vector_complex* v, bool halfBandShift, unsigned NC)
+{
+  if (fbinX >= size()) throw jdimension_error("fbinX %d must be less than %d\n", fbinX, size());
+  if (has_bf_ptr_) throw jconsistency_error("ZelinskiPostFilter: the weights belong to the beamformer given to set_beamformer()\n");
+  const unsigned chanN = (unsigned)v->size;
+  if (!own_weights_) {
+    own_weights_ = new BeamformerWeights(size(), chanN, halfBandShift, NC);
+    own_weights_->set_csd_provider([this](gsl_vector_complex** out) { fill_csds_(out); });
+  }
+  if (chanN != own_weights_->chanN()) throw jdimension_error("array manifold vector of %d channels, %d expected\n", chanN, own_weights_->chanN());
+  gsl_vector_complex** dst = (type_ & TYPE_ZELINSKI2) ? own_weights_->wq() : own_weights_->arrayManifold();
+  for (unsigned c = 0; c < chanN; c++) gsl_vector_complex_set(dst[fbinX], c, gsl_vector_complex_get(v, c));
+}
+
+void ZelinskiPostFilter::bind_csd_provider_()
+{
+  if (has_bf_ptr_ && bf_ptr_->beamformer_weight_object())
+    bf_ptr_->beamformer_weight_object()->set_csd_provider([this](gsl_vector_complex** out) { fill_csds_(out); });
+}
+
+// BeamformerWeights::CSDs() on demand (postfilter.cc:77-116): Phi_ij <- a Phi_ij + (1 - a) x'_i conj x'_j for i < j and the same
+// recursion on |x'_i|^2, x' = conj(d) x, a = 0 for the post-filter's first two frames, history restarted where the weights were
+// recomputed.  The recursion is linear, so the state after the last served frame t is sum_tau fw[tau] x(tau) x(tau)^H with
+// fw[tau] = (1 - a_tau) prod_{sigma > tau} a_sigma: ONE weighted covariance launch (btk_cov_accumulate) over the raw snapshots,
+// rotated by conj(d_i) d_j on the way into the reference's layout (entry i N + j; the lower triangle stays zero).
+void ZelinskiPostFilter::fill_csds_(gsl_vector_complex** out)
+{
+  const unsigned K = fftLen_ / 2 + 1;
+  const bool manual = !has_bf_ptr_;
+  BeamformerWeights* bw = manual ? own_weights_ : bf_ptr_->beamformer_weight_object();
+  if (!bw) return;
+  const unsigned N = bw->chanN();
+  const long t = manual ? manual_frames_ - 1 : (long)frame_no_;     // last frame whose statistics entered the recursion
+  for (unsigned k = 0; k < fftLen_; k++) gsl_vector_complex_set_zero(out[k]);
+  if (t < 0 || t < hist_start_) return;
+  const long Tn = t + 1;
+  std::vector<float> fw((size_t)Tn, 0.f);
+  double tail = 1.0;                                                // prod of a_sigma over sigma in (tau, t]
+  for (long tau = t; tau >= hist_start_; tau--) {
+    const double a_tau = (tau <= 1) ? 0.0 : alpha_;
+    fw[(size_t)tau] = (float)((1.0 - a_tau) * tail);
+    tail *= a_tau;
+    if (tail == 0.0) break;
+  }
+  void* dX;
+  void* dXown = NULL;
+  long Tstride;
+  if (manual) {                                                     // [T][K][N] on the host -> [K][N][T] on the device
+    std::vector<float> Xt((size_t)2 * K * N * Tn);
+    for (long f = 0; f < Tn; f++)
+      for (size_t kn = 0; kn < (size_t)K * N; kn++) {
+        Xt[2 * (kn * Tn + f)] = Xhist_[2 * ((size_t)f * K * N + kn)];
+        Xt[2 * (kn * Tn + f) + 1] = Xhist_[2 * ((size_t)f * K * N + kn) + 1];
+      }
+    dXown = dev_alloc(sizeof(float) * Xt.size());
+    h2d(dXown, Xt.data(), sizeof(float) * Xt.size());
+    dX = dXown; Tstride = Tn;
+  } else {
+    dX = bf_ptr_->device_snapshots(); Tstride = bf_ptr_->num_frames();
+  }
+  void* dF = dev_alloc(sizeof(float) * Tn);
+  void* dR = dev_alloc(sizeof(float) * 2 * K * N * N);
+  h2d(dF, fw.data(), sizeof(float) * Tn);
+  check_hip(hipMemset(dR, 0, sizeof(float) * 2 * K * N * N), "hipMemset");
+  check_abi(btk_cov_accumulate(dX, NULL, (const float*)dF, dR, 1, (int)K, (int)N, Tstride, Tn, 0, NULL));
+  check_abi(btk_synchronize(NULL));
+  std::vector<float> R((size_t)2 * K * N * N);
+  d2h(R.data(), dR, sizeof(float) * R.size());
+  dev_free(dF); dev_free(dR); dev_free(dXown);
+  gsl_vector_complex** dvec = align_with_wq_() ? bw->wq() : bw->arrayManifold();
+  for (unsigned k = 0; k < K; k++)
+    for (unsigned i = 0; i < N; i++) {
+      const cd di(dvec[k]->data[2 * i], dvec[k]->data[2 * i + 1]);
+      for (unsigned j = i; j < N; j++) {
+        const cd dj(dvec[k]->data[2 * j], dvec[k]->data[2 * j + 1]);
+        const size_t o = 2 * (((size_t)k * N + i) * N + j);
+        const cd v = std::conj(di) * dj * cd(R[o], R[o + 1]);
+        out[k]->data[2 * (i * N + j)] = v.real();
+        out[k]->data[2 * (i * N + j) + 1] = (i == j) ? 0.0 : v.imag();
+      }
+    }
+}
+
+// next() without a beamformer object (postfilter.cc:424-491 with snapshot_array_ / bf_weights_ given by the caller): the frame of
+// samp_ is scaled by the gain the snapshot of this moment yields -- the two kernels of the block path on a one-frame block
+const gsl_vector_complex* ZelinskiPostFilter::next_manual_(int frame_no)
+{
+  const gsl_vector_complex* output;
+  if (frame_no >= 0) output = samp_->next(frame_no);
+  else output = samp_->next(frame_no_ == frame_reset_no_ ? 0 : frame_no_ + 1);
+  if (!own_weights_) throw j_error("set beamformer's weights \n");
+  if (lefkimmiatis_or_mccowan_()) throw j_error("%s without a beamformer object is not supported: set_beamformer() first\n", name().c_str());
+  if (snapshot_array_.is_null()) throw j_error("ZelinskiPostFilter: set_snapshot_array() first\n");
+  if (own_weights_->isHalfBandShift()) throw j_error("post-filters with halfBandShift==true are not supported by this engine\n");
+  const unsigned K = fftLen_ / 2 + 1, N = own_weights_->chanN();
+  if (snapshot_array_->nChan() != N || snapshot_array_->fftLen() != fftLen_)
+    throw jdimension_error("snapshot array is %d x %d, %d x %d expected\n", snapshot_array_->fftLen(), snapshot_array_->nChan(), fftLen_, N);
+  gsl_vector_complex** dvec = (type_ & TYPE_ZELINSKI2) ? own_weights_->wq() : own_weights_->arrayManifold();
+  std::vector<float> x((size_t)2 * K * N), d((size_t)2 * K * N), y((size_t)2 * K);
+  for (unsigned k = 0; k < K; k++) {
+    const gsl_vector_complex* sn = snapshot_array_->snapshot(k);
+    for (unsigned c = 0; c < N; c++) {
+      x[2 * ((size_t)k * N + c)] = (float)sn->data[2 * c]; x[2 * ((size_t)k * N + c) + 1] = (float)sn->data[2 * c + 1];
+      d[2 * ((size_t)k * N + c)] = (float)dvec[k]->data[2 * c]; d[2 * ((size_t)k * N + c) + 1] = (float)dvec[k]->data[2 * c + 1];
+    }
+    y[2 * k] = (float)output->data[2 * k]; y[2 * k + 1] = (float)output->data[2 * k + 1];
+  }
+  Xhist_.insert(Xhist_.end(), x.begin(), x.end());
+  if (!dPhi_) {
+    dPhi_ = dev_alloc(sizeof(float) * 2 * K); dPsi_ = dev_alloc(sizeof(float) * K); dWl_ = dev_alloc(sizeof(float) * K);
+    check_hip(hipMemset(dPhi_, 0, sizeof(float) * 2 * K), "hipMemset");
+    check_hip(hipMemset(dPsi_, 0, sizeof(float) * K), "hipMemset");
+    check_hip(hipMemset(dWl_, 0, sizeof(float) * K), "hipMemset");
+  }
+  void* dXf = dev_alloc(sizeof(float) * x.size());
+  void* dD = dev_alloc(sizeof(float) * d.size());
+  void* dY = dev_alloc(sizeof(float) * 2 * K);
+  void* dC = dev_alloc(sizeof(float) * 2 * K);
+  void* dE = dev_alloc(sizeof(float) * K);
+  h2d(dXf, x.data(), sizeof(float) * x.size());
+  h2d(dD, d.data(), sizeof(float) * d.size());
+  check_abi(btk_bf_apply_stats(dD, dD, 0, dXf, dY, dC, (float*)dE, 1, (int)K, (int)N, 1, 1, NULL));   // only C and E are used
+  h2d(dY, y.data(), sizeof(float) * y.size());                                                        // the frame to filter is samp_'s
+  check_abi(btk_zelinski_process(dY, dC, (const float*)dE, 1, (int)K, (int)N, 1, 1, alpha_, (int)type_, min_frames_,
+                                 manual_frames_, dPhi_, (float*)dPsi_, (float*)dWl_, NULL));
+  check_abi(btk_synchronize(NULL));
+  d2h(y.data(), dY, sizeof(float) * y.size());
+  dev_free(dXf); dev_free(dD); dev_free(dY); dev_free(dC); dev_free(dE);
+  for (unsigned k = 0; k < K; k++) {
+    vector_->data[2 * k] = y[2 * k]; vector_->data[2 * k + 1] = y[2 * k + 1];
+    if (k > 0 && k < fftLen_ / 2) { vector_->data[2 * (fftLen_ - k)] = y[2 * k]; vector_->data[2 * (fftLen_ - k) + 1] = -y[2 * k + 1]; }
+  }
+  manual_frames_++;
+  increment_();
+  return vector_;
+}
 
 void ZelinskiPostFilter::compute_(long from_frame)
 {
@@ -1230,6 +1598,8 @@ void ZelinskiPostFilter::compute_(long from_frame)
   }
   merge_output_(Ynew, from_frame);
   bf_version_ = bf->weights_version();
+  hist_start_ = from_frame;
+  bind_csd_provider_();
   prepared_ = true;
 }
 
@@ -1245,7 +1615,7 @@ void ZelinskiPostFilter::merge_output_(std::vector<float>& Ynew, long from_frame
 const gsl_vector_complex* ZelinskiPostFilter::next(int frame_no)
 {
   if (frame_no == frame_no_) return vector_;
-  if (!has_bf_ptr_) throw j_error("set beamformer's weights \n");
+  if (!has_bf_ptr_) return next_manual_(frame_no);
   if (!prepared_ || bf_version_ != bf_ptr_->weights_version()) compute_(frame_no_ + 1);
   const long idx = frame_no_ + 1;
   if (idx >= T_) { is_end_ = true; throw jiterator_error("end of samples!"); }
@@ -1280,8 +1650,8 @@ const gsl_vector_complex* ZelinskiPostFilter::postfilter_weights()
     if (k > 0 && k < fftLen_ / 2) { wp1_->data[2 * (fftLen_ - k)] = wl[k]; wp1_->data[2 * (fftLen_ - k) + 1] = 0.0; }
   }
   // the reference keeps these gains in the beamformer's weight object (BeamformerWeights::wp1(), postfilter.cc:447): mirror them
-  if (has_bf_ptr_ && bf_ptr_->beamformer_weight_object() && bf_ptr_->beamformer_weight_object()->fftLen() == fftLen_)
-    memcpy(bf_ptr_->beamformer_weight_object()->wp1()->data, wp1_->data, sizeof(double) * 2 * fftLen_);
+  if (weights_object() && weights_object()->fftLen() == fftLen_)
+    memcpy(weights_object()->wp1()->data, wp1_->data, sizeof(double) * 2 * fftLen_);
   return wp1_;
 }
 
@@ -1291,6 +1661,13 @@ void ZelinskiPostFilter::reset()
   VectorComplexFeatureStream::reset();
   is_end_ = false;
   prepared_ = false; Yhost_.clear();
+  Xhist_.clear(); manual_frames_ = 0; hist_start_ = 0;
+  if (!has_bf_ptr_ && dPhi_) {              // manual mode: the densities of the next utterance start from zero
+    const unsigned K = fftLen_ / 2 + 1;
+    check_hip(hipMemset(dPhi_, 0, sizeof(float) * 2 * K), "hipMemset");
+    check_hip(hipMemset(dPsi_, 0, sizeof(float) * K), "hipMemset");
+    check_hip(hipMemset(dWl_, 0, sizeof(float) * K), "hipMemset");
+  }
 }
 
 // ================================================================================ McCowan / Lefkimmiatis
@@ -1468,6 +1845,8 @@ void McCowanPostFilter::compute_(long from_frame)
   }
   merge_output_(Ynew, from_frame);
   bf_version_ = bf->weights_version();
+  hist_start_ = from_frame;
+  bind_csd_provider_();
   prepared_ = true;
 }
 

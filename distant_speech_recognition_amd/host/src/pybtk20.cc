@@ -248,7 +248,29 @@ PYBIND11_MODULE(_btk20cpp, m)
       .def("set_samples", [](SampleFeature& s, py::array_t<float, py::array::c_style | py::array::forcecast> a) { s.set_samples(a.data(), (size_t)a.size()); })
       .def("samplerate", &SampleFeature::getSampleRate)
       .def("getSampleRate", &SampleFeature::getSampleRate)
-      .def("samplesN", &SampleFeature::samplesN);
+      .def("getChanN", &SampleFeature::getChanN)
+      .def("samplesN", &SampleFeature::samplesN)
+      .def("write", [](SampleFeature& s, const std::string& fn, int format, int sampleRate) { s.write(fn, format, sampleRate); },
+           py::arg("fn"), py::arg("format") = (int)(sndfile::SF_FORMAT_WAV | sndfile::SF_FORMAT_PCM_16), py::arg("sampleRate") = -1)
+      .def("cut", &SampleFeature::cut, py::arg("cfrom"), py::arg("cto"))
+      .def("randomize", &SampleFeature::randomize, py::arg("startX"), py::arg("endX"), py::arg("sigma2"))
+      .def("exit", &SampleFeature::exit)
+      .def("data", [](SampleFeature& s) {
+             const gsl_vector_float* v = s.data();
+             py::array_t<float> a((py::ssize_t)v->size);
+             if (v->size) memcpy(a.mutable_data(), v->data, sizeof(float) * v->size);
+             return a; })
+      .def("dataDouble", [](SampleFeature& s) {
+             const gsl_vector* v = s.dataDouble();
+             py::array_t<double> a((py::ssize_t)v->size);
+             if (v->size) memcpy(a.mutable_data(), v->data, sizeof(double) * v->size);
+             return a; })
+      .def("copySamples", [](SampleFeature& s, SampleFeature* src, unsigned cfrom, unsigned to) { SampleFeaturePtr p(src); s.copySamples(p, cfrom, to); },
+           py::arg("src"), py::arg("cfrom"), py::arg("to"))
+      .def("zeroMean", &SampleFeature::zeroMean)
+      .def("addWhiteNoise", &SampleFeature::addWhiteNoise, py::arg("snr"))
+      .def("setSamples", [](SampleFeature& s, py::array_t<double, py::array::c_style | py::array::forcecast> a, unsigned sampleRate) {
+             GslVec v(a); s.setSamples(v.v, sampleRate); }, py::arg("samples"), py::arg("sampleRate"));
 
   // ---- modulated/modulated.h
   py::class_<OverSampledDFTAnalysisBank, VectorComplexFeatureStream, cref<OverSampledDFTAnalysisBank>>(m, "OverSampledDFTAnalysisBankPtr")
@@ -265,13 +287,27 @@ PYBIND11_MODULE(_btk20cpp, m)
       .def("nBlocks", &OverSampledDFTAnalysisBank::nBlocks)
       .def("subSampRate", &OverSampledDFTAnalysisBank::subSampRate);
   py::class_<OverSampledDFTSynthesisBank, VectorFloatFeatureStream, cref<OverSampledDFTSynthesisBank>>(m, "OverSampledDFTSynthesisBankPtr")
+      // source-less form (modulated/modulated.i:151-171): frames are pushed with input_source_vector(); registered first so that a
+      // prototype array in the first position is not taken for a source object
+      .def(py::init([](py::array_t<double, py::array::c_style | py::array::forcecast> prototype, unsigned M, unsigned mm, unsigned r,
+                       unsigned dct, int gain_factor, const std::string& nm) {
+             GslVec g(prototype);
+             return new OverSampledDFTSynthesisBank(g.v, M, mm, r, dct, gain_factor, nm);
+           }), py::arg("prototype"), py::arg("M"), py::arg("m"), py::arg("r") = 0, py::arg("delay_compensation_type") = 0,
+           py::arg("gain_factor") = 1, py::arg("nm") = "OverSampledDFTSynthesisBank")
       .def(py::init([](py::object samp, py::array_t<double, py::array::c_style | py::array::forcecast> prototype, unsigned M, unsigned mm,
                        unsigned r, unsigned dct, int gain_factor, const std::string& nm) {
              VectorComplexFeatureStreamPtr sp = as_cstream(samp);
              GslVec g(prototype);
              return new OverSampledDFTSynthesisBank(sp, g.v, M, mm, r, dct, gain_factor, nm);
            }), py::arg("samp"), py::arg("prototype"), py::arg("M"), py::arg("m"), py::arg("r") = 0, py::arg("delay_compensation_type") = 0,
-           py::arg("gain_factor") = 1, py::arg("nm") = "OverSampledDFTSynthesisBank");
+           py::arg("gain_factor") = 1, py::arg("nm") = "OverSampledDFTSynthesisBank")
+      .def("input_source_vector", [](OverSampledDFTSynthesisBank& b, py::array_t<cd, py::array::c_style | py::array::forcecast> block) {
+             GslCVec v(block); b.input_source_vector(v.v); }, py::arg("block"))
+      .def("inputSourceVector", [](OverSampledDFTSynthesisBank& b, py::array_t<cd, py::array::c_style | py::array::forcecast> block) {
+             GslCVec v(block); b.input_source_vector(v.v); }, py::arg("block"))
+      .def("no_stream_feature", &OverSampledDFTSynthesisBank::no_stream_feature, py::arg("flag") = true)
+      .def("doNotUseStreamFeature", &OverSampledDFTSynthesisBank::no_stream_feature, py::arg("flag") = true);
 
   // ---- beamformer/beamformer.h
   py::class_<SnapShotArray, cref<SnapShotArray>>(m, "SnapShotArrayPtr")
@@ -329,6 +365,13 @@ PYBIND11_MODULE(_btk20cpp, m)
       .def_property_readonly("wa", [](BeamformerWeights& w) {
              py::array_t<cd> a({(py::ssize_t)w.fftLen(), (py::ssize_t)(w.chanN() - w.NC())});
              memcpy(static_cast<void*>(a.mutable_data()), w.wa_v.data(), sizeof(cd) * w.wa_v.size()); return a; })
+      // the reference's auto / cross spectral densities of bin fbinX as an N x N matrix (entry [i][j], i <= j; rebuilt on demand)
+      .def("CSDs", [](BeamformerWeights& w, unsigned fbinX) {
+             if (fbinX >= w.fftLen()) throw jindex_error("bin %d of %d", (int)fbinX, (int)w.fftLen());
+             gsl_vector_complex** c = w.CSDs();
+             py::array_t<cd> a({(py::ssize_t)w.chanN(), (py::ssize_t)w.chanN()});
+             memcpy(static_cast<void*>(a.mutable_data()), c[fbinX]->data, sizeof(cd) * w.chanN() * w.chanN()); return a; }, py::arg("fbinX"))
+      .def("wp1", [](BeamformerWeights& w) { return copy_of(w.wp1()); })
       .def_property_readonly("B", [](BeamformerWeights& w) {
              py::array_t<cd> a({(py::ssize_t)w.fftLen(), (py::ssize_t)w.chanN(), (py::ssize_t)(w.chanN() - w.NC())});
              memcpy(static_cast<void*>(a.mutable_data()), w.B_v.data(), sizeof(cd) * w.B_v.size()); return a; });
@@ -420,6 +463,18 @@ PYBIND11_MODULE(_btk20cpp, m)
            }), py::arg("output"), py::arg("fftlen"), py::arg("alpha") = 0.6, py::arg("type") = 2, py::arg("min_frames") = 0, py::arg("nm") = "ZelinskPostFilter")
       .def("set_beamformer", [](ZelinskiPostFilter& f, SubbandDS* bf) { SubbandDSPtr p(bf); f.set_beamformer(p); })
       .def("setBeamformer", [](ZelinskiPostFilter& f, SubbandDS* bf) { SubbandDSPtr p(bf); f.set_beamformer(p); })
+      .def("set_snapshot_array", [](ZelinskiPostFilter& f, SnapShotArray* a) { SnapShotArrayPtr p(a); f.set_snapshot_array(p); }, py::arg("snapShotArray"))
+      .def("setSnapShotArray", [](ZelinskiPostFilter& f, SnapShotArray* a) { SnapShotArrayPtr p(a); f.set_snapshot_array(p); }, py::arg("snapShotArray"))
+      .def("set_array_manifold_vector", [](ZelinskiPostFilter& f, unsigned fbinX, py::array_t<cd, py::array::c_style | py::array::forcecast> v, bool halfBandShift, unsigned NC) {
+             GslCVec g(v); f.set_array_manifold_vector(fbinX, g.v, halfBandShift, NC); },
+           py::arg("fbinX"), py::arg("arrayManifoldVector"), py::arg("halfBandShift"), py::arg("NC") = 1)
+      .def("setArrayManifoldVector", [](ZelinskiPostFilter& f, unsigned fbinX, py::array_t<cd, py::array::c_style | py::array::forcecast> v, bool halfBandShift, unsigned NC) {
+             GslCVec g(v); f.set_array_manifold_vector(fbinX, g.v, halfBandShift, NC); },
+           py::arg("fbinX"), py::arg("arrayManifoldVector"), py::arg("halfBandShift"), py::arg("NC") = 1)
+      .def("weights_object", [](ZelinskiPostFilter& f) -> py::object {      // bf_weights_ (postfilter.h:104); None before any weights exist
+             BeamformerWeights* w = f.weights_object();
+             return w ? py::cast(w, py::return_value_policy::reference) : py::none(); })
+      .def("getPostFilterWeights", [](ZelinskiPostFilter& f) { return copy_of(f.postfilter_weights()); })
       .def("postfilter_weights", [](ZelinskiPostFilter& f) { return copy_of(f.postfilter_weights()); })
       .def("device_block", [](ZelinskiPostFilter& f) { return block_of(f); })
       .def("_output_version", [](ZelinskiPostFilter& f) { return f.block_version(); })

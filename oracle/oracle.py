@@ -275,9 +275,10 @@ def gsc_frames(X, wq, wl=None, normalize=False):
     return out
 
 
-def zelinski_frames(X, Y, d, alpha, type_=2, min_frames=0):
+def zelinski_frames(X, Y, d, alpha, type_=2, min_frames=0, return_csd=False):
     """ZelinskiPostFilter over a whole utterance. X [T][N][M], Y [T][M] beamformer output,
-    d [M][N] (wq or ta_).  Returns filtered Y [T][M] and weights [T][M]."""
+    d [M][N] (wq or ta_).  Returns filtered Y [T][M] and weights [T][M] (and, with return_csd, BeamformerWeights::CSDs()
+    after the last frame: [M][N*N], entry i N + j for i <= j, postfilter.cc:77-116)."""
     X, Y, d = _c128(X), _c128(Y).copy(), _c128(d)
     T, N, M = X.shape
     csd = np.zeros((M, N * N), np.complex128)
@@ -290,7 +291,7 @@ def zelinski_frames(X, Y, d, alpha, type_=2, min_frames=0):
         L.orc_zelinski_frame(_p(d), _p(snaps), M, N, _p(csd), _p(wp1), float(alpha), int(type_),
                              int(min_frames), t - 1, _p(Y[t]))
         W[t] = wp1
-    return Y, W
+    return (Y, W, csd) if return_csd else (Y, W)
 
 
 def mccowan_frames(X, Y, d, R, alpha=0.6, type_=2, min_frames=0, threshold=0.99):

@@ -214,3 +214,116 @@ int main() {
         for k in range(M):
             R[k] = muf * R[k] + (1.0 - muf) * np.outer(x[:, k], x[:, k])
     assert np.max(np.abs(got - R)) < 1e-12
+
+
+def test_sample_feature_full_class(tmp_path):
+    """The rest of SampleFeature (feature/feature.h:153-206, feature.cc:391-680): 16-bit write() / read() round trip, cut (both bounds
+    inclusive), zeroMean (int16 clamp, truncation toward zero), copySamples' `to - cfrom` count, setSamples / data / dataDouble,
+    getChanN, exit(), normalised reads (libsndfile's x / 32768 times norm) and the write() that undoes them."""
+    from distant_speech_recognition_amd.btk20 import SampleFeaturePtr, j_error
+    rng = np.random.default_rng(3)
+    x = rng.integers(-20000, 20000, 4000).astype(np.int16)
+    p = tmp_path / "a.wav"
+    _wav(p, x, fs=8000)
+    sf = SampleFeaturePtr(block_len=256, shift_len=256, pad_zeros=True)
+    assert sf.read(str(p)) == 4000 and sf.getSampleRate() == 8000 and sf.getChanN() == 1
+    assert np.array_equal(sf.data(), x.astype(np.float32)) and sf.dataDouble().dtype == np.float64
+    # write -> read is the identity on int16 values; the file keeps the sample rate
+    sf.write(str(tmp_path / "b.wav"))
+    w = wave.open(str(tmp_path / "b.wav"))
+    assert (w.getnchannels(), w.getsampwidth(), w.getframerate(), w.getnframes()) == (1, 2, 8000, 4000)
+    assert np.array_equal(np.frombuffer(w.readframes(4000), np.int16), x)
+    with pytest.raises(j_error):
+        sf.write(str(tmp_path / "c.au"), format=0x030002)              # only WAV | PCM_16
+    # cut: samples cfrom..cto inclusive
+    sf.cut(cfrom=100, cto=1099)
+    assert sf.samplesN() == 1000 and np.array_equal(sf.data(), x[100:1100].astype(np.float32))
+    with pytest.raises(j_error):
+        sf.cut(5, 5)
+    with pytest.raises(j_error):
+        sf.cut(0, 1000)
+    # zeroMean: x - mean clamped to int16 and truncated toward zero
+    m = float(np.mean(x[100:1100].astype(np.float64)))
+    sf.zeroMean()
+    want = np.trunc(np.clip(x[100:1100].astype(np.float32).astype(np.float64) - m, -32768, 32767)).astype(np.float32)
+    assert np.array_equal(sf.data(), want)
+    # copySamples: `to - cfrom` samples from cfrom (the reference's count), to == 0 copies everything
+    src = SampleFeaturePtr(block_len=256, shift_len=256)
+    src.read(str(p))
+    dst = SampleFeaturePtr(block_len=256, shift_len=256)
+    dst.copySamples(src, cfrom=10, to=110)
+    assert dst.samplesN() == 100 and np.array_equal(dst.data(), x[10:110].astype(np.float32))
+    dst.copySamples(src, 0, 0)
+    assert dst.samplesN() == 4000
+    # setSamples takes doubles and a sample rate, and the node iterates over them
+    dst.setSamples(np.arange(600, dtype=np.float64), sampleRate=44100)
+    assert dst.getSampleRate() == 44100 and np.array_equal(np.concatenate([np.array(b) for b in dst])[:512], np.arange(512, dtype=np.float32))
+    with pytest.raises(StopIteration):
+        dst.exit()
+    # normalised read (norm != 0): x / 32768 * norm, and write() maps it back to the same int16 values
+    nf = SampleFeaturePtr(block_len=256, shift_len=256)
+    nf.read(str(p), norm=1.0)
+    assert np.allclose(nf.data(), x / 32768.0, rtol=0, atol=1e-7)
+    nf.write(str(tmp_path / "n.wav"))
+    back = np.frombuffer(wave.open(str(tmp_path / "n.wav")).readframes(4000), np.int16)
+    assert np.max(np.abs(back.astype(int) - x.astype(int))) <= 1        # 0x7FFF vs 0x8000 scale, as libsndfile
+
+
+def test_sample_feature_randomize_is_gsl_mt19937_gaussian():
+    """randomize() (feature.cc:589-603) draws gsl_ran_gaussian from gsl_rng_default = mt19937 with GSL's default seed; GSL's manual
+    gives the known answer of that generator ("generator type: mt19937, seed = 0, first value = 4293858116"); the polar Box-Muller
+    on top is restated here from the published algorithm."""
+    from distant_speech_recognition_amd.btk20 import SampleFeaturePtr
+    bg = np.random.MT19937()
+    bg._legacy_seeding(4357)                                            # GSL: seed 0 means 4357
+    raw = bg.random_raw(400).astype(np.float64)
+    assert int(raw[0]) == 4293858116
+    u = iter(raw / 4294967296.0)
+    want = []
+    while len(want) < 50:
+        xx, yy = -1 + 2 * next(u), -1 + 2 * next(u)
+        r2 = xx * xx + yy * yy
+        if r2 > 1.0 or r2 == 0:
+            continue
+        want.append(3.0 * yy * np.sqrt(-2.0 * np.log(r2) / r2))
+    sf = SampleFeaturePtr(block_len=16, shift_len=16)
+    sf.setSamples(np.zeros(100), 16000)
+    sf.randomize(startX=20, endX=69, sigma2=3.0)
+    d = sf.data()
+    assert np.all(d[:20] == 0) and np.all(d[70:] == 0)
+    assert np.allclose(d[20:70], np.array(want, np.float32), rtol=1e-6, atol=0)
+
+
+def test_sample_feature_add_white_noise_is_the_references_arithmetic():
+    """addWhiteNoise (feature.cc:391-427) draws its noise into SHORT integers, so every noise sample is 0 or one negative level;
+    the mean absolute noise equals the level the SNR asks for (up to the truncation of that one level to a short)."""
+    from distant_speech_recognition_amd.btk20 import SampleFeaturePtr
+    x = np.full(20000, 1000.0)
+    sf = SampleFeaturePtr(block_len=16, shift_len=16)
+    sf.setSamples(x, 16000)
+    sf.addWhiteNoise(snr=20.0)
+    n = sf.data().astype(np.float64) - x
+    vals = np.unique(n)
+    assert len(vals) == 2 and vals[1] == 0 and vals[0] < 0
+    assert abs(np.mean(np.abs(n)) - 100.0) <= 100.0 * (1.0 / abs(vals[0])) + 1e-9     # |level| truncated by < 1
+
+
+def test_kwargs_are_the_swig_interface_names():
+    """%feature("kwargs") in btk20_src/*/*.i: the parameter names a script may use are the ones the .i files declare (the table
+    is generated from them, tools/gen_swig_signatures.py); the spellings earlier versions used still work, and a keyword neither
+    table knows reaches the binding's own py::arg names instead of raising here."""
+    from distant_speech_recognition_amd import btk20
+    from distant_speech_recognition_amd.btk20cpp import _signatures as S
+    assert S.METHODS["SubbandGSCPtr"]["set_active_weights_f"] == [("fbinX", "required"), ("packedWeight", "required")]
+    assert S.METHODS["MultiChannelWPEDereverberationPtr"]["estimate_filter"] == [("start_frame_no", 0), ("frame_num", -1)]
+    assert [p for p, _ in S.METHODS["SubbandGSCPtr"]["calc_gsc_weights_2"]] == ["samplerate", "delaysT", "delaysJ"]
+    assert [p for p, _ in S.METHODS["SnapShotArrayPtr"]["set_samples"]] == ["samp", "chanX"]
+    a = btk20.SnapShotArrayPtr(fftlen=8, chan_num=2)
+    a.set_samples(samp=np.arange(8) + 1j, chanX=1)                      # the .i names
+    a.set_samples(samp=np.arange(8) + 2j, chan_no=0)                    # the earlier spelling
+    a.update()
+    assert a.snapshot(fbinX=3)[1] == 3 + 1j and a.snapshot(fbin_no=3)[0] == 3 + 2j
+    sf = btk20.SampleFeaturePtr(block_len=4, shift_len=4)
+    sf.setSamples(samples=np.arange(8.0), sampleRate=8000)
+    with pytest.raises(TypeError):
+        sf.setSamples(samples=np.arange(8.0), no_such_name=1)
