@@ -90,6 +90,7 @@ SIGNATURES = {
     "btk_mvdr_pinv_fallback": (_i, [_vp, _vp, _vp, _i, _i, _i, _f, _vp, C.POINTER(_i), _vp]),
     "btk_mvdr_pinv_scratch_bytes": (_l, [_i, _i]),
     "btk_mvdr_pinv_fallback_async": (_i, [_vp, _vp, _vp, _i, _i, _i, _f, _vp, _vp, _vp, _vp]),
+    "btk_mvdr_pinv_not_converged": (_i, []),
     "btk_mvdr_pinv_fallback_host": (_i, [_vp, _vp, _vp, _i, _i, _i, _f, _vp, C.POINTER(_i), _vp]),
     "btk_pinv": (_i, [_vp, _i, _i, _f, _vp, C.POINTER(_i)]),
     "btk_wpe_workspace_bytes": (_l, [_i, _i, _i, _i, _i, _l]),

@@ -6,6 +6,7 @@ hand-written HIP kernel in csrc/.  Tensor layouts:
     pcm  float32   [S][N][L]       X  complex64 [S][K][N][T]
     W    complex64 [S|1][K][N]     Y  complex64 [S][K][T]      out float32 [S][B*D]
 """
+import collections
 import ctypes as C
 
 import numpy as np
@@ -185,11 +186,18 @@ class FilterBank:
         # the weight-pair scratch is written by a kernel of THIS launch's stream: one buffer per (device, stream), so that a plan
         # shared by several streams (serving.BatchBeamformerPipeline next to a caller's own stream) never has two launches
         # re-packing weights into the same bytes
+        # The buffers come from torch's stream-aware caching allocator and are RETURNED to it when evicted: it re-issues a block only
+        # to the stream that allocated it, so a recycled raw stream handle cannot be handed bytes another stream is still writing.
+        # At most eight (device, stream) pairs are kept, least recently used first out: transient torch.cuda.Stream objects do not
+        # pile up one buffer each.
         key = (pcm.device.index, int(torch.cuda.current_stream().cuda_stream))
-        cache = self.__dict__.setdefault("_bf_scratch", {})
-        buf = cache.get(key)
+        cache = self.__dict__.setdefault("_bf_scratch", collections.OrderedDict())
+        buf = cache.pop(key, None)
         if buf is None or buf.numel() < nb:
-            buf = cache[key] = torch.empty(nb, dtype=torch.uint8, device=pcm.device)
+            buf = torch.empty(nb, dtype=torch.uint8, device=pcm.device)
+        cache[key] = buf
+        while len(cache) > 8:
+            cache.popitem(last=False)
         check(_lib.lib().btk_fb_analysis_bf(self._h, _ptr(pcm), nsamples, L, S, N, _ptr(W), per_stream, _ptr(out), t_stride,
                                             t0, tcount, _ptr(buf), buf.numel(), _stream()))
         return out

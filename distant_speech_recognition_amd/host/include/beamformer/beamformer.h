@@ -173,6 +173,7 @@ class SubbandDS : public SubbandBeamformer, public BlockSource {
   virtual const char* need_weights_msg_() const { return "call calc_array_manifold_vectorsX() once\n"; }
   BeamformerWeights* bfweight_;
   unsigned long weights_version_, output_version_;
+  long handed_;                   // block protocol: frames 0 .. handed_ were handed to a batching consumer (advance_to)
   std::vector<float> Yhost_;      // [K][T] complex64
   gsl_vector_complex* wq_view_;
 };
@@ -230,8 +231,10 @@ class SubbandGSCRLS : public SubbandGSC {
  private:
   void alloc_state_();
   void run_block_();
+  void refresh_block_();
   float mu_, diagonal_weight_, alpha_;
   QuadraticConstraintType qctype_;
+  unsigned long rls_version_;       // weights_version_ the cached block was computed with
   bool is_wa_updated_, have_P_;
   void *dP_, *dW_, *dV_, *dSS_;     // device: P complex128 [K][N][N], w complex128 [K][N], wq complex128 [K][N], stream state
   void* dCx_;                       // NC > 1: the further blocked directions, complex128 [K][NC-1][N] (btk_rls_*_nc)

@@ -58,6 +58,7 @@ class ZelinskiPostFilter : public VectorComplexFeatureStream, public BlockSource
   BeamformerWeights* own_weights_;          // manual mode: created by set_array_manifold_vector
   std::vector<float> Xhist_;                // manual mode: the snapshots seen so far, complex64 [T][K][N] (for CSDs())
   long manual_frames_;
+  long handed_;                             // block protocol mark (see SubbandDS::advance_to)
 };
 typedef Inherit<ZelinskiPostFilter, VectorComplexFeatureStreamPtr> ZelinskiPostFilterPtr;
 

@@ -931,7 +931,7 @@ SnapShotArrayPtr SubbandBeamformer::snapshot_array()
 // ================================================================================ SubbandDS
 SubbandDS::SubbandDS(unsigned fftLen, bool halfBandShift, const String& nm)
     : SubbandBeamformer(fftLen, halfBandShift, nm), bfweight_(NULL), weights_version_(0), output_version_(0),
-      wq_view_(gsl_vector_complex_calloc(1)) {}
+      handed_(-1), wq_view_(gsl_vector_complex_calloc(1)) {}
 SubbandDS::~SubbandDS() { delete bfweight_; gsl_vector_complex_free(wq_view_); }
 
 void SubbandDS::clear_channel() { SubbandBeamformer::clear_channel(); delete bfweight_; bfweight_ = NULL; }
@@ -1062,7 +1062,7 @@ const gsl_vector_complex* SubbandDS::next(int frame_no)
 {
   if (frame_no == frame_no_) return vector_;
   if (!bfweight_) throw j_error("%s", need_weights_msg_());
-  if (Yhost_.empty() || output_version_ != weights_version_) compute_output_(frame_no_ + 1);
+  if (Yhost_.empty() || output_version_ != weights_version_) compute_output_(std::max<long>(frame_no_, handed_) + 1);
   const long idx = frame_no_ + 1;
   if (idx >= T_) { is_end_ = true; throw jiterator_error("end of samples!"); }
   if (halfBandShift_) serve_frame_all_bins(Yhost_, T_, fftLen_, idx, vector_);
@@ -1071,21 +1071,23 @@ const gsl_vector_complex* SubbandDS::next(int frame_no)
   return vector_;
 }
 
-void SubbandDS::reset() { SubbandBeamformer::reset(); Yhost_.clear(); }
+void SubbandDS::reset() { SubbandBeamformer::reset(); Yhost_.clear(); handed_ = -1; }
 
 const std::vector<float>& SubbandDS::block(long& T)
 {
   if (!bfweight_) throw j_error("%s", need_weights_msg_());
-  if (Yhost_.empty() || output_version_ != weights_version_) compute_output_(frame_no_ + 1);
+  if (Yhost_.empty() || output_version_ != weights_version_) compute_output_(std::max<long>(frame_no_, handed_) + 1);
   T = T_;
   return Yhost_;
 }
 
 void SubbandDS::advance_to(long frame_idx)
 {
-  // frames 0 .. frame_idx count as handed over: a weight change from now on recomputes only the frames beyond
+  // frames 0 .. frame_idx count as handed over to the block consumer: a weight change from now on recomputes only the frames
+  // beyond.  The mark is the block protocol's own -- frame_no_ stays what next() has served, so a second consumer that pulls this
+  // node frame by frame (or the script itself) still gets every frame
   if (frame_idx >= T_) frame_idx = T_ - 1;
-  if (frame_idx > frame_no_) frame_no_ = (int)frame_idx;
+  if (frame_idx > handed_) handed_ = frame_idx;
 }
 
 // ================================================================================ SubbandGSC
@@ -1396,7 +1398,7 @@ ZelinskiPostFilter::ZelinskiPostFilter(VectorComplexFeatureStreamPtr& output, un
                                        int minFrames, const String& nm)
     : VectorComplexFeatureStream(fftLen, nm), fftLen_(fftLen), samp_(output), type_((PostfilterType)type), alpha_(alpha),
       min_frames_(minFrames), has_bf_ptr_(false), T_(0), prepared_(false), bf_version_(0), dPhi_(NULL), dPsi_(NULL), dWl_(NULL),
-      wp1_(gsl_vector_complex_calloc(fftLen)), hist_start_(0), own_weights_(NULL), manual_frames_(0)
+      wp1_(gsl_vector_complex_calloc(fftLen)), hist_start_(0), own_weights_(NULL), manual_frames_(0), handed_(-1)
 {
   if (output->size() != fftLen) throw jdimension_error("Input block length (%d) != fftLen (%d)\n", output->size(), fftLen);
 }
@@ -1451,7 +1453,7 @@ void ZelinskiPostFilter::fill_csds_(gsl_vector_complex** out)
   BeamformerWeights* bw = manual ? own_weights_ : bf_ptr_->beamformer_weight_object();
   if (!bw) return;
   const unsigned N = bw->chanN();
-  const long t = manual ? manual_frames_ - 1 : (long)frame_no_;     // last frame whose statistics entered the recursion
+  const long t = manual ? manual_frames_ - 1 : std::max<long>(frame_no_, handed_);   // last frame a per-frame graph has pulled
   for (unsigned k = 0; k < fftLen_; k++) gsl_vector_complex_set_zero(out[k]);
   if (t < 0 || t < hist_start_) return;
   const long Tn = t + 1;
@@ -1616,7 +1618,7 @@ const gsl_vector_complex* ZelinskiPostFilter::next(int frame_no)
 {
   if (frame_no == frame_no_) return vector_;
   if (!has_bf_ptr_) return next_manual_(frame_no);
-  if (!prepared_ || bf_version_ != bf_ptr_->weights_version()) compute_(frame_no_ + 1);
+  if (!prepared_ || bf_version_ != bf_ptr_->weights_version()) compute_(std::max<long>(frame_no_, handed_) + 1);
   const long idx = frame_no_ + 1;
   if (idx >= T_) { is_end_ = true; throw jiterator_error("end of samples!"); }
   serve_frame(Yhost_, T_, fftLen_, idx, vector_);
@@ -1627,7 +1629,7 @@ const gsl_vector_complex* ZelinskiPostFilter::next(int frame_no)
 const std::vector<float>& ZelinskiPostFilter::block(long& T)
 {
   if (!has_bf_ptr_) throw j_error("set beamformer's weights \n");
-  if (!prepared_ || bf_version_ != bf_ptr_->weights_version()) compute_(frame_no_ + 1);
+  if (!prepared_ || bf_version_ != bf_ptr_->weights_version()) compute_(std::max<long>(frame_no_, handed_) + 1);
   T = T_;
   return Yhost_;
 }
@@ -1635,7 +1637,7 @@ const std::vector<float>& ZelinskiPostFilter::block(long& T)
 void ZelinskiPostFilter::advance_to(long frame_idx)
 {
   if (frame_idx >= T_) frame_idx = T_ - 1;
-  if (frame_idx > frame_no_) frame_no_ = (int)frame_idx;
+  if (frame_idx > handed_) handed_ = frame_idx;
   if (has_bf_ptr_) bf_ptr_->advance_to(frame_idx);
 }
 
@@ -1661,7 +1663,7 @@ void ZelinskiPostFilter::reset()
   VectorComplexFeatureStream::reset();
   is_end_ = false;
   prepared_ = false; Yhost_.clear();
-  Xhist_.clear(); manual_frames_ = 0; hist_start_ = 0;
+  Xhist_.clear(); manual_frames_ = 0; hist_start_ = 0; handed_ = -1;
   if (!has_bf_ptr_ && dPhi_) {              // manual mode: the densities of the next utterance start from zero
     const unsigned K = fftLen_ / 2 + 1;
     check_hip(hipMemset(dPhi_, 0, sizeof(float) * 2 * K), "hipMemset");
@@ -1869,7 +1871,7 @@ void LefkimmiatisPostFilter::calc_inverse_noise_spatial_spectral_matrix()
 // ================================================================================ SubbandGSCRLS
 SubbandGSCRLS::SubbandGSCRLS(unsigned fftLen, bool halfBandShift, float mu, float sigma2, const String& nm)
     : SubbandGSC(fftLen, halfBandShift, nm), mu_(mu), diagonal_weight_(sigma2), alpha_(-1.0f), qctype_(NO_QUADRATIC_CONSTRAINT),
-      is_wa_updated_(true), have_P_(false), dP_(NULL), dW_(NULL), dV_(NULL), dSS_(NULL), dCx_(NULL) {}
+      rls_version_(0), is_wa_updated_(true), have_P_(false), dP_(NULL), dW_(NULL), dV_(NULL), dSS_(NULL), dCx_(NULL) {}
 
 SubbandGSCRLS::~SubbandGSCRLS() { dev_free(dP_); dev_free(dW_); dev_free(dV_); dev_free(dSS_); dev_free(dCx_); }
 
@@ -1980,9 +1982,22 @@ const std::vector<float>& SubbandGSCRLS::block(long& T)
   if (!bfweight_) throw j_error("call calc_gsc_weights_x() once\n");
   if (!have_P_) throw j_error("set the precision matrix with init_precision_matrix() or set_precision_matrix()\n");
   if (halfBandShift_) throw j_error("halfBandShift==true is not yet supported\n");
-  if (Yhost_.empty()) run_block_();
+  refresh_block_();
   T = T_;
   return Yhost_;
+}
+
+// The recursion of the whole utterance ran with the weights of that moment, and P / w_a have moved to its end.  New quiescent
+// weights or a new blocking matrix before any frame was served: run it again; after frames were served the per-frame meaning
+// (the recursion continuing from frame t with the new B) would need the state of frame t, which this engine does not keep:
+// refuse instead of handing the stale block over
+void SubbandGSCRLS::refresh_block_()
+{
+  if (!Yhost_.empty() && rls_version_ == weights_version_) return;
+  if (!Yhost_.empty() && std::max<long>(frame_no_, handed_) >= 0)
+    throw jconsistency_error("SubbandGSCRLS: the weights changed after frames of this utterance were served; reset() first\n");
+  run_block_();
+  rls_version_ = weights_version_;
 }
 
 const gsl_vector_complex* SubbandGSCRLS::next(int frame_no)
@@ -1991,7 +2006,7 @@ const gsl_vector_complex* SubbandGSCRLS::next(int frame_no)
   if (!bfweight_) throw j_error("call calc_gsc_weights_x() once\n");
   if (!have_P_) throw j_error("set the precision matrix with init_precision_matrix() or set_precision_matrix()\n");
   if (halfBandShift_) throw j_error("halfBandShift==true is not yet supported\n");          // reference beamformer.cc:1528-1530
-  if (Yhost_.empty()) run_block_();
+  refresh_block_();
   const long idx = frame_no_ + 1;
   if (idx >= T_) { is_end_ = true; throw jiterator_error("end of samples!"); }
   serve_frame(Yhost_, T_, fftLen_, idx, vector_);

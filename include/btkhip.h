@@ -291,16 +291,21 @@ int  btk_mvdr_weights_flags(const void* R, const void* wq, void* W, int K, int N
                             void* scratch, int* fallback_count, int* fail_flags, void* stream);
 int  btk_mvdr_pinv_fallback(const void* R, const void* wq, void* W, int K, int N, int first_bin, float threshold,
                             const int* fail_flags, int* identity_count, void* stream);
-/* The solve behind it (pinv_kernels.hip): one workgroup per flagged bin, one-sided Jacobi SVD of the float32-rounded matrix in
- *   float64 (LDS for N <= 64, a slice of `scratch` above), the reference's threshold / identity rule, weights formed without the
- *   inverse.  btk_mvdr_pinv_fallback_async: on `stream`, no allocation, no host synchronisation; *identity_count [dev int] is
- *   incremented per bin that ended with the identity; scratch [dev] btk_mvdr_pinv_scratch_bytes(K, N) bytes (0 for N <= 64).
- *   btk_mvdr_pinv_fallback_host: the same solve bin by bin on one host thread (the round-2 form; checker / A-B timing only). */
+/* The solve behind it (pinv_kernels.hip), one workgroup per flagged bin, float64 on the float32-rounded matrix: while the matrix
+ *   fits in LDS (N <= 70) a one-sided Jacobi SVD with the reference's threshold / identity rule, weights formed without the
+ *   inverse; above that the explicit inverse (in-place Gauss-Jordan with row pivoting in a slice of `scratch`) and
+ *   1 / sigma_min = || R^-1 ||_2 by power iteration -- the rule only asks whether SOME singular value is below the threshold, and
+ *   if none is the pseudo-inverse is the inverse.  btk_mvdr_pinv_fallback_async: on `stream`, no allocation, no host
+ *   synchronisation; identity_count [dev int[2]]: [0] += bins that ended with the identity, [1] += bins whose Jacobi sweeps hit
+ *   their limit of 60 without converging; scratch [dev] btk_mvdr_pinv_scratch_bytes(K, N) bytes (0 for the LDS form).
+ *   btk_mvdr_pinv_not_converged: that second count for this thread's last (blocking) btk_mvdr_pinv_fallback call.
+ *   btk_mvdr_pinv_fallback_host: the SVD solve bin by bin on one host thread (the round-2 form; checker / A-B timing only). */
 long btk_mvdr_pinv_scratch_bytes(int K, int N);
 int  btk_mvdr_pinv_fallback_async(const void* R, const void* wq, void* W, int K, int N, int first_bin, float threshold,
                                   const int* fail_flags, int* identity_count, void* scratch, void* stream);
 int  btk_mvdr_pinv_fallback_host(const void* R, const void* wq, void* W, int K, int N, int first_bin, float threshold,
                                  const int* fail_flags, int* identity_count, void* stream);
+int  btk_mvdr_pinv_not_converged(void);
 int  btk_pinv(const double* A, int M, int N, float threshold, double* invA, int* below_threshold);
 /* The same solve for a bin SHARD [first_bin, first_bin + K) of a bin-sharded run: only global bin 0 gets the
  * all-ones weight of calc_mvdr_weights (beamformer.cc:2369-2371).                                                    */

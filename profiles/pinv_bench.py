@@ -17,7 +17,7 @@ for N, K, T in ((64, 513, 40), (128, 513, 64), (256, 1025, 128)):
     d = torch.polar(torch.full((K, N), 1.0 / N, device=dev), torch.rand((K, N), device=dev, generator=g) * 6.2831853).to(torch.complex64)
     flags = torch.ones(K, dtype=torch.int32, device=dev)
     W = torch.zeros((K, N), dtype=torch.complex64, device=dev)
-    cnt = torch.zeros(1, dtype=torch.int32, device=dev)
+    cnt = torch.zeros(2, dtype=torch.int32, device=dev)
     sb = L.btk_mvdr_pinv_scratch_bytes(K, N)
     scratch = torch.empty(max(sb, 16), dtype=torch.uint8, device=dev)
     args = (R.data_ptr(), d.data_ptr(), W.data_ptr(), K, N, 1, 1e-8, flags.data_ptr(), cnt.data_ptr(), scratch.data_ptr() if sb else None, None)

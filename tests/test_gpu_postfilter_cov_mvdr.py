@@ -211,7 +211,7 @@ def _pinv_fallback_both(eng, R, d, threshold, first_bin=0):
     flags = torch.ones(K, dtype=torch.int32, device=R.device)
     Wg = torch.zeros((K, N), dtype=torch.complex64, device=R.device)
     Wh = torch.zeros_like(Wg)
-    cnt = torch.zeros(1, dtype=torch.int32, device=R.device)
+    cnt = torch.zeros(2, dtype=torch.int32, device=R.device)          # [identity, not converged]
     sb = L.btk_mvdr_pinv_scratch_bytes(K, N)
     scratch = torch.empty(max(sb, 16), dtype=torch.uint8, device=R.device)
     st = torch.cuda.current_stream().cuda_stream
@@ -228,7 +228,8 @@ def _pinv_fallback_both(eng, R, d, threshold, first_bin=0):
     ni = C.c_int(0)
     _lib.check(L.btk_mvdr_pinv_fallback_host(R.data_ptr(), d.data_ptr(), Wh.data_ptr(), K, N, first_bin, threshold,
                                              flags.data_ptr(), C.byref(ni), st))
-    return (Wg.cpu().numpy(), int(cnt.item()), e0.elapsed_time(e1)), (Wh.cpu().numpy(), ni.value)
+    assert int(cnt[1].item()) == 0                                         # every Jacobi solve converged
+    return (Wg.cpu().numpy(), int(cnt[0].item()), e0.elapsed_time(e1)), (Wh.cpu().numpy(), ni.value)
 
 
 def test_mvdr_pinv_gpu_all_bins_rank_deficient_n64(orc, dev):

@@ -225,3 +225,72 @@ def test_push_nodes_through_cpp(orc, dev, material, tmp_path):
         assert np.max(np.abs(got[k] - csd[k])) < 3e-5 * np.max(np.abs(csd[k]))
     wp1 = np.fromfile(str(tmp_path / "wp1.c128"), np.complex128)
     assert np.allclose(wp1[:M // 2 + 1].real, W[-1][:M // 2 + 1].real, rtol=2e-4, atol=2e-6)
+
+
+def _wav_channels(btk20, kinect_pcm, h, tmp_path, L=8000):
+    import wave
+    afbs = []
+    for c in range(N):
+        p = str(tmp_path / ("c%d.wav" % c))
+        w = wave.open(p, "wb")
+        w.setnchannels(1); w.setsampwidth(2); w.setframerate(FS)
+        w.writeframes(kinect_pcm[c][:L].astype(np.int16).tobytes())
+        w.close()
+        sf = btk20.SampleFeaturePtr(block_len=D, shift_len=D, pad_zeros=True)
+        sf.read(p, FS)
+        afbs.append(btk20.OverSampledDFTAnalysisBankPtr(sf, prototype=h, M=M, m=m, r=r, delay_compensation_type=2))
+    return afbs
+
+
+def test_block_protocol_leaves_the_frame_counter_alone(orc, dev, material, kinect_pcm, tmp_path):
+    """A synthesis bank that took the beamformer's block tells it how far a per-frame graph would have pulled (advance_to); that
+    mark is the block protocol's own: a second consumer pulling the SAME node frame by frame still starts at frame 0 and sees every
+    frame (round 3 moved the node's frame counter and silently skipped them)."""
+    from distant_speech_recognition_amd import btk20
+    afbs = _wav_channels(btk20, kinect_pcm, material["h"], tmp_path)
+    bf = btk20.SubbandDSPtr(fftlen=M, half_band_shift=False)
+    for a in afbs:
+        bf.set_channel(a)
+    bf.calc_array_manifold_vectors(FS, material["delays"])
+    sfb = btk20.OverSampledDFTSynthesisBankPtr(bf, prototype=material["g"], M=M, m=m, r=r, delay_compensation_type=2)
+    for _ in range(6):
+        sfb.next()
+    assert bf.frame_no() == -1
+    Y = material["Y"]
+    for t in range(5):
+        fr = np.array(bf.next())
+        assert bf.frame_no() == t
+        assert np.max(np.abs(fr - Y[t])) <= 2e-5 * np.max(np.abs(Y))
+    # the mark still does its job: new weights recompute only what was not handed over to the synthesis bank
+    first = np.concatenate([np.array(sfb.next()) for _ in range(3)])
+    assert np.all(np.isfinite(first))
+
+
+def test_gscrls_refuses_a_stale_block(orc, dev, material, kinect_pcm, tmp_path):
+    """SubbandGSCRLS runs its recursion over the whole utterance once; new weights after frames were served cannot continue it from
+    that frame (the state of that frame is gone) -- jconsistency_error instead of the cached block of the old weights; before any
+    frame was served the recursion simply runs again"""
+    from distant_speech_recognition_amd import btk20
+
+    def graph(delays):          # (a SampleFeature frees its samples at end of stream, feature.cc:612-620: a new graph per utterance)
+        bf = btk20.SubbandGSCRLSPtr(fftlen=M, half_band_shift=False, myu=0.95, sigma2=0.0)
+        for a in _wav_channels(btk20, kinect_pcm, material["h"], tmp_path):
+            bf.set_channel(a)
+        bf.calc_gsc_weights(FS, delays)
+        bf.init_precision_matrix(0.01)
+        return bf, btk20.OverSampledDFTSynthesisBankPtr(bf, prototype=material["g"], M=M, m=m, r=r, delay_compensation_type=2)
+
+    bf, sfb = graph(material["delays"])
+    a0 = np.array(sfb.next()).copy()
+    bf.calc_gsc_weights(FS, material["delays"] * 0.5)                        # mid-stream
+    with pytest.raises(btk20.jconsistency_error):
+        sfb.next()
+    # no frame served yet: changing the weights just reruns the recursion with them
+    bf, sfb = graph(material["delays"] * 0.5)
+    ref = np.array(sfb.next()).copy()
+    bf, sfb = graph(material["delays"])
+    bf.calc_gsc_weights(FS, material["delays"] * 0.5)
+    bf.init_precision_matrix(0.01)
+    c0 = np.array(sfb.next())
+    assert np.all(np.isfinite(c0)) and not np.array_equal(a0, c0)
+    assert np.max(np.abs(c0 - ref)) <= 1e-4 * max(np.max(np.abs(ref)), 1.0)

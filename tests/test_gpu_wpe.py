@@ -79,4 +79,42 @@ def test_wpe_reference_configuration_8ch_lags0to32(orc, dev):
     assert gscale > 0.1
     assert np.max(np.abs(Gg - Gref[:, :K])) <= 5e-3 * gscale             # 264-dim normal equations in float32 vs float64
     got = np.transpose(out, (2, 1, 0))
-    assert np.max(np.abs(got - ref[:, :, :K])) <= 5e-3 * np.max(np.abs(Yo))
+    # lag 0 predicts the frame from itself, so the output is small: bound the error by the REFERENCE OUTPUT's scale (a bound at the
+    # input's scale would pass almost anything), and make sure that output is not just noise around zero
+    assert np.max(np.abs(ref)) > 1e-3 * np.max(np.abs(Yo))
+    assert np.max(np.abs(got - ref[:, :, :K])) <= 2e-2 * np.max(np.abs(ref[:, :, :K]))
+    assert np.linalg.norm(got - ref[:, :, :K]) <= 5e-3 * np.linalg.norm(ref[:, :, :K])
+
+
+@pytest.mark.parametrize("T", [520, 777])
+def test_wpe_delayed_prediction_8ch_lags1to33(orc, dev, T):
+    """The reference-size system (8 channels x 33 lags = 264 x 264 per bin and channel) with DELAYED prediction, lower_num = 1
+    (lags 1..33, dereverberation.cc:557-690): the lag-product normal equations with their own r-vector kernel, against the oracle --
+    round 3 checked this size against the oracle only with lower_num = 0 and the delayed form only kernel against kernel.  The
+    output here is the dereverberated signal itself (same order of magnitude as the input), bounded at ITS scale."""
+    import torch
+    from distant_speech_recognition_amd import engine as eng
+    C, M, lower, upper, iters = 8, 16, 1, 33, 2
+    rng = np.random.default_rng(4000 + T)
+    K = M // 2 + 1
+    Y = _reverberant(rng, T, C, M)
+    Xe = np.ascontiguousarray(np.transpose(Y[:, :, :K], (2, 1, 0))[None]).astype(np.complex64)
+    Yo = np.zeros((T, C, M), np.complex128)
+    Yo[:, :, :K] = np.transpose(Xe[0].astype(np.complex128), (2, 1, 0))
+    Yo[:, :, K:] = np.conj(Yo[:, :, M // 2 - 1:0:-1])
+    Gref = orc.wpe_estimate(Yo, lower, upper, iters, -18.0, 0.0, 1e-4)
+    ref = orc.wpe_apply(Yo, Gref, lower, upper)
+    Xd = torch.from_numpy(Xe).to(dev)
+    G = eng.wpe_estimate(Xd, M, lower_num=lower, upper_num=upper, iterations_num=iters, load_db=-18.0, diagonal_bias=1e-4)
+    assert G.shape == (1, C, K, C * (upper - lower + 1))
+    out = eng.wpe_apply(Xd, G, M, lower_num=lower, upper_num=upper).cpu().numpy()[0]
+    Gg = G.cpu().numpy()[0]
+    gscale = np.max(np.abs(Gref[:, :K]))
+    assert gscale > 1e-2
+    assert np.max(np.abs(Gg - Gref[:, :K])) <= 5e-3 * gscale             # 264-dim normal equations in float32 vs float64
+    got = np.transpose(out, (2, 1, 0))
+    rscale = np.max(np.abs(ref[:, :, :K]))
+    assert rscale > 0.05 * np.max(np.abs(Yo))                             # a real signal, not a residual near zero
+    assert np.max(np.abs(got - ref[:, :, :K])) <= 5e-3 * rscale
+    assert np.linalg.norm(got - ref[:, :, :K]) <= 2e-3 * np.linalg.norm(ref[:, :, :K])
+    assert np.sum(np.abs(got) ** 2) < 0.99 * np.sum(np.abs(Yo[:, :, :K]) ** 2)
