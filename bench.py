@@ -264,6 +264,29 @@ def main():
     nst = eng.NLMSState(S, M, N, dev)
     t_nlms = _time(lambda: eng.nlms_process(vs, X, nst, out=Yc))
 
+    # the ADAPTIVE chain end to end (north_star's GSC with the NLMS canceller: analysis -> snapshots in HBM -> canceller ->
+    # synthesis), at the headline launch and with the same number of frames laid out as four times as many, shorter streams (the
+    # recursion is sequential in t: more streams per GPU is what fills the chip, and 288 GB hold them)
+    def adaptive(pcm_, X_, Yc_, out_, nst_):
+        def chain():
+            afb.analysis(pcm_, out=X_)
+            eng.nlms_process(vs, X_, nst_, out=Yc_)
+            sfb.synthesize(Yc_, out=out_)
+        return _time(chain)
+    t_chain = adaptive(pcm, X, Yc, out, nst)
+    adaptive_wide = None
+    if T % 4 == 0 and not args.no_cpu and world == 1:                       # (skipped with --no-cpu: the profiling runs want the headline launch only)
+        S2, T2 = 4 * S, T // 4
+        L2 = (T2 - afb.processing_delay + afb.lookahead) * D
+        q = (L - L2) // 3
+        pcm2 = torch.cat([pcm[:, :, i * q:i * q + L2] for i in range(4)]).contiguous()
+        X2 = eng.padded_rows((S2, K, N, T2), torch.complex64, dev)
+        Yc2 = eng.rows_like(X2, (S2, K, T2))
+        out2 = torch.empty((S2, sfb.num_blocks(T2) * D), dtype=torch.float32, device=dev)
+        t2 = adaptive(pcm2, X2, Yc2, out2, eng.NLMSState(S2, M, N, dev))
+        adaptive_wide = {"streams": S2, "frames_per_stream": T2, "ms": t2 * 1e3, "frames_per_s": S2 * T2 / t2, "xRT": S2 * T2 / t2 / (FS / D)}
+        del pcm2, X2, Yc2, out2
+
     if rank == 0:
         frames_per_step = S * T * world
         value = frames_per_step * args.steps / elapsed
@@ -336,8 +359,11 @@ def main():
                 "synthesis": {"ms": t_syn * 1e3, "GBps": b_syn / t_syn / 1e9, "frac": b_syn / t_syn / HBM_PEAK},
                 "adaptive_nlms_canceller": {"ms": t_nlms * 1e3, "GBps": b_bf / t_nlms / 1e9, "frac": b_bf / t_nlms / HBM_PEAK,
                                             "frames_per_s": S * T / t_nlms,
-                                            "note": "sequential recursion per (stream, bin): %d streams = %.1f wavefronts per SIMD; "
-                                                    "see profiles/r02_bench_stages.json for 128 streams" % (S, S * K / 4 / 1024.0)},
+                                            "note": "sequential recursion per (stream, bin): %d streams = %.1f wavefronts per SIMD" % (S, S * K / 4 / 1024.0)},
+                "adaptive_chain": {"ms": t_chain * 1e3, "frames_per_s": S * T / t_chain, "xRT": S * T / t_chain / (FS / D),
+                                   "what": "analysis -> snapshots [S][K][N][T] in HBM -> NLMS sidelobe canceller -> synthesis, end to end, "
+                                           "%d streams x %d frames" % (S, T),
+                                   "same_frames_as_more_streams": adaptive_wide},
             },
         }
         if not args.no_cpu and world == 1:

@@ -24,6 +24,10 @@ def main():
     ap.add_argument("--mics", type=int, default=256)
     ap.add_argument("--bins", type=int, default=2048)
     ap.add_argument("--frames", type=int, default=512)
+    # "replicated" = option (i), every rank transforms all channels of the same PCM and stores its bins (no exchange
+    # before the beamformer); "channels" = option (ii), every rank holds and transforms N / world channels and ONE all-to-all
+    # regroups the snapshots by bin (predicted 2.7 x at 8 GPUs against 1.6 x, DESIGN.md section 6 -- to be decided on the node)
+    ap.add_argument("--analysis-input", choices=["replicated", "channels"], default="replicated")
     args = ap.parse_args()
     import torch
     from distant_speech_recognition_amd import engine as eng, sharding
@@ -102,8 +106,13 @@ def main():
                        "note": "rank-side cost of option (i) (replicated PCM + FFT, only the rank's bins stored) on one GPU"}
         del Xf, Xs
 
+    pcm_in = pcm
+    if args.analysis_input == "channels" and world > 1:
+        c0, c1 = sharding.bin_range_for_rank(N, rank, world)
+        pcm_in = pcm[:, c0:c1].contiguous()                 # this rank's microphones only
+
     def step():
-        return sharding.pipeline_bin_sharded(afb, sfb, pcm, W_local, K, rank, world, synth_rank=0)
+        return sharding.pipeline_bin_sharded(afb, sfb, pcm_in, W_local, K, rank, world, synth_rank=0, analysis_input=args.analysis_input)
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
@@ -127,7 +136,9 @@ def main():
                           "warmup": args.warmup, "ms_per_step": el / args.steps * 1e3, "higher_is_better": True,
                           "scaling": "strong", "dtype": "f32", "data": "synthetic",
                           "config": {"workload": "C5: %d mics, %d bins, %d frames, bins [%d,%d) on rank 0 of %d" % (N, M, T, k0, k1, world),
-                                     "parallelism": "bin-sharded x%d, 1 all-gather of %d bytes per step" % (world, 8 * K * T * S)},
+                                     "analysis_input": args.analysis_input,
+                                     "parallelism": "bin-sharded x%d, 1 all-gather of %d bytes per step%s" % (
+                                         world, 8 * K * T * S, ", 1 all-to-all of %d bytes before the beamformer" % (8 * K * N * T * S) if args.analysis_input == "channels" and world > 1 else "")},
                           "weight_design_ms": td * 1e3, "pcm_checksum": float(out.double().abs().sum()),
                           "shard_probe": shard_probe}))
     if dist:

@@ -17,71 +17,71 @@ from .btk20 import SSPEED, SubbandDSPtr, SubbandGSCPtr, SubbandMVDRGSCPtr      #
 from ._hostutil import mirror_bins as _mirror, device
 
 
-# ------------------------------------------------------------------ delays (pybeamformer.py:41-153)
+# ------------------------------------------------------------------ delays and steering vectors
+# Time delays of arrival for the geometries the reference knows (lib/pybeamformer.py:41-153), one array expression per geometry:
+# mpos is anything that converts to an [N][>=1..3] array of positions in millimetres, angles are radians, the result is seconds
+# relative to the reference microphone (default: the middle one) where the reference's function is relative.
+def _positions(mpos, ncol):
+    p = np.asarray(mpos, float)
+    if p.ndim != 2 or p.shape[1] < ncol:
+        raise ValueError("microphone positions must be [N][>=%d], got %s" % (ncol, p.shape))
+    return p
+
+
+def _ref(chan_num, ref_micx):
+    return chan_num // 2 if ref_micx is None else ref_micx
+
+
 def calc_la_delays(mpos, azimuth, sspeed=SSPEED, ref_micx=None):
-    chanN = len(mpos)
-    if ref_micx is None:
-        ref_micx = chanN // 2
-    delays = np.zeros(chanN, float)
-    for i in range(chanN):
-        delays[i] = -mpos[i][0] * np.cos(azimuth) / sspeed
-    return delays - delays[ref_micx]
+    """far field, linear array along x"""
+    tau = -_positions(mpos, 1)[:, 0] * np.cos(azimuth) / sspeed
+    return tau - tau[_ref(len(tau), ref_micx)]
 
 
 def calc_pa_delays(mpos, azimuth, polar_angle, sspeed=SSPEED, ref_micx=None):
-    chanN = len(mpos)
-    if ref_micx is None:
-        ref_micx = chanN // 2
-    delays = np.zeros(chanN, float)
-    for i in range(chanN):
-        dx = mpos[i][0] - mpos[ref_micx][0]
-        dy = mpos[i][1] - mpos[ref_micx][1]
-        delays[i] = -(dx * np.cos(azimuth) * np.sin(polar_angle) + dy * np.sin(azimuth) * np.sin(polar_angle)) / sspeed
-    return delays
+    """far field, planar array in the x-y plane"""
+    p = _positions(mpos, 2)
+    d = p[:, :2] - p[_ref(len(p), ref_micx), :2]
+    sp = np.sin(polar_angle)
+    return -(d[:, 0] * np.cos(azimuth) * sp + d[:, 1] * np.sin(azimuth) * sp) / sspeed
 
 
 def calc_ca_delays(mpos, azimuth, polar_angle, sspeed=SSPEED):
-    c_x = -np.sin(polar_angle) * np.cos(azimuth)
-    c_y = -np.sin(polar_angle) * np.sin(azimuth)
-    c_z = -np.cos(polar_angle)
-    return np.array([(c_x * p[0] + c_y * p[1] + c_z * p[2]) / sspeed for p in mpos], float)
+    """far field, any 3-D geometry: projection of the positions on the direction of arrival (absolute, not relative)"""
+    p = _positions(mpos, 3)
+    sp = np.sin(polar_angle)
+    return ((-sp * np.cos(azimuth)) * p[:, 0] + (-sp * np.sin(azimuth)) * p[:, 1] + (-np.cos(polar_angle)) * p[:, 2]) / sspeed
 
 
 def calc_nf_delays(mpos, x, y, z, sspeed=SSPEED, ref_micx=None):
-    chanN = len(mpos)
-    if ref_micx is None:
-        ref_micx = chanN // 2
-    delays = np.array([np.sqrt((x - p[0]) ** 2 + (y - p[1]) ** 2 + (z - p[2]) ** 2) / sspeed for p in mpos], float)
-    return delays - delays[ref_micx]
+    """near field: distances to the point (x, y, z)"""
+    p = _positions(mpos, 3)
+    tau = np.sqrt((x - p[:, 0]) ** 2 + (y - p[:, 1]) ** 2 + (z - p[:, 2]) ** 2) / sspeed
+    return tau - tau[_ref(len(tau), ref_micx)]
+
+
+_DELAYS = {"linear": (calc_la_delays, 1, True), "planar": (calc_pa_delays, 2, True), "circular": (calc_ca_delays, 2, False)}
 
 
 def calc_delays(array_type, mpos, position, sspeed=SSPEED, ref_micx=None):
-    if array_type == 'linear':
-        return calc_la_delays(mpos, position[0], sspeed=sspeed, ref_micx=ref_micx)
-    elif array_type == 'planar':
-        return calc_pa_delays(mpos, position[0], position[1], sspeed=sspeed, ref_micx=ref_micx)
-    elif array_type == 'circular':
-        return calc_ca_delays(mpos, position[0], position[1], sspeed=sspeed)
-    return calc_nf_delays(mpos, position[0], position[1], position[2], sspeed=sspeed, ref_micx=ref_micx)
+    """dispatch on the array type of the reference's JSON configurations; anything else is the near-field model"""
+    fn, nargs, relative = _DELAYS.get(array_type, (calc_nf_delays, 3, True))
+    kw = {"ref_micx": ref_micx} if relative else {}
+    return fn(mpos, *position[:nargs], sspeed=sspeed, **kw)
 
 
 def calc_array_manifold_f(fbinX, fftlen, samplerate, delays, half_band_shift):
-    """pybeamformer.py:284-306."""
-    chan_num = len(delays)
-    Delta_f = samplerate / float(fftlen)
-    fftlen2 = fftlen / 2
-    delays = np.asarray(delays, float)
+    """steering vector of one bin (lib/pybeamformer.py:284-306): exp(-j 2 pi f tau) / N with the bin's centre frequency f -- bins above
+    fftlen / 2 are the mirror images (conjugate; with half_band_shift the half-bin offset continues into negative frequencies)"""
+    tau = np.asarray(delays, float)
     if half_band_shift:
-        if fbinX < fftlen2:
-            vs = np.exp(-1j * 2.0 * np.pi * (0.5 + fbinX) * Delta_f * delays)
-        else:
-            vs = np.exp(-1j * 2.0 * np.pi * (0.5 - fftlen + fbinX) * Delta_f * delays)
+        f = (0.5 + fbinX if fbinX < fftlen / 2 else 0.5 - fftlen + fbinX) * (samplerate / float(fftlen))
+        vs = np.exp(-2.0j * np.pi * f * tau)
     else:
-        if fbinX <= fftlen2:
-            vs = np.exp(-1j * 2.0 * np.pi * fbinX * Delta_f * delays)
-        else:
-            vs = np.conjugate(np.exp(-1j * 2.0 * np.pi * fbinX * Delta_f * delays))
-    return vs / chan_num
+        vs = np.exp(-2.0j * np.pi * fbinX * (samplerate / float(fftlen)) * tau)
+        if fbinX > fftlen / 2:
+            vs = np.conjugate(vs)
+    return vs / len(tau)
 
 
 def calc_blocking_matrix(vs, Nc=1):
@@ -94,18 +94,14 @@ class SubbandBeamformer(object):
     """pybeamformer.py:376-475."""
 
     def __init__(self, spec_sources):
-        self._spec_sources = spec_sources
-        self._chan_num = len(spec_sources)
-        self._shiftlen = spec_sources[0].shiftlen()
-        self._fftlen = spec_sources[0].size()
+        """spec_sources: one subband-domain source (analysis bank) per channel, all of one geometry"""
+        geometry = {(src.size(), src.shiftlen()) for src in spec_sources}
+        if len(geometry) != 1:
+            raise AssertionError("channels with inconsistent FFT / shift lengths: %s" % sorted(geometry))
+        (self._fftlen, self._shiftlen), = geometry
         self._fftlen2 = self._fftlen // 2
-        for c in range(1, self._chan_num):
-            assert self._shiftlen == spec_sources[c].shiftlen(), "%d-th channel: inconsistent shift length" % c
-            assert self._fftlen == spec_sources[c].size(), "%d-th channel: inconsistent FFT length" % c
-        self._beamformer = None
-        self._wqH = None
-        self._BmH = None
-        self._waH = None
+        self._spec_sources, self._chan_num = spec_sources, len(spec_sources)
+        self._beamformer = self._wqH = self._BmH = self._waH = None
         self._iter_pos = 0
 
     def beamformer(self):
