@@ -48,5 +48,9 @@ int btk_fast_analysis_try(const btk_fb* fb, const float* pcm, long nsamples, lon
                           long T_stride, long t0, long tcount, hipStream_t st);
 int btk_fast_analysis_bf_try(const btk_fb* fb, const float* pcm, long nsamples, long pcm_stride, int S, int N, const void* W,
                              int per_stream, void* Wt_scratch, void* Y, long T_stride, long t0, long tcount, hipStream_t st);
+// fb_fused_big.hip: fused analysis -> fixed-weight beamformer for M = 1024 / 2048 (m = 4, r = 1); scratch bytes 0 = geometry not covered
+long btk_big_analysis_bf_scratch_bytes(const btk_fb* fb, int S, int N, int per_stream, long tcount);
+int btk_big_analysis_bf_try(const btk_fb* fb, const float* pcm, long nsamples, long pcm_stride, int S, int N, const void* W,
+                            int per_stream, void* scratch, void* Y, long T_stride, long t0, long tcount, hipStream_t st);
 int btk_fast_synthesis_try(const btk_fb* fb, const void* Y, long nframes, long T_stride, int S, float* out, long out_stride,
                            long b0, long bcount, hipStream_t st);

@@ -432,14 +432,19 @@ int btk_fb_analysis_bf(const btk_fb_t* fb, const float* pcm, long nsamples, long
   const bool fuse512 = fb->M == 512 && fb->m == 4;
   const bool fusefast = fb->m == 4 && fb->M == 256 && (fb->R == 1 || fb->R == 2 || fb->R == 4);
   const long Sw = per_stream_weights ? S : 1;
-  const long wt_bytes = fuse512 ? (long)sizeof(float4) * Sw * 320 * N : fusefast ? (long)sizeof(float2) * Sw * fb->K * N : 0;
+  const long big_bytes = btk_big_analysis_bf_scratch_bytes(fb, S, N, per_stream_weights, tcount);      // M = 1024 / 2048 (fb_fused_big.hip)
+  const long wt_bytes = fuse512 ? (long)sizeof(float4) * Sw * 320 * N : fusefast ? (long)sizeof(float2) * Sw * fb->K * N : big_bytes;
   hipStream_t st = as_stream(stream);
   const bool nofuse = btk_switches().disable_fused;
   if (!nofuse) {
-    if ((fuse512 || fusefast) && scratch_bytes < wt_bytes)
+    if ((fuse512 || fusefast || big_bytes) && scratch_bytes < wt_bytes)
       return btk_set_error(BTK_ERR_PARAMETER, "btk_fb_analysis_bf: scratch too small (%ld < %ld)", scratch_bytes, wt_bytes);
     int rc = btk_analysis512_bf_try(fb, pcm, nsamples, pcm_stride, S, N, W, per_stream_weights, scratch, Y, T_stride, t0, tcount, st);
     if (rc != 0) return rc > 0 ? BTK_OK : rc;
+    if (big_bytes) {
+      rc = btk_big_analysis_bf_try(fb, pcm, nsamples, pcm_stride, S, N, W, per_stream_weights, scratch, Y, T_stride, t0, tcount, st);
+      if (rc != 0) return rc > 0 ? BTK_OK : rc;
+    }
     if (fusefast) {
       rc = btk_fast_analysis_bf_try(fb, pcm, nsamples, pcm_stride, S, N, W, per_stream_weights, scratch, Y, T_stride, t0, tcount, st);
       if (rc != 0) return rc > 0 ? BTK_OK : rc;
@@ -464,6 +469,10 @@ long btk_fb_analysis_bf_scratch_bytes(const btk_fb_t* fb, int S, int N, int per_
     return (long)sizeof(float4) * (per_stream_weights ? S : 1) * 320 * N;                // weight pairs [Sw][N][320], see fb_analysis512.hip
   if (!nofuse && rok && fb->m == 4 && fb->M == 256)
     return (long)sizeof(float2) * (per_stream_weights ? S : 1) * fb->K * N;              // transposed weights [Sw][N][K], see fb_fast.hip
+  if (!nofuse) {
+    const long big = btk_big_analysis_bf_scratch_bytes(fb, S, N, per_stream_weights, tcount);   // weight pairs + channel-group partial blocks
+    if (big) return big;
+  }
   return (long)sizeof(float2) * S * fb->K * N * tcount;
 }
 

@@ -105,8 +105,9 @@ int  btk_bf_apply(const void* W, int per_stream_weights, const void* X, void* Y,
 
 /* Fused OverSampledDFTAnalysisBank x N -> fixed-weight beamformer (the chain SubbandGSC::next pulls per frame,
  * beamformer.cc:1267-1311): Y[s][k][t] = sum_n conj(W[k][n]) X_n[k][t] without materialising the snapshots in HBM
- * (fused kernels: M = 512 and M = 256 with m = 4, r <= 2; other geometries run btk_fb_analysis + btk_bf_apply through
- * `scratch`, which then needs T_stride == tcount).
+ * (fused kernels: M = 512 and M = 256 with m = 4, r <= 2, and M = 1024 / 2048 with m = 4, r = 1 -- there one stream of a large
+ * array is split over channel groups whose partial sums are added in a fixed order; other geometries run btk_fb_analysis +
+ * btk_bf_apply through `scratch`, which then needs T_stride == tcount).
  * scratch [dev] of btk_fb_analysis_bf_scratch_bytes(...) bytes, 16-byte aligned (the fused kernel stages its weight
  * pairs [Sw][N][320] float4 there and fetches them by LDS-DMA).  Y rows may be spaced T_stride >= tcount frames apart
  * (fused geometries); rows a multiple of 4 KiB apart are worth padding.  Use the staged calls when a post-filter, the

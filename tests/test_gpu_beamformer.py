@@ -250,3 +250,58 @@ def test_row_padded_snapshots_give_identical_results(dev):
     assert torch.equal(eng.bf_apply_zelinski(W, W, Xc, zc, alpha=0.7), eng.bf_apply_zelinski(W, W, Xp, zp, alpha=0.7))
     with pytest.raises(Exception):
         eng.frame_energy(Xp, M)                                   # the remaining consumers want contiguous snapshots
+
+
+@pytest.mark.parametrize("M,N,S,T,extra", [(1024, 6, 2, 100, 0), (1024, 64, 1, 40, 0), (1024, 5, 3, 37, 301), (2048, 4, 2, 70, 0),
+                                           (2048, 40, 1, 24, 0), (2048, 7, 1, 19, 1023), (2048, 256, 1, 16, 0)])
+def test_fused_large_geometries(orc, dev, M, N, S, T, extra):
+    """analysis_bfz_big_kernel (fb_fused_big.hip: M = 1024 / 2048, the three-pass 16 x Q x 16 transform with the beamformer sum on
+    the FFT lanes): equal to the staged pair btk_fb_analysis + btk_bf_apply on every frame -- interior tiles (unguarded window
+    loads), the edge tiles at both ends, recordings whose length is odd (element-wise guarded loads everywhere), ragged last tiles,
+    shared and per-stream weights, few tiles (the channels are split over workgroups and the partial sums added in a second
+    kernel) -- and to the oracle on whole tiles."""
+    import torch
+    from distant_speech_recognition_amd import engine as eng, _lib
+    m, r = 4, 1
+    D, K = M >> r, M // 2 + 1
+    h = design_prototype(M, m)
+    fb = eng.FilterBank(h, M, m, r, 2)
+    L = (T - fb.processing_delay + fb.lookahead) * D + extra
+    pcm, _ = synthetic_pcm(S, N, L, seed=M + N)
+    p = torch.from_numpy(pcm).to(dev)
+    rng = np.random.default_rng(M + 3 * N)
+    Wn = ((rng.normal(size=(S, K, N)) + 1j * rng.normal(size=(S, K, N))) / N).astype(np.complex64)
+    nb = _lib.lib().btk_fb_analysis_bf_scratch_bytes(fb._h, S, N, 0, fb.num_frames(L))
+    assert nb < 8 * S * K * N * fb.num_frames(L) or N <= 8                   # the fused form: weight pairs (+ partial blocks), not the snapshots
+    for W in (torch.from_numpy(Wn).to(dev), torch.from_numpy(Wn[0]).to(dev)):
+        ref = eng.bf_apply(W, fb.analysis(p))
+        got = fb.analysis_beamform(p, W)
+        assert got.shape == ref.shape
+        scale = float(ref.abs().max())
+        assert float((got - ref).abs().max()) <= 2e-6 * np.sqrt(N) * scale + 1e-6 * scale
+    if N <= 8:
+        gots = got.cpu().numpy()
+        Tn = gots.shape[-1]
+        Xo = np.stack([orc.analysis(h, M, m, r, 2, pcm[0, n]) for n in range(N)], axis=1)      # [T][N][M]
+        assert Xo.shape[0] == Tn
+        for t0 in sorted({0, 8 * (Tn // 16), 8 * ((Tn - 1) // 8)}):
+            t1 = min(t0 + 8, Tn)
+            Yo = np.einsum("kn,tnk->kt", np.conj(Wn[0].astype(np.complex128)), Xo[t0:t1, :, :K])
+            assert np.max(np.abs(gots[0, :, t0:t1] - Yo)) <= 4e-6 * np.sqrt(N) * np.max(np.abs(Yo)), t0
+
+
+def test_fused_large_geometry_is_bit_reproducible(dev):
+    """a channel-split launch (one stream, few tiles: eight channel groups per tile at this size) adds its partial sums in a fixed
+    order in a second kernel -- no atomics, the same bits every run"""
+    import torch
+    from distant_speech_recognition_amd import engine as eng
+    M, N, T = 2048, 64, 40
+    fb = eng.FilterBank(design_prototype(M, 4), M, 4, 1, 2)
+    L = (T - fb.processing_delay + fb.lookahead) * (M // 2)
+    pcm, _ = synthetic_pcm(1, N, L, seed=9)
+    p = torch.from_numpy(pcm).to(dev)
+    rng = np.random.default_rng(2)
+    W = torch.from_numpy(((rng.normal(size=(M // 2 + 1, N)) + 1j * rng.normal(size=(M // 2 + 1, N))) / N).astype(np.complex64)).to(dev)
+    a = fb.analysis_beamform(p, W).clone()
+    for _ in range(3):
+        assert torch.equal(fb.analysis_beamform(p, W), a)
