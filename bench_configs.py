@@ -169,8 +169,16 @@ def main():
     t_b, _ = timed(torch, lambda: eng.bf_apply(Wm, X, out=Y))
     t_s, _ = timed(torch, lambda: sfb.synthesize(Y))
     tot = t_a + t_b + t_s
+    # round 4: the superdirective weights are static, so the block runs through the fused analysis -> apply kernel of the large
+    # geometries (fb_fused_big.hip): the 256 x 1025 snapshot block never reaches HBM
+    Yf = eng.padded_rows((S, K, T), torch.complex64, dev)
+    t_f, _ = timed(torch, lambda: afb.analysis_beamform(pcm, Wm, out=Yf))
+    t_sf, _ = timed(torch, lambda: sfb.synthesize(Yf))
     out["C4_256mic_superdirective_2048bins"] = {
         "frames": S * T,
+        "fused_analysis_apply": stage(t_f, S * T, (4 * D * N + 8 * K) * S * T, {"staged_pair_ms": (t_a + t_b) * 1e3,
+                                      "rel_diff_vs_staged": float((Yf - Y).abs().max() / Y.abs().max())}),
+        "chain_fused_without_design": {"ms": (t_f + t_sf) * 1e3, "frames_per_s": S * T / (t_f + t_sf), "xRT": S * T / (t_f + t_sf) / (FS / D)},
         "analysis": stage(t_a, S * T, (4 * D + 8 * K) * N * S * T),
         "superdirective_design": {"ms": t_m * 1e3, "identity_fallbacks": nfb, "GFLOPs": (32.0 / 3) * K * N ** 3 / t_m / 1e9},
         "apply": stage(t_b, S * T, 8 * K * (N + 1) * S * T),

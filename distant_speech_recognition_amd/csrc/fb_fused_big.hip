@@ -69,7 +69,7 @@ __global__ void big_reduce_kernel(const float2* __restrict__ P, float2* __restri
   Y[row * T_stride + t] = a;
 }
 
-template <int LOG2M>
+template <int LOG2M, int VAR>     // VAR & 1: the window loads of the next channel are issued unconditionally and interleaved with the transform
 __global__ __launch_bounds__(BG<LOG2M>::NT, (LOG2M == 10) ? 2 : 1)
 void analysis_bfz_big_kernel(const float* __restrict__ pcm, long nsamples, long pcm_stride,
                              const float* __restrict__ proto, const float2* __restrict__ twg,
@@ -194,7 +194,9 @@ void analysis_bfz_big_kernel(const float* __restrict__ pcm, long nsamples, long 
           for (int q = 0; q < 2; q++) fbuf[g * FRS + n0 + q * NT] = po[q][g];
       }
       __syncthreads();                                                       // B: frames written
-      if (n + 1 < nend) { wload(n + 1, fast); wfetch(n + 1); }               // land under the transform
+      constexpr bool SPREAD = (VAR & 1) != 0 && decltype(fast)::value;
+      if constexpr (SPREAD) { wload(n + 1 < nend ? n + 1 : n, fast); wfetch(n + 1 < nend ? n + 1 : n); }   // same basic block as the transform
+      else if (n + 1 < nend) { wload(n + 1, fast); wfetch(n + 1); }          // land under the transform
 
       // ---- wave-private NF-point FFT of this lane's frame, result in registers
       f2 v[16];
@@ -267,6 +269,13 @@ void analysis_bfz_big_kernel(const float* __restrict__ pcm, long nsamples, long 
         accN.x = fmaf(wN.x, r, accN.x);
         accN.y = fmaf(-wN.y, r, accN.y);
       }
+      if constexpr (SPREAD) {
+#pragma unroll
+        for (int i = 0; i < NWG + NWP; i++) {                                // one load after every three LDS instructions of the transform
+          __builtin_amdgcn_sched_group_barrier(0x080, 3, 0);
+          __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        }
+      }
       if (n + 1 < nend) wstage(wbuf ^ 1);                                    // the other buffer was last read one channel ago (barrier A)
     }
   };
@@ -336,7 +345,10 @@ int launch_big(const btk_fb* fb, const float* pcm, long nsamples, long pcm_strid
   const int tiles_per_xcd = (ntiles + 7) / 8;
   const long nblocks = (long)8 * tiles_per_xcd * S * CG;
   const size_t lds = sizeof(f2) * B_TT * G::FRS + sizeof(f4) * 2 * G::WSTRB;
-  auto kern = analysis_bfz_big_kernel<LOG2M>;
+  // interleaving the window loads with the transform (VAR 1): -0.7 % at M = 2048 (one 8-wave workgroup per CU), +2 % at M = 1024
+  // (profiles/r04_fused_big_ab.txt); BTK_FUSED_VAR = 0 / 1 forces either form (diagnostics)
+  const int var = btk_switches().fused_var >= 0 ? (btk_switches().fused_var & 1) : (LOG2M == 11 ? 1 : 0);
+  auto kern = var ? analysis_bfz_big_kernel<LOG2M, 1> : analysis_bfz_big_kernel<LOG2M, 0>;
   BTK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(kern, dim3((unsigned)nblocks), dim3(G::NT), lds, st, pcm, nsamples, pcm_stride, fb->d_proto, fb->d_tw, fb->laN, gain,
                      N, K, Wq, per_stream ? (long)N * G::WSTRB : 0L, CG > 1 ? part : Y, CG > 1 ? tcount : T_stride,
