@@ -568,8 +568,8 @@ int btk_nlms_process_nc(const float* params /* host, 8 floats */, const void* vs
 {
   if (!params || !vs || !X || !Y || !u_state || !sigma2 || !stream_state || !workspace || (NC > 1 && !cextra))
     return btk_set_error(BTK_ERR_PARAMETER, "btk_nlms_process: null argument");
-  if (NC < 1 || NC > 4 || NC >= N)
-    return btk_set_error(BTK_ERR_DIMENSION, "btk_nlms_process: %d constraints (1..4, < N = %d channels) not supported", NC, N);
+  if (NC < 1 || NC > 8 || NC >= N)
+    return btk_set_error(BTK_ERR_DIMENSION, "btk_nlms_process: %d constraints (1..8, < N = %d channels) not supported", NC, N);
   if (S <= 0 || N < 2 || M < 2 || T < 0 || T_stride < T)
     return btk_set_error(BTK_ERR_DIMENSION, "btk_nlms_process: bad sizes S=%d N=%d M=%d T=%ld", S, N, M, T);
   if (N > 256) return btk_set_error(BTK_ERR_DIMENSION, "btk_nlms_process: N=%d > 256 channels not supported", N);
@@ -605,7 +605,11 @@ int btk_nlms_process_nc(const float* params /* host, 8 floats */, const void* vs
     switch (NC) {                                                                                                                    \
       case 2: return launch_bin2<G, C, TB_, 2>(Xp, VS, Yp, S, K, N, T_stride, T, ctrl, state_before, p, U, sigma2, st, CXp);          \
       case 3: return launch_bin2<G, C, TB_, 3>(Xp, VS, Yp, S, K, N, T_stride, T, ctrl, state_before, p, U, sigma2, st, CXp);          \
-      default: return launch_bin2<G, C, TB_, 4>(Xp, VS, Yp, S, K, N, T_stride, T, ctrl, state_before, p, U, sigma2, st, CXp);         \
+      case 4: return launch_bin2<G, C, TB_, 4>(Xp, VS, Yp, S, K, N, T_stride, T, ctrl, state_before, p, U, sigma2, st, CXp);          \
+      case 5: return launch_bin2<G, C, TB_, 5>(Xp, VS, Yp, S, K, N, T_stride, T, ctrl, state_before, p, U, sigma2, st, CXp);          \
+      case 6: return launch_bin2<G, C, TB_, 6>(Xp, VS, Yp, S, K, N, T_stride, T, ctrl, state_before, p, U, sigma2, st, CXp);          \
+      case 7: return launch_bin2<G, C, TB_, 7>(Xp, VS, Yp, S, K, N, T_stride, T, ctrl, state_before, p, U, sigma2, st, CXp);          \
+      default: return launch_bin2<G, C, TB_, 8>(Xp, VS, Yp, S, K, N, T_stride, T, ctrl, state_before, p, U, sigma2, st, CXp);         \
     }
     if (N <= 16) { BTK_NLMS_NC(16, 1, 16) }
     else if (N <= 64) { BTK_NLMS_NC(16, 4, 8) }

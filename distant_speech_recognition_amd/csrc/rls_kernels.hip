@@ -465,15 +465,20 @@ __device__ __forceinline__ void block_sums(double (&v)[NV], double* red)
   }
 }
 
-// out_i = sum_j P_ij in_j (CONJ_IN: in_j conjugated), Hermitian packed; two lanes per row (even / odd j), N <= 128
-template <bool CONJ_IN>
+// PG (round 4, 128 < N <= 256): the Hermitian-packed matrix no longer fits the LDS (N (N + 1) / 2 complex128 = 526 KB at N = 256), so
+// the recursion works on the exported state itself -- the FULL [N][N] array in global memory, both triangles kept.  Every access is
+// then a sweep along rows with consecutive lanes on consecutive columns (P_ij is read as conj(P_ji)), and the two triangles stay
+// exact conjugates of each other because (i, j) and (j, i) are updated with the same products (den_inv and sc are real).
+
+// out_i = sum_j P_ij in_j (CONJ_IN: in_j conjugated), Hermitian packed; two lanes per row (even / odd j), N <= NT / 2
+template <bool CONJ_IN, bool PG = false>
 __device__ __forceinline__ void pk_matvec(const zd* P, const zd* in, zd* out, int N)
 {
   const int tid = threadIdx.x, i = tid >> 1, h = tid & 1;
   zd acc = zmk(0.0, 0.0);
   if (i < N) {
     for (int j = h; j < N; j += 2) {
-      const zd pij = pk_get(P, i, j);
+      const zd pij = PG ? zconj(P[(long)j * N + i]) : pk_get(P, i, j);
       acc = zfma(pij, CONJ_IN ? zconj(in[j]) : in[j], acc);
     }
   }
@@ -483,9 +488,23 @@ __device__ __forceinline__ void pk_matvec(const zd* P, const zd* in, zd* out, in
 }
 
 // P <- sc (P - g a^H)  on the stored triangle (g = a den_inv with a real den_inv keeps it Hermitian); two lanes per row
+template <bool PG = false>
 __device__ __forceinline__ void pk_rank1(zd* P, const zd* a, double den_inv, double sc, int N)
 {
   const int tid = threadIdx.x, i = tid >> 1, h = tid & 1;
+  if constexpr (PG) {
+    for (int r = tid >> 6; r < N; r += blockDim.x >> 6) {               // one wavefront per row, lanes along the columns
+      const zd gr = zscale(a[r], den_inv);
+      zd* row = P + (long)r * N;
+      for (int c = tid & 63; c < N; c += 64) {
+        zd e = zscale(zsub(row[c], zmul(gr, zconj(a[c]))), sc);
+        if (c == r) e.y = 0.0;
+        row[c] = e;
+      }
+    }
+    __syncthreads();
+    return;
+  }
   if (i < N) {
     const zd gi = zscale(a[i], den_inv);
     zd* row = P + i * (i + 1) / 2;
@@ -501,9 +520,21 @@ __device__ __forceinline__ void pk_rank1(zd* P, const zd* a, double den_inv, dou
 }
 
 // P <- p0 (I - sum_d n_d n_d^H) with the orthonormal directions n_0 = vdir / |vdir| and c_j
+template <bool PG = false>
 __device__ __forceinline__ void pk_set_projector(zd* P, const zd* vdir, double inv_vv, const zd* cx, int NC, double p0, int N)
 {
   const int tid = threadIdx.x, i = tid >> 1, h = tid & 1;
+  if constexpr (PG) {
+    for (int r = tid >> 6; r < N; r += blockDim.x >> 6)
+      for (int c = tid & 63; c < N; c += 64) {
+        zd q = zscale(zmul(vdir[r], zconj(vdir[c])), -inv_vv);
+        for (int d = 0; d + 1 < NC; d++) q = zsub(q, zmul(cx[d * N + r], zconj(cx[d * N + c])));
+        if (r == c) { q.x += 1.0; q.y = 0.0; }
+        P[(long)r * N + c] = zscale(q, p0);
+      }
+    __syncthreads();
+    return;
+  }
   if (i < N) {
     zd* row = P + i * (i + 1) / 2;
     for (int j = h; j <= i; j += 2) {
@@ -516,7 +547,7 @@ __device__ __forceinline__ void pk_set_projector(zd* P, const zd* vdir, double i
   __syncthreads();
 }
 
-template <int NT>
+template <int NT, bool PG = false>
 __global__ __launch_bounds__(NT)
 void rls_packed_kernel(const float2* __restrict__ X, const zd* __restrict__ V, int per_stream, const zd* __restrict__ CX, int NC,
                        float2* __restrict__ Y, int K, int N, long T_stride, long T, const float* __restrict__ ctrl,
@@ -528,18 +559,22 @@ void rls_packed_kernel(const float2* __restrict__ X, const zd* __restrict__ V, i
   const int s = blockIdx.y, k = blockIdx.x;
   const int rld = rtb + 1, nbuf = rtb == RTB ? 2 : 1;
   const long sk = (long)s * K + k;
-  const int NP = N * (N + 1) / 2;
+  const int NP = PG ? 0 : N * (N + 1) / 2;
   RlsLds L;
   L.P = reinterpret_cast<zd*>(smem);
   L.xv = L.P + NP; L.av = L.xv + N; L.wv = L.av + N; L.nv = L.wv + N; L.vv = L.nv + N; L.dv = L.vv + N; L.cx = L.dv + N;
   L.red = reinterpret_cast<double*>(L.cx + (NC > 1 ? (NC - 1) * N : 0));
-  L.xt = reinterpret_cast<float2*>(L.red + 32);
+  L.xt = reinterpret_cast<float2*>(L.red + 72);                       // (8 cells per wavefront, up to 8 wavefronts + spare)
   float2* yout = L.xt + nbuf * N * rld;
   const zd* v = V + ((long)(per_stream ? s : 0) * K + k) * N;
   zd* Pk = Pst + sk * N * N;
   zd* wk = Wst + sk * N;
   const float2* xk = X + sk * N * T_stride;
 
+  if constexpr (PG) {
+    L.P = Pk;                                              // the state itself; its diagonal is real by contract
+    for (int n = tid; n < N; n += NT) Pk[(long)n * N + n].y = 0.0;
+  }
   for (int e = tid; e < NP; e += NT) {                     // lower triangle of the exported [N][N] state
     int i = (int)((sqrt(8.0 * e + 1.0) - 1.0) * 0.5);
     while (i * (i + 1) / 2 > e) i--;
@@ -599,17 +634,17 @@ void rls_packed_kernel(const float2* __restrict__ X, const zd* __restrict__ V, i
         y = Yc;
       }
       if (adapt) {                                                           // (workgroup-uniform)
-        pk_matvec<false>(L.P, L.xv, L.av, N);                                // a = P x;  x^H P = a^H
+        pk_matvec<false, PG>(L.P, L.xv, L.av, N);                                // a = P x;  x^H P = a^H
         double ipr[1] = {0.0};
         for (int n = tid; n < N; n += NT) { const zd x = L.xv[n], a = L.av[n]; ipr[0] += x.x * a.x + x.y * a.y; }   // Re(x^H a)
         block_sums<1, NT>(ipr, L.red);
         // mode 1: g = a / (mu + x^H P x) (pybeamformer.py:840); mode 0: g = a / (mu (1 + x^H P x / mu)) (beamformer.cc:1598-1606)
         double den_inv = 1.0 / (p.mu + ipr[0]);
         if (!commit) den_inv = 0.0;
-        pk_rank1(L.P, L.av, den_inv, commit ? inv_mu : 1.0, N);              // P <- (P - g a^H) / mu
+        pk_rank1<PG>(L.P, L.av, den_inv, commit ? inv_mu : 1.0, N);              // P <- (P - g a^H) / mu
         // regularisation mat-vec with the OLD weights and the NEW P: mode 0 (P wl), mode 1 (P conj(u))
         const bool need_rr = (p.mode == 1) ? (p.reg > 0.0) : (p.diag_w != 0.0);
-        if (need_rr) { if (p.mode == 1) pk_matvec<true>(L.P, L.wv, L.nv, N); else pk_matvec<false>(L.P, L.wv, L.nv, N); }
+        if (need_rr) { if (p.mode == 1) pk_matvec<true, PG>(L.P, L.wv, L.nv, N); else pk_matvec<false, PG>(L.P, L.wv, L.nv, N); }
         double n2s[1] = {0.0};
         for (int n = tid; n < N; n += NT) {
           const zd g = zscale(L.av[n], den_inv), w_n = L.wv[n];
@@ -634,7 +669,7 @@ void rls_packed_kernel(const float2* __restrict__ X, const zd* __restrict__ V, i
         } else if (p.copt > 0) {
           const bool quad = (p.copt == 1 || p.copt == 3) && n2 > p.alpha2;   // :853-866
           if (quad) {
-            pk_matvec<true>(L.P, L.xv, L.nv, N);                             // va = P conj(waHK)
+            pk_matvec<true, PG>(L.P, L.xv, L.nv, N);                             // va = P conj(waHK)
             double q2[2] = {0.0, 0.0};
             for (int n = tid; n < N; n += NT) {
               const zd va = L.nv[n], nq = L.xv[n];
@@ -650,7 +685,7 @@ void rls_packed_kernel(const float2* __restrict__ X, const zd* __restrict__ V, i
           }
           if (p.copt >= 2 && n2 > p.max_norm) {                              // :867-870 (n2 of the unconstrained candidate)
             scale_w = sqrt(p.max_norm / n2);
-            pk_set_projector(L.P, L.dv, inv_vv, L.cx, NC, 1.0 / p.init_load, N);
+            pk_set_projector<PG>(L.P, L.dv, inv_vv, L.cx, NC, 1.0 / p.init_load, N);
           }
         }
         if (commit) for (int n = tid; n < N; n += NT) L.wv[n] = zscale(L.xv[n], scale_w);
@@ -676,12 +711,25 @@ void rls_packed_kernel(const float2* __restrict__ X, const zd* __restrict__ V, i
         L.xv[n] = (d == 0) ? zscale(L.dv[n], sqrt(inv_vv)) : L.cx[(d - 1) * N + n];
       }
       __syncthreads();
-      pk_matvec<false>(L.P, L.xv, L.av, N);                                  // a = P n
+      pk_matvec<false, PG>(L.P, L.xv, L.av, N);                                  // a = P n
       double sv[1] = {0.0};
       for (int n = tid; n < N; n += NT) { const zd nd = L.xv[n], a = L.av[n]; sv[0] += nd.x * a.x + nd.y * a.y; }   // n^H P n (real)
       block_sums<1, NT>(sv, L.red);
       const int i = tid >> 1, h = tid & 1;
-      if (i < N) {
+      if constexpr (PG) {
+        for (int r = tid >> 6; r < N; r += NT >> 6) {
+          zd* row = L.P + (long)r * N;
+          const zd ar = L.av[r], nr = L.xv[r];
+          for (int c = tid & 63; c < N; c += 64) {
+            const zd ac = L.av[c], nc = L.xv[c];
+            zd dlt = zadd(zmul(ar, zconj(nc)), zmul(nr, zconj(ac)));
+            dlt = zsub(dlt, zscale(zmul(nr, zconj(nc)), sv[0]));
+            zd e = zsub(row[c], dlt);
+            if (c == r) e.y = 0.0;
+            row[c] = e;
+          }
+        }
+      } else if (i < N) {
         zd* row = L.P + i * (i + 1) / 2;
         const zd ai = L.av[i], ni = L.xv[i];
         for (int j = h; j <= i; j += 2) {
@@ -697,24 +745,24 @@ void rls_packed_kernel(const float2* __restrict__ X, const zd* __restrict__ V, i
     }
   }
   // export: both triangles of P [N][N], w [N]
-  for (int e = tid; e < N * N; e += NT) { const int i = e / N, j = e % N; Pk[e] = pk_get(L.P, i, j); }
+  if constexpr (!PG) { for (int e = tid; e < N * N; e += NT) { const int i = e / N, j = e % N; Pk[e] = pk_get(L.P, i, j); } }
   for (int n = tid; n < N; n += NT) wk[n] = L.wv[n];
 }
 
-inline size_t rls_packed_lds(int N, int NC, int rtb)
+inline size_t rls_packed_lds(int N, int NC, int rtb, bool pg = false)
 {
-  return sizeof(zd) * ((size_t)N * (N + 1) / 2 + 6 * (size_t)N + (size_t)(NC > 1 ? NC - 1 : 0) * N) + sizeof(double) * 32 +
+  return sizeof(zd) * ((pg ? 0 : (size_t)N * (N + 1) / 2) + 6 * (size_t)N + (size_t)(NC > 1 ? NC - 1 : 0) * N) + sizeof(double) * 72 +
          sizeof(float2) * ((rtb == RTB ? 2 : 1) * (size_t)N * (rtb + 1) + RTB);
 }
 inline int rls_packed_rtb(int N, int NC) { return rls_packed_lds(N, NC, RTB) <= 160 * 1024 - 256 ? RTB : 8; }
 
 
-template <int NT>
+template <int NT, bool PG = false>
 int launch_rls_packed(const float2* X, const zd* V, int per_stream, const zd* cx, int NC, float2* Y, int S, int K, int N, long T_stride, long T,
                       const float* ctrl, const double* state_before, const RlsParams& p, zd* P, zd* W, int rtb, size_t lds, hipStream_t st)
 {
-  BTK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(rls_packed_kernel<NT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(rls_packed_kernel<NT>, dim3((unsigned)K, (unsigned)S), dim3(NT), lds, st, X, V, per_stream, cx, NC, Y, K, N, T_stride, T,
+  BTK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(rls_packed_kernel<NT, PG>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL((rls_packed_kernel<NT, PG>), dim3((unsigned)K, (unsigned)S), dim3(NT), lds, st, X, V, per_stream, cx, NC, Y, K, N, T_stride, T,
                      ctrl, state_before, p, P, W, rtb);
   BTK_HIP_CHECK(hipGetLastError());
   return BTK_OK;
@@ -768,8 +816,10 @@ int btk_rls_process_nc(int mode, const double* params /* host, 10 doubles */, co
   if (NC < 1 || NC >= N || (NC > 1 && !cx)) return btk_set_error(BTK_ERR_DIMENSION, "btk_rls_process: NC=%d constraints with N=%d channels", NC, N);
   // register kernel: N <= 64 with one constraint; packed-Hermitian LDS kernel: anything else that fits the LDS (N <= 128)
   const bool packed = N > 64 || NC > 1 || btk_switches().rls_packed;
-  if (packed && (N > 128 /* two lanes per matrix row in a 256-thread workgroup */ || rls_packed_lds(N, NC, rls_packed_rtb(N, NC)) > 160 * 1024 - 256))
-    return btk_set_error(BTK_ERR_DIMENSION, "btk_rls_process: N=%d channels (NC=%d) exceed the LDS-resident precision matrix (N <= 128)", N, NC);
+  // ... and up to N = 256 (two lanes per row in a 512-thread workgroup) on the precision matrix in global memory, where it is exported anyway
+  const bool pglobal = packed && (N > 128 || rls_packed_lds(N, NC, rls_packed_rtb(N, NC)) > 160 * 1024 - 256);
+  if (pglobal && (N > 256 || rls_packed_lds(N, NC, 8, true) > 160 * 1024 - 256))
+    return btk_set_error(BTK_ERR_DIMENSION, "btk_rls_process: N=%d channels (NC=%d) exceed this kernel (N <= 256)", N, NC);
   if (T == 0) return BTK_OK;
   const int K = M / 2 + 1;
   RlsParams p = {};
@@ -799,6 +849,11 @@ int btk_rls_process_nc(int mode, const double* params /* host, 10 doubles */, co
   float2* Yp = static_cast<float2*>(Y);
   zd* P = static_cast<zd*>(P_state);
   zd* Wst = static_cast<zd*>(w_state);
+  if (pglobal) {
+    const int rtb = rls_packed_lds(N, NC, RTB, true) <= 160 * 1024 - 256 ? RTB : 8;
+    return launch_rls_packed<512, true>(Xp, V, per_stream, static_cast<const zd*>(cx), NC, Yp, S, K, N, T_stride, T, ctrl, state_before, p, P, Wst, rtb,
+                                        rls_packed_lds(N, NC, rtb, true), st);
+  }
   if (packed) {
     const int rtb = rls_packed_rtb(N, NC);
     const size_t lds = rls_packed_lds(N, NC, rtb);

@@ -212,8 +212,8 @@ class SubbandGSCLMSBeamformer(SubbandBeamformer):
     def __init__(self, spec_sources, beta=0.97, gamma=0.01, init_diagonal_load=1.0E+6, regularization_param=1.0E-4,
                  energy_floor=90, sil_thresh=1.0E+8, max_wa_l2norm=100.0, min_frames=128, slowdown_after=4096, Nc=1):
         SubbandBeamformer.__init__(self, spec_sources)
-        if not (1 <= Nc <= 4 and Nc < len(spec_sources)):
-            raise ValueError("Nc = %d: the GPU canceller takes 1..4 constraints, fewer than the %d channels" % (Nc, len(spec_sources)))
+        if not (1 <= Nc <= 8 and Nc < len(spec_sources)):
+            raise ValueError("Nc = %d: the GPU canceller takes 1..8 constraints, fewer than the %d channels" % (Nc, len(spec_sources)))
         self._Nc = Nc
         self._front = SubbandGSCPtr(fftlen=self._fftlen, half_band_shift=False)   # owns channels + device snapshots
         for source in self._spec_sources:

@@ -135,7 +135,7 @@ int  btk_nlms_process(const float* params, const void* vs, const void* X, void* 
 /* Nc > 1 constraints (SubbandGSCLMSBeamformer(..., Nc), lib/pybeamformer.py:588-607, 742): the blocking matrix keeps the
  * first N - Nc Gram-Schmidt columns (calc_blocking_matrix, :309-341), so the canceller's projector loses Nc - 1 more
  * directions: cextra [dev] complex64 [K][NC-1][N], per bin from btk_nlms_constraint_vectors (host, complex128
- * [NC-1][N]; B [N][N-NC] from btk_weights_blocking_matrix).  NC = 1 is btk_nlms_process.  1 <= NC <= 4.              */
+ * [NC-1][N]; B [N][N-NC] from btk_weights_blocking_matrix).  NC = 1 is btk_nlms_process.  1 <= NC <= 8.              */
 int  btk_nlms_process_nc(const float* params, const void* vs, const void* cextra, int NC, const void* X, void* Y,
                          int S, int M, int N, long T_stride, long T,
                          void* u_state, float* sigma2, double* stream_state, void* workspace, void* stream);
@@ -164,7 +164,7 @@ int  btk_nlms_u_to_wa(const double* u, const double* B, int N, double* waH);
  * beamformer.cc:1482-1494) resp. reset_stats (p0 = 1/init_diagonal_load, pybeamformer.py:921-925).
  * workspace [dev] btk_rls_workspace_bytes(S,T) bytes.  Y [dev] complex64 [S][K][T_stride].
  * N <= 64 with one constraint: P in registers (row and column copies, the reference's two products separately); otherwise, up to
- * N = 128: P as a packed Hermitian matrix in LDS (rls_kernels.hip).
+ * N = 128: P as a packed Hermitian matrix in LDS; up to N = 256: P in place in the exported [N][N] state (rls_kernels.hip).
  * btk_rls_init_nc / btk_rls_process_nc: NC >= 1 constraints (SubbandGSCRLSBeamformer(..., Nc), pybeamformer.py:784-797;
  *   SubbandGSCRLS after calc_gsc_weights_2 / _n): cx [dev] complex128 [Sv][K][NC-1][N], the orthonormal directions the blocking
  *   matrix removes besides the one implied by v -- mode 1: btk_nlms_constraint_vectors(vs, B) (conj(B) B^T = I - vs vs^H/|vs|^2 -

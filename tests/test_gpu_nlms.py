@@ -129,7 +129,7 @@ def test_nlms_nc_constraints_vs_reference_python_golden(orc, dev, proto256, kine
         assert np.max(np.abs(cx[k].conj() @ vs[k])) < 1e-6 and np.max(np.abs(cx[k].conj() @ B.conj())) < 1e-6
 
 
-@pytest.mark.parametrize("N,Nc", [(8, 2), (64, 2), (16, 4), (100, 3)])
+@pytest.mark.parametrize("N,Nc", [(8, 2), (64, 2), (16, 4), (100, 3), (16, 6), (64, 8), (12, 5), (130, 7)])
 def test_nlms_nc_matches_oracle_synthetic(orc, dev, N, Nc):
     import torch
     from distant_speech_recognition_amd import engine as eng

@@ -90,6 +90,10 @@ def test_rls_vs_reference_python_golden(orc, dev, proto256, kinect_pcm, pygolden
     (9, 32, 80, 1, dict(min_frames=0, Nc=3, gamma=0.3, alpha2=1e-4, max_wa_l2norm=5e-4, init_diagonal_load=1e3)),
     (100, 8, 50, 1, dict(min_frames=2, Nc=2)),
     (8, 16, 1500, 1, dict(min_frames=64, Nc=2)),                 # long run with two blocked directions
+    # round 4: more than 128 channels (the precision matrix stays in global memory, full [N][N], both triangles updated)
+    (129, 8, 30, 1, dict(min_frames=2)),
+    (200, 8, 40, 1, dict(min_frames=0, gamma=0.2, constraint_option=2, max_wa_l2norm=0.05)),
+    (256, 4, 36, 2, dict(min_frames=2, Nc=2)),
 ])
 def test_rls_py_matches_oracle_synthetic(orc, dev, N, M, T, S, kw):
     """mode 1 (pybeamformer) at other array sizes, two consecutive blocks continuing the recursion."""
@@ -136,6 +140,8 @@ def test_rls_py_matches_oracle_synthetic(orc, dev, N, M, T, S, kw):
     (8, 64, 60, 2, dict(mu=0.9, sigma2=0.01, Nc=2)),
     (9, 32, 50, 1, dict(mu=0.95, sigma2=0.0, Nc=3, qc=(0.05, 1))),
     (100, 8, 24, 1, dict(mu=0.9, sigma2=0.0, Nc=2, normalize=True)),
+    (160, 8, 24, 1, dict(mu=0.9, sigma2=0.0)),                   # round 4: N > 128
+    (256, 4, 20, 1, dict(mu=0.95, sigma2=0.01, Nc=2, qc=(0.05, 1))),
 ])
 def test_rls_cc_matches_oracle_synthetic(orc, dev, N, M, T, S, opts):
     """mode 0 (C++ SubbandGSCRLS, beamformer.cc:1514-1645)."""
@@ -191,6 +197,6 @@ def test_rls_hold_and_errors(dev):
     Y = eng.rls_process(torch.from_numpy(Xe).to(dev), st).cpu().numpy()[0]
     ref = np.einsum("kn,knt->kt", np.conj(v), Xe[0].astype(np.complex128))
     assert np.max(np.abs(Y - ref)) <= 2e-6 * np.max(np.abs(ref))
-    st129 = eng.RLSState(0, 1, M, 129, torch.zeros((K, 129), dtype=torch.complex128, device=dev))
-    with pytest.raises(_lib.BtkError):                           # beyond the LDS-resident precision matrix (N <= 128)
-        eng.rls_process(torch.zeros((1, K, 129, 4), dtype=torch.complex64, device=dev), st129)
+    st257 = eng.RLSState(0, 1, 8, 257, torch.zeros((5, 257), dtype=torch.complex128, device=dev))
+    with pytest.raises(_lib.BtkError):                           # beyond two lanes per matrix row in a 512-thread workgroup (N <= 256)
+        eng.rls_process(torch.zeros((1, 5, 257, 4), dtype=torch.complex64, device=dev), st257)
