@@ -459,6 +459,14 @@ void analysis512_bfz_kernel(const float* __restrict__ pcm, long nsamples, long p
   auto mark = [&](int i) { if constexpr (TIMED) { const long long c = clock64(); tm[i] += c - tlast; tlast = c; } };
   auto body = [&](int n, float2 (&win)[NWG]) {
     mark(0);                                                         // (loop overhead / previous accumulate tail)
+    constexpr bool W256S = (VAR & 256) != 0 && FAST;
+    f2 w256s = f2{0.f, 0.f};
+    if constexpr (W256S) {
+      // (a plain load would become a VECTOR load: the asm statements of this loop clobber memory, so hipcc cannot call the table
+      //  invariant.)  The scalar load lands long before the sums; its s_waitcnt sits in front of the packed FMA that reads the pair
+      const float4* wp = wts + (long)n * WSTR + 256;
+      asm volatile("s_load_dwordx2 %0, %1, 0x0" : "=s"(w256s) : "s"(wp));
+    }
     // ---- phase 1: registers -> LDS (PCM span + weight pairs)
     if (SHARED) stage(PIPE ? (n & 1) : 0);
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // the LDS-DMA of channel n (and, GW, its window) has landed
@@ -566,9 +574,18 @@ void analysis512_bfz_kernel(const float* __restrict__ pcm, long nsamples, long p
         }
       }
       const float r = v[0].x - v[0].y;                                // bin 256 (lanes j == 0): X = gain (Z0.re - Z0.im)
+      if constexpr (W256S) {
+        // VAR & 256: the channel's bin-256 weight is wave-uniform -- a scalar load issued at the top of the channel, one packed FMA
+        // with the SGPR pair (acc += (w.x, -w.y) r) instead of an LDS read and two FMAs
+        f2 a2 = f2{acc256.x, acc256.y};
+        const f2 rr = f2{r, r};
+        asm volatile("s_waitcnt lgkmcnt(0)\n\tv_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[1,0,1] neg_hi:[1,0,0]" : "+v"(a2) : "s"(w256s), "v"(rr));
+        acc256 = make_float2(a2.x, a2.y);
+      } else {
       const float4 w256 = wq[wbuf * WSTR + 256];
       acc256.x = fmaf(w256.x, r, acc256.x);
       acc256.y = fmaf(-w256.y, r, acc256.y);
+      }
     }
     if constexpr (GWF && SPREAD) {
       constexpr int PAT = (VAR >> 4) & 1;
@@ -669,9 +686,9 @@ int launch512_bf(const btk_fb* fb, const float* pcm, long nsamples, long pcm_str
   // BTK_FUSED_VAR (diagnostics, read once): 1 = register staging with the span and the frames sharing one LDS region (the only
   // form for R = 1, whose 38 KB span leaves no room for a separate region), 3 = LDS-DMA staging of the span,
   // 7 = polyphase window straight from HBM, only frames and weights in LDS, 15 = 7 with the window loads interleaved with the FFT
-  // (31: the other interleaving pattern), 79 = 15 with the polyphase products' halves crossed by op_sel, 207 (default for R = 2) =
-  // 79 with the folded-constant radix-16 passes
-  const int var = btk_switches().fused_var >= 0 ? btk_switches().fused_var : (R == 2 ? 207 : 3);
+  // (31: the other interleaving pattern), 79 = 15 with the polyphase products' halves crossed by op_sel, 207 =
+  // 79 with the folded-constant radix-16 passes, 463 (default for R = 2) = 207 with the bin-256 weight of a channel taken from a scalar load
+  const int var = btk_switches().fused_var >= 0 ? btk_switches().fused_var : (R == 2 ? 463 : 3);
   const bool pipe = (var & 2) && R >= 2;
   const bool gw = pipe && (var & 4) && R == 2;
   // (TT = 8 -- two wavefronts per workgroup, four workgroups per CU, the same occupancy with less barrier coupling -- measured
@@ -689,7 +706,7 @@ int launch512_bf(const btk_fb* fb, const float* pcm, long nsamples, long pcm_str
   auto kern = pipe ? analysis512_bfz_kernel<R, 3> : analysis512_bfz_kernel<R, 1>;
   if (gw) kern = analysis512_bfz_kernel<2, 7>;
   if (t8) kern = analysis512_bfz_kernel<2, 7, 8>;
-  if (gw && !t8 && (var & 8)) kern = (var & 16) ? analysis512_bfz_kernel<2, 31> : ((var & 64) ? ((var & 128) ? analysis512_bfz_kernel<2, 207> : analysis512_bfz_kernel<2, 79>) : analysis512_bfz_kernel<2, 15>);
+  if (gw && !t8 && (var & 8)) kern = (var & 16) ? analysis512_bfz_kernel<2, 31> : ((var & 64) ? ((var & 128) ? ((var & 256) ? analysis512_bfz_kernel<2, 463> : analysis512_bfz_kernel<2, 207>) : analysis512_bfz_kernel<2, 79>) : analysis512_bfz_kernel<2, 15>);
 #ifdef BTK_FUSED_ABLATE
   if (gw && !t8) switch ((var >> 12) & 7) {
     case 1: kern = analysis512_bfz_kernel<2, 15 + 4096 * 1>; break;
@@ -704,7 +721,7 @@ int launch512_bf(const btk_fb* fb, const float* pcm, long nsamples, long pcm_str
 #endif
   unsigned long long* phase = nullptr;
   if (R == 2 && (var & 512)) {                       // diagnostics: per-phase shader cycles of wave 0, printed by every launch
-    kern = gw ? analysis512_bfz_kernel<2, 719> : analysis512_bfz_kernel<2, 515>;   // 719 = the default form (207) with the marks
+    kern = gw ? analysis512_bfz_kernel<2, 975> : analysis512_bfz_kernel<2, 515>;   // 975 = the default form (463) with the marks
     static unsigned long long* dbuf = nullptr;
     if (!dbuf) BTK_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&dbuf), 16 * sizeof(unsigned long long)));
     BTK_HIP_CHECK(hipMemsetAsync(dbuf, 0, 16 * sizeof(unsigned long long), st));
