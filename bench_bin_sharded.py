@@ -27,7 +27,9 @@ def main():
     # "replicated" = option (i), every rank transforms all channels of the same PCM and stores its bins (no exchange
     # before the beamformer); "channels" = option (ii), every rank holds and transforms N / world channels and ONE all-to-all
     # regroups the snapshots by bin (predicted 2.7 x at 8 GPUs against 1.6 x, DESIGN.md section 6 -- to be decided on the node)
-    ap.add_argument("--analysis-input", choices=["replicated", "channels"], default="replicated")
+    # "frames": static weights only -- no bin shards at all: every rank runs the FUSED analysis -> beamformer kernel over its range of
+    # frames and the one all-gather runs along the frame axis (sharding.pipeline_frame_sharded)
+    ap.add_argument("--analysis-input", choices=["replicated", "channels", "frames"], default="replicated")
     args = ap.parse_args()
     import torch
     from distant_speech_recognition_amd import engine as eng, sharding
@@ -111,7 +113,19 @@ def main():
         c0, c1 = sharding.bin_range_for_rank(N, rank, world)
         pcm_in = pcm[:, c0:c1].contiguous()                 # this rank's microphones only
 
+    W_all = None
+    if args.analysis_input == "frames":
+        if world > 1:                                       # every rank needs the whole weight set: gather the designed shards once
+            parts = [torch.zeros((-(-K // world), N), dtype=torch.complex64, device=dev) for _ in range(world)]
+            mine = torch.zeros_like(parts[0]); mine[: k1 - k0] = W_local
+            dist.all_gather(parts, mine)
+            W_all = torch.cat(parts)[:K].contiguous()
+        else:
+            W_all = W_local
+
     def step():
+        if args.analysis_input == "frames":
+            return sharding.pipeline_frame_sharded(afb, sfb, pcm, W_all, rank, world, synth_rank=0)
         return sharding.pipeline_bin_sharded(afb, sfb, pcm_in, W_local, K, rank, world, synth_rank=0, analysis_input=args.analysis_input)
     for _ in range(args.warmup):
         step()

@@ -175,7 +175,8 @@ class FilterBank:
             raise _lib.BtkError(_lib.BTK_ERR_DIMENSION, "weights %s do not match pcm %s" % (tuple(W.shape), tuple(pcm.shape)))
         per_stream = int(W.shape[0] == S and S > 1)
         if out is None:
-            fused = self.M in (256, 512) and self.m == 4 and self.r <= 2          # the staged fall-back needs contiguous rows
+            # (the staged fall-back of the other geometries needs contiguous rows)
+            fused = self.m == 4 and ((self.M in (256, 512) and self.r <= 2) or (self.M in (1024, 2048) and self.r == 1))
             out = (padded_rows((S, self.K, tcount), torch.complex64, pcm.device) if fused
                    else torch.empty((S, self.K, tcount), dtype=torch.complex64, device=pcm.device))
         t_stride = _row_stride(out, "Y")          # out may be a [..., :T] view of a row-padded buffer

@@ -7,6 +7,10 @@ The path shards two ways:
   * by frequency BIN -- every stage between the analysis FFT and the synthesis FFT is independent per
     bin (`for fbinX` loops, beamformer.cc:1298, postfilter.cc:184, pybeamformer.py:674): rank g owns a
     contiguous bin range, and ONE all-gather of the beamformed block Y[K_g][T] precedes synthesis.
+With STATIC weights (the superdirective array of C5) a third partition costs less than either: the fused analysis -> beamformer
+kernel never writes the snapshots, so nothing per-bin exists to shard; rank g runs the fused kernel over a contiguous range of
+FRAMES (all channels, all bins; the analysis window makes it read m M - D samples of halo from the replicated PCM) and the same
+single all-gather -- along the frame axis -- assembles Y before synthesis (pipeline_frame_sharded).
 """
 
 
@@ -112,6 +116,50 @@ def exchange_channels_for_bins(X_chan, K, N, group=None):
             if b > a:
                 X_bins[:, :, a:b] = torch.view_as_complex(o)[:, k0:k1, : b - a]
     return X_bins
+
+
+def frame_range_for_rank(T, rank, world, tile=16):
+    """Contiguous frame range [t0, t1) of rank `rank`: whole tiles of the fused kernel, ceil(T / world) rounded up to `tile` frames."""
+    per = -(-(-(-T // world)) // tile) * tile
+    t0 = min(rank * per, T)
+    return t0, min(t0 + per, T)
+
+
+def allgather_frames(Y_local, T, group=None, tile=16):
+    """All-gather along the FRAME axis: Y_local complex [S][K][T_g] (this rank's frame range, possibly short or empty on the last
+    ranks) -> Y complex [S][K][T] on every rank.  One collective per block, the same 8 K T S bytes as the bin form."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    per = -(-(-(-T // world)) // tile) * tile
+    S, K, Tg = Y_local.shape
+    t0, t1 = frame_range_for_rank(T, rank, world, tile)
+    assert Tg == t1 - t0, "local block does not match this rank's frame range"
+    pad = torch.zeros((S, K, per), dtype=Y_local.dtype, device=Y_local.device)
+    pad[:, :, :Tg] = Y_local
+    buf = torch.view_as_real(pad).contiguous()
+    out = [torch.empty_like(buf) for _ in range(world)]
+    dist.all_gather(out, buf, group=group)
+    return torch.cat([torch.view_as_complex(o) for o in out], dim=2)[:, :, :T].contiguous()
+
+
+def pipeline_frame_sharded(afb, sfb, pcm, W, rank, world, group=None, synth_rank=None, tile=16):
+    """Static weights on `world` GPUs: every rank holds the SAME multichannel PCM and the whole weight set W complex64 [K][N], runs the
+    fused analysis -> beamformer kernel (no snapshots in HBM) over its frame range, ONE all-gather along the frame axis assembles
+    Y [S][K][T], the synthesis bank runs on `synth_rank` (every rank if None).  Returns (pcm_out or None, Y).  Per rank: 1 / world of
+    the fused kernel's work plus the window halo -- at C5 (256 mics, 2048 bins, 512 frames) 0.29 ms / world against 0.40 ms per rank
+    for option (i) of the bin partition, whose every rank transforms all channels."""
+    T = afb.num_frames(pcm.shape[-1])
+    t0, t1 = frame_range_for_rank(T, rank, world, tile)
+    import torch
+    if t1 > t0:
+        Y_local = afb.analysis_beamform(pcm, W, t0=t0, tcount=t1 - t0).contiguous()
+    else:
+        Y_local = torch.zeros((pcm.shape[0], afb.K, 0), dtype=torch.complex64, device=pcm.device)
+    Y = allgather_frames(Y_local, T, group, tile) if world > 1 else Y_local
+    out = sfb.synthesize(Y) if (synth_rank is None or synth_rank == rank) else None
+    return out, Y
 
 
 def max_over_ranks(value, device, group=None):

@@ -61,6 +61,8 @@ def _worker(rank, world, port, ret):
             _, Y2 = sharding.pipeline_bin_sharded(afb, sfb, pcm[:, c0:c1].contiguous(), W_local, K, rank, world, synth_rank=0,
                                                   analysis_input="channels")
             assert torch.equal(Y2, ref_Y), "option (ii): all_to_all_single with uneven splits over RCCL"
+            _, Y3 = sharding.pipeline_frame_sharded(afb, sfb, pcm, W_full, rank, world, synth_rank=0)
+            assert torch.equal(Y3, afb.analysis_beamform(pcm, W_full)), "frame partition of the fused kernel"
         t = sharding.max_over_ranks(1.0 + rank, dev)
         assert t == float(world)
         ret[rank] = 1
@@ -79,7 +81,7 @@ def test_bin_sharded_collectives_over_rccl_two_gpus():
 
 
 @pytest.mark.skipif(_ndev() < 2, reason="needs two GPUs")
-@pytest.mark.parametrize("analysis_input", ["replicated", "channels"])
+@pytest.mark.parametrize("analysis_input", ["replicated", "channels", "frames"])
 def test_bench_bin_sharded_two_gpus(analysis_input):
     """bench_bin_sharded.py the way it runs on the 8-GPU node (torch.distributed.run, backend nccl), with both analysis inputs"""
     import json

@@ -54,6 +54,10 @@ def _worker(rank, world, port, ret):
         out2, Y2 = sharding.pipeline_bin_sharded(afb, sfb, pcm[:, c0:c1].contiguous(), W_local, K, rank, world, synth_rank=0,
                                                  analysis_input="channels")
         assert torch.equal(Y2, ref_Y)
+        # static weights: the frame partition of the fused kernel (no snapshots, no bin shards), one all-gather along the frame axis
+        out3, Y3 = sharding.pipeline_frame_sharded(afb, sfb, pcm, W_full, rank, world, synth_rank=0)
+        assert torch.equal(Y3, afb.analysis_beamform(pcm, W_full))
+        assert (out3 is None) == (rank != 0)
         # stream sharding: each rank runs its streams, no collective on the data path
         mine = sharding.streams_for_rank(S, rank, world)
         Ym = afb.analysis_beamform(pcm[mine].contiguous(), W_full)

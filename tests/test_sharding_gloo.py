@@ -42,6 +42,12 @@ def _worker(rank, world, port, K, ret):
         c0, c1 = sharding.bin_range_for_rank(N, rank, world)
         Xb = sharding.exchange_channels_for_bins(Xall[:, :, c0:c1].contiguous(), K, N)
         assert Xb.shape == (S, k1 - k0, N, T) and torch.equal(Xb, Xall[:, k0:k1])
+        # the frame partition of the fused static-weight path: whole 16-frame tiles per rank, one all-gather along the frame axis
+        for Tq in (17, 40, 5):
+            Yq = torch.view_as_complex(torch.randn((S, K, Tq, 2), generator=g))
+            a0, a1 = sharding.frame_range_for_rank(Tq, rank, world)
+            assert (a0 % 16 == 0 or a0 == Tq) and (a1 % 16 == 0 or a1 == Tq) and 0 <= a0 <= a1 <= Tq
+            assert torch.equal(sharding.allgather_frames(Yq[:, :, a0:a1].contiguous(), Tq), Yq)
         t = sharding.max_over_ranks(1.0 + rank, torch.device("cpu"))
         assert t == float(world)
         mine = sharding.streams_for_rank(7, rank, world)
