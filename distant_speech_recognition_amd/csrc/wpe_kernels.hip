@@ -17,6 +17,7 @@
 //   wpe_solve_kernel   : diagonal bias + loading + in-place Cholesky (matrix in global memory / L2) + solves
 #include "btk_internal.h"
 #include "chol_blocked.h"
+#include "chol_reg.h"
 #include <cstdlib>
 
 namespace {
@@ -724,6 +725,57 @@ void wpe_solve_kernel(float2* __restrict__ R, const float2* __restrict__ rvec, W
   }
 }
 
+// Round 4: the same solve with the matrix resident in the accumulator registers of one 512-thread workgroup (chol_reg.h), P <= 271.
+// R is only read (the lower triangle, once); diagonal bias and loading as above, applied on the way into the registers.
+__global__ __launch_bounds__(cholr::NTH)
+void wpe_solve_reg_kernel(const float2* __restrict__ R, const float2* __restrict__ rvec, WpeGeom g, float load_factor,
+                          float diagonal_bias, float2* __restrict__ G, int* __restrict__ fail_count,
+                          unsigned long long* __restrict__ phase_cycles)
+{
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int k = blockIdx.x, sc = blockIdx.y;
+  if (!bin_active(g, k)) return;
+  const int P = g.C * g.L;
+  const int tid = threadIdx.x;
+  const float2* mat = R + ((long)sc * g.K + k) * (long)P * P;
+  const int s = sc / g.C, c = sc % g.C;
+  float2* gout = G + (((long)s * g.C + c) * g.K + k) * (long)P;
+  float* diagv = reinterpret_cast<float*>(reinterpret_cast<float2*>(smem) + cholr::OFF_DIAG);
+  float* red = diagv + cholr::ROWS;
+  // diagonal bias (dereverberation.cc:574-577) then load_R_ (:648-663): |d + bias| + max |.| * load_factor
+  float a = 0.f;
+  if (tid < P) {
+    float2 d = mat[(long)tid * P + tid];
+    d.x += diagonal_bias;
+    a = sqrtf(d.x * d.x + d.y * d.y);
+  }
+  float mx = a;
+  for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+  if ((tid & 63) == 0) red[tid >> 6] = mx;
+  __syncthreads();
+  mx = red[0];
+  for (int w = 1; w < cholr::NWAVE; w++) mx = fmaxf(mx, red[w]);
+  const float load = mx * load_factor;
+  if (tid < P) diagv[tid] = a + load;
+  __syncthreads();
+  long long tm[5] = {0, 0, 0, 0, 0};
+  long long tlast = phase_cycles ? clock64() : 0;
+  auto mark = [&](int i) { if (phase_cycles) { const long long cy = clock64(); tm[i] += cy - tlast; tlast = cy; } };
+  const int q = c * g.L;                                            // lowerN == 0: r_c is column c L of R (see wpe_solve_kernel)
+  auto rhs_conj = [&](int p) {
+    if (rvec) { const float2 v = rvec[((long)sc * g.K + k) * P + p]; return make_float2(v.x, -v.y); }
+    const float2 v = (p >= q) ? mat[(long)p * P + q] : mat[(long)q * P + p];
+    return (p >= q) ? make_float2(v.x, -v.y) : v;
+  };
+  const float2* x = cholr::solve(mat, P, rhs_conj, [&](int p) { return diagv[p]; }, 0.f, smem, mark);
+  if (!x) { if (tid == 0) atomicAdd(fail_count, 1); return; }
+  if (tid < P) gout[tid] = x[tid];
+  if (phase_cycles && tid == 0) {
+    for (int i = 0; i < 5; i++) atomicAdd(phase_cycles + i, (unsigned long long)tm[i]);
+    atomicAdd(phase_cycles + 6, 1ull);
+  }
+}
+
 WpeGeom make_geom(int K, int C, int lowerN, int upperN, int lower_bw, int upper_bw, long T_stride, long T)
 {
   WpeGeom g;
@@ -790,7 +842,11 @@ int btk_wpe_estimate(const void* X, int S, int K, int C, long T_stride, long T, 
   const size_t lds_solve = sizeof(float2) * ((P + 1) & ~1L) + sizeof(float) * 512 + sizeof(float2) * (size_t)P * cholb::CH_LD;
   if (lds_solve > 160 * 1024)
     return btk_set_error(BTK_ERR_DIMENSION, "btk_wpe_estimate: C*(upperN-lowerN+1) = %ld taps exceed the LDS-resident solver (max ~560)", P);
-  if (lds_solve > 64 * 1024)
+  // register-resident solver (chol_reg.h) for 96 <= P <= 271 (BTK_WPE_SOLVE_REG=1: every P <= 271; BTK_WPE_SOLVE_PANEL=1: never)
+  const bool solve_reg = P <= cholr::P_MAX && !btk_switches().wpe_solve_panel && (P >= 96 || btk_switches().wpe_solve_reg);
+  if (solve_reg)
+    BTK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(wpe_solve_reg_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)cholr::lds_bytes()));
+  else if (lds_solve > 64 * 1024)
     BTK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(wpe_solve_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_solve));
   unsigned long long* phase = nullptr;                              // BTK_WPE_TIMING=1: shader cycles per phase of the solver, printed per call
   if (btk_switches().wpe_timing) {
@@ -841,15 +897,21 @@ int btk_wpe_estimate(const void* X, int S, int K, int C, long T_stride, long T, 
       hipLaunchKernelGGL(wpe_herk_kernel<1>, hgrid1, dim3(256), lds_herk, st, Xp, Winv, g, ntile, R, skip, nspan);
     const bool rvec_from_R = (lowerN == 0) && skip;            // the lag-0 row of the target channel is y_c itself
     if (!rvec_from_R) hipLaunchKernelGGL(wpe_rvec_kernel, dim3((unsigned)K, (unsigned)(S * C)), dim3(256), 0, st, Xp, Winv, g, rvec);
-    hipLaunchKernelGGL(wpe_solve_kernel, dim3((unsigned)K, (unsigned)(S * C)), dim3(256), lds_solve, st,
-                       R, rvec_from_R ? static_cast<const float2*>(nullptr) : rvec, g, load_factor, (float)diagonal_bias, Gp, fail_count, phase);
+    if (solve_reg)
+      hipLaunchKernelGGL(wpe_solve_reg_kernel, dim3((unsigned)K, (unsigned)(S * C)), dim3(cholr::NTH), cholr::lds_bytes(), st,
+                         R, rvec_from_R ? static_cast<const float2*>(nullptr) : rvec, g, load_factor, (float)diagonal_bias, Gp, fail_count, phase);
+    else
+      hipLaunchKernelGGL(wpe_solve_kernel, dim3((unsigned)K, (unsigned)(S * C)), dim3(256), lds_solve, st,
+                         R, rvec_from_R ? static_cast<const float2*>(nullptr) : rvec, g, load_factor, (float)diagonal_bias, Gp, fail_count, phase);
     BTK_HIP_CHECK(hipGetLastError());
   }
   if (phase) {
     unsigned long long h[8];
     BTK_HIP_CHECK(hipMemcpyAsync(h, phase, sizeof(h), hipMemcpyDeviceToHost, st));
     BTK_HIP_CHECK(hipStreamSynchronize(st));
-    static const char* names[6] = {"panel_load", "mfma_update", "diagonal_block", "row_solves", "writeback_forward", "back_substitution"};
+    static const char* names_panel[6] = {"panel_load", "mfma_update", "diagonal_block", "row_solves", "writeback_forward", "back_substitution"};
+    static const char* names_reg[6] = {"load", "diagonal_block", "row_solves", "trailing_update", "back_substitution", "-"};
+    const char** names = solve_reg ? names_reg : names_panel;
     double tot = 0; for (int i = 0; i < 6; i++) tot += (double)h[i];
     fprintf(stderr, "wpe_solve phases (%llu systems, P = %ld): %.0f cycles per system:", h[6], P, tot / (h[6] ? h[6] : 1));
     for (int i = 0; i < 6; i++) fprintf(stderr, " %s %.1f%%", names[i], 100.0 * h[i] / (tot > 0 ? tot : 1));

@@ -59,7 +59,18 @@ for Tc in CHUNKS:
     nst2 = eng.NLMSState(S, M, N, dev)
     chunked(nst2)
     err = (Yfull - ref_Y).abs().max().item() / ref_Y.abs().max().item()
-    t = gpu_time(torch, lambda: chunked(nst2), n=3)[0]
+    t_eager = gpu_time(torch, lambda: chunked(nst2), n=2)[0]
+    # the same launches replayed from a HIP graph (the eager loop is bound by the host: ~25 us per launch from Python)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        chunked(nst2)
+    torch.cuda.current_stream().wait_stream(side)
+    gr = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(gr):
+        chunked(nst2)
+    t = gpu_time(torch, gr.replay, n=3)[0]
+    print("   eager %.3f ms" % (t_eager * 1e3))
     print("chunks of %4d frames (%6.1f MB of snapshots): chain %.3f ms = %.2f M frames/s   max |dY| / max |Y| = %.2e"
           % (Tc, S * K * N * Tc * 8 / 1e6, t * 1e3, S * T / t / 1e6, err))
     del Xc, Ycc

@@ -57,3 +57,28 @@ def test_round3_wpe_kernels_match_the_kernels_they_replace(dev, tmp_path):
         # both are float32 normal equations solved by the same Cholesky: they differ by the summation order of the accumulations only
         assert np.max(np.abs(G1 - G0)) <= 2e-3 * gs, (shape, np.max(np.abs(G1 - G0)) / gs)
         assert np.max(np.abs(Y1 - Y0)) <= 1e-3 * ys, (shape, np.max(np.abs(Y1 - Y0)) / ys)
+
+
+def test_register_resident_solver_matches_the_panel_solver(dev, tmp_path):
+    """round 4: chol_reg.h (matrix in the accumulator registers, default for 96 <= P <= 271) forced for every P <= 271 against the panel
+    solver of chol_blocked.h forced for every P, same normal equations: P = 30 ... 264, one shape above the register solver's limit."""
+    reg = _run(tmp_path, "reg", {"BTK_WPE_SOLVE_REG": "1"})
+    pan = _run(tmp_path, "pan", {"BTK_WPE_SOLVE_PANEL": "1"})
+    for i, shape in enumerate(SHAPES):
+        G0, G1, Y0, Y1 = pan["G%d" % i], reg["G%d" % i], pan["Y%d" % i], reg["Y%d" % i]
+        assert np.all(np.isfinite(G1)) and np.all(np.isfinite(Y1)), shape
+        gs, ys = max(np.max(np.abs(G0)), 1e-6), np.max(np.abs(Y0))
+        assert np.max(np.abs(G1 - G0)) <= 2e-3 * gs, (shape, np.max(np.abs(G1 - G0)) / gs)
+        assert np.max(np.abs(Y1 - Y0)) <= 1e-3 * ys, (shape, np.max(np.abs(Y1 - Y0)) / ys)
+
+
+@pytest.mark.parametrize("switch", ["BTK_WPE_SOLVE_REG", "BTK_WPE_SOLVE_PANEL"])
+def test_both_solvers_against_the_oracle(dev, switch):
+    """the oracle tests of tests/test_gpu_wpe.py once with each solver forced (the default picks by size: small systems would never
+    reach the register solver, the reference configuration never the panel solver)"""
+    env = dict(os.environ)
+    env[switch] = "1"
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_wpe.py"), "-x", "-q", "-m", "gpu", "-p", "no:cacheprovider"],
+                       env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-500:])
+    assert " passed" in r.stdout
