@@ -11,6 +11,7 @@
 //     w_k = z / (N d^H z),  w_0 = all ones (:2369-2371),  d = wq_k (carries the 1/N factor, :542).
 #include "btk_internal.h"
 #include "chol_blocked.h"
+#include "chol_reg.h"
 
 namespace {
 
@@ -220,6 +221,43 @@ void mvdr_solve_blocked_kernel(const float2* __restrict__ R, const float2* __res
   }
 }
 
+// Round 4: the same solve with the matrix resident in the accumulator registers of a 512-thread workgroup (chol_reg.h), 136 < N <= 271
+// (C4 / C5: 256 microphones).  R is read once (its lower triangle) and never copied: no scratch buffer.
+__global__ __launch_bounds__(cholr::NTH)
+void mvdr_solve_reg_kernel(const float2* __restrict__ R, const float2* __restrict__ Dq, float2* __restrict__ Wout, int N, float threshold,
+                           int* __restrict__ fallback_count, float2* __restrict__ lambda_out, int k_offset, int* __restrict__ fail_flags)
+{
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int k = blockIdx.x, tid = threadIdx.x;
+  const float2* Rk = R + (long)k * N * N;
+  const float2* dq = Dq + (long)k * N;
+  const bool dc_bin = (k + k_offset) == 0;
+  if (dc_bin && Wout) {                                            // wmvdr_[0] = ones (calc_mvdr_weights starts at bin 1)
+    if (tid < N) Wout[(long)k * N + tid] = make_float2(1.f, 0.f);
+    if (!lambda_out) { if (fail_flags && tid == 0) fail_flags[k] = 0; return; }
+  }
+  const float2* x = cholr::solve(Rk, N, [&](int p) { const float2 d = dq[p]; return make_float2(d.x, -d.y); },
+                                 [&](int p) { return Rk[(long)p * N + p].x; }, threshold, smem, [](int) {});
+  if (fail_flags && tid == 0) fail_flags[k] = x ? 0 : 1;
+  // pseudoinverse() reported failure -> invR = identity -> tmpH = d  (beamformer.cc:2381-2383); see mvdr_solve_blocked_kernel
+  if (!x && tid == 0) atomicAdd(fallback_count, 1);
+  const float2 d = (tid < N) ? dq[tid] : make_float2(0.f, 0.f);
+  const float2 z = (tid < N) ? (x ? x[tid] : d) : make_float2(0.f, 0.f);
+  float pr = d.x * z.x + d.y * z.y, pi = z.x * d.y - z.y * d.x;
+  for (int o = 32; o > 0; o >>= 1) { pr += __shfl_xor(pr, o, 64); pi += __shfl_xor(pi, o, 64); }
+  __syncthreads();                                                 // (the solver's LDS is free from here on)
+  float* red = reinterpret_cast<float*>(smem);
+  if ((tid & 63) == 0) { red[2 * (tid >> 6)] = pr; red[2 * (tid >> 6) + 1] = pi; }
+  __syncthreads();
+  float sr = 0.f, si = 0.f;
+  for (int w = 0; w < cholr::NWAVE; w++) { sr += red[2 * w]; si += red[2 * w + 1]; }
+  if (lambda_out && tid == 0) lambda_out[k] = make_float2(sr, si);
+  if (!Wout || dc_bin) return;
+  const float nr = sr * (float)N, ni = si * (float)N;
+  const float den = nr * nr + ni * ni;
+  if (tid < N) Wout[(long)k * N + tid] = make_float2((z.x * nr + z.y * ni) / den, (z.y * nr - z.x * ni) / den);
+}
+
 }  // namespace
 
 extern "C" {
@@ -254,6 +292,11 @@ static int mvdr_solve(const void* R, const void* wq, void* W, void* lambda_out, 
       BTK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_mat));
     hipLaunchKernelGGL(kern, dim3((unsigned)K), dim3(256), lds_mat, as_stream(stream), static_cast<const float2*>(R),
                        static_cast<const float2*>(wq), static_cast<float2*>(W), nullptr, N, threshold, fallback_count,
+                       static_cast<float2*>(lambda_out), k_offset, fail_flags);
+  } else if (N <= cholr::P_MAX && !btk_switches().wpe_solve_panel) {
+    BTK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(mvdr_solve_reg_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)cholr::lds_bytes()));
+    hipLaunchKernelGGL(mvdr_solve_reg_kernel, dim3((unsigned)K), dim3(cholr::NTH), cholr::lds_bytes(), as_stream(stream),
+                       static_cast<const float2*>(R), static_cast<const float2*>(wq), static_cast<float2*>(W), N, threshold, fallback_count,
                        static_cast<float2*>(lambda_out), k_offset, fail_flags);
   } else {
     if (!scratch) return btk_set_error(BTK_ERR_PARAMETER, "btk_mvdr_weights: N=%d needs a [K][N][N] complex64 scratch buffer", N);
