@@ -7,8 +7,9 @@ cp $R/pmc_fused_sq.txt profiles/r04_pmc_fused_sq.txt
 cp $R/bench_stages.json profiles/r04_bench_stages.json; cp $R/bench_configs.json profiles/r04_bench_configs.json
 cp $R/bench_bin_sharded.json profiles/r04_bench_bin_sharded.json
 (head -3 $R/fused_phase_timing.txt; echo "..."; tail -4 $R/fused_phase_timing.txt) > profiles/r04_fused_phase_timing.txt
-cp $R/mvdr_solve.json profiles/r04_mvdr_solve.json
+cp $R/mvdr_solve.json profiles/r04_mvdr_solve.json; cp $R/fused_big_ab.txt profiles/r04_fused_big_ab_final.txt; cp $R/fused_ab.txt profiles/r04_fused_ab_final.txt
 (echo "# WPE estimate, reference configuration (8 ch x lags 0..32, 2 iterations, 1000 frames), 2 streams per call: profiles/wpe_one.py under rocprofv3 --kernel-trace --stats"; cat $R/wpe_profile.txt) > profiles/r04_wpe_kernel_stats.txt
+(cat $R/wpe_solver_ab.txt) >> profiles/r04_wpe_kernel_stats.txt
 (echo "# profiles/fb_ab.py (staged filter banks, 8 streams x 64 channels, round 4)"; cat $R/fb_ab.txt) > profiles/r04_fb_ab.txt
 (echo "# profiles/nlms_ab.py (NLMS canceller at C0 channel count, round 4)"; cat $R/nlms_ab.txt) > profiles/r04_nlms_ab.txt
 python - <<'PY'

@@ -31,6 +31,7 @@ cp gpurun_out/r03_fused_ab.log $O/fused_ab_raw.log
 for v in 463; do BTK_FUSED_VAR=$v PROBE_SECONDS=6 python profiles/clock_probe.py 2>/dev/null | tail -1; done > $O/clock_probe.txt
 python profiles/fused_big_ab.py > $O/fused_big_ab.txt 2>/dev/null
 WPE_S=2 bash profiles/scripts/r02_wpe_profile.sh > $O/wpe_profile.txt 2>&1
+(echo "# solver A/B in separate processes (BTK_WPE_TIMING=1 prints the phase shares of wave 0, shader cycles per system)"; for v in REG PANEL; do echo "BTK_WPE_SOLVE_$v=1"; env BTK_WPE_SOLVE_$v=1 BTK_WPE_TIMING=1 WPE_S=2 python profiles/wpe_one.py 2>&1 | grep -E "wpe_solve phases|wpe_estimate" | tail -2; done) > $O/wpe_solver_ab.txt 2>&1
 python profiles/fb_ab.py 2>/dev/null | tail -4 > $O/fb_ab.txt
 python profiles/pinv_bench.py > $O/pinv_bench.txt 2>/dev/null
 python profiles/mvdr256_time.py 2>/dev/null | tail -1 > $O/mvdr_solve.json
