@@ -43,6 +43,7 @@ int main()
     float2* X;
     if (hipMalloc(reinterpret_cast<void**>(&X), (size_t)S * K * N * T_stride * 8) != hipSuccess) { printf("alloc failed\n"); return 1; }
     printf("snapshots [%d][%d][%d][%ld], row pitch %ld B (%.1f GB written per launch)\n", S, K, N, T, T_stride * 8, (double)S * K * N * T * 8 / 1e9);
+    run<8>(X, S, N, K, T, T_stride);                         // 64-byte runs: what the M = 2048 bank stores (8-frame tiles)
     run<16>(X, S, N, K, T, T_stride);
     run<32>(X, S, N, K, T, T_stride);
     run<64>(X, S, N, K, T, T_stride);
