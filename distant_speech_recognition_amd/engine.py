@@ -8,6 +8,7 @@ hand-written HIP kernel in csrc/.  Tensor layouts:
 """
 import collections
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -794,7 +795,7 @@ def mvdr_weights(R, wq, threshold=1.0e-8, first_bin=0):
     fb = torch.zeros(1, dtype=torch.int32, device=R.device)
     flags = torch.zeros(max(K, 1), dtype=torch.int32, device=R.device)
     scratch = None
-    if 2064 + 8 * (N * N + N) > 150 * 1024:
+    if N > 271 or (N > 136 and os.environ.get("BTK_WPE_SOLVE_PANEL")):     # (136 < N <= 271: the register-resident solver reads R in place)
         scratch = torch.empty((K, N, N), dtype=torch.complex64, device=R.device)
     nident = 0
     if K > 0:

@@ -6,6 +6,7 @@
 // same-frame caching, consecutive frame numbers, jiterator_error("end of samples!") at the end.
 // Weight changes between frames recompute only the frames not yet served (analysis is
 // weight-independent and stays resident on the device).
+#include <cstdlib>
 #include <hip/hip_runtime_api.h>
 #include <cmath>
 #include <cstdio>
@@ -1275,7 +1276,7 @@ bool SubbandMVDR::calc_mvdr_weights(float, float dThreshold, bool)
   void* dW = dev_alloc(sizeof(float) * d.size());
   void* dfb = dev_alloc(sizeof(int));
   void* scratch = NULL;
-  if (8 * ((size_t)N * N + N) > 150 * 1024) scratch = dev_alloc(sizeof(float) * 2 * K * N * N);
+  if (N > 271 || (N > 136 && getenv("BTK_WPE_SOLVE_PANEL"))) scratch = dev_alloc(sizeof(float) * 2 * K * N * N);   // (only the panel solver copies R)
   void* dflags = dev_alloc(sizeof(int) * K);
   h2d(dD, d.data(), sizeof(float) * d.size());
   check_hip(hipMemset(dfb, 0, sizeof(int)), "hipMemset");

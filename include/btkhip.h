@@ -272,7 +272,8 @@ int  btk_gev_weights(const void* Rt, const void* Rn, int K, int N, void* WqH, vo
  *   w_0 = ones; batched complex Cholesky, identity fall-back counted in *fallback_count [dev int]
  *   when a pivot <= threshold (the reference's pseudoinverse() failure path, :262-270, :2381-2383).
  *   wq [dev] complex64 [K][N] = d; W [dev] complex64 [K][N]; scratch [dev] [K][N][N] complex64 only
- *   needed when N*N*8 bytes exceed the LDS budget (N > 136).                                        */
+ *   needed for N > 271 (N <= 136: R_k in LDS; 136 < N <= 271: R_k in the matrix cores' accumulator
+ *   registers, read once, never copied; above: panel solver on a copy of R_k); may be NULL otherwise. */
 int  btk_mvdr_diffuse_model(const float* mpos, int N, int M, float samplerate, float sspeed, void* R, void* stream);
 int  btk_mvdr_diagonal_loading(void* R, int nbins, int N, float weight, void* stream);
 int  btk_mvdr_weights(const void* R, const void* wq, void* W, int K, int N, float threshold,

@@ -328,6 +328,54 @@ def test_mvdr_identity_fallback(dev):
     assert torch.allclose(W[1:], torch.full((K - 1, N), 0.25 + 0.0j, dtype=torch.complex64, device=dev), atol=1e-6)
 
 
+@pytest.mark.parametrize("N", [137, 160, 255, 256, 257, 271, 272])
+def test_mvdr_register_resident_solver_sizes(dev, N):
+    """round 4: 136 < N <= 271 run on the register-resident Cholesky (csrc/chol_reg.h: 16 x 16 tiles in the matrix cores' accumulators,
+    the right-hand side as an extra matrix row) -- sizes around its tile-row boundaries (N + 1 = 256, 257, 272) and the first size that
+    falls back to the panel solver (272), random Hermitian positive definite R against a float64 solve, plus the distortionless answer."""
+    import torch
+    from distant_speech_recognition_amd import engine as eng
+    K = 4
+    rng = np.random.default_rng(N)
+    A = rng.normal(size=(K, N, N + 40)) + 1j * rng.normal(size=(K, N, N + 40))
+    R = (A @ A.conj().transpose(0, 2, 1)) / (N + 40) + 0.05 * np.eye(N)
+    d = (rng.normal(size=(K, N)) + 1j * rng.normal(size=(K, N))) / N
+    W, nfb = eng.mvdr_weights(torch.from_numpy(R.astype(np.complex64)).to(dev), torch.from_numpy(d.astype(np.complex64)).to(dev))
+    W = W.cpu().numpy()
+    assert nfb == 0
+    assert np.allclose(W[0], 1.0)                                  # bin 0 is the reference's all-ones vector
+    R32 = R.astype(np.complex64).astype(np.complex128)
+    for k in range(1, K):
+        z = np.linalg.solve(R32[k], d[k].astype(np.complex64).astype(np.complex128))
+        exact = z / (N * np.vdot(d[k], z))
+        assert np.linalg.norm(W[k] - exact) <= 1e-3 * np.linalg.norm(exact), (N, k)
+        assert abs(np.vdot(W[k], d[k]) - 1.0 / N) < 1e-3 / N + 1e-5
+
+
+@pytest.mark.parametrize("N", [200, 256])
+def test_mvdr_register_resident_solver_flags_singular_bins(dev, N):
+    """a rank-deficient bin trips the pivot threshold inside the register-resident solver and takes the reference's identity answer
+    (beamformer.cc:2381-2383); its well-conditioned neighbours are solved"""
+    import torch
+    from distant_speech_recognition_amd import engine as eng
+    K = 4
+    rng = np.random.default_rng(7 * N)
+    A = rng.normal(size=(K, N, N + 16)) + 1j * rng.normal(size=(K, N, N + 16))
+    R = (A @ A.conj().transpose(0, 2, 1)) / (N + 16) + 0.05 * np.eye(N)
+    B = rng.normal(size=(N, 5)) + 1j * rng.normal(size=(N, 5))
+    R[2] = B @ B.conj().T                                           # rank 5
+    d = (rng.normal(size=(K, N)) + 1j * rng.normal(size=(K, N))) / N
+    W, nfb = eng.mvdr_weights(torch.from_numpy(R.astype(np.complex64)).to(dev), torch.from_numpy(d.astype(np.complex64)).to(dev), threshold=1e-6)
+    W = W.cpu().numpy()
+    assert nfb == 1
+    ident = d[2] / (N * np.vdot(d[2], d[2]))
+    assert np.linalg.norm(W[2] - ident) <= 1e-5 * np.linalg.norm(ident)
+    for k in (1, 3):
+        z = np.linalg.solve(R[k], d[k])
+        exact = z / (N * np.vdot(d[k], z))
+        assert np.linalg.norm(W[k] - exact) <= 1e-3 * np.linalg.norm(exact)
+
+
 def _coherent_snapshots(rng, S, K, N, T):
     X = _rand_snapshots(rng, S, K, N, T)
     X += (rng.normal(size=(S, K, 1, T)) + 1j * rng.normal(size=(S, K, 1, T))).astype(np.complex64) * 2500.0
