@@ -954,7 +954,8 @@ void synthesis512w_kernel(const float2* __restrict__ Y, long nframes, long T_str
   const int fl = lane >> 4, jj = lane & 15;
   f2 twr[15];                                                 // W_256^{j k1}, k1 = 1..15
 #pragma unroll
-  for (int k1 = 1; k1 < 16; k1++) { const float2 t = twg[(2 * jj * k1) & 511]; twr[k1 - 1] = f2{t.x, t.y}; }
+  for (int k1 = 1; k1 < 16; k1++) { const float2 t = twg[(2 * jj * k1) & 511]; twr[k1 - 1] = tw_tangent(t.x, t.y); }   // (cos, tan): folded-constant passes below
+  const f2 k_hc = f2{0.70710678118654752f, 0.92387953251128674f}, k_t1 = f2{0.41421356237309503f, 0.41421356237309503f};
 
   const int dq = tid % NQ, bg = tid / NQ, d0 = 4 * dq;
   float gco[4][R][A_MT];                                      // g[M-1-(d+jD)+M k], d = d0 + dd
@@ -1032,14 +1033,12 @@ void synthesis512w_kernel(const float2* __restrict__ Y, long nframes, long T_str
         f2 v[16];
 #pragma unroll
         for (int r = 0; r < 16; r++) { const f2 z = fb[r * 17 + jj]; v[r] = f2{z.x, -z.y}; }
-        dft16q(v);
-#pragma unroll
-        for (int k1 = 1; k1 < 16; k1++) v[k1] = cmulv(v[k1], twr[k1 - 1]);
+        dft16t(v, k_hc, k_t1);
 #pragma unroll
         for (int k1 = 0; k1 < 16; k1++) fb[jj * 17 + k1] = v[k1];
 #pragma unroll
         for (int jp = 0; jp < 16; jp++) v[jp] = fb[jp * 17 + jj];
-        dft16q(v);
+        dft16t_tw(v, twr, k_hc, k_t1);                                  // (inter-pass twiddles behind the exchange, fft_packed.h)
 #pragma unroll
         for (int k2 = 0; k2 < 16; k2++) fb[k2 * 17 + jj] = f2{v[k2].x, -v[k2].y};     // z[n]: v[2n] = Re, v[2n+1] = Im
       }
