@@ -352,6 +352,27 @@ def test_mvdr_register_resident_solver_sizes(dev, N):
         assert abs(np.vdot(W[k], d[k]) - 1.0 / N) < 1e-3 / N + 1e-5
 
 
+def test_mvdr_register_resident_solver_every_size(dev):
+    """every N the register-resident solver takes (137 .. 271: every padding count of the last tile row, every number of tile rows from 9
+    to 17), one random positive definite system each, against a float64 solve of the float32-rounded matrix"""
+    import torch
+    from distant_speech_recognition_amd import engine as eng
+    rng = np.random.default_rng(2026)
+    worst = 0.0
+    for N in range(137, 272):
+        A = rng.normal(size=(N, N + 24)) + 1j * rng.normal(size=(N, N + 24))
+        R = np.stack([np.eye(N), (A @ A.conj().T) / (N + 24) + 0.1 * np.eye(N)]).astype(np.complex64)
+        d = ((rng.normal(size=(2, N)) + 1j * rng.normal(size=(2, N))) / N).astype(np.complex64)
+        W, nfb = eng.mvdr_weights(torch.from_numpy(R).to(dev), torch.from_numpy(d).to(dev))
+        assert nfb == 0, N
+        z = np.linalg.solve(R[1].astype(np.complex128), d[1].astype(np.complex128))
+        exact = z / (N * np.vdot(d[1].astype(np.complex128), z))
+        err = np.linalg.norm(W[1].cpu().numpy() - exact) / np.linalg.norm(exact)
+        worst = max(worst, err)
+        assert err <= 1e-3, (N, err)
+    assert worst < 1e-3
+
+
 @pytest.mark.parametrize("N", [200, 256])
 def test_mvdr_register_resident_solver_flags_singular_bins(dev, N):
     """a rank-deficient bin trips the pivot threshold inside the register-resident solver and takes the reference's identity answer
