@@ -100,7 +100,9 @@ __device__ __forceinline__ const float2* solve(const float2* __restrict__ mat, i
       for (int v = 0; v < 4; v++) {
         const int r = 16 * ti + 4 * mg + v;
         const bool low = r < P && q < r;
-        const float2 a = mat[low ? (long)r * P + q : 0L];
+        int idx = low ? r * P + q : 0;                              // (P <= 271: 32 bits)
+        asm volatile("" : "+v"(idx));                               // (opaque: keeps the load unconditional)
+        const float2 a = mat[idx];
         const float dg = (r < P) ? diag(r) : ((r < RH) ? 1.f : 0.f);
         re[s][v] = low ? a.x : ((q == r) ? dg : 0.f);
         im[s][v] = low ? a.y : 0.f;
@@ -153,8 +155,9 @@ __device__ __forceinline__ const float2* solve(const float2* __restrict__ mat, i
         const int grow = (lane < 16) ? 16 * k + lane : 16 * (k + 1) + wave * 48 + lr;
         f2 row[16];
         const bool real = lane < 16 || isrow;
-        const float2* src = col + (real ? grow : 16 * k) * LD;       // (every lane reads a valid row and selects afterwards: a branch around each
-                                                                     //  read costs an LDS round trip per column)
+        int srow = real ? grow : 16 * k;                              // every lane reads a valid row and selects afterwards; the row index goes
+        asm volatile("" : "+v"(srow));                                // through an opaque copy, or hipcc turns the selects back into branches
+        const float2* src = col + srow * LD;                          // around the reads
 #pragma unroll
         for (int c2 = 0; c2 < 16; c2++) {
           const float2 t = src[c2];
