@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Shader clock and package power while one kernel runs back to back for a few seconds: PROBE_WORK = fused (the fused
-analysis+beamform kernel, BTK_FUSED_VAR selects the form), nlms or apply (PROBE_S streams); rocm-smi is sampled from a
+analysis+beamform kernel, BTK_FUSED_VAR selects the form), nlms or apply (PROBE_S streams), wpe (the estimate at the reference configuration); rocm-smi is sampled from a
 thread of the same process."""
 import os, sys, json, re, subprocess, threading, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -22,6 +22,12 @@ if WORK == "fused":
     W = torch.from_numpy(eng.weights_gsc_effective(wq, np.zeros_like(wq), M)).to(dev)
     Y = torch.empty((S, K, T), dtype=torch.complex64, device=dev)
     step = lambda: afb.analysis_beamform(pcm, W, out=Y)
+elif WORK == "wpe":                        # WPE estimate at the reference configuration (8 ch x lags 0..32, 1000 frames): 2/3 lag products on the matrix cores
+    S, C, M, T = int(os.environ.get("PROBE_S", "2")), 8, 512, 1000
+    K = M // 2 + 1
+    g = torch.Generator(device=dev).manual_seed(3)
+    X = ((torch.randn((S, K, C, T), device=dev, generator=g) + 1j * torch.randn((S, K, C, T), device=dev, generator=g)) * 300).to(torch.complex64)
+    step = lambda: eng.wpe_estimate(X, M, lower_num=0, upper_num=32, iterations_num=2, load_db=-18.0, diagonal_bias=1e-4)
 else:                                       # "nlms": PROBE_S streams x 64 mics x 257 bins x 4096 frames; "apply": the same snapshots through bf_apply
     N, M, S, T = 64, 512, int(os.environ.get("PROBE_S", "32")), 4096
     K = M // 2 + 1
@@ -51,7 +57,7 @@ def sampler():
 th = threading.Thread(target=sampler)
 t_end = time.time() + float(os.environ.get("PROBE_SECONDS", "8"))
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-NREP = 50 if WORK == "fused" else 10
+NREP = 50 if WORK == "fused" else (3 if WORK == "wpe" else 10)
 th.start()
 times = []
 while time.time() < t_end:
