@@ -102,15 +102,18 @@ def main():
     delays = la_delays(ula_positions(N), -1.306379)
     wqd = torch.from_numpy(eng.weights_mainlobe(M, N, FS, delays)[:K].astype(np.complex64)).to(dev)
     t_m, (Wm, nfb) = timed(torch, lambda: eng.mvdr_weights(R[0], wqd))
+    wqs = wqd.unsqueeze(0).expand(S, K, N).contiguous()
+    t_ms, (Wms, nfbs) = timed(torch, lambda: eng.mvdr_weights(R, wqs))      # the S streams' designs in one launch (btk_mvdr_weights_streams)
     Y = eng.rows_like(X, (S, K, T))
-    t_b, _ = timed(torch, lambda: eng.bf_apply(Wm, X, out=Y))
+    t_b, _ = timed(torch, lambda: eng.bf_apply(Wms, X, out=Y))               # per-stream weights
     t_s, _ = timed(torch, lambda: sfb.synthesize(Y))
-    tot = t_a + t_c + t_m * S + t_b + t_s
+    tot = t_a + t_c + t_ms + t_b + t_s
     out["C2_64mic_mvdr_1024bins"] = {
         "frames": S * T, "streams": S,
         "analysis": stage(t_a, S * T, (4 * D + 8 * K) * N * S * T),
         "covariance_mfma": stage(t_c, S * T, None, {"TFLOPs": 8.0 * K * N * N * S * T / t_c / 1e12}),
         "mvdr_solve_per_stream": {"ms": t_m * 1e3, "identity_fallbacks": nfb, "GFLOPs": (32.0 / 3) * K * N ** 3 / t_m / 1e9},
+        "mvdr_solve_all_streams_one_launch": {"ms": t_ms * 1e3, "identity_fallbacks": nfbs, "GFLOPs": (32.0 / 3) * S * K * N ** 3 / t_ms / 1e9},
         "apply": stage(t_b, S * T, 8 * K * (N + 1) * S * T),
         "synthesis": stage(t_s, S * T, (8 * K + 4 * D) * S * T),
         "chain": {"ms": tot * 1e3, "frames_per_s": S * T / tot, "xRT": S * T / tot / (FS / D)},

@@ -87,6 +87,7 @@ SIGNATURES = {
     "btk_mvdr_weights_shard": (_i, [_vp, _vp, _vp, _i, _i, _i, _f, _vp, _vp, _vp]),
     "btk_mvdr_divide_nondiagonal": (_i, [_vp, _i, _i, _f, _vp]),
     "btk_mvdr_weights_flags": (_i, [_vp, _vp, _vp, _i, _i, _i, _f, _vp, _vp, _vp, _vp]),
+    "btk_mvdr_weights_streams": (_i, [_vp, _vp, _vp, _i, _i, _i, _f, _vp, _vp, _vp, _vp]),
     "btk_mvdr_pinv_fallback": (_i, [_vp, _vp, _vp, _i, _i, _i, _f, _vp, C.POINTER(_i), _vp]),
     "btk_mvdr_pinv_scratch_bytes": (_l, [_i, _i]),
     "btk_mvdr_pinv_fallback_async": (_i, [_vp, _vp, _vp, _i, _i, _i, _f, _vp, _vp, _vp, _vp]),

@@ -57,7 +57,7 @@ __global__ __launch_bounds__(256)
 void mvdr_solve_kernel(const float2* __restrict__ R, const float2* __restrict__ Dq /* [K][N] d=wq */,
                        float2* __restrict__ Wout /* [K][N] or null */, float2* __restrict__ scratch,
                        int N, float threshold, int* __restrict__ fallback_count,
-                       float2* __restrict__ lambda_out /* [K] or null: d^H invR d */, int k_offset /* global index of bin 0 */,
+                       float2* __restrict__ lambda_out /* [K] or null: d^H invR d */, int k_offset /* global index of bin 0 */, int kper /* > 0: S stacked streams of kper bins each, every stream's bin 0 is a DC bin */,
                        int* __restrict__ fail_flags /* [K] or null: 1 where the Cholesky factorisation stopped */)
 {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -70,7 +70,7 @@ void mvdr_solve_kernel(const float2* __restrict__ R, const float2* __restrict__ 
   float2* rhs = reinterpret_cast<float2*>(smem + 2064);            // [N]
   float2* mat = IN_LDS ? rhs + N : scratch + (long)k * N * N;      // [N][N]
   const float2* Rk = R + (long)k * N * N;
-  const bool dc_bin = (k + k_offset) == 0;
+  const bool dc_bin = kper > 0 ? (k % kper) == 0 : (k + k_offset) == 0;
   if (dc_bin && Wout) {                                            // wmvdr_[0] = ones (calc_mvdr_weights starts at bin 1)
     for (int c = tid; c < N; c += 256) Wout[(long)k * N + c] = make_float2(1.f, 0.f);
     if (!lambda_out) { if (fail_flags && tid == 0) fail_flags[k] = 0; return; }
@@ -171,7 +171,7 @@ void mvdr_solve_kernel(const float2* __restrict__ R, const float2* __restrict__ 
 __global__ __launch_bounds__(256)
 void mvdr_solve_blocked_kernel(const float2* __restrict__ R, const float2* __restrict__ Dq, float2* __restrict__ Wout,
                                float2* __restrict__ scratch, int N, float threshold, int* __restrict__ fallback_count,
-                               float2* __restrict__ lambda_out, int k_offset, int* __restrict__ fail_flags)
+                               float2* __restrict__ lambda_out, int k_offset, int kper, int* __restrict__ fail_flags)
 {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int k = blockIdx.x, tid = threadIdx.x;
@@ -180,7 +180,7 @@ void mvdr_solve_blocked_kernel(const float2* __restrict__ R, const float2* __res
   float2* panel = reinterpret_cast<float2*>(red + 512);            // [N][CH_LD]
   float2* mat = scratch + (long)k * N * N;
   const float2* Rk = R + (long)k * N * N;
-  const bool dc_bin = (k + k_offset) == 0;
+  const bool dc_bin = kper > 0 ? (k % kper) == 0 : (k + k_offset) == 0;
   if (dc_bin && Wout) {                                            // wmvdr_[0] = ones (calc_mvdr_weights starts at bin 1)
     for (int c = tid; c < N; c += 256) Wout[(long)k * N + c] = make_float2(1.f, 0.f);
     if (!lambda_out) { if (fail_flags && tid == 0) fail_flags[k] = 0; return; }
@@ -225,13 +225,13 @@ void mvdr_solve_blocked_kernel(const float2* __restrict__ R, const float2* __res
 // (C4 / C5: 256 microphones).  R is read once (its lower triangle) and never copied: no scratch buffer.
 __global__ __launch_bounds__(cholr::NTH)
 void mvdr_solve_reg_kernel(const float2* __restrict__ R, const float2* __restrict__ Dq, float2* __restrict__ Wout, int N, float threshold,
-                           int* __restrict__ fallback_count, float2* __restrict__ lambda_out, int k_offset, int* __restrict__ fail_flags)
+                           int* __restrict__ fallback_count, float2* __restrict__ lambda_out, int k_offset, int kper, int* __restrict__ fail_flags)
 {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int k = blockIdx.x, tid = threadIdx.x;
   const float2* Rk = R + (long)k * N * N;
   const float2* dq = Dq + (long)k * N;
-  const bool dc_bin = (k + k_offset) == 0;
+  const bool dc_bin = kper > 0 ? (k % kper) == 0 : (k + k_offset) == 0;
   if (dc_bin && Wout) {                                            // wmvdr_[0] = ones (calc_mvdr_weights starts at bin 1)
     if (tid < N) Wout[(long)k * N + tid] = make_float2(1.f, 0.f);
     if (!lambda_out) { if (fail_flags && tid == 0) fail_flags[k] = 0; return; }
@@ -281,7 +281,7 @@ int btk_mvdr_diagonal_loading(void* R, int nbins, int N, float weight, void* str
 }
 
 static int mvdr_solve(const void* R, const void* wq, void* W, void* lambda_out, int K, int N, float threshold,
-                      void* scratch, int* fallback_count, void* stream, int k_offset = 0, int* fail_flags = nullptr)
+                      void* scratch, int* fallback_count, void* stream, int k_offset = 0, int* fail_flags = nullptr, int kper = 0)
 {
   if (!R || !wq || !fallback_count) return btk_set_error(BTK_ERR_PARAMETER, "btk_mvdr_weights: null argument");
   if (K < 1 || N < 1) return btk_set_error(BTK_ERR_DIMENSION, "btk_mvdr_weights: bad sizes");
@@ -292,12 +292,12 @@ static int mvdr_solve(const void* R, const void* wq, void* W, void* lambda_out, 
       BTK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_mat));
     hipLaunchKernelGGL(kern, dim3((unsigned)K), dim3(256), lds_mat, as_stream(stream), static_cast<const float2*>(R),
                        static_cast<const float2*>(wq), static_cast<float2*>(W), nullptr, N, threshold, fallback_count,
-                       static_cast<float2*>(lambda_out), k_offset, fail_flags);
+                       static_cast<float2*>(lambda_out), k_offset, kper, fail_flags);
   } else if (N <= cholr::P_MAX && !btk_switches().wpe_solve_panel) {
     BTK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(mvdr_solve_reg_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)cholr::lds_bytes()));
     hipLaunchKernelGGL(mvdr_solve_reg_kernel, dim3((unsigned)K), dim3(cholr::NTH), cholr::lds_bytes(), as_stream(stream),
                        static_cast<const float2*>(R), static_cast<const float2*>(wq), static_cast<float2*>(W), N, threshold, fallback_count,
-                       static_cast<float2*>(lambda_out), k_offset, fail_flags);
+                       static_cast<float2*>(lambda_out), k_offset, kper, fail_flags);
   } else {
     if (!scratch) return btk_set_error(BTK_ERR_PARAMETER, "btk_mvdr_weights: N=%d needs a [K][N][N] complex64 scratch buffer", N);
     const size_t lds = cholb::lds_bytes(N);
@@ -305,7 +305,7 @@ static int mvdr_solve(const void* R, const void* wq, void* W, void* lambda_out, 
     BTK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(mvdr_solve_blocked_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(mvdr_solve_blocked_kernel, dim3((unsigned)K), dim3(256), lds, as_stream(stream),
                        static_cast<const float2*>(R), static_cast<const float2*>(wq), static_cast<float2*>(W),
-                       static_cast<float2*>(scratch), N, threshold, fallback_count, static_cast<float2*>(lambda_out), k_offset, fail_flags);
+                       static_cast<float2*>(scratch), N, threshold, fallback_count, static_cast<float2*>(lambda_out), k_offset, kper, fail_flags);
   }
   BTK_HIP_CHECK(hipGetLastError());
   return BTK_OK;
@@ -332,6 +332,15 @@ int btk_mvdr_weights_flags(const void* R, const void* wq, void* W, int K, int N,
   if (!W || !fail_flags) return btk_set_error(BTK_ERR_PARAMETER, "btk_mvdr_weights_flags: null argument");
   if (first_bin < 0) return btk_set_error(BTK_ERR_DIMENSION, "btk_mvdr_weights_flags: first_bin = %d", first_bin);
   return mvdr_solve(R, wq, W, nullptr, K, N, threshold, scratch, fallback_count, stream, first_bin, fail_flags);
+}
+
+int btk_mvdr_weights_streams(const void* R, const void* wq, void* W, int S, int K, int N, float threshold,
+                             void* scratch, int* fallback_count, int* fail_flags, void* stream)
+{
+  if (!W || !fail_flags) return btk_set_error(BTK_ERR_PARAMETER, "btk_mvdr_weights_streams: null argument");
+  if (S < 1) return btk_set_error(BTK_ERR_DIMENSION, "btk_mvdr_weights_streams: S = %d", S);
+  if ((long)S * K > 0x7fffffffL) return btk_set_error(BTK_ERR_DIMENSION, "btk_mvdr_weights_streams: S * K too large");
+  return mvdr_solve(R, wq, W, nullptr, S * K, N, threshold, scratch, fallback_count, stream, 0, fail_flags, K);
 }
 
 int btk_mvdr_divide_nondiagonal(void* R, int nbins, int N, float mu, void* stream)

@@ -786,24 +786,39 @@ def mvdr_weights(R, wq, threshold=1.0e-8, first_bin=0):
     first_bin: global index of row 0 when R / wq are one rank's bin range (only global bin 0 gets the all-ones weight).
     Bins whose Cholesky factorisation stops (R_k not positive definite, pivot <= threshold) are re-solved with the
     reference's float32-SVD pseudo-inverse rule (btk_mvdr_pinv_fallback): identity only where a singular value is below
-    the threshold, the pseudo-inverse weights otherwise (beamformer.cc:232-289, 2372-2397)."""
-    _check(R, "R", torch.complex64, 3); _check(wq, "wq", torch.complex64, (R.shape[0], R.shape[1]))
-    K, N, N2 = R.shape
+    the threshold, the pseudo-inverse weights otherwise (beamformer.cc:232-289, 2372-2397).
+    S streams at once: R [S][K][N][N], wq [S][K][N] -> W [S][K][N] (btk_mvdr_weights_streams: one launch, every stream's bin 0
+    gets the all-ones weight; first_bin must be 0)."""
+    batched = R.dim() == 4
+    if batched:
+        _check(R, "R", torch.complex64, 4); _check(wq, "wq", torch.complex64, (R.shape[0], R.shape[1], R.shape[2]))
+        if first_bin != 0:
+            raise _lib.BtkError(_lib.BTK_ERR_PARAMETER, "mvdr_weights: stacked streams are whole bin ranges (first_bin = 0)")
+        S, K, N, N2 = R.shape
+    else:
+        _check(R, "R", torch.complex64, 3); _check(wq, "wq", torch.complex64, (R.shape[0], R.shape[1]))
+        S = 1
+        K, N, N2 = R.shape
     if N2 != N:
         raise _lib.BtkError(_lib.BTK_ERR_DIMENSION, "R must be [K][N][N], got %s" % (tuple(R.shape),))
-    W = torch.empty((K, N), dtype=torch.complex64, device=R.device)
+    W = torch.empty(tuple(wq.shape), dtype=torch.complex64, device=R.device)
     fb = torch.zeros(1, dtype=torch.int32, device=R.device)
-    flags = torch.zeros(max(K, 1), dtype=torch.int32, device=R.device)
+    KS = K * S
+    flags = torch.zeros(max(KS, 1), dtype=torch.int32, device=R.device)
     scratch = None
     if N > 271 or (N > 136 and os.environ.get("BTK_WPE_SOLVE_PANEL")):     # (136 < N <= 271: the register-resident solver reads R in place)
-        scratch = torch.empty((K, N, N), dtype=torch.complex64, device=R.device)
+        scratch = torch.empty((KS, N, N), dtype=torch.complex64, device=R.device)
     nident = 0
-    if K > 0:
-        check(_lib.lib().btk_mvdr_weights_flags(_ptr(R), _ptr(wq), _ptr(W), K, N, int(first_bin), float(threshold),
-                                                None if scratch is None else _ptr(scratch), _ptr(fb), _ptr(flags), _stream()))
+    if KS > 0:
+        sp = None if scratch is None else _ptr(scratch)
+        if batched:
+            check(_lib.lib().btk_mvdr_weights_streams(_ptr(R), _ptr(wq), _ptr(W), S, K, N, float(threshold), sp, _ptr(fb), _ptr(flags), _stream()))
+        else:
+            check(_lib.lib().btk_mvdr_weights_flags(_ptr(R), _ptr(wq), _ptr(W), K, N, int(first_bin), float(threshold), sp, _ptr(fb), _ptr(flags),
+                                                    _stream()))
         if int(fb.item()) > 0:
             ni = C.c_int(0)
-            check(_lib.lib().btk_mvdr_pinv_fallback(_ptr(R), _ptr(wq), _ptr(W), K, N, int(first_bin), float(threshold),
+            check(_lib.lib().btk_mvdr_pinv_fallback(_ptr(R), _ptr(wq), _ptr(W), KS, N, int(first_bin), float(threshold),
                                                     _ptr(flags), C.byref(ni), _stream()))
             nident = ni.value
     return W, nident

@@ -291,6 +291,12 @@ int  btk_mvdr_weights(const void* R, const void* wq, void* W, int K, int N, floa
 int  btk_mvdr_divide_nondiagonal(void* R, int nbins, int N, float mu, void* stream);
 int  btk_mvdr_weights_flags(const void* R, const void* wq, void* W, int K, int N, int first_bin, float threshold,
                             void* scratch, int* fallback_count, int* fail_flags, void* stream);
+/* btk_mvdr_weights_streams: the design of S independent streams (each with its own covariance matrices and look direction -- the
+ *   SMI-MVDR of S utterances) in ONE launch: R [dev] complex64 [S][K][N][N], wq / W [dev] [S][K][N], fail_flags [dev] int [S*K];
+ *   bin 0 of EVERY stream gets the all-ones weight.  The flagged bins go through btk_mvdr_pinv_fallback(R, wq, W, S*K, N, 0, ...)
+ *   (a stream's bin 0 is never flagged).  scratch [dev] [S*K][N][N] complex64 for N > 271 only.                                   */
+int  btk_mvdr_weights_streams(const void* R, const void* wq, void* W, int S, int K, int N, float threshold,
+                              void* scratch, int* fallback_count, int* fail_flags, void* stream);
 int  btk_mvdr_pinv_fallback(const void* R, const void* wq, void* W, int K, int N, int first_bin, float threshold,
                             const int* fail_flags, int* identity_count, void* stream);
 /* The solve behind it (pinv_kernels.hip), one workgroup per flagged bin, float64 on the float32-rounded matrix: while the matrix

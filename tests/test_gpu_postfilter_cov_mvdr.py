@@ -397,6 +397,30 @@ def test_mvdr_register_resident_solver_flags_singular_bins(dev, N):
         assert np.linalg.norm(W[k] - exact) <= 1e-3 * np.linalg.norm(exact)
 
 
+@pytest.mark.parametrize("N", [8, 64, 160])
+def test_mvdr_weights_of_stacked_streams_equal_the_per_stream_design(dev, N):
+    """btk_mvdr_weights_streams (engine.mvdr_weights with R [S][K][N][N]): S designs in one launch, bit for bit what S calls give -- every
+    stream's bin 0 is the all-ones vector, a singular bin of one stream takes the identity rule without touching its neighbours"""
+    import torch
+    from distant_speech_recognition_amd import engine as eng
+    S, K = 3, 5
+    rng = np.random.default_rng(100 + N)
+    A = rng.normal(size=(S, K, N, N + 8)) + 1j * rng.normal(size=(S, K, N, N + 8))
+    R = (A @ A.conj().transpose(0, 1, 3, 2)) / (N + 8) + 0.05 * np.eye(N)
+    B = rng.normal(size=(N, 2)) + 1j * rng.normal(size=(N, 2))
+    R[1, 3] = B @ B.conj().T                                        # rank 2: flagged, identity answer
+    d = (rng.normal(size=(S, K, N)) + 1j * rng.normal(size=(S, K, N))) / N
+    Rt = torch.from_numpy(R.astype(np.complex64)).to(dev)
+    dt = torch.from_numpy(d.astype(np.complex64)).to(dev)
+    W, nfb = eng.mvdr_weights(Rt, dt, threshold=1e-6)
+    assert W.shape == (S, K, N) and nfb == 1
+    for s in range(S):
+        Ws, n1 = eng.mvdr_weights(Rt[s].contiguous(), dt[s].contiguous(), threshold=1e-6)
+        assert n1 == (1 if s == 1 else 0)
+        assert torch.equal(W[s], Ws), s
+        assert torch.all(W[s, 0] == 1.0)
+
+
 def _coherent_snapshots(rng, S, K, N, T):
     X = _rand_snapshots(rng, S, K, N, T)
     X += (rng.normal(size=(S, K, 1, T)) + 1j * rng.normal(size=(S, K, 1, T))).astype(np.complex64) * 2500.0
