@@ -23,7 +23,7 @@ int btk_set_error(int code, const char* fmt, ...);
 struct btk_switches_t {
   bool disable_analysis512, disable_synthesis512, disable_fast, disable_fused, nlms_v1, wpe_noskip, wpe_timing, syn_narrow, rls_packed, wpe_solve_panel, wpe_solve_reg, wpe_herk_blocks /* BTK_WPE_HERK_BLOCKS: the round-2 block HERK instead of the lag-product form */,
        wpe_predict_valu /* BTK_WPE_PREDICT_VALU: the vector prediction kernel instead of the matrix-core one */;
-  int nlms_alt, fused_var /* -1: default */, pf_jb, pf_tpw /* 0: default */, pf_mfma_min /* channels from which the matrix-core statistics kernel runs */;
+  int mvdr_reg_min /* BTK_MVDR_REG_MIN: channel count from which the MVDR design runs on the register-resident solver (default 64) */, nlms_alt, fused_var /* -1: default */, pf_jb, pf_tpw /* 0: default */, pf_mfma_min /* channels from which the matrix-core statistics kernel runs */;
 };
 const btk_switches_t& btk_switches();
 

@@ -10,6 +10,7 @@
 // falls back to z = d (identity) when a pivot drops below the threshold -- the same observable rule.
 //     w_k = z / (N d^H z),  w_0 = all ones (:2369-2371),  d = wq_k (carries the 1/N factor, :542).
 #include "btk_internal.h"
+#include <cstdlib>
 #include "chol_blocked.h"
 #include "chol_reg.h"
 
@@ -286,7 +287,11 @@ static int mvdr_solve(const void* R, const void* wq, void* W, void* lambda_out, 
   if (!R || !wq || !fallback_count) return btk_set_error(BTK_ERR_PARAMETER, "btk_mvdr_weights: null argument");
   if (K < 1 || N < 1) return btk_set_error(BTK_ERR_DIMENSION, "btk_mvdr_weights: bad sizes");
   const size_t lds_mat = 2064 + sizeof(float2) * ((size_t)N * N + N);
-  if (lds_mat <= 150 * 1024) {
+  // Which solver (profiles/r04_mvdr_sweep.txt, 513 / 2052 systems): the LDS kernel (unblocked, a barrier per column) wins below 64 channels --
+  // several small systems per CU --, the register-resident one from 64 on (N = 64: 0.18 -> 0.11 ms, N = 100: 0.65 -> 0.14, N = 136: 1.33 -> 0.17 ms
+  // for 513 bins).  BTK_MVDR_REG_MIN moves the switch-over (A/B).
+  const int reg_min = btk_switches().mvdr_reg_min;
+  if (lds_mat <= 150 * 1024 && N < reg_min) {
     auto kern = mvdr_solve_kernel<true>;
     if (lds_mat > 64 * 1024)
       BTK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_mat));
