@@ -842,8 +842,9 @@ int btk_wpe_estimate(const void* X, int S, int K, int C, long T_stride, long T, 
   const size_t lds_solve = sizeof(float2) * ((P + 1) & ~1L) + sizeof(float) * 512 + sizeof(float2) * (size_t)P * cholb::CH_LD;
   if (lds_solve > 160 * 1024)
     return btk_set_error(BTK_ERR_DIMENSION, "btk_wpe_estimate: C*(upperN-lowerN+1) = %ld taps exceed the LDS-resident solver (max ~560)", P);
-  // register-resident solver (chol_reg.h) for 96 <= P <= 271 (BTK_WPE_SOLVE_REG=1: every P <= 271; BTK_WPE_SOLVE_PANEL=1: never)
-  const bool solve_reg = P <= cholr::P_MAX && !btk_switches().wpe_solve_panel && (P >= 96 || btk_switches().wpe_solve_reg);
+  // register-resident solver (chol_reg.h) for 112 <= P <= 271 (profiles/r04_wpe_solver_sweep.txt: the panel solver's four systems per CU win below;
+  // BTK_WPE_SOLVE_REG=1: every P <= 271; BTK_WPE_SOLVE_PANEL=1: never)
+  const bool solve_reg = P <= cholr::P_MAX && !btk_switches().wpe_solve_panel && (P >= 112 || btk_switches().wpe_solve_reg);
   if (solve_reg)
     BTK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(wpe_solve_reg_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)cholr::lds_bytes()));
   else if (lds_solve > 64 * 1024)
