@@ -60,7 +60,7 @@ def test_round3_wpe_kernels_match_the_kernels_they_replace(dev, tmp_path):
 
 
 def test_register_resident_solver_matches_the_panel_solver(dev, tmp_path):
-    """round 4: chol_reg.h (matrix in the accumulator registers, default for 96 <= P <= 271) forced for every P <= 271 against the panel
+    """round 4: chol_reg.h (matrix in the accumulator registers, default for 112 <= P <= 271) forced for every P <= 271 against the panel
     solver of chol_blocked.h forced for every P, same normal equations: P = 30 ... 264, one shape above the register solver's limit."""
     reg = _run(tmp_path, "reg", {"BTK_WPE_SOLVE_REG": "1"})
     pan = _run(tmp_path, "pan", {"BTK_WPE_SOLVE_PANEL": "1"})
