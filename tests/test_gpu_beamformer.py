@@ -290,6 +290,42 @@ def test_fused_large_geometries(orc, dev, M, N, S, T, extra):
             assert np.max(np.abs(gots[0, :, t0:t1] - Yo)) <= 4e-6 * np.sqrt(N) * np.max(np.abs(Yo)), t0
 
 
+@pytest.mark.parametrize("seed", range(8))
+def test_fused_large_geometries_fuzz(dev, seed):
+    """random launches of the M = 1024 / 2048 fused kernel -- channel counts that do not divide by the channel-group split, stream counts,
+    recording lengths (odd ones: element-wise guarded window loads), frame sub-ranges [t0, t0 + tcount) as the frame-sharded path issues
+    them, shared and per-stream weights -- against the staged pair on the same frames"""
+    import torch
+    from distant_speech_recognition_amd import engine as eng
+    rng = np.random.default_rng(4000 + seed)
+    M = int(rng.choice([1024, 2048]))
+    N = int(rng.choice([1, 2, 3, 5, 9, 17, 33, 70]))
+    S = int(rng.integers(1, 4))
+    T = int(rng.integers(1, 90))
+    m, r = 4, 1
+    D, K = M >> r, M // 2 + 1
+    fb = eng.FilterBank(design_prototype(M, m), M, m, r, 2)
+    L = (T - fb.processing_delay + fb.lookahead) * D + int(rng.integers(0, 3)) * int(rng.integers(0, D))
+    pcm, _ = synthetic_pcm(S, N, L, seed=seed)
+    p = torch.from_numpy(pcm).to(dev)
+    Tn = fb.num_frames(L)
+    per_stream = bool(rng.integers(0, 2))
+    Wn = ((rng.normal(size=(S if per_stream else 1, K, N)) + 1j * rng.normal(size=(S if per_stream else 1, K, N))) / N).astype(np.complex64)
+    W = torch.from_numpy(Wn if per_stream else Wn[0]).to(dev)
+    ref = eng.bf_apply(W, fb.analysis(p))
+    scale = float(ref.abs().max())
+    tol = 2e-6 * np.sqrt(N) * scale + 1e-6 * scale
+    got = fb.analysis_beamform(p, W)
+    assert got.shape == ref.shape == (S, K, Tn)
+    assert float((got - ref).abs().max()) <= tol, (M, N, S, T, per_stream)
+    for _ in range(3):
+        t0 = int(rng.integers(0, Tn))
+        tc = int(rng.integers(1, Tn - t0 + 1))
+        part = fb.analysis_beamform(p, W, t0=t0, tcount=tc)
+        assert part.shape == (S, K, tc)
+        assert float((part - ref[:, :, t0:t0 + tc]).abs().max()) <= tol, (M, N, S, T, t0, tc)
+
+
 def test_fused_large_geometry_is_bit_reproducible(dev):
     """a channel-split launch (one stream, few tiles: eight channel groups per tile at this size) adds its partial sums in a fixed
     order in a second kernel -- no atomics, the same bits every run"""
