@@ -18,6 +18,7 @@
 namespace {
 
 struct zd { double x, y; };
+typedef double d4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ zd zmk(double x, double y) { zd r; r.x = x; r.y = y; return r; }
 __device__ __forceinline__ zd zconj(zd a) { return zmk(a.x, -a.y); }
 __device__ __forceinline__ zd zscale(zd a, double s) { return zmk(a.x * s, a.y * s); }
@@ -224,14 +225,48 @@ void gev_vectors_kernel(const float2* __restrict__ Rt, const float2* __restrict_
   zd* dst = C2;
   for (int it = 0; it < GEV_SQUARINGS; it++) {
     // dst = src src^H = src^2 (Hermitian): only i <= j computed, mirrored
-    for (int e = tid; e < N * N; e += SOS_NT) {
-      const int i = e / N, j = e % N;
-      if (i <= j) {
-        zd a = zmk(0.0, 0.0);
-        for (int q = 0; q < N; q++) a = zfma(src[(long)i * N + q], zconj(src[(long)j * N + q]), a);
-        if (i == j) a.y = 0.0;
-        dst[(long)i * N + j] = a;
-        if (i != j) dst[(long)j * N + i] = zconj(a);
+    if (N >= 16) {
+      // round 4: on the float64 matrix cores (v_mfma_f64_16x16x4_f64: A[i][kk] from lane i + 16 kk, B[kk][j] from lane j + 16 kk, register v of
+      // lane l = D[4 v + l / 16][l % 16] -- profiles/ubench/mfma_f64_layout.hip; the float32 instruction of the same shape has
+      // D[4 (l / 16) + v][l % 16]): 16 x 16 tiles of the upper triangle dealt to the four wavefronts, re = ar br + ai bi, im = ai br - ar bi.
+      // 64 microphones: 640 matrix instructions per squaring instead of 133 000 dependent float64 multiply-adds out of LDS (10.3 -> 0.9 ms
+      // for 257 bins).
+      const int nt = (N + 15) >> 4, lane = tid & 63, wave = tid >> 6, mi = lane & 15, mg = lane >> 4;
+      for (int t = wave; t < nt * (nt + 1) / 2; t += SOS_NT / 64) {
+        int ti = 0, rem = t;
+        while (rem >= nt - ti) { rem -= nt - ti; ti++; }
+        const int tj = ti + rem;
+        const int ra = 16 * ti + mi, rb = 16 * tj + mi;
+        d4 cr = {0.0, 0.0, 0.0, 0.0}, ci = {0.0, 0.0, 0.0, 0.0};
+        for (int q0 = 0; q0 < N; q0 += 4) {
+          const int q = q0 + mg;
+          const zd a = (ra < N && q < N) ? src[(long)ra * N + q] : zmk(0.0, 0.0);
+          const zd b = (rb < N && q < N) ? src[(long)rb * N + q] : zmk(0.0, 0.0);
+          cr = __builtin_amdgcn_mfma_f64_16x16x4f64(a.x, b.x, cr, 0, 0, 0);
+          cr = __builtin_amdgcn_mfma_f64_16x16x4f64(a.y, b.y, cr, 0, 0, 0);
+          ci = __builtin_amdgcn_mfma_f64_16x16x4f64(a.y, b.x, ci, 0, 0, 0);
+          ci = __builtin_amdgcn_mfma_f64_16x16x4f64(-a.x, b.y, ci, 0, 0, 0);
+        }
+#pragma unroll
+        for (int v = 0; v < 4; v++) {
+          const int i = 16 * ti + 4 * v + mg, j = 16 * tj + mi;
+          if (i < N && j < N && i <= j) {
+            const zd a = zmk(cr[v], (i == j) ? 0.0 : ci[v]);
+            dst[(long)i * N + j] = a;
+            if (i != j) dst[(long)j * N + i] = zconj(a);
+          }
+        }
+      }
+    } else {
+      for (int e = tid; e < N * N; e += SOS_NT) {
+        const int i = e / N, j = e % N;
+        if (i <= j) {
+          zd a = zmk(0.0, 0.0);
+          for (int q = 0; q < N; q++) a = zfma(src[(long)i * N + q], zconj(src[(long)j * N + q]), a);
+          if (i == j) a.y = 0.0;
+          dst[(long)i * N + j] = a;
+          if (i != j) dst[(long)j * N + i] = zconj(a);
+        }
       }
     }
     __syncthreads();
