@@ -479,6 +479,11 @@ void analysis512_bfz_kernel(const float* __restrict__ pcm, long nsamples, long p
     mark(2);                                                         // barrier A
     const int wbuf = PIPE ? (n & 1) : 0;
 
+    // PRIO (VAR & 32768, round 4): the polyphase stage -- 64 packed instructions between the channel's two barriers -- runs at wave priority 1.
+    // The two workgroups of a CU are out of phase; a wavefront that is between its barriers holds three others up, one that is in its
+    // FFT holds nobody up: letting the short stage win the issue arbitration measured -1.0 ... -1.5 % in 15 of 16 alternating pairs on
+    // three boxes (profiles/r04_fused_ab.txt).  Priority around the FFT instead: +3.8 %; from the loop top through the load issue: +1.9 %.
+    if constexpr ((VAR & 32768) != 0) __builtin_amdgcn_s_setprio(1);
     // ---- phase 2: polyphase (sliding register window), frames overwrite the span after the barrier.
     //      V[i] = xs[(M - 2 - 2 n0 - (G-1) 512/G) + (f0 + i) D]; index n0 + q NPG, frame f0 + g, tap k uses
     //      V[g + R (m-1-k) + (G-1-q) CG]  (= xs[f D + m M - 2 - 2 n - M k], modulated.cc:380-392)
@@ -520,6 +525,7 @@ void analysis512_bfz_kernel(const float* __restrict__ pcm, long nsamples, long p
         }
       }
     }
+    if constexpr ((VAR & 32768) != 0) __builtin_amdgcn_s_setprio(0);
     mark(3);                                                         // polyphase (+ LDS window reads when staged)
     if constexpr (ABL != 5) __syncthreads();
     mark(4);                                                         // barrier B
@@ -691,8 +697,9 @@ int launch512_bf(const btk_fb* fb, const float* pcm, long nsamples, long pcm_str
   // form for R = 1, whose 38 KB span leaves no room for a separate region), 3 = LDS-DMA staging of the span,
   // 7 = polyphase window straight from HBM, only frames and weights in LDS, 15 = 7 with the window loads interleaved with the FFT
   // (31: the other interleaving pattern), 79 = 15 with the polyphase products' halves crossed by op_sel, 207 =
-  // 79 with the folded-constant radix-16 passes, 463 (default for R = 2) = 207 with the bin-256 weight of a channel taken from a scalar load
-  const int var = btk_switches().fused_var >= 0 ? btk_switches().fused_var : (R == 2 ? 463 : 3);
+  // 79 with the folded-constant radix-16 passes, 463 = 207 with the bin-256 weight of a channel taken from a scalar load,
+  // 33231 (default for R = 2) = 463 with the polyphase stage at wave priority 1
+  const int var = btk_switches().fused_var >= 0 ? btk_switches().fused_var : (R == 2 ? 33231 : 3);
   const bool pipe = (var & 2) && R >= 2;
   const bool gw = pipe && (var & 4) && R == 2;
   // (TT = 8 -- two wavefronts per workgroup, four workgroups per CU, the same occupancy with less barrier coupling -- measured
@@ -710,7 +717,7 @@ int launch512_bf(const btk_fb* fb, const float* pcm, long nsamples, long pcm_str
   auto kern = pipe ? analysis512_bfz_kernel<R, 3> : analysis512_bfz_kernel<R, 1>;
   if (gw) kern = analysis512_bfz_kernel<2, 7>;
   if (t8) kern = analysis512_bfz_kernel<2, 7, 8>;
-  if (gw && !t8 && (var & 8)) kern = (var & 16) ? analysis512_bfz_kernel<2, 31> : ((var & 64) ? ((var & 128) ? ((var & 256) ? analysis512_bfz_kernel<2, 463> : analysis512_bfz_kernel<2, 207>) : analysis512_bfz_kernel<2, 79>) : analysis512_bfz_kernel<2, 15>);
+  if (gw && !t8 && (var & 8)) kern = (var & 16) ? analysis512_bfz_kernel<2, 31> : ((var & 64) ? ((var & 128) ? ((var & 256) ? ((var & 32768) ? analysis512_bfz_kernel<2, 33231> : analysis512_bfz_kernel<2, 463>) : analysis512_bfz_kernel<2, 207>) : analysis512_bfz_kernel<2, 79>) : analysis512_bfz_kernel<2, 15>);
 #ifdef BTK_FUSED_ABLATE
   if (gw && !t8) switch ((var >> 12) & 7) {
     case 1: kern = analysis512_bfz_kernel<2, 15 + 4096 * 1>; break;
@@ -725,7 +732,7 @@ int launch512_bf(const btk_fb* fb, const float* pcm, long nsamples, long pcm_str
 #endif
   unsigned long long* phase = nullptr;
   if (R == 2 && (var & 512)) {                       // diagnostics: per-phase shader cycles of wave 0, printed by every launch
-    kern = gw ? analysis512_bfz_kernel<2, 975> : analysis512_bfz_kernel<2, 515>;   // 975 = the default form (463) with the marks
+    kern = gw ? analysis512_bfz_kernel<2, 33743> : analysis512_bfz_kernel<2, 515>;   // 33743 = the default form (33231) with the marks
     static unsigned long long* dbuf = nullptr;
     if (!dbuf) BTK_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&dbuf), 16 * sizeof(unsigned long long)));
     BTK_HIP_CHECK(hipMemsetAsync(dbuf, 0, 16 * sizeof(unsigned long long), st));

@@ -69,7 +69,7 @@ __global__ void big_reduce_kernel(const float2* __restrict__ P, float2* __restri
   Y[row * T_stride + t] = a;
 }
 
-template <int LOG2M, int VAR>     // VAR & 1: the window loads of the next channel are issued unconditionally and interleaved with the transform
+template <int LOG2M, int VAR>     // VAR & 1: the window loads of the next channel are issued unconditionally and interleaved with the transform; VAR & 2: see the polyphase stage
 __global__ __launch_bounds__(BG<LOG2M>::NT, (LOG2M == 10) ? 2 : 1)
 void analysis_bfz_big_kernel(const float* __restrict__ pcm, long nsamples, long pcm_stride,
                              const float* __restrict__ proto, const float2* __restrict__ twg,
@@ -175,6 +175,7 @@ void analysis_bfz_big_kernel(const float* __restrict__ pcm, long nsamples, long 
       const int wbuf = (n - nbeg) & 1;
       __syncthreads();                                                       // A: frames and weight buffer of channel n - 1 are consumed
       // ---- polyphase: z = (h.x x.y, h.y x.x) summed over the taps; tap k of index n0 + q NT, frame g uses row g + 2 (3 - k) + (1 - q)
+      if constexpr ((VAR & 2) != 0) __builtin_amdgcn_s_setprio(1);          // (between its two barriers a wavefront holds the others up: fb_analysis512.hip PRIO)
       {
         f2 po[2][TT];
 #pragma unroll
@@ -193,6 +194,7 @@ void analysis_bfz_big_kernel(const float* __restrict__ pcm, long nsamples, long 
 #pragma unroll
           for (int q = 0; q < 2; q++) fbuf[g * FRS + n0 + q * NT] = po[q][g];
       }
+      if constexpr ((VAR & 2) != 0) __builtin_amdgcn_s_setprio(0);
       __syncthreads();                                                       // B: frames written
       constexpr bool SPREAD = (VAR & 1) != 0 && decltype(fast)::value;
       if constexpr (SPREAD) { wload(n + 1 < nend ? n + 1 : n, fast); wfetch(n + 1 < nend ? n + 1 : n); }   // same basic block as the transform
@@ -347,8 +349,8 @@ int launch_big(const btk_fb* fb, const float* pcm, long nsamples, long pcm_strid
   const size_t lds = sizeof(f2) * B_TT * G::FRS + sizeof(f4) * 2 * G::WSTRB;
   // interleaving the window loads with the transform (VAR 1): -0.7 % at M = 2048 (one 8-wave workgroup per CU), +2 % at M = 1024
   // (profiles/r04_fused_big_ab.txt); BTK_FUSED_VAR = 0 / 1 forces either form (diagnostics)
-  const int var = btk_switches().fused_var >= 0 ? (btk_switches().fused_var & 1) : (LOG2M == 11 ? 1 : 0);
-  auto kern = var ? analysis_bfz_big_kernel<LOG2M, 1> : analysis_bfz_big_kernel<LOG2M, 0>;
+  const int var = btk_switches().fused_var >= 0 ? (btk_switches().fused_var & 3) : (LOG2M == 11 ? 3 : 0);       // VAR & 2: polyphase stage at wave priority 1 (M = 2048: -0.6 ... -1.0 %, M = 1024: no change)
+  auto kern = (var & 2) ? ((var & 1) ? analysis_bfz_big_kernel<LOG2M, 3> : analysis_bfz_big_kernel<LOG2M, 2>) : ((var & 1) ? analysis_bfz_big_kernel<LOG2M, 1> : analysis_bfz_big_kernel<LOG2M, 0>);
   BTK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(kern, dim3((unsigned)nblocks), dim3(G::NT), lds, st, pcm, nsamples, pcm_stride, fb->d_proto, fb->d_tw, fb->laN, gain,
                      N, K, Wq, per_stream ? (long)N * G::WSTRB : 0L, CG > 1 ? part : Y, CG > 1 ? tcount : T_stride,
