@@ -81,6 +81,11 @@ SIGNATURES = {
     "btk_sos_scratch_bytes": (_l, [_i, _i]),
     "btk_bmvdr_weights": (_i, [_vp, _vp, _i, _i, _i, _d, _vp, _vp, _vp, _vp]),
     "btk_gev_weights": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp]),
+    "btk_mvdr_scratch_bytes": (_l, [_i, _i]),
+    "btk_csvdc_scratch_bytes": (_l, [_i, _i, _i]),
+    "btk_csvdc_values": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    "btk_mvdr_linpack_rule_scratch_bytes": (_l, [_i, _i]),
+    "btk_mvdr_linpack_rule": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp]),
     "btk_mvdr_diffuse_model": (_i, [_vp, _i, _i, _f, _f, _vp, _vp]),
     "btk_mvdr_diagonal_loading": (_i, [_vp, _i, _i, _f, _vp]),
     "btk_mvdr_weights": (_i, [_vp, _vp, _vp, _i, _i, _f, _vp, _vp, _vp]),

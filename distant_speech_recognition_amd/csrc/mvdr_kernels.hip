@@ -316,6 +316,17 @@ static int mvdr_solve(const void* R, const void* wq, void* W, void* lambda_out, 
   return BTK_OK;
 }
 
+// Bytes of the [K][N][N] scratch copy the solver mvdr_solve() would pick for N channels needs (0: none) -- the one place
+// that knows the dispatch rule, so that callers never re-derive it.
+long btk_mvdr_scratch_bytes(int K, int N)
+{
+  if (K < 1 || N < 1) return 0;
+  const size_t lds_mat = 2064 + sizeof(float2) * ((size_t)N * N + N);
+  if (lds_mat <= 150 * 1024 && N < btk_switches().mvdr_reg_min) return 0;
+  if (N <= cholr::P_MAX && !btk_switches().wpe_solve_panel) return 0;
+  return (long)sizeof(float2) * K * N * N;
+}
+
 int btk_mvdr_weights(const void* R, const void* wq, void* W, int K, int N, float threshold,
                      void* scratch, int* fallback_count, void* stream)
 {

@@ -608,18 +608,25 @@ class CoherencePostFilterState:
         check(_lib.lib().btk_pf_coherence_coeffs(_ptr(R.contiguous()), float(np.float32(threshold)), K, N, _ptr(self.Cs),
                                                  None if self.Cv is None else _ptr(self.Cv), _stream()))
 
-    def set_lambda(self, R, d, min_sv=1.0e-8):
+    def set_lambda(self, R, d, min_sv=1.0e-8, svd_rule=None):
         """Lambda_k = d^H pinv(R_k) d (calcLambda, postfilter.cc:982-995) for all bins; returns the number of bins
-        that fell back to the identity (:975-977)."""
+        that fell back to the identity (:975-977).  svd_rule as in mvdr_weights(): "linpack" (default) takes the identity
+        exactly where the reference's pseudoinverse() returns false (all bins, bin 0 included: postfilter.cc:971)."""
         _need_cuda(R, "R"); _need_cuda(d, "d")
         K, N = self.K, self.N
+        rule = svd_rule_default() if svd_rule is None else svd_rule
+        if rule not in SVD_RULES:
+            raise _lib.BtkError(_lib.BTK_ERR_PARAMETER, "svd_rule must be one of %s, got %r" % (SVD_RULES, rule))
+        R, d = R.contiguous(), d.contiguous()
         self.lam = torch.empty((K,), dtype=torch.complex64, device=R.device)
         fb = torch.zeros(1, dtype=torch.int32, device=R.device)
-        scratch = None
-        if 2064 + 8 * (N * N + N) > 150 * 1024:
-            scratch = torch.empty((K, N, N), dtype=torch.complex64, device=R.device)
-        check(_lib.lib().btk_mvdr_lambda(_ptr(R.contiguous()), _ptr(d.contiguous()), _ptr(self.lam), K, N, float(min_sv),
+        sb = _lib.lib().btk_mvdr_scratch_bytes(K, N)
+        scratch = torch.empty((sb,), dtype=torch.uint8, device=R.device) if sb else None
+        check(_lib.lib().btk_mvdr_lambda(_ptr(R), _ptr(d), _ptr(self.lam), K, N, float(min_sv),
                                          None if scratch is None else _ptr(scratch), _ptr(fb), _stream()))
+        if rule == "linpack":
+            counts = _linpack_rule(R, d, None, self.lam, K, N, 0, 0, 0, min_sv, None)
+            return int(counts.sum().item())
         return int(fb.item())
 
 
@@ -781,14 +788,62 @@ def mvdr_diagonal_loading(R, weight):
     return R
 
 
-def mvdr_weights(R, wq, threshold=1.0e-8, first_bin=0):
-    """R complex64 [K][N][N], wq complex64 [K][N] (cuda) -> (W [K][N], number of identity fall-backs).
+SVD_RULES = ("linpack", "exact")
+
+
+def svd_rule_default():
+    """The rule that decides where pseudoinverse() 'fails' and the identity replaces inv(R_k) (beamformer.cc:253-270, 2379-2384):
+    "linpack" (default) takes the decision of the reference's float32 csvdc, rounding for rounding -- INFO != 0 or a singular
+    value under the threshold -- so a design matches the reference bin for bin (on BASELINE config C5 that is delay-and-sum on
+    about half the spectrum); "exact" solves every positive definite bin and uses the identity only where a singular value is
+    really below the threshold.  BTK_MVDR_SVD_RULE overrides the default."""
+    rule = os.environ.get("BTK_MVDR_SVD_RULE", "linpack")
+    if rule not in SVD_RULES:
+        raise _lib.BtkError(_lib.BTK_ERR_PARAMETER, "BTK_MVDR_SVD_RULE must be one of %s, got %r" % (SVD_RULES, rule))
+    return rule
+
+
+def csvdc_values(A):
+    """LINPACK's float32 csvdc with job = 0 (matrix/linpack_c.cc:9516) for a batch: A complex64 [K][n][p] (cuda) ->
+    (s float32 [K][m], e float32 [K][m], info int32 [K]), m = min(n + 1, p); bit-identical to the reference's compiled routine."""
+    _check(A, "A", torch.complex64, 3)
+    K, n, p = A.shape
+    m = min(n + 1, p)
+    s = torch.zeros((K, m), dtype=torch.float32, device=A.device)
+    e = torch.zeros((K, m), dtype=torch.float32, device=A.device)
+    info = torch.zeros((K,), dtype=torch.int32, device=A.device)
+    if K > 0:
+        sb = _lib.lib().btk_csvdc_scratch_bytes(K, n, p)
+        scratch = torch.empty((sb,), dtype=torch.uint8, device=A.device) if sb else None
+        check(_lib.lib().btk_csvdc_values(_ptr(A), K, n, p, _ptr(s), _ptr(e), _ptr(info), None if scratch is None else _ptr(scratch),
+                                          _stream()))
+    return s, e, info
+
+
+def _linpack_rule(R, wq, W, lam, KS, N, first_bin, kper, skip_dc, threshold, flags):
+    """btk_mvdr_linpack_rule on the current stream; returns the device counters [INFO != 0, singular value < threshold]."""
+    counts = torch.zeros(2, dtype=torch.int32, device=R.device)
+    scratch = torch.empty((_lib.lib().btk_mvdr_linpack_rule_scratch_bytes(KS, N),), dtype=torch.uint8, device=R.device)
+    check(_lib.lib().btk_mvdr_linpack_rule(_ptr(R), _ptr(wq), None if W is None else _ptr(W), None if lam is None else _ptr(lam),
+                                           KS, N, int(first_bin), int(kper), int(skip_dc), float(threshold),
+                                           None if flags is None else _ptr(flags), _ptr(counts), _ptr(scratch), _stream()))
+    return counts
+
+
+def mvdr_weights(R, wq, threshold=1.0e-8, first_bin=0, svd_rule=None):
+    """R complex64 [K][N][N], wq complex64 [K][N] (cuda) -> (W [K][N], number of bins that ended with the identity).
     first_bin: global index of row 0 when R / wq are one rank's bin range (only global bin 0 gets the all-ones weight).
-    Bins whose Cholesky factorisation stops (R_k not positive definite, pivot <= threshold) are re-solved with the
-    reference's float32-SVD pseudo-inverse rule (btk_mvdr_pinv_fallback): identity only where a singular value is below
-    the threshold, the pseudo-inverse weights otherwise (beamformer.cc:232-289, 2372-2397).
+    svd_rule (svd_rule_default() when None): with "linpack" the bins for which the reference's pseudoinverse() returns false --
+    its float32 csvdc does not converge, or leaves a singular value under the threshold -- take the identity exactly as in
+    calc_mvdr_weights (beamformer.cc:253-270, 2379-2396); every other bin keeps the Cholesky solution.  Bins whose Cholesky
+    factorisation stops (R_k not positive definite) and that the rule did not already decide are re-solved through the
+    pseudo-inverse (btk_mvdr_pinv_fallback).  mvdr_weights.last_counts = (INFO != 0, converged but under the threshold,
+    identity from the fall-back) of the last call.
     S streams at once: R [S][K][N][N], wq [S][K][N] -> W [S][K][N] (btk_mvdr_weights_streams: one launch, every stream's bin 0
     gets the all-ones weight; first_bin must be 0)."""
+    rule = svd_rule_default() if svd_rule is None else svd_rule
+    if rule not in SVD_RULES:
+        raise _lib.BtkError(_lib.BTK_ERR_PARAMETER, "svd_rule must be one of %s, got %r" % (SVD_RULES, rule))
     batched = R.dim() == 4
     if batched:
         _check(R, "R", torch.complex64, 4); _check(wq, "wq", torch.complex64, (R.shape[0], R.shape[1], R.shape[2]))
@@ -805,23 +860,31 @@ def mvdr_weights(R, wq, threshold=1.0e-8, first_bin=0):
     fb = torch.zeros(1, dtype=torch.int32, device=R.device)
     KS = K * S
     flags = torch.zeros(max(KS, 1), dtype=torch.int32, device=R.device)
-    scratch = None
-    if N > 271 or (N > 136 and os.environ.get("BTK_WPE_SOLVE_PANEL")):     # (136 < N <= 271: the register-resident solver reads R in place)
-        scratch = torch.empty((KS, N, N), dtype=torch.complex64, device=R.device)
     nident = 0
+    mvdr_weights.last_counts = (0, 0, 0)
     if KS > 0:
+        sb = _lib.lib().btk_mvdr_scratch_bytes(KS, N)
+        scratch = torch.empty((sb,), dtype=torch.uint8, device=R.device) if sb else None
         sp = None if scratch is None else _ptr(scratch)
         if batched:
             check(_lib.lib().btk_mvdr_weights_streams(_ptr(R), _ptr(wq), _ptr(W), S, K, N, float(threshold), sp, _ptr(fb), _ptr(flags), _stream()))
         else:
             check(_lib.lib().btk_mvdr_weights_flags(_ptr(R), _ptr(wq), _ptr(W), K, N, int(first_bin), float(threshold), sp, _ptr(fb), _ptr(flags),
                                                     _stream()))
-        if int(fb.item()) > 0:
-            ni = C.c_int(0)
+        c0 = c1 = 0
+        if rule == "linpack":
+            counts = _linpack_rule(R, wq, W, None, KS, N, first_bin, K if batched else 0, 1, threshold, flags)
+            c0, c1 = (int(v) for v in counts.tolist())
+        ni = C.c_int(0)
+        if int(fb.item()) > 0 and (rule != "linpack" or int(flags.sum().item()) > 0):
             check(_lib.lib().btk_mvdr_pinv_fallback(_ptr(R), _ptr(wq), _ptr(W), KS, N, int(first_bin), float(threshold),
                                                     _ptr(flags), C.byref(ni), _stream()))
-            nident = ni.value
+        nident = c0 + c1 + ni.value
+        mvdr_weights.last_counts = (c0, c1, ni.value)
     return W, nident
+
+
+mvdr_weights.last_counts = (0, 0, 0)
 
 
 def mvdr_divide_nondiagonal(R, mu):

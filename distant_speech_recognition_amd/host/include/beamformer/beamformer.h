@@ -267,12 +267,20 @@ class SubbandMVDR : public SubbandDS {
   void divideNonDiagonalElements(unsigned fbinX, float mu) { divide_nondiagonal_elements(fbinX, mu); }
   virtual void effective_weights(std::vector<float>& w);
   int identity_fallbacks() const { return fallbacks_; }
+  // Which bins take the identity in place of inv(R_k) (reference beamformer.cc:253-270, 2379-2384): "linpack" (default; the
+  // environment variable BTK_MVDR_SVD_RULE overrides) = exactly where the reference's float32 csvdc reports INFO != 0 or
+  // leaves a singular value under the threshold; "exact" = only where a singular value really is under the threshold.
+  void set_svd_rule(const String& rule);
+  const String& svd_rule() const { return svd_rule_; }
+  int csvdc_not_converged() const { return csvdc_not_converged_; }    // bins of the last design with INFO != 0
  protected:
   void alloc_R_();
   void* dR_;                        // device complex64 [K][N][N]
   std::vector<float> wmvdr_;        // complex64 [K][N]
   bool have_mvdr_;
   int fallbacks_;
+  String svd_rule_;
+  int csvdc_not_converged_;
   gsl_vector_complex* wm_view_;
   gsl_matrix_complex* R_view_;
 };

@@ -1171,9 +1171,24 @@ void SubbandGSC::effective_weights_all_bins(std::vector<float>& w)
 }
 
 // ================================================================================ SubbandMVDR
+// "linpack" | "exact": see SubbandMVDR::set_svd_rule (beamformer.h); BTK_MVDR_SVD_RULE overrides the default "linpack"
+static String default_svd_rule()
+{
+  const char* e = getenv("BTK_MVDR_SVD_RULE");
+  if (!e || !*e) return "linpack";
+  if (strcmp(e, "linpack") && strcmp(e, "exact")) throw jparameter_error("BTK_MVDR_SVD_RULE must be linpack or exact, got %s\n", e);
+  return e;
+}
+
+void SubbandMVDR::set_svd_rule(const String& rule)
+{
+  if (rule != "linpack" && rule != "exact") throw jparameter_error("svd rule must be linpack or exact, got %s\n", rule.c_str());
+  svd_rule_ = rule;
+}
+
 SubbandMVDR::SubbandMVDR(unsigned fftLen, bool halfBandShift, const String& nm)
-    : SubbandDS(fftLen, halfBandShift, nm), dR_(NULL), have_mvdr_(false), fallbacks_(0), wm_view_(gsl_vector_complex_calloc(1)),
-      R_view_(NULL)
+    : SubbandDS(fftLen, halfBandShift, nm), dR_(NULL), have_mvdr_(false), fallbacks_(0), svd_rule_(default_svd_rule()),
+      csvdc_not_converged_(0), wm_view_(gsl_vector_complex_calloc(1)), R_view_(NULL)
 {
   if (halfBandShift) {                                       // reference beamformer.cc:2283-2285
     gsl_vector_complex_free(wm_view_);
@@ -1275,18 +1290,34 @@ bool SubbandMVDR::calc_mvdr_weights(float, float dThreshold, bool)
   void* dD = dev_alloc(sizeof(float) * d.size());
   void* dW = dev_alloc(sizeof(float) * d.size());
   void* dfb = dev_alloc(sizeof(int));
-  void* scratch = NULL;
-  if (N > 271 || (N > 136 && getenv("BTK_WPE_SOLVE_PANEL"))) scratch = dev_alloc(sizeof(float) * 2 * K * N * N);   // (only the panel solver copies R)
+  const long sbytes = btk_mvdr_scratch_bytes((int)K, (int)N);                   // (only the panel solver copies R)
+  void* scratch = sbytes ? dev_alloc((size_t)sbytes) : NULL;
   void* dflags = dev_alloc(sizeof(int) * K);
   h2d(dD, d.data(), sizeof(float) * d.size());
   check_hip(hipMemset(dfb, 0, sizeof(int)), "hipMemset");
   check_abi(btk_mvdr_weights_flags(dR_, dD, dW, (int)K, (int)N, 0, dThreshold, scratch, (int*)dfb, (int*)dflags, NULL));
+  int rule_counts[2] = {0, 0};
+  if (svd_rule_ == "linpack") {
+    // pseudoinverse() returns false where the reference's float32 csvdc gives INFO != 0 or a singular value under the
+    // threshold -> identity (beamformer.cc:253-270, 2379-2384); those bins also leave the fall-back's list
+    void* dcnt = dev_alloc(sizeof(int) * 2);
+    void* rs = dev_alloc((size_t)btk_mvdr_linpack_rule_scratch_bytes((int)K, (int)N));
+    check_hip(hipMemset(dcnt, 0, sizeof(int) * 2), "hipMemset");
+    check_abi(btk_mvdr_linpack_rule(dR_, dD, dW, NULL, (int)K, (int)N, 0, 0, 1, dThreshold, (int*)dflags, (int*)dcnt, rs, NULL));
+    check_abi(btk_synchronize(NULL));
+    d2h(rule_counts, dcnt, sizeof(rule_counts));
+    dev_free(dcnt); dev_free(rs);
+  }
   check_abi(btk_synchronize(NULL));
+  csvdc_not_converged_ = rule_counts[0];
+  std::vector<int> hflags(K);
+  d2h(hflags.data(), dflags, sizeof(int) * K);
   int stopped = 0;
-  d2h(&stopped, dfb, sizeof(int));
+  for (unsigned k = 0; k < K; ++k) stopped += hflags[k] != 0;
   fallbacks_ = 0;
-  if (stopped > 0)     // bins the Cholesky solve gave up on: the reference's float32-SVD pseudo-inverse rule (beamformer.cc:232-289)
+  if (stopped > 0)     // bins the Cholesky solve gave up on and the rule above left open: the pseudo-inverse (beamformer.cc:232-289)
     check_abi(btk_mvdr_pinv_fallback(dR_, dD, dW, (int)K, (int)N, 0, dThreshold, (const int*)dflags, &fallbacks_, NULL));
+  fallbacks_ += rule_counts[0] + rule_counts[1];
   wmvdr_.resize(d.size());
   d2h(wmvdr_.data(), dW, sizeof(float) * wmvdr_.size());
   dev_free(dD); dev_free(dW); dev_free(dfb); dev_free(dflags); dev_free(scratch);
@@ -1831,8 +1862,15 @@ void McCowanPostFilter::compute_(long from_frame)
       void* dLam = dev_alloc(sizeof(float) * 2 * K);
       void* dFb = dev_alloc(sizeof(int));
       check_hip(hipMemset(dFb, 0, sizeof(int)), "hipMemset");
-      void* scratch = (2064 + 8 * ((size_t)N * N + N) > 150 * 1024) ? dev_alloc(sizeof(float) * 2 * K * N * N) : NULL;
+      const long sbytes = btk_mvdr_scratch_bytes((int)K, (int)N);
+      void* scratch = sbytes ? dev_alloc((size_t)sbytes) : NULL;
       check_abi(btk_mvdr_lambda(dR_, dD, dLam, (int)K, (int)N, (float)minSV_, scratch, (int*)dFb, NULL));   // :967-995
+      if (default_svd_rule() == "linpack") {               // pseudoinverse() false -> identity, every bin incl. 0 (:971-977)
+        void* rs = dev_alloc((size_t)btk_mvdr_linpack_rule_scratch_bytes((int)K, (int)N));
+        check_abi(btk_mvdr_linpack_rule(dR_, dD, NULL, dLam, (int)K, (int)N, 0, 0, 0, (float)minSV_, NULL, NULL, rs, NULL));
+        check_abi(btk_synchronize(NULL));
+        dev_free(rs);
+      }
       invR_computed_ = true;
       check_abi(btk_lefkimmiatis_process(Yo, Uo, Vo, dLam, (int)fbinX1_, 1, (int)K, (int)N, T_, Tn, alpha_, (int)type_,
                                          min_frames_, from_frame, dPhi_, dV_, (float*)dWl_, NULL));

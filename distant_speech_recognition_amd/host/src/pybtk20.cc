@@ -440,7 +440,10 @@ PYBIND11_MODULE(_btk20cpp, m)
       .def("set_diagonal_looading", &SubbandMVDR::set_diagonal_looading)
       .def("divide_all_nondiagonal_elements", &SubbandMVDR::divide_all_nondiagonal_elements)
       .def("divide_nondiagonal_elements", &SubbandMVDR::divide_nondiagonal_elements)
-      .def("identity_fallbacks", &SubbandMVDR::identity_fallbacks);
+      .def("identity_fallbacks", &SubbandMVDR::identity_fallbacks)
+      .def("set_svd_rule", &SubbandMVDR::set_svd_rule, py::arg("rule"))
+      .def("svd_rule", &SubbandMVDR::svd_rule)
+      .def("csvdc_not_converged", &SubbandMVDR::csvdc_not_converged);
 
   py::class_<SubbandMVDRGSC, SubbandMVDR, cref<SubbandMVDRGSC>>(m, "SubbandMVDRGSCPtr")
       .def(py::init([](unsigned fftlen, bool half_band_shift, const std::string& nm) { return new SubbandMVDRGSC(fftlen, half_band_shift, nm); }),

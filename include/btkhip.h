@@ -274,6 +274,9 @@ int  btk_gev_weights(const void* Rt, const void* Rn, int K, int N, void* WqH, vo
  *   wq [dev] complex64 [K][N] = d; W [dev] complex64 [K][N]; scratch [dev] [K][N][N] complex64 only
  *   needed for N > 271 (N <= 136: R_k in LDS; 136 < N <= 271: R_k in the matrix cores' accumulator
  *   registers, read once, never copied; above: panel solver on a copy of R_k); may be NULL otherwise. */
+/* btk_mvdr_scratch_bytes: bytes of `scratch` the design entries below (btk_mvdr_weights*, btk_mvdr_lambda) need for K bins of
+ *   N channels -- 0 when the solver that will run keeps R_k in LDS or in registers (scratch may then be NULL).            */
+long btk_mvdr_scratch_bytes(int K, int N);
 int  btk_mvdr_diffuse_model(const float* mpos, int N, int M, float samplerate, float sspeed, void* R, void* stream);
 int  btk_mvdr_diagonal_loading(void* R, int nbins, int N, float weight, void* stream);
 int  btk_mvdr_weights(const void* R, const void* wq, void* W, int K, int N, float threshold,
@@ -315,6 +318,28 @@ int  btk_mvdr_pinv_fallback_host(const void* R, const void* wq, void* W, int K, 
                                  const int* fail_flags, int* identity_count, void* stream);
 int  btk_mvdr_pinv_not_converged(void);
 int  btk_pinv(const double* A, int M, int N, float threshold, double* invA, int* below_threshold);
+/* ---- The reference's float32 csvdc, decision for decision -------------------------------------------
+ * pseudoinverse() (beamformer/beamformer.cc:232-289) returns false -- and calc_mvdr_weights (:2379-2384) /
+ * LefkimmiatisPostFilter::calc_inverse_noise_spatial_spectral_matrix (postfilter/postfilter.cc:967-980) then use the identity --
+ * when LINPACK's float32 csvdc (matrix/linpack_c.cc:9516) reports INFO != 0 (no convergence within 30 QR sweeps) or leaves a
+ * singular value below the threshold.  On the 256-microphone diffuse model of BASELINE config C5 INFO != 0 on about half the
+ * bins; the decision depends on the float32 roundings, so it is reproduced with the same arithmetic in the same order.
+ * btk_csvdc_values: csvdc with job = 0 (no vectors: they never feed back into s, e or INFO) for K matrices A [dev] complex64
+ *   [K][n][p] row-major (not modified); s, e [dev] float32 [K][min(n + 1, p)] (either may be NULL), info [dev] int32 [K];
+ *   scratch [dev] btk_csvdc_scratch_bytes(K, n, p) bytes (0: the matrix lives in LDS, scratch may be NULL).  Bit-identical to
+ *   the reference's compiled csvdc (tests/test_gpu_linpack_rule.py against oracle/_ref and tests/golden/c5_csvdc_info.npz).
+ * btk_mvdr_linpack_rule: applies that decision to a design some solver has already written: R [K][N][N], wq [K][N]; every bin
+ *   for which pseudoinverse() returns false gets W_k = d / (N d^H d) (W may be NULL) and lambda_k = d^H d (lambda may be NULL)
+ *   and its fail_flags entry (may be NULL) is cleared, so btk_mvdr_pinv_fallback afterwards only visits bins that converged but
+ *   are not positive definite.  skip_dc != 0: the DC bin (first_bin + k == 0, or k % kper == 0 for kper > 0 stacked streams)
+ *   is left alone like calc_mvdr_weights does; the Lefkimmiatis filter decomposes bin 0 too (skip_dc = 0).
+ *   counts [dev int[2]] (may be NULL): [0] += bins with INFO != 0, [1] += converged bins with a singular value < threshold.
+ *   scratch [dev] btk_mvdr_linpack_rule_scratch_bytes(K, N) bytes.  All on `stream`, no allocation, no synchronisation.      */
+long btk_csvdc_scratch_bytes(int K, int n, int p);
+int  btk_csvdc_values(const void* A, int K, int n, int p, float* s, float* e, int* info, void* scratch, void* stream);
+long btk_mvdr_linpack_rule_scratch_bytes(int K, int N);
+int  btk_mvdr_linpack_rule(const void* R, const void* wq, void* W, void* lambda, int K, int N, int first_bin, int kper,
+                           int skip_dc, float threshold, int* fail_flags, int* counts, void* scratch, void* stream);
 /* The same solve for a bin SHARD [first_bin, first_bin + K) of a bin-sharded run: only global bin 0 gets the
  * all-ones weight of calc_mvdr_weights (beamformer.cc:2369-2371).                                                    */
 int  btk_mvdr_weights_shard(const void* R, const void* wq, void* W, int K, int N, int first_bin, float threshold,

@@ -69,28 +69,30 @@ def test_c5_superdirective_256mic_2048bins_bin_sharded(orc, dev):
     wq = orc.calc_mainlobe(M, N, 16000, delays)
     Rd = eng.mvdr_diffuse_model(mpos, M, 16000, device=dev)
     eng.mvdr_diagonal_loading(Rd, 0.01)
+    # The design follows the reference's pseudoinverse() rule (svd_rule "linpack", the default): on this model LINPACK's float32
+    # csvdc returns INFO != 0 on 752 of the 1024 bins at this 10 mm pitch (tests/golden/c5_csvdc_info.npz, produced by the
+    # reference's own compiled routine) and calc_mvdr_weights then uses the identity there, i.e. delay-and-sum
+    # (beamformer.cc:253-260, 2379-2396).  EVERY sampled bin is compared with the oracle, whose pseudoinverse() runs that csvdc.
     W, nfb = eng.mvdr_weights(Rd, torch.from_numpy(wq[:K].astype(np.complex64)).to(dev))
-    assert nfb == 0
+    info_fixture = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "c5_csvdc_info.npz"))["info"][1]
+    assert abs(nfb - int(np.sum(info_fixture[1:] != 0))) <= 5        # (the device builds R itself: a last-bit difference may move a bin)
     Wh = W.cpu().numpy()
+    We = eng.mvdr_weights(Rd, torch.from_numpy(wq[:K].astype(np.complex64)).to(dev), svd_rule="exact")[0].cpu().numpy()
     Rref = orc.diagonal_loading(orc.diffuse_noise_model(mpos, M, 16000), M, 0.01)
-    for k in (1, 100, 1024):
+    nident = 0
+    for k in (1, 100, 192, 193, 300, 600, 1024):
         z = np.linalg.solve(Rref[k], wq[k])
         exact = z / (N * np.vdot(wq[k], z))
-        # ill-conditioned at low bins (coherence ~ 1): the reference's own float32 SVD is no better than this
-        assert np.linalg.norm(Wh[k] - exact) <= 2e-2 * np.linalg.norm(exact)
+        # "exact" solves every bin; ill-conditioned at low bins (coherence ~ 1): the reference's float32 SVD is no better than this
+        assert np.linalg.norm(We[k] - exact) <= 2e-2 * np.linalg.norm(exact)
         inv, ok, info = orc.pseudoinverse(Rref[k], return_info=True)   # the oracle's pinned path: the reference's compiled csvdc
-        if info != 0:
-            # Reference quirk: LINPACK's float32 QR iteration does not converge on this 256 x 256 matrix (253 of
-            # its singular values sit within 1e-7 of the 0.01 loading at the Nyquist bin); pseudoinverse() then reports
-            # failure and calc_mvdr_weights silently substitutes the identity, i.e. delay-and-sum.  The engine solves the
-            # system; it is compared with the exact solution above and NOT made to reproduce that failure.
-            assert k == 1024
-            continue
-        assert ok
-        tH = inv.conj().T @ wq[k]
+        assert info == info_fixture[k] and ok == (info == 0)
+        tH = (inv if ok else np.eye(N)).conj().T @ wq[k]               # ret == false -> identity (beamformer.cc:2381-2383)
         ref = tH / (N * np.vdot(tH, wq[k]))
-        assert np.linalg.norm(Wh[k] - ref) <= 2e-2 * np.linalg.norm(ref)
+        nident += not ok
+        assert np.linalg.norm(Wh[k] - ref) <= (2e-2 if ok else 1e-6) * np.linalg.norm(ref), k
         assert abs(np.vdot(Wh[k], wq[k]) - 1.0 / N) < 1e-3 / N + 1e-6
+    assert nident >= 3
     rng = np.random.default_rng(5)
     Xe = ((rng.normal(size=(S, K, N, T)) + 1j * rng.normal(size=(S, K, N, T))) * 1000).astype(np.complex64)
     Xd = torch.from_numpy(Xe).to(dev)
@@ -110,7 +112,6 @@ def test_c5_superdirective_256mic_2048bins_bin_sharded(orc, dev):
     for rk in range(8):
         a, b = sharding.bin_range_for_rank(K, rk, 8)
         Ws, nf = eng.mvdr_weights(Rd[a:b].contiguous(), torch.from_numpy(wq[a:b].astype(np.complex64)).to(dev), first_bin=a)
-        assert nf == 0
         shards.append(Ws)
     assert torch.equal(torch.cat(shards), W)
     g = design_prototype(M, 4, "g")

@@ -1,0 +1,218 @@
+"""GPU parity of the reference's `csvdc INFO != 0 / sigma < threshold -> identity` rule (SURVEY 8(a) row a12,
+beamformer/beamformer.cc:232-289, 2379-2396; matrix/linpack_c.cc:9516): btk_csvdc_values bit for bit against the reference's
+compiled csvdc, the whole C5 model against tests/golden/c5_csvdc_info.npz, and the designs that use the rule against the oracle."""
+import os
+import time
+import zlib
+
+import numpy as np
+import pytest
+
+from tests import linpack_host as lh
+from tests.util import la_delays, ula_positions
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "c5_csvdc_info.npz")
+
+
+def _bits(x):
+    return np.ascontiguousarray(x, np.float32).view(np.uint32)
+
+
+def test_csvdc_values_bit_exact_small_and_nonsquare(orc, dev):
+    """LDS-resident and scratch-resident matrices, tall / wide / rank deficient / zero columns: s, e, INFO of every matrix equal
+    the reference's compiled csvdc (oracle/_ref) to the last bit (the serial g++ build of the same body stands in if absent)."""
+    import torch
+    from distant_speech_recognition_amd import engine as eng
+    mats = lh.test_matrices()
+    by_shape = {}
+    for A in mats:
+        by_shape.setdefault(A.shape, []).append(A)
+    for shape, group in by_shape.items():
+        s, e, info = eng.csvdc_values(torch.from_numpy(np.stack(group)).to(dev))
+        s, e, info = s.cpu().numpy(), e.cpu().numpy(), info.cpu().numpy()
+        for i, A in enumerate(group):
+            sr, er, ir = lh.ref_csvdc(orc, A) if orc.ref_lib() is not None else lh.csvdc_values(A)
+            assert int(info[i]) == ir, (shape, i, int(info[i]), ir)
+            assert np.array_equal(_bits(s[i]), _bits(sr)) and np.array_equal(_bits(e[i]), _bits(er)), (shape, i)
+
+
+@pytest.mark.parametrize("g", [0, 1])
+def test_c5_info_vector_all_bins(orc, dev, g):
+    """All 1024 designed bins of BASELINE config C5 (256 microphones, 2048 sub-bands, loading 1e-2): INFO and the singular
+    values from the GPU equal the fixture the reference's compiled csvdc produced -- 100 % of the bins, bit for bit, on the
+    oracle's float64 model rounded to float32 like pseudoinverse() does (beamformer.cc:247-251); on the model the device builds
+    itself (btk_mvdr_diffuse_model, float64 sinc rounded once) the agreement is reported and must be >= 99.5 %."""
+    import torch
+    from distant_speech_recognition_amd import engine as eng
+    z = np.load(GOLDEN)
+    N, M = 256, 2048
+    K = M // 2 + 1
+    pitch = float(z["pitch_mm"][g])
+    mpos = ula_positions(N, pitch)
+    Rref = orc.diagonal_loading(orc.diffuse_noise_model(mpos, M, 16000), M, 0.01).astype(np.complex64)
+    Rd = torch.from_numpy(Rref).to(dev)
+    eng.csvdc_values(Rd[:8].contiguous())                       # warm-up (module load)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    s, e, info = eng.csvdc_values(Rd)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    info = info.cpu().numpy()
+    s = s.cpu().numpy()
+    want = z["info"][g]
+    agree = int(np.sum(info[1:] == want[1:]))
+    crc_ok = sum(zlib.crc32(np.ascontiguousarray(s[k, :N]).tobytes()) == int(z["s_crc"][g, k]) for k in range(1, K))
+    print("\nC5 %g mm: csvdc on 1025 bins of 256 x 256 in %.1f ms; INFO agreement %d / %d, singular values bit-identical on %d / %d; "
+          "INFO != 0 on %d bins" % (pitch, dt * 1e3, agree, K - 1, crc_ok, K - 1, int(np.sum(info[1:] != 0))))
+    assert agree == K - 1 and crc_ok == K - 1
+    for j in range(1, (K + 15) // 16):
+        assert np.array_equal(_bits(s[16 * j, :N]), _bits(z["s_sub"][g, j]))
+    # the device-built model
+    Rdev = eng.mvdr_diffuse_model(mpos, M, 16000, device=dev)
+    eng.mvdr_diagonal_loading(Rdev, 0.01)
+    same_input = float(torch.mean((Rdev.view(torch.float32).view(torch.int32) == Rd.view(torch.float32).view(torch.int32)).float()))
+    _, _, info2 = eng.csvdc_values(Rdev)
+    agree2 = int(np.sum(info2.cpu().numpy()[1:] == want[1:]))
+    print("device-built model: %.6f of the float32 words equal the oracle's; INFO agreement %d / %d" % (same_input, agree2, K - 1))
+    assert agree2 >= 0.995 * (K - 1)
+
+
+def test_c5_weights_follow_the_reference_rule(orc, dev):
+    """calc_mvdr_weights on C5 with svd_rule = "linpack" (the default): every sampled bin -- converging or not -- against
+    orc.mvdr_weights, whose pseudoinverse() is the reference's compiled csvdc: the identity (delay-and-sum, w = d / (N d^H d))
+    exactly where INFO != 0, the inverse elsewhere.  "exact" instead solves those bins; the distance is printed."""
+    import torch
+    from distant_speech_recognition_amd import engine as eng
+    z = np.load(GOLDEN)
+    N, M = 256, 2048
+    K = M // 2 + 1
+    mpos = ula_positions(N, 20.0)
+    wq = orc.calc_mainlobe(M, N, 16000, la_delays(mpos, 0.8))
+    Rref = orc.diagonal_loading(orc.diffuse_noise_model(mpos, M, 16000), M, 0.01)
+    Rd = torch.from_numpy(Rref.astype(np.complex64)).to(dev)
+    wqd = torch.from_numpy(wq[:K].astype(np.complex64)).to(dev)
+    W, nident = eng.mvdr_weights(Rd, wqd)                        # default rule
+    assert eng.svd_rule_default() == "linpack"
+    c_info, c_thr, c_fb = eng.mvdr_weights.last_counts
+    assert c_info == int(np.sum(z["info"][0, 1:] != 0)) == 505 and c_thr == 0 and c_fb == 0 and nident == 505
+    We, nie = eng.mvdr_weights(Rd, wqd, svd_rule="exact")
+    assert nie == 0
+    Wh, Weh = W.cpu().numpy(), We.cpu().numpy()
+    assert np.allclose(Wh[0], 1.0)
+    bins = sorted(set(list(range(1, K, 37)) + [108, 109, 110, 160, 161, 641, 769, 770, 1024]))
+    sub = np.zeros((len(bins) + 1, N, N), np.complex128)
+    sub[1:] = Rref[bins]
+    wsub = np.zeros((2 * len(bins), N), np.complex128)           # orc.mvdr_weights wants wq [M'][N] with M' / 2 + 1 bins
+    wsub[1:len(bins) + 1] = wq[bins]
+    ref = orc.mvdr_weights(sub, wsub, 2 * len(bins))
+    nid = 0
+    dist = []
+    for j, k in enumerate(bins):
+        r = ref[j + 1]
+        if z["info"][0, k] != 0:
+            nid += 1
+            ident = wq[k] / (N * np.vdot(wq[k], wq[k]))
+            assert np.linalg.norm(r - ident) <= 1e-12 * np.linalg.norm(ident)          # the oracle took the identity branch
+            assert np.linalg.norm(Wh[k] - r) <= 1e-6 * np.linalg.norm(r), k
+            dist.append(np.linalg.norm(Weh[k] - r) / np.linalg.norm(r))
+        else:
+            # float32 SVD inverse of a matrix with condition number up to 2.5e4 (the reference's own accuracy)
+            assert np.linalg.norm(Wh[k] - r) <= 2e-2 * np.linalg.norm(r), k
+            assert np.array_equal(Wh[k], Weh[k])
+    assert nid >= 8
+    print("\nC5 sampled bins: %d of %d take the identity; || w_exact - w_reference || / || w_reference || on them: median %.3g, max %.3g"
+          % (nid, len(bins), float(np.median(dist)), float(np.max(dist))))
+
+
+def test_rule_on_small_arrays_and_threshold(orc, dev):
+    """N = 8 / 64: well-conditioned bins keep the solved weights; a bin with a singular value under the threshold and a bin
+    csvdc converges on both follow orc.mvdr_weights; the stacked-stream form leaves every stream's bin 0 alone."""
+    import torch
+    from distant_speech_recognition_amd import engine as eng
+    rng = np.random.default_rng(3)
+    for N, K in ((8, 9), (64, 5)):
+        M = 2 * (K - 1)
+        R = np.zeros((K, N, N), np.complex128)
+        for k in range(K):
+            B = rng.normal(size=(N, N + 4)) + 1j * rng.normal(size=(N, N + 4))
+            R[k] = B @ B.conj().T / N + 0.01 * np.eye(N)
+        u = rng.normal(size=(N, 2)) + 1j * rng.normal(size=(N, 2))
+        R[2] = u @ u.conj().T                                    # rank 2: singular values under any sensible threshold
+        wq = np.zeros((M, N), np.complex128)
+        wq[:K] = np.exp(1j * rng.uniform(0, 6.28, size=(K, N)))
+        thr = 1e-4
+        W, nident = eng.mvdr_weights(torch.from_numpy(R.astype(np.complex64)).to(dev), torch.from_numpy(wq[:K].astype(np.complex64)).to(dev), thr)
+        ref = orc.mvdr_weights(R, wq, M, thr)
+        Wh = W.cpu().numpy()
+        assert nident == 1 and eng.mvdr_weights.last_counts[1] + eng.mvdr_weights.last_counts[2] == 1
+        for k in range(K):
+            assert np.linalg.norm(Wh[k] - ref[k]) <= 2e-3 * np.linalg.norm(ref[k]), (N, k)
+        Rs = torch.from_numpy(np.stack([R, R]).astype(np.complex64)).to(dev)
+        ws = torch.from_numpy(np.stack([wq[:K], wq[:K]]).astype(np.complex64)).to(dev)
+        W2, nid2 = eng.mvdr_weights(Rs, ws, thr)
+        assert nid2 == 2 and torch.equal(W2[0], W) and torch.equal(W2[1], W)
+
+
+def test_cpp_node_and_lefkimmiatis_lambda_use_the_rule(orc, dev):
+    """SubbandMVDR (C++ node, pybind) reports the bins whose csvdc did not converge and lets the rule be switched; the
+    Lefkimmiatis Lambda takes d^H d on those bins (postfilter.cc:967-995)."""
+    import torch
+    from distant_speech_recognition_amd import btk20, engine as eng
+    z = np.load(GOLDEN)
+    N, M = 256, 2048
+    K = M // 2 + 1
+    mpos = ula_positions(N, 20.0)
+    delays = la_delays(mpos, 0.8)
+    bf = btk20.SubbandMVDRPtr(fftlen=M, half_band_shift=False)
+    src = btk20.PyVectorComplexFeatureStreamPtr(_ZeroSource(M))      # the design never pulls a frame
+    for c in range(N):
+        bf.set_channel(src)
+    bf.calc_array_manifold_vectors(16000.0, delays)
+    bf.set_diffuse_noise_model(mpos, 16000.0, 343740.0)
+    bf.set_all_diagonal_loading(0.01)
+    assert bf.svd_rule() == "linpack"
+    bf.calc_mvdr_weights(16000.0, 1.0e-8, True)
+    nbad = int(np.sum(z["info"][0, 1:] != 0))
+    assert abs(bf.csvdc_not_converged() - nbad) <= 5 and bf.identity_fallbacks() == bf.csvdc_not_converged()   # (device-built model)
+    wq = orc.calc_mainlobe(M, N, 16000, delays)
+    k = 400
+    assert z["info"][0, k] != 0
+    ident = wq[k] / (N * np.vdot(wq[k], wq[k]))
+    assert np.linalg.norm(np.asarray(bf.mvdr_weights(k)) - ident) <= 1e-6 * np.linalg.norm(ident)
+    bf.set_svd_rule("exact")
+    bf.calc_mvdr_weights(16000.0, 1.0e-8, True)
+    assert bf.csvdc_not_converged() == 0 and bf.identity_fallbacks() == 0
+    zk = np.linalg.solve(orc.diagonal_loading(orc.diffuse_noise_model(mpos, M, 16000)[k:k + 1], 0, 0.01)[0], wq[k])
+    exact = zk / (N * np.vdot(wq[k], zk))
+    assert np.linalg.norm(np.asarray(bf.mvdr_weights(k)) - exact) <= 2e-2 * np.linalg.norm(exact)
+    with pytest.raises(Exception):
+        bf.set_svd_rule("lapack")
+    # Lambda of the Lefkimmiatis filter
+    pf = eng.CoherencePostFilterState(1, K, N, dev, lefkimmiatis=True)
+    Rd = eng.mvdr_diffuse_model(mpos, M, 16000, device=dev)
+    eng.mvdr_diagonal_loading(Rd, 0.01)
+    d = torch.from_numpy(wq[:K].astype(np.complex64)).to(dev)
+    nid = pf.set_lambda(Rd, d)
+    assert abs(nid - nbad) <= 6                                  # bin 0 is decomposed as well
+    lam = pf.lam.cpu().numpy()
+    assert abs(lam[k] - np.vdot(wq[k], wq[k])) <= 1e-5 * N
+
+
+class _ZeroSource:
+    def __init__(self, M):
+        self._M = M
+
+    def size(self):
+        return self._M
+
+    def __iter__(self):
+        return self
+
+    def next(self):
+        raise StopIteration
+
+    __next__ = next
+
+    def reset(self):
+        pass

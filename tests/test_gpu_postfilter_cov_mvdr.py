@@ -131,39 +131,42 @@ def test_mvdr_weights_match_oracle(orc, dev, N, M):
     assert np.max(np.abs(Rd.cpu().numpy() - Rref)) < 2e-6
     eng.mvdr_diagonal_loading(Rd, mu)
     Rref = orc.diagonal_loading(Rref, M, mu)
-    W, nfb = eng.mvdr_weights(Rd, torch.from_numpy(wq[:K].astype(np.complex64)).to(dev))
-    W = W.cpu().numpy()
-    assert nfb == 0
-    assert np.allclose(W[0], 1.0)
+    wqd = torch.from_numpy(wq[:K].astype(np.complex64)).to(dev)
+    W, nfb = eng.mvdr_weights(Rd, wqd)                              # default rule "linpack": the reference's pseudoinverse() decision
+    We, nfe = eng.mvdr_weights(Rd, wqd, svd_rule="exact")           # every positive definite bin solved
+    W, We = W.cpu().numpy(), We.cpu().numpy()
+    assert nfe == 0
+    assert np.allclose(W[0], 1.0) and np.allclose(We[0], 1.0)
     inv = np.linalg.inv(Rref[1:])
     nonconv = 0
     for k in range(1, K):
         z = inv[k - 1].conj().T @ wq[k]
         exact = z / (N * np.vdot(z, wq[k]))
         # stated tolerance: MVDR weights <= 1e-3 relative (the reference itself uses a float32 SVD)
-        assert np.linalg.norm(W[k] - exact) <= 1e-3 * np.linalg.norm(exact)
-        if N <= 16 or k in (1, 2, K // 2, K - 1):
-            # the oracle's pinned path: pseudoinverse() through the reference's own compiled csvdc (oracle/_ref)
-            ref = _oracle_mvdr_bin(orc, Rref[k], wq[k])
-            if ref is None:                                          # csvdc INFO != 0: the reference itself substitutes the identity here
-                nonconv += 1
-                continue
-            assert np.linalg.norm(W[k] - ref) <= 3e-3 * np.linalg.norm(ref)
+        assert np.linalg.norm(We[k] - exact) <= 1e-3 * np.linalg.norm(exact)
+        # the oracle's pinned path: pseudoinverse() through the reference's own compiled csvdc (oracle/_ref); where it returns
+        # INFO != 0 the reference substitutes the identity and so does the default rule -- no bin is stepped around
+        ref, info = _oracle_mvdr_bin(orc, Rref[k], wq[k], with_info=True)
+        nonconv += info != 0
+        assert np.linalg.norm(W[k] - ref) <= (3e-3 if info == 0 else 1e-6) * np.linalg.norm(ref), (k, info)
+        if info == 0:
+            assert np.array_equal(W[k], We[k])
         # distortionless known answer: w^H d = 1/N
         assert abs(np.vdot(W[k], wq[k]) - 1.0 / N) < 1e-3 / N + 1e-5
+    assert nfb == nonconv
     assert N > 64 or nonconv == 0        # LINPACK's float32 SVD only gives up on the large, highly degenerate diffuse matrices
 
 
-def _oracle_mvdr_bin(orc, Rk, d, threshold=1.0e-8):
-    """calc_mvdr_weights for one bin, literally (beamformer.cc:2372-2397), on the oracle's pseudoinverse()"""
+def _oracle_mvdr_bin(orc, Rk, d, threshold=1.0e-8, with_info=False):
+    """calc_mvdr_weights for one bin, literally (beamformer.cc:2372-2397), on the oracle's pseudoinverse(): the identity replaces
+    the inverse whenever it returns false -- a singular value under the threshold or csvdc INFO != 0 (:253-270, 2381-2383)"""
     N = d.shape[0]
     inv, ok, info = orc.pseudoinverse(Rk, threshold, return_info=True)
-    if info != 0:
-        return None          # LINPACK's float32 QR iteration did not converge (a reference failure the engine does not reproduce)
     if not ok:
         inv = np.eye(N, dtype=np.complex128)
     t = inv.conj().T @ d
-    return t / (np.vdot(t, d) * N)
+    w = t / (np.vdot(t, d) * N)
+    return (w, info) if with_info else w
 
 
 @pytest.mark.parametrize("N", [4, 64])
@@ -257,8 +260,8 @@ def test_mvdr_pinv_gpu_all_bins_rank_deficient_n64(orc, dev):
     for k in (7, 9):
         assert np.allclose(Wg[k], d[k] / (N * np.vdot(d[k], d[k])), atol=1e-6)       # invR = I
     for k in (1, 2, 256, 512):
-        ref = _oracle_mvdr_bin(orc, R[k].astype(np.complex128), d[k].astype(np.complex128))
-        if ref is not None:
+        ref, info = _oracle_mvdr_bin(orc, R[k].astype(np.complex128), d[k].astype(np.complex128), with_info=True)
+        if info == 0:                 # (this entry is the pseudo-inverse solve itself; the INFO != 0 rule is btk_mvdr_linpack_rule's)
             cond = np.linalg.cond(R[k].astype(np.complex128))
             assert np.linalg.norm(Wg[k] - ref) <= (2e-6 * cond + 1e-5) * np.linalg.norm(ref), (k, cond)
     # and through the product entry: the Cholesky kernel takes what it can, the rest goes to the GPU fall-back
@@ -501,14 +504,16 @@ def test_lefkimmiatis_matches_oracle(orc, dev, N, M, T, type_, minf, x1):
     st = eng.CoherencePostFilterState(S, K, N, dev, lefkimmiatis=True)
     st.set_coherence(R, 0.99)
     Dd = torch.from_numpy(d).to(dev)
-    assert st.set_lambda(R, Dd, 1.0e-4) == 0
+    Ro = orc.diagonal_loading(orc.diffuse_noise_model(mpos, M, 16000.0), M, 0.1)
+    # bins whose pseudoinverse() returns false in the reference (csvdc INFO != 0 at N = 100): identity, Lambda = d^H d (:971-977)
+    nfalse = sum(not orc.pseudoinverse(Ro[k], 1.0e-4)[1] for k in range(K))
+    assert st.set_lambda(R, Dd, 1.0e-4) == nfalse and (N > 64 or nfalse == 0)
     Xd = torch.from_numpy(X).to(dev)
     Wd = torch.from_numpy(w).to(dev)
     T1 = T // 2
     kw = dict(fbin_x1=x1, alpha=0.8, type_=type_, min_frames=minf)
     Y = torch.cat([eng.bf_apply_lefkimmiatis(Wd, Dd, Xd[..., :T1].contiguous(), st, **kw),
                    eng.bf_apply_lefkimmiatis(Wd, Dd, Xd[..., T1:].contiguous(), st, **kw)], dim=-1).cpu().numpy()
-    Ro = orc.diagonal_loading(orc.diffuse_noise_model(mpos, M, 16000.0), M, 0.1)
     for s in range(S):
         Xo = _full(X[s], M)
         ref, Wref = orc.lefkimmiatis_frames(Xo, orc.gsc_frames(Xo, wq), wq, Ro, min_sv=1.0e-4, fbin_x1=x1, alpha=0.8,
