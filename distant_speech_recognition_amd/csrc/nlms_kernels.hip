@@ -72,9 +72,11 @@ void nlms_control_kernel(const float* __restrict__ energy, long T, NlmsParams p,
   const long sa = p.slowdown_after;
   // halvings applied before frame isamp0 are already in gamma0: multiples of sa in [1, isamp0 - 1]
   const long h0 = isamp0 > 0 ? (isamp0 - 1) / sa : 0;
-  for (long t0 = 0; t0 < T; t0 += 64) {
+  // scan chunks on multiples of 64 of the stream's sample counter (not of this launch): a stream processed block by block (blocks
+  // ending on multiples of 64) and in one launch round alike, also when a recursion restarts mid-stream
+  for (long t0 = -(isamp0 & 63); t0 < T; t0 += 64) {
     const long t = t0 + lane;
-    const bool ok = t < T;
+    const bool ok = t >= 0 && t < T;
     const double en = ok ? (double)e[t] : 0.0;
     double a = ok ? beta : 1.0, b = ok ? omb * en : 0.0;
 #pragma unroll

@@ -116,12 +116,17 @@ void zelinski_iir_kernel(float2* __restrict__ Y, const float2* __restrict__ Cc, 
   // the statistics (and the beamformer output the gain scales) of chunk i + 1 are requested before chunk i is scanned: the
   // 24 dependent cross-lane steps of a scan and the latency of a chunk's loads no longer add up
   const bool scales = type != 0;
-  float2 cn = (lane < T) ? Cc[row * T_stride + lane] : make_float2(0.f, 0.f);
-  float en = (lane < T) ? Ee[row * T_stride + lane] : 0.f;
-  float2 yn = (scales && lane < T) ? Y[row * T_stride + lane] : make_float2(0.f, 0.f);
-  for (long t0 = 0; t0 < T; t0 += 64) {
+  // the 64-frame scan chunks sit on multiples of 64 of the STREAM's frame counter, not of this launch: a launch that starts
+  // inside a chunk (history restarted mid-stream by a weight change) scans the same chunks whether the stream is processed in
+  // one launch or block by block (the blocks of the node layer end on multiples of 64), hence the same roundings
+  const long ph = frame_base & 63;
+  const long tf = lane - ph;
+  float2 cn = (tf >= 0 && tf < T) ? Cc[row * T_stride + tf] : make_float2(0.f, 0.f);
+  float en = (tf >= 0 && tf < T) ? Ee[row * T_stride + tf] : 0.f;
+  float2 yn = (scales && tf >= 0 && tf < T) ? Y[row * T_stride + tf] : make_float2(0.f, 0.f);
+  for (long t0 = -ph; t0 < T; t0 += 64) {
     const long t = t0 + lane;
-    const bool ok = t < T;
+    const bool ok = t >= 0 && t < T;
     const long g = frame_base + t;                              // global frame index; frame_no_ before increment = g-1
     float a = ok ? ((g >= 2) ? alpha : 0.f) : 1.f;              // identity element beyond the end
     const float bsc = (g >= 2 && alpha > 0.f) ? 1.f - alpha : 1.f;
@@ -130,7 +135,7 @@ void zelinski_iir_kernel(float2* __restrict__ Y, const float2* __restrict__ Cc, 
     const float e = en;
     {
       const long tn = t + 64;
-      const bool okn = tn < T;
+      const bool okn = tn >= 0 && tn < T;
       cn = okn ? Cc[row * T_stride + tn] : make_float2(0.f, 0.f);
       en = okn ? Ee[row * T_stride + tn] : 0.f;
       yn = (scales && okn) ? Y[row * T_stride + tn] : make_float2(0.f, 0.f);
@@ -525,9 +530,9 @@ void lefkimmiatis_iir_kernel(float2* __restrict__ Y, const float2* __restrict__ 
   float wlast = Wlast[row];
   float lam = 1.f;
   if (k >= fbinX1) { const float2 L = Lambda[k]; lam = (type & 1) ? L.x : sqrtf(L.x * L.x + L.y * L.y); }
-  for (long t0 = 0; t0 < T; t0 += 64) {
+  for (long t0 = -(frame_base & 63); t0 < T; t0 += 64) {       // chunks on multiples of 64 of the stream's frame counter (see zelinski_iir_kernel)
     const long t = t0 + lane;
-    const bool ok = t < T;
+    const bool ok = t >= 0 && t < T;
     const long g = frame_base + t;
     float a = ok ? ((g >= 2) ? alpha : 0.f) : 1.f;
     const float bsc = (g >= 2 && alpha > 0.f) ? 1.f - alpha : 1.f;

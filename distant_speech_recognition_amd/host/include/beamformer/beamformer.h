@@ -122,12 +122,27 @@ class SubbandBeamformer : public VectorComplexFeatureStream {
   SnapShotArrayPtr getSnapShotArray() { return snapshot_array(); }
   bool is_half_band_shift() const { return halfBandShift_; }
   bool isHalfBandShift() const { return halfBandShift_; }
-  // device hooks
-  void* device_snapshots();       // complex64 [1][K][N][T] on the device
+  // device hooks: the CURRENT BLOCK of snapshots (modulated/modulated.h, BlockSource): frames chunk_base() .. chunk_base() + num_frames() - 1
+  void* device_snapshots();       // complex64 [1][K][N][T] on the device (the first block is loaded on demand)
   void* device_snapshots_all_bins() { device_snapshots(); return dXfull_; }   // halfBandShift over pulled sources: [1][M][N][T], else NULL
   long num_frames() { device_snapshots(); return T_; }
+  long chunk_base() { device_snapshots(); return chunk_base_; }
+  bool next_chunk();              // drop the current block and load the following one; false: the channels have ended
+  // frames per block for channels that are pulled through next(); analysis banks bring their own block_frames()
+  void set_block_frames(long n) { block_frames_ = n < 0 ? 0 : n; }
+  long block_frames() const { return block_frames_; }
+  // Blocks end at stream indices that are multiples of q (the last one excepted).  The recursions that run as parallel scans over
+  // 64-frame chunks (post-filter densities, the NLMS step-size control) round differently when a block boundary falls inside a
+  // chunk; the nodes that own such a recursion ask for q = 64 so that their output does not depend on the block size at all.
+  // A block then holds at least q frames; BTK_BLOCK_QUANTUM=1 in the environment trades that bit-equality for latency.
+  void set_block_quantum(long q);
+  long block_quantum() const { return quantum_; }
  protected:
+  bool load_chunk_();
   void free_device_();
+  long chunk_base_, block_frames_;
+  bool chunk_loaded_, channels_ended_;
+  long quantum_;
   bool halfBandShift_;
   void* dXfull_;
   typedef std::list<VectorComplexFeatureStreamPtr> ChannelList_;
@@ -166,10 +181,13 @@ class SubbandDS : public SubbandBeamformer, public BlockSource {
   // BlockSource (modulated/modulated.h): the whole beamformed utterance for a batching consumer, weight changes mid-stream
   virtual unsigned long block_version() { return weights_version_; }
   virtual const std::vector<float>& block(long& T);
+  virtual long block_base() { return chunk_base(); }
+  virtual bool next_block() { return advance_chunk_(); }
   virtual void advance_to(long frame_idx);
  protected:
   void alloc_bfweight_(int NC);
   void compute_output_(long from_frame);
+  virtual bool advance_chunk_();  // the next block of snapshots; what was computed for this one is dropped
   virtual const char* need_weights_msg_() const { return "call calc_array_manifold_vectorsX() once\n"; }
   BeamformerWeights* bfweight_;
   unsigned long weights_version_, output_version_;
@@ -210,7 +228,8 @@ class SubbandGSC : public SubbandDS {
 typedef Inherit<SubbandGSC, SubbandDSPtr> SubbandGSCPtr;
 
 // RLS sidelobe canceller (reference beamformer.h:207-263, beamformer.cc:1447-1699): the recursion of the whole
-// utterance runs in one btk_rls_process launch (mode 0); Pz_ and the active weights survive reset() as in the reference.
+// utterance runs block by block in btk_rls_process launches (mode 0), the state carried on the device; Pz_ and the active
+// weights survive reset() as in the reference.
 typedef enum { CONSTANT_NORM = 0x01, THRESHOLD_LIMITATION = 0x02, NO_QUADRATIC_CONSTRAINT = 0x00 } QuadraticConstraintType;
 
 class SubbandGSCRLS : public SubbandGSC {
@@ -219,7 +238,8 @@ class SubbandGSCRLS : public SubbandGSC {
                 const String& nm = "SubbandGSCRLS");
   ~SubbandGSCRLS();
   virtual const gsl_vector_complex* next(int frame_no = -5);
-  virtual const std::vector<float>& block(long& T);          // the adaptive recursion of the whole utterance (not the static apply)
+  virtual const std::vector<float>& block(long& T);          // the adaptive recursion over the current block (not the static apply)
+  virtual void reset() { SubbandGSC::reset(); block_ran_ = false; }
   void init_precision_matrix(float sigma2 = 0.01);
   void set_precision_matrix(unsigned fbinX, gsl_matrix_complex* Pz);
   void update_active_weight_vecotrs(bool flag) { is_wa_updated_ = flag; }   // sic (reference spelling)
@@ -230,14 +250,19 @@ class SubbandGSCRLS : public SubbandGSC {
   void setQuadraticConstraint(float alpha, int qctype = 1) { set_quadratic_constraint(alpha, qctype); }
  private:
   void alloc_state_();
+  void upload_weights_();
   void run_block_();
   void refresh_block_();
+  virtual bool advance_chunk_();
   float mu_, diagonal_weight_, alpha_;
   QuadraticConstraintType qctype_;
   unsigned long rls_version_;       // weights_version_ the cached block was computed with
   bool is_wa_updated_, have_P_;
   void *dP_, *dW_, *dV_, *dSS_;     // device: P complex128 [K][N][N], w complex128 [K][N], wq complex128 [K][N], stream state
   void* dCx_;                       // NC > 1: the further blocked directions, complex128 [K][NC-1][N] (btk_rls_*_nc)
+  void *dP0_, *dW0_, *dSS0_;        // the state at the start of the current block (a weight change before its first frame is served reruns it)
+  unsigned long uploaded_version_;  // weights_version_ dV_ / dCx_ were built from
+  bool block_ran_;
 };
 typedef Inherit<SubbandGSCRLS, SubbandGSCPtr> SubbandGSCRLSPtr;
 

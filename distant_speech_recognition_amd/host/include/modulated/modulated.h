@@ -5,21 +5,31 @@
 #include "stream/stream.h"
 #include <vector>
 
-// Virtual-pull protocol between the engine's nodes (not part of the reference's interface, which stays in stream/stream.h).  A
-// reference node hands over one frame per next(); an engine node computes the whole utterance in one launch.  To keep the
-// per-frame MEANING when weights change between two next() calls (the moving look direction of
+// Block protocol between the engine's nodes (not part of the reference's interface, which stays in stream/stream.h).  A
+// reference node hands over one frame per next(); an engine node computes a BLOCK of frames per launch: at most block_frames
+// frames (btk_default_block_frames(), set_block_frames() on the source nodes; 0 = the whole utterance in one block).  The
+// analysis banks pull at most that many input blocks per round and keep the m R blocks of sample history the next round's
+// first frame reaches back to; every node downstream works on the block its source currently holds and carries its recursion
+// state (post-filter densities, RLS precision matrix and weights, the synthesis bank's last m R + R - 1 frames) into the next.
+// A live source therefore yields its first output after one block, and memory stays bounded however long the stream runs.
+//
+// To keep the per-frame MEANING when weights change between two next() calls (the moving look direction of
 // unit_test/test_online_beamforming.py:209-226), a consumer that batches -- the synthesis bank -- asks a producer that
-// implements this interface for its whole block instead of draining it through next(), tells it after every block it serves how
-// far a per-frame graph would have pulled (advance_to), and re-fetches the block when block_version() changes: the producer
+// implements this interface for its current block instead of draining it through next(), tells it after every output it serves
+// how far a per-frame graph would have pulled (advance_to), and re-fetches the block when block_version() changes: the producer
 // recomputes only the frames beyond that mark with the new weights, everything already handed over keeps its value.
 class BlockSource {
  public:
   virtual ~BlockSource() {}
   virtual unsigned long block_version() = 0;                 // changes whenever the frames not yet handed over may have changed
   virtual const std::vector<float>& block(long& T) = 0;      // complex64 [>= K rows][T], row k = bin k, frames <= the mark unchanged
-  virtual void advance_to(long frame_idx) = 0;               // a per-frame graph would have pulled frames 0 .. frame_idx by now
+  virtual long block_base() { return 0; }                    // stream index of the block's first frame
+  virtual bool next_block() { return false; }                // move on to the following block; false: the stream has ended
+  virtual void advance_to(long frame_idx) = 0;               // a per-frame graph would have pulled frames 0 .. frame_idx (stream indices) by now
   virtual bool has_block() { return true; }                  // a wrapper around a foreign object (pyStream) may have no block to offer: drain next()
 };
+// frames per block: the environment variable BTK_BLOCK_FRAMES, 8192 when unset (0: unbounded, one block per utterance)
+long btk_default_block_frames();
 #include "btkhip.h"
 
 class OverSampledDFTAnalysisBank : public VectorComplexFeatureStream {
@@ -35,22 +45,33 @@ class OverSampledDFTAnalysisBank : public VectorComplexFeatureStream {
   unsigned fftLen() const { return fftlen(); }          // ENABLE_LEGACY_BTK_API aliases
   unsigned nBlocks() const { return m_; }
   unsigned subSampRate() const { return r_; }
-  // engine hooks used by the beamformer nodes to batch all channels into one launch
-  const std::vector<float>& pcm();                      // drains the upstream node once
+  // frames per round (see BlockSource above); takes effect at the next round
+  void set_block_frames(long n) { block_frames_ = n < 0 ? 0 : n; }
+  long block_frames() const { return block_frames_; }
+  // engine hooks used by the beamformer nodes to batch all channels into one launch: the bank as a sliding window of samples
+  bool pull_more();                                     // up to block_frames() more input blocks (all of them for 0); false: nothing came
+  bool at_end() const { return eos_; }                  // the upstream node has ended
+  long blocks_pulled() const { return nblk_; }
+  long frames_ready() const;                            // frames 0 .. frames_ready() - 1 can be computed from what was pulled
+  long window_first_block() const { return win_b0_; }
+  const float* window(long b0) const { return win_.data() + (size_t)(b0 - win_b0_) * D_; }   // samples of blocks b0 .. blocks_pulled() - 1
+  long first_block_of_frame(long t) const;              // oldest input block frame t reads (>= 0)
+  void release_before(long t);                          // frames < t are done: drop the samples only they needed
   const btk_fb_t* plan() const { return plan_; }
   unsigned delay_compensation_type() const { return dct_; }
   unsigned m() const { return m_; }
   unsigned r() const { return r_; }
  private:
-  void prepare_();
+  bool load_chunk_();
   VectorFloatFeatureStreamPtr samp_;
   unsigned M_, m_, r_, D_, dct_;
   btk_fb_t* plan_;
-  std::vector<float> pcm_;
-  bool drained_;
-  std::vector<double> frames_;                          // [T][2M]
-  long nframes_;
-  bool prepared_;
+  long block_frames_;
+  std::vector<float> win_;                              // samples of input blocks win_b0_ .. nblk_ - 1
+  long win_b0_, nblk_;
+  bool eos_;
+  std::vector<double> frames_;                          // the current block of frames, [chunk_len_][2M]
+  long chunk_base_, chunk_len_;
 };
 typedef Inherit<OverSampledDFTAnalysisBank, VectorComplexFeatureStreamPtr> OverSampledDFTAnalysisBankPtr;
 
@@ -70,20 +91,28 @@ class OverSampledDFTSynthesisBank : public VectorFloatFeatureStream {
   virtual void reset();
   void input_source_vector(const gsl_vector_complex* block);
   void no_stream_feature(bool flag = true) { no_stream_feature_ = flag; }
+  void set_block_frames(long n) { block_frames_ = n < 0 ? 0 : n; }     // rounds of a source that is drained through next()
+  long block_frames() const { return block_frames_; }
   void inputSourceVector(const gsl_vector_complex* block) { input_source_vector(block); }          // ENABLE_LEGACY_BTK_API aliases
   void doNotUseStreamFeature(bool flag = true) { no_stream_feature(flag); }
  private:
   void init_(gsl_vector* prototype, unsigned dct);
   const gsl_vector_float* next_pushed_();
   void prepare_();
-  void synthesize_(const std::vector<float>& Yk, long T, long keep_blocks);
+  void synthesize_(const std::vector<float>& Yk, long T, long base, bool last, long keep_blocks);
   VectorComplexFeatureStreamPtr samp_;
   unsigned M_, m_, r_, D_;
   int gain_;
   btk_fb_t* plan_;
-  std::vector<float> blocks_;                           // [B][D]
-  long nblocks_;
-  bool prepared_;
+  bool fetch_round_();
+  std::vector<float> blocks_;                           // output blocks blk_base_ .. blk_base_ + nblocks_ - 1, [nblocks_][D]
+  long nblocks_, blk_base_;
+  bool prepared_, src_ended_;
+  long block_frames_;                                   // frames per round when the source is drained through next()
+  std::vector<float> hist_;                             // the last <= m R + R - 1 input frames before the current round, [K][hist_len_]
+  long hist_len_, frames_in_;                           // frames_in_: input frames of the rounds before the current one
+  std::vector<float> cur_;                              // the current round's input frames [K][cur_T_] (drained sources)
+  long cur_T_;
   BlockSource* bsrc_;                                   // samp_ seen as a block source (NULL: drained through next())
   unsigned long src_version_;
   bool no_stream_feature_;

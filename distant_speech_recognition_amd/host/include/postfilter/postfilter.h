@@ -29,9 +29,13 @@ class ZelinskiPostFilter : public VectorComplexFeatureStream, public BlockSource
   // BlockSource: see modulated/modulated.h
   virtual unsigned long block_version() { return has_bf_ptr_ ? bf_ptr_->weights_version() : 0; }
   virtual const std::vector<float>& block(long& T);
+  virtual long block_base();
+  virtual bool next_block();
   virtual void advance_to(long frame_idx);
  protected:
   virtual void compute_(long from_frame);
+  bool advance_chunk_();                    // the beamformer's next block of snapshots; the recursions continue from this one's end
+  void csd_state_(long t, std::vector<float>& R);
   void merge_output_(std::vector<float>& Ynew, long from_frame);
   const gsl_vector_complex* next_manual_(int frame_no);
   // the reference keeps the N x N spectral densities of every bin in BeamformerWeights::CSDs(); this engine keeps only their
@@ -53,11 +57,14 @@ class ZelinskiPostFilter : public VectorComplexFeatureStream, public BlockSource
   unsigned long bf_version_;
   void *dPhi_, *dPsi_, *dWl_;
   gsl_vector_complex* wp1_;
-  long hist_start_;                         // frame at which the density history last restarted (weights recomputed)
+  long hist_start_;                         // stream index of the frame at which the density history last restarted (weights recomputed)
   SnapShotArrayPtr snapshot_array_;         // manual mode: multi-channel input kept current by the caller
   BeamformerWeights* own_weights_;          // manual mode: created by set_array_manifold_vector
-  std::vector<float> Xhist_;                // manual mode: the snapshots seen so far, complex64 [T][K][N] (for CSDs())
+  std::vector<std::complex<double> > csd_manual_;   // manual mode: the recursively averaged x x^H behind CSDs(), [K][N][N] (upper triangle)
   long manual_frames_;
+  long base_;                               // stream index of the current block's first frame
+  bool carry_state_;                        // the next compute_() continues the recursions (a new block of the same stream)
+  std::vector<float> csd_carry_;            // CSD state after the block before, complex64 [K][N][N] (for CSDs())
   long handed_;                             // block protocol mark (see SubbandDS::advance_to)
 };
 typedef Inherit<ZelinskiPostFilter, VectorComplexFeatureStreamPtr> ZelinskiPostFilterPtr;

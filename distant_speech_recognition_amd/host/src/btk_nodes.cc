@@ -71,20 +71,6 @@ void serve_frame_all_bins(const std::vector<float>& Y, long T, unsigned M, long 
   for (unsigned k = 0; k < M; k++) { out->data[2 * k] = Y[2 * ((size_t)k * T + t)]; out->data[2 * k + 1] = Y[2 * ((size_t)k * T + t) + 1]; }
 }
 
-// drain a complex node keeping all M bins: frames [T][M] complex64 (halfBandShift over sources that are not analysis banks)
-long drain_complex_all_bins(VectorComplexFeatureStreamPtr& src, unsigned M, std::vector<float>& frames)
-{
-  long T = 0;
-  for (;;) {
-    const gsl_vector_complex* v;
-    try { v = src->next(); } catch (jiterator_error&) { break; }
-    frames.resize((size_t)(T + 1) * M * 2);
-    for (unsigned k = 0; k < 2 * M; k++) frames[2 * (size_t)T * M + k] = (float)v->data[k];
-    T++;
-  }
-  return T;
-}
-
 // drain a complex node: frames [T][K] complex64 (bins 0..M/2)
 long drain_complex(VectorComplexFeatureStreamPtr& src, unsigned M, std::vector<float>& frames)
 {
@@ -350,10 +336,18 @@ const gsl_vector_float* SampleFeature::next(int frame_no)
 }
 
 // ================================================================================ analysis bank
+long btk_default_block_frames()
+{
+  const char* e = getenv("BTK_BLOCK_FRAMES");
+  if (!e || !*e) return 8192;
+  const long v = atol(e);
+  return v < 0 ? 0 : v;
+}
+
 OverSampledDFTAnalysisBank::OverSampledDFTAnalysisBank(VectorFloatFeatureStreamPtr& samp, gsl_vector* prototype, unsigned M,
                                                        unsigned m, unsigned r, unsigned delayCompensationType, const String& nm)
     : VectorComplexFeatureStream(M, nm), samp_(samp), M_(M), m_(m), r_(r), D_(M >> r), dct_(delayCompensationType),
-      plan_(NULL), drained_(false), nframes_(0), prepared_(false)
+      plan_(NULL), block_frames_(btk_default_block_frames()), win_b0_(0), nblk_(0), eos_(false), chunk_base_(0), chunk_len_(0)
 {
   if (prototype->size != (size_t)M * m)
     throw jconsistency_error("Prototype sizes do not match (%d vs. %d).", (int)prototype->size, (int)(M * m));
@@ -365,50 +359,80 @@ OverSampledDFTAnalysisBank::OverSampledDFTAnalysisBank(VectorFloatFeatureStreamP
 
 OverSampledDFTAnalysisBank::~OverSampledDFTAnalysisBank() { btk_fb_destroy(plan_); }
 
-const std::vector<float>& OverSampledDFTAnalysisBank::pcm()
+// one round of input: at most block_frames() blocks of D samples from the upstream node (modulated.cc:419-438 pulls one per frame)
+bool OverSampledDFTAnalysisBank::pull_more()
 {
-  if (!drained_) {
-    pcm_.clear();
-    for (;;) {
-      const gsl_vector_float* b;
-      try { b = samp_->next(); } catch (jiterator_error&) { break; }
-      pcm_.insert(pcm_.end(), b->data, b->data + b->size);
-    }
-    drained_ = true;
+  if (eos_) return false;
+  long got = 0;
+  while (block_frames_ == 0 || got < block_frames_) {
+    const gsl_vector_float* b;
+    try { b = samp_->next(); } catch (jiterator_error&) { eos_ = true; break; }
+    win_.insert(win_.end(), b->data, b->data + b->size);
+    nblk_++; got++;
   }
-  return pcm_;
+  return got > 0;
 }
 
-void OverSampledDFTAnalysisBank::prepare_()
+// frame t reads the samples (t + laN + 1 - m R) D .. (t + laN + 1) D - 1 (csrc/fb_kernels.hip: closed form of the ring of
+// modulated.cc:375-409); once the source has ended the remaining pd frames read zeros beyond it (btk_fb_analysis_num_frames)
+long OverSampledDFTAnalysisBank::frames_ready() const
 {
-  const std::vector<float>& x = pcm();
-  const long L = (long)x.size();
-  nframes_ = btk_fb_analysis_num_frames(plan_, L);
-  const unsigned K = M_ / 2 + 1;
-  void* dp = dev_alloc(sizeof(float) * (L ? L : 1));
-  void* dX = dev_alloc(sizeof(float) * 2 * K * (nframes_ ? nframes_ : 1));
-  if (L) h2d(dp, x.data(), sizeof(float) * L);
-  check_abi(btk_fb_analysis(plan_, (const float*)dp, L, L ? L : 1, 1, 1, dX, nframes_, 0, nframes_, NULL));
-  check_abi(btk_synchronize(NULL));
-  std::vector<float> Xh((size_t)2 * K * nframes_);
-  if (nframes_) d2h(Xh.data(), dX, sizeof(float) * Xh.size());
-  dev_free(dp); dev_free(dX);
-  frames_.assign((size_t)nframes_ * 2 * M_, 0.0);
-  gsl_vector_complex tmp; tmp.size = M_; tmp.stride = 1;
-  for (long t = 0; t < nframes_; t++) {
-    tmp.data = frames_.data() + (size_t)t * 2 * M_;
-    serve_frame(Xh, nframes_, M_, t, &tmp);
+  const long laN = btk_fb_lookahead(plan_), pd = btk_fb_processing_delay(plan_);
+  if (eos_) return nblk_ < laN ? 0 : nblk_ - laN + pd;
+  return nblk_ > laN ? nblk_ - laN : 0;
+}
+
+long OverSampledDFTAnalysisBank::first_block_of_frame(long t) const
+{
+  const long b = t + btk_fb_lookahead(plan_) + 1 - (long)m_ * (1L << r_);
+  return b < 0 ? 0 : b;
+}
+
+void OverSampledDFTAnalysisBank::release_before(long t)
+{
+  const long keep = std::min(first_block_of_frame(t), nblk_);
+  if (keep > win_b0_) {
+    win_.erase(win_.begin(), win_.begin() + (size_t)(keep - win_b0_) * D_);
+    win_b0_ = keep;
   }
-  prepared_ = true;
+}
+
+// the next block of frames of a bank that is pulled frame by frame (a beamformer node batches its banks itself)
+bool OverSampledDFTAnalysisBank::load_chunk_()
+{
+  const long f0 = chunk_base_ + chunk_len_;
+  while (!eos_ && frames_ready() <= f0) pull_more();
+  const long f1 = frames_ready();
+  if (f1 <= f0) return false;
+  const unsigned K = M_ / 2 + 1;
+  const long b0 = std::max(first_block_of_frame(f0), win_b0_), L = (nblk_ - b0) * (long)D_, Tn = f1 - f0;
+  void* dp = dev_alloc(sizeof(float) * (L ? L : 1));
+  void* dX = dev_alloc(sizeof(float) * 2 * K * Tn);
+  if (L) h2d(dp, window(b0), sizeof(float) * L);
+  // the window starts at block b0: stream frame t is frame t - b0 of the window, and nothing it reads lies before the window
+  check_abi(btk_fb_analysis(plan_, (const float*)dp, L, L ? L : 1, 1, 1, dX, Tn, f0 - b0, Tn, NULL));
+  check_abi(btk_synchronize(NULL));
+  std::vector<float> Xh((size_t)2 * K * Tn);
+  d2h(Xh.data(), dX, sizeof(float) * Xh.size());
+  dev_free(dp); dev_free(dX);
+  frames_.assign((size_t)Tn * 2 * M_, 0.0);
+  gsl_vector_complex tmp; tmp.size = M_; tmp.stride = 1;
+  for (long t = 0; t < Tn; t++) {
+    tmp.data = frames_.data() + (size_t)t * 2 * M_;
+    serve_frame(Xh, Tn, M_, t, &tmp);
+  }
+  chunk_base_ = f0; chunk_len_ = Tn;
+  release_before(f1);
+  return true;
 }
 
 const gsl_vector_complex* OverSampledDFTAnalysisBank::next(int frame_no)
 {
   if (frame_no == frame_no_) return vector_;
-  if (!prepared_) prepare_();
   const long idx = frame_no_ + 1;
-  if (idx >= nframes_) { is_end_ = true; throw jiterator_error("end of samples!"); }
-  memcpy(vector_->data, frames_.data() + (size_t)idx * 2 * M_, sizeof(double) * 2 * M_);
+  while (idx >= chunk_base_ + chunk_len_)
+    if (!load_chunk_()) { is_end_ = true; throw jiterator_error("end of samples!"); }
+  memcpy(vector_->data, frames_.data() + (size_t)(idx - chunk_base_) * 2 * M_, sizeof(double) * 2 * M_);
   increment_();
   return vector_;
 }
@@ -417,7 +441,7 @@ void OverSampledDFTAnalysisBank::reset()
 {
   samp_->reset();
   VectorComplexFeatureStream::reset();
-  drained_ = false; prepared_ = false; pcm_.clear(); frames_.clear(); nframes_ = 0;
+  win_.clear(); win_b0_ = 0; nblk_ = 0; eos_ = false; frames_.clear(); chunk_base_ = 0; chunk_len_ = 0;
 }
 
 // ================================================================================ synthesis bank
@@ -425,7 +449,8 @@ OverSampledDFTSynthesisBank::OverSampledDFTSynthesisBank(VectorComplexFeatureStr
                                                          unsigned m, unsigned r, unsigned delayCompensationType, int gainFactor,
                                                          const String& nm)
     : VectorFloatFeatureStream(M >> r, nm), samp_(samp), M_(M), m_(m), r_(r), D_(M >> r), gain_(gainFactor), plan_(NULL),
-      nblocks_(0), prepared_(false), bsrc_(NULL), src_version_(0), no_stream_feature_(false), npushed_(0), npushed_at_next_(0),
+      nblocks_(0), blk_base_(0), prepared_(false), src_ended_(false), block_frames_(btk_default_block_frames()), hist_len_(0),
+      frames_in_(0), cur_T_(0), bsrc_(NULL), src_version_(0), no_stream_feature_(false), npushed_(0), npushed_at_next_(0),
       dWin_(NULL), dBlk_(NULL)
 {
   init_(prototype, delayCompensationType);
@@ -434,7 +459,8 @@ OverSampledDFTSynthesisBank::OverSampledDFTSynthesisBank(VectorComplexFeatureStr
 OverSampledDFTSynthesisBank::OverSampledDFTSynthesisBank(gsl_vector* prototype, unsigned M, unsigned m, unsigned r,
                                                          unsigned delayCompensationType, int gainFactor, const String& nm)
     : VectorFloatFeatureStream(M >> r, nm), samp_(NULL), M_(M), m_(m), r_(r), D_(M >> r), gain_(gainFactor), plan_(NULL),
-      nblocks_(0), prepared_(false), bsrc_(NULL), src_version_(0), no_stream_feature_(true), npushed_(0), npushed_at_next_(0),
+      nblocks_(0), blk_base_(0), prepared_(false), src_ended_(false), block_frames_(btk_default_block_frames()), hist_len_(0),
+      frames_in_(0), cur_T_(0), bsrc_(NULL), src_version_(0), no_stream_feature_(true), npushed_(0), npushed_at_next_(0),
       dWin_(NULL), dBlk_(NULL)
 {
   init_(prototype, delayCompensationType);
@@ -451,19 +477,32 @@ void OverSampledDFTSynthesisBank::init_(gsl_vector* prototype, unsigned delayCom
 
 OverSampledDFTSynthesisBank::~OverSampledDFTSynthesisBank() { btk_fb_destroy(plan_); dev_free(dWin_); dev_free(dBlk_); }
 
-// Yk complex64 [>= K rows][T] -> blocks_; the first keep_blocks blocks (already handed over) keep their values
-void OverSampledDFTSynthesisBank::synthesize_(const std::vector<float>& Yk, long T, long keep_blocks)
+// One round: Yk complex64 [>= K rows][T] are the input frames base .. base + T - 1 of the stream; the output blocks whose newest
+// input frame b + pd lies in this round are synthesised from them and from the frames kept of the rounds before (block b reads
+// the frames b + pd - (m R - 1) .. b + pd, csrc/fb_kernels.hip; frames before the stream read as zero == the zeroed ring of
+// modulated.cc:615-621).  The first keep_blocks blocks of the round (already handed over) keep their values.
+void OverSampledDFTSynthesisBank::synthesize_(const std::vector<float>& Yk, long T, long base, bool, long keep_blocks)
 {
   const unsigned K = M_ / 2 + 1;
+  const long pd = btk_fb_processing_delay(plan_);
   std::vector<float> old;
   if (keep_blocks > 0) old.assign(blocks_.begin(), blocks_.begin() + (size_t)std::min<long>(keep_blocks, nblocks_) * D_);
-  nblocks_ = btk_fb_synthesis_num_blocks(plan_, T);
+  const long b_first = std::max<long>(0, base - pd), b_end = base + T - pd;
+  blk_base_ = b_first;
+  nblocks_ = b_end > b_first ? b_end - b_first : 0;
   blocks_.assign((size_t)nblocks_ * D_, 0.f);
   if (nblocks_ > 0) {
-    void* dY = dev_alloc(sizeof(float) * 2 * K * T);
+    const long Lw = hist_len_ + T, w0 = base - hist_len_;
+    std::vector<float> win((size_t)2 * K * Lw);
+    for (unsigned k = 0; k < K; k++) {
+      if (hist_len_) memcpy(&win[2 * (size_t)k * Lw], &hist_[2 * (size_t)k * hist_len_], sizeof(float) * 2 * hist_len_);
+      memcpy(&win[2 * ((size_t)k * Lw + hist_len_)], &Yk[2 * (size_t)k * T], sizeof(float) * 2 * T);
+    }
+    void* dY = dev_alloc(sizeof(float) * win.size());
     void* dO = dev_alloc(sizeof(float) * blocks_.size());
-    h2d(dY, Yk.data(), sizeof(float) * 2 * K * T);
-    check_abi(btk_fb_synthesis(plan_, dY, T, T, 1, (float*)dO, nblocks_ * D_, 0, nblocks_, NULL));
+    h2d(dY, win.data(), sizeof(float) * win.size());
+    // the window starts at stream frame w0: block b of the stream is block b - w0 of the window
+    check_abi(btk_fb_synthesis(plan_, dY, Lw, Lw, 1, (float*)dO, nblocks_ * D_, b_first - w0, nblocks_, NULL));
     check_abi(btk_synchronize(NULL));
     d2h(blocks_.data(), dO, sizeof(float) * blocks_.size());
     dev_free(dY); dev_free(dO);
@@ -472,30 +511,73 @@ void OverSampledDFTSynthesisBank::synthesize_(const std::vector<float>& Yk, long
   if (!old.empty()) memcpy(blocks_.data(), old.data(), sizeof(float) * std::min(old.size(), blocks_.size()));
 }
 
+// the input frames of the current round: the block of an engine node upstream (it is not advanced through next()), or up to
+// block_frames() frames pulled from a plain stream
 void OverSampledDFTSynthesisBank::prepare_()
 {
   const unsigned K = M_ / 2 + 1;
-  bsrc_ = dynamic_cast<BlockSource*>(samp_.operator->());
-  if (bsrc_ && !bsrc_->has_block()) bsrc_ = NULL;
+  if (!prepared_) {
+    bsrc_ = dynamic_cast<BlockSource*>(samp_.operator->());
+    if (bsrc_ && !bsrc_->has_block()) bsrc_ = NULL;
+  }
   if (bsrc_) {
-    // an engine node upstream: take its whole block (it is not advanced), keep what was already served; next() tells it after
-    // every block how far a per-frame graph would have pulled, so that a later weight change touches only the frames beyond
+    // keep what was already served; next() tells the producer after every block how far a per-frame graph would have pulled, so
+    // that a later weight change touches only the frames beyond
     long T = 0;
     const std::vector<float>& Yk = bsrc_->block(T);
     src_version_ = bsrc_->block_version();
-    synthesize_(Yk, T, frame_no_ + 1);
+    frames_in_ = bsrc_->block_base();
+    cur_T_ = T;
+    synthesize_(Yk, T, frames_in_, false, prepared_ ? frame_no_ + 1 - blk_base_ : 0);
   } else {
     std::vector<float> fr;                       // [T][K]
-    const long T = drain_complex(samp_, M_, fr);
-    std::vector<float> Yk((size_t)2 * K * T);    // [K][T]
+    long T = 0;
+    while (!src_ended_ && (block_frames_ == 0 || T < block_frames_)) {
+      const gsl_vector_complex* v;
+      try { v = samp_->next(); } catch (jiterator_error&) { src_ended_ = true; break; }
+      fr.resize((size_t)(T + 1) * K * 2);
+      for (unsigned k = 0; k < K; k++) {
+        fr[2 * ((size_t)T * K + k)] = (float)v->data[2 * k];
+        fr[2 * ((size_t)T * K + k) + 1] = (float)v->data[2 * k + 1];
+      }
+      T++;
+    }
+    cur_.assign((size_t)2 * K * T, 0.f);         // [K][T]
     for (long t = 0; t < T; t++)
       for (unsigned k = 0; k < K; k++) {
-        Yk[2 * ((size_t)k * T + t)] = fr[2 * ((size_t)t * K + k)];
-        Yk[2 * ((size_t)k * T + t) + 1] = fr[2 * ((size_t)t * K + k) + 1];
+        cur_[2 * ((size_t)k * T + t)] = fr[2 * ((size_t)t * K + k)];
+        cur_[2 * ((size_t)k * T + t) + 1] = fr[2 * ((size_t)t * K + k) + 1];
       }
-    synthesize_(Yk, T, 0);
+    cur_T_ = T;
+    synthesize_(cur_, T, frames_in_, false, 0);
   }
   prepared_ = true;
+}
+
+// the current round is used up: its last frames become the history of the next one.  false: the input stream has ended
+bool OverSampledDFTSynthesisBank::fetch_round_()
+{
+  const unsigned K = M_ / 2 + 1;
+  const long pd = btk_fb_processing_delay(plan_);
+  const long H = std::max<long>((long)m_ * (1L << r_) + (1L << r_), pd);
+  long T = cur_T_;
+  const std::vector<float>* Yk = &cur_;
+  if (bsrc_) Yk = &bsrc_->block(T);
+  const long total = hist_len_ + T, keep = std::min(total, H);
+  std::vector<float> nh((size_t)2 * K * keep);
+  for (unsigned k = 0; k < K; k++)
+    for (long i = 0; i < keep; i++) {
+      const long j = total - keep + i;           // position in [history | this round]
+      const float* src = j < hist_len_ ? &hist_[2 * ((size_t)k * hist_len_ + j)] : &(*Yk)[2 * ((size_t)k * T + (j - hist_len_))];
+      nh[2 * ((size_t)k * keep + i)] = src[0]; nh[2 * ((size_t)k * keep + i) + 1] = src[1];
+    }
+  const long next_base = frames_in_ + T;
+  if (bsrc_) { if (!bsrc_->next_block()) return false; }
+  else if (src_ended_) return false;
+  hist_.swap(nh); hist_len_ = keep; frames_in_ = next_base;
+  blocks_.clear(); nblocks_ = 0;
+  prepare_();
+  return true;
 }
 
 // update_buf_ of the source-less form (modulated.cc:551-567): one more subband frame enters the ring
@@ -549,8 +631,9 @@ const gsl_vector_float* OverSampledDFTSynthesisBank::next(int frame_no)
   if (samp_.is_null()) throw jconsistency_error("OverSampledDFTSynthesisBank: no source stream (no_stream_feature(false) on a source-less bank)\n");
   if (!prepared_ || (bsrc_ && bsrc_->block_version() != src_version_)) prepare_();
   const long idx = frame_no_ + 1;
-  if (idx >= nblocks_) { is_end_ = true; throw jiterator_error("end of samples!"); }
-  memcpy(vector_->data, blocks_.data() + (size_t)idx * D_, sizeof(float) * D_);
+  while (idx >= blk_base_ + nblocks_)
+    if (!fetch_round_()) { is_end_ = true; throw jiterator_error("end of samples!"); }
+  memcpy(vector_->data, blocks_.data() + (size_t)(idx - blk_base_) * D_, sizeof(float) * D_);
   increment_();
   // block idx of a per-frame graph has pulled the frames 0 .. pd + idx (the priming of modulated.cc:574-578 included)
   if (bsrc_) bsrc_->advance_to((long)btk_fb_processing_delay(plan_) + idx);
@@ -561,7 +644,8 @@ void OverSampledDFTSynthesisBank::reset()
 {
   if (!no_stream_feature_ && !samp_.is_null()) samp_->reset();
   VectorFloatFeatureStream::reset();
-  prepared_ = false; blocks_.clear(); nblocks_ = 0; bsrc_ = NULL; src_version_ = 0;
+  prepared_ = false; blocks_.clear(); nblocks_ = 0; blk_base_ = 0; bsrc_ = NULL; src_version_ = 0; src_ended_ = false;
+  hist_.clear(); hist_len_ = 0; frames_in_ = 0; cur_.clear(); cur_T_ = 0;
   ring_.clear(); npushed_ = 0; npushed_at_next_ = 0;      // buffer_.zero() (modulated.cc:614-622)
 }
 
@@ -829,10 +913,15 @@ void BeamformerWeights::calcSidelobeCancellerP_f(unsigned fbinX, const gsl_vecto
 
 // ================================================================================ SubbandBeamformer
 SubbandBeamformer::SubbandBeamformer(unsigned fftLen, bool halfBandShift, const String& nm)
-    : VectorComplexFeatureStream(fftLen, nm), halfBandShift_(halfBandShift), dXfull_(NULL), snapshot_array_(NULL), fftLen_(fftLen),
+    : VectorComplexFeatureStream(fftLen, nm), chunk_base_(0), block_frames_(btk_default_block_frames()), chunk_loaded_(false),
+      channels_ended_(false), quantum_(1), halfBandShift_(halfBandShift), dXfull_(NULL), snapshot_array_(NULL), fftLen_(fftLen),
       fftLen2_(fftLen / 2), dX_(NULL), T_(0) {}
 SubbandBeamformer::~SubbandBeamformer() { free_device_(); }
-void SubbandBeamformer::free_device_() { dev_free(dX_); dX_ = NULL; dev_free(dXfull_); dXfull_ = NULL; T_ = 0; Xhost_.clear(); }
+void SubbandBeamformer::free_device_()
+{
+  dev_free(dX_); dX_ = NULL; dev_free(dXfull_); dXfull_ = NULL; T_ = 0; Xhost_.clear();
+  chunk_base_ = 0; chunk_loaded_ = false; channels_ended_ = false;
+}
 void SubbandBeamformer::set_channel(VectorComplexFeatureStreamPtr& chan) { channelList_.push_back(chan); }
 void SubbandBeamformer::clear_channel() { channelList_.clear(); snapshot_array_ = NULL; free_device_(); }
 
@@ -845,11 +934,35 @@ void SubbandBeamformer::reset()
   free_device_();
 }
 
+void SubbandBeamformer::set_block_quantum(long q)
+{
+  const char* e = getenv("BTK_BLOCK_QUANTUM");
+  if (e && *e) q = atol(e);
+  quantum_ = q < 1 ? 1 : q;
+}
+
 void* SubbandBeamformer::device_snapshots()
 {
-  if (dX_) return dX_;
+  if (!chunk_loaded_) load_chunk_();
+  return dX_;
+}
+
+bool SubbandBeamformer::next_chunk()
+{
+  if (!chunk_loaded_) return load_chunk_();
+  if (channels_ended_) return false;
+  return load_chunk_();
+}
+
+// The block of snapshots after the current one (the first one when none is loaded): frames chunk_base_ .. chunk_base_ + T_ - 1.
+// Returns false when the channels have no further frame (the block is then empty).
+bool SubbandBeamformer::load_chunk_()
+{
   const unsigned N = chanN(), K = fftLen2_ + 1;
   if (N == 0) throw j_error("set channels first\n");
+  const long f0 = chunk_loaded_ ? chunk_base_ + T_ : 0;
+  dev_free(dX_); dX_ = NULL; dev_free(dXfull_); dXfull_ = NULL; Xhost_.clear();
+  chunk_loaded_ = true; chunk_base_ = f0; T_ = 0;
   // fast path: every channel is an analysis bank with the same plan -> one batched analysis launch
   bool all_banks = true;
   std::vector<OverSampledDFTAnalysisBank*> banks;
@@ -860,68 +973,86 @@ void* SubbandBeamformer::device_snapshots()
     banks.push_back(b);
   }
   if (all_banks) {
-    long L = -1;
-    for (size_t c = 0; c < banks.size(); c++) { const long l = (long)banks[c]->pcm().size(); if (L < 0 || l < L) L = l; }
-    T_ = btk_fb_analysis_num_frames(banks[0]->plan(), L);
-    void* dp = dev_alloc(sizeof(float) * N * (L ? L : 1));
-    for (unsigned c = 0; c < N; c++)
-      if (L) h2d(static_cast<float*>(dp) + (size_t)c * L, banks[c]->pcm().data(), sizeof(float) * L);
+    // every bank pulls one round of input blocks (its block_frames()); the channels advance in lock step, the shortest one ends
+    // the stream (its zero-padded tail frames included, like a per-frame graph whose first exhausted channel ends it)
+    const long laN = btk_fb_lookahead(banks[0]->plan()), pd = btk_fb_processing_delay(banks[0]->plan());
+    const long want = (f0 / quantum_ + 1) * quantum_;            // a block ends on a multiple of the quantum (or with the stream)
+    for (size_t c = 0; c < banks.size(); c++)
+      while (!banks[c]->at_end() && banks[c]->frames_ready() < want) banks[c]->pull_more();
+    long nblk = -1; bool ended = false;
+    for (size_t c = 0; c < banks.size(); c++) { const long n = banks[c]->blocks_pulled(); if (nblk < 0 || n < nblk) nblk = n; }
+    for (size_t c = 0; c < banks.size(); c++) if (banks[c]->at_end() && banks[c]->blocks_pulled() == nblk) ended = true;
+    long f1 = ended ? (nblk < laN ? 0 : nblk - laN + pd) : (nblk > laN ? nblk - laN : 0);
+    if (!ended) f1 = f1 / quantum_ * quantum_;
+    channels_ended_ = ended;
+    T_ = f1 > f0 ? f1 - f0 : 0;
+    long b0 = banks[0]->first_block_of_frame(f0);
+    for (size_t c = 0; c < banks.size(); c++) b0 = std::max(b0, banks[c]->window_first_block());
+    b0 = std::min(b0, nblk);
+    const long D = (long)banks[0]->shiftlen(), L = (nblk - b0) * D;
     dX_ = dev_alloc(sizeof(float) * 2 * K * N * (T_ ? T_ : 1));
-    check_abi(btk_fb_analysis(banks[0]->plan(), (const float*)dp, L, L ? L : 1, 1, (int)N, dX_, T_, 0, T_, NULL));
-    check_abi(btk_synchronize(NULL));
-    dev_free(dp);
-  } else if (halfBandShift_) {
-    // the reference dots every one of the M snapshots as supplied (beamformer.cc:1113-1128): a generic source owes no conjugate
-    // symmetry between its bins, so all M bins go to the device; dX_ keeps the usual bins 0..M/2 for the other consumers
-    const unsigned M = fftLen_;
-    std::vector<std::vector<float> > fr(N);
-    long T = -1; unsigned c = 0;
-    for (ChannelList_::iterator it = channelList_.begin(); it != channelList_.end(); ++it, ++c) {
-      const long t = drain_complex_all_bins(*it, M, fr[c]);
-      if (T < 0 || t < T) T = t;
+    if (T_ > 0) {
+      void* dp = dev_alloc(sizeof(float) * N * (L ? L : 1));
+      for (unsigned c = 0; c < N; c++)
+        if (L) h2d(static_cast<float*>(dp) + (size_t)c * L, banks[c]->window(b0), sizeof(float) * L);
+      // the windows start at input block b0: stream frame t is frame t - b0 of the window (csrc/fb_kernels.hip: frame t ends at
+      // sample (t + laN + 1) D - 1), and no frame of this block reads a sample before it
+      check_abi(btk_fb_analysis(banks[0]->plan(), (const float*)dp, L, L ? L : 1, 1, (int)N, dX_, T_, f0 - b0, T_, NULL));
+      check_abi(btk_synchronize(NULL));
+      dev_free(dp);
     }
-    T_ = T;
-    std::vector<float> Xf((size_t)2 * M * N * T_);
-    for (unsigned k = 0; k < M; k++)
-      for (unsigned n = 0; n < N; n++)
-        for (long t = 0; t < T_; t++) {
-          Xf[2 * (((size_t)k * N + n) * T_ + t)] = fr[n][2 * ((size_t)t * M + k)];
-          Xf[2 * (((size_t)k * N + n) * T_ + t) + 1] = fr[n][2 * ((size_t)t * M + k) + 1];
-        }
-    dXfull_ = dev_alloc(sizeof(float) * (Xf.empty() ? 2 : Xf.size()));
-    dX_ = dev_alloc(sizeof(float) * 2 * K * N * (T_ ? T_ : 1));
-    if (!Xf.empty()) { h2d(dXfull_, Xf.data(), sizeof(float) * Xf.size()); h2d(dX_, Xf.data(), sizeof(float) * 2 * K * N * T_); }
+    for (size_t c = 0; c < banks.size(); c++) banks[c]->release_before(f0 + T_);
   } else {
+    // channels of any other kind are pulled frame by frame, at most block_frames() frames per block; with halfBandShift the
+    // reference dots every one of the M snapshots as supplied (beamformer.cc:1113-1128): a generic source owes no conjugate
+    // symmetry between its bins, so all M bins go to the device; dX_ keeps the usual bins 0..M/2 for the other consumers
+    const unsigned M = fftLen_, rows = halfBandShift_ ? M : K;
     std::vector<std::vector<float> > fr(N);
     long T = -1; unsigned c = 0;
+    bool ended = false;
     for (ChannelList_::iterator it = channelList_.begin(); it != channelList_.end(); ++it, ++c) {
-      const long t = drain_complex(*it, fftLen_, fr[c]);
+      long t = 0;
+      const long per_block = block_frames_ == 0 ? 0 : (block_frames_ + quantum_ - 1) / quantum_ * quantum_;
+      while (per_block == 0 || t < per_block) {
+        const gsl_vector_complex* v;
+        try { v = (*it)->next(); } catch (jiterator_error&) { ended = true; break; }
+        fr[c].resize((size_t)(t + 1) * rows * 2);
+        for (unsigned k = 0; k < 2 * rows; k++) fr[c][2 * (size_t)t * rows + k] = (float)v->data[k];
+        t++;
+      }
       if (T < 0 || t < T) T = t;
     }
+    channels_ended_ = ended;
     T_ = T;
-    std::vector<float> Xh((size_t)2 * K * N * T_);
-    for (unsigned k = 0; k < K; k++)
+    std::vector<float> Xh((size_t)2 * rows * N * T_);
+    for (unsigned k = 0; k < rows; k++)
       for (unsigned n = 0; n < N; n++)
         for (long t = 0; t < T_; t++) {
-          Xh[2 * (((size_t)k * N + n) * T_ + t)] = fr[n][2 * ((size_t)t * K + k)];
-          Xh[2 * (((size_t)k * N + n) * T_ + t) + 1] = fr[n][2 * ((size_t)t * K + k) + 1];
+          Xh[2 * (((size_t)k * N + n) * T_ + t)] = fr[n][2 * ((size_t)t * rows + k)];
+          Xh[2 * (((size_t)k * N + n) * T_ + t) + 1] = fr[n][2 * ((size_t)t * rows + k) + 1];
         }
-    dX_ = dev_alloc(sizeof(float) * Xh.size());
-    if (!Xh.empty()) h2d(dX_, Xh.data(), sizeof(float) * Xh.size());
+    dX_ = dev_alloc(sizeof(float) * 2 * K * N * (T_ ? T_ : 1));
+    if (halfBandShift_) {
+      dXfull_ = dev_alloc(sizeof(float) * (Xh.empty() ? 2 : Xh.size()));
+      if (!Xh.empty()) { h2d(dXfull_, Xh.data(), sizeof(float) * Xh.size()); h2d(dX_, Xh.data(), sizeof(float) * 2 * K * N * T_); }
+    } else if (!Xh.empty()) {
+      h2d(dX_, Xh.data(), sizeof(float) * Xh.size());
+    }
   }
-  return dX_;
+  return T_ > 0;
 }
 
 SnapShotArrayPtr SubbandBeamformer::snapshot_array()
 {
   const unsigned N = chanN(), K = fftLen2_ + 1;
   if (snapshot_array_.is_null()) snapshot_array_ = new SnapShotArray(fftLen_, N);
-  if (dX_ && frame_no_ >= 0 && frame_no_ < T_) {
+  const long lf = frame_no_ - chunk_base_;                     // the frame next() served last, within the current block
+  if (dX_ && lf >= 0 && lf < T_) {
     if (Xhost_.empty()) { Xhost_.resize((size_t)2 * K * N * T_); d2h(Xhost_.data(), dX_, sizeof(float) * Xhost_.size()); }
     gsl_vector_complex** snaps = snapshot_array_->raw_snapshots();
     for (unsigned k = 0; k < K; k++)
       for (unsigned n = 0; n < N; n++) {
-        const double re = Xhost_[2 * (((size_t)k * N + n) * T_ + frame_no_)], im = Xhost_[2 * (((size_t)k * N + n) * T_ + frame_no_) + 1];
+        const double re = Xhost_[2 * (((size_t)k * N + n) * T_ + lf)], im = Xhost_[2 * (((size_t)k * N + n) * T_ + lf) + 1];
         snaps[k]->data[2 * n] = re; snaps[k]->data[2 * n + 1] = im;
         if (k > 0 && k < fftLen2_) { snaps[fftLen_ - k]->data[2 * n] = re; snaps[fftLen_ - k]->data[2 * n + 1] = -im; }
       }
@@ -1059,35 +1190,51 @@ void SubbandDS::compute_output_(long from_frame)
   output_version_ = weights_version_;
 }
 
+// frames of the current block a weight change must leave alone: everything next() served or a block consumer was handed
+static long kept_frames(long frame_no, long handed, long chunk_base, long T)
+{
+  const long k = std::max<long>(frame_no, handed) + 1 - chunk_base;
+  return k < 0 ? 0 : (k > T ? T : k);
+}
+
 const gsl_vector_complex* SubbandDS::next(int frame_no)
 {
   if (frame_no == frame_no_) return vector_;
   if (!bfweight_) throw j_error("%s", need_weights_msg_());
-  if (Yhost_.empty() || output_version_ != weights_version_) compute_output_(std::max<long>(frame_no_, handed_) + 1);
+  device_snapshots();
   const long idx = frame_no_ + 1;
-  if (idx >= T_) { is_end_ = true; throw jiterator_error("end of samples!"); }
-  if (halfBandShift_) serve_frame_all_bins(Yhost_, T_, fftLen_, idx, vector_);
-  else serve_frame(Yhost_, T_, fftLen_, idx, vector_);
+  while (idx >= chunk_base_ + T_)
+    if (!advance_chunk_()) { is_end_ = true; throw jiterator_error("end of samples!"); }
+  if (Yhost_.empty() || output_version_ != weights_version_) compute_output_(kept_frames(frame_no_, handed_, chunk_base_, T_));
+  if (halfBandShift_) serve_frame_all_bins(Yhost_, T_, fftLen_, idx - chunk_base_, vector_);
+  else serve_frame(Yhost_, T_, fftLen_, idx - chunk_base_, vector_);
   increment_();
   return vector_;
 }
 
 void SubbandDS::reset() { SubbandBeamformer::reset(); Yhost_.clear(); handed_ = -1; }
 
+bool SubbandDS::advance_chunk_()
+{
+  Yhost_.clear();
+  return next_chunk();
+}
+
 const std::vector<float>& SubbandDS::block(long& T)
 {
   if (!bfweight_) throw j_error("%s", need_weights_msg_());
-  if (Yhost_.empty() || output_version_ != weights_version_) compute_output_(std::max<long>(frame_no_, handed_) + 1);
+  device_snapshots();
+  if (Yhost_.empty() || output_version_ != weights_version_) compute_output_(kept_frames(frame_no_, handed_, chunk_base_, T_));
   T = T_;
   return Yhost_;
 }
 
 void SubbandDS::advance_to(long frame_idx)
 {
-  // frames 0 .. frame_idx count as handed over to the block consumer: a weight change from now on recomputes only the frames
-  // beyond.  The mark is the block protocol's own -- frame_no_ stays what next() has served, so a second consumer that pulls this
-  // node frame by frame (or the script itself) still gets every frame
-  if (frame_idx >= T_) frame_idx = T_ - 1;
+  // frames 0 .. frame_idx (stream indices) count as handed over to the block consumer: a weight change from now on recomputes only
+  // the frames beyond.  The mark is the block protocol's own -- frame_no_ stays what next() has served, so a second consumer that
+  // pulls this node frame by frame (or the script itself) still gets every frame
+  if (frame_idx >= chunk_base_ + T_) frame_idx = chunk_base_ + T_ - 1;
   if (frame_idx > handed_) handed_ = frame_idx;
 }
 
@@ -1430,7 +1577,8 @@ ZelinskiPostFilter::ZelinskiPostFilter(VectorComplexFeatureStreamPtr& output, un
                                        int minFrames, const String& nm)
     : VectorComplexFeatureStream(fftLen, nm), fftLen_(fftLen), samp_(output), type_((PostfilterType)type), alpha_(alpha),
       min_frames_(minFrames), has_bf_ptr_(false), T_(0), prepared_(false), bf_version_(0), dPhi_(NULL), dPsi_(NULL), dWl_(NULL),
-      wp1_(gsl_vector_complex_calloc(fftLen)), hist_start_(0), own_weights_(NULL), manual_frames_(0), handed_(-1)
+      wp1_(gsl_vector_complex_calloc(fftLen)), hist_start_(0), own_weights_(NULL), manual_frames_(0), base_(0), carry_state_(false),
+      handed_(-1)
 {
   if (output->size() != fftLen) throw jdimension_error("Input block length (%d) != fftLen (%d)\n", output->size(), fftLen);
 }
@@ -1447,6 +1595,7 @@ void ZelinskiPostFilter::set_beamformer(SubbandDSPtr& bfptr)
   if (!has_bf_ptr_ && own_weights_) { delete own_weights_; own_weights_ = NULL; }      // postfilter.cc:373-382
   has_bf_ptr_ = true;
   bf_ptr_ = bfptr;
+  bf_ptr_->set_block_quantum(64);           // the density recursions are scanned in 64-frame chunks (csrc/pf_kernels.hip)
 }
 
 void ZelinskiPostFilter::set_snapshot_array(SnapShotArrayPtr& snapShotArray) { snapshot_array_ = snapShotArray; }
@@ -1475,9 +1624,41 @@ void ZelinskiPostFilter::bind_csd_provider_()
 
 // BeamformerWeights::CSDs() on demand (postfilter.cc:77-116): Phi_ij <- a Phi_ij + (1 - a) x'_i conj x'_j for i < j and the same
 // recursion on |x'_i|^2, x' = conj(d) x, a = 0 for the post-filter's first two frames, history restarted where the weights were
-// recomputed.  The recursion is linear, so the state after the last served frame t is sum_tau fw[tau] x(tau) x(tau)^H with
-// fw[tau] = (1 - a_tau) prod_{sigma > tau} a_sigma: ONE weighted covariance launch (btk_cov_accumulate) over the raw snapshots,
-// rotated by conj(d_i) d_j on the way into the reference's layout (entry i N + j; the lower triangle stays zero).
+// recomputed.  The recursion is linear, so the state after frame t of the current block is
+//   (prod of a over the block's frames up to t) * [state after the block before]  +  sum_tau fw[tau] x(tau) x(tau)^H,
+// fw[tau] = (1 - a_tau) prod_{sigma > tau} a_sigma: ONE weighted covariance launch (btk_cov_accumulate) over the block's raw
+// snapshots plus the carried matrices (csd_carry_, refreshed whenever a block is used up).  R: complex64 [K][N][N], unrotated.
+void ZelinskiPostFilter::csd_state_(long t, std::vector<float>& R)
+{
+  const unsigned K = fftLen_ / 2 + 1, N = bf_ptr_->chanN();
+  R.assign((size_t)2 * K * N * N, 0.f);
+  const long lo = std::max(hist_start_, base_);                      // first frame of this block that belongs to the history
+  if (t < lo && csd_carry_.empty()) return;
+  const long Tn = t - base_ + 1;                                      // frames of the block up to t
+  double tail = 1.0;                                                  // prod of a_sigma over sigma in (tau, t]
+  if (Tn > 0) {
+    std::vector<float> fw((size_t)Tn, 0.f);
+    for (long tau = t; tau >= lo; tau--) {
+      const double a_tau = (tau <= 1) ? 0.0 : alpha_;
+      fw[(size_t)(tau - base_)] = (float)((1.0 - a_tau) * tail);
+      tail *= a_tau;
+      if (tail == 0.0) break;
+    }
+    void* dX = bf_ptr_->device_snapshots();
+    const long Tstride = bf_ptr_->num_frames();
+    void* dF = dev_alloc(sizeof(float) * Tn);
+    void* dR = dev_alloc(sizeof(float) * R.size());
+    h2d(dF, fw.data(), sizeof(float) * Tn);
+    check_hip(hipMemset(dR, 0, sizeof(float) * R.size()), "hipMemset");
+    check_abi(btk_cov_accumulate(dX, NULL, (const float*)dF, dR, 1, (int)K, (int)N, Tstride, Tn, 0, NULL));
+    check_abi(btk_synchronize(NULL));
+    d2h(R.data(), dR, sizeof(float) * R.size());
+    dev_free(dF); dev_free(dR);
+  }
+  if (hist_start_ < base_ && csd_carry_.size() == R.size() && tail != 0.0)
+    for (size_t i = 0; i < R.size(); i++) R[i] += (float)(tail * csd_carry_[i]);
+}
+
 void ZelinskiPostFilter::fill_csds_(gsl_vector_complex** out)
 {
   const unsigned K = fftLen_ / 2 + 1;
@@ -1485,43 +1666,17 @@ void ZelinskiPostFilter::fill_csds_(gsl_vector_complex** out)
   BeamformerWeights* bw = manual ? own_weights_ : bf_ptr_->beamformer_weight_object();
   if (!bw) return;
   const unsigned N = bw->chanN();
-  const long t = manual ? manual_frames_ - 1 : std::max<long>(frame_no_, handed_);   // last frame a per-frame graph has pulled
   for (unsigned k = 0; k < fftLen_; k++) gsl_vector_complex_set_zero(out[k]);
-  if (t < 0 || t < hist_start_) return;
-  const long Tn = t + 1;
-  std::vector<float> fw((size_t)Tn, 0.f);
-  double tail = 1.0;                                                // prod of a_sigma over sigma in (tau, t]
-  for (long tau = t; tau >= hist_start_; tau--) {
-    const double a_tau = (tau <= 1) ? 0.0 : alpha_;
-    fw[(size_t)tau] = (float)((1.0 - a_tau) * tail);
-    tail *= a_tau;
-    if (tail == 0.0) break;
-  }
-  void* dX;
-  void* dXown = NULL;
-  long Tstride;
-  if (manual) {                                                     // [T][K][N] on the host -> [K][N][T] on the device
-    std::vector<float> Xt((size_t)2 * K * N * Tn);
-    for (long f = 0; f < Tn; f++)
-      for (size_t kn = 0; kn < (size_t)K * N; kn++) {
-        Xt[2 * (kn * Tn + f)] = Xhist_[2 * ((size_t)f * K * N + kn)];
-        Xt[2 * (kn * Tn + f) + 1] = Xhist_[2 * ((size_t)f * K * N + kn) + 1];
-      }
-    dXown = dev_alloc(sizeof(float) * Xt.size());
-    h2d(dXown, Xt.data(), sizeof(float) * Xt.size());
-    dX = dXown; Tstride = Tn;
+  std::vector<float> R;
+  if (manual) {                                                      // the recursion itself, kept frame by frame (next_manual_)
+    if (csd_manual_.empty()) return;
+    R.resize(csd_manual_.size() * 2);
+    for (size_t i = 0; i < csd_manual_.size(); i++) { R[2 * i] = (float)csd_manual_[i].real(); R[2 * i + 1] = (float)csd_manual_[i].imag(); }
   } else {
-    dX = bf_ptr_->device_snapshots(); Tstride = bf_ptr_->num_frames();
+    const long t = std::max<long>(frame_no_, handed_);              // last frame a per-frame graph has pulled
+    if (!prepared_ || t < 0 || t < hist_start_) return;
+    csd_state_(std::min(t, base_ + T_ - 1), R);
   }
-  void* dF = dev_alloc(sizeof(float) * Tn);
-  void* dR = dev_alloc(sizeof(float) * 2 * K * N * N);
-  h2d(dF, fw.data(), sizeof(float) * Tn);
-  check_hip(hipMemset(dR, 0, sizeof(float) * 2 * K * N * N), "hipMemset");
-  check_abi(btk_cov_accumulate(dX, NULL, (const float*)dF, dR, 1, (int)K, (int)N, Tstride, Tn, 0, NULL));
-  check_abi(btk_synchronize(NULL));
-  std::vector<float> R((size_t)2 * K * N * N);
-  d2h(R.data(), dR, sizeof(float) * R.size());
-  dev_free(dF); dev_free(dR); dev_free(dXown);
   gsl_vector_complex** dvec = align_with_wq_() ? bw->wq() : bw->arrayManifold();
   for (unsigned k = 0; k < K; k++)
     for (unsigned i = 0; i < N; i++) {
@@ -1560,7 +1715,21 @@ const gsl_vector_complex* ZelinskiPostFilter::next_manual_(int frame_no)
     }
     y[2 * k] = (float)output->data[2 * k]; y[2 * k + 1] = (float)output->data[2 * k + 1];
   }
-  Xhist_.insert(Xhist_.end(), x.begin(), x.end());
+  {
+    // the spectral densities BeamformerWeights::CSDs() reports (postfilter.cc:77-116), as the recursion itself on the raw
+    // snapshots: R <- a R + (1 - a) x x^H, a = 0 for the first two frames (upper triangle; rotated by d when asked for)
+    if (csd_manual_.size() != (size_t)K * N * N) csd_manual_.assign((size_t)K * N * N, cd(0, 0));
+    const double a = (manual_frames_ <= 1) ? 0.0 : alpha_;
+    for (unsigned k = 0; k < K; k++)
+      for (unsigned i = 0; i < N; i++) {
+        const cd xi(x[2 * ((size_t)k * N + i)], x[2 * ((size_t)k * N + i) + 1]);
+        for (unsigned j = i; j < N; j++) {
+          const cd xj(x[2 * ((size_t)k * N + j)], x[2 * ((size_t)k * N + j) + 1]);
+          cd& r = csd_manual_[((size_t)k * N + i) * N + j];
+          r = a * r + (1.0 - a) * xi * std::conj(xj);
+        }
+      }
+  }
   if (!dPhi_) {
     dPhi_ = dev_alloc(sizeof(float) * 2 * K); dPsi_ = dev_alloc(sizeof(float) * K); dWl_ = dev_alloc(sizeof(float) * K);
     check_hip(hipMemset(dPhi_, 0, sizeof(float) * 2 * K), "hipMemset");
@@ -1600,15 +1769,21 @@ void ZelinskiPostFilter::compute_(long from_frame)
   const unsigned N = bf->chanN(), K = fftLen_ / 2 + 1;
   void* dX = bf->device_snapshots();
   T_ = bf->num_frames();
+  base_ = bf->chunk_base();
   std::vector<float> w, d;
   bf->effective_weights(w);
   bf->alignment_vector((type_ & TYPE_ZELINSKI2) != 0, d);
   const long Tn = T_ - from_frame;
+  const bool carry = carry_state_ && dPhi_ && bf_version_ == bf->weights_version();
+  carry_state_ = false;
   if (!dPhi_) { dPhi_ = dev_alloc(sizeof(float) * 2 * K); dPsi_ = dev_alloc(sizeof(float) * K); dWl_ = dev_alloc(sizeof(float) * K); }
-  // weights (re)computed: the CSD history restarts, the frame counter keeps counting
-  check_hip(hipMemset(dPhi_, 0, sizeof(float) * 2 * K), "hipMemset");
-  check_hip(hipMemset(dPsi_, 0, sizeof(float) * K), "hipMemset");
-  check_hip(hipMemset(dWl_, 0, sizeof(float) * K), "hipMemset");
+  if (!carry) {
+    // weights (re)computed: the CSD history restarts, the frame counter keeps counting; the following block
+    // of the same stream instead continues from the densities the block before left on the device
+    check_hip(hipMemset(dPhi_, 0, sizeof(float) * 2 * K), "hipMemset");
+    check_hip(hipMemset(dPsi_, 0, sizeof(float) * K), "hipMemset");
+    check_hip(hipMemset(dWl_, 0, sizeof(float) * K), "hipMemset");
+  }
   std::vector<float> Ynew((size_t)2 * K * T_);
   if (Tn > 0) {
     void* dW = dev_alloc(sizeof(float) * w.size());
@@ -1624,7 +1799,7 @@ void ZelinskiPostFilter::compute_(long from_frame)
     float* Co = static_cast<float*>(dC) + 2 * from_frame;
     float* Eo = static_cast<float*>(dE) + from_frame;
     check_abi(btk_bf_apply_stats(dW, dD, 0, Xo, Yo, Co, Eo, 1, (int)K, (int)N, T_, Tn, NULL));
-    check_abi(btk_zelinski_process(Yo, Co, Eo, 1, (int)K, (int)N, T_, Tn, alpha_, (int)type_, min_frames_, from_frame,
+    check_abi(btk_zelinski_process(Yo, Co, Eo, 1, (int)K, (int)N, T_, Tn, alpha_, (int)type_, min_frames_, base_ + from_frame,
                                    dPhi_, (float*)dPsi_, (float*)dWl_, NULL));
     check_abi(btk_synchronize(NULL));
     d2h(Ynew.data(), dY, sizeof(float) * Ynew.size());
@@ -1632,9 +1807,27 @@ void ZelinskiPostFilter::compute_(long from_frame)
   }
   merge_output_(Ynew, from_frame);
   bf_version_ = bf->weights_version();
-  hist_start_ = from_frame;
+  if (!carry) { hist_start_ = base_ + from_frame; csd_carry_.clear(); }
   bind_csd_provider_();
   prepared_ = true;
+}
+
+// The block is used up: the densities on the device are those after its last frame (every block is processed to its end), and so
+// is the CSD state kept for BeamformerWeights::CSDs(); the beamformer moves on to its next block of snapshots.
+bool ZelinskiPostFilter::advance_chunk_()
+{
+  if (!has_bf_ptr_) return false;
+  if (prepared_ && T_ > 0) {
+    BeamformerWeights* bw = bf_ptr_->beamformer_weight_object();
+    if (bw && base_ + T_ - 1 >= hist_start_) {
+      std::vector<float> R;
+      csd_state_(base_ + T_ - 1, R);
+      csd_carry_.swap(R);
+    }
+  }
+  if (!bf_ptr_->next_block()) return false;
+  prepared_ = false; carry_state_ = true; Yhost_.clear();
+  return true;
 }
 
 void ZelinskiPostFilter::merge_output_(std::vector<float>& Ynew, long from_frame)
@@ -1650,10 +1843,13 @@ const gsl_vector_complex* ZelinskiPostFilter::next(int frame_no)
 {
   if (frame_no == frame_no_) return vector_;
   if (!has_bf_ptr_) return next_manual_(frame_no);
-  if (!prepared_ || bf_version_ != bf_ptr_->weights_version()) compute_(std::max<long>(frame_no_, handed_) + 1);
+  if (!prepared_ || bf_version_ != bf_ptr_->weights_version()) compute_(kept_frames(frame_no_, handed_, bf_ptr_->chunk_base(), bf_ptr_->num_frames()));
   const long idx = frame_no_ + 1;
-  if (idx >= T_) { is_end_ = true; throw jiterator_error("end of samples!"); }
-  serve_frame(Yhost_, T_, fftLen_, idx, vector_);
+  while (idx >= base_ + T_) {
+    if (!advance_chunk_()) { is_end_ = true; throw jiterator_error("end of samples!"); }
+    compute_(0);
+  }
+  serve_frame(Yhost_, T_, fftLen_, idx - base_, vector_);
   increment_();
   return vector_;
 }
@@ -1661,14 +1857,28 @@ const gsl_vector_complex* ZelinskiPostFilter::next(int frame_no)
 const std::vector<float>& ZelinskiPostFilter::block(long& T)
 {
   if (!has_bf_ptr_) throw j_error("set beamformer's weights \n");
-  if (!prepared_ || bf_version_ != bf_ptr_->weights_version()) compute_(std::max<long>(frame_no_, handed_) + 1);
+  if (!prepared_ || bf_version_ != bf_ptr_->weights_version()) compute_(kept_frames(frame_no_, handed_, bf_ptr_->chunk_base(), bf_ptr_->num_frames()));
   T = T_;
   return Yhost_;
 }
 
+long ZelinskiPostFilter::block_base()
+{
+  long T;
+  block(T);
+  return base_;
+}
+
+bool ZelinskiPostFilter::next_block()
+{
+  if (!advance_chunk_()) return false;
+  compute_(0);
+  return true;
+}
+
 void ZelinskiPostFilter::advance_to(long frame_idx)
 {
-  if (frame_idx >= T_) frame_idx = T_ - 1;
+  if (frame_idx >= base_ + T_) frame_idx = base_ + T_ - 1;
   if (frame_idx > handed_) handed_ = frame_idx;
   if (has_bf_ptr_) bf_ptr_->advance_to(frame_idx);
 }
@@ -1694,8 +1904,8 @@ void ZelinskiPostFilter::reset()
   samp_->reset();
   VectorComplexFeatureStream::reset();
   is_end_ = false;
-  prepared_ = false; Yhost_.clear();
-  Xhist_.clear(); manual_frames_ = 0; hist_start_ = 0; handed_ = -1;
+  prepared_ = false; Yhost_.clear(); T_ = 0; base_ = 0; carry_state_ = false; csd_carry_.clear();
+  csd_manual_.clear(); manual_frames_ = 0; hist_start_ = 0; handed_ = -1;
   if (!has_bf_ptr_ && dPhi_) {              // manual mode: the densities of the next utterance start from zero
     const unsigned K = fftLen_ / 2 + 1;
     check_hip(hipMemset(dPhi_, 0, sizeof(float) * 2 * K), "hipMemset");
@@ -1829,16 +2039,21 @@ void McCowanPostFilter::compute_(long from_frame)
   const bool lef = lefkimmiatis_();
   void* dX = bf->device_snapshots();
   T_ = bf->num_frames();
+  base_ = bf->chunk_base();
   std::vector<float> w, d;
   bf->effective_weights(w);
   bf->alignment_vector(!lef && (type_ & TYPE_ZELINSKI2) != 0, d);              // postfilter.cc:858-863 vs :1098
   const long Tn = T_ - from_frame;
+  const bool carry = carry_state_ && dPhi_ && dU_ && bf_version_ == bf->weights_version();
+  carry_state_ = false;
   if (!dPhi_) { dPhi_ = dev_alloc(sizeof(float) * 2 * K); dPsi_ = dev_alloc(sizeof(float) * K); dWl_ = dev_alloc(sizeof(float) * K); }
   if (!dU_) { dU_ = dev_alloc(sizeof(float) * 2 * K); dV_ = dev_alloc(sizeof(float) * 2 * K); }
-  check_hip(hipMemset(dPhi_, 0, sizeof(float) * 2 * K), "hipMemset");
-  check_hip(hipMemset(dPsi_, 0, sizeof(float) * K), "hipMemset");
-  check_hip(hipMemset(dWl_, 0, sizeof(float) * K), "hipMemset");
-  check_hip(hipMemset(dV_, 0, sizeof(float) * 2 * K), "hipMemset");
+  if (!carry) {                                                                // (the next block of a stream continues the recursions)
+    check_hip(hipMemset(dPhi_, 0, sizeof(float) * 2 * K), "hipMemset");
+    check_hip(hipMemset(dPsi_, 0, sizeof(float) * K), "hipMemset");
+    check_hip(hipMemset(dWl_, 0, sizeof(float) * K), "hipMemset");
+    check_hip(hipMemset(dV_, 0, sizeof(float) * 2 * K), "hipMemset");
+  }
   std::vector<float> Ynew((size_t)2 * K * T_);
   if (Tn > 0) {
     void* dW = dev_alloc(sizeof(float) * w.size());
@@ -1873,11 +2088,11 @@ void McCowanPostFilter::compute_(long from_frame)
       }
       invR_computed_ = true;
       check_abi(btk_lefkimmiatis_process(Yo, Uo, Vo, dLam, (int)fbinX1_, 1, (int)K, (int)N, T_, Tn, alpha_, (int)type_,
-                                         min_frames_, from_frame, dPhi_, dV_, (float*)dWl_, NULL));
+                                         min_frames_, base_ + from_frame, dPhi_, dV_, (float*)dWl_, NULL));
       check_abi(btk_synchronize(NULL));
       dev_free(dLam); dev_free(dFb); dev_free(scratch);
     } else {
-      check_abi(btk_zelinski_process(Yo, Uo, Eo, 1, (int)K, (int)N, T_, Tn, alpha_, (int)type_ & 3, min_frames_, from_frame,
+      check_abi(btk_zelinski_process(Yo, Uo, Eo, 1, (int)K, (int)N, T_, Tn, alpha_, (int)type_ & 3, min_frames_, base_ + from_frame,
                                      dPhi_, (float*)dPsi_, (float*)dWl_, NULL));
       check_abi(btk_synchronize(NULL));
     }
@@ -1886,7 +2101,7 @@ void McCowanPostFilter::compute_(long from_frame)
   }
   merge_output_(Ynew, from_frame);
   bf_version_ = bf->weights_version();
-  hist_start_ = from_frame;
+  if (!carry) { hist_start_ = base_ + from_frame; csd_carry_.clear(); }
   bind_csd_provider_();
   prepared_ = true;
 }
@@ -1910,15 +2125,16 @@ void LefkimmiatisPostFilter::calc_inverse_noise_spatial_spectral_matrix()
 // ================================================================================ SubbandGSCRLS
 SubbandGSCRLS::SubbandGSCRLS(unsigned fftLen, bool halfBandShift, float mu, float sigma2, const String& nm)
     : SubbandGSC(fftLen, halfBandShift, nm), mu_(mu), diagonal_weight_(sigma2), alpha_(-1.0f), qctype_(NO_QUADRATIC_CONSTRAINT),
-      rls_version_(0), is_wa_updated_(true), have_P_(false), dP_(NULL), dW_(NULL), dV_(NULL), dSS_(NULL), dCx_(NULL) {}
+      rls_version_(0), is_wa_updated_(true), have_P_(false), dP_(NULL), dW_(NULL), dV_(NULL), dSS_(NULL), dCx_(NULL), dP0_(NULL),
+      dW0_(NULL), dSS0_(NULL), uploaded_version_(0), block_ran_(false) {}
 
-SubbandGSCRLS::~SubbandGSCRLS() { dev_free(dP_); dev_free(dW_); dev_free(dV_); dev_free(dSS_); dev_free(dCx_); }
+SubbandGSCRLS::~SubbandGSCRLS() { dev_free(dP_); dev_free(dW_); dev_free(dV_); dev_free(dSS_); dev_free(dCx_); dev_free(dP0_); dev_free(dW0_); dev_free(dSS0_); }
 
-void SubbandGSCRLS::alloc_state_()
+// quiescent weights and the further blocked directions as the kernels want them, from the weight object as it is NOW
+void SubbandGSCRLS::upload_weights_()
 {
-  if (!bfweight_) throw j_error("call calc_gsc_weights_x() once\n");
   const unsigned N = chanN(), K = fftLen2_ + 1, NC = bfweight_->NC();
-  dev_free(dP_); dev_free(dW_); dev_free(dV_); dev_free(dSS_); dev_free(dCx_); dCx_ = NULL;
+  dev_free(dCx_); dCx_ = NULL;
   if (NC > 1) {
     // the blocking matrix of calc_gsc_weights_2 / _n keeps N - NC columns: B B^H = I - conj(wq) wq^T / |wq|^2 - sum_j c_j c_j^H;
     // btk_nlms_constraint_vectors returns the directions of conj(B) B^T, i.e. the complex conjugates (include/btkhip.h)
@@ -1933,12 +2149,24 @@ void SubbandGSCRLS::alloc_state_()
     dCx_ = dev_alloc(sizeof(double) * 2 * cx.size());
     h2d(dCx_, cx.data(), sizeof(double) * 2 * cx.size());
   }
+  if (!dV_) dV_ = dev_alloc(sizeof(double) * 2 * K * N);
+  h2d(dV_, bfweight_->wq_v.data(), sizeof(double) * 2 * K * N);                 // bins 0..M/2 of wq [M][N]
+  uploaded_version_ = weights_version_;
+}
+
+void SubbandGSCRLS::alloc_state_()
+{
+  if (!bfweight_) throw j_error("call calc_gsc_weights_x() once\n");
+  const unsigned N = chanN(), K = fftLen2_ + 1;
+  dev_free(dP_); dev_free(dW_); dev_free(dV_); dV_ = NULL; dev_free(dSS_); dev_free(dP0_); dev_free(dW0_); dev_free(dSS0_);
   dP_ = dev_alloc(sizeof(double) * 2 * K * N * N);
   dW_ = dev_alloc(sizeof(double) * 2 * K * N);
-  dV_ = dev_alloc(sizeof(double) * 2 * K * N);
   dSS_ = dev_alloc(sizeof(double) * 4);
+  dP0_ = dev_alloc(sizeof(double) * 2 * K * N * N);
+  dW0_ = dev_alloc(sizeof(double) * 2 * K * N);
+  dSS0_ = dev_alloc(sizeof(double) * 4);
   check_hip(hipMemset(dSS_, 0, sizeof(double) * 4), "hipMemset");
-  h2d(dV_, bfweight_->wq_v.data(), sizeof(double) * 2 * K * N);                 // bins 0..M/2 of wq [M][N]
+  upload_weights_();
 }
 
 void SubbandGSCRLS::init_precision_matrix(float sigma2)
@@ -1950,7 +2178,7 @@ void SubbandGSCRLS::init_precision_matrix(float sigma2)
   // the active weights kept in the weight object are the starting point (zeros after calc_gsc_weights)
   h2d(dW_, bfweight_->wl_v.data(), sizeof(double) * 2 * K * N);
   have_P_ = true;
-  Yhost_.clear();
+  Yhost_.clear(); block_ran_ = false;
 }
 
 void SubbandGSCRLS::set_precision_matrix(unsigned fbinX, gsl_matrix_complex* Pz)
@@ -1984,13 +2212,18 @@ void SubbandGSCRLS::set_precision_matrix(unsigned fbinX, gsl_matrix_complex* Pz)
       P[(size_t)a * N + b] = acc;
     }
   h2d(static_cast<double*>(dP_) + (size_t)2 * fbinX * N * N, P.data(), sizeof(double) * 2 * N * N);
-  Yhost_.clear();
+  Yhost_.clear(); block_ran_ = false;
 }
 
+// The recursion over the current block of snapshots, from the state the block before left (P, w_a and the stream counters move
+// to this block's end).  The state at the block's start is kept so that the block can be run again (refresh_block_).
 void SubbandGSCRLS::run_block_()
 {
   const unsigned N = chanN(), K = fftLen2_ + 1;
   void* dX = device_snapshots();
+  check_hip(hipMemcpy(dP0_, dP_, sizeof(double) * 2 * K * N * N, hipMemcpyDeviceToDevice), "hipMemcpy D2D");
+  check_hip(hipMemcpy(dW0_, dW_, sizeof(double) * 2 * K * N, hipMemcpyDeviceToDevice), "hipMemcpy D2D");
+  check_hip(hipMemcpy(dSS0_, dSS_, sizeof(double) * 4, hipMemcpyDeviceToDevice), "hipMemcpy D2D");
   void* dY = dev_alloc(sizeof(float) * 2 * K * (T_ ? T_ : 1));
   const double params[6] = { (double)mu_, (double)diagonal_weight_, (double)(int)qctype_, (double)alpha_,
                              normalize_weight_ ? 1.0 : 0.0, is_wa_updated_ ? 1.0 : 0.0 };
@@ -2014,6 +2247,7 @@ void SubbandGSCRLS::run_block_()
     }
   }
   output_version_ = weights_version_;
+  block_ran_ = true;
 }
 
 const std::vector<float>& SubbandGSCRLS::block(long& T)
@@ -2021,20 +2255,35 @@ const std::vector<float>& SubbandGSCRLS::block(long& T)
   if (!bfweight_) throw j_error("call calc_gsc_weights_x() once\n");
   if (!have_P_) throw j_error("set the precision matrix with init_precision_matrix() or set_precision_matrix()\n");
   if (halfBandShift_) throw j_error("halfBandShift==true is not yet supported\n");
+  device_snapshots();
   refresh_block_();
   T = T_;
   return Yhost_;
 }
 
-// The recursion of the whole utterance ran with the weights of that moment, and P / w_a have moved to its end.  New quiescent
-// weights or a new blocking matrix before any frame was served: run it again; after frames were served the per-frame meaning
-// (the recursion continuing from frame t with the new B) would need the state of frame t, which this engine does not keep:
-// refuse instead of handing the stale block over
+bool SubbandGSCRLS::advance_chunk_()
+{
+  Yhost_.clear(); block_ran_ = false;
+  return next_chunk();
+}
+
+// The recursion over the current block ran with the weights of that moment, and P / w_a have moved to the block's end.  New
+// quiescent weights or a new blocking matrix before any frame OF THIS BLOCK was served: the state at the block's start is put
+// back, the new wq / blocked directions are uploaded and the block runs again.  After frames of the block were served the
+// per-frame meaning (the recursion continuing from frame t with the new B) would need the state of frame t, which this engine
+// does not keep: refuse instead of handing the stale block over
 void SubbandGSCRLS::refresh_block_()
 {
-  if (!Yhost_.empty() && rls_version_ == weights_version_) return;
-  if (!Yhost_.empty() && std::max<long>(frame_no_, handed_) >= 0)
-    throw jconsistency_error("SubbandGSCRLS: the weights changed after frames of this utterance were served; reset() first\n");
+  if (block_ran_ && rls_version_ == weights_version_) return;
+  if (block_ran_) {
+    if (kept_frames(frame_no_, handed_, chunk_base_, T_) > 0)
+      throw jconsistency_error("SubbandGSCRLS: the weights changed after frames of this block were served; reset() first\n");
+    const unsigned N = chanN(), K = fftLen2_ + 1;
+    check_hip(hipMemcpy(dP_, dP0_, sizeof(double) * 2 * K * N * N, hipMemcpyDeviceToDevice), "hipMemcpy D2D");
+    check_hip(hipMemcpy(dW_, dW0_, sizeof(double) * 2 * K * N, hipMemcpyDeviceToDevice), "hipMemcpy D2D");
+    check_hip(hipMemcpy(dSS_, dSS0_, sizeof(double) * 4, hipMemcpyDeviceToDevice), "hipMemcpy D2D");
+  }
+  if (uploaded_version_ != weights_version_) upload_weights_();
   run_block_();
   rls_version_ = weights_version_;
 }
@@ -2045,10 +2294,12 @@ const gsl_vector_complex* SubbandGSCRLS::next(int frame_no)
   if (!bfweight_) throw j_error("call calc_gsc_weights_x() once\n");
   if (!have_P_) throw j_error("set the precision matrix with init_precision_matrix() or set_precision_matrix()\n");
   if (halfBandShift_) throw j_error("halfBandShift==true is not yet supported\n");          // reference beamformer.cc:1528-1530
-  refresh_block_();
+  device_snapshots();
   const long idx = frame_no_ + 1;
-  if (idx >= T_) { is_end_ = true; throw jiterator_error("end of samples!"); }
-  serve_frame(Yhost_, T_, fftLen_, idx, vector_);
+  while (idx >= chunk_base_ + T_)
+    if (!advance_chunk_()) { is_end_ = true; throw jiterator_error("end of samples!"); }
+  refresh_block_();
+  serve_frame(Yhost_, T_, fftLen_, idx - chunk_base_, vector_);
   increment_();
   return vector_;
 }

@@ -146,6 +146,16 @@ class PyStream : public Base, public BlockSource {
     py::gil_scoped_acquire g;
     if (py::hasattr(cont_, "_advance_to")) cont_.attr("_advance_to")(idx);
   }
+  // blocks of a bounded number of frames (modulated/modulated.h): _block_base() = stream index of the block's first frame,
+  // _next_block() moves the object on to its following block and returns False at the end of the stream
+  long block_base() override {
+    py::gil_scoped_acquire g;
+    return py::hasattr(cont_, "_block_base") ? cont_.attr("_block_base")().template cast<long>() : 0l;
+  }
+  bool next_block() override {
+    py::gil_scoped_acquire g;
+    return py::hasattr(cont_, "_next_block") ? cont_.attr("_next_block")().template cast<bool>() : false;
+  }
  private:
   static unsigned size_of_(const py::object& c) { return c.attr("size")().cast<unsigned>(); }
   py::object cont_, iter_;
@@ -285,7 +295,9 @@ PYBIND11_MODULE(_btk20cpp, m)
       .def("fftLen", &OverSampledDFTAnalysisBank::fftlen)
       .def("shiftlen", &OverSampledDFTAnalysisBank::shiftlen)
       .def("nBlocks", &OverSampledDFTAnalysisBank::nBlocks)
-      .def("subSampRate", &OverSampledDFTAnalysisBank::subSampRate);
+      .def("subSampRate", &OverSampledDFTAnalysisBank::subSampRate)
+      .def("set_block_frames", &OverSampledDFTAnalysisBank::set_block_frames, py::arg("n"))
+      .def("block_frames", &OverSampledDFTAnalysisBank::block_frames);
   py::class_<OverSampledDFTSynthesisBank, VectorFloatFeatureStream, cref<OverSampledDFTSynthesisBank>>(m, "OverSampledDFTSynthesisBankPtr")
       // source-less form (modulated/modulated.i:151-171): frames are pushed with input_source_vector(); registered first so that a
       // prototype array in the first position is not taken for a source object
@@ -307,7 +319,9 @@ PYBIND11_MODULE(_btk20cpp, m)
       .def("inputSourceVector", [](OverSampledDFTSynthesisBank& b, py::array_t<cd, py::array::c_style | py::array::forcecast> block) {
              GslCVec v(block); b.input_source_vector(v.v); }, py::arg("block"))
       .def("no_stream_feature", &OverSampledDFTSynthesisBank::no_stream_feature, py::arg("flag") = true)
-      .def("doNotUseStreamFeature", &OverSampledDFTSynthesisBank::no_stream_feature, py::arg("flag") = true);
+      .def("doNotUseStreamFeature", &OverSampledDFTSynthesisBank::no_stream_feature, py::arg("flag") = true)
+      .def("set_block_frames", &OverSampledDFTSynthesisBank::set_block_frames, py::arg("n"))
+      .def("block_frames", &OverSampledDFTSynthesisBank::block_frames);
 
   // ---- beamformer/beamformer.h
   py::class_<SnapShotArray, cref<SnapShotArray>>(m, "SnapShotArrayPtr")
@@ -339,7 +353,12 @@ PYBIND11_MODULE(_btk20cpp, m)
       .def("fftlen", &SubbandBeamformer::fftLen)
       .def("fftLen", &SubbandBeamformer::fftLen)
       .def("dim", &SubbandBeamformer::dim)
-      .def("num_frames", &SubbandBeamformer::num_frames)
+      .def("num_frames", &SubbandBeamformer::num_frames)                 // frames of the current block of snapshots
+      .def("chunk_base", &SubbandBeamformer::chunk_base)                 // stream index of its first frame
+      .def("set_block_frames", &SubbandBeamformer::set_block_frames, py::arg("n"))
+      .def("block_frames", &SubbandBeamformer::block_frames)
+      .def("set_block_quantum", &SubbandBeamformer::set_block_quantum, py::arg("q"))
+      .def("block_quantum", &SubbandBeamformer::block_quantum)
       .def("is_half_band_shift", &SubbandBeamformer::is_half_band_shift)
       .def("snapshot_array_f", [](SubbandBeamformer& b, unsigned fbinX) { return copy_of(b.snapshot_array_f(fbinX)); })
       .def("snapshot_array", [](SubbandBeamformer& b) { SnapShotArrayPtr a = b.snapshot_array(); return cref<SnapShotArray>(a.operator->()); })
@@ -395,7 +414,9 @@ PYBIND11_MODULE(_btk20cpp, m)
       // the block protocol a batching consumer uses (modulated/modulated.h BlockSource), under the names of the Python-side protocol
       .def("device_block", [](SubbandDS& b) { return block_of(b); })
       .def("_output_version", [](SubbandDS& b) { return b.block_version(); })
-      .def("_advance_to", [](SubbandDS& b, long idx) { b.advance_to(idx); });
+      .def("_advance_to", [](SubbandDS& b, long idx) { b.advance_to(idx); })
+      .def("_block_base", [](SubbandDS& b) { return b.block_base(); })
+      .def("_next_block", [](SubbandDS& b) { return b.next_block(); });
 
   py::class_<SubbandGSC, SubbandDS, cref<SubbandGSC>>(m, "SubbandGSCPtr")
       .def(py::init([](unsigned fftlen, bool half_band_shift, const std::string& nm) { return new SubbandGSC(fftlen, half_band_shift, nm); }),
@@ -481,7 +502,9 @@ PYBIND11_MODULE(_btk20cpp, m)
       .def("postfilter_weights", [](ZelinskiPostFilter& f) { return copy_of(f.postfilter_weights()); })
       .def("device_block", [](ZelinskiPostFilter& f) { return block_of(f); })
       .def("_output_version", [](ZelinskiPostFilter& f) { return f.block_version(); })
-      .def("_advance_to", [](ZelinskiPostFilter& f, long idx) { f.advance_to(idx); });
+      .def("_advance_to", [](ZelinskiPostFilter& f, long idx) { f.advance_to(idx); })
+      .def("_block_base", [](ZelinskiPostFilter& f) { return f.block_base(); })
+      .def("_next_block", [](ZelinskiPostFilter& f) { return f.next_block(); });
   py::class_<McCowanPostFilter, ZelinskiPostFilter, cref<McCowanPostFilter>>(m, "McCowanPostFilterPtr")
       .def(py::init([](py::object output, unsigned fftlen, double alpha, int type, int min_frames, float threshold, const std::string& nm) {
              VectorComplexFeatureStreamPtr p = as_cstream(output);

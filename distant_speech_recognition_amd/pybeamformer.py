@@ -120,6 +120,14 @@ class SubbandBeamformer(object):
     def _output_version(self):
         return 0 if self._beamformer is None else self._beamformer._output_version()
 
+    # blocks of a bounded number of frames (host/include/modulated/modulated.h, BlockSource): the C++ node computes one block of
+    # the stream at a time; device_block() is the current one, _block_base() the stream index of its first frame
+    def _block_base(self):
+        return 0 if self._beamformer is None else self._beamformer._block_base()
+
+    def _next_block(self):
+        return False if self._beamformer is None else self._beamformer._next_block()
+
     def __iter__(self):
         if self._beamformer is None:
             raise NotImplementedError("Undefined beamformer object")
@@ -205,7 +213,42 @@ class SubbandMVDRBeamformer(SubbandBeamformer):
         self._wqH = np.conjugate(np.array([self._beamformer.mvdr_weights(m) for m in range(self._fftlen2 + 1)], complex))
 
 
-class SubbandGSCLMSBeamformer(SubbandBeamformer):
+class _OwnBlocks(object):
+    """Classes that run their own kernels over the snapshots of a front node (self._front): the adaptive cancellers and the
+    batch beamformers.  device_block() is computed from the front's current block of snapshots; moving on to the next block
+    first makes sure this one went through the recursion, so the state carries over exactly as frame by frame."""
+
+    def _block_base(self):
+        return self._front.chunk_base()
+
+    def _next_block(self):
+        self.device_block()
+        ok = self._front._next_block()
+        self._Y = None
+        self._frames = None
+        return ok
+
+    def _iter_blocks(self):
+        while True:
+            Y = self.device_block()
+            if self._frames is None:
+                self._frames = _mirror(Y[0].cpu().numpy(), self._fftlen)
+            frames = self._frames
+            for t in range(frames.shape[0]):
+                yield frames[t]
+            if not self._next_block():
+                return
+
+    def _snapshot_blocks(self):
+        """(stream index of the first frame, X complex64 [1][K][N][T]) for every block of the front node's stream"""
+        while True:
+            X = self._front.device_snapshots()
+            yield self._front.chunk_base(), X
+            if not self._front._next_block():
+                return
+
+
+class SubbandGSCLMSBeamformer(_OwnBlocks, SubbandBeamformer):
     """pybeamformer.py:588-762: leaky power-normalised NLMS in GSC configuration.  The recursion runs
     on the GPU (btk_nlms_process); this class keeps the reference's state names as read-only views."""
 
@@ -218,6 +261,7 @@ class SubbandGSCLMSBeamformer(SubbandBeamformer):
         self._front = SubbandGSCPtr(fftlen=self._fftlen, half_band_shift=False)   # owns channels + device snapshots
         for source in self._spec_sources:
             self._front.set_channel(source)
+        self._front.set_block_quantum(64)      # the step-size control is scanned in 64-frame chunks (csrc/nlms_kernels.hip)
         self._beamformer = self._front
         self._params = dict(beta=beta, gamma=gamma, init_diagonal_load=init_diagonal_load,
                             regularization_param=regularization_param, energy_floor=float(energy_floor),
@@ -251,6 +295,12 @@ class SubbandGSCLMSBeamformer(SubbandBeamformer):
         if self._Y is None:
             assert self._vs is not None, "call calc_beamformer_weights() first"
             X = self._front.device_snapshots()
+            if X.shape[-1] % 2:
+                # the canceller picks its kernel by the parity of the row pitch (csrc/nlms_kernels.hip: frame pairs need an even
+                # one); an even pitch for every block makes the output independent of how the stream is cut into blocks
+                Xp = torch.empty(tuple(X.shape[:-1]) + (X.shape[-1] + 1,), dtype=X.dtype, device=X.device)
+                Xp[..., :-1] = X
+                X = Xp[..., :-1]
             if self._state is None:
                 self._state = engine.NLMSState(1, self._fftlen, self._chan_num, device(), Nc=self._Nc, **self._params)
             if self._Nc > 1 and self._state.cextra is None:
@@ -259,11 +309,7 @@ class SubbandGSCLMSBeamformer(SubbandBeamformer):
         return self._Y
 
     def __iter__(self):
-        Y = self.device_block()
-        if self._frames is None:
-            self._frames = _mirror(Y[0].cpu().numpy(), self._fftlen)
-        for t in range(self._frames.shape[0]):
-            yield self._frames[t]
+        return self._iter_blocks()
 
     @property
     def _waH(self):
@@ -284,7 +330,7 @@ class SubbandGSCLMSBeamformer(SubbandBeamformer):
         self._frames = None
 
 
-class SubbandGSCRLSBeamformer(SubbandBeamformer):
+class SubbandGSCRLSBeamformer(_OwnBlocks, SubbandBeamformer):
     """pybeamformer.py:765-928: RLS beamformer in GSC configuration with a regularisation term.  The recursion runs
     on the GPU (btk_rls_process mode 1, float64); _waH / _Pz are exported in the reference's basis on demand."""
 
@@ -335,11 +381,7 @@ class SubbandGSCRLSBeamformer(SubbandBeamformer):
         return self._Y
 
     def __iter__(self):
-        Y = self.device_block()
-        if self._frames is None:
-            self._frames = _mirror(Y[0].cpu().numpy(), self._fftlen)
-        for t in range(self._frames.shape[0]):
-            yield self._frames[t]
+        return self._iter_blocks()
 
     def _export(self):
         K = self._fftlen2 + 1
@@ -381,24 +423,27 @@ class SubbandSMIMVDRBeamformer(SubbandMVDRBeamformer):
 
     def accu_stats_from_label(self, samplerate, target_labs=[(0.1, -1)], energy_threshold=10):
         import torch
-        X = self._beamformer.device_snapshots()
-        T = X.shape[-1]
-        # noise-frame label exactly as the loop of pybeamformer.py:967-985 walks the VAD segments
+        # noise-frame label exactly as the loop of pybeamformer.py:967-985 walks the VAD segments, block after block of the stream
         elapsed_time, time_delta, labx = 0.0, self.shiftlen() / float(samplerate), 0
-        label = np.zeros(T, np.float32)
-        for t in range(T):
-            is_target = False
-            if labx < len(target_labs):
-                if elapsed_time >= target_labs[labx][0] and (elapsed_time <= target_labs[labx][1] or target_labs[labx][1] < 0):
-                    is_target = True
-                elif elapsed_time > target_labs[labx][1]:
-                    labx += 1
-            label[t] = 0.0 if is_target else 1.0
-            elapsed_time += time_delta
-        en = engine.frame_energy(X, self._fftlen)
-        w, self._noise_frame_num = engine.cov_frame_gate(en, torch.from_numpy(label[None]).to(device()), energy_threshold,
-                                                         count=self._noise_frame_num)
-        self._noise_covariance_matrices = engine.cov_accumulate(X, R=self._noise_covariance_matrices, frame_weights=w)
+        while True:
+            X = self._beamformer.device_snapshots()
+            T = X.shape[-1]
+            label = np.zeros(T, np.float32)
+            for t in range(T):
+                is_target = False
+                if labx < len(target_labs):
+                    if elapsed_time >= target_labs[labx][0] and (elapsed_time <= target_labs[labx][1] or target_labs[labx][1] < 0):
+                        is_target = True
+                    elif elapsed_time > target_labs[labx][1]:
+                        labx += 1
+                label[t] = 0.0 if is_target else 1.0
+                elapsed_time += time_delta
+            en = engine.frame_energy(X, self._fftlen)
+            w, self._noise_frame_num = engine.cov_frame_gate(en, torch.from_numpy(label[None]).to(device()), energy_threshold,
+                                                             count=self._noise_frame_num)
+            self._noise_covariance_matrices = engine.cov_accumulate(X, R=self._noise_covariance_matrices, frame_weights=w)
+            if not self._beamformer._next_block():
+                break
         self._beamformer.reset()          # the reference drained its sources here; they are re-read afterwards
 
     def finalize_stats(self):
@@ -432,7 +477,7 @@ def _vad_noise_label(T, time_delta, target_labs):
     return is_target
 
 
-class SubbandSOSBatchBeamformer(SubbandBeamformer):
+class SubbandSOSBatchBeamformer(_OwnBlocks, SubbandBeamformer):
     """pybeamformer.py:1022-1197: batch beamformer driven by target / noise spatial covariance matrices.
     Statistics are accumulated on the GPU (btk_cov_accumulate); _target/_noise_covariance_matrices are device
     complex64 [1][K][N][N], the frame counters device float32 [1][K]."""
@@ -462,32 +507,35 @@ class SubbandSOSBatchBeamformer(SubbandBeamformer):
                                                                 tf_weights=tf_j, frame_weights=fw_j)
         self._target_frame_counts = cnt_t if self._target_frame_counts is None else self._target_frame_counts + cnt_t
         self._noise_frame_counts = cnt_j if self._noise_frame_counts is None else self._noise_frame_counts + cnt_j
-        self._front.reset()          # the reference drained its sources here; they are re-read afterwards
 
     def accu_stats_from_label(self, samplerate, target_labs=[(0.1, -1)], energy_threshold=10):
         import torch
-        X = self._front.device_snapshots()
-        T, K = X.shape[-1], self._fftlen2 + 1
-        tgt = _vad_noise_label(T, self.shiftlen() / float(samplerate), target_labs)
-        en = engine.frame_energy(X, self._fftlen)
-        fw_t, ct = engine.cov_frame_gate(en, torch.from_numpy(tgt[None]).to(device()), energy_threshold)
-        fw_j, cj = engine.cov_frame_gate(en, torch.from_numpy((1.0 - tgt)[None]).to(device()), energy_threshold)
-        self._accumulate(X, None, None, fw_t, fw_j, ct[:, None].expand(1, K).contiguous(), cj[:, None].expand(1, K).contiguous())
+        K = self._fftlen2 + 1
+        for base, X in self._snapshot_blocks():
+            T = X.shape[-1]
+            tgt = _vad_noise_label(base + T, self.shiftlen() / float(samplerate), target_labs)[base:]
+            en = engine.frame_energy(X, self._fftlen)
+            fw_t, ct = engine.cov_frame_gate(en, torch.from_numpy(tgt[None]).to(device()), energy_threshold)
+            fw_j, cj = engine.cov_frame_gate(en, torch.from_numpy((1.0 - tgt)[None]).to(device()), energy_threshold)
+            self._accumulate(X, None, None, fw_t, fw_j, ct[:, None].expand(1, K).contiguous(), cj[:, None].expand(1, K).contiguous())
+        self._front.reset()          # the reference drained its sources here; they are re-read afterwards
 
     def accu_stats_from_tfmask(self, samplerate, mask_t, mask_j, energy_threshold=10):
         import torch
-        X = self._front.device_snapshots()
-        T, K = X.shape[-1], self._fftlen2 + 1
-        mt = np.zeros((K, T), np.float32)
-        mj = np.zeros((K, T), np.float32)
-        n = min(T, len(mask_t))
-        mt[:, :n] = np.asarray(mask_t, np.float32)[:n, :K].T
-        mj[:, :n] = np.asarray(mask_j, np.float32)[:n, :K].T
-        mt, mj = np.maximum(mt, 0.0), np.maximum(mj, 0.0)           # only mask > 0 contributes (:1137-1146)
-        tf_t, tf_j = torch.from_numpy(mt[None]).to(device()), torch.from_numpy(mj[None]).to(device())
-        en = engine.frame_energy(X, self._fftlen)
-        fw, _ = engine.cov_frame_gate(en, None, energy_threshold)
-        self._accumulate(X, tf_t, tf_j, fw, fw, engine.cov_mask_count(tf_t, fw), engine.cov_mask_count(tf_j, fw))
+        K = self._fftlen2 + 1
+        for base, X in self._snapshot_blocks():
+            T = X.shape[-1]
+            mt = np.zeros((K, T), np.float32)
+            mj = np.zeros((K, T), np.float32)
+            n = max(0, min(T, len(mask_t) - base))
+            mt[:, :n] = np.asarray(mask_t, np.float32)[base:base + n, :K].T
+            mj[:, :n] = np.asarray(mask_j, np.float32)[base:base + n, :K].T
+            mt, mj = np.maximum(mt, 0.0), np.maximum(mj, 0.0)           # only mask > 0 contributes (:1137-1146)
+            tf_t, tf_j = torch.from_numpy(mt[None]).to(device()), torch.from_numpy(mj[None]).to(device())
+            en = engine.frame_energy(X, self._fftlen)
+            fw, _ = engine.cov_frame_gate(en, None, energy_threshold)
+            self._accumulate(X, tf_t, tf_j, fw, fw, engine.cov_mask_count(tf_t, fw), engine.cov_mask_count(tf_j, fw))
+        self._front.reset()          # the reference drained its sources here; they are re-read afterwards
 
     def finalize_stats(self):
         pass
@@ -501,12 +549,9 @@ class SubbandSOSBatchBeamformer(SubbandBeamformer):
         return self._Y
 
     def __iter__(self):
-        Y = self.device_block()
-        if self._frames is None:
-            self._frames = _mirror(Y[0].cpu().numpy(), self._fftlen)
-        for t in range(self._frames.shape[0]):
+        for frame in self._iter_blocks():
             self._isamp += 1
-            yield self._frames[t]
+            yield frame
 
     def reset(self):
         self._front.reset()

@@ -1,0 +1,229 @@
+"""GPU: bounded-block streaming of the node layer (host/include/modulated/modulated.h, BlockSource).  The reference is frame-in /
+frame-out (modulated/modulated.cc:375-469, 569-612; stream/pyStream.h:44-160); the engine computes blocks of at most
+block_frames frames and must (a) give the SAME output bit for bit for every block size, (b) deliver the first output after one
+block of input, (c) run an endless source in bounded memory."""
+import os
+import resource
+import subprocess
+import wave
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXE = os.path.join(ROOT, "distant_speech_recognition_amd", "host", "examples", "beamformer_ds")
+EXE_MVDRGSC = os.path.join(ROOT, "distant_speech_recognition_amd", "host", "examples", "beamformer_mvdrgsc")
+MPOS = np.array([[-113.0, 0.0, 2.0], [36.0, 0.0, 2.0], [76.0, 0.0, 2.0], [113.0, 0.0, 2.0]])
+AZIMUTH = -1.306379
+M, m, r, D, FS = 256, 4, 1, 128, 16000
+
+
+def _wav(path, pcm):
+    w = wave.open(path, "wb")
+    w.setnchannels(1); w.setsampwidth(2); w.setframerate(FS)
+    w.writeframes(pcm.astype(np.int16).tobytes())
+    w.close()
+
+
+@pytest.mark.parametrize("pf,alpha,kind", [(0, 0.0, ""), (2, 0.7, ""), (2, 0.7, "mccowan"), (2, 0.8, "lefkimmiatis"), (0, 0.0, "gscrls")])
+def test_example_binary_same_bits_for_every_block_size(dev, tmp_path, proto256, kinect_pcm, pf, alpha, kind):
+    """src/beamformerDS.cc's graph (SampleFeature -> analysis x 4 -> GSC / GSC-RLS (-> post-filter) -> synthesis) through the C++
+    example: one block for the whole utterance (BTK_BLOCK_FRAMES=0) against 16-, 37- and 100-frame blocks, byte for byte."""
+    from tests.util import la_delays
+    h, g = proto256
+    coeffs = str(tmp_path / "coeffs.f64")
+    np.concatenate([h, g]).astype(np.float64).tofile(coeffs)
+    delays = la_delays(MPOS, AZIMUTH)
+    L = 30000
+    chan = []
+    for c in range(4):
+        p = str(tmp_path / ("c%d.wav" % c))
+        _wav(p, kinect_pcm[c][:L])
+        chan += [repr(float(delays[c])), p]
+    outs = {}
+    for bf in (0, 16, 37, 100):
+        out = str(tmp_path / ("out%d.f32" % bf))
+        env = dict(os.environ, BTK_BLOCK_FRAMES=str(bf))
+        if kind in ("mccowan", "lefkimmiatis"):
+            env["BTK_EXAMPLE_PF"] = kind
+            env["BTK_EXAMPLE_MPOS"] = ";".join(",".join(repr(float(v)) for v in row) for row in MPOS)
+        if kind == "gscrls":
+            env["BTK_EXAMPLE_BF"] = "gscrls"
+        res = subprocess.run([EXE, coeffs, str(M), str(m), str(r), str(pf), str(alpha), out] + chan, capture_output=True, text=True,
+                             timeout=300, env=env)
+        assert res.returncode == 0, res.stderr
+        outs[bf] = np.fromfile(out, np.float32)
+    assert outs[0].size > 200 * D and np.max(np.abs(outs[0])) > 100
+    for bf in (16, 37, 100):
+        assert outs[bf].shape == outs[0].shape, (bf, outs[bf].shape, outs[0].shape)
+        assert np.array_equal(outs[bf].view(np.uint32), outs[0].view(np.uint32)), (kind, bf, float(np.max(np.abs(outs[bf] - outs[0]))))
+
+
+def _graph(wavs, h, g, block_frames, postfilter=False, dct=2):
+    from distant_speech_recognition_amd.btk20 import (SampleFeaturePtr, OverSampledDFTAnalysisBankPtr, SubbandGSCPtr, ZelinskiPostFilterPtr,
+                                                      OverSampledDFTSynthesisBankPtr)
+    from distant_speech_recognition_amd.pybeamformer import calc_delays
+    afbs = []
+    for p in wavs:
+        sf = SampleFeaturePtr(block_len=D, shift_len=D, pad_zeros=True)
+        sf.read(p, FS)
+        a = OverSampledDFTAnalysisBankPtr(sf, prototype=h, M=M, m=m, r=r, delay_compensation_type=dct)
+        a.set_block_frames(block_frames)
+        afbs.append(a)
+    bf = SubbandGSCPtr(fftlen=M, half_band_shift=False)
+    for a in afbs:
+        bf.set_channel(a)
+    delays = calc_delays("linear", MPOS.tolist(), [AZIMUTH, None, None])
+    bf.calc_gsc_weights(FS, delays)
+    top = bf
+    if postfilter:
+        top = ZelinskiPostFilterPtr(bf, M, 0.7, 2)
+        top.set_beamformer(bf)
+    sfb = OverSampledDFTSynthesisBankPtr(top, prototype=g, M=M, m=m, r=r, delay_compensation_type=dct)
+    return afbs, bf, top, sfb
+
+
+@pytest.fixture(scope="module")
+def wavs(tmp_path_factory, kinect_pcm):
+    d = tmp_path_factory.mktemp("swav")
+    paths = []
+    for c in range(4):
+        p = str(d / ("c%d.wav" % c))
+        _wav(p, kinect_pcm[c][:40000])
+        paths.append(p)
+    return paths
+
+
+@pytest.mark.parametrize("postfilter", [False, True])
+def test_python_graph_same_bits_and_weight_change_mid_stream(dev, proto256, wavs, postfilter):
+    """The same graph through the Python binding: every block size gives the whole-utterance bits, also when the look direction
+    moves while the stream runs (unit_test/test_online_beamforming.py:209-226): frames already pulled keep the old weights."""
+    from distant_speech_recognition_amd.pybeamformer import calc_delays
+    h, g = proto256
+    outs = {}
+    for bfr in (0, 16, 50):
+        _, bf, _, sfb = _graph(wavs, h, g, bfr, postfilter)
+        blocks = []
+        for i, b in enumerate(sfb):
+            blocks.append(np.array(b))
+            if i == 120:                                         # the speaker moves: new look direction from the next frame on
+                bf.calc_gsc_weights(FS, calc_delays("linear", MPOS.tolist(), [0.3, None, None]))
+        outs[bfr] = np.concatenate(blocks)
+    assert outs[0].size == 313 * D
+    for bfr in (16, 50):
+        assert outs[bfr].shape == outs[0].shape
+        assert np.array_equal(outs[bfr].view(np.uint32), outs[0].view(np.uint32)), (bfr, float(np.max(np.abs(outs[bfr] - outs[0]))))
+
+
+def test_gsc_lms_and_rls_python_classes_same_bits(dev, proto256, wavs):
+    """pybeamformer.SubbandGSCLMSBeamformer / SubbandGSCRLSBeamformer (lib/pybeamformer.py:588-928) over snapshot blocks: the
+    recursion state lives on the device and carries from block to block -- same bits as one block for the utterance."""
+    from distant_speech_recognition_amd.btk20 import (SampleFeaturePtr, OverSampledDFTAnalysisBankPtr, PyVectorComplexFeatureStreamPtr,
+                                                      OverSampledDFTSynthesisBankPtr)
+    from distant_speech_recognition_amd.pybeamformer import SubbandGSCLMSBeamformer, SubbandGSCRLSBeamformer, calc_delays
+    h, g = proto256
+    delays = calc_delays("linear", MPOS.tolist(), [AZIMUTH, None, None])
+    for cls, kw in ((SubbandGSCLMSBeamformer, dict(min_frames=16, slowdown_after=64)), (SubbandGSCRLSBeamformer, dict(min_frames=16))):
+        outs = {}
+        for bfr in (0, 24):
+            afbs = []
+            for p in wavs:
+                sf = SampleFeaturePtr(block_len=D, shift_len=D, pad_zeros=True)
+                sf.read(p, FS)
+                a = OverSampledDFTAnalysisBankPtr(sf, prototype=h, M=M, m=m, r=r, delay_compensation_type=2)
+                a.set_block_frames(bfr)
+                afbs.append(a)
+            bf = cls(afbs, **kw)
+            bf.calc_beamformer_weights(FS, delays)
+            sfb = OverSampledDFTSynthesisBankPtr(PyVectorComplexFeatureStreamPtr(bf), prototype=g, M=M, m=m, r=r, delay_compensation_type=2)
+            outs[bfr] = np.concatenate([np.array(b) for b in sfb])
+        assert outs[0].size == 313 * D and outs[24].shape == outs[0].shape
+        assert np.array_equal(outs[24].view(np.uint32), outs[0].view(np.uint32)), (cls.__name__, float(np.max(np.abs(outs[24] - outs[0]))))
+
+
+class _CountingSource:
+    """A live PCM source for PyVectorFloatFeatureStream (stream/pyStream.h:44-160): counts the blocks pulled from it; endless
+    unless `limit` is given."""
+
+    def __init__(self, seed, limit=None):
+        self._seed, self._limit = seed, limit
+        self.reset()
+
+    def size(self):
+        return D
+
+    def __iter__(self):
+        return self
+
+    def next(self):
+        if self._limit is not None and self.pulled >= self._limit:
+            raise StopIteration
+        self.pulled += 1
+        return np.rint(self._rng.normal(0.0, 1000.0, D)).astype(np.float32)
+
+    __next__ = next
+
+    def reset(self):
+        self._rng = np.random.default_rng(self._seed)
+        self.pulled = 0
+
+
+def _live_graph(h, g, block_frames, limit=None, postfilter=True):
+    from distant_speech_recognition_amd.btk20 import (PyVectorFloatFeatureStreamPtr, OverSampledDFTAnalysisBankPtr, SubbandGSCPtr,
+                                                      ZelinskiPostFilterPtr, OverSampledDFTSynthesisBankPtr)
+    from distant_speech_recognition_amd.pybeamformer import calc_delays
+    srcs = [_CountingSource(100 + c, limit) for c in range(4)]
+    bf = SubbandGSCPtr(fftlen=M, half_band_shift=False)
+    for s in srcs:
+        a = OverSampledDFTAnalysisBankPtr(PyVectorFloatFeatureStreamPtr(s), prototype=h, M=M, m=m, r=r, delay_compensation_type=2)
+        a.set_block_frames(block_frames)
+        bf.set_channel(a)
+    bf.calc_gsc_weights(FS, calc_delays("linear", MPOS.tolist(), [AZIMUTH, None, None]))
+    top = bf
+    if postfilter:
+        top = ZelinskiPostFilterPtr(bf, M, 0.7, 2)
+        top.set_beamformer(bf)
+    return srcs, OverSampledDFTSynthesisBankPtr(top, prototype=g, M=M, m=m, r=r, delay_compensation_type=2)
+
+
+def test_first_output_after_one_block_of_input(dev, proto256):
+    """A source that counts its pulls: the first output block arrives after block_frames input blocks per channel (a per-frame
+    graph needs laN + pd + 1 = 8 at this geometry), and block i after at most i + block_frames + laN + pd + 1.  A chain with a
+    post-filter rounds its blocks to the 64-frame chunks of the density scan (set_block_quantum): first output after 64 + laN."""
+    h, g = proto256
+    for pf, bfr, first in ((False, 8, 8), (False, 16, 16), (False, 64, 64), (True, 64, 67), (True, 128, 128), (True, 16, 67)):
+        srcs, sfb = _live_graph(h, g, bfr, postfilter=pf)
+        sfb.next()
+        assert all(s.pulled <= first + bfr - 1 and s.pulled >= min(first, 8) for s in srcs), (pf, bfr, [s.pulled for s in srcs])
+        p0 = srcs[0].pulled
+        for i in range(1, 200):
+            sfb.next()
+            assert all(s.pulled <= i + p0 + bfr + 64 for s in srcs), (bfr, i, [s.pulled for s in srcs])
+
+
+def test_live_source_equals_the_finite_one(dev, proto256):
+    """the first 300 output blocks of an endless source are the 300 blocks a 400-block recording of the same samples gives"""
+    h, g = proto256
+    _, live = _live_graph(h, g, 32)
+    _, rec = _live_graph(h, g, 0, limit=400)
+    a = np.concatenate([np.array(live.next()) for _ in range(300)])
+    b = np.concatenate([np.array(v) for v in rec])
+    assert b.size >= 300 * D and np.array_equal(a.view(np.uint32), b[:300 * D].view(np.uint32))
+
+
+def test_endless_source_runs_in_bounded_memory(dev, proto256):
+    """20 000 output blocks (160 s of audio at this geometry) from a source that never ends: the resident set does not grow with
+    the stream (the sample windows, the block buffers and the synthesis history are all bounded by the block size)"""
+    h, g = proto256
+    srcs, sfb = _live_graph(h, g, 64)
+    for _ in range(4000):
+        sfb.next()
+    rss0 = resource.getrusage(resource.RUSAGE_SELF).ru_maxrss
+    acc = 0.0
+    for _ in range(16000):
+        acc += float(np.abs(np.array(sfb.next())).max())
+    rss1 = resource.getrusage(resource.RUSAGE_SELF).ru_maxrss
+    assert acc > 0 and srcs[0].pulled >= 20000
+    assert rss1 - rss0 < 64 * 1024, (rss0, rss1)                 # KiB: whole-utterance buffering would add > 100 MB here
