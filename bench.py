@@ -25,7 +25,13 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK = 8.0e12          # B/s, MI355X spec (MI355X_MICROARCH.md)
-TRAFFIC_JSON = "r04_pmc_traffic.json"      # profiles/: PMC traffic of the kernels below, with the launch size and kernel-source hash it holds for
+VECTOR_PEAK = 157.3e12     # flop/s: 256 CUs x 4 SIMDs x 64 float32 flops per clock x 2.4 GHz (MI355X_MICROARCH.md)
+SCLK_PEAK = 2.4e9          # Hz, nominal peak engine clock; under the 1 400 W cap the fused kernel runs at ~2.1 GHz (profiles/*_clock_probe.txt)
+# Interior loop of analysis512_bfz_kernel<2,33231,16>, per wavefront (= 4 frames) and channel, counted in the ISA of the sources
+# with this sha256: packed float32 instructions; a wave64 packed instruction occupies its SIMD for 4 cycles.
+FUSED_ISA = {"kernel_source_sha256": "94ceef2a0dd36a62bc6d87bd67c893bea0517daa7f134a86f2087ad8410f43f8",
+             "v_pk_fma_f32": 184, "v_pk_add_f32": 89, "v_pk_mul_f32": 23, "frames_per_wave": 4}
+TRAFFIC_JSON = "r05_pmc_traffic.json"      # profiles/: PMC traffic of the kernels below, with the launch size and kernel-source hash it holds for
 FS = 16000.0
 
 
@@ -241,9 +247,18 @@ def main():
     if dist: dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    my_elapsed = elapsed
+    per_rank = [S * T * args.steps / my_elapsed]
+    rccl_world = None
     if dist:
         from distant_speech_recognition_amd import sharding
         elapsed = sharding.max_over_ranks(elapsed, dev)
+        # every rank's own rate (frames/s between the two barriers) and the world size the communicator itself reports
+        mine = torch.tensor([per_rank[0]], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        per_rank = [float(v.item()) for v in allr]
+        rccl_world = dist.get_world_size()
 
     t_a = np.mean([e[0].elapsed_time(e[1]) for e in ev]) * 1e-3          # fused: analysis+apply kernel
     t_b = np.mean([e[1].elapsed_time(e[2]) for e in ev]) * 1e-3
@@ -319,6 +334,25 @@ def main():
                     return e["traffic_bytes"]
             traffic_note["why"] = "profiles/%s holds no kernel named *%s*: refused" % (TRAFFIC_JSON, kernel_substr)
             return None
+        def compute_side(t_kernel):
+            """What the dominant kernel does to the vector ALU next to what it does to HBM: packed instructions issued (ISA count x
+            launches) against the issue slots of the launch's duration, and the flops they carry against the vector peak."""
+            if FUSED_ISA["kernel_source_sha256"] != kernel_source_sha():
+                return {"valu_slot_frac": None, "executed_TFLOPs": None,
+                        "why": "the kernel sources changed since the ISA count in bench.py (FUSED_ISA) was taken: refused as stale"}
+            n_pk = FUSED_ISA["v_pk_fma_f32"] + FUSED_ISA["v_pk_add_f32"] + FUSED_ISA["v_pk_mul_f32"]
+            waves_ch = N * S * T / FUSED_ISA["frames_per_wave"]                 # (wavefront, channel) passes per launch
+            flop = waves_ch * 64 * (4 * FUSED_ISA["v_pk_fma_f32"] + 2 * (FUSED_ISA["v_pk_add_f32"] + FUSED_ISA["v_pk_mul_f32"]))
+            cyc_per_simd = waves_ch * n_pk * 4 / 1024.0                         # 256 CUs x 4 SIMDs
+            return {"packed_instr_per_wave_and_channel": n_pk, "flop_per_launch": flop,
+                    "executed_TFLOPs": flop / t_kernel / 1e12, "vector_peak_TFLOPs": VECTOR_PEAK / 1e12,
+                    "flop_frac": flop / t_kernel / VECTOR_PEAK,
+                    "valu_slot_frac": cyc_per_simd / (t_kernel * SCLK_PEAK),
+                    "valu_slot_frac_at_2p1GHz": cyc_per_simd / (t_kernel * 2.1e9),
+                    "note": "issue cycles of the packed float32 instructions (4 per wave64 instruction) / cycles of the launch at the "
+                            "2.4 GHz peak clock; the part sits at its 1 400 W cap and clocks ~2.1 GHz under this kernel "
+                            "(profiles/*_clock_probe.txt), second figure.  Neither roof is reached: two wavefronts per SIMD at 227 "
+                            "VGPRs hide LDS and issue latency only partly (DESIGN.md 3.1b)"}
         if fused:
             # algorithmic bytes of the FUSED operator: every PCM sample in once, every beamformed bin out once (4 D N + 8 K
             # per frame); the N x K snapshots that SURVEY 8(d) prices for the staged pair never exist in HBM
@@ -327,6 +361,7 @@ def main():
                     "frac": b_fused_hbm / t_a / HBM_PEAK, "frac_survey_8d": (b_ana + b_bf) / t_a / HBM_PEAK,
                     "traffic": pmc_traffic("analysis512_bfz_kernel"), "traffic_source": None,
                     "bytes_per_launch": b_fused_hbm, "avg_launch_ms": t_a * 1e3,
+                    "compute": compute_side(t_a),
                     "staged_equivalent": {"bytes_per_launch": b_ana + b_bf, "GBps": (b_ana + b_bf) / t_a / 1e9,
                                           "frac": (b_ana + b_bf) / t_a / HBM_PEAK},
                     "note": "bytes_per_launch = 4DN+8K per frame (PCM in, Y out): the fused kernel keeps the N x K snapshots on "
@@ -348,6 +383,8 @@ def main():
             "config": {"workload": "C0: %d-mic %d-bin SubbandGSC, analysis->GSC apply->synthesis (%s), m=4 r=1 (D=%d), "
                                    "%d streams/GPU x %d frames/step" % (N, M, "fused analysis+apply" if fused else "staged", D, S, T),
                        "streams_per_gpu": S, "frames_per_stream": T, "parallelism": "stream-sharded x%d" % world,
+                       "rccl_world": rccl_world, "dist_backend": (backend if dist else None),
+                       "per_rank_frames_per_s": per_rank,
                        "y_row_stride_frames": int(Y.stride(1))},
             "roofline": roof,
             "stages": {

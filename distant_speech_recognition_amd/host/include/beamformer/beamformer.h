@@ -17,6 +17,11 @@ class SnapShotArray : public Countable {
   virtual ~SnapShotArray();
   const gsl_vector_complex* snapshot(unsigned fbinX) const { return snapshots_[fbinX]; }
   void set_samples(const gsl_vector_complex* samp, unsigned chanX);
+  // one bin's snapshot directly (reference beamformer.cc:79-93, used by the modal beamformers): the conjugate goes to bin
+  // fftLen/2 - fbinX exactly as the reference writes it; do not call update() afterwards
+  void set_snapshots(const gsl_vector_complex* snapshots, unsigned fbinX);
+  const gsl_vector_complex* getSnapShot(unsigned fbinX) const { return snapshot(fbinX); }          // ENABLE_LEGACY_BTK_API aliases
+  void newSample(const gsl_vector_complex* samp, unsigned chanX) { set_samples(samp, chanX); }     // (spectralinfoarray.h:26-27)
   virtual void update();
   virtual void zero();
   unsigned fftLen() const { return fftLen_; }
@@ -251,6 +256,7 @@ class SubbandGSCRLS : public SubbandGSC {
  private:
   void alloc_state_();
   void upload_weights_();
+  void change_basis_(void* dP, void* dW);
   void run_block_();
   void refresh_block_();
   virtual bool advance_chunk_();
@@ -263,6 +269,7 @@ class SubbandGSCRLS : public SubbandGSC {
   void *dP0_, *dW0_, *dSS0_;        // the state at the start of the current block (a weight change before its first frame is served reruns it)
   unsigned long uploaded_version_;  // weights_version_ dV_ / dCx_ were built from
   bool block_ran_;
+  std::vector<std::complex<double> > wq_uploaded_;   // the quiescent weights (bins 0..M/2) the device state was built with
 };
 typedef Inherit<SubbandGSCRLS, SubbandGSCPtr> SubbandGSCRLSPtr;
 

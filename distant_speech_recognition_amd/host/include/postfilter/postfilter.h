@@ -82,9 +82,14 @@ class McCowanPostFilter : public ZelinskiPostFilter {
   void set_diagonal_looading(unsigned fbinX, float diagonalWeight);          // sic (reference spelling)
   void divide_all_nondiagonal_elements(float mu);
   void divide_nondiagonal_elements(unsigned fbinX, float mu);
-  // legacy API
+  // ENABLE_LEGACY_BTK_API aliases (reference postfilter/postfilter.h:140-148)
+  const gsl_matrix_complex* getNoiseSpatialSpectralMatrix(unsigned fbinX) { return noise_spatial_spectral_matrix(fbinX); }
+  bool setNoiseSpatialSpectralMatrix(unsigned fbinX, gsl_matrix_complex* Rnn) { return set_noise_spatial_spectral_matrix(fbinX, Rnn); }
   bool setDiffuseNoiseModel(const gsl_matrix* mp, double fs, double c = 343740.0) { return set_diffuse_noise_model(mp, fs, c); }
   void setAllLevelsOfDiagonalLoading(float w) { set_all_diagonal_loading(w); }
+  void setLevelOfDiagonalLoading(unsigned fbinX, float w) { set_diagonal_looading(fbinX, w); }
+  void divideAllNonDiagonalElements(float mu) { divide_all_nondiagonal_elements(mu); }
+  void divideNonDiagonalElements(unsigned fbinX, float mu) { divide_nondiagonal_elements(fbinX, mu); }
  protected:
   virtual void compute_(long from_frame);
   virtual bool lefkimmiatis_() const { return false; }

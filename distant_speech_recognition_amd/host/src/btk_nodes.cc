@@ -673,6 +673,16 @@ void SnapShotArray::set_samples(const gsl_vector_complex* samp, unsigned chanX)
 {
   memcpy(samples_[chanX]->data, samp->data, sizeof(double) * 2 * fftLen_);
 }
+void SnapShotArray::set_snapshots(const gsl_vector_complex* snapshots, unsigned fbinX)
+{
+  const unsigned fftLen2 = fftLen_ / 2;
+  if (fbinX > fftLen2) throw jindex_error("frequency bin %d is out of range (0..%d)\n", (int)fbinX, (int)fftLen2);
+  if (snapshots->size != nChan_) throw jdimension_error("snapshot of %d channels, %d expected\n", (int)snapshots->size, (int)nChan_);
+  for (unsigned c = 0; c < nChan_; c++) gsl_vector_complex_set(snapshots_[fbinX], c, gsl_vector_complex_get(snapshots, c));
+  if (fbinX == 0 || fbinX == fftLen2) return;
+  for (unsigned c = 0; c < nChan_; c++)                      // the reference's own target index: fftLen/2 - fbinX (beamformer.cc:88-91)
+    gsl_vector_complex_set(snapshots_[fftLen2 - fbinX], c, gsl_complex_conjugate(gsl_vector_complex_get(snapshots, c)));
+}
 void SnapShotArray::update()
 {
   for (unsigned k = 0; k < fftLen_; k++)
@@ -2151,7 +2161,54 @@ void SubbandGSCRLS::upload_weights_()
   }
   if (!dV_) dV_ = dev_alloc(sizeof(double) * 2 * K * N);
   h2d(dV_, bfweight_->wq_v.data(), sizeof(double) * 2 * K * N);                 // bins 0..M/2 of wq [M][N]
+  wq_uploaded_.assign(bfweight_->wq_v.begin(), bfweight_->wq_v.begin() + (size_t)K * N);
   uploaded_version_ = weights_version_;
+}
+
+// New quiescent weights / blocking matrix while the recursion state is kept: the reference's state lives in the space of the
+// active weights (Pz_ is (N - NC) x (N - NC), wa has N - NC entries: beamformer.cc:1480-1515) and simply meets the new blocking
+// matrix B'; this engine keeps P = B Pz B^H and wl = B wa in channel space, so both change basis: with T = B' B^H (B has
+// orthonormal columns) P <- T P T^H, wl <- T wl.  Host float64, bins 1 .. M/2; a rare event (the look direction of an RLS
+// canceller moving between blocks).
+void SubbandGSCRLS::change_basis_(void* dP, void* dW)
+{
+  const unsigned N = chanN(), K = fftLen2_ + 1, NC = bfweight_->NC(), bs = N - NC;
+  std::vector<cd> P((size_t)K * N * N), W((size_t)K * N), B1((size_t)N * bs), Tm((size_t)N * N), TP((size_t)N * N);
+  d2h(P.data(), dP, sizeof(double) * 2 * P.size());
+  d2h(W.data(), dW, sizeof(double) * 2 * W.size());
+  for (unsigned k = 1; k < K; k++) {
+    check_abi(btk_weights_blocking_matrix(reinterpret_cast<const double*>(&wq_uploaded_[(size_t)k * N]), (int)N, (int)NC,
+                                          reinterpret_cast<double*>(B1.data())));
+    const cd* B2 = &bfweight_->B_v[(size_t)k * N * bs];
+    for (unsigned a = 0; a < N; a++)
+      for (unsigned b = 0; b < N; b++) {
+        cd acc(0, 0);
+        for (unsigned j = 0; j < bs; j++) acc += B2[(size_t)a * bs + j] * std::conj(B1[(size_t)b * bs + j]);
+        Tm[(size_t)a * N + b] = acc;
+      }
+    cd* Pk = &P[(size_t)k * N * N];
+    for (unsigned a = 0; a < N; a++)
+      for (unsigned b = 0; b < N; b++) {
+        cd acc(0, 0);
+        for (unsigned c = 0; c < N; c++) acc += Tm[(size_t)a * N + c] * Pk[(size_t)c * N + b];
+        TP[(size_t)a * N + b] = acc;
+      }
+    for (unsigned a = 0; a < N; a++)
+      for (unsigned b = 0; b < N; b++) {
+        cd acc(0, 0);
+        for (unsigned c = 0; c < N; c++) acc += TP[(size_t)a * N + c] * std::conj(Tm[(size_t)b * N + c]);
+        Pk[(size_t)a * N + b] = acc;
+      }
+    std::vector<cd> w(N);
+    for (unsigned a = 0; a < N; a++) {
+      cd acc(0, 0);
+      for (unsigned c = 0; c < N; c++) acc += Tm[(size_t)a * N + c] * W[(size_t)k * N + c];
+      w[a] = acc;
+    }
+    for (unsigned a = 0; a < N; a++) W[(size_t)k * N + a] = w[a];
+  }
+  h2d(dP, P.data(), sizeof(double) * 2 * P.size());
+  h2d(dW, W.data(), sizeof(double) * 2 * W.size());
 }
 
 void SubbandGSCRLS::alloc_state_()
@@ -2283,7 +2340,11 @@ void SubbandGSCRLS::refresh_block_()
     check_hip(hipMemcpy(dW_, dW0_, sizeof(double) * 2 * K * N, hipMemcpyDeviceToDevice), "hipMemcpy D2D");
     check_hip(hipMemcpy(dSS_, dSS0_, sizeof(double) * 4, hipMemcpyDeviceToDevice), "hipMemcpy D2D");
   }
-  if (uploaded_version_ != weights_version_) upload_weights_();
+  if (uploaded_version_ != weights_version_) {
+    const bool had_state = !wq_uploaded_.empty();
+    if (had_state) change_basis_(dP_, dW_);                 // (uses the wq the state was built with, then ...)
+    upload_weights_();                                      // ... the new wq / blocked directions go to the device
+  }
   run_block_();
   rls_version_ = weights_version_;
 }

@@ -331,6 +331,12 @@ PYBIND11_MODULE(_btk20cpp, m)
       .def("set_samples", [](SnapShotArray& a, py::array_t<cd, py::array::c_style | py::array::forcecast> s, unsigned chanX) {
              if ((unsigned)s.size() != a.fftLen()) throw jdimension_error("sample vector has %d entries, fftLen is %d", (int)s.size(), (int)a.fftLen());
              GslCVec v(s); a.set_samples(v.v, chanX); })
+      .def("set_snapshots", [](SnapShotArray& a, py::array_t<cd, py::array::c_style | py::array::forcecast> s, unsigned fbinX) {
+             GslCVec v(s); a.set_snapshots(v.v, fbinX); })
+      .def("newSample", [](SnapShotArray& a, py::array_t<cd, py::array::c_style | py::array::forcecast> s, unsigned chanX) {
+             if ((unsigned)s.size() != a.fftLen()) throw jdimension_error("sample vector has %d entries, fftLen is %d", (int)s.size(), (int)a.fftLen());
+             GslCVec v(s); a.set_samples(v.v, chanX); })
+      .def("getSnapShot", [](SnapShotArray& a, unsigned fbinX) { return copy_of(a.snapshot(fbinX)); })
       .def("update", [](SnapShotArray& a) { a.update(); })
       .def("zero", [](SnapShotArray& a) { a.zero(); })
       .def("snapshot", [](SnapShotArray& a, unsigned fbinX) { return copy_of(a.snapshot(fbinX)); });
@@ -520,7 +526,14 @@ PYBIND11_MODULE(_btk20cpp, m)
       .def("set_all_diagonal_loading", &McCowanPostFilter::set_all_diagonal_loading)
       .def("set_diagonal_looading", &McCowanPostFilter::set_diagonal_looading)
       .def("divide_nondiagonal_elements", &McCowanPostFilter::divide_nondiagonal_elements)
-      .def("divide_all_nondiagonal_elements", &McCowanPostFilter::divide_all_nondiagonal_elements);
+      .def("divide_all_nondiagonal_elements", &McCowanPostFilter::divide_all_nondiagonal_elements)
+      .def("setAllLevelsOfDiagonalLoading", &McCowanPostFilter::set_all_diagonal_loading)
+      .def("setLevelOfDiagonalLoading", &McCowanPostFilter::set_diagonal_looading)
+      .def("divideNonDiagonalElements", &McCowanPostFilter::divide_nondiagonal_elements)
+      .def("divideAllNonDiagonalElements", &McCowanPostFilter::divide_all_nondiagonal_elements)
+      .def("setNoiseSpatialSpectralMatrix", [](McCowanPostFilter& f, unsigned fbinX, py::array_t<cd, py::array::c_style | py::array::forcecast> Rnn) {
+             GslCMat M(Rnn); return f.set_noise_spatial_spectral_matrix(fbinX, M.m); })
+      .def("getNoiseSpatialSpectralMatrix", [](McCowanPostFilter& f, unsigned fbinX) { return copy_of(f.noise_spatial_spectral_matrix(fbinX)); });
   py::class_<LefkimmiatisPostFilter, McCowanPostFilter, cref<LefkimmiatisPostFilter>>(m, "LefkimmiatisPostFilterPtr")
       .def(py::init([](py::object output, unsigned fftlen, double min_sv, unsigned fbin_x1, double alpha, int type, int min_frames,
                        float threshold, const std::string& nm) {

@@ -163,6 +163,15 @@ def test_noise_matrix_accessors_are_range_checked(dev):
                  lambda: pf.divide_nondiagonal_elements(Mh, 0.1), lambda: pf.set_noise_spatial_spectral_matrix(Mh // 2 + 1, R)):
         with pytest.raises(B.jindex_error):
             call()
+    # the ENABLE_LEGACY_BTK_API spellings of the same calls (reference postfilter/postfilter.h:140-148)
+    R2 = R + 0.5 * (np.ones((N, N)) - np.eye(N))
+    assert pf.setNoiseSpatialSpectralMatrix(5, R2) and np.allclose(pf.getNoiseSpatialSpectralMatrix(5), R2)
+    pf.setLevelOfDiagonalLoading(5, 0.25)
+    pf.divideNonDiagonalElements(5, 1.0)
+    assert np.allclose(pf.getNoiseSpatialSpectralMatrix(5), np.eye(N) * 2.25 + 0.25 * (np.ones((N, N)) - np.eye(N)))
+    pf.setAllLevelsOfDiagonalLoading(0.5)
+    pf.divideAllNonDiagonalElements(0.0)
+    assert np.allclose(pf.getNoiseSpatialSpectralMatrix(3), R + 0.5 * np.eye(N))
 
 
 @pytest.mark.gpu

@@ -227,3 +227,51 @@ def test_endless_source_runs_in_bounded_memory(dev, proto256):
     rss1 = resource.getrusage(resource.RUSAGE_SELF).ru_maxrss
     assert acc > 0 and srcs[0].pulled >= 20000
     assert rss1 - rss0 < 64 * 1024, (rss0, rss1)                 # KiB: whole-utterance buffering would add > 100 MB here
+
+
+def test_rls_node_weight_change_before_and_between_blocks(dev, proto256, wavs):
+    """SubbandGSCRLS (beamformer.cc:1447-1699): the recursion of a block ran with the weights of that moment.  New look direction
+    before any frame of the block was served -> the block runs again from the state at its start, with the new quiescent vector
+    and blocked directions on the device and P / w_a carried into the new blocking matrix's basis (the reference keeps them in
+    active-weight space); the result equals a node that had the new weights from the start.  Between two blocks the recursion
+    simply continues in the new basis; after frames of the block were served the node refuses."""
+    from distant_speech_recognition_amd.btk20 import (SampleFeaturePtr, OverSampledDFTAnalysisBankPtr, SubbandGSCRLSPtr, jconsistency_error)
+    from distant_speech_recognition_amd.pybeamformer import calc_delays
+    h, _ = proto256
+    d1 = calc_delays("linear", MPOS.tolist(), [AZIMUTH, None, None])
+    d2 = calc_delays("linear", MPOS.tolist(), [0.4, None, None])
+
+    def node(delays, bfr):
+        bf = SubbandGSCRLSPtr(fftlen=M, half_band_shift=False, mu=0.97, sigma2=0.001)
+        for p in wavs:
+            sf = SampleFeaturePtr(block_len=D, shift_len=D, pad_zeros=True)
+            sf.read(p, FS)
+            a = OverSampledDFTAnalysisBankPtr(sf, prototype=h, M=M, m=m, r=r, delay_compensation_type=2)
+            a.set_block_frames(bfr)
+            bf.set_channel(a)
+        bf.calc_gsc_weights(FS, delays)
+        bf.init_precision_matrix(1.0e6)
+        return bf
+
+    fresh = node(d2, 0)
+    want = np.array(fresh.device_block())
+    moved = node(d1, 0)
+    first = np.array(moved.device_block())                          # the whole utterance ran towards d1 ...
+    moved.calc_gsc_weights(FS, d2)                                  # ... the look direction changes before a frame is pulled
+    got = np.array(moved.device_block())
+    scale = float(np.max(np.abs(want)))
+    assert np.max(np.abs(first - want)) > 1e-3 * scale              # the two directions do differ
+    assert np.max(np.abs(got - want)) <= 1e-5 * scale, float(np.max(np.abs(got - want)) / scale)
+    # between blocks: frames 0..63 towards d1, the rest towards d2 == a whole-utterance node switched at frame 64?  That one
+    # refuses (frames of its only block were served); the blockwise node carries on
+    blk = node(d1, 64)
+    a = [np.array(blk.next()) for _ in range(64)]
+    blk.calc_gsc_weights(FS, d2)
+    b = [np.array(v) for v in blk]
+    assert len(a) + len(b) == first.shape[-1] and np.all(np.isfinite(np.array(b)))
+    whole = node(d1, 0)
+    for _ in range(64):
+        whole.next()
+    whole.calc_gsc_weights(FS, d2)
+    with pytest.raises(jconsistency_error):
+        whole.next()
