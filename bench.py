@@ -289,6 +289,11 @@ def main():
             sfb.synthesize(Yc_, out=out_)
         return _time(chain)
     t_chain = adaptive(pcm, X, Yc, out, nst)
+    # the same chain with the analysis bank running ahead of the canceller on a second HIP stream (engine.AdaptiveGSCChain):
+    # identical output, the two kernels share the chip instead of taking turns
+    pipe = eng.AdaptiveGSCChain(afb, sfb, chunk_frames=512)
+    nst_p = eng.NLMSState(S, M, N, dev)
+    t_chain_pipe = _time(lambda: pipe(pcm, vs, nst_p, X, Yc, out))
     adaptive_wide = None
     if T % 4 == 0 and not args.no_cpu and world == 1:                       # (skipped with --no-cpu: the profiling runs want the headline launch only)
         S2, T2 = 4 * S, T // 4
@@ -401,6 +406,9 @@ def main():
                                    "what": "analysis -> snapshots [S][K][N][T] in HBM -> NLMS sidelobe canceller -> synthesis, end to end, "
                                            "%d streams x %d frames" % (S, T),
                                    "same_frames_as_more_streams": adaptive_wide},
+                "adaptive_chain_two_hip_streams": {"ms": t_chain_pipe * 1e3, "frames_per_s": S * T / t_chain_pipe, "xRT": S * T / t_chain_pipe / (FS / D),
+                                                   "what": "the same chain, the analysis bank running 512-frame chunks ahead of the canceller on a second "
+                                                           "HIP stream (engine.AdaptiveGSCChain); bit-identical output"},
             },
         }
         if not args.no_cpu and world == 1:

@@ -158,3 +158,65 @@ def test_c0_coherence_postfilter_properties(dev):
         assert torch.equal(Ys, Y) and torch.equal(wls, wl)
         Y2, wl2 = run(X * 2, lef)                                               # gains are ratios of quadratic forms
         assert torch.equal(Y2, Y * 2) and torch.equal(wl2, wl)
+
+
+def test_c0_adaptive_chain_full_launch_properties(dev):
+    """The ADAPTIVE chain at bench.py's launch (32 streams x 64 mics x 4096 frames, M = 512: analysis -> snapshots in HBM -> NLMS
+    sidelobe canceller (lib/pybeamformer.py:659-762) -> synthesis), properties that need no float64 oracle run:
+    the two-HIP-stream pipeline (engine.AdaptiveGSCChain) and a split in time give the one-launch chain's bits incl. the state;
+    a stream alone is its slice of the batch; with a zero step size the canceller is the quiescent beamformer vs^H x; and with
+    adaptation on, a target that lies in the look direction passes while the output power does not exceed the quiescent one's."""
+    import torch
+    from distant_speech_recognition_amd import engine as eng
+    from tests.util import la_delays, ula_positions
+    S, N, M, m, r, T = 32, 64, 512, 4, 1, 4096
+    D, K = M >> r, M // 2 + 1
+    afb = eng.FilterBank(design_prototype(M, m), M, m, r, 2)
+    sfb = eng.FilterBank(design_prototype(M, m, "g"), M, m, r, 2, synthesis=True)
+    L = (T - afb.processing_delay + afb.lookahead) * D
+    g = torch.Generator(device=dev).manual_seed(4321)
+    pcm = (torch.randn((S, N, L), device=dev, generator=g) * 1000).round_()
+    pcm += (torch.randn((S, 1, L), device=dev, generator=g) * 3000).round_()           # a broadside target, common to all channels
+    delays = la_delays(ula_positions(N), 0.5 * np.pi)                                 # look direction: broadside (all delays 0)
+    assert np.max(np.abs(delays)) < 1e-12
+    vs = torch.from_numpy(np.stack([np.exp(-2j * np.pi * k * (16000.0 / M) * delays) / N for k in range(K)]).astype(np.complex64)).to(dev)
+    kw = dict(min_frames=16, slowdown_after=1024)
+
+    def fresh():
+        return eng.NLMSState(S, M, N, dev, **kw)
+
+    # one launch per kernel
+    st = fresh()
+    X = afb.analysis(pcm)
+    Y = eng.nlms_process(vs, X, st)
+    out = sfb.synthesize(Y)
+    assert torch.isfinite(out).all() and float(st.u.abs().max()) > 0                   # the canceller adapted
+    # 1. analysis running ahead of the canceller on a second HIP stream: same bits, same state
+    for chunk in (512, 1024):
+        st2, X2 = fresh(), torch.empty_like(X)
+        Y2 = torch.empty_like(Y)
+        out2 = eng.AdaptiveGSCChain(afb, sfb, chunk_frames=chunk)(pcm, vs, st2, X2, Y2)
+        torch.cuda.synchronize()
+        assert torch.equal(out2, out) and torch.equal(Y2, Y) and torch.equal(st2.u, st.u) and torch.equal(st2.sigma2, st.sigma2)
+        assert torch.equal(st2.stream_state, st.stream_state)
+    del X2, Y2
+    # 2. a split in time (blocks of 1024 + 3072 frames) continues the recursion exactly
+    st3 = fresh()
+    Y3 = torch.cat([eng.nlms_process(vs, X[..., :1024].contiguous(), st3), eng.nlms_process(vs, X[..., 1024:].contiguous(), st3)], dim=-1)
+    assert torch.equal(Y3, Y) and torch.equal(st3.u, st.u)
+    del Y3
+    # 3. streams are independent
+    st4 = eng.NLMSState(1, M, N, dev, **kw)
+    assert torch.equal(eng.nlms_process(vs, X[5:6].contiguous(), st4), Y[5:6]) and torch.equal(st4.u, st.u[5:6])
+    # 4. zero step size: the quiescent beamformer Yc = vs^H x
+    st5 = eng.NLMSState(S, M, N, dev, gamma=0.0, **kw)
+    Yq = eng.nlms_process(vs, X, st5)
+    Yref = eng.bf_apply(vs, X)
+    assert float((Yq - Yref).abs().max()) <= 2e-6 * np.sqrt(N) * float(Yref.abs().max()) and not bool(st5.u.any())
+    # 5. the canceller removes what is not in the look direction: less output power than the quiescent beamformer, and the target
+    #    (the common signal: channel mean of the snapshots, which the blocking matrix cannot see) is still there
+    p_q, p_a = float(Yq[..., 64:].abs().double().pow(2).sum()), float(Y[..., 64:].abs().double().pow(2).sum())
+    assert p_a < p_q
+    tgt = X.mean(dim=2)                                                                # broadside: vs^H x is this mean
+    corr = float((Y * tgt.conj()).real.double().sum() / tgt.abs().double().pow(2).sum())
+    assert 0.8 < corr < 1.1, corr

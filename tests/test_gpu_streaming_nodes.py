@@ -265,10 +265,18 @@ def test_rls_node_weight_change_before_and_between_blocks(dev, proto256, wavs):
     # between blocks: frames 0..63 towards d1, the rest towards d2 == a whole-utterance node switched at frame 64?  That one
     # refuses (frames of its only block were served); the blockwise node carries on
     blk = node(d1, 64)
-    a = [np.array(blk.next()) for _ in range(64)]
+    n0 = blk.num_frames()                                            # frames of the first block (64 input blocks minus the look-ahead)
+    assert 32 <= n0 <= 64
+    a = [np.array(blk.next()) for _ in range(n0)]
     blk.calc_gsc_weights(FS, d2)
-    b = [np.array(v) for v in blk]
+    b = []
+    while True:                                                      # (iter() would reset the node)
+        try:
+            b.append(np.array(blk.next()))
+        except StopIteration:
+            break
     assert len(a) + len(b) == first.shape[-1] and np.all(np.isfinite(np.array(b)))
+    assert np.max(np.abs(np.array(a)[:, :M // 2 + 1].T - first[0][:, :n0])) <= 1e-5 * scale       # the first block: still towards d1
     whole = node(d1, 0)
     for _ in range(64):
         whole.next()
