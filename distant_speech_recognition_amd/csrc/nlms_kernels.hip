@@ -29,21 +29,40 @@ namespace {
 constexpr int TB = 16;                 // frames per LDS tile (128-byte rows)
 constexpr int LDW = TB + 1;            // padded row length (float2 units): conflict-free column reads
 
+// |X_0^H X_0| / M of channel 0 per frame (MultiChannelSource.update_snapshot_array, lib/pybeamformer.py:263-277).  A workgroup owns 64
+// frames; its four wavefronts take the bins k = q, q + 4, ... (rows 2 MB apart: every load is its own DRAM page, so the loads of eight
+// bins are in flight before the first is used) and their partial sums are added in a fixed order.  Round 4's one-thread-per-frame loop
+// over all 257 bins ran 0.33-0.64 ms per 32 x 4096 frames on two latency-bound wavefronts per SIMD; this form streams.
 __global__ __launch_bounds__(256)
 void nlms_energy_kernel(const float2* __restrict__ X, int K, int N, int M, long T_stride, long T,
                         float* __restrict__ energy /* [S][e_stride] */, long e_stride)
 {
-  const int s = blockIdx.y;
-  const long t = (long)blockIdx.x * 256 + threadIdx.x;
-  if (t >= T) return;
-  const float2* x = X + (long)s * K * N * T_stride + t;        // channel 0
+  __shared__ float part[4][64];
+  const int s = blockIdx.y, lane = threadIdx.x & 63, q = threadIdx.x >> 6;
+  const long t = (long)blockIdx.x * 64 + lane;
+  const bool ok = t < T;
+  const float2* x = X + (long)s * K * N * T_stride + (ok ? t : 0);   // channel 0
+  const long kstep = (long)N * T_stride;
   float acc = 0.f;
-  for (int k = 0; k < K; k++) {
-    const float2 v = x[(long)k * N * T_stride];
-    const float p = fmaf(v.x, v.x, v.y * v.y);
-    acc += (k == 0 || k == K - 1) ? p : 2.f * p;               // mirror bins M-k carry |X_k|^2 again
+  int k = q;
+  for (; k + 28 < K; k += 32) {
+    float2 v[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) v[j] = x[(long)(k + 4 * j) * kstep];
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      const float p = fmaf(v[j].x, v[j].x, v[j].y * v[j].y);
+      acc += (k + 4 * j == 0 || k + 4 * j == K - 1) ? p : 2.f * p;   // mirror bins M-k carry |X_k|^2 again
+    }
   }
-  energy[(long)s * e_stride + t] = acc / (float)M;
+  for (; k < K; k += 4) {
+    const float2 v = x[(long)k * kstep];
+    const float p = fmaf(v.x, v.x, v.y * v.y);
+    acc += (k == 0 || k == K - 1) ? p : 2.f * p;
+  }
+  part[q][lane] = acc;
+  __syncthreads();
+  if (q == 0 && ok) energy[(long)s * e_stride + t] = ((part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane])) / (float)M;
 }
 
 struct NlmsParams {
@@ -545,7 +564,7 @@ int btk_frame_energy(const void* X, int S, int M, int N, long T_stride, long T, 
   if (!X || !energy) return btk_set_error(BTK_ERR_PARAMETER, "btk_frame_energy: null argument");
   if (S <= 0 || N <= 0 || T < 0 || T_stride < T || e_stride < T) return btk_set_error(BTK_ERR_DIMENSION, "btk_frame_energy: bad sizes");
   if (T == 0) return BTK_OK;
-  hipLaunchKernelGGL(nlms_energy_kernel, dim3((unsigned)((T + 255) / 256), (unsigned)S), dim3(256), 0, as_stream(stream),
+  hipLaunchKernelGGL(nlms_energy_kernel, dim3((unsigned)((T + 63) / 64), (unsigned)S), dim3(256), 0, as_stream(stream),
                      static_cast<const float2*>(X), M / 2 + 1, N, M, T_stride, T, energy, e_stride);
   BTK_HIP_CHECK(hipGetLastError());
   return BTK_OK;
@@ -588,7 +607,7 @@ int btk_nlms_process_nc(const float* params /* host, 8 floats */, const void* vs
   double* state_before = reinterpret_cast<double*>((reinterpret_cast<uintptr_t>(ctrl + (long)S * T) + 63) & ~(uintptr_t)63);
   const float2* Xp = static_cast<const float2*>(X);
 
-  hipLaunchKernelGGL(nlms_energy_kernel, dim3((unsigned)((T + 255) / 256), (unsigned)S), dim3(256), 0, st,
+  hipLaunchKernelGGL(nlms_energy_kernel, dim3((unsigned)((T + 63) / 64), (unsigned)S), dim3(256), 0, st,
                      Xp, K, N, M, T_stride, T, energy, T);
   BTK_HIP_CHECK(hipMemcpyAsync(state_before, stream_state, sizeof(double) * 4 * S, hipMemcpyDeviceToDevice, st));
   hipLaunchKernelGGL(nlms_control_kernel, dim3((unsigned)S), dim3(64), 0, st, energy, T, p, stream_state, ctrl);

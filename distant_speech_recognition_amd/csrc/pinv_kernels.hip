@@ -300,8 +300,14 @@ void mvdr_gj_kernel(const float2* __restrict__ R, const float2* __restrict__ Dq,
         f[i] = cd2{(double)(h & 0xffff) / 32768.0 - 1.0, (double)(h >> 16) / 32768.0 - 1.0};
       }
       __syncthreads();
+      // The iterate approaches 1 / sigma_min^2 from BELOW, i.e. sigma_min is over-estimated until it has converged; a plateau on
+      // a non-dominant component or a cluster of small singular values could hide one that is under the threshold.  So the early
+      // stop (relative gain <= 1e-7 after 8 steps, at most 40) only decides bins whose estimate is clear of the threshold; an
+      // estimate within a factor 4 above it keeps iterating -- up to 400 steps, gain <= 1e-12 -- before the bin is called regular.
       double mu = 0.0;
-      for (int it = 0; it < 40; it++) {
+      int limit = 40;
+      double gain = 1.0e-7;
+      for (int it = 0; it < limit; it++) {
         const double n2 = norm2(f);
         const double sc = n2 > 0.0 ? 1.0 / sqrt(n2) : 0.0;
         for (int i = tid; i < N; i += NT) f[i] = cd2{f[i].x * sc, f[i].y * sc};
@@ -309,9 +315,14 @@ void mvdr_gj_kernel(const float2* __restrict__ R, const float2* __restrict__ Dq,
         matvec(f, rk);                                                     // y = R^-1 x
         __syncthreads();
         const double mu_new = norm2(rk);                                   // -> 1 / sigma_min^2 from below
-        const bool done = it >= 8 && mu_new <= mu * (1.0 + 1.0e-7);
+        bool done = it >= 8 && mu_new <= mu * (1.0 + gain);
         mu = mu_new;
-        if (done || !(mu < 1.0e300)) break;                                // uniform
+        if (!(mu < 1.0e300)) break;                                        // uniform
+        const double est = mu > 0.0 ? 1.0 / sqrt(mu) : 0.0;
+        if ((done || it + 1 == limit) && limit == 40 && (float)est >= threshold && est < 4.0 * (double)threshold) {
+          limit = 400; gain = 1.0e-12; done = false;                       // close call: do not stop on the loose criterion
+        }
+        if (done) break;
         matvec_h(rk, f);                                                   // x = R^-H y
         __syncthreads();
       }

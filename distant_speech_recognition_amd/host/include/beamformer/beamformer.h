@@ -90,7 +90,10 @@ class BeamformerWeights {
   gsl_matrix_complex** B() const { return B_views_; }
   gsl_vector_complex** wa() const { return wa_views_; }
   gsl_vector_complex** CSDs() const { if (csd_provider_) csd_provider_(CSDs_); return CSDs_; }
-  void set_csd_provider(const std::function<void(gsl_vector_complex**)>& f) { csd_provider_ = f; }
+  // owner: the post-filter that installs / removes the provider; a filter only removes the provider it installed itself (another
+  // filter may have bound itself to the same weight object since)
+  void set_csd_provider(const std::function<void(gsl_vector_complex**)>& f, const void* owner = NULL) { csd_provider_ = f; csd_owner_ = f ? owner : NULL; }
+  void clear_csd_provider(const void* owner) { if (csd_owner_ == owner) { csd_provider_ = nullptr; csd_owner_ = NULL; } }
   gsl_vector_complex* wp1() const { return wp1_; }
   unsigned fftLen() const { return fftLen_; }
   unsigned chanN() const { return chanN_; }
@@ -104,6 +107,7 @@ class BeamformerWeights {
   gsl_matrix_complex** B_views_;
   gsl_vector_complex* wp1_;
   std::function<void(gsl_vector_complex**)> csd_provider_;
+  const void* csd_owner_ = NULL;
 };
 
 class SubbandBeamformer : public VectorComplexFeatureStream {

@@ -1595,7 +1595,7 @@ ZelinskiPostFilter::ZelinskiPostFilter(VectorComplexFeatureStreamPtr& output, un
 
 ZelinskiPostFilter::~ZelinskiPostFilter()
 {
-  if (has_bf_ptr_ && bf_ptr_->beamformer_weight_object()) bf_ptr_->beamformer_weight_object()->set_csd_provider(nullptr);
+  if (has_bf_ptr_ && bf_ptr_->beamformer_weight_object()) bf_ptr_->beamformer_weight_object()->clear_csd_provider(this);
   dev_free(dPhi_); dev_free(dPsi_); dev_free(dWl_); gsl_vector_complex_free(wp1_);
   delete own_weights_;
 }
@@ -1619,7 +1619,7 @@ void ZelinskiPostFilter::set_array_manifold_vector(unsigned fbinX, gsl_vector_co
   const unsigned chanN = (unsigned)v->size;
   if (!own_weights_) {
     own_weights_ = new BeamformerWeights(size(), chanN, halfBandShift, NC);
-    own_weights_->set_csd_provider([this](gsl_vector_complex** out) { fill_csds_(out); });
+    own_weights_->set_csd_provider([this](gsl_vector_complex** out) { fill_csds_(out); }, this);
   }
   if (chanN != own_weights_->chanN()) throw jdimension_error("array manifold vector of %d channels, %d expected\n", chanN, own_weights_->chanN());
   gsl_vector_complex** dst = (type_ & TYPE_ZELINSKI2) ? own_weights_->wq() : own_weights_->arrayManifold();
@@ -1629,7 +1629,7 @@ void ZelinskiPostFilter::set_array_manifold_vector(unsigned fbinX, gsl_vector_co
 void ZelinskiPostFilter::bind_csd_provider_()
 {
   if (has_bf_ptr_ && bf_ptr_->beamformer_weight_object())
-    bf_ptr_->beamformer_weight_object()->set_csd_provider([this](gsl_vector_complex** out) { fill_csds_(out); });
+    bf_ptr_->beamformer_weight_object()->set_csd_provider([this](gsl_vector_complex** out) { fill_csds_(out); }, this);
 }
 
 // BeamformerWeights::CSDs() on demand (postfilter.cc:77-116): Phi_ij <- a Phi_ij + (1 - a) x'_i conj x'_j for i < j and the same

@@ -501,9 +501,12 @@ PYBIND11_MODULE(_btk20cpp, m)
       .def("setArrayManifoldVector", [](ZelinskiPostFilter& f, unsigned fbinX, py::array_t<cd, py::array::c_style | py::array::forcecast> v, bool halfBandShift, unsigned NC) {
              GslCVec g(v); f.set_array_manifold_vector(fbinX, g.v, halfBandShift, NC); },
            py::arg("fbinX"), py::arg("arrayManifoldVector"), py::arg("halfBandShift"), py::arg("NC") = 1)
-      .def("weights_object", [](ZelinskiPostFilter& f) -> py::object {      // bf_weights_ (postfilter.h:104); None before any weights exist
+      .def("weights_object", [](py::object self) -> py::object {            // bf_weights_ (postfilter.h:104); None before any weights exist
+             ZelinskiPostFilter& f = self.cast<ZelinskiPostFilter&>();
              BeamformerWeights* w = f.weights_object();
-             return w ? py::cast(w, py::return_value_policy::reference) : py::none(); })
+             // the handle keeps the post-filter alive (reference_internal): the filter owns the object it made for
+             // set_array_manifold_vector(), and keeps its beamformer -- the owner otherwise -- alive itself
+             return w ? py::cast(w, py::return_value_policy::reference_internal, self) : py::none(); })
       .def("getPostFilterWeights", [](ZelinskiPostFilter& f) { return copy_of(f.postfilter_weights()); })
       .def("postfilter_weights", [](ZelinskiPostFilter& f) { return copy_of(f.postfilter_weights()); })
       .def("device_block", [](ZelinskiPostFilter& f) { return block_of(f); })
