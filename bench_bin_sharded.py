@@ -29,7 +29,9 @@ def main():
     # regroups the snapshots by bin (predicted 2.7 x at 8 GPUs against 1.6 x, DESIGN.md section 6 -- to be decided on the node)
     # "frames": static weights only -- no bin shards at all: every rank runs the FUSED analysis -> beamformer kernel over its range of
     # frames and the one all-gather runs along the frame axis (sharding.pipeline_frame_sharded)
-    ap.add_argument("--analysis-input", choices=["replicated", "channels", "frames"], default="replicated")
+    # round 5: the default -- this bench's weights (diffuse-noise MVDR) ARE static; "replicated" / "channels" are what adaptive
+    # statistics per bin need
+    ap.add_argument("--analysis-input", choices=["replicated", "channels", "frames"], default="frames")
     args = ap.parse_args()
     import torch
     from distant_speech_recognition_amd import engine as eng, sharding

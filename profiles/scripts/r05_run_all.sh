@@ -22,7 +22,8 @@ DB=$(find $O/prof -name "*.db" | head -1)
 cd $R
 python bench_stages.py > $O/bench_stages.json 2> $O/bench_stages.err
 python bench_configs.py > $O/bench_configs.json 2> $O/bench_configs.err
-python bench_bin_sharded.py > $O/bench_bin_sharded.json 2> $O/bench_bin_sharded.err
+python bench_bin_sharded.py > $O/bench_bin_sharded.json 2> $O/bench_bin_sharded.err                                   # (default: frame-range partition of the fused operator)
+python bench_bin_sharded.py --analysis-input replicated > $O/bench_bin_sharded_replicated.json 2> $O/bench_bin_sharded_replicated.err
 BTK_FUSED_VAR=33231 bash profiles/scripts/r02_pmc_fused.sh > $O/pmc_fused_sq.txt 2>&1
 for v in 33743; do BTK_FUSED_VAR=$v python profiles/fused_ab.py 2>&1 | grep -E "phases|ms"; done > $O/fused_phase_timing.txt 2>&1
 for v in 33231; do BTK_FUSED_VAR=$v PROBE_SECONDS=6 python profiles/clock_probe.py 2>/dev/null | tail -1; done > $O/clock_probe.txt

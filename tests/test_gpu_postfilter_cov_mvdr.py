@@ -629,3 +629,32 @@ def test_coherence_postfilters_on_row_padded_snapshots(dev, N):
                 outs.append(eng.bf_apply_mccowan(d, d, X, st, alpha=0.7))
         assert outs[1].stride(1) == Xp.stride(2) and outs[0].is_contiguous()
         assert torch.equal(outs[0], outs[1])
+
+
+@pytest.mark.parametrize("N", [96, 200])
+def test_mvdr_pinv_gpu_threshold_close_calls(dev, N):
+    """The Gauss-Jordan + power-iteration form of the pseudo-inverse rule (N > 70) on matrices whose smallest singular value sits
+    just under / just above the threshold, alone and hidden in a cluster of values slightly above it (the iterate approaches
+    1 / sigma_min^2 from below: a loose stop would over-estimate sigma_min): identity exactly where sigma_min < threshold."""
+    import torch
+    rng = np.random.default_rng(N)
+    thr = 1.0e-3
+    K = 7
+    Q, _ = np.linalg.qr(rng.normal(size=(N, N)) + 1j * rng.normal(size=(N, N)))
+    base = np.linspace(0.5, 3.0, N)
+    base[0] = -1.0                                                    # indefinite: the Cholesky solve never takes these bins
+    want = []
+    R = np.zeros((K, N, N), np.complex128)
+    for k, (smin, cluster) in enumerate([(None, 0), (0.8 * thr, 0), (1.25 * thr, 0), (0.8 * thr, 12), (1.25 * thr, 12), (0.97 * thr, 3), (1.03 * thr, 3)]):
+        sv = base.copy()
+        if smin is not None:
+            sv[-1] = smin
+            sv[-1 - cluster:-1] = thr * np.linspace(1.3, 1.6, cluster) if cluster else sv[-1 - cluster:-1]
+        R[k] = (Q * sv) @ Q.conj().T
+        want.append(smin is not None and smin < thr)
+    from distant_speech_recognition_amd import engine as eng
+    d = (np.exp(-2j * np.pi * rng.uniform(size=(K, N))) / N).astype(np.complex64)
+    (Wg, nig, _), _ = _pinv_fallback_both(eng, torch.from_numpy(R.astype(np.complex64)).to(dev), torch.from_numpy(d).to(dev), thr, first_bin=1)
+    got = [bool(np.allclose(Wg[k], d[k] / (N * np.vdot(d[k], d[k])), atol=1e-7 / N)) for k in range(K)]
+    assert got == want, (got, want)
+    assert nig == sum(want)

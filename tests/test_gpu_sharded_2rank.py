@@ -98,6 +98,11 @@ def test_bench_two_ranks_contract(dev):
     assert d["unit"] == "frames/s" and d["cpu_baseline"] is None and "roofline" in d and d["config"]["parallelism"].endswith("x2")
     # whole-job aggregate: 2 ranks x 4 streams x 1024 frames per step
     assert abs(d["value"] - 2 * 4 * 1024 / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
+    # round 5: the line shows N ranks -- the world size the communicator itself reports and every rank's own rate (the job's value is
+    # the units of all ranks over the SLOWEST rank's time, so it cannot exceed the sum of the ranks' own rates)
+    assert d["config"]["rccl_world"] == 2 and d["config"]["dist_backend"] == "gloo"
+    pr = d["config"]["per_rank_frames_per_s"]
+    assert len(pr) == 2 and all(v > 0 for v in pr) and d["value"] <= sum(pr) * (1 + 1e-9)
 
 
 @pytest.mark.parametrize("M,r,N", [(512, 1, 5), (256, 1, 3), (2048, 1, 2), (64, 0, 4), (128, 2, 3)])
