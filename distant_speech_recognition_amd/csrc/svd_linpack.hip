@@ -32,7 +32,19 @@ __host__ __device__ inline size_t lp_small_lds(int n, int p)
   return sizeof(float2) * ((size_t)4 * n + (size_t)3 * p + 9) + sizeof(float) * 2 * (size_t)lp_m(n, p) + 16;
 }
 inline size_t lp_mat_lds(int n, int p) { return sizeof(float2) * (size_t)n * lp_ld(p); }
-inline bool lp_in_lds(int n, int p) { return lp_small_lds(n, p) + lp_mat_lds(n, p) <= (size_t)150 * 1024; }
+// Where the working copy of a matrix lives.  A bin is mostly ONE thread's serial work (scnrm2's scaled sums, the QR sweeps: serial
+// in the reference's rounding order), so the batch runs at the latency of a bin as long as every bin is resident at once.  LDS holds
+// 160 KB / (matrix + work arrays) bins per CU -- four at 64 channels --; a batch beyond that (the designs of several streams in one
+// call) keeps its matrices in a global scratch copy (L2) instead, where a CU takes as many bins as it has wavefront slots.
+inline bool lp_fits_lds(int n, int p) { return lp_small_lds(n, p) + lp_mat_lds(n, p) <= (size_t)150 * 1024; }
+inline bool lp_in_lds(int K, int n, int p)
+{
+  if (!lp_fits_lds(n, p)) return false;
+  const size_t per_cu = ((size_t)160 * 1024) / (lp_small_lds(n, p) + lp_mat_lds(n, p) + 512);
+  return (size_t)K <= 256 * (per_cu ? per_cu : 1);
+}
+// one wavefront per bin up to 64 x 64 (every column / row has its thread, barriers cost nothing), four above
+inline int lp_threads(int n, int p) { return (n <= 64 && p <= 64) ? 64 : LP_THREADS; }
 
 // A [K][n][p] complex64 row-major.  s_out / e_out [K][m] (may be null), info_out [K] (may be null).
 // rule_flags (may be null) [K]: 1 where pseudoinverse() returns false.  A DC bin (skip_dc: bin 0 of the whole spectrum /
@@ -48,7 +60,7 @@ void csvdc_values_kernel(const float2* __restrict__ A, int n, int p, float* __re
   const int k = blockIdx.x, tid = threadIdx.x, m = lp_m(n, p);
   if (skip_dc && (kper > 0 ? (k % kper) == 0 : (k + k_offset) == 0)) {
     if (tid == 0) { if (info_out) info_out[k] = 0; if (rule_flags) rule_flags[k] = 0; }
-    for (int i = tid; i < m; i += LP_THREADS) { if (s_out) s_out[(long)k * m + i] = 0.f; if (e_out) e_out[(long)k * m + i] = 0.f; }
+    for (int i = tid; i < m; i += (int)blockDim.x) { if (s_out) s_out[(long)k * m + i] = 0.f; if (e_out) e_out[(long)k * m + i] = 0.f; }
     return;
   }
   cf* col = reinterpret_cast<cf*>(smem);
@@ -64,7 +76,7 @@ void csvdc_values_kernel(const float2* __restrict__ A, int n, int p, float* __re
   const int ld = IN_LDS ? lp_ld(p) : p;
   cf* x = IN_LDS ? reinterpret_cast<cf*>(smem + small) : reinterpret_cast<cf*>(scratch + (long)k * n * p);
   const float2* Ak = A + (long)k * n * p;
-  for (int idx = tid; idx < n * p; idx += LP_THREADS) {
+  for (int idx = tid; idx < n * p; idx += (int)blockDim.x) {
     const float2 v = Ak[idx];
     x[(long)(idx / p) * ld + (idx % p)] = lpk::mk(v.x, v.y);
   }
@@ -80,7 +92,7 @@ void csvdc_values_kernel(const float2* __restrict__ A, int n, int p, float* __re
       rule_flags[k] = bad;
     }
   }
-  for (int i = tid; i < m; i += LP_THREADS) { if (s_out) s_out[(long)k * m + i] = s[i]; if (e_out) e_out[(long)k * m + i] = e[i]; }
+  for (int i = tid; i < m; i += (int)blockDim.x) { if (s_out) s_out[(long)k * m + i] = s[i]; if (e_out) e_out[(long)k * m + i] = e[i]; }
 }
 
 // invR = identity (beamformer.cc:2381-2396): tmpH = d, Lambda = d^H d, w = d / (N Lambda).  One wavefront per flagged bin;
@@ -112,14 +124,14 @@ int launch_values(const void* A, int K, int n, int p, float* s, float* e, int* i
 {
   if (!A) return btk_set_error(BTK_ERR_PARAMETER, "btk_csvdc_values: null argument");
   if (K < 1 || n < 1 || p < 1 || n > 2048 || p > 2048) return btk_set_error(BTK_ERR_DIMENSION, "btk_csvdc_values: bad sizes K=%d n=%d p=%d", K, n, p);
-  const bool in_lds = lp_in_lds(n, p);
-  if (!in_lds && !scratch) return btk_set_error(BTK_ERR_PARAMETER, "btk_csvdc_values: %d x %d needs a scratch buffer (btk_csvdc_scratch_bytes)", n, p);
+  const bool in_lds = lp_in_lds(K, n, p);
+  if (!in_lds && !scratch) return btk_set_error(BTK_ERR_PARAMETER, "btk_csvdc_values: %d matrices of %d x %d need a scratch buffer (btk_csvdc_scratch_bytes)", K, n, p);
   const size_t small = (lp_small_lds(n, p) + 15) & ~(size_t)15;
   const size_t lds = small + (in_lds ? lp_mat_lds(n, p) : 0);
   auto kern = in_lds ? csvdc_values_kernel<true> : csvdc_values_kernel<false>;
   if (lds > 64 * 1024)
     BTK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(kern, dim3((unsigned)K), dim3(LP_THREADS), lds, st, static_cast<const float2*>(A), n, p, s, e, info,
+  hipLaunchKernelGGL(kern, dim3((unsigned)K), dim3((unsigned)lp_threads(n, p)), lds, st, static_cast<const float2*>(A), n, p, s, e, info,
                      static_cast<float2*>(scratch), threshold, rule_flags, skip_dc, k_offset, kper);
   BTK_HIP_CHECK(hipGetLastError());
   return BTK_OK;
@@ -132,7 +144,7 @@ extern "C" {
 long btk_csvdc_scratch_bytes(int K, int n, int p)
 {
   if (K < 1 || n < 1 || p < 1) return 0;
-  return lp_in_lds(n, p) ? 0 : (long)sizeof(float2) * K * n * p;
+  return lp_in_lds(K, n, p) ? 0 : (long)sizeof(float2) * K * n * p;
 }
 
 int btk_csvdc_values(const void* A, int K, int n, int p, float* s, float* e, int* info, void* scratch, void* stream)
