@@ -21,7 +21,7 @@ const btk_switches_t& btk_switches()
     btk_switches_t s;
     s.disable_analysis512 = flag("BTK_DISABLE_ANALYSIS512"); s.disable_synthesis512 = flag("BTK_DISABLE_SYNTHESIS512");
     s.disable_fast = flag("BTK_DISABLE_FAST"); s.disable_fused = flag("BTK_DISABLE_FUSED");
-    s.nlms_v1 = flag("BTK_NLMS_V1"); s.wpe_noskip = flag("BTK_WPE_NOSKIP"); s.wpe_timing = flag("BTK_WPE_TIMING"); s.syn_narrow = flag("BTK_SYN_NARROW"); s.rls_packed = flag("BTK_RLS_PACKED"); s.wpe_herk_blocks = flag("BTK_WPE_HERK_BLOCKS"); s.wpe_solve_panel = flag("BTK_WPE_SOLVE_PANEL"); s.wpe_solve_reg = flag("BTK_WPE_SOLVE_REG"); s.wpe_predict_valu = flag("BTK_WPE_PREDICT_VALU");
+    s.nlms_v1 = flag("BTK_NLMS_V1"); s.wpe_noskip = flag("BTK_WPE_NOSKIP"); s.wpe_timing = flag("BTK_WPE_TIMING"); s.syn_narrow = flag("BTK_SYN_NARROW"); s.rls_packed = flag("BTK_RLS_PACKED"); s.wpe_herk_blocks = flag("BTK_WPE_HERK_BLOCKS"); s.wpe_solve_panel = flag("BTK_WPE_SOLVE_PANEL"); s.wpe_solve_reg = flag("BTK_WPE_SOLVE_REG"); s.wpe_predict_valu = flag("BTK_WPE_PREDICT_VALU"); s.wpe_lagprod_f32 = flag("BTK_WPE_LAGPROD_F32"); { const char* e = getenv("BTK_WPE_LAGPROD_WAVES"); s.wpe_lagprod_waves = e ? atoi(e) : 2; }
     s.nlms_alt = num("BTK_NLMS_ALT", 0); s.mvdr_reg_min = num("BTK_MVDR_REG_MIN", 64); s.fused_var = num("BTK_FUSED_VAR", -1);
     s.pf_jb = num("BTK_PF_JB", 0);
     s.pf_tpw = num("BTK_PF_TPW", 0);

@@ -22,7 +22,9 @@ int btk_set_error(int code, const char* fmt, ...);
 // that sizing and dispatch can never disagree; production runs leave them unset.
 struct btk_switches_t {
   bool disable_analysis512, disable_synthesis512, disable_fast, disable_fused, nlms_v1, wpe_noskip, wpe_timing, syn_narrow, rls_packed, wpe_solve_panel, wpe_solve_reg, wpe_herk_blocks /* BTK_WPE_HERK_BLOCKS: the round-2 block HERK instead of the lag-product form */,
-       wpe_predict_valu /* BTK_WPE_PREDICT_VALU: the vector prediction kernel instead of the matrix-core one */;
+       wpe_predict_valu /* BTK_WPE_PREDICT_VALU: the vector prediction kernel instead of the matrix-core one */,
+       wpe_lagprod_f32 /* BTK_WPE_LAGPROD_F32: the float32 matrix instruction in the lag-product kernel (round 4) instead of the float16-split form */;
+  int wpe_lagprod_waves /* BTK_WPE_LAGPROD_WAVES: 4 = four wavefronts x one column block per task (A/B: 8.6 ms per stream) instead of two x two (7.3, the default) */;
   int mvdr_reg_min /* BTK_MVDR_REG_MIN: channel count from which the MVDR design runs on the register-resident solver (default 64) */, nlms_alt, fused_var /* -1: default */, pf_jb, pf_tpw /* 0: default */, pf_mfma_min /* channels from which the matrix-core statistics kernel runs */;
 };
 const btk_switches_t& btk_switches();

@@ -606,6 +606,283 @@ __device__ __forceinline__ void lagprod_task(const float2* __restrict__ Xk, cons
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Round 5: the same lag-product GEMM on the float16 matrix instruction (v_mfma_f32_32x32x16_f16: 16 frames per instruction at 16 x the
+// rate of v_mfma_f32_32x32x2_f32) with BOTH operands split into a high and a low float16 part, a = ah + al, b = bh + bl, and three
+// products ah bh + ah bl + al bh accumulated in float32: the dropped al bl term and the parts' own rounding are 2^-22 of |a| |b|, i.e.
+// the accuracy of the float32 instruction it replaces (one bin, 8 channels x 33 lags, 1000 frames against float64: max |R - R64| /
+// max |R64| 1.1e-7 for the split, 1.3e-7 for float32 products; filter taps 4.7e-6 vs 5.3e-6).  float16's range is met by one power-of-two
+// scale per (stream, bin) and operand (wpe_lp_scale_kernel: 2^14 / max, exact to undo).  48 matrix instructions of 32 cycles per 16 frames
+// of a task instead of 128 of 64.  The Hankel operand Wh[(l1, c)][u] = w_c(u + l1) needs 8 consecutive float16 values starting at ANY
+// index: the weight span of a tile is kept in LDS as its eight one-frame shifts, split, so that every read is one aligned 16-byte word.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef __fp16 fp16x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ unsigned pk_hi(float a, float b) { return __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(a, b)); }
+__device__ __forceinline__ f16x8 mk8(unsigned a, unsigned b, unsigned c, unsigned d)
+{
+  const uint4 v = make_uint4(a, b, c, d);
+  return __builtin_bit_cast(f16x8, v);
+}
+
+// scales[(s K + k) 2 + {0, 1}] = power of two that brings the largest weight / the bound 2 max|y|^2 of the products to < 2^14
+__global__ __launch_bounds__(256)
+void wpe_lp_scale_kernel(const float2* __restrict__ X, const float* __restrict__ Winv, WpeGeom g, float* __restrict__ scales)
+{
+  __shared__ float red[2][4];
+  const int k = blockIdx.x, s = blockIdx.y, tid = threadIdx.x;
+  float wm = 0.f, ym = 0.f;
+  if (bin_active(g, k)) {
+    for (int c = 0; c < g.C; c++) {
+      const float* w = Winv + (((long)s * g.C + c) * g.K + k) * g.T_stride;
+      const float2* y = X + (((long)s * g.K + k) * g.C + c) * g.T_stride;
+      for (long t = tid; t < g.T; t += 256) {
+        if (t >= g.lowerN) wm = fmaxf(wm, w[t]);
+        const float2 v = y[t];
+        ym = fmaxf(ym, fmaf(v.x, v.x, v.y * v.y));
+      }
+    }
+  }
+  for (int o = 32; o > 0; o >>= 1) { wm = fmaxf(wm, __shfl_xor(wm, o)); ym = fmaxf(ym, __shfl_xor(ym, o)); }
+  if ((tid & 63) == 0) { red[0][tid >> 6] = wm; red[1][tid >> 6] = ym; }
+  __syncthreads();
+  if (tid == 0) {
+    wm = fmaxf(fmaxf(red[0][0], red[0][1]), fmaxf(red[0][2], red[0][3]));
+    ym = 2.f * fmaxf(fmaxf(red[1][0], red[1][1]), fmaxf(red[1][2], red[1][3]));
+    int ea = 0, eb = 0;
+    if (wm > 0.f && wm < 3.0e38f) (void)frexpf(wm, &ea);                     // wm < 2^ea
+    if (ym > 0.f && ym < 3.0e38f) (void)frexpf(ym, &eb);
+    scales[((long)s * g.K + k) * 2 + 0] = ldexpf(1.f, 14 - ea);
+    scales[((long)s * g.K + k) * 2 + 1] = ldexpf(1.f, 14 - eb);
+  }
+}
+
+// 8-frame blocks of a shifted weight span: a row's shift within its task is at most RL LP_RMAX - 1 frames (15 at 8 channels, 31 at 4)
+__host__ __device__ constexpr int lp16_nb(int C) { return 8 + (32 / C * 4 - 1) / 8; }
+
+// b - (float)h as ONE instruction: v_fma_mix_f32 reads the float16 operand in place (no separate conversion)
+__device__ __forceinline__ float sub_h_lo(float b, unsigned hpair)
+{
+  float r;
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(hpair), "v"(b));
+  return r;
+}
+__device__ __forceinline__ float sub_h_hi(float b, unsigned hpair)
+{
+  float r;
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(hpair), "v"(b));
+  return r;
+}
+// (a, b) -> packed float16 high parts (round toward zero) and packed float16 remainders: 4 instructions per pair
+__device__ __forceinline__ void split2m(float a, float b, unsigned& hi, unsigned& lo)
+{
+  hi = pk_hi(a, b);
+  lo = pk_hi(sub_h_lo(a, hi), sub_h_hi(b, hi));
+}
+
+// One task = (lag difference d, up to four 32-row blocks) as before, but run by TWO wavefronts that share the staged tile: wavefront wv
+// owns the column blocks 2 wv, 2 wv + 1 (8 accumulator blocks = 128 registers), so that two wavefronts fit a SIMD and one's operand
+// preparation (LDS reads, products, float16 splits: ~3 vector instructions per matrix instruction) runs under the other's matrix
+// instructions.  (One wavefront per SIMD with all 16 accumulator blocks measured no faster than the float32 kernel: with nothing else
+// resident every LDS wait and every dependent vector instruction is exposed, ~22 cycles per instruction.)
+template <int C, int NR, int NCW>
+__device__ __forceinline__ void lagprod16_task(const float2* __restrict__ Xk, const float* __restrict__ Wk, const WpeGeom& g, float2* __restrict__ R,
+                                               int ys_ld, int ws_ld, int d, int la, int s, int k, float2* ys, float* ws, uint4* wcp,
+                                               float sa, float sb)
+{
+  static_assert(C == 8 && (NCW == 1 || NCW == 2), "4 / NCW wavefronts x NCW column blocks");   // column blocks per wavefront: col = 2 (c1 C + c2) + (0 re | 1 im)
+  constexpr int RL = 32 / C;                                       // l1 values per 32-row block: row m of block j -> (l1 = la + RL j + m / C, c = m % C)
+  constexpr int LP16_NB = lp16_nb(C);
+  static_assert(LP_RMAX == 4, "lp16_nb");
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int L = g.L, P = C * L;
+  const int YN = LP_WT + L - 1;                                    // samples per channel span (<= 128: L <= 65)
+  constexpr int WN = LP_WT + RL * NR - 1;                          // weights per target-channel span
+  float2* ysp = ys + C * ys_ld;                                    // the second factors ready to multiply: [2 (re | im column)][C][ys_ld], scaled
+  float2 ypf[C];
+  float wpf[C];
+  auto prefetch = [&](long u0) {                                   // threads 0 .. 127: one sample and one weight per channel and thread
+    const int e = tid;
+    if (e >= 128) return;
+    const long u = u0 + e;
+    const long t = u0 + g.lowerN + la + e;
+#pragma unroll
+    for (int c = 0; c < C; c++) {
+      ypf[c] = (e < YN && u < g.T) ? Xk[(long)c * g.T_stride + u] : make_float2(0.f, 0.f);
+      wpf[c] = (e < WN && t >= g.lowerN && t < g.T) ? Wk[(long)c * g.K * g.T_stride + t] * sa : 0.f;
+    }
+  };
+  f32x16 acc[NR][NCW];
+#pragma unroll
+  for (int j = 0; j < NR; j++)
+#pragma unroll
+    for (int cb = 0; cb < NCW; cb++) acc[j][cb] = f32x16{0};
+  const int m = lane & 31, lk = lane >> 5;
+  const bool im = lane & 1;
+  // A of block j: the 8 weights w_c(u0 + lowerN + la + e), e = kk + 8 lk + sh .. + 7, sh = RL j + m / C: copy (sh & 7) at the aligned
+  // offset kk + 8 lk + (sh & ~7).  wcp[((hl 8 + copy) C + c) LP16_NB + block] (uint4 = 8 float16)
+  int aidx[NR];
+#pragma unroll
+  for (int j = 0; j < NR; j++) { const int sh = RL * j + m / C; aidx[j] = ((sh & 7) * C + (m % C)) * LP16_NB + lk + (sh >> 3); }
+  // B: x = y_c1(u), y = y_c2(u + d), pair = 16 cbg + (lane & 31) / 2 = c1 C + c2 for the global column block cbg = 2 wv + cb
+  int boffx[NCW];
+#pragma unroll
+  for (int cb = 0; cb < NCW; cb++) boffx[cb] = (((16 * (NCW * wv + cb) + (m >> 1)) / C) * ys_ld) / 2 + 4 * lk;   // in float4 units (ys_ld is even)
+  // x conj(y): re = x.x y.x + x.y y.y, im = x.x (-y.y) + x.y y.x: the lane's column parity picks the staged (p, q) = sb (y.x, y.y) or sb (-y.y, y.x)
+  const int boffp = ((im ? C : 0) + (m >> 1) % C) * ys_ld + 8 * lk + d;
+  static_assert(16 % C == 0, "the second factor's channel must not depend on the column block");
+  prefetch(0);
+  for (long u0 = 0; u0 < g.T; u0 += LP_WT) {
+    __syncthreads();                                               // the reads of the last tile are done
+    if (tid < 128) {
+      const int e = tid;
+#pragma unroll
+      for (int c = 0; c < C; c++) {
+        if (e < YN) {
+          const float2 v = ypf[c];
+          ys[c * ys_ld + e] = v;
+          ysp[c * ys_ld + e] = make_float2(v.x * sb, v.y * sb);
+          ysp[(C + c) * ys_ld + e] = make_float2(-v.y * sb, v.x * sb);
+        }
+        if (e < WN) ws[c * ws_ld + e] = wpf[c];
+        else if (e < ws_ld) ws[c * ws_ld + e] = 0.f;               // (the shifted copies read up to 14 values past a block's start)
+      }
+    }
+    __syncthreads();
+    if (u0 + LP_WT < g.T) prefetch(u0 + LP_WT);
+    // the weight span of every channel as its eight one-frame shifts, each split into float16 high / low parts: unit (c, block b)
+    // reads w[8 b .. 8 b + 14] and writes copy_s[8 b .. 8 b + 7] = w[8 b + s ..] for s = 0 .. 7
+    if (tid < C * LP16_NB) {
+      const int c = tid / LP16_NB, b = tid % LP16_NB;
+      float wv16[16];
+#pragma unroll
+      for (int i = 0; i < 16; i++) { const int e = 8 * b + i; wv16[i] = (e < ws_ld && i < 15) ? ws[c * ws_ld + e] : 0.f; }
+      unsigned he[8], le[8], ho[7], lo_[7];                         // pairs (2 i, 2 i + 1) and (2 i + 1, 2 i + 2)
+#pragma unroll
+      for (int i = 0; i < 8; i++) { he[i] = pk_hi(wv16[2 * i], wv16[2 * i + 1]); le[i] = pk_hi(sub_h_lo(wv16[2 * i], he[i]), sub_h_hi(wv16[2 * i + 1], he[i])); }
+#pragma unroll
+      for (int i = 0; i < 7; i++) {
+        ho[i] = pk_hi(wv16[2 * i + 1], wv16[2 * i + 2]);
+        lo_[i] = (le[i] >> 16) | (le[i + 1] << 16);                 // (the parts of a value do not depend on its partner in the pair)
+      }
+#pragma unroll
+      for (int sft = 0; sft < 8; sft++) {
+        const int h = sft >> 1;
+        uint4 vh, vl;
+        if (sft & 1) { vh = make_uint4(ho[h], ho[h + 1], ho[h + 2], ho[h + 3]); vl = make_uint4(lo_[h], lo_[h + 1], lo_[h + 2], lo_[h + 3]); }
+        else         { vh = make_uint4(he[h], he[h + 1], he[h + 2], he[h + 3]); vl = make_uint4(le[h], le[h + 1], le[h + 2], le[h + 3]); }
+        wcp[((0 * 8 + sft) * C + c) * LP16_NB + b] = vh;
+        wcp[((1 * 8 + sft) * C + c) * LP16_NB + b] = vl;
+      }
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int kk = 0; kk < LP_WT; kk += 16) {
+      f16x8 ah[NR], al[NR];
+#pragma unroll
+      for (int j = 0; j < NR; j++) {
+        ah[j] = __builtin_bit_cast(f16x8, wcp[aidx[j] + kk / 8]);
+        al[j] = __builtin_bit_cast(f16x8, wcp[8 * C * LP16_NB + aidx[j] + kk / 8]);
+      }
+      float2 pq[8];
+#pragma unroll
+      for (int i = 0; i < 8; i++) pq[i] = ysp[boffp + kk + i];    // (odd d: not 16-byte aligned)
+#pragma unroll
+      for (int cb = 0; cb < NCW; cb++) {
+        unsigned bh[4], bl[4];
+#pragma unroll
+        for (int i2 = 0; i2 < 4; i2++) {
+          const float4 x4 = reinterpret_cast<const float4*>(ys)[boffx[cb] + kk / 2 + i2];
+          const float b0 = fmaf(x4.x, pq[2 * i2].x, x4.y * pq[2 * i2].y);
+          const float b1 = fmaf(x4.z, pq[2 * i2 + 1].x, x4.w * pq[2 * i2 + 1].y);
+          split2m(b0, b1, bh[i2], bl[i2]);
+        }
+        const f16x8 Bh = mk8(bh[0], bh[1], bh[2], bh[3]), Bl = mk8(bl[0], bl[1], bl[2], bl[3]);
+#pragma unroll
+        for (int j = 0; j < NR; j++) acc[j][cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[j], Bh, acc[j][cb], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < NR; j++) acc[j][cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[j], Bl, acc[j][cb], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < NR; j++) acc[j][cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[j], Bh, acc[j][cb], 0, 0, 0);
+      }
+    }
+  }
+  // ---- store (as lagprod_task), with the two scales undone
+  const float unscale = 1.0f / (sa * sb);
+  const int c1c2 = m >> 1;
+  float* Rc[4];
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const int c = i + 4 * lk;                                      // row % C for row = i + 8 (r >> 2) + 4 lk
+    Rc[i] = reinterpret_cast<float*>(R + (((long)s * C + c) * g.K + k) * (long)P * P) + (im ? 1 : 0);
+  }
+#pragma unroll
+  for (int cb = 0; cb < NCW; cb++) {
+    const int pair = 16 * (NCW * wv + cb) + c1c2, c1 = pair / C, c2 = pair % C;
+    const bool lower = c1 >= c2;
+    const bool skip = (d == 0 && c1 < c2);
+    const long off0 = lower ? (long)c1 * L * P + (long)c2 * L - d : ((long)c2 * L - d) * P + (long)c1 * L;
+    const float sgn = ((!lower && im) ? -1.f : 1.f) * unscale;
+#pragma unroll
+    for (int j = 0; j < NR; j++) {
+#pragma unroll
+      for (int reg = 0; reg < 16; reg++) {
+        const int row = (reg & 3) + 8 * (reg >> 2) + 4 * lk;
+        const int l1 = la + RL * j + row / C;
+        if (l1 < d || skip) continue;
+        Rc[reg & 3][2 * (off0 + (long)l1 * (P + 1))] = sgn * acc[j][cb][reg];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+}
+
+template <int C, int NCW>
+__device__ __forceinline__ void wpe_lagprod16_body(const float2* __restrict__ X, const float* __restrict__ Winv, WpeGeom g, float2* __restrict__ R, int ys_ld, int ws_ld,
+                          const float* __restrict__ scales)
+{
+  constexpr int RL = 32 / C;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int LP16_NB = lp16_nb(C);
+  uint4* wcp = reinterpret_cast<uint4*>(smem);                     // [2 (high | low)][8 shifts][C][LP16_NB] x 8 float16
+  float2* ys = reinterpret_cast<float2*>(wcp + 2 * 8 * C * LP16_NB);   // [C][ys_ld]: sample u0 + e of channel c'
+  float* ws = reinterpret_cast<float*>(ys + 3 * C * ys_ld);        // (ys is followed by the two pre-multiplied forms of the second factor) [C][ws_ld]: w_c(u0 + lowerN + la + e), scaled
+  const int k = blockIdx.y, s = blockIdx.z;
+  if (!bin_active(g, k)) return;
+  const int L = g.L;
+  int d = 0, grp = blockIdx.x;
+  auto nblk = [&](int dd) { return (L - dd + RL - 1) / RL; };
+  auto ngrp = [&](int dd) { return (nblk(dd) + LP_RMAX - 1) / LP_RMAX; };
+  while (grp >= ngrp(d)) { grp -= ngrp(d); d++; }
+  const int nbd = nblk(d), ng = ngrp(d), base = nbd / ng, extra = nbd % ng;
+  const int nb = base + (grp < extra ? 1 : 0);
+  const int first = grp * base + (grp < extra ? grp : extra);
+  const int la = L - RL * (first + nb);
+  const float2* Xk = X + ((long)s * g.K + k) * C * g.T_stride;
+  const float* Wk = Winv + ((long)s * C * g.K + k) * g.T_stride;
+  const float sa = scales[((long)s * g.K + k) * 2], sb = scales[((long)s * g.K + k) * 2 + 1];
+  switch (nb) {
+    case 4: lagprod16_task<C, 4, NCW>(Xk, Wk, g, R, ys_ld, ws_ld, d, la, s, k, ys, ws, wcp, sa, sb); break;
+    case 3: lagprod16_task<C, 3, NCW>(Xk, Wk, g, R, ys_ld, ws_ld, d, la, s, k, ys, ws, wcp, sa, sb); break;
+    case 2: lagprod16_task<C, 2, NCW>(Xk, Wk, g, R, ys_ld, ws_ld, d, la, s, k, ys, ws, wcp, sa, sb); break;
+    default: lagprod16_task<C, 1, NCW>(Xk, Wk, g, R, ys_ld, ws_ld, d, la, s, k, ys, ws, wcp, sa, sb); break;
+  }
+}
+
+// two wavefronts x two column blocks (256 registers per lane: two wavefronts per SIMD) / four x one (168: three per SIMD)
+__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void wpe_lagprod16_w2_kernel(const float2* __restrict__ X, const float* __restrict__ Winv, WpeGeom g, float2* __restrict__ R, int ys_ld, int ws_ld,
+                             const float* __restrict__ scales)
+{
+  wpe_lagprod16_body<8, 2>(X, Winv, g, R, ys_ld, ws_ld, scales);
+}
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3)))
+void wpe_lagprod16_w4_kernel(const float2* __restrict__ X, const float* __restrict__ Winv, WpeGeom g, float2* __restrict__ R, int ys_ld, int ws_ld,
+                             const float* __restrict__ scales)
+{
+  wpe_lagprod16_body<8, 1>(X, Winv, g, R, ys_ld, ws_ld, scales);
+}
+
 template <int C>
 __global__ __launch_bounds__(64)
 void wpe_lagprod_kernel(const float2* __restrict__ X, const float* __restrict__ Winv, WpeGeom g, float2* __restrict__ R, int ys_ld, int ws_ld)
@@ -815,7 +1092,7 @@ long btk_wpe_workspace_bytes(int S, int K, int C, int lowerN, int upperN, long T
 {
   const long P = (long)C * (upperN - lowerN + 1);
   const long nb = (long)S * C * K;
-  return nb * P * P * 8 + nb * P * 8 + nb * T_stride * 4 + 256;
+  return nb * P * P * 8 + nb * P * 8 + nb * T_stride * 4 + (long)S * K * 8 + 256;
 }
 
 int btk_wpe_estimate(const void* X, int S, int K, int C, long T_stride, long T, int lowerN, int upperN, int iterations,
@@ -833,6 +1110,7 @@ int btk_wpe_estimate(const void* X, int S, int K, int C, long T_stride, long T, 
   float2* R = static_cast<float2*>(workspace);
   float2* rvec = R + nb * P * P;
   float* Winv = reinterpret_cast<float*>(rvec + nb * P);
+  float* lp_scales = Winv + nb * T_stride;                          // [S][K][2]: operand scales of the float16 lag-product kernel
   const float2* Xp = static_cast<const float2*>(X);
   float2* Gp = static_cast<float2*>(G);
   const int ntile = (int)((P + 63) / 64);
@@ -878,7 +1156,18 @@ int btk_wpe_estimate(const void* X, int S, int K, int C, long T_stride, long T, 
       int ys_ld = LP_WT + g.L - 1; while (ys_ld % 32 != 4) ys_ld++;          // float2 row pitch: channel rows 8 banks apart (16-byte reads of the two lane halves 4 apart)
       int ws_ld = LP_WT + RL * LP_RMAX - 1; while (ws_ld % 64 != (C == 8 ? 8 : 16)) ws_ld++;    // weight rows 8 / 16 banks apart: a wavefront's read2 touches 7 / 13 consecutive words per row
       const size_t lds_lp = sizeof(float2) * (size_t)C * ys_ld + sizeof(float) * (size_t)C * ws_ld;
-      if (C == 8) hipLaunchKernelGGL(wpe_lagprod_kernel<8>, dim3(ntask, (unsigned)K, (unsigned)S), dim3(64), lds_lp, st, Xp, Winv, g, R, ys_ld, ws_ld);
+      if (!btk_switches().wpe_lagprod_f32 && C == 8) {
+        // round 5: float16-split operands on the 16 x faster matrix instruction (see lagprod16_task)
+        const int nb16 = lp16_nb(C);
+        const int ws16 = 8 * nb16 + 8;                                         // >= 8 (nb16 - 1) + 15 values (40 KB of LDS per task with this: four tasks per CU)
+        const size_t lds16p = sizeof(uint4) * 2 * 8 * (size_t)C * nb16 + sizeof(float2) * 3 * (size_t)C * ys_ld + sizeof(float) * (size_t)C * ws16;
+        hipLaunchKernelGGL(wpe_lp_scale_kernel, dim3((unsigned)K, (unsigned)S), dim3(256), 0, st, Xp, Winv, g, lp_scales);
+        if (btk_switches().wpe_lagprod_waves == 2)
+          hipLaunchKernelGGL(wpe_lagprod16_w2_kernel, dim3(ntask, (unsigned)K, (unsigned)S), dim3(128), lds16p, st, Xp, Winv, g, R, ys_ld, ws16, lp_scales);
+        else
+          hipLaunchKernelGGL(wpe_lagprod16_w4_kernel, dim3(ntask, (unsigned)K, (unsigned)S), dim3(256), lds16p, st, Xp, Winv, g, R, ys_ld, ws16, lp_scales);
+      }
+      else if (C == 8) hipLaunchKernelGGL(wpe_lagprod_kernel<8>, dim3(ntask, (unsigned)K, (unsigned)S), dim3(64), lds_lp, st, Xp, Winv, g, R, ys_ld, ws_ld);
       else        hipLaunchKernelGGL(wpe_lagprod_kernel<4>, dim3(ntask, (unsigned)K, (unsigned)S), dim3(64), lds_lp, st, Xp, Winv, g, R, ys_ld, ws_ld);
     } else if (skip && C % 4 == 0) {
       hipLaunchKernelGGL(wpe_herk32_kernel<4>, dim3(nblk, (unsigned)K, (unsigned)(S * C / 4)), dim3(64), lds32, st, Xp, Winv, g, R, nspan32);
