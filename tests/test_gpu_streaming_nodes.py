@@ -283,3 +283,80 @@ def test_rls_node_weight_change_before_and_between_blocks(dev, proto256, wavs):
     whole.calc_gsc_weights(FS, d2)
     with pytest.raises(jconsistency_error):
         whole.next()
+
+
+def _sample_graph(pcms, h, g, block_frames, dct=2, half_band=False):
+    """analysis x N -> SubbandDS -> synthesis over in-memory PCM (SampleFeature.set_samples); returns the synthesis node"""
+    from distant_speech_recognition_amd.btk20 import SampleFeaturePtr, OverSampledDFTAnalysisBankPtr, SubbandDSPtr, OverSampledDFTSynthesisBankPtr
+    from distant_speech_recognition_amd.pybeamformer import calc_delays
+    bf = SubbandDSPtr(fftlen=M, half_band_shift=half_band)
+    feats = []
+    for x in pcms:
+        sf = SampleFeaturePtr(block_len=D, shift_len=D, pad_zeros=True)
+        sf.setSamples(np.asarray(x, np.float64), FS)
+        a = OverSampledDFTAnalysisBankPtr(sf, prototype=h, M=M, m=m, r=r, delay_compensation_type=dct)
+        a.set_block_frames(block_frames)
+        bf.set_channel(a)
+        feats.append(sf)
+    bf.calc_array_manifold_vectors(FS, calc_delays("linear", MPOS[:len(pcms)].tolist(), [AZIMUTH, None, None]))
+    return feats, bf, OverSampledDFTSynthesisBankPtr(bf, prototype=g, M=M, m=m, r=r, delay_compensation_type=dct)
+
+
+@pytest.mark.parametrize("dct", [0, 2])
+def test_blocks_edge_cases_equal_whole_utterance(dev, proto256, kinect_pcm, dct):
+    """Inputs a block protocol can trip over -- empty, shorter than the look-ahead, one sample, a length that is not a multiple
+    of the shift, channels of unequal length (the shortest ends the stream) -- give the same number of output blocks and the same
+    bits at block sizes 1, 3, 8 and 64 as with one block per utterance; both delay-compensation types; reset() replays the stream."""
+    h, g = proto256
+    cases = [[np.zeros(0), np.zeros(0)], [kinect_pcm[0][:1], kinect_pcm[1][:1]], [kinect_pcm[0][:3 * D], kinect_pcm[1][:3 * D]],
+             [kinect_pcm[0][:10 * D + 17], kinect_pcm[1][:10 * D + 17]], [kinect_pcm[0][:9000], kinect_pcm[1][:5000], kinect_pcm[2][:7001]],
+             [kinect_pcm[c][:20011] for c in range(4)]]
+    for pcms in cases:
+        _, _, ref_node = _sample_graph(pcms, h, g, 0, dct)
+        ref = [np.array(b) for b in ref_node]
+        for bfr in (1, 3, 8, 64):
+            feats, bf, sfb = _sample_graph(pcms, h, g, bfr, dct)
+            got = [np.array(b) for b in sfb]
+            assert len(got) == len(ref), (len(pcms[0]), bfr, len(got), len(ref))
+            if ref:
+                assert np.array_equal(np.concatenate(got).view(np.uint32), np.concatenate(ref).view(np.uint32)), (len(pcms[0]), bfr)
+            if bfr == 8 and len(ref) > 4:                       # reset in mid-stream, then the whole stream again
+                for f, x in zip(feats, pcms):
+                    f.setSamples(np.asarray(x, np.float64), FS)
+                it = iter(sfb)
+                first = [np.array(next(it)) for _ in range(3)]
+                for f, x in zip(feats, pcms):
+                    f.setSamples(np.asarray(x, np.float64), FS)
+                again = [np.array(b) for b in sfb]
+                assert len(again) == len(ref) and np.array_equal(np.concatenate(again), np.concatenate(ref))
+                assert np.array_equal(np.concatenate(first), np.concatenate(ref[:3]))
+
+
+def test_half_band_shift_and_mvdrgsc_example_in_blocks(dev, tmp_path, proto256, kinect_pcm):
+    """halfBandShift == true (all M bins carried through the blocks) and the MVDR-GSC example binary: same bits for every block size"""
+    from tests.util import la_delays
+    h, g = proto256
+    pcms = [kinect_pcm[c][:15000] for c in range(4)]
+    _, _, ref_node = _sample_graph(pcms, h, g, 0, 2, half_band=True)
+    ref = np.concatenate([np.array(b) for b in ref_node])
+    for bfr in (5, 32):
+        _, _, sfb = _sample_graph(pcms, h, g, bfr, 2, half_band=True)
+        got = np.concatenate([np.array(b) for b in sfb])
+        assert got.shape == ref.shape and np.array_equal(got.view(np.uint32), ref.view(np.uint32)), bfr
+    coeffs = str(tmp_path / "coeffs.f64")
+    np.concatenate([h, g]).astype(np.float64).tofile(coeffs)
+    delays = la_delays(MPOS, AZIMUTH)
+    chan = []
+    for c in range(4):
+        p = str(tmp_path / ("c%d.wav" % c))
+        _wav(p, kinect_pcm[c][:30000])
+        chan += [repr(float(delays[c])), p]
+    outs = {}
+    for bfr in (0, 20):
+        out = str(tmp_path / ("mg%d.f32" % bfr))
+        env = dict(os.environ, BTK_BLOCK_FRAMES=str(bfr))
+        mpos = ";".join(",".join(repr(float(v)) for v in row) for row in MPOS)
+        res = subprocess.run([EXE_MVDRGSC, coeffs, str(M), str(m), str(r), "0.01", out, mpos] + chan, capture_output=True, text=True, timeout=300, env=env)
+        assert res.returncode == 0, res.stderr
+        outs[bfr] = np.fromfile(out, np.float32)
+    assert outs[0].size > 100 * D and np.array_equal(outs[20].view(np.uint32), outs[0].view(np.uint32))
