@@ -752,7 +752,11 @@ __device__ __forceinline__ void lagprod16_task(const float2* __restrict__ Xk, co
     if (u0 + LP_WT < g.T) prefetch(u0 + LP_WT);
     // the weight span of every channel as its eight one-frame shifts, each split into float16 high / low parts: unit (c, block b)
     // reads w[8 b .. 8 b + 14] and writes copy_s[8 b .. 8 b + 7] = w[8 b + s ..] for s = 0 .. 7
+#if defined(BTK_LP_ABLATE) && (BTK_LP_ABLATE & 2)              // ablation build: the shifted copies are built for the first tile only
+    if (tid < C * LP16_NB && u0 == 0) {
+#else
     if (tid < C * LP16_NB) {
+#endif
       const int c = tid / LP16_NB, b = tid % LP16_NB;
       float wv16[16];
 #pragma unroll
@@ -798,12 +802,17 @@ __device__ __forceinline__ void lagprod16_task(const float2* __restrict__ Xk, co
           split2m(b0, b1, bh[i2], bl[i2]);
         }
         const f16x8 Bh = mk8(bh[0], bh[1], bh[2], bh[3]), Bl = mk8(bl[0], bl[1], bl[2], bl[3]);
+#if defined(BTK_LP_ABLATE) && (BTK_LP_ABLATE & 1)              // ablation build (profiles/): the operands are prepared, no matrix instruction consumes them
+#pragma unroll
+        for (int j = 0; j < NR; j++) asm volatile("" :: "v"(ah[j]), "v"(al[j]), "v"(Bh), "v"(Bl));
+#else
 #pragma unroll
         for (int j = 0; j < NR; j++) acc[j][cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[j], Bh, acc[j][cb], 0, 0, 0);
 #pragma unroll
         for (int j = 0; j < NR; j++) acc[j][cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[j], Bl, acc[j][cb], 0, 0, 0);
 #pragma unroll
         for (int j = 0; j < NR; j++) acc[j][cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[j], Bh, acc[j][cb], 0, 0, 0);
+#endif
       }
     }
   }
