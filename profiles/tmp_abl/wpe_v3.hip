@@ -478,7 +478,6 @@ void wpe_herk16_kernel(const float2* __restrict__ X, const float* __restrict__ W
 // matrix instruction, kept the pipe 52 % busy).  Spans of the C snapshot rows and weight rows of a 64-frame tile are staged per
 // wavefront (register prefetch one tile ahead), operands of frame group g + 1 are read from LDS before the matrix instructions of g.
 constexpr int LP_WT = 64, LP_RMAX = 4;
-constexpr long LP16_SEG = 2048;                                  // frames per accumulator flush of the float16 lag-product kernel (multiple of LP_WT)
 
 template <int C, int NR>
 __device__ __forceinline__ void lagprod_task(const float2* __restrict__ Xk, const float* __restrict__ Wk, const WpeGeom& g, float2* __restrict__ R,
@@ -733,12 +732,7 @@ __device__ __forceinline__ void lagprod16_task(const float2* __restrict__ Xk, co
   const int boffp = ((im ? C : 0) + (m >> 1) % C) * ys_ld + 8 * lk + d;
   static_assert(16 % C == 0, "the second factor's channel must not depend on the column block");
   prefetch(0);
-  // Segments of LP16_SEG frames: the low-part products are 2^-11 of the high-part ones and, on the diagonal of R, of one sign; added to
-  // an accumulator that has grown over very many frames they would fall under half an ulp and vanish (a bias, not noise).  So the
-  // accumulators are flushed to R every LP16_SEG frames (first segment: store, later ones: add -- same task, fixed order).
-  for (long seg0 = 0; seg0 < g.T; seg0 += LP16_SEG) {
-  const long seg1 = seg0 + LP16_SEG < g.T ? seg0 + LP16_SEG : g.T;
-  for (long u0 = seg0; u0 < seg1; u0 += LP_WT) {
+  for (long u0 = 0; u0 < g.T; u0 += LP_WT) {
     __syncthreads();                                               // the reads of the last tile are done
     if (tid < 128) {
       const int e = tid;
@@ -822,19 +816,14 @@ __device__ __forceinline__ void lagprod16_task(const float2* __restrict__ Xk, co
       }
     }
   }
-  // ---- store the segment (as lagprod_task), with the two scales undone
-  // (the lane indices pass through an opaque move: the addresses below are then computed here, per flush, instead of being hoisted
-  // out of the segment loop and held in ~80 registers across the tile loop, which spilled the accumulators)
-  int ms = m, lks = lk;
-  asm volatile("" : "+v"(ms), "+v"(lks));
-  const bool ims = ms & 1;
+  // ---- store (as lagprod_task), with the two scales undone
   const float unscale = 1.0f / (sa * sb);
-  const int c1c2 = ms >> 1;
+  const int c1c2 = m >> 1;
   float* Rc[4];
 #pragma unroll
   for (int i = 0; i < 4; i++) {
-    const int c = i + 4 * lks;                                     // row % C for row = i + 8 (r >> 2) + 4 lk
-    Rc[i] = reinterpret_cast<float*>(R + (((long)s * C + c) * g.K + k) * (long)P * P) + (ims ? 1 : 0);
+    const int c = i + 4 * lk;                                      // row % C for row = i + 8 (r >> 2) + 4 lk
+    Rc[i] = reinterpret_cast<float*>(R + (((long)s * C + c) * g.K + k) * (long)P * P) + (im ? 1 : 0);
   }
 #pragma unroll
   for (int cb = 0; cb < NCW; cb++) {
@@ -842,22 +831,18 @@ __device__ __forceinline__ void lagprod16_task(const float2* __restrict__ Xk, co
     const bool lower = c1 >= c2;
     const bool skip = (d == 0 && c1 < c2);
     const long off0 = lower ? (long)c1 * L * P + (long)c2 * L - d : ((long)c2 * L - d) * P + (long)c1 * L;
-    const float sgn = ((!lower && ims) ? -1.f : 1.f) * unscale;
+    const float sgn = ((!lower && im) ? -1.f : 1.f) * unscale;
 #pragma unroll
     for (int j = 0; j < NR; j++) {
 #pragma unroll
       for (int reg = 0; reg < 16; reg++) {
-        const int row = (reg & 3) + 8 * (reg >> 2) + 4 * lks;
+        const int row = (reg & 3) + 8 * (reg >> 2) + 4 * lk;
         const int l1 = la + RL * j + row / C;
         if (l1 < d || skip) continue;
-        float* dst = &Rc[reg & 3][2 * (off0 + (long)l1 * (P + 1))];
-        const float v = sgn * acc[j][cb][reg];
-        *dst = seg0 > 0 ? *dst + v : v;
-        acc[j][cb][reg] = 0.f;
+        Rc[reg & 3][2 * (off0 + (long)l1 * (P + 1))] = sgn * acc[j][cb][reg];
       }
       __builtin_amdgcn_sched_barrier(0);
     }
-  }
   }
 }
 

@@ -118,3 +118,29 @@ def test_wpe_delayed_prediction_8ch_lags1to33(orc, dev, T):
     assert np.max(np.abs(got - ref[:, :, :K])) <= 5e-3 * rscale
     assert np.linalg.norm(got - ref[:, :, :K]) <= 2e-3 * np.linalg.norm(ref[:, :, :K])
     assert np.sum(np.abs(got) ** 2) < 0.99 * np.sum(np.abs(Yo[:, :, :K]) ** 2)
+
+
+def test_wpe_long_utterance_accumulators_are_flushed(orc, dev):
+    """20 000 frames (80 s at D = 64) through the float16-split lag-product kernel: the low-part products are 2^-11 of the high-part ones
+    and of one sign on the diagonal of the normal equations, so an accumulator that runs over the whole utterance loses them to rounding
+    (measured: 4.9e-3 of the largest tap at this length, 0.29 at 100 000 frames -- profiles/r05_wpe_long_utterance.txt).  The kernel
+    flushes its accumulators to R every 2048 frames; the filters then stay at the float32-solve level against the float64 oracle
+    (6.2e-4 measured; the all-float32 kernel gives 1.4e-3 here)."""
+    import torch
+    from distant_speech_recognition_amd import engine as eng
+    M, C, T = 16, 8, 20000
+    K = M // 2 + 1
+    g = torch.Generator(device=dev).manual_seed(3)
+    src = (torch.randn((K, T + 16), device=dev, generator=g) + 1j * torch.randn((K, T + 16), device=dev, generator=g)) * 500
+    X = torch.zeros((1, K, C, T), dtype=torch.complex64, device=dev)
+    for c in range(C):
+        for dd in range(6):
+            X[0, :, c] += (0.6 ** dd) * np.exp(1j * (c + dd)) * src[:, 16 - dd: 16 - dd + T]
+    X += 5 * (torch.randn(X.shape, device=dev, generator=g) + 1j * torch.randn(X.shape, device=dev, generator=g))
+    G = eng.wpe_estimate(X, M, lower_num=0, upper_num=7, iterations_num=2, load_db=-18.0, diagonal_bias=1e-4).cpu().numpy()[0]
+    Y = np.zeros((T, C, M), np.complex128)
+    Y[:, :, :K] = X[0].cpu().numpy().transpose(2, 1, 0)
+    Y[:, :, K:] = np.conj(Y[:, :, M // 2 - 1:0:-1])
+    Gref = orc.wpe_estimate(Y, 0, 7, 2, -18.0, 0.0, 1e-4)[:, :K]
+    assert np.max(np.abs(Gref)) > 1e-2
+    assert np.max(np.abs(G - Gref)) <= 2e-3 * np.max(np.abs(Gref))
