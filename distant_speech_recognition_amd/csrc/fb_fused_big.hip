@@ -15,9 +15,12 @@
 //   1a  lane (b, j)   : B[c]          = sum_a z[LPF a + l] W_16^{a c}                                   (radix 16)
 //   1b  lane (jg, c)  : A[c + 16 d]   = sum_b W_LPF^{b c} B_b[c] W_Q^{b d}   for its 16 / Q values of j   (radix Q, twiddle folded)
 //   2   lane k1       : Z[k1 + LPF k2] = sum_j W_NF^{j k1} A_j[k1] W_16^{j k2}                          (radix 16, twiddle folded)
-// with the folded-constant butterflies of fft_packed.h (a twiddle is one rotation FMA, its cosine rides in the butterfly), two
-// wave-private LDS exchanges (17-column padded rows) and no workgroup barrier inside the transform.  Per channel a lane spends
-// 64 (4-tap polyphase) + 72 + 12 Q + 94 (FFT) + 66 (two complex multiply-adds per bin) packed instructions.
+// with the folded-constant butterflies of fft_packed.h (a twiddle is one rotation FMA, its cosine rides in the butterfly) and no
+// workgroup barrier inside the transform.  The hand-over 1b -> 2 is a wave-private LDS exchange (17-column padded rows); the hand-over
+// 1a -> 1b trades the lane's ROW (b = lane bits 4, 5) against two bits of the register index, which gfx950 does in registers:
+// v_permlane32_swap / v_permlane16_swap (rows4 / rows2 below; the first version went through LDS here too: 16 ds_write_b64 +
+// 16 ds_read_b64 a lane, and LDS stores cost three times a load).  Per channel a lane spends 64 (4-tap polyphase) + 72 + 12 Q + 94 (FFT)
+// + 66 (two complex multiply-adds per bin) packed instructions and 8 Q row swaps.
 // The polyphase stage is the register-window form of the M = 512 kernel (15 eight-byte loads straight from HBM / L2 for 16 outputs,
 // issued one channel ahead), weights are staged as (w[q], w[NF - q]) pairs through a double-buffered LDS region.
 // One stream of a large array has few tiles (512 frames = 64): the channels are then split over CG workgroups per tile whose
@@ -29,6 +32,8 @@
 namespace {
 
 constexpr int B_MT = 4, B_TT = 8;
+typedef unsigned u2 __attribute__((ext_vector_type(2)));
+typedef unsigned u4 __attribute__((ext_vector_type(4)));
 
 template <int LOG2M> struct BG {
   static constexpr int M = 1 << LOG2M, NF = M / 2, Q = NF / 256, LPF = NF / 16;
@@ -69,7 +74,30 @@ __global__ void big_reduce_kernel(const float2* __restrict__ P, float2* __restri
   Y[row * T_stride + t] = a;
 }
 
-template <int LOG2M, int VAR>     // VAR & 1: the window loads of the next channel are issued unconditionally and interleaved with the transform; VAR & 2: see the polyphase stage
+// Register <-> lane-row exchanges of gfx950 (a row = 16 lanes): v_permlane32_swap trades rows 2, 3 of its first operand with rows 0, 1 of
+// its second, v_permlane16_swap the odd rows of the first with the even rows of the second.  rows4(): slot s of lane row p receives x_p of
+// lane row s (a 4 x 4 transpose of register index against row index, four instructions per four registers); rows2(): the same 2 x 2
+// inside each pair of rows.  They carry pass 1a's result to pass 1b without the LDS round trip (16 ds_write_b64 + 16 ds_read_b64 a lane).
+__device__ __forceinline__ void swap32(f2& a, f2& b)                         // both components
+{
+  const float ax = a.x, ay = a.y, bx = b.x, by = b.y;                        // (a bit cast applied to a vector ELEMENT reads element 0 with this compiler: go through scalars)
+  const auto rx = __builtin_amdgcn_permlane32_swap(__float_as_uint(ax), __float_as_uint(bx), false, false);
+  const auto ry = __builtin_amdgcn_permlane32_swap(__float_as_uint(ay), __float_as_uint(by), false, false);
+  a = f2{__uint_as_float(rx[0]), __uint_as_float(ry[0])};
+  b = f2{__uint_as_float(rx[1]), __uint_as_float(ry[1])};
+}
+__device__ __forceinline__ void swap16(f2& a, f2& b)
+{
+  const float ax = a.x, ay = a.y, bx = b.x, by = b.y;                        // (a bit cast applied to a vector ELEMENT reads element 0 with this compiler: go through scalars)
+  const auto rx = __builtin_amdgcn_permlane16_swap(__float_as_uint(ax), __float_as_uint(bx), false, false);
+  const auto ry = __builtin_amdgcn_permlane16_swap(__float_as_uint(ay), __float_as_uint(by), false, false);
+  a = f2{__uint_as_float(rx[0]), __uint_as_float(ry[0])};
+  b = f2{__uint_as_float(rx[1]), __uint_as_float(ry[1])};
+}
+__device__ __forceinline__ void rows4(f2* u) { swap32(u[0], u[2]); swap32(u[1], u[3]); swap16(u[0], u[1]); swap16(u[2], u[3]); }
+__device__ __forceinline__ void rows2(f2* u) { swap16(u[0], u[1]); }
+
+template <int LOG2M, int VAR>     // VAR & 4: pass 1a -> 1b through rows4 / rows2 instead of LDS; VAR & 1: the window loads of the next channel are issued unconditionally and interleaved with the transform; VAR & 2: see the polyphase stage
 __global__ __launch_bounds__(BG<LOG2M>::NT, (LOG2M == 10) ? 2 : 1)
 void analysis_bfz_big_kernel(const float* __restrict__ pcm, long nsamples, long pcm_stride,
                              const float* __restrict__ proto, const float2* __restrict__ twg,
@@ -115,9 +143,26 @@ void analysis_bfz_big_kernel(const float* __restrict__ pcm, long nsamples, long 
   const int fw = lane / LPF, l = lane % LPF;
   const int frame = wave * G::FPWV + fw;
   f2* fb = fbuf + frame * FRS;
-  f2 tw1b[Q > 1 ? Q - 1 : 1];                                                // W_LPF^{b c}, c = l & 15 (pass 1b lane), as (cos, tan)
+  constexpr bool SWAP = (VAR & 4) != 0;
+  constexpr bool TWL = SWAP && Q == 4;                                       // the 12 twiddles of a lane live in LDS (24 registers the M = 2048 kernel does not have)
+  constexpr int NS = (SWAP && !TWL) ? 16 / Q : 1;                            // SWAP: the lane of row b' holds c = Q sg + b' for sg < 16 / Q, so it needs their twiddles
+  f2 tw1b[NS * (Q > 1 ? Q - 1 : 1)];                                         // W_LPF^{b c} as (cos, tan); c = l & 15 (pass 1b lane of the LDS form)
 #pragma unroll
-  for (int b = 1; b < Q; b++) { const float2 t = twg[(32 * b * (l & 15)) & (M - 1)]; tw1b[b - 1] = tw_tangent(t.x, t.y); }
+  for (int sg = 0; sg < NS; sg++)
+#pragma unroll
+    for (int b = 1; b < Q; b++) {
+      const int c = SWAP ? Q * sg + (l >> 4) : (l & 15);
+      const float2 t = twg[(32 * b * c) & (M - 1)];
+      tw1b[sg * (Q - 1) + b - 1] = tw_tangent(t.x, t.y);
+    }
+  f2* twl = reinterpret_cast<f2*>(wq + 2 * WSTRB);                           // TWL: [16 / Q][Q - 1][LPF]
+  if constexpr (TWL) {
+    for (int i = tid; i < (16 / Q) * (Q - 1) * LPF; i += NT) {
+      const int li = i % LPF, e = i / LPF, sg = e / (Q - 1), b = e % (Q - 1) + 1;
+      const float2 t = twg[(32 * b * (Q * sg + (li >> 4))) & (M - 1)];
+      twl[i] = tw_tangent(t.x, t.y);                                         // (read after the first channel's barriers)
+    }
+  }
   f2 tw2[15];                                                                // W_NF^{j k1}, k1 = l, j = 1..15, as (cos, tan)
 #pragma unroll
   for (int j = 1; j < 16; j++) { const float2 t = twg[(2 * j * l) & (M - 1)]; tw2[j - 1] = tw_tangent(t.x, t.y); }
@@ -128,7 +173,7 @@ void analysis_bfz_big_kernel(const float* __restrict__ pcm, long nsamples, long 
 #pragma unroll
   for (int j = 0; j < 15; j++) asm volatile("" : "+v"(tw2[j]));
 #pragma unroll
-  for (int b = 0; b < (Q > 1 ? Q - 1 : 1); b++) asm volatile("" : "+v"(tw1b[b]));
+  for (int b = 0; b < NS * (Q > 1 ? Q - 1 : 1); b++) asm volatile("" : "+v"(tw1b[b]));
   const f2 k_hc = f2{0.70710678118654752f, 0.92387953251128674f}, k_t1 = f2{0.41421356237309503f, 0.41421356237309503f};
 
   f2 accA[16], accB[16];
@@ -142,9 +187,15 @@ void analysis_bfz_big_kernel(const float* __restrict__ pcm, long nsamples, long 
   auto wload = [&](int n, auto fast) {
     const float* src = pcm + ((long)s * N + n) * pcm_stride;
     if constexpr (decltype(fast)::value) {
-      const float* wsrc = src + g0 + woff;
+      // buffer loads: the channel's row base is a scalar resource, the row a scalar offset, the thread's part one 32-bit register --
+      // no vector address arithmetic per load (plain pointers cost the loop 32 v_add_co / v_addc per channel)
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src + g0), 0, 0x7fffffff, 0x00020000);
+      const unsigned vo = (unsigned)woff * 4u;                               // woff >= 0: M / 2 - 2 - 2 n0, n0 < M / 4
 #pragma unroll
-      for (int i = 0; i < NWG; i++) win[i] = *reinterpret_cast<const float2*>(wsrc + i * D);
+      for (int i = 0; i < NWG; i++) {
+        const u2 t = __builtin_amdgcn_raw_buffer_load_b64(rs, vo, i * D * 4, 0);
+        win[i] = make_float2(__uint_as_float(t.x), __uint_as_float(t.y));
+      }
     } else {
 #pragma unroll
       for (int i = 0; i < NWG; i++) {
@@ -158,7 +209,11 @@ void analysis_bfz_big_kernel(const float* __restrict__ pcm, long nsamples, long 
 #pragma unroll
     for (int q = 0; q < NWP; q++) {
       const int e = tid + q * NT;
-      if ((WSTRB % NT) == 0 || e < WSTRB) { const float4 t = wts[(long)n * WSTRB + e]; wpre[q] = f4{t.x, t.y, t.z, t.w}; }
+      if ((WSTRB % NT) == 0 || e < WSTRB) {
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float4*>(wts + (long)n * WSTRB), 0, WSTRB * 16, 0x00020000);
+        const u4 t = __builtin_amdgcn_raw_buffer_load_b128(rs, (unsigned)tid * 16u, q * NT * 16, 0);
+        wpre[q] = f4{__uint_as_float(t.x), __uint_as_float(t.y), __uint_as_float(t.z), __uint_as_float(t.w)};
+      }
     }
   };
   auto wstage = [&](int buf) {
@@ -173,7 +228,9 @@ void analysis_bfz_big_kernel(const float* __restrict__ pcm, long nsamples, long 
     if (nbeg < nend) { wload(nbeg, fast); wfetch(nbeg); wstage(0); }
     for (int n = nbeg; n < nend; n++) {
       const int wbuf = (n - nbeg) & 1;
+#if !defined(BTK_BIG_ABLATE) || !(BTK_BIG_ABLATE & 1)                        // ablation builds (profiles/; results WRONG by design): 1 = no barriers in the channel loop
       __syncthreads();                                                       // A: frames and weight buffer of channel n - 1 are consumed
+#endif
       // ---- polyphase: z = (h.x x.y, h.y x.x) summed over the taps; tap k of index n0 + q NT, frame g uses row g + 2 (3 - k) + (1 - q)
       if constexpr ((VAR & 2) != 0) __builtin_amdgcn_s_setprio(1);          // (between its two barriers a wavefront holds the others up: fb_analysis512.hip PRIO)
       {
@@ -195,7 +252,9 @@ void analysis_bfz_big_kernel(const float* __restrict__ pcm, long nsamples, long 
           for (int q = 0; q < 2; q++) fbuf[g * FRS + n0 + q * NT] = po[q][g];
       }
       if constexpr ((VAR & 2) != 0) __builtin_amdgcn_s_setprio(0);
+#if !defined(BTK_BIG_ABLATE) || !(BTK_BIG_ABLATE & 1)
       __syncthreads();                                                       // B: frames written
+#endif
       constexpr bool SPREAD = (VAR & 1) != 0 && decltype(fast)::value;
       if constexpr (SPREAD) { wload(n + 1 < nend ? n + 1 : n, fast); wfetch(n + 1 < nend ? n + 1 : n); }   // same basic block as the transform
       else if (n + 1 < nend) { wload(n + 1, fast); wfetch(n + 1); }          // land under the transform
@@ -207,37 +266,49 @@ void analysis_bfz_big_kernel(const float* __restrict__ pcm, long nsamples, long 
 #pragma unroll
         for (int a = 0; a < 16; a++) v[a] = fb[LPF * a + l];
         dft16t(v, k_hc, k_t1);
+        if constexpr (!SWAP) {
 #pragma unroll
-        for (int c = 0; c < 16; c++) fb[b * 272 + 17 * j + c] = v[c];
+          for (int c = 0; c < 16; c++) fb[b * 272 + 17 * j + c] = v[c];
+        }
       }
       if constexpr (Q > 1) {                                                 // pass 1b: radix Q over b, twiddles W_LPF^{b c} folded
-        const int jg = l >> 4, c = l & 15;
+        const int jg = l >> 4, c = l & 15;                                   // (SWAP: jg is the lane's row b', c its j)
 #pragma unroll
         for (int jl = 0; jl < 16 / Q; jl++) {
-          const int j = jg + Q * jl;
+          if constexpr (SWAP) {                                              // v[Q jl + s] <- B_{b = s}[c = Q jl + b'] of this lane's j
+            if constexpr (Q == 4) rows4(v + jl * Q); else rows2(v + jl * Q);
+          } else {
+            const int j = jg + Q * jl;
 #pragma unroll
-          for (int b = 0; b < Q; b++) v[jl * Q + b] = fb[b * 272 + 17 * j + c];
+            for (int b = 0; b < Q; b++) v[jl * Q + b] = fb[b * 272 + 17 * j + c];
+          }
         }
 #pragma unroll
         for (int jl = 0; jl < 16 / Q; jl++) {
           f2* u = v + jl * Q;
+          f2 twv[Q - 1];
+#pragma unroll
+          for (int b = 0; b < Q - 1; b++) twv[b] = TWL ? twl[(jl * (Q - 1) + b) * LPF + l] : tw1b[(SWAP ? jl * (Q - 1) : 0) + b];
+          const f2* tw = twv;
           if constexpr (Q == 2) {
-            const f2 r1 = fma_ib_kv<1>(tw1b[0], u[1], u[1]);
-            const f2 o0 = fma_kv<0>(tw1b[0], r1, u[0]), o1 = fms_kv<0>(tw1b[0], r1, u[0]);
+            const f2 r1 = fma_ib_kv<1>(tw[0], u[1], u[1]);
+            const f2 o0 = fma_kv<0>(tw[0], r1, u[0]), o1 = fms_kv<0>(tw[0], r1, u[0]);
             u[0] = o0; u[1] = o1;
           } else {
-            const f2 r1 = fma_ib_kv<1>(tw1b[0], u[1], u[1]), r2 = fma_ib_kv<1>(tw1b[1], u[2], u[2]), r3 = fma_ib_kv<1>(tw1b[2], u[3], u[3]);
-            const f2 s02 = fma_kv<0>(tw1b[1], r2, u[0]), d02 = fms_kv<0>(tw1b[1], r2, u[0]);
-            const f2 m1 = mul_kv<0>(tw1b[0], r1);
-            const f2 s13 = fma_kv<0>(tw1b[2], r3, m1), td = fms_kv<0>(tw1b[2], r3, m1);
+            const f2 r1 = fma_ib_kv<1>(tw[0], u[1], u[1]), r2 = fma_ib_kv<1>(tw[1], u[2], u[2]), r3 = fma_ib_kv<1>(tw[2], u[3], u[3]);
+            const f2 s02 = fma_kv<0>(tw[1], r2, u[0]), d02 = fms_kv<0>(tw[1], r2, u[0]);
+            const f2 m1 = mul_kv<0>(tw[0], r1);
+            const f2 s13 = fma_kv<0>(tw[2], r3, m1), td = fms_kv<0>(tw[2], r3, m1);
             u[0] = s02 + s13; u[1] = add_ib(d02, td); u[2] = s02 - s13; u[3] = sub_ib(d02, td);
           }
         }
 #pragma unroll
         for (int jl = 0; jl < 16 / Q; jl++) {
-          const int j = jg + Q * jl;
 #pragma unroll
-          for (int d = 0; d < Q; d++) fb[17 * (c + 16 * d) + j] = v[jl * Q + d];
+          for (int d = 0; d < Q; d++) {
+            if constexpr (SWAP) fb[17 * ((Q * jl + jg) + 16 * d) + c] = v[jl * Q + d];      // A_j[c' + 16 d], c' = Q jl + b', j = this lane's
+            else fb[17 * (c + 16 * d) + (jg + Q * jl)] = v[jl * Q + d];
+          }
         }
 #pragma unroll
         for (int j = 0; j < 16; j++) v[j] = fb[17 * l + j];
@@ -322,6 +393,7 @@ void analysis_bfz_big_kernel(const float* __restrict__ pcm, long nsamples, long 
 }
 
 // channel groups per tile: enough workgroups for the chip (about two per CU of work items), never fewer than 8 channels per group
+// (C5 block, 64 tiles: 8 groups 0.279 ms, 4 groups -- one round of 256 workgroups -- 0.286, 16 groups 0.298)
 inline int big_cg(int S, int N, long tcount)
 {
   const long tiles = (tcount + B_TT - 1) / B_TT * (long)S;
@@ -346,11 +418,16 @@ int launch_big(const btk_fb* fb, const float* pcm, long nsamples, long pcm_strid
   const int ntiles = (int)((tcount + B_TT - 1) / B_TT);
   const int tiles_per_xcd = (ntiles + 7) / 8;
   const long nblocks = (long)8 * tiles_per_xcd * S * CG;
-  const size_t lds = sizeof(f2) * B_TT * G::FRS + sizeof(f4) * 2 * G::WSTRB;
-  // interleaving the window loads with the transform (VAR 1): -0.7 % at M = 2048 (one 8-wave workgroup per CU), +2 % at M = 1024
-  // (profiles/r04_fused_big_ab.txt); BTK_FUSED_VAR = 0 / 1 forces either form (diagnostics)
-  const int var = btk_switches().fused_var >= 0 ? (btk_switches().fused_var & 3) : (LOG2M == 11 ? 3 : 0);       // VAR & 2: polyphase stage at wave priority 1 (M = 2048: -0.6 ... -1.0 %, M = 1024: no change)
-  auto kern = (var & 2) ? ((var & 1) ? analysis_bfz_big_kernel<LOG2M, 3> : analysis_bfz_big_kernel<LOG2M, 2>) : ((var & 1) ? analysis_bfz_big_kernel<LOG2M, 1> : analysis_bfz_big_kernel<LOG2M, 0>);
+  const size_t lds = sizeof(f2) * B_TT * G::FRS + sizeof(f4) * 2 * G::WSTRB + sizeof(f2) * 16 * G::LPF;   // (+ the pass-1b twiddle table of the row-swap form)
+  // VAR bits (BTK_FUSED_VAR forces a combination; profiles/r04_fused_big_ab.txt, profiles/r05_fused_big_ab.txt):
+  //   1  window loads interleaved with the transform     M = 2048 -0.7 %, M = 1024 +2 % alone, -1 % on top of 4
+  //   2  polyphase stage at wave priority 1              M = 2048 -0.6 ... -1.0 %
+  //   4  pass 1a -> 1b through v_permlane32/16_swap instead of LDS (round 5): M = 1024 -7.5 %, M = 2048 -2 %, bit-identical
+  const int var = btk_switches().fused_var >= 0 ? (btk_switches().fused_var & 7) : 7;
+  using KernT = decltype(&analysis_bfz_big_kernel<LOG2M, 0>);
+  static const KernT kerns[8] = {analysis_bfz_big_kernel<LOG2M, 0>, analysis_bfz_big_kernel<LOG2M, 1>, analysis_bfz_big_kernel<LOG2M, 2>, analysis_bfz_big_kernel<LOG2M, 3>,
+                                 analysis_bfz_big_kernel<LOG2M, 4>, analysis_bfz_big_kernel<LOG2M, 5>, analysis_bfz_big_kernel<LOG2M, 6>, analysis_bfz_big_kernel<LOG2M, 7>};
+  const KernT kern = kerns[var];
   BTK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(kern, dim3((unsigned)nblocks), dim3(G::NT), lds, st, pcm, nsamples, pcm_stride, fb->d_proto, fb->d_tw, fb->laN, gain,
                      N, K, Wq, per_stream ? (long)N * G::WSTRB : 0L, CG > 1 ? part : Y, CG > 1 ? tcount : T_stride,
