@@ -419,7 +419,7 @@ int launch_big(const btk_fb* fb, const float* pcm, long nsamples, long pcm_strid
   const int tiles_per_xcd = (ntiles + 7) / 8;
   const long nblocks = (long)8 * tiles_per_xcd * S * CG;
   const size_t lds = sizeof(f2) * B_TT * G::FRS + sizeof(f4) * 2 * G::WSTRB + sizeof(f2) * 16 * G::LPF;   // (+ the pass-1b twiddle table of the row-swap form)
-  // VAR bits (BTK_FUSED_VAR forces a combination; profiles/r04_fused_big_ab.txt, profiles/r05_fused_big_ab.txt):
+  // VAR bits (BTK_FUSED_VAR forces a combination; profiles/r04_fused_big_ab.txt, profiles/r05_fused_big_variants.txt):
   //   1  window loads interleaved with the transform     M = 2048 -0.7 %, M = 1024 +2 % alone, -1 % on top of 4
   //   2  polyphase stage at wave priority 1              M = 2048 -0.6 ... -1.0 %
   //   4  pass 1a -> 1b through v_permlane32/16_swap instead of LDS (round 5): M = 1024 -7.5 %, M = 2048 -2 %, bit-identical
