@@ -228,7 +228,7 @@ void analysis_bfz_big_kernel(const float* __restrict__ pcm, long nsamples, long 
     if (nbeg < nend) { wload(nbeg, fast); wfetch(nbeg); wstage(0); }
     for (int n = nbeg; n < nend; n++) {
       const int wbuf = (n - nbeg) & 1;
-#if !defined(BTK_BIG_ABLATE) || !(BTK_BIG_ABLATE & 1)                        // ablation builds (profiles/; results WRONG by design): 1 = no barriers in the channel loop
+#if !defined(BTK_BIG_ABLATE) || !(BTK_BIG_ABLATE & 3)                        // ablation builds (profiles/; results WRONG by design): 1 = no barriers in the channel loop, 2 = no barrier A
       __syncthreads();                                                       // A: frames and weight buffer of channel n - 1 are consumed
 #endif
       // ---- polyphase: z = (h.x x.y, h.y x.x) summed over the taps; tap k of index n0 + q NT, frame g uses row g + 2 (3 - k) + (1 - q)
