@@ -341,3 +341,36 @@ def test_fused_large_geometry_is_bit_reproducible(dev):
     a = fb.analysis_beamform(p, W).clone()
     for _ in range(3):
         assert torch.equal(fb.analysis_beamform(p, W), a)
+
+
+_ROWSWAP_CHILD = r"""
+import sys, hashlib, numpy as np, torch
+sys.path.insert(0, sys.argv[1])
+from distant_speech_recognition_amd import engine as eng
+from tests.util import design_prototype, synthetic_pcm
+dev = torch.device("cuda", 0)
+for M, N, S, T, extra in ((1024, 12, 2, 100, 0), (2048, 9, 2, 70, 0), (2048, 64, 1, 40, 7)):
+    fb = eng.FilterBank(design_prototype(M, 4), M, 4, 1, 2)
+    L = (T - fb.processing_delay + fb.lookahead) * (M // 2) + extra
+    pcm, _ = synthetic_pcm(S, N, L, seed=M + N)
+    rng = np.random.default_rng(M)
+    W = ((rng.normal(size=(M // 2 + 1, N)) + 1j * rng.normal(size=(M // 2 + 1, N))) / N).astype(np.complex64)
+    Y = fb.analysis_beamform(torch.from_numpy(pcm).to(dev), torch.from_numpy(W).to(dev))
+    print("DIGEST", M, N, hashlib.sha256(torch.view_as_real(Y).contiguous().cpu().numpy().tobytes()).hexdigest())
+"""
+
+
+def test_fused_large_row_swap_form_equals_lds_form_bit_for_bit():
+    """analysis_bfz_big_kernel hands pass 1a's result to pass 1b through v_permlane32_swap / v_permlane16_swap (lane row against two bits
+    of the register index) instead of an LDS round trip: pure data movement, so the output is the LDS form's bit for bit -- interior and
+    edge tiles, odd recording length, channel-split launch.  (The forms are chosen once per process by BTK_FUSED_VAR: two children.)"""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for var in ("3", "7"):
+        env = dict(os.environ)
+        env["BTK_FUSED_VAR"] = var
+        r = subprocess.run([sys.executable, "-c", _ROWSWAP_CHILD, root], env=env, capture_output=True, text=True, timeout=600, cwd=root)
+        assert r.returncode == 0, (r.stdout[-800:], r.stderr[-800:])
+        outs.append([l for l in r.stdout.splitlines() if l.startswith("DIGEST")])
+    assert len(outs[0]) == 3 and outs[0] == outs[1], outs
