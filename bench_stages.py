@@ -141,10 +141,8 @@ def main():
     C, M, T = 8, 512, 1000
     K = M // 2 + 1
     Xw = (torch.randn((1, K, C, T), device=dev) + 1j * torch.randn((1, K, C, T), device=dev)).to(torch.complex64) * 500
-    t0 = time.perf_counter()
-    G = eng.wpe_estimate(Xw, M, 0, 32, 2, -18.0, 0.0, 1e-4)
-    torch.cuda.synchronize()
-    t = time.perf_counter() - t0
+    G = eng.wpe_estimate(Xw, M, 0, 32, 2, -18.0, 0.0, 1e-4)                 # (first call: workspace allocation, kernel attributes)
+    t = timeit(torch, lambda: eng.wpe_estimate(Xw, M, 0, 32, 2, -18.0, 0.0, 1e-4), n=3, warm=1)
     P = C * 33
     out["wpe_estimate_c4"] = {"ms": t * 1e3, "iterations": 2, "P": P, "herk_TFLOPs": 2 * 8.0 * K * C * T * P * P / 2 / t / 1e12}
     t = timeit(torch, lambda: eng.wpe_apply(Xw, G, M, 0, 32), n=3, warm=1)
