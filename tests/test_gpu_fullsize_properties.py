@@ -220,3 +220,36 @@ def test_c0_adaptive_chain_full_launch_properties(dev):
     tgt = X.mean(dim=2)                                                                # broadside: vs^H x is this mean
     corr = float((Y * tgt.conj()).real.double().sum() / tgt.abs().double().pow(2).sum())
     assert 0.8 < corr < 1.1, corr
+
+
+@pytest.mark.parametrize("M,S,N,T", [(1024, 8, 64, 16384), (2048, 8, 64, 8192)])
+def test_large_geometry_fused_kernel_beyond_4GB_of_samples(dev, M, S, N, T):
+    """analysis_bfz_big_kernel on 17 GB of PCM (C3's channel count; its window rows and weight pairs are buffer loads whose resource is the
+    channel's row base -- a 48-bit address -- and whose offsets stay inside one tile's span): equal to the staged pair on every frame of
+    every stream, streams independent bit for bit, linear in the samples."""
+    import torch
+    from distant_speech_recognition_amd import engine as eng
+    D, K = M // 2, M // 2 + 1
+    afb = eng.FilterBank(design_prototype(M, 4), M, 4, 1, 2)
+    L = (T - afb.processing_delay + afb.lookahead) * D
+    assert S * N * L * 4 > 15 * 2 ** 30
+    g = torch.Generator(device=dev).manual_seed(M)
+    pcm = torch.empty((S, N, L), dtype=torch.float32, device=dev)
+    for s in range(S):
+        pcm[s] = (torch.randn((N, L), device=dev, generator=g) * 1000).round_()
+    W = (torch.randn((K, N), device=dev, generator=g) + 1j * torch.randn((K, N), device=dev, generator=g)).to(torch.complex64) / N
+    Yf = afb.analysis_beamform(pcm, W)
+    assert Yf.shape == (S, K, T)
+    for s in (0, S - 1):                                                      # the staged pair one stream at a time (34 GB of snapshots for all of them)
+        Ys = eng.bf_apply(W, afb.analysis(pcm[s:s + 1]))
+        scale = float(Ys.abs().max())
+        assert float((Yf[s:s + 1] - Ys).abs().max()) <= 2e-6 * np.sqrt(N) * scale + 1e-6 * scale
+        assert torch.equal(afb.analysis_beamform(pcm[s:s + 1], W), Yf[s:s + 1])
+        del Ys
+    pcm2 = torch.empty_like(pcm)
+    for s in range(S):
+        pcm2[s] = (torch.randn((N, L), device=dev, generator=g) * 700).round_()
+    Y2 = afb.analysis_beamform(pcm2, W)
+    pcm2 += pcm
+    Y12 = afb.analysis_beamform(pcm2, W)
+    assert float((Y12 - (Yf + Y2)).abs().max()) <= 2e-5 * float(Y12.abs().max())
