@@ -14,6 +14,6 @@ gen = torch.Generator(device=dev).manual_seed(M + N)
 pcm = (torch.randn((S, N, L), device=dev, generator=gen) * 1000.0).round_()
 W = ((torch.randn((K, N), device=dev, generator=gen) + 1j * torch.randn((K, N), device=dev, generator=gen)) / N).to(torch.complex64)
 Y = eng.padded_rows((S, K, T), torch.complex64, dev)
-for _ in range(6):
+for _ in range(int(os.environ.get("BIG_CALLS", "6"))):
     afb.analysis_beamform(pcm, W, out=Y)
 torch.cuda.synchronize()
