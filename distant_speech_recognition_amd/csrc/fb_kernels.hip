@@ -415,6 +415,14 @@ int btk_fb_synthesis(const btk_fb_t* fb, const void* Y, long nframes, long T_str
   return btk_set_error(BTK_ERR_PARAMETER, "unsupported M=%d", fb->M);
 }
 
+int btk_fb_synthesis_aligned_form(const btk_fb_t* fb)
+{
+  if (!fb || !fb->synthesis) return btk_set_error(BTK_ERR_PARAMETER, "btk_fb_synthesis_aligned_form: not a synthesis plan");
+  if (btk_switches().syn_narrow || fb->m != 4 || fb->R > 2) return 0;
+  if (fb->M == 512) return btk_switches().disable_synthesis512 ? 0 : 1;      // synthesis512w_kernel (fb_analysis512.hip)
+  return (fb->M == 1024 || fb->M == 2048) && !btk_switches().disable_fast;   // fast_synthesis_w_kernel (fb_fast.hip)
+}
+
 // Fused OverSampledDFTAnalysisBank xN -> SubbandDS/GSC/MVDR::next for static weights.  Falls back to the staged
 // pair (btk_fb_analysis into `scratch` + btk_bf_apply) for geometries the fused kernel does not cover.
 int btk_fb_analysis_bf(const btk_fb_t* fb, const float* pcm, long nsamples, long pcm_stride, int S, int N,
@@ -458,6 +466,15 @@ int btk_fb_analysis_bf(const btk_fb_t* fb, const float* pcm, long nsamples, long
   // staged layout has T_stride == tcount for X; Y keeps the caller's stride only when they agree
   if (T_stride != tcount) return btk_set_error(BTK_ERR_PARAMETER, "btk_fb_analysis_bf: staged fall-back needs T_stride == tcount");
   return btk_bf_apply(W, per_stream_weights, scratch, Y, S, fb->K, N, tcount, tcount, stream);
+}
+
+int btk_fb_analysis_bf_fused(const btk_fb_t* fb)
+{
+  if (!fb || fb->synthesis) return btk_set_error(BTK_ERR_PARAMETER, "btk_fb_analysis_bf_fused: not an analysis plan");
+  if (btk_switches().disable_fused || fb->m != 4 || fb->kx0 != 0 || fb->kx1 != fb->K) return 0;
+  const bool rok = fb->R == 1 || fb->R == 2 || fb->R == 4;
+  if ((fb->M == 512 || fb->M == 256) && rok) return 1;                       // fb_analysis512.hip, fb_fast.hip
+  return (fb->M == 1024 || fb->M == 2048) && fb->R == 2;                      // fb_fused_big.hip
 }
 
 long btk_fb_analysis_bf_scratch_bytes(const btk_fb_t* fb, int S, int N, int per_stream_weights, long tcount)

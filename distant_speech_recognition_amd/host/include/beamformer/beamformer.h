@@ -131,12 +131,18 @@ class SubbandBeamformer : public VectorComplexFeatureStream {
   SnapShotArrayPtr getSnapShotArray() { return snapshot_array(); }
   bool is_half_band_shift() const { return halfBandShift_; }
   bool isHalfBandShift() const { return halfBandShift_; }
-  // device hooks: the CURRENT BLOCK of snapshots (modulated/modulated.h, BlockSource): frames chunk_base() .. chunk_base() + num_frames() - 1
-  void* device_snapshots();       // complex64 [1][K][N][T] on the device (the first block is loaded on demand)
+  // device hooks: the CURRENT BLOCK of the stream, frames chunk_base() .. chunk_base() + num_frames() - 1 (modulated/modulated.h,
+  // BlockSource).  Over analysis banks the block's PCM windows are what is resident on the device; the snapshots are computed
+  // from them when somebody asks -- a post-filter, an adaptive canceller, snapshot_array(), a Python beamformer --, and from
+  // then on with every block.  A fixed-weight beamformer nobody asks runs the fused analysis -> apply kernel and the
+  // N x K x T snapshots never exist.
+  void* device_snapshots();       // complex64 [1][K][N][T] on the device, complete on return (the first block is loaded on demand)
   void* device_snapshots_all_bins() { device_snapshots(); return dXfull_; }   // halfBandShift over pulled sources: [1][M][N][T], else NULL
-  long num_frames() { device_snapshots(); return T_; }
-  long chunk_base() { device_snapshots(); return chunk_base_; }
+  long num_frames() { ensure_chunk_(); return T_; }
+  long chunk_base() { ensure_chunk_(); return chunk_base_; }
   bool next_chunk();              // drop the current block and load the following one; false: the channels have ended
+  bool snapshots_materialised() const { return snap_valid_; }     // (tests: which path a block took)
+  void want_snapshots() { snapshots_wanted_ = true; }             // every block from now on brings its snapshots along (staged path)
   // frames per block for channels that are pulled through next(); analysis banks bring their own block_frames()
   void set_block_frames(long n) { block_frames_ = n < 0 ? 0 : n; }
   long block_frames() const { return block_frames_; }
@@ -146,8 +152,18 @@ class SubbandBeamformer : public VectorComplexFeatureStream {
   // A block then holds at least q frames; BTK_BLOCK_QUANTUM=1 in the environment trades that bit-equality for latency.
   void set_block_quantum(long q);
   long block_quantum() const { return quantum_; }
+  // The next block of a beamformer whose channels are all analysis banks of one geometry, as SubbandGraphPool batches it with the
+  // blocks of other graphs: which frames [f0, f0 + T), from which input block b0 on (L samples per channel), whether the stream
+  // ends with it.  plan pulls the banks' input; commit makes the block the node's current one (without loading anything).
+  struct BlockPlan { long f0, T, b0, L; bool ended; };
+  bool banks_only();                                     // (re)scans the channel list
+  void plan_bank_block(BlockPlan& p);
+  void commit_bank_block(const BlockPlan& p);
+  OverSampledDFTAnalysisBank* bank(unsigned c) { return banks_[c]; }
  protected:
   bool load_chunk_();
+  void ensure_chunk_() { if (!chunk_loaded_) load_chunk_(); }
+  void* snapshots_();             // the block's snapshots, launched on the node stream (not waited for)
   void free_device_();
   long chunk_base_, block_frames_;
   bool chunk_loaded_, channels_ended_;
@@ -158,9 +174,15 @@ class SubbandBeamformer : public VectorComplexFeatureStream {
   ChannelList_ channelList_;
   SnapShotArrayPtr snapshot_array_;
   unsigned fftLen_, fftLen2_;
-  void* dX_;                      // device snapshots
+  void* dX_;                      // device snapshots of the current block (NULL until somebody asked for them)
   long T_;
   std::vector<float> Xhost_;      // lazily fetched host copy for snapshot_array()
+  std::vector<OverSampledDFTAnalysisBank*> banks_;   // the channels as analysis banks (banks_only_)
+  bool banks_only_;
+  DeviceBuffer dPcmBuf_, dXBuf_, dXfullBuf_;
+  PinnedBuffer hStage_;           // channels that are pulled frame by frame: the transposed block on its way up
+  long pcm_L_, pcm_t0_;           // the resident PCM windows [N][pcm_L_]; stream frame chunk_base_ is frame pcm_t0_ of the window
+  bool pcm_valid_, snap_valid_, snapshots_wanted_;
 };
 
 class SubbandDS : public SubbandBeamformer, public BlockSource {
@@ -190,18 +212,28 @@ class SubbandDS : public SubbandBeamformer, public BlockSource {
   // BlockSource (modulated/modulated.h): the whole beamformed utterance for a batching consumer, weight changes mid-stream
   virtual unsigned long block_version() { return weights_version_; }
   virtual const std::vector<float>& block(long& T);
+  virtual const void* device_block(long& T, long& T_stride);
   virtual long block_base() { return chunk_base(); }
   virtual bool next_block() { return advance_chunk_(); }
   virtual void advance_to(long frame_idx);
+  // true while the node's blocks come from the fused analysis -> apply kernel (channels = analysis banks of a geometry that has
+  // one, no half-band shift, nobody has asked for the snapshots)
+  bool fused_path();
  protected:
   void alloc_bfweight_(int NC);
   void compute_output_(long from_frame);
+  void ensure_output_();          // the current block beamformed with the current weights (frames already handed over keep theirs)
+  const float* host_output_();    // ... and mirrored on the host
   virtual bool advance_chunk_();  // the next block of snapshots; what was computed for this one is dropped
   virtual const char* need_weights_msg_() const { return "call calc_array_manifold_vectorsX() once\n"; }
   BeamformerWeights* bfweight_;
   unsigned long weights_version_, output_version_;
   long handed_;                   // block protocol: frames 0 .. handed_ were handed to a batching consumer (advance_to)
-  std::vector<float> Yhost_;      // [K][T] complex64
+  std::vector<float> Yhost_;      // [K][T] complex64: host mirror of dYBuf_, fetched when a frame or the host block is asked for
+  bool out_valid_, Yhost_valid_;
+  DeviceBuffer dWBuf_, dYBuf_, dScratchBuf_;
+  unsigned long w_dev_version_;   // weights_version_ dWBuf_ holds
+  bool w_dev_valid_;
   gsl_vector_complex* wq_view_;
 };
 typedef Inherit<SubbandDS, VectorComplexFeatureStreamPtr> SubbandDSPtr;
@@ -248,7 +280,9 @@ class SubbandGSCRLS : public SubbandGSC {
   ~SubbandGSCRLS();
   virtual const gsl_vector_complex* next(int frame_no = -5);
   virtual const std::vector<float>& block(long& T);          // the adaptive recursion over the current block (not the static apply)
+  virtual const void* device_block(long& T, long& T_stride);
   virtual void reset() { SubbandGSC::reset(); block_ran_ = false; }
+  // (the recursion needs the snapshots: an RLS node never takes the fused path)
   void init_precision_matrix(float sigma2 = 0.01);
   void set_precision_matrix(unsigned fbinX, gsl_matrix_complex* Pz);
   void update_active_weight_vecotrs(bool flag) { is_wa_updated_ = flag; }   // sic (reference spelling)
@@ -263,6 +297,7 @@ class SubbandGSCRLS : public SubbandGSC {
   void change_basis_(void* dP, void* dW);
   void run_block_();
   void refresh_block_();
+  const float* rls_host_output_();
   virtual bool advance_chunk_();
   float mu_, diagonal_weight_, alpha_;
   QuadraticConstraintType qctype_;
@@ -273,6 +308,7 @@ class SubbandGSCRLS : public SubbandGSC {
   void *dP0_, *dW0_, *dSS0_;        // the state at the start of the current block (a weight change before its first frame is served reruns it)
   unsigned long uploaded_version_;  // weights_version_ dV_ / dCx_ were built from
   bool block_ran_;
+  DeviceBuffer dWs_;                // workspace of the recursion
   std::vector<std::complex<double> > wq_uploaded_;   // the quiescent weights (bins 0..M/2) the device state was built with
 };
 typedef Inherit<SubbandGSCRLS, SubbandGSCPtr> SubbandGSCRLSPtr;
@@ -348,3 +384,45 @@ class SubbandMVDRGSC : public SubbandMVDR {
   bool normalize_weight_;
 };
 typedef Inherit<SubbandMVDRGSC, SubbandMVDRPtr> SubbandMVDRGSCPtr;
+
+// Many utterance graphs advanced as ONE launch (not part of the reference's interface).  The reference's unit of work is one
+// graph per utterance (unit_test/test_online_beamforming.py:80-88 builds SampleFeature x N -> OverSampledDFTAnalysisBank x N ->
+// beamformer -> OverSampledDFTSynthesisBank for every file); pulled one by one, G utterances are G independent S = 1 launches
+// per block.  A pool takes the tails of G such graphs -- a fixed-weight beamformer (SubbandDS / GSC / MVDR / MVDRGSC) whose
+// channels are analysis banks, and the synthesis bank behind it -- and advances them in lock step: per round every graph's
+// banks pull one block of input, the sample windows go up into one [G][N][L] block, ONE fused analysis -> apply launch with
+// S = G and per-stream weights writes the beamformed frames straight into the synthesis banks' window block, ONE synthesis
+// launch with S = G turns them into PCM.  next() then hands out one output block per graph and call, like G synthesis nodes
+// pulled side by side.  The results are those of the graphs pulled on their own (tests/test_gpu_graph_pool.py).
+// Rules: all graphs share the filter-bank geometry (which must have a fused kernel: btk_fb_analysis_bf_fused), the channel
+// count and the banks' block_frames(); the member nodes are driven by the pool only (do not call their next()); weights are
+// read once per round, so a weight change takes effect with the next round -- the per-frame meaning of a change inside a block
+// (BlockSource::advance_to) belongs to the single-graph path.
+class SubbandGraphPool : public Countable {
+ public:
+  SubbandGraphPool();
+  ~SubbandGraphPool();
+  void add(SubbandDSPtr& beamformer, OverSampledDFTSynthesisBankPtr& synthesis);
+  unsigned size() const { return (unsigned)graphs_.size(); }
+  bool next();                                              // one more output block of every graph that has one; false: all have ended
+  const gsl_vector_float* output(unsigned g) const;         // graph g's block of the last next(); NULL once that graph has ended
+  bool is_end(unsigned g) const;
+  long rounds() const { return rounds_; }                   // batched rounds (= launches of each kind) so far
+  void reset();
+ private:
+  struct Graph {
+    SubbandDSPtr bf;
+    OverSampledDFTSynthesisBankPtr syn;
+    bool live;                 // its channels have more input
+    long T, nblocks, served;   // this round: valid frames, output blocks, blocks handed out
+    gsl_vector_float* out;
+    bool has_out;
+  };
+  bool load_round_();
+  std::vector<Graph> graphs_;
+  long rounds_, base_, prev_T_, prev_Lw_, prev_Lp_, prev_hist_, blk_base_, out_stride_;
+  bool first_round_;
+  DeviceBuffer dPcm_, dW_, dWinA_, dWinB_, dOut_, dScratch_;
+  PinnedBuffer hW_, hOut_;
+};
+typedef refcountable_ptr<SubbandGraphPool> SubbandGraphPoolPtr;

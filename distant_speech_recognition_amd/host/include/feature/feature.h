@@ -40,6 +40,9 @@ class SampleFeature : public VectorFloatFeatureStream {
   void addWhiteNoise(float snr);
   void setSamples(const gsl_vector* samples, unsigned sampleRate);
   void set_samples(const float* samples, size_t n);          // in-memory source (same state as after read())
+  // engine hook: up to nmax consecutive next() calls at once, the blocks stored back to back in dst (nmax * size() floats);
+  // returns how many there were -- fewer than nmax: the stream has ended exactly as the throwing next() would have ended it
+  long next_blocks(float* dst, long nmax);
  private:
   SampleFeature(const SampleFeature&);
   SampleFeature& operator=(const SampleFeature&);

@@ -3,7 +3,7 @@
 #pragma once
 #include <vector>
 #include "stream/stream.h"
-#include <vector>
+#include "common/devmem.h"
 
 // Block protocol between the engine's nodes (not part of the reference's interface, which stays in stream/stream.h).  A
 // reference node hands over one frame per next(); an engine node computes a BLOCK of frames per launch: at most block_frames
@@ -27,6 +27,10 @@ class BlockSource {
   virtual bool next_block() { return false; }                // move on to the following block; false: the stream has ended
   virtual void advance_to(long frame_idx) = 0;               // a per-frame graph would have pulled frames 0 .. frame_idx (stream indices) by now
   virtual bool has_block() { return true; }                  // a wrapper around a foreign object (pyStream) may have no block to offer: drain next()
+  // The same block where it was computed: complex64 [>= K rows][T_stride] on the device, T valid frames per row, written by
+  // launches on btk_node_stream() (a consumer that launches on that stream needs no synchronisation; the pointer stays valid
+  // until the producer is advanced, reset or asked again).  NULL: the producer has only the host view above.
+  virtual const void* device_block(long& T, long& T_stride) { T = 0; T_stride = 0; return NULL; }
 };
 // frames per block: the environment variable BTK_BLOCK_FRAMES, 8192 when unset (0: unbounded, one block per utterance)
 long btk_default_block_frames();
@@ -54,7 +58,7 @@ class OverSampledDFTAnalysisBank : public VectorComplexFeatureStream {
   long blocks_pulled() const { return nblk_; }
   long frames_ready() const;                            // frames 0 .. frames_ready() - 1 can be computed from what was pulled
   long window_first_block() const { return win_b0_; }
-  const float* window(long b0) const { return win_.data() + (size_t)(b0 - win_b0_) * D_; }   // samples of blocks b0 .. blocks_pulled() - 1
+  const float* window(long b0) const { return static_cast<const float*>(win_.get()) + (size_t)(b0 - win_b0_) * D_; }   // samples of blocks b0 .. blocks_pulled() - 1 (pinned host memory)
   long first_block_of_frame(long t) const;              // oldest input block frame t reads (>= 0)
   void release_before(long t);                          // frames < t are done: drop the samples only they needed
   const btk_fb_t* plan() const { return plan_; }
@@ -67,11 +71,14 @@ class OverSampledDFTAnalysisBank : public VectorComplexFeatureStream {
   unsigned M_, m_, r_, D_, dct_;
   btk_fb_t* plan_;
   long block_frames_;
-  std::vector<float> win_;                              // samples of input blocks win_b0_ .. nblk_ - 1
+  void append_(const float* blocks, long n);            // n more input blocks into the window
+  PinnedBuffer win_;                                    // samples of input blocks win_b0_ .. nblk_ - 1 (pinned: uploaded as they lie)
   long win_b0_, nblk_;
   bool eos_;
   std::vector<double> frames_;                          // the current block of frames, [chunk_len_][2M]
   long chunk_base_, chunk_len_;
+  DeviceBuffer dPcm_, dX_;                              // a bank that is pulled frame by frame: its window and its block of frames
+  PinnedBuffer hX_;
 };
 typedef Inherit<OverSampledDFTAnalysisBank, VectorComplexFeatureStreamPtr> OverSampledDFTAnalysisBankPtr;
 
@@ -93,6 +100,13 @@ class OverSampledDFTSynthesisBank : public VectorFloatFeatureStream {
   void no_stream_feature(bool flag = true) { no_stream_feature_ = flag; }
   void set_block_frames(long n) { block_frames_ = n < 0 ? 0 : n; }     // rounds of a source that is drained through next()
   long block_frames() const { return block_frames_; }
+  // engine hooks (SubbandGraphPool synthesises the blocks of many graphs in one launch with this bank's plan)
+  const btk_fb_t* plan() const { return plan_; }
+  unsigned fftlen() const { return M_; }
+  unsigned shiftlen() const { return D_; }
+  unsigned m() const { return m_; }
+  unsigned r() const { return r_; }
+  int gain_factor() const { return gain_; }
   void inputSourceVector(const gsl_vector_complex* block) { input_source_vector(block); }          // ENABLE_LEGACY_BTK_API aliases
   void doNotUseStreamFeature(bool flag = true) { no_stream_feature(flag); }
  private:
@@ -100,12 +114,14 @@ class OverSampledDFTSynthesisBank : public VectorFloatFeatureStream {
   const gsl_vector_float* next_pushed_();
   void prepare_();
   void synthesize_(const std::vector<float>& Yk, long T, long base, bool last, long keep_blocks);
+  void synthesize_dev_(const void* dYk, long T, long T_stride, long base, long keep_blocks);
+  void run_window_(long Lw, long w0, long b_first, long keep_blocks);
   VectorComplexFeatureStreamPtr samp_;
   unsigned M_, m_, r_, D_;
   int gain_;
   btk_fb_t* plan_;
   bool fetch_round_();
-  std::vector<float> blocks_;                           // output blocks blk_base_ .. blk_base_ + nblocks_ - 1, [nblocks_][D]
+  PinnedBuffer blocks_;                                 // output blocks blk_base_ .. blk_base_ + nblocks_ - 1, float32 [nblocks_][D]
   long nblocks_, blk_base_;
   bool prepared_, src_ended_;
   long block_frames_;                                   // frames per round when the source is drained through next()
@@ -118,6 +134,14 @@ class OverSampledDFTSynthesisBank : public VectorFloatFeatureStream {
   bool no_stream_feature_;
   std::vector<float> ring_;                             // pushed frames, complex64 [W][K], oldest first (W = m R + R)
   long npushed_, npushed_at_next_;
-  void *dWin_, *dBlk_;                                  // device window [K][W] complex64 and one output block
+  void *dWin_, *dBlk_;                                  // source-less form: device window [K][W] complex64 and one output block
+  // rounds: the input window [history | this round's frames] complex64 [K][win_len_] and the output blocks, on the device; the
+  // history of a device-resident source never visits the host (dev_hist_: hist_ is then empty and the window itself is the record)
+  DeviceBuffer dRound_, dRoundNext_, dOut_;
+  PinnedBuffer hRound_;
+  long win_len_, win_pitch_;                            // frames in the window / frames between its rows (even)
+  bool dev_hist_;
+  long carry_cols_;                                     // >= 0: the next device round starts a new window with that many frames of the current one as history
+  long prev_nblocks_;
 };
 typedef Inherit<OverSampledDFTSynthesisBank, VectorFloatFeatureStreamPtr> OverSampledDFTSynthesisBankPtr;

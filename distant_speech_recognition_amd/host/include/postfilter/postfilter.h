@@ -29,6 +29,7 @@ class ZelinskiPostFilter : public VectorComplexFeatureStream, public BlockSource
   // BlockSource: see modulated/modulated.h
   virtual unsigned long block_version() { return has_bf_ptr_ ? bf_ptr_->weights_version() : 0; }
   virtual const std::vector<float>& block(long& T);
+  virtual const void* device_block(long& T, long& T_stride);
   virtual long block_base();
   virtual bool next_block();
   virtual void advance_to(long frame_idx);
@@ -36,7 +37,7 @@ class ZelinskiPostFilter : public VectorComplexFeatureStream, public BlockSource
   virtual void compute_(long from_frame);
   bool advance_chunk_();                    // the beamformer's next block of snapshots; the recursions continue from this one's end
   void csd_state_(long t, std::vector<float>& R);
-  void merge_output_(std::vector<float>& Ynew, long from_frame);
+  const float* host_output_();              // the filtered block mirrored on the host (fetched on demand)
   const gsl_vector_complex* next_manual_(int frame_no);
   // the reference keeps the N x N spectral densities of every bin in BeamformerWeights::CSDs(); this engine keeps only their
   // sums on the device and rebuilds the matrices on demand: one weighted covariance launch over the frames served so far
@@ -52,6 +53,8 @@ class ZelinskiPostFilter : public VectorComplexFeatureStream, public BlockSource
   SubbandDSPtr bf_ptr_;
   bool has_bf_ptr_;
   std::vector<float> Yhost_, wlast_;
+  bool Yhost_valid_;
+  DeviceBuffer dWb_, dDb_, dYb_, dCb_, dEb_;   // weights, alignment vector, filtered block [K][T_], per-frame statistics (grow-only)
   long T_;
   bool prepared_;
   unsigned long bf_version_;
@@ -90,6 +93,10 @@ class McCowanPostFilter : public ZelinskiPostFilter {
   void setLevelOfDiagonalLoading(unsigned fbinX, float w) { set_diagonal_looading(fbinX, w); }
   void divideAllNonDiagonalElements(float mu) { divide_all_nondiagonal_elements(mu); }
   void divideNonDiagonalElements(unsigned fbinX, float mu) { divide_nondiagonal_elements(fbinX, mu); }
+  // Lefkimmiatis: which bins take the identity in place of pinv(R_k) when Lambda is formed -- "linpack" (default; the
+  // environment variable BTK_MVDR_SVD_RULE overrides) or "exact", as SubbandMVDR::set_svd_rule (beamformer/beamformer.h)
+  void set_svd_rule(const String& rule);
+  const String& svd_rule() const { return svd_rule_; }
  protected:
   virtual void compute_(long from_frame);
   virtual bool lefkimmiatis_() const { return false; }
@@ -107,6 +114,10 @@ class McCowanPostFilter : public ZelinskiPostFilter {
   double minSV_;
   unsigned fbinX1_;
   void *dU_, *dV_;
+  DeviceBuffer dVsb_, dCsb_, dCvb_, dLamb_;
+  String svd_rule_, lam_rule_;      // the rule in force / the one the kept Lambda was designed with
+  bool lam_valid_;                  // dLamb_ matches R, the look direction (lam_version_) and the rule
+  unsigned long lam_version_;
 };
 typedef Inherit<McCowanPostFilter, ZelinskiPostFilterPtr> McCowanPostFilterPtr;
 

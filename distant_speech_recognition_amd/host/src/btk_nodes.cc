@@ -1,13 +1,17 @@
 // btk_nodes.cc -- C++ node layer: the reference's FeatureStream nodes for the beamforming hot path,
 // implemented over the C-ABI of libbtkhip (include/btkhip.h).
 //
-// A node drains its finite upstream once, runs the whole utterance through the HIP kernels and serves
-// frames from a host mirror, so next() keeps the reference's per-frame contract: node-owned buffer,
-// same-frame caching, consecutive frame numbers, jiterator_error("end of samples!") at the end.
-// Weight changes between frames recompute only the frames not yet served (analysis is
-// weight-independent and stays resident on the device).
+// A node computes BLOCKS of frames on the device (modulated/modulated.h, BlockSource) and serves frames from a host mirror,
+// so next() keeps the reference's per-frame contract: node-owned buffer, same-frame caching, consecutive frame numbers,
+// jiterator_error("end of samples!") at the end.  Weight changes between frames recompute only the frames not yet served.
+// Steady state (common/devmem.h): one non-NULL HIP stream per host thread, node-owned grow-only device / pinned buffers,
+// asynchronous copies from / to pinned memory; a beamformer over analysis banks whose snapshots nobody asks for runs the
+// FUSED analysis -> apply kernel (btk_fb_analysis_bf) and hands its block to the synthesis bank on the device.
 #include <cstdlib>
 #include <hip/hip_runtime_api.h>
+#include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -44,18 +48,66 @@ void check_hip(hipError_t e, const char* what)
   throw j_error("%s: %s", what, hipGetErrorString(e));
 }
 
+std::atomic<long> g_device_allocs(0), g_pinned_allocs(0);
+std::atomic<long long> g_pull_ns(0), g_upload_ns(0), g_device_ns(0);
+struct ScopedNs {                                   // adds the scope's wall time to one of the counters of btk_node_timers()
+  std::atomic<long long>& acc;
+  std::chrono::steady_clock::time_point t0;
+  explicit ScopedNs(std::atomic<long long>& a) : acc(a), t0(std::chrono::steady_clock::now()) {}
+  ~ScopedNs() { acc += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count(); }
+};
+
+hipStream_t nstream() { return static_cast<hipStream_t>(btk_node_stream()); }
+void nsync() { check_hip(hipStreamSynchronize(nstream()), "hipStreamSynchronize"); }
+
+// one-off device blocks of the design-time paths (weight design, WPE estimate, CSD rebuild): not the per-block steady state
 void* dev_alloc(size_t bytes)
 {
   void* p = NULL;
   check_hip(hipMalloc(&p, bytes ? bytes : 16), "hipMalloc");
+  g_device_allocs++;
   return p;
 }
 void dev_free(void* p) { if (p) (void)hipFree(p); }
-void h2d(void* d, const void* h, size_t n) { check_hip(hipMemcpy(d, h, n, hipMemcpyHostToDevice), "hipMemcpy H2D"); }
-void d2h(void* h, const void* d, size_t n) { check_hip(hipMemcpy(h, d, n, hipMemcpyDeviceToHost), "hipMemcpy D2H"); }
+// copies between pageable host memory and the device, complete on return, ordered on the node stream like every launch
+void h2d(void* d, const void* h, size_t n)
+{
+  if (!n) return;
+  check_hip(hipMemcpyAsync(d, h, n, hipMemcpyHostToDevice, nstream()), "hipMemcpyAsync H2D");
+  nsync();
+}
+void d2h(void* h, const void* d, size_t n)
+{
+  if (!n) return;
+  check_hip(hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, nstream()), "hipMemcpyAsync D2H");
+  nsync();
+}
+// the asynchronous forms: `h` is pinned memory that stays untouched until the stream has passed the copy
+void h2d_async(void* d, const void* h, size_t n)
+{
+  if (n) check_hip(hipMemcpyAsync(d, h, n, hipMemcpyHostToDevice, nstream()), "hipMemcpyAsync H2D");
+}
+void d2h_async(void* h, const void* d, size_t n)
+{
+  if (n) check_hip(hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, nstream()), "hipMemcpyAsync D2H");
+}
+void d2d_async(void* dst, const void* src, size_t n)
+{
+  if (n) check_hip(hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToDevice, nstream()), "hipMemcpyAsync D2D");
+}
+// rows x width bytes between two pitched device arrays
+void d2d_2d_async(void* dst, size_t dpitch, const void* src, size_t spitch, size_t width, size_t rows)
+{
+  if (!width || !rows) return;
+  check_hip(hipMemcpy2DAsync(dst, dpitch, src, spitch, width, rows, hipMemcpyDeviceToDevice, nstream()), "hipMemcpy2DAsync D2D");
+}
+void dev_zero_async(void* d, size_t n)
+{
+  if (n) check_hip(hipMemsetAsync(d, 0, n, nstream()), "hipMemsetAsync");
+}
 
 // [K][T] complex64 -> frame t as gsl_vector_complex of M bins with conjugate mirror
-void serve_frame(const std::vector<float>& Y, long T, unsigned M, long t, gsl_vector_complex* out)
+void serve_frame(const float* Y, long T, unsigned M, long t, gsl_vector_complex* out)
 {
   const unsigned K = M / 2 + 1;
   for (unsigned k = 0; k < K; k++) {
@@ -66,7 +118,7 @@ void serve_frame(const std::vector<float>& Y, long T, unsigned M, long t, gsl_ve
 }
 
 // halfBandShift: every bin has its own output, nothing is mirrored.  Y [M][T] complex64
-void serve_frame_all_bins(const std::vector<float>& Y, long T, unsigned M, long t, gsl_vector_complex* out)
+void serve_frame_all_bins(const float* Y, long T, unsigned M, long t, gsl_vector_complex* out)
 {
   for (unsigned k = 0; k < M; k++) { out->data[2 * k] = Y[2 * ((size_t)k * T + t)]; out->data[2 * k + 1] = Y[2 * ((size_t)k * T + t) + 1]; }
 }
@@ -90,6 +142,59 @@ long drain_complex(VectorComplexFeatureStreamPtr& src, unsigned M, std::vector<f
 }
 
 }  // namespace
+
+// ================================================================================ node stream, device / pinned buffers
+void* btk_node_stream()
+{
+  // one stream per host thread, never destroyed (a thread_local destructor would run after the HIP runtime's own teardown)
+  static thread_local hipStream_t st = NULL;
+  if (!st) check_hip(hipStreamCreateWithFlags(&st, hipStreamNonBlocking), "hipStreamCreateWithFlags");
+  return st;
+}
+void btk_node_synchronize() { nsync(); }
+void btk_node_alloc_counts(long* device_allocs, long* pinned_allocs)
+{
+  if (device_allocs) *device_allocs = g_device_allocs.load();
+  if (pinned_allocs) *pinned_allocs = g_pinned_allocs.load();
+}
+
+void btk_node_timers(double* pull_s, double* upload_s, double* device_s)
+{
+  if (pull_s) *pull_s = 1e-9 * (double)g_pull_ns.load();
+  if (upload_s) *upload_s = 1e-9 * (double)g_upload_ns.load();
+  if (device_s) *device_s = 1e-9 * (double)g_device_ns.load();
+}
+void btk_node_timers_reset() { g_pull_ns = 0; g_upload_ns = 0; g_device_ns = 0; }
+
+void* DeviceBuffer::ensure(size_t bytes)
+{
+  if (bytes <= cap_ && p_) return p_;
+  const size_t want = std::max(bytes ? bytes : (size_t)16, cap_ + cap_ / 2);
+  if (p_) { nsync(); (void)hipFree(p_); p_ = NULL; cap_ = 0; }          // launches that still read the old block
+  check_hip(hipMalloc(&p_, want), "hipMalloc");
+  g_device_allocs++;
+  cap_ = want;
+  return p_;
+}
+void DeviceBuffer::release() { if (p_) (void)hipFree(p_); p_ = NULL; cap_ = 0; }
+
+void* PinnedBuffer::ensure(size_t bytes) { return ensure_keep(bytes, 0); }
+void* PinnedBuffer::ensure_keep(size_t bytes, size_t keep_bytes)
+{
+  if (bytes <= cap_ && p_) return p_;
+  const size_t want = std::max(bytes ? bytes : (size_t)16, cap_ + cap_ / 2);
+  void* q = NULL;
+  check_hip(hipHostMalloc(&q, want, hipHostMallocDefault), "hipHostMalloc");
+  g_pinned_allocs++;
+  if (p_) {
+    nsync();                                                                // copies that still read the old block
+    if (keep_bytes) memcpy(q, p_, std::min(keep_bytes, cap_));
+    (void)hipHostFree(p_);
+  }
+  p_ = q; cap_ = want;
+  return p_;
+}
+void PinnedBuffer::release() { if (p_) (void)hipHostFree(p_); p_ = NULL; cap_ = 0; }
 
 // ================================================================================ SampleFeature
 SampleFeature::SampleFeature(const String& fn, unsigned blockLen, unsigned shiftLen, bool padZeros, const String& nm)
@@ -335,6 +440,34 @@ const gsl_vector_float* SampleFeature::next(int frame_no)
   return vector_;
 }
 
+// next() nmax times in a row, the blocks written one after the other to dst (an analysis bank filling its sample window): the
+// same state transitions as the loop of next() calls it replaces -- frame counter, read position, zero padding of the last
+// block, and at the end of the samples exactly what the throwing call does (is_end_, samples dropped) with the count returned
+// instead of the exception.  vector_ holds the last block handed out, as after next().
+long SampleFeature::next_blocks(float* dst, long nmax)
+{
+  long n = 0;
+  const unsigned sz = size();
+  while (n < nmax) {
+    if (is_end_) break;
+    const size_t ttl = samples_.size();
+    if (!have_samples_ || cur_ >= ttl) { is_end_ = true; have_samples_ = false; samples_.clear(); break; }
+    float* o = dst + (size_t)n * sz;
+    if (cur_ + sz >= ttl) {
+      if (!pad_zeros_) { is_end_ = true; have_samples_ = false; samples_.clear(); break; }
+      memset(o, 0, sizeof(float) * sz);
+      memcpy(o, samples_.data() + cur_, sizeof(float) * (ttl - cur_));
+    } else {
+      memcpy(o, samples_.data() + cur_, sizeof(float) * sz);
+    }
+    cur_ += shiftLen_;
+    increment_();
+    n++;
+  }
+  if (n > 0) memcpy(vector_->data, dst + (size_t)(n - 1) * sz, sizeof(float) * sz);
+  return n;
+}
+
 // ================================================================================ analysis bank
 long btk_default_block_frames()
 {
@@ -359,16 +492,43 @@ OverSampledDFTAnalysisBank::OverSampledDFTAnalysisBank(VectorFloatFeatureStreamP
 
 OverSampledDFTAnalysisBank::~OverSampledDFTAnalysisBank() { btk_fb_destroy(plan_); }
 
+void OverSampledDFTAnalysisBank::append_(const float* blocks, long n)
+{
+  const size_t have = (size_t)(nblk_ - win_b0_) * D_;
+  float* w = static_cast<float*>(win_.ensure_keep(sizeof(float) * (have + (size_t)n * D_), sizeof(float) * have));
+  if (blocks) memcpy(w + have, blocks, sizeof(float) * (size_t)n * D_);
+  nblk_ += n;
+}
+
 // one round of input: at most block_frames() blocks of D samples from the upstream node (modulated.cc:419-438 pulls one per frame)
 bool OverSampledDFTAnalysisBank::pull_more()
 {
   if (eos_) return false;
   long got = 0;
+  // the window is sized once for a whole round (+ the m R blocks of history + a beamformer's block quantum), so that a steady-
+  // state round allocates nothing; an unbounded round (block_frames() == 0) grows geometrically
+  const size_t have = (size_t)(nblk_ - win_b0_) * D_;
+  if (block_frames_ > 0)
+    win_.ensure_keep(sizeof(float) * (have + (size_t)(block_frames_ + (long)m_ * (1L << r_) + 64) * D_), sizeof(float) * have);
+  SampleFeature* sf = dynamic_cast<SampleFeature*>(samp_.operator->());
+  if (sf && sf->size() == D_) {
+    // a SampleFeature hands its blocks over in bulk, straight into the window (SampleFeature::next_blocks == the loop below)
+    for (;;) {
+      const long ask = block_frames_ == 0 ? 4096 : block_frames_ - got;
+      if (ask <= 0) break;
+      const size_t h = (size_t)(nblk_ - win_b0_) * D_;
+      float* w = static_cast<float*>(win_.ensure_keep(sizeof(float) * (h + (size_t)ask * D_), sizeof(float) * h));
+      const long n = sf->next_blocks(w + h, ask);
+      nblk_ += n; got += n;
+      if (n < ask) { eos_ = true; break; }
+    }
+    return got > 0;
+  }
   while (block_frames_ == 0 || got < block_frames_) {
     const gsl_vector_float* b;
     try { b = samp_->next(); } catch (jiterator_error&) { eos_ = true; break; }
-    win_.insert(win_.end(), b->data, b->data + b->size);
-    nblk_++; got++;
+    append_(b->data, 1);
+    got++;
   }
   return got > 0;
 }
@@ -392,7 +552,9 @@ void OverSampledDFTAnalysisBank::release_before(long t)
 {
   const long keep = std::min(first_block_of_frame(t), nblk_);
   if (keep > win_b0_) {
-    win_.erase(win_.begin(), win_.begin() + (size_t)(keep - win_b0_) * D_);
+    float* w = static_cast<float*>(win_.get());
+    const size_t drop = (size_t)(keep - win_b0_) * D_, left = (size_t)(nblk_ - keep) * D_;
+    if (left) memmove(w, w + drop, sizeof(float) * left);
     win_b0_ = keep;
   }
 }
@@ -404,17 +566,22 @@ bool OverSampledDFTAnalysisBank::load_chunk_()
   while (!eos_ && frames_ready() <= f0) pull_more();
   const long f1 = frames_ready();
   if (f1 <= f0) return false;
+  // a bank is either a channel of a beamformer node (which releases the samples its blocks are done with) or pulled frame by
+  // frame; both at once would find the window already cut -- frames computed as if the stream began later: refuse instead
+  if (win_b0_ > first_block_of_frame(f0))
+    throw jconsistency_error("OverSampledDFTAnalysisBank %s: frame %ld needs samples from input block %ld on, but a beamformer node "
+                             "this bank is a channel of has released everything before block %ld; pull the bank through the "
+                             "beamformer or on its own, not both\n", name().c_str(), f0, first_block_of_frame(f0), win_b0_);
   const unsigned K = M_ / 2 + 1;
-  const long b0 = std::max(first_block_of_frame(f0), win_b0_), L = (nblk_ - b0) * (long)D_, Tn = f1 - f0;
-  void* dp = dev_alloc(sizeof(float) * (L ? L : 1));
-  void* dX = dev_alloc(sizeof(float) * 2 * K * Tn);
-  if (L) h2d(dp, window(b0), sizeof(float) * L);
+  const long b0 = first_block_of_frame(f0), L = (nblk_ - b0) * (long)D_, Tn = f1 - f0;
+  float* dp = static_cast<float*>(dPcm_.ensure(sizeof(float) * (L ? L : 1)));
+  void* dX = dX_.ensure(sizeof(float) * 2 * K * Tn);
+  float* Xh = static_cast<float*>(hX_.ensure(sizeof(float) * 2 * K * Tn));
+  h2d_async(dp, window(b0), sizeof(float) * L);
   // the window starts at block b0: stream frame t is frame t - b0 of the window, and nothing it reads lies before the window
-  check_abi(btk_fb_analysis(plan_, (const float*)dp, L, L ? L : 1, 1, 1, dX, Tn, f0 - b0, Tn, NULL));
-  check_abi(btk_synchronize(NULL));
-  std::vector<float> Xh((size_t)2 * K * Tn);
-  d2h(Xh.data(), dX, sizeof(float) * Xh.size());
-  dev_free(dp); dev_free(dX);
+  check_abi(btk_fb_analysis(plan_, dp, L, L ? L : 1, 1, 1, dX, Tn, f0 - b0, Tn, nstream()));
+  d2h_async(Xh, dX, sizeof(float) * 2 * K * Tn);
+  nsync();
   frames_.assign((size_t)Tn * 2 * M_, 0.0);
   gsl_vector_complex tmp; tmp.size = M_; tmp.stride = 1;
   for (long t = 0; t < Tn; t++) {
@@ -441,7 +608,7 @@ void OverSampledDFTAnalysisBank::reset()
 {
   samp_->reset();
   VectorComplexFeatureStream::reset();
-  win_.clear(); win_b0_ = 0; nblk_ = 0; eos_ = false; frames_.clear(); chunk_base_ = 0; chunk_len_ = 0;
+  win_b0_ = 0; nblk_ = 0; eos_ = false; frames_.clear(); chunk_base_ = 0; chunk_len_ = 0;
 }
 
 // ================================================================================ synthesis bank
@@ -451,7 +618,7 @@ OverSampledDFTSynthesisBank::OverSampledDFTSynthesisBank(VectorComplexFeatureStr
     : VectorFloatFeatureStream(M >> r, nm), samp_(samp), M_(M), m_(m), r_(r), D_(M >> r), gain_(gainFactor), plan_(NULL),
       nblocks_(0), blk_base_(0), prepared_(false), src_ended_(false), block_frames_(btk_default_block_frames()), hist_len_(0),
       frames_in_(0), cur_T_(0), bsrc_(NULL), src_version_(0), no_stream_feature_(false), npushed_(0), npushed_at_next_(0),
-      dWin_(NULL), dBlk_(NULL)
+      dWin_(NULL), dBlk_(NULL), win_len_(0), win_pitch_(0), dev_hist_(false), carry_cols_(0), prev_nblocks_(0)
 {
   init_(prototype, delayCompensationType);
 }
@@ -461,7 +628,7 @@ OverSampledDFTSynthesisBank::OverSampledDFTSynthesisBank(gsl_vector* prototype, 
     : VectorFloatFeatureStream(M >> r, nm), samp_(NULL), M_(M), m_(m), r_(r), D_(M >> r), gain_(gainFactor), plan_(NULL),
       nblocks_(0), blk_base_(0), prepared_(false), src_ended_(false), block_frames_(btk_default_block_frames()), hist_len_(0),
       frames_in_(0), cur_T_(0), bsrc_(NULL), src_version_(0), no_stream_feature_(true), npushed_(0), npushed_at_next_(0),
-      dWin_(NULL), dBlk_(NULL)
+      dWin_(NULL), dBlk_(NULL), win_len_(0), win_pitch_(0), dev_hist_(false), carry_cols_(0), prev_nblocks_(0)
 {
   init_(prototype, delayCompensationType);
 }
@@ -477,38 +644,92 @@ void OverSampledDFTSynthesisBank::init_(gsl_vector* prototype, unsigned delayCom
 
 OverSampledDFTSynthesisBank::~OverSampledDFTSynthesisBank() { btk_fb_destroy(plan_); dev_free(dWin_); dev_free(dBlk_); }
 
+// Rows of a round's input window are win_pitch_ frames apart: the next even number, so that every launch of a stream can be an
+// ALIGNED one (btk_fb_synthesis_aligned_form: such geometries have a second kernel form for aligned launches, <= 2 ulp from the
+// other; a stream cut into rounds gives the same bits as one round only if all its launches take the same form)
+static long even_pitch(long frames) { return frames + (frames & 1); }
+
+// The output blocks of one round, from the round's input window on the device: dRound_ complex64 [K][win_pitch_] holds the
+// stream frames w0 .. w0 + Lw - 1 (history first), blk_base_ / nblocks_ say which blocks.  The first keep_blocks blocks of the
+// round (already handed over) keep their values.
+void OverSampledDFTSynthesisBank::run_window_(long Lw, long w0, long b_first, long keep_blocks)
+{
+  ScopedNs timer(g_device_ns);
+  std::vector<float> old;
+  const float* prev = static_cast<const float*>(blocks_.get());
+  if (keep_blocks > 0 && prev) old.assign(prev, prev + (size_t)std::min<long>(keep_blocks, prev_nblocks_) * D_);
+  float* hb = static_cast<float*>(blocks_.ensure(sizeof(float) * (size_t)(nblocks_ ? nblocks_ : 1) * D_));
+  if (nblocks_ > 0) {
+    // the window starts at stream frame w0: block b of the stream is block b - w0 of the window.  An aligned launch starts at a
+    // block whose newest frame has an even index in the window: where the round's first block does not, the launch begins one
+    // block earlier (block -1 of a stream: zeros) and that block lands in D samples of slack in front of the others
+    const long pd = btk_fb_processing_delay(plan_);
+    const long bw = b_first - w0;
+    const long lead = (btk_fb_synthesis_aligned_form(plan_) == 1 && ((bw + pd) & 1)) ? 1 : 0;
+    const long slack = (D_ + 3) / 4 * 4;
+    float* dO = static_cast<float*>(dOut_.ensure(sizeof(float) * ((size_t)(nblocks_ + 1) * D_ + slack)));
+    float* first = dO + slack;                                   // (16-byte aligned like dO itself)
+    check_abi(btk_fb_synthesis(plan_, dRound_.get(), Lw, win_pitch_, 1, first - lead * (long)D_, (nblocks_ + lead) * D_, bw - lead, nblocks_ + lead, nstream()));
+    d2h_async(hb, first, sizeof(float) * (size_t)nblocks_ * D_);
+    nsync();
+    if (gain_ > 1) for (size_t i = 0; i < (size_t)nblocks_ * D_; i++) hb[i] *= (float)gain_;
+  }
+  if (!old.empty()) memcpy(hb, old.data(), sizeof(float) * std::min(old.size(), (size_t)nblocks_ * D_));
+  prev_nblocks_ = nblocks_;
+}
+
 // One round: Yk complex64 [>= K rows][T] are the input frames base .. base + T - 1 of the stream; the output blocks whose newest
 // input frame b + pd lies in this round are synthesised from them and from the frames kept of the rounds before (block b reads
 // the frames b + pd - (m R - 1) .. b + pd, csrc/fb_kernels.hip; frames before the stream read as zero == the zeroed ring of
-// modulated.cc:615-621).  The first keep_blocks blocks of the round (already handed over) keep their values.
+// modulated.cc:615-621).  Host form: the source has no device view (a drained stream, a Python object).
 void OverSampledDFTSynthesisBank::synthesize_(const std::vector<float>& Yk, long T, long base, bool, long keep_blocks)
 {
   const unsigned K = M_ / 2 + 1;
   const long pd = btk_fb_processing_delay(plan_);
-  std::vector<float> old;
-  if (keep_blocks > 0) old.assign(blocks_.begin(), blocks_.begin() + (size_t)std::min<long>(keep_blocks, nblocks_) * D_);
   const long b_first = std::max<long>(0, base - pd), b_end = base + T - pd;
+  prev_nblocks_ = nblocks_;
   blk_base_ = b_first;
   nblocks_ = b_end > b_first ? b_end - b_first : 0;
-  blocks_.assign((size_t)nblocks_ * D_, 0.f);
+  const long Lw = hist_len_ + T, w0 = base - hist_len_, Lp = even_pitch(Lw);
+  win_len_ = Lw; win_pitch_ = Lp;
   if (nblocks_ > 0) {
-    const long Lw = hist_len_ + T, w0 = base - hist_len_;
-    std::vector<float> win((size_t)2 * K * Lw);
+    float* win = static_cast<float*>(hRound_.ensure(sizeof(float) * 2 * K * Lp));
     for (unsigned k = 0; k < K; k++) {
-      if (hist_len_) memcpy(&win[2 * (size_t)k * Lw], &hist_[2 * (size_t)k * hist_len_], sizeof(float) * 2 * hist_len_);
-      memcpy(&win[2 * ((size_t)k * Lw + hist_len_)], &Yk[2 * (size_t)k * T], sizeof(float) * 2 * T);
+      if (hist_len_) memcpy(&win[2 * (size_t)k * Lp], &hist_[2 * (size_t)k * hist_len_], sizeof(float) * 2 * hist_len_);
+      memcpy(&win[2 * ((size_t)k * Lp + hist_len_)], &Yk[2 * (size_t)k * T], sizeof(float) * 2 * T);
+      if (Lp > Lw) { win[2 * ((size_t)k * Lp + Lw)] = 0.f; win[2 * ((size_t)k * Lp + Lw) + 1] = 0.f; }
     }
-    void* dY = dev_alloc(sizeof(float) * win.size());
-    void* dO = dev_alloc(sizeof(float) * blocks_.size());
-    h2d(dY, win.data(), sizeof(float) * win.size());
-    // the window starts at stream frame w0: block b of the stream is block b - w0 of the window
-    check_abi(btk_fb_synthesis(plan_, dY, Lw, Lw, 1, (float*)dO, nblocks_ * D_, b_first - w0, nblocks_, NULL));
-    check_abi(btk_synchronize(NULL));
-    d2h(blocks_.data(), dO, sizeof(float) * blocks_.size());
-    dev_free(dY); dev_free(dO);
-    if (gain_ > 1) for (size_t i = 0; i < blocks_.size(); i++) blocks_[i] *= (float)gain_;
+    h2d_async(dRound_.ensure(sizeof(float) * 2 * K * Lp), win, sizeof(float) * 2 * K * Lp);
   }
-  if (!old.empty()) memcpy(blocks_.data(), old.data(), sizeof(float) * std::min(old.size(), blocks_.size()));
+  run_window_(Lw, w0, b_first, keep_blocks);
+}
+
+// The same round from a block that already lies on the device (BlockSource::device_block): the window is put together by
+// device copies -- the tail of the round before as history, then the block -- and nothing but the PCM comes back to the host.
+void OverSampledDFTSynthesisBank::synthesize_dev_(const void* dYk, long T, long T_stride, long base, long keep_blocks)
+{
+  const unsigned K = M_ / 2 + 1;
+  const long pd = btk_fb_processing_delay(plan_);
+  if (carry_cols_ >= 0) {
+    // a new round: its window = the last carry_cols_ frames of the window before + the new block.  (The two buffers swap roles
+    // every round: both are sized for the larger of the two windows, so that both reach their final size within two rounds.)
+    const long keep = carry_cols_, Lw = keep + T, Lp = even_pitch(Lw);
+    const size_t need = std::max(sizeof(float) * 2 * K * (Lp ? Lp : 2), sizeof(float) * 2 * K * (size_t)(win_pitch_ ? win_pitch_ : 2));
+    char* nw = static_cast<char*>(dRoundNext_.ensure(need));
+    if (keep) d2d_2d_async(nw, sizeof(float) * 2 * Lp, static_cast<const char*>(dRound_.get()) + sizeof(float) * 2 * (win_len_ - keep),
+                           sizeof(float) * 2 * win_pitch_, sizeof(float) * 2 * keep, K);
+    dRound_.swap(dRoundNext_);
+    hist_len_ = keep; win_len_ = Lw; win_pitch_ = Lp; carry_cols_ = -1;
+  }
+  const long Lw = win_len_;
+  if (Lw != hist_len_ + T) throw jconsistency_error("OverSampledDFTSynthesisBank: the source's block changed its length within a round (%ld -> %ld frames)\n", Lw - hist_len_, T);
+  if (T) d2d_2d_async(static_cast<char*>(dRound_.get()) + sizeof(float) * 2 * hist_len_, sizeof(float) * 2 * win_pitch_, dYk, sizeof(float) * 2 * T_stride,
+                      sizeof(float) * 2 * T, K);
+  const long b_first = std::max<long>(0, base - pd), b_end = base + T - pd;
+  prev_nblocks_ = nblocks_;
+  blk_base_ = b_first;
+  nblocks_ = b_end > b_first ? b_end - b_first : 0;
+  run_window_(Lw, base - hist_len_, b_first, keep_blocks);
 }
 
 // the input frames of the current round: the block of an engine node upstream (it is not advanced through next()), or up to
@@ -523,12 +744,22 @@ void OverSampledDFTSynthesisBank::prepare_()
   if (bsrc_) {
     // keep what was already served; next() tells the producer after every block how far a per-frame graph would have pulled, so
     // that a later weight change touches only the frames beyond
-    long T = 0;
-    const std::vector<float>& Yk = bsrc_->block(T);
-    src_version_ = bsrc_->block_version();
-    frames_in_ = bsrc_->block_base();
-    cur_T_ = T;
-    synthesize_(Yk, T, frames_in_, false, prepared_ ? frame_no_ + 1 - blk_base_ : 0);
+    long T = 0, Ts = 0;
+    const long keep_blocks = prepared_ ? frame_no_ + 1 - blk_base_ : 0;
+    const void* dY = (hist_len_ == 0 || dev_hist_) ? bsrc_->device_block(T, Ts) : NULL;
+    if (dY) {
+      dev_hist_ = true;
+      src_version_ = bsrc_->block_version();
+      frames_in_ = bsrc_->block_base();
+      cur_T_ = T;
+      synthesize_dev_(dY, T, Ts, frames_in_, keep_blocks);
+    } else {
+      const std::vector<float>& Yk = bsrc_->block(T);
+      src_version_ = bsrc_->block_version();
+      frames_in_ = bsrc_->block_base();
+      cur_T_ = T;
+      synthesize_(Yk, T, frames_in_, false, keep_blocks);
+    }
   } else {
     std::vector<float> fr;                       // [T][K]
     long T = 0;
@@ -561,9 +792,18 @@ bool OverSampledDFTSynthesisBank::fetch_round_()
   const long pd = btk_fb_processing_delay(plan_);
   const long H = std::max<long>((long)m_ * (1L << r_) + (1L << r_), pd);
   long T = cur_T_;
+  const long total = hist_len_ + T, keep = std::min(total, H);
+  const long next_base = frames_in_ + T;
+  if (bsrc_ && dev_hist_) {
+    // every frame of the round has been handed over by now (advance_to), so the device window still is what the source holds
+    if (!bsrc_->next_block()) return false;
+    carry_cols_ = keep; frames_in_ = next_base;
+    nblocks_ = 0;
+    prepare_();
+    return true;
+  }
   const std::vector<float>* Yk = &cur_;
   if (bsrc_) Yk = &bsrc_->block(T);
-  const long total = hist_len_ + T, keep = std::min(total, H);
   std::vector<float> nh((size_t)2 * K * keep);
   for (unsigned k = 0; k < K; k++)
     for (long i = 0; i < keep; i++) {
@@ -571,11 +811,10 @@ bool OverSampledDFTSynthesisBank::fetch_round_()
       const float* src = j < hist_len_ ? &hist_[2 * ((size_t)k * hist_len_ + j)] : &(*Yk)[2 * ((size_t)k * T + (j - hist_len_))];
       nh[2 * ((size_t)k * keep + i)] = src[0]; nh[2 * ((size_t)k * keep + i) + 1] = src[1];
     }
-  const long next_base = frames_in_ + T;
   if (bsrc_) { if (!bsrc_->next_block()) return false; }
   else if (src_ended_) return false;
   hist_.swap(nh); hist_len_ = keep; frames_in_ = next_base;
-  blocks_.clear(); nblocks_ = 0;
+  nblocks_ = 0;
   prepare_();
   return true;
 }
@@ -616,8 +855,7 @@ const gsl_vector_float* OverSampledDFTSynthesisBank::next_pushed_()
   }
   if (!dWin_) { dWin_ = dev_alloc(sizeof(float) * 2 * K * W); dBlk_ = dev_alloc(sizeof(float) * D_); }
   h2d(dWin_, win.data(), sizeof(float) * win.size());
-  check_abi(btk_fb_synthesis(plan_, dWin_, Lw, Lw, 1, (float*)dBlk_, D_, Lw - 1 - pd, 1, NULL));
-  check_abi(btk_synchronize(NULL));
+  check_abi(btk_fb_synthesis(plan_, dWin_, Lw, Lw, 1, (float*)dBlk_, D_, Lw - 1 - pd, 1, nstream()));
   d2h(vector_->data, dBlk_, sizeof(float) * D_);
   if (gain_ > 1) for (unsigned i = 0; i < D_; i++) vector_->data[i] *= (float)gain_;
   npushed_at_next_ = npushed_;
@@ -633,7 +871,7 @@ const gsl_vector_float* OverSampledDFTSynthesisBank::next(int frame_no)
   const long idx = frame_no_ + 1;
   while (idx >= blk_base_ + nblocks_)
     if (!fetch_round_()) { is_end_ = true; throw jiterator_error("end of samples!"); }
-  memcpy(vector_->data, blocks_.data() + (size_t)(idx - blk_base_) * D_, sizeof(float) * D_);
+  memcpy(vector_->data, static_cast<const float*>(blocks_.get()) + (size_t)(idx - blk_base_) * D_, sizeof(float) * D_);
   increment_();
   // block idx of a per-frame graph has pulled the frames 0 .. pd + idx (the priming of modulated.cc:574-578 included)
   if (bsrc_) bsrc_->advance_to((long)btk_fb_processing_delay(plan_) + idx);
@@ -644,8 +882,8 @@ void OverSampledDFTSynthesisBank::reset()
 {
   if (!no_stream_feature_ && !samp_.is_null()) samp_->reset();
   VectorFloatFeatureStream::reset();
-  prepared_ = false; blocks_.clear(); nblocks_ = 0; blk_base_ = 0; bsrc_ = NULL; src_version_ = 0; src_ended_ = false;
-  hist_.clear(); hist_len_ = 0; frames_in_ = 0; cur_.clear(); cur_T_ = 0;
+  prepared_ = false; nblocks_ = 0; prev_nblocks_ = 0; blk_base_ = 0; bsrc_ = NULL; src_version_ = 0; src_ended_ = false;
+  hist_.clear(); hist_len_ = 0; frames_in_ = 0; cur_.clear(); cur_T_ = 0; win_len_ = 0; win_pitch_ = 0; dev_hist_ = false; carry_cols_ = 0;
   ring_.clear(); npushed_ = 0; npushed_at_next_ = 0;      // buffer_.zero() (modulated.cc:614-622)
 }
 
@@ -925,15 +1163,17 @@ void BeamformerWeights::calcSidelobeCancellerP_f(unsigned fbinX, const gsl_vecto
 SubbandBeamformer::SubbandBeamformer(unsigned fftLen, bool halfBandShift, const String& nm)
     : VectorComplexFeatureStream(fftLen, nm), chunk_base_(0), block_frames_(btk_default_block_frames()), chunk_loaded_(false),
       channels_ended_(false), quantum_(1), halfBandShift_(halfBandShift), dXfull_(NULL), snapshot_array_(NULL), fftLen_(fftLen),
-      fftLen2_(fftLen / 2), dX_(NULL), T_(0) {}
-SubbandBeamformer::~SubbandBeamformer() { free_device_(); }
+      fftLen2_(fftLen / 2), dX_(NULL), T_(0), banks_only_(false), pcm_L_(0), pcm_t0_(0), pcm_valid_(false), snap_valid_(false),
+      snapshots_wanted_(false) {}
+SubbandBeamformer::~SubbandBeamformer() {}
+// the block state starts over; the device buffers stay (they only ever grow: common/devmem.h)
 void SubbandBeamformer::free_device_()
 {
-  dev_free(dX_); dX_ = NULL; dev_free(dXfull_); dXfull_ = NULL; T_ = 0; Xhost_.clear();
-  chunk_base_ = 0; chunk_loaded_ = false; channels_ended_ = false;
+  dX_ = NULL; dXfull_ = NULL; T_ = 0; Xhost_.clear();
+  chunk_base_ = 0; chunk_loaded_ = false; channels_ended_ = false; pcm_valid_ = false; snap_valid_ = false; pcm_L_ = 0; pcm_t0_ = 0;
 }
 void SubbandBeamformer::set_channel(VectorComplexFeatureStreamPtr& chan) { channelList_.push_back(chan); }
-void SubbandBeamformer::clear_channel() { channelList_.clear(); snapshot_array_ = NULL; free_device_(); }
+void SubbandBeamformer::clear_channel() { channelList_.clear(); banks_.clear(); banks_only_ = false; snapshot_array_ = NULL; free_device_(); }
 
 void SubbandBeamformer::reset()
 {
@@ -951,10 +1191,32 @@ void SubbandBeamformer::set_block_quantum(long q)
   quantum_ = q < 1 ? 1 : q;
 }
 
+// the snapshots of the current block, launched on the node stream.  Over analysis banks they are computed from the resident
+// PCM windows the first time somebody asks; from then on every block brings them along (snapshots_wanted_)
+void* SubbandBeamformer::snapshots_()
+{
+  ensure_chunk_();
+  snapshots_wanted_ = true;
+  if (!snap_valid_) {
+    const unsigned N = chanN(), K = fftLen2_ + 1;
+    dX_ = dXBuf_.ensure(sizeof(float) * 2 * K * N * (T_ ? T_ : 1));
+    if (T_ > 0) {
+      if (!pcm_valid_) throw jconsistency_error("SubbandBeamformer %s: the samples of the current block are gone\n", name().c_str());
+      // the windows start at input block b0: stream frame t is frame t - b0 of the window (csrc/fb_kernels.hip: frame t ends at
+      // sample (t + laN + 1) D - 1), and no frame of this block reads a sample before it
+      check_abi(btk_fb_analysis(banks_[0]->plan(), static_cast<const float*>(dPcmBuf_.get()), pcm_L_, pcm_L_ ? pcm_L_ : 1, 1, (int)N, dX_, T_,
+                                pcm_t0_, T_, nstream()));
+    }
+    snap_valid_ = true;
+  }
+  return dX_;
+}
+
 void* SubbandBeamformer::device_snapshots()
 {
-  if (!chunk_loaded_) load_chunk_();
-  return dX_;
+  void* p = snapshots_();
+  nsync();                                                       // the caller may read them from any stream
+  return p;
 }
 
 bool SubbandBeamformer::next_chunk()
@@ -964,58 +1226,78 @@ bool SubbandBeamformer::next_chunk()
   return load_chunk_();
 }
 
-// The block of snapshots after the current one (the first one when none is loaded): frames chunk_base_ .. chunk_base_ + T_ - 1.
+// every channel an analysis bank with the same plan -> the channels advance as one batch of sample windows
+bool SubbandBeamformer::banks_only()
+{
+  banks_.clear();
+  banks_only_ = !channelList_.empty();
+  for (ChannelList_::iterator it = channelList_.begin(); it != channelList_.end(); ++it) {
+    OverSampledDFTAnalysisBank* b = dynamic_cast<OverSampledDFTAnalysisBank*>(it->operator->());
+    if (!b || (!banks_.empty() && (b->fftlen() != banks_[0]->fftlen() || b->m() != banks_[0]->m() || b->r() != banks_[0]->r() ||
+                                   b->delay_compensation_type() != banks_[0]->delay_compensation_type()))) { banks_only_ = false; break; }
+    banks_.push_back(b);
+  }
+  if (!banks_only_) banks_.clear();
+  return banks_only_;
+}
+
+// every bank pulls one round of input blocks (its block_frames()); the channels advance in lock step, the shortest one ends
+// the stream (its zero-padded tail frames included, like a per-frame graph whose first exhausted channel ends it)
+void SubbandBeamformer::plan_bank_block(BlockPlan& p)
+{
+  ScopedNs timer(g_pull_ns);
+  const long f0 = chunk_loaded_ ? chunk_base_ + T_ : 0;
+  const long laN = btk_fb_lookahead(banks_[0]->plan()), pd = btk_fb_processing_delay(banks_[0]->plan());
+  const long want = (f0 / quantum_ + 1) * quantum_;            // a block ends on a multiple of the quantum (or with the stream)
+  for (size_t c = 0; c < banks_.size(); c++)
+    while (!banks_[c]->at_end() && banks_[c]->frames_ready() < want) banks_[c]->pull_more();
+  long nblk = -1; bool ended = false;
+  for (size_t c = 0; c < banks_.size(); c++) { const long n = banks_[c]->blocks_pulled(); if (nblk < 0 || n < nblk) nblk = n; }
+  for (size_t c = 0; c < banks_.size(); c++) if (banks_[c]->at_end() && banks_[c]->blocks_pulled() == nblk) ended = true;
+  long f1 = ended ? (nblk < laN ? 0 : nblk - laN + pd) : (nblk > laN ? nblk - laN : 0);
+  if (!ended) f1 = f1 / quantum_ * quantum_;
+  long b0 = banks_[0]->first_block_of_frame(f0);
+  for (size_t c = 0; c < banks_.size(); c++) b0 = std::max(b0, banks_[c]->window_first_block());
+  b0 = std::min(b0, nblk);
+  p.f0 = f0; p.T = f1 > f0 ? f1 - f0 : 0; p.b0 = b0; p.L = (nblk - b0) * (long)banks_[0]->shiftlen(); p.ended = ended;
+}
+
+void SubbandBeamformer::commit_bank_block(const BlockPlan& p)
+{
+  Xhost_.clear();
+  chunk_loaded_ = true; chunk_base_ = p.f0; T_ = p.T; channels_ended_ = p.ended;
+  pcm_valid_ = false; snap_valid_ = false; dX_ = NULL; dXfull_ = NULL;
+  for (size_t c = 0; c < banks_.size(); c++) banks_[c]->release_before(p.f0 + p.T);
+}
+
+// The block after the current one (the first one when none is loaded): frames chunk_base_ .. chunk_base_ + T_ - 1.
 // Returns false when the channels have no further frame (the block is then empty).
 bool SubbandBeamformer::load_chunk_()
 {
   const unsigned N = chanN(), K = fftLen2_ + 1;
   if (N == 0) throw j_error("set channels first\n");
-  const long f0 = chunk_loaded_ ? chunk_base_ + T_ : 0;
-  dev_free(dX_); dX_ = NULL; dev_free(dXfull_); dXfull_ = NULL; Xhost_.clear();
-  chunk_loaded_ = true; chunk_base_ = f0; T_ = 0;
-  // fast path: every channel is an analysis bank with the same plan -> one batched analysis launch
-  bool all_banks = true;
-  std::vector<OverSampledDFTAnalysisBank*> banks;
-  for (ChannelList_::iterator it = channelList_.begin(); it != channelList_.end(); ++it) {
-    OverSampledDFTAnalysisBank* b = dynamic_cast<OverSampledDFTAnalysisBank*>(it->operator->());
-    if (!b || (!banks.empty() && (b->fftlen() != banks[0]->fftlen() || b->m() != banks[0]->m() || b->r() != banks[0]->r() ||
-                                  b->delay_compensation_type() != banks[0]->delay_compensation_type()))) { all_banks = false; break; }
-    banks.push_back(b);
-  }
-  if (all_banks) {
-    // every bank pulls one round of input blocks (its block_frames()); the channels advance in lock step, the shortest one ends
-    // the stream (its zero-padded tail frames included, like a per-frame graph whose first exhausted channel ends it)
-    const long laN = btk_fb_lookahead(banks[0]->plan()), pd = btk_fb_processing_delay(banks[0]->plan());
-    const long want = (f0 / quantum_ + 1) * quantum_;            // a block ends on a multiple of the quantum (or with the stream)
-    for (size_t c = 0; c < banks.size(); c++)
-      while (!banks[c]->at_end() && banks[c]->frames_ready() < want) banks[c]->pull_more();
-    long nblk = -1; bool ended = false;
-    for (size_t c = 0; c < banks.size(); c++) { const long n = banks[c]->blocks_pulled(); if (nblk < 0 || n < nblk) nblk = n; }
-    for (size_t c = 0; c < banks.size(); c++) if (banks[c]->at_end() && banks[c]->blocks_pulled() == nblk) ended = true;
-    long f1 = ended ? (nblk < laN ? 0 : nblk - laN + pd) : (nblk > laN ? nblk - laN : 0);
-    if (!ended) f1 = f1 / quantum_ * quantum_;
-    channels_ended_ = ended;
-    T_ = f1 > f0 ? f1 - f0 : 0;
-    long b0 = banks[0]->first_block_of_frame(f0);
-    for (size_t c = 0; c < banks.size(); c++) b0 = std::max(b0, banks[c]->window_first_block());
-    b0 = std::min(b0, nblk);
-    const long D = (long)banks[0]->shiftlen(), L = (nblk - b0) * D;
-    dX_ = dev_alloc(sizeof(float) * 2 * K * N * (T_ ? T_ : 1));
-    if (T_ > 0) {
-      void* dp = dev_alloc(sizeof(float) * N * (L ? L : 1));
-      for (unsigned c = 0; c < N; c++)
-        if (L) h2d(static_cast<float*>(dp) + (size_t)c * L, banks[c]->window(b0), sizeof(float) * L);
-      // the windows start at input block b0: stream frame t is frame t - b0 of the window (csrc/fb_kernels.hip: frame t ends at
-      // sample (t + laN + 1) D - 1), and no frame of this block reads a sample before it
-      check_abi(btk_fb_analysis(banks[0]->plan(), (const float*)dp, L, L ? L : 1, 1, (int)N, dX_, T_, f0 - b0, T_, NULL));
-      check_abi(btk_synchronize(NULL));
-      dev_free(dp);
+  if (banks_only()) {
+    BlockPlan p;
+    plan_bank_block(p);
+    float* dp = NULL;
+    if (p.T > 0) {
+      ScopedNs timer(g_upload_ns);
+      // the banks keep their windows in pinned memory: N asynchronous copies, one per channel, and the block's samples are
+      // resident -- for the fused kernel (SubbandDS::compute_output_) or for snapshots_()
+      dp = static_cast<float*>(dPcmBuf_.ensure(sizeof(float) * N * (p.L ? p.L : 1)));
+      for (unsigned c = 0; c < N; c++) h2d_async(dp + (size_t)c * p.L, banks_[c]->window(p.b0), sizeof(float) * p.L);
+      nsync();                                                   // before the banks move their windows on
     }
-    for (size_t c = 0; c < banks.size(); c++) banks[c]->release_before(f0 + T_);
+    commit_bank_block(p);
+    pcm_L_ = p.L; pcm_t0_ = p.f0 - p.b0; pcm_valid_ = p.T > 0;
+    if (snapshots_wanted_) snapshots_();
   } else {
     // channels of any other kind are pulled frame by frame, at most block_frames() frames per block; with halfBandShift the
     // reference dots every one of the M snapshots as supplied (beamformer.cc:1113-1128): a generic source owes no conjugate
     // symmetry between its bins, so all M bins go to the device; dX_ keeps the usual bins 0..M/2 for the other consumers
+    const long f0 = chunk_loaded_ ? chunk_base_ + T_ : 0;
+    Xhost_.clear();
+    chunk_loaded_ = true; chunk_base_ = f0; T_ = 0; pcm_valid_ = false; snap_valid_ = false; dX_ = NULL; dXfull_ = NULL;
     const unsigned M = fftLen_, rows = halfBandShift_ ? M : K;
     std::vector<std::vector<float> > fr(N);
     long T = -1; unsigned c = 0;
@@ -1034,20 +1316,24 @@ bool SubbandBeamformer::load_chunk_()
     }
     channels_ended_ = ended;
     T_ = T;
-    std::vector<float> Xh((size_t)2 * rows * N * T_);
+    const size_t nx = (size_t)2 * rows * N * T_;
+    float* Xh = static_cast<float*>(hStage_.ensure(sizeof(float) * (nx ? nx : 1)));
     for (unsigned k = 0; k < rows; k++)
       for (unsigned n = 0; n < N; n++)
         for (long t = 0; t < T_; t++) {
           Xh[2 * (((size_t)k * N + n) * T_ + t)] = fr[n][2 * ((size_t)t * rows + k)];
           Xh[2 * (((size_t)k * N + n) * T_ + t) + 1] = fr[n][2 * ((size_t)t * rows + k) + 1];
         }
-    dX_ = dev_alloc(sizeof(float) * 2 * K * N * (T_ ? T_ : 1));
+    dX_ = dXBuf_.ensure(sizeof(float) * 2 * K * N * (T_ ? T_ : 1));
     if (halfBandShift_) {
-      dXfull_ = dev_alloc(sizeof(float) * (Xh.empty() ? 2 : Xh.size()));
-      if (!Xh.empty()) { h2d(dXfull_, Xh.data(), sizeof(float) * Xh.size()); h2d(dX_, Xh.data(), sizeof(float) * 2 * K * N * T_); }
-    } else if (!Xh.empty()) {
-      h2d(dX_, Xh.data(), sizeof(float) * Xh.size());
+      dXfull_ = dXfullBuf_.ensure(sizeof(float) * (nx ? nx : 2));
+      h2d_async(dXfull_, Xh, sizeof(float) * nx);
+      h2d_async(dX_, Xh, sizeof(float) * 2 * K * N * T_);
+    } else {
+      h2d_async(dX_, Xh, sizeof(float) * nx);
     }
+    nsync();                                                     // the staging buffer is free again
+    snap_valid_ = true;
   }
   return T_ > 0;
 }
@@ -1057,8 +1343,8 @@ SnapShotArrayPtr SubbandBeamformer::snapshot_array()
   const unsigned N = chanN(), K = fftLen2_ + 1;
   if (snapshot_array_.is_null()) snapshot_array_ = new SnapShotArray(fftLen_, N);
   const long lf = frame_no_ - chunk_base_;                     // the frame next() served last, within the current block
-  if (dX_ && lf >= 0 && lf < T_) {
-    if (Xhost_.empty()) { Xhost_.resize((size_t)2 * K * N * T_); d2h(Xhost_.data(), dX_, sizeof(float) * Xhost_.size()); }
+  if (chunk_loaded_ && lf >= 0 && lf < T_) {
+    if (Xhost_.empty()) { void* dX = snapshots_(); Xhost_.resize((size_t)2 * K * N * T_); d2h(Xhost_.data(), dX, sizeof(float) * Xhost_.size()); }
     gsl_vector_complex** snaps = snapshot_array_->raw_snapshots();
     for (unsigned k = 0; k < K; k++)
       for (unsigned n = 0; n < N; n++) {
@@ -1073,7 +1359,8 @@ SnapShotArrayPtr SubbandBeamformer::snapshot_array()
 // ================================================================================ SubbandDS
 SubbandDS::SubbandDS(unsigned fftLen, bool halfBandShift, const String& nm)
     : SubbandBeamformer(fftLen, halfBandShift, nm), bfweight_(NULL), weights_version_(0), output_version_(0),
-      handed_(-1), wq_view_(gsl_vector_complex_calloc(1)) {}
+      handed_(-1), out_valid_(false), Yhost_valid_(false), w_dev_version_(0), w_dev_valid_(false),
+      wq_view_(gsl_vector_complex_calloc(1)) {}
 SubbandDS::~SubbandDS() { delete bfweight_; gsl_vector_complex_free(wq_view_); }
 
 void SubbandDS::clear_channel() { SubbandBeamformer::clear_channel(); delete bfweight_; bfweight_ = NULL; }
@@ -1137,66 +1424,84 @@ void SubbandDS::alignment_vector(bool use_wq, std::vector<float>& d)
   for (size_t i = 0; i < (size_t)K * N; i++) { d[2 * i] = (float)src[i].real(); d[2 * i + 1] = (float)src[i].imag(); }
 }
 
+// fused analysis -> apply: the channels are analysis banks of a geometry that has a fused kernel, the block's samples are
+// resident, and nobody has asked for the snapshots (then the staged pair runs: the snapshots exist anyway)
+bool SubbandDS::fused_path()
+{
+  ensure_chunk_();
+  return banks_only_ && !halfBandShift_ && !snapshots_wanted_ && !snap_valid_ && btk_fb_analysis_bf_fused(banks_[0]->plan()) == 1;
+}
+
+// Frames [from_frame, T_) of the current block with the current weights, on the device: Y complex64 [rows][T_] in dYBuf_
+// (rows = K, or M with halfBandShift: every bin has its own output).  Frames before from_frame keep what they hold.
 void SubbandDS::compute_output_(long from_frame)
 {
+  ScopedNs timer(g_device_ns);
   const unsigned N = chanN(), K = fftLen2_ + 1, M = fftLen_;
-  void* dX = device_snapshots();
-  const unsigned rows = halfBandShift_ ? M : K;                  // halfBandShift: every bin has its own output (Yhost_ [M][T])
-  std::vector<float> Ynew((size_t)2 * rows * T_);
+  ensure_chunk_();
+  const unsigned rows = halfBandShift_ ? M : K;
+  const long Tn = T_ - from_frame;
+  float* dY = static_cast<float*>(dYBuf_.ensure(sizeof(float) * 2 * rows * (T_ ? T_ : 1)));
   if (!halfBandShift_) {
-    std::vector<float> w;
-    effective_weights(w);
-    void* dW = dev_alloc(sizeof(float) * w.size());
-    void* dY = dev_alloc(sizeof(float) * 2 * K * (T_ ? T_ : 1));
-    h2d(dW, w.data(), sizeof(float) * w.size());
-    check_abi(btk_bf_apply(dW, 0, dX, dY, 1, (int)K, (int)N, T_, T_, NULL));
-    check_abi(btk_synchronize(NULL));
-    if (T_) d2h(Ynew.data(), dY, sizeof(float) * Ynew.size());
-    dev_free(dW); dev_free(dY);
-  } else {
-    // reference beamformer.cc:1113-1128 / 1276-1285: y_k = w_k^H x_k for k = 0..M-1.
+    {
+      // from the weight object as it is NOW: what a caller wrote through wq() / wa() / B() counts from the next block on even
+      // without a call that bumps weights_version_ (131 KB per block at 64 channels x 257 bins)
+      std::vector<float> w;
+      effective_weights(w);
+      h2d(dWBuf_.ensure(sizeof(float) * w.size()), w.data(), sizeof(float) * w.size());
+      w_dev_valid_ = true; w_dev_version_ = weights_version_;
+    }
+    if (Tn > 0) {
+      if (fused_path() && pcm_valid_) {
+        // SubbandGSC::next over OverSampledDFTAnalysisBank::next (beamformer.cc:1251-1316 over modulated.cc:375-409) in one
+        // kernel: the block's samples in, the beamformed frames out
+        const long sb = btk_fb_analysis_bf_scratch_bytes(banks_[0]->plan(), 1, (int)N, 0, Tn);
+        void* scratch = dScratchBuf_.ensure((size_t)(sb > 0 ? sb : 16));
+        check_abi(btk_fb_analysis_bf(banks_[0]->plan(), static_cast<const float*>(dPcmBuf_.get()), pcm_L_, pcm_L_ ? pcm_L_ : 1, 1, (int)N,
+                                     dWBuf_.get(), 0, dY + 2 * from_frame, T_, pcm_t0_ + from_frame, Tn, scratch, sb, nstream()));
+      } else {
+        // frames [from_frame, T): the frame axis offset by pointer arithmetic, strides stay T_
+        const float* dX = static_cast<const float*>(snapshots_());
+        check_abi(btk_bf_apply(dWBuf_.get(), 0, dX + 2 * from_frame, dY + 2 * from_frame, 1, (int)K, (int)N, T_, Tn, nstream()));
+      }
+    }
+  } else if (Tn > 0) {
+    // reference beamformer.cc:1113-1128 / 1276-1285: y_k = w_k^H x_k for k = 0..M-1 (a rare configuration: host-staged weights)
     std::vector<float> wf;
     effective_weights_all_bins(wf);                              // [M][N]
-    void* dY = dev_alloc(sizeof(float) * 2 * M * (T_ ? T_ : 1));
+    w_dev_valid_ = false;
+    const float* dX = static_cast<const float*>(snapshots_());
     if (dXfull_) {                                               // pulled sources: all M snapshot bins as supplied, one pass
-      void* dW = dev_alloc(sizeof(float) * wf.size());
-      h2d(dW, wf.data(), sizeof(float) * wf.size());
-      check_abi(btk_bf_apply(dW, 0, dXfull_, dY, 1, (int)M, (int)N, T_, T_, NULL));
-      check_abi(btk_synchronize(NULL));
-      if (T_) d2h(Ynew.data(), dY, sizeof(float) * Ynew.size());
-      dev_free(dW);
+      h2d(dWBuf_.ensure(sizeof(float) * wf.size()), wf.data(), sizeof(float) * wf.size());
+      check_abi(btk_bf_apply(dWBuf_.get(), 0, static_cast<const float*>(dXfull_) + 2 * from_frame, dY + 2 * from_frame, 1, (int)M, (int)N, T_, Tn, nstream()));
     } else {
       // analysis banks of a real signal: x_{M-k} = conj(x_k), so y_{M-k} = conj((conj w_{M-k})^H x_k): a second pass of the same
-      // kernel over bins 1 .. M/2-1 with the conjugated upper weights
-      std::vector<float> w2((size_t)2 * K * N, 0.f), up((size_t)2 * K * T_);
+      // kernel over bins 1 .. M/2-1 with the conjugated upper weights, into rows K .. 2K-1 of the scratch block, mirrored on the host
+      std::vector<float> w2((size_t)2 * K * N, 0.f), lo((size_t)2 * K * T_), up((size_t)2 * K * T_), Yfull((size_t)2 * M * T_);
       for (unsigned k = 1; k + 1 < K; k++)
         for (unsigned c = 0; c < N; c++) {
           w2[2 * ((size_t)k * N + c)] = wf[2 * ((size_t)(M - k) * N + c)];
           w2[2 * ((size_t)k * N + c) + 1] = -wf[2 * ((size_t)(M - k) * N + c) + 1];
         }
-      void* dW = dev_alloc(sizeof(float) * 2 * K * N);
-      h2d(dW, wf.data(), sizeof(float) * 2 * K * N);
-      check_abi(btk_bf_apply(dW, 0, dX, dY, 1, (int)K, (int)N, T_, T_, NULL));
-      check_abi(btk_synchronize(NULL));
-      if (T_) d2h(Ynew.data(), dY, sizeof(float) * 2 * K * T_);
-      h2d(dW, w2.data(), sizeof(float) * 2 * K * N);
-      check_abi(btk_bf_apply(dW, 0, dX, dY, 1, (int)K, (int)N, T_, T_, NULL));
-      check_abi(btk_synchronize(NULL));
-      if (T_) d2h(up.data(), dY, sizeof(float) * up.size());
+      float* dT = static_cast<float*>(dScratchBuf_.ensure(sizeof(float) * 2 * K * (T_ ? T_ : 1)));
+      h2d(dWBuf_.ensure(sizeof(float) * 2 * M * N), wf.data(), sizeof(float) * 2 * K * N);
+      check_abi(btk_bf_apply(dWBuf_.get(), 0, dX, dT, 1, (int)K, (int)N, T_, T_, nstream()));
+      d2h(lo.data(), dT, sizeof(float) * lo.size());
+      h2d(dWBuf_.get(), w2.data(), sizeof(float) * 2 * K * N);
+      check_abi(btk_bf_apply(dWBuf_.get(), 0, dX, dT, 1, (int)K, (int)N, T_, T_, nstream()));
+      d2h(up.data(), dT, sizeof(float) * up.size());
+      if (from_frame > 0) d2h(Yfull.data(), dY, sizeof(float) * Yfull.size());      // frames already served keep their values
+      for (unsigned k = 0; k < K; k++)
+        memcpy(&Yfull[2 * ((size_t)k * T_ + from_frame)], &lo[2 * ((size_t)k * T_ + from_frame)], sizeof(float) * 2 * (size_t)Tn);
       for (unsigned k = 1; k + 1 < K; k++)
-        for (long t = 0; t < T_; t++) {
-          Ynew[2 * ((size_t)(M - k) * T_ + t)] = up[2 * ((size_t)k * T_ + t)];
-          Ynew[2 * ((size_t)(M - k) * T_ + t) + 1] = -up[2 * ((size_t)k * T_ + t) + 1];
+        for (long t = from_frame; t < T_; t++) {
+          Yfull[2 * ((size_t)(M - k) * T_ + t)] = up[2 * ((size_t)k * T_ + t)];
+          Yfull[2 * ((size_t)(M - k) * T_ + t) + 1] = -up[2 * ((size_t)k * T_ + t) + 1];
         }
-      dev_free(dW);
+      h2d(dY, Yfull.data(), sizeof(float) * Yfull.size());
     }
-    dev_free(dY);
   }
-  if (Yhost_.size() == Ynew.size() && from_frame > 0) {
-    for (unsigned k = 0; k < rows; k++)                     // frames already served keep their values
-      memcpy(&Ynew[2 * ((size_t)k * T_)], &Yhost_[2 * ((size_t)k * T_)], sizeof(float) * 2 * (size_t)from_frame);
-  }
-  Yhost_.swap(Ynew);
+  out_valid_ = true; Yhost_valid_ = false;
   output_version_ = weights_version_;
 }
 
@@ -1207,36 +1512,64 @@ static long kept_frames(long frame_no, long handed, long chunk_base, long T)
   return k < 0 ? 0 : (k > T ? T : k);
 }
 
+void SubbandDS::ensure_output_()
+{
+  if (!bfweight_) throw j_error("%s", need_weights_msg_());
+  ensure_chunk_();
+  if (!out_valid_) compute_output_(0);
+  else if (output_version_ != weights_version_) compute_output_(kept_frames(frame_no_, handed_, chunk_base_, T_));
+}
+
+const float* SubbandDS::host_output_()
+{
+  ensure_output_();
+  if (!Yhost_valid_) {
+    const unsigned rows = halfBandShift_ ? fftLen_ : fftLen2_ + 1;
+    Yhost_.resize((size_t)2 * rows * T_);
+    d2h(Yhost_.data(), dYBuf_.get(), sizeof(float) * Yhost_.size());
+    Yhost_valid_ = true;
+  }
+  return Yhost_.data();
+}
+
 const gsl_vector_complex* SubbandDS::next(int frame_no)
 {
   if (frame_no == frame_no_) return vector_;
   if (!bfweight_) throw j_error("%s", need_weights_msg_());
-  device_snapshots();
+  ensure_chunk_();
   const long idx = frame_no_ + 1;
   while (idx >= chunk_base_ + T_)
     if (!advance_chunk_()) { is_end_ = true; throw jiterator_error("end of samples!"); }
-  if (Yhost_.empty() || output_version_ != weights_version_) compute_output_(kept_frames(frame_no_, handed_, chunk_base_, T_));
-  if (halfBandShift_) serve_frame_all_bins(Yhost_, T_, fftLen_, idx - chunk_base_, vector_);
-  else serve_frame(Yhost_, T_, fftLen_, idx - chunk_base_, vector_);
+  if (idx < chunk_base_)      // a block consumer (the synthesis bank, a post-filter) has moved the node past this frame
+    throw jconsistency_error("%s: frame %ld was asked for after a block consumer moved the stream on to frame %ld; pull the node "
+                             "through one consumer\n", name().c_str(), idx, chunk_base_);
+  const float* Yh = host_output_();
+  if (halfBandShift_) serve_frame_all_bins(Yh, T_, fftLen_, idx - chunk_base_, vector_);
+  else serve_frame(Yh, T_, fftLen_, idx - chunk_base_, vector_);
   increment_();
   return vector_;
 }
 
-void SubbandDS::reset() { SubbandBeamformer::reset(); Yhost_.clear(); handed_ = -1; }
+void SubbandDS::reset() { SubbandBeamformer::reset(); Yhost_.clear(); handed_ = -1; out_valid_ = false; Yhost_valid_ = false; }
 
 bool SubbandDS::advance_chunk_()
 {
-  Yhost_.clear();
+  out_valid_ = false; Yhost_valid_ = false;
   return next_chunk();
 }
 
 const std::vector<float>& SubbandDS::block(long& T)
 {
-  if (!bfweight_) throw j_error("%s", need_weights_msg_());
-  device_snapshots();
-  if (Yhost_.empty() || output_version_ != weights_version_) compute_output_(kept_frames(frame_no_, handed_, chunk_base_, T_));
+  host_output_();
   T = T_;
   return Yhost_;
+}
+
+const void* SubbandDS::device_block(long& T, long& T_stride)
+{
+  ensure_output_();
+  T = T_; T_stride = T_;
+  return dYBuf_.get();
 }
 
 void SubbandDS::advance_to(long frame_idx)
@@ -1357,7 +1690,7 @@ SubbandMVDR::~SubbandMVDR() { dev_free(dR_); gsl_vector_complex_free(wm_view_); 
 void SubbandMVDR::divide_all_nondiagonal_elements(float mu)
 {
   if (!dR_) throw j_error("Construct first a noise covariance matrix\n");
-  check_abi(btk_mvdr_divide_nondiagonal(dR_, (int)(fftLen2_ + 1), (int)chanN(), mu, NULL));
+  check_abi(btk_mvdr_divide_nondiagonal(dR_, (int)(fftLen2_ + 1), (int)chanN(), mu, nstream()));
 }
 
 void SubbandMVDR::divide_nondiagonal_elements(unsigned fbinX, float mu)
@@ -1365,7 +1698,7 @@ void SubbandMVDR::divide_nondiagonal_elements(unsigned fbinX, float mu)
   if (!dR_) throw j_error("Construct first a noise covariance matrix\n");
   if (fbinX > fftLen2_) throw jindex_error("frequency bin %d is out of range: the matrices exist for bins 0..%d\n", (int)fbinX, (int)fftLen2_);
   const unsigned N = chanN();
-  check_abi(btk_mvdr_divide_nondiagonal(static_cast<float*>(dR_) + (size_t)fbinX * 2 * N * N, 1, (int)N, mu, NULL));
+  check_abi(btk_mvdr_divide_nondiagonal(static_cast<float*>(dR_) + (size_t)fbinX * 2 * N * N, 1, (int)N, mu, nstream()));
 }
 
 const gsl_matrix_complex* SubbandMVDR::noise_spatial_spectral_matrix(unsigned fbinX)
@@ -1375,7 +1708,7 @@ const gsl_matrix_complex* SubbandMVDR::noise_spatial_spectral_matrix(unsigned fb
   const unsigned N = chanN();
   if (!R_view_ || R_view_->size1 != N) { gsl_matrix_complex_free(R_view_); R_view_ = gsl_matrix_complex_alloc(N, N); }
   std::vector<float> r((size_t)2 * N * N);
-  check_abi(btk_synchronize(NULL));
+  nsync();
   d2h(r.data(), static_cast<float*>(dR_) + (size_t)fbinX * 2 * N * N, sizeof(float) * r.size());
   for (size_t i = 0; i < (size_t)2 * N * N; i++) R_view_->data[i] = r[i];
   return R_view_;
@@ -1387,7 +1720,7 @@ void SubbandMVDR::alloc_R_()
   if (dR_) return;
   const size_t n = (size_t)2 * (fftLen2_ + 1) * chanN() * chanN();
   dR_ = dev_alloc(sizeof(float) * n);
-  check_hip(hipMemset(dR_, 0, sizeof(float) * n), "hipMemset");
+  dev_zero_async(dR_, sizeof(float) * n);
 }
 
 bool SubbandMVDR::set_noise_spatial_spectral_matrix(unsigned fbinX, gsl_matrix_complex* Rnn)
@@ -1417,8 +1750,8 @@ bool SubbandMVDR::set_diffuse_noise_model(const gsl_matrix* micPositions, float 
   for (unsigned a = 0; a < N; a++) for (int j = 0; j < 3; j++) mp[3 * a + j] = (float)gsl_matrix_get(micPositions, a, j);
   void* dmp = dev_alloc(sizeof(float) * mp.size());
   h2d(dmp, mp.data(), sizeof(float) * mp.size());
-  check_abi(btk_mvdr_diffuse_model((const float*)dmp, (int)N, (int)fftLen_, samplerate, sspeed, dR_, NULL));
-  check_abi(btk_synchronize(NULL));
+  check_abi(btk_mvdr_diffuse_model((const float*)dmp, (int)N, (int)fftLen_, samplerate, sspeed, dR_, nstream()));
+  nsync();
   dev_free(dmp);
   return true;
 }
@@ -1426,7 +1759,7 @@ bool SubbandMVDR::set_diffuse_noise_model(const gsl_matrix* micPositions, float 
 void SubbandMVDR::set_all_diagonal_loading(float diagonalWeight)
 {
   if (!dR_) throw j_error("Construct first a noise covariance matrix\n");
-  check_abi(btk_mvdr_diagonal_loading(dR_, (int)(fftLen2_ + 1), (int)chanN(), diagonalWeight, NULL));
+  check_abi(btk_mvdr_diagonal_loading(dR_, (int)(fftLen2_ + 1), (int)chanN(), diagonalWeight, nstream()));
 }
 
 void SubbandMVDR::set_diagonal_looading(unsigned fbinX, float diagonalWeight)
@@ -1434,7 +1767,7 @@ void SubbandMVDR::set_diagonal_looading(unsigned fbinX, float diagonalWeight)
   if (!dR_) throw j_error("Construct first a noise covariance matrix\n");
   if (fbinX > fftLen2_) throw jindex_error("frequency bin %d is out of range: the matrices exist for bins 0..%d\n", (int)fbinX, (int)fftLen2_);
   const unsigned N = chanN();
-  check_abi(btk_mvdr_diagonal_loading(static_cast<float*>(dR_) + (size_t)fbinX * 2 * N * N, 1, (int)N, diagonalWeight, NULL));
+  check_abi(btk_mvdr_diagonal_loading(static_cast<float*>(dR_) + (size_t)fbinX * 2 * N * N, 1, (int)N, diagonalWeight, nstream()));
 }
 
 bool SubbandMVDR::calc_mvdr_weights(float, float dThreshold, bool)
@@ -1451,21 +1784,21 @@ bool SubbandMVDR::calc_mvdr_weights(float, float dThreshold, bool)
   void* scratch = sbytes ? dev_alloc((size_t)sbytes) : NULL;
   void* dflags = dev_alloc(sizeof(int) * K);
   h2d(dD, d.data(), sizeof(float) * d.size());
-  check_hip(hipMemset(dfb, 0, sizeof(int)), "hipMemset");
-  check_abi(btk_mvdr_weights_flags(dR_, dD, dW, (int)K, (int)N, 0, dThreshold, scratch, (int*)dfb, (int*)dflags, NULL));
+  dev_zero_async(dfb, sizeof(int));
+  check_abi(btk_mvdr_weights_flags(dR_, dD, dW, (int)K, (int)N, 0, dThreshold, scratch, (int*)dfb, (int*)dflags, nstream()));
   int rule_counts[2] = {0, 0};
   if (svd_rule_ == "linpack") {
     // pseudoinverse() returns false where the reference's float32 csvdc gives INFO != 0 or a singular value under the
     // threshold -> identity (beamformer.cc:253-270, 2379-2384); those bins also leave the fall-back's list
     void* dcnt = dev_alloc(sizeof(int) * 2);
     void* rs = dev_alloc((size_t)btk_mvdr_linpack_rule_scratch_bytes((int)K, (int)N));
-    check_hip(hipMemset(dcnt, 0, sizeof(int) * 2), "hipMemset");
-    check_abi(btk_mvdr_linpack_rule(dR_, dD, dW, NULL, (int)K, (int)N, 0, 0, 1, dThreshold, (int*)dflags, (int*)dcnt, rs, NULL));
-    check_abi(btk_synchronize(NULL));
+    dev_zero_async(dcnt, sizeof(int) * 2);
+    check_abi(btk_mvdr_linpack_rule(dR_, dD, dW, NULL, (int)K, (int)N, 0, 0, 1, dThreshold, (int*)dflags, (int*)dcnt, rs, nstream()));
+    nsync();
     d2h(rule_counts, dcnt, sizeof(rule_counts));
     dev_free(dcnt); dev_free(rs);
   }
-  check_abi(btk_synchronize(NULL));
+  nsync();
   csvdc_not_converged_ = rule_counts[0];
   std::vector<int> hflags(K);
   d2h(hflags.data(), dflags, sizeof(int) * K);
@@ -1473,7 +1806,7 @@ bool SubbandMVDR::calc_mvdr_weights(float, float dThreshold, bool)
   for (unsigned k = 0; k < K; ++k) stopped += hflags[k] != 0;
   fallbacks_ = 0;
   if (stopped > 0)     // bins the Cholesky solve gave up on and the rule above left open: the pseudo-inverse (beamformer.cc:232-289)
-    check_abi(btk_mvdr_pinv_fallback(dR_, dD, dW, (int)K, (int)N, 0, dThreshold, (const int*)dflags, &fallbacks_, NULL));
+    check_abi(btk_mvdr_pinv_fallback(dR_, dD, dW, (int)K, (int)N, 0, dThreshold, (const int*)dflags, &fallbacks_, nstream()));
   fallbacks_ += rule_counts[0] + rule_counts[1];
   wmvdr_.resize(d.size());
   d2h(wmvdr_.data(), dW, sizeof(float) * wmvdr_.size());
@@ -1586,7 +1919,7 @@ void SubbandMVDRGSC::effective_weights(std::vector<float>& w)
 ZelinskiPostFilter::ZelinskiPostFilter(VectorComplexFeatureStreamPtr& output, unsigned fftLen, double alpha, int type,
                                        int minFrames, const String& nm)
     : VectorComplexFeatureStream(fftLen, nm), fftLen_(fftLen), samp_(output), type_((PostfilterType)type), alpha_(alpha),
-      min_frames_(minFrames), has_bf_ptr_(false), T_(0), prepared_(false), bf_version_(0), dPhi_(NULL), dPsi_(NULL), dWl_(NULL),
+      min_frames_(minFrames), has_bf_ptr_(false), Yhost_valid_(false), T_(0), prepared_(false), bf_version_(0), dPhi_(NULL), dPsi_(NULL), dWl_(NULL),
       wp1_(gsl_vector_complex_calloc(fftLen)), hist_start_(0), own_weights_(NULL), manual_frames_(0), base_(0), carry_state_(false),
       handed_(-1)
 {
@@ -1659,9 +1992,9 @@ void ZelinskiPostFilter::csd_state_(long t, std::vector<float>& R)
     void* dF = dev_alloc(sizeof(float) * Tn);
     void* dR = dev_alloc(sizeof(float) * R.size());
     h2d(dF, fw.data(), sizeof(float) * Tn);
-    check_hip(hipMemset(dR, 0, sizeof(float) * R.size()), "hipMemset");
-    check_abi(btk_cov_accumulate(dX, NULL, (const float*)dF, dR, 1, (int)K, (int)N, Tstride, Tn, 0, NULL));
-    check_abi(btk_synchronize(NULL));
+    dev_zero_async(dR, sizeof(float) * R.size());
+    check_abi(btk_cov_accumulate(dX, NULL, (const float*)dF, dR, 1, (int)K, (int)N, Tstride, Tn, 0, nstream()));
+    nsync();
     d2h(R.data(), dR, sizeof(float) * R.size());
     dev_free(dF); dev_free(dR);
   }
@@ -1742,9 +2075,9 @@ const gsl_vector_complex* ZelinskiPostFilter::next_manual_(int frame_no)
   }
   if (!dPhi_) {
     dPhi_ = dev_alloc(sizeof(float) * 2 * K); dPsi_ = dev_alloc(sizeof(float) * K); dWl_ = dev_alloc(sizeof(float) * K);
-    check_hip(hipMemset(dPhi_, 0, sizeof(float) * 2 * K), "hipMemset");
-    check_hip(hipMemset(dPsi_, 0, sizeof(float) * K), "hipMemset");
-    check_hip(hipMemset(dWl_, 0, sizeof(float) * K), "hipMemset");
+    dev_zero_async(dPhi_, sizeof(float) * 2 * K);
+    dev_zero_async(dPsi_, sizeof(float) * K);
+    dev_zero_async(dWl_, sizeof(float) * K);
   }
   void* dXf = dev_alloc(sizeof(float) * x.size());
   void* dD = dev_alloc(sizeof(float) * d.size());
@@ -1753,11 +2086,11 @@ const gsl_vector_complex* ZelinskiPostFilter::next_manual_(int frame_no)
   void* dE = dev_alloc(sizeof(float) * K);
   h2d(dXf, x.data(), sizeof(float) * x.size());
   h2d(dD, d.data(), sizeof(float) * d.size());
-  check_abi(btk_bf_apply_stats(dD, dD, 0, dXf, dY, dC, (float*)dE, 1, (int)K, (int)N, 1, 1, NULL));   // only C and E are used
+  check_abi(btk_bf_apply_stats(dD, dD, 0, dXf, dY, dC, (float*)dE, 1, (int)K, (int)N, 1, 1, nstream()));   // only C and E are used
   h2d(dY, y.data(), sizeof(float) * y.size());                                                        // the frame to filter is samp_'s
   check_abi(btk_zelinski_process(dY, dC, (const float*)dE, 1, (int)K, (int)N, 1, 1, alpha_, (int)type_, min_frames_,
-                                 manual_frames_, dPhi_, (float*)dPsi_, (float*)dWl_, NULL));
-  check_abi(btk_synchronize(NULL));
+                                 manual_frames_, dPhi_, (float*)dPsi_, (float*)dWl_, nstream()));
+  nsync();
   d2h(y.data(), dY, sizeof(float) * y.size());
   dev_free(dXf); dev_free(dD); dev_free(dY); dev_free(dC); dev_free(dE);
   for (unsigned k = 0; k < K; k++) {
@@ -1790,17 +2123,17 @@ void ZelinskiPostFilter::compute_(long from_frame)
   if (!carry) {
     // weights (re)computed: the CSD history restarts, the frame counter keeps counting; the following block
     // of the same stream instead continues from the densities the block before left on the device
-    check_hip(hipMemset(dPhi_, 0, sizeof(float) * 2 * K), "hipMemset");
-    check_hip(hipMemset(dPsi_, 0, sizeof(float) * K), "hipMemset");
-    check_hip(hipMemset(dWl_, 0, sizeof(float) * K), "hipMemset");
+    dev_zero_async(dPhi_, sizeof(float) * 2 * K);
+    dev_zero_async(dPsi_, sizeof(float) * K);
+    dev_zero_async(dWl_, sizeof(float) * K);
   }
-  std::vector<float> Ynew((size_t)2 * K * T_);
+  // node-owned blocks that only grow; the frames before from_frame keep what the pass before left in dYb_ (same block, same size)
+  void* dY = dYb_.ensure(sizeof(float) * 2 * K * (T_ ? T_ : 1));
   if (Tn > 0) {
-    void* dW = dev_alloc(sizeof(float) * w.size());
-    void* dD = dev_alloc(sizeof(float) * d.size());
-    void* dY = dev_alloc(sizeof(float) * 2 * K * T_);
-    void* dC = dev_alloc(sizeof(float) * 2 * K * T_);
-    void* dE = dev_alloc(sizeof(float) * K * T_);
+    void* dW = dWb_.ensure(sizeof(float) * w.size());
+    void* dD = dDb_.ensure(sizeof(float) * d.size());
+    void* dC = dCb_.ensure(sizeof(float) * 2 * K * T_);
+    void* dE = dEb_.ensure(sizeof(float) * K * T_);
     h2d(dW, w.data(), sizeof(float) * w.size());
     h2d(dD, d.data(), sizeof(float) * d.size());
     // process frames [from_frame, T): offset the frame axis by pointer arithmetic, strides stay T_
@@ -1808,14 +2141,11 @@ void ZelinskiPostFilter::compute_(long from_frame)
     float* Yo = static_cast<float*>(dY) + 2 * from_frame;
     float* Co = static_cast<float*>(dC) + 2 * from_frame;
     float* Eo = static_cast<float*>(dE) + from_frame;
-    check_abi(btk_bf_apply_stats(dW, dD, 0, Xo, Yo, Co, Eo, 1, (int)K, (int)N, T_, Tn, NULL));
+    check_abi(btk_bf_apply_stats(dW, dD, 0, Xo, Yo, Co, Eo, 1, (int)K, (int)N, T_, Tn, nstream()));
     check_abi(btk_zelinski_process(Yo, Co, Eo, 1, (int)K, (int)N, T_, Tn, alpha_, (int)type_, min_frames_, base_ + from_frame,
-                                   dPhi_, (float*)dPsi_, (float*)dWl_, NULL));
-    check_abi(btk_synchronize(NULL));
-    d2h(Ynew.data(), dY, sizeof(float) * Ynew.size());
-    dev_free(dW); dev_free(dD); dev_free(dY); dev_free(dC); dev_free(dE);
+                                   dPhi_, (float*)dPsi_, (float*)dWl_, nstream()));
   }
-  merge_output_(Ynew, from_frame);
+  Yhost_valid_ = false;
   bf_version_ = bf->weights_version();
   if (!carry) { hist_start_ = base_ + from_frame; csd_carry_.clear(); }
   bind_csd_provider_();
@@ -1836,17 +2166,19 @@ bool ZelinskiPostFilter::advance_chunk_()
     }
   }
   if (!bf_ptr_->next_block()) return false;
-  prepared_ = false; carry_state_ = true; Yhost_.clear();
+  prepared_ = false; carry_state_ = true; Yhost_valid_ = false;
   return true;
 }
 
-void ZelinskiPostFilter::merge_output_(std::vector<float>& Ynew, long from_frame)
+// the filtered block as the host sees it (fetched when a frame or the host block is asked for)
+const float* ZelinskiPostFilter::host_output_()
 {
-  const unsigned K = fftLen_ / 2 + 1;
-  if (Yhost_.size() == Ynew.size() && from_frame > 0)
-    for (unsigned k = 0; k < K; k++)                          // frames already served keep their values
-      memcpy(&Ynew[2 * ((size_t)k * T_)], &Yhost_[2 * ((size_t)k * T_)], sizeof(float) * 2 * (size_t)from_frame);
-  Yhost_.swap(Ynew);
+  if (!Yhost_valid_) {
+    Yhost_.resize((size_t)2 * (fftLen_ / 2 + 1) * T_);
+    d2h(Yhost_.data(), dYb_.get(), sizeof(float) * Yhost_.size());
+    Yhost_valid_ = true;
+  }
+  return Yhost_.data();
 }
 
 const gsl_vector_complex* ZelinskiPostFilter::next(int frame_no)
@@ -1859,7 +2191,7 @@ const gsl_vector_complex* ZelinskiPostFilter::next(int frame_no)
     if (!advance_chunk_()) { is_end_ = true; throw jiterator_error("end of samples!"); }
     compute_(0);
   }
-  serve_frame(Yhost_, T_, fftLen_, idx - base_, vector_);
+  serve_frame(host_output_(), T_, fftLen_, idx - base_, vector_);
   increment_();
   return vector_;
 }
@@ -1868,8 +2200,17 @@ const std::vector<float>& ZelinskiPostFilter::block(long& T)
 {
   if (!has_bf_ptr_) throw j_error("set beamformer's weights \n");
   if (!prepared_ || bf_version_ != bf_ptr_->weights_version()) compute_(kept_frames(frame_no_, handed_, bf_ptr_->chunk_base(), bf_ptr_->num_frames()));
+  host_output_();
   T = T_;
   return Yhost_;
+}
+
+const void* ZelinskiPostFilter::device_block(long& T, long& T_stride)
+{
+  if (!has_bf_ptr_) throw j_error("set beamformer's weights \n");
+  if (!prepared_ || bf_version_ != bf_ptr_->weights_version()) compute_(kept_frames(frame_no_, handed_, bf_ptr_->chunk_base(), bf_ptr_->num_frames()));
+  T = T_; T_stride = T_;
+  return dYb_.get();
 }
 
 long ZelinskiPostFilter::block_base()
@@ -1914,13 +2255,13 @@ void ZelinskiPostFilter::reset()
   samp_->reset();
   VectorComplexFeatureStream::reset();
   is_end_ = false;
-  prepared_ = false; Yhost_.clear(); T_ = 0; base_ = 0; carry_state_ = false; csd_carry_.clear();
+  prepared_ = false; Yhost_.clear(); Yhost_valid_ = false; T_ = 0; base_ = 0; carry_state_ = false; csd_carry_.clear();
   csd_manual_.clear(); manual_frames_ = 0; hist_start_ = 0; handed_ = -1;
   if (!has_bf_ptr_ && dPhi_) {              // manual mode: the densities of the next utterance start from zero
     const unsigned K = fftLen_ / 2 + 1;
-    check_hip(hipMemset(dPhi_, 0, sizeof(float) * 2 * K), "hipMemset");
-    check_hip(hipMemset(dPsi_, 0, sizeof(float) * K), "hipMemset");
-    check_hip(hipMemset(dWl_, 0, sizeof(float) * K), "hipMemset");
+    dev_zero_async(dPhi_, sizeof(float) * 2 * K);
+    dev_zero_async(dPsi_, sizeof(float) * K);
+    dev_zero_async(dWl_, sizeof(float) * K);
   }
 }
 
@@ -1928,7 +2269,14 @@ void ZelinskiPostFilter::reset()
 McCowanPostFilter::McCowanPostFilter(VectorComplexFeatureStreamPtr& output, unsigned fftLen, double alpha, int type,
                                      int minFrames, float threshold, const String& nm)
     : ZelinskiPostFilter(output, fftLen, alpha, type, minFrames, nm), threshold_of_Rij_(threshold), nChanR_(0), dR_(NULL),
-      Rview_(NULL), invR_computed_(false), minSV_(1.0e-8), fbinX1_(0), dU_(NULL), dV_(NULL) {}
+      Rview_(NULL), invR_computed_(false), minSV_(1.0e-8), fbinX1_(0), dU_(NULL), dV_(NULL), svd_rule_(default_svd_rule()),
+      lam_valid_(false), lam_version_(0) {}
+
+void McCowanPostFilter::set_svd_rule(const String& rule)
+{
+  if (rule != "linpack" && rule != "exact") throw jparameter_error("svd rule must be linpack or exact, got %s\n", rule.c_str());
+  if (rule != svd_rule_) { svd_rule_ = rule; prepared_ = false; }
+}
 
 McCowanPostFilter::~McCowanPostFilter()
 {
@@ -1945,7 +2293,7 @@ void McCowanPostFilter::fetch_R_()
 void McCowanPostFilter::push_R_()
 {
   h2d(dR_, Rhost_.data(), sizeof(float) * Rhost_.size());
-  invR_computed_ = false;
+  invR_computed_ = false; lam_valid_ = false;
   prepared_ = false;
 }
 
@@ -1970,7 +2318,7 @@ bool McCowanPostFilter::set_noise_spatial_spectral_matrix(unsigned fbinX, gsl_ma
     dev_free(dR_);
     nChanR_ = N;
     dR_ = dev_alloc(sizeof(float) * 2 * K * N * N);
-    check_hip(hipMemset(dR_, 0, sizeof(float) * 2 * K * N * N), "hipMemset");
+    dev_zero_async(dR_, sizeof(float) * 2 * K * N * N);
   }
   fetch_R_();
   for (unsigned a = 0; a < N; a++)
@@ -1992,10 +2340,10 @@ bool McCowanPostFilter::set_diffuse_noise_model(const gsl_matrix* micPositions, 
   for (unsigned a = 0; a < N; a++) for (int j = 0; j < 3; j++) mp[3 * a + j] = (float)gsl_matrix_get(micPositions, a, j);
   void* dmp = dev_alloc(sizeof(float) * mp.size());
   h2d(dmp, mp.data(), sizeof(float) * mp.size());
-  check_abi(btk_mvdr_diffuse_model((const float*)dmp, (int)N, (int)fftLen_, (float)sampleRate, (float)sspeed, dR_, NULL));
-  check_abi(btk_synchronize(NULL));
+  check_abi(btk_mvdr_diffuse_model((const float*)dmp, (int)N, (int)fftLen_, (float)sampleRate, (float)sspeed, dR_, nstream()));
+  nsync();
   dev_free(dmp);
-  invR_computed_ = false;
+  invR_computed_ = false; lam_valid_ = false;
   prepared_ = false;
   return true;
 }
@@ -2003,8 +2351,8 @@ bool McCowanPostFilter::set_diffuse_noise_model(const gsl_matrix* micPositions, 
 void McCowanPostFilter::set_all_diagonal_loading(float diagonalWeight)
 {
   if (!dR_) throw j_error("Construct/set first a noise coherence matrix\n");
-  check_abi(btk_mvdr_diagonal_loading(dR_, (int)(fftLen_ / 2 + 1), (int)nChanR_, diagonalWeight, NULL));
-  invR_computed_ = false;
+  check_abi(btk_mvdr_diagonal_loading(dR_, (int)(fftLen_ / 2 + 1), (int)nChanR_, diagonalWeight, nstream()));
+  invR_computed_ = false; lam_valid_ = false;
   prepared_ = false;
 }
 
@@ -2013,8 +2361,8 @@ void McCowanPostFilter::set_diagonal_looading(unsigned fbinX, float diagonalWeig
   if (!dR_) throw j_error("Construct/set first a noise coherence matrix\n");
   if (fbinX > fftLen_ / 2) throw jindex_error("frequency bin %d is out of range: the matrices exist for bins 0..%d\n", (int)fbinX, (int)(fftLen_ / 2));
   check_abi(btk_mvdr_diagonal_loading(static_cast<float*>(dR_) + (size_t)2 * fbinX * nChanR_ * nChanR_, 1, (int)nChanR_,
-                                      diagonalWeight, NULL));
-  invR_computed_ = false;
+                                      diagonalWeight, nstream()));
+  invR_computed_ = false; lam_valid_ = false;
   prepared_ = false;
 }
 
@@ -2059,57 +2407,59 @@ void McCowanPostFilter::compute_(long from_frame)
   if (!dPhi_) { dPhi_ = dev_alloc(sizeof(float) * 2 * K); dPsi_ = dev_alloc(sizeof(float) * K); dWl_ = dev_alloc(sizeof(float) * K); }
   if (!dU_) { dU_ = dev_alloc(sizeof(float) * 2 * K); dV_ = dev_alloc(sizeof(float) * 2 * K); }
   if (!carry) {                                                                // (the next block of a stream continues the recursions)
-    check_hip(hipMemset(dPhi_, 0, sizeof(float) * 2 * K), "hipMemset");
-    check_hip(hipMemset(dPsi_, 0, sizeof(float) * K), "hipMemset");
-    check_hip(hipMemset(dWl_, 0, sizeof(float) * K), "hipMemset");
-    check_hip(hipMemset(dV_, 0, sizeof(float) * 2 * K), "hipMemset");
+    dev_zero_async(dPhi_, sizeof(float) * 2 * K);
+    dev_zero_async(dPsi_, sizeof(float) * K);
+    dev_zero_async(dWl_, sizeof(float) * K);
+    dev_zero_async(dV_, sizeof(float) * 2 * K);
   }
-  std::vector<float> Ynew((size_t)2 * K * T_);
+  void* dY = dYb_.ensure(sizeof(float) * 2 * K * (T_ ? T_ : 1));
   if (Tn > 0) {
-    void* dW = dev_alloc(sizeof(float) * w.size());
-    void* dD = dev_alloc(sizeof(float) * d.size());
-    void* dY = dev_alloc(sizeof(float) * 2 * K * T_);
-    void* dUs = dev_alloc(sizeof(float) * 2 * K * T_);
-    void* dVs = lef ? dev_alloc(sizeof(float) * 2 * K * T_) : NULL;
-    void* dE = dev_alloc(sizeof(float) * K * T_);
-    void* dCs = dev_alloc(sizeof(float) * 2 * K * N * N);
-    void* dCv = lef ? dev_alloc(sizeof(float) * 2 * K * N * N) : NULL;
+    void* dW = dWb_.ensure(sizeof(float) * w.size());
+    void* dD = dDb_.ensure(sizeof(float) * d.size());
+    void* dUs = dCb_.ensure(sizeof(float) * 2 * K * T_);
+    void* dVs = lef ? dVsb_.ensure(sizeof(float) * 2 * K * T_) : NULL;
+    void* dE = dEb_.ensure(sizeof(float) * K * T_);
+    void* dCs = dCsb_.ensure(sizeof(float) * 2 * K * N * N);
+    void* dCv = lef ? dCvb_.ensure(sizeof(float) * 2 * K * N * N) : NULL;
     h2d(dW, w.data(), sizeof(float) * w.size());
     h2d(dD, d.data(), sizeof(float) * d.size());
-    check_abi(btk_pf_coherence_coeffs(dR_, threshold_of_Rij_, (int)K, (int)N, dCs, dCv, NULL));
+    check_abi(btk_pf_coherence_coeffs(dR_, threshold_of_Rij_, (int)K, (int)N, dCs, dCv, nstream()));
     const float* Xo = static_cast<const float*>(dX) + 2 * from_frame;
     float* Yo = static_cast<float*>(dY) + 2 * from_frame;
     float* Uo = static_cast<float*>(dUs) + 2 * from_frame;
     float* Vo = lef ? static_cast<float*>(dVs) + 2 * from_frame : NULL;
     float* Eo = static_cast<float*>(dE) + from_frame;
-    check_abi(btk_bf_apply_stats2(dW, dD, 0, Xo, Yo, dCs, dCv, Uo, Vo, Eo, 1, (int)K, (int)N, T_, Tn, NULL));
+    check_abi(btk_bf_apply_stats2(dW, dD, 0, Xo, Yo, dCs, dCv, Uo, Vo, Eo, 1, (int)K, (int)N, T_, Tn, nstream()));
     if (lef) {
-      void* dLam = dev_alloc(sizeof(float) * 2 * K);
-      void* dFb = dev_alloc(sizeof(int));
-      check_hip(hipMemset(dFb, 0, sizeof(int)), "hipMemset");
-      const long sbytes = btk_mvdr_scratch_bytes((int)K, (int)N);
-      void* scratch = sbytes ? dev_alloc((size_t)sbytes) : NULL;
-      check_abi(btk_mvdr_lambda(dR_, dD, dLam, (int)K, (int)N, (float)minSV_, scratch, (int*)dFb, NULL));   // :967-995
-      if (default_svd_rule() == "linpack") {               // pseudoinverse() false -> identity, every bin incl. 0 (:971-977)
-        void* rs = dev_alloc((size_t)btk_mvdr_linpack_rule_scratch_bytes((int)K, (int)N));
-        check_abi(btk_mvdr_linpack_rule(dR_, dD, NULL, dLam, (int)K, (int)N, 0, 0, 0, (float)minSV_, NULL, NULL, rs, NULL));
-        check_abi(btk_synchronize(NULL));
-        dev_free(rs);
+      // Lambda = d^H pinv(R) d of every bin (:967-995) depends on the coherence matrix, the look direction and the SVD rule only:
+      // designed once and kept until one of them changes (the csvdc rule alone takes ~0.1 s at 256 channels -- per block it
+      // would dominate a stream)
+      if (!lam_valid_ || lam_version_ != bf->weights_version() || lam_rule_ != svd_rule_) {
+        void* dLam = dLamb_.ensure(sizeof(float) * 2 * K);
+        void* dFb = dev_alloc(sizeof(int));
+        dev_zero_async(dFb, sizeof(int));
+        const long sbytes = btk_mvdr_scratch_bytes((int)K, (int)N);
+        void* scratch = sbytes ? dev_alloc((size_t)sbytes) : NULL;
+        check_abi(btk_mvdr_lambda(dR_, dD, dLam, (int)K, (int)N, (float)minSV_, scratch, (int*)dFb, nstream()));
+        if (svd_rule_ == "linpack") {                      // pseudoinverse() false -> identity, every bin incl. 0 (:971-977)
+          void* rs = dev_alloc((size_t)btk_mvdr_linpack_rule_scratch_bytes((int)K, (int)N));
+          check_abi(btk_mvdr_linpack_rule(dR_, dD, NULL, dLam, (int)K, (int)N, 0, 0, 0, (float)minSV_, NULL, NULL, rs, nstream()));
+          nsync();
+          dev_free(rs);
+        }
+        nsync();
+        dev_free(dFb); dev_free(scratch);
+        lam_valid_ = true; lam_version_ = bf->weights_version(); lam_rule_ = svd_rule_;
       }
       invR_computed_ = true;
-      check_abi(btk_lefkimmiatis_process(Yo, Uo, Vo, dLam, (int)fbinX1_, 1, (int)K, (int)N, T_, Tn, alpha_, (int)type_,
-                                         min_frames_, base_ + from_frame, dPhi_, dV_, (float*)dWl_, NULL));
-      check_abi(btk_synchronize(NULL));
-      dev_free(dLam); dev_free(dFb); dev_free(scratch);
+      check_abi(btk_lefkimmiatis_process(Yo, Uo, Vo, dLamb_.get(), (int)fbinX1_, 1, (int)K, (int)N, T_, Tn, alpha_, (int)type_,
+                                         min_frames_, base_ + from_frame, dPhi_, dV_, (float*)dWl_, nstream()));
     } else {
       check_abi(btk_zelinski_process(Yo, Uo, Eo, 1, (int)K, (int)N, T_, Tn, alpha_, (int)type_ & 3, min_frames_, base_ + from_frame,
-                                     dPhi_, (float*)dPsi_, (float*)dWl_, NULL));
-      check_abi(btk_synchronize(NULL));
+                                     dPhi_, (float*)dPsi_, (float*)dWl_, nstream()));
     }
-    d2h(Ynew.data(), dY, sizeof(float) * Ynew.size());
-    dev_free(dW); dev_free(dD); dev_free(dY); dev_free(dUs); dev_free(dVs); dev_free(dE); dev_free(dCs); dev_free(dCv);
   }
-  merge_output_(Ynew, from_frame);
+  Yhost_valid_ = false;
   bf_version_ = bf->weights_version();
   if (!carry) { hist_start_ = base_ + from_frame; csd_carry_.clear(); }
   bind_csd_provider_();
@@ -2129,7 +2479,7 @@ void LefkimmiatisPostFilter::calc_inverse_noise_spatial_spectral_matrix()
 {
   // calcLambda only needs d^H pinv(R) d, formed with the look direction when the block is computed
   if (!dR_) throw j_error("%s", no_R_msg_());
-  prepared_ = false;
+  prepared_ = false; lam_valid_ = false;
 }
 
 // ================================================================================ SubbandGSCRLS
@@ -2222,7 +2572,7 @@ void SubbandGSCRLS::alloc_state_()
   dP0_ = dev_alloc(sizeof(double) * 2 * K * N * N);
   dW0_ = dev_alloc(sizeof(double) * 2 * K * N);
   dSS0_ = dev_alloc(sizeof(double) * 4);
-  check_hip(hipMemset(dSS_, 0, sizeof(double) * 4), "hipMemset");
+  dev_zero_async(dSS_, sizeof(double) * 4);
   upload_weights_();
 }
 
@@ -2231,11 +2581,11 @@ void SubbandGSCRLS::init_precision_matrix(float sigma2)
   alloc_state_();
   const unsigned N = chanN(), K = fftLen2_ + 1;
   const float p0 = 1 / sigma2;                                                // float division, beamformer.cc:1491
-  check_abi(btk_rls_init_nc(0, dV_, 0, dCx_, (int)bfweight_->NC(), (double)p0, 1, (int)K, (int)N, dP_, dW_, NULL));
+  check_abi(btk_rls_init_nc(0, dV_, 0, dCx_, (int)bfweight_->NC(), (double)p0, 1, (int)K, (int)N, dP_, dW_, nstream()));
   // the active weights kept in the weight object are the starting point (zeros after calc_gsc_weights)
   h2d(dW_, bfweight_->wl_v.data(), sizeof(double) * 2 * K * N);
   have_P_ = true;
-  Yhost_.clear(); block_ran_ = false;
+  out_valid_ = false; Yhost_valid_ = false; block_ran_ = false;
 }
 
 void SubbandGSCRLS::set_precision_matrix(unsigned fbinX, gsl_matrix_complex* Pz)
@@ -2243,7 +2593,7 @@ void SubbandGSCRLS::set_precision_matrix(unsigned fbinX, gsl_matrix_complex* Pz)
   if (!have_P_) {
     alloc_state_();
     const unsigned N = chanN(), K = fftLen2_ + 1;
-    check_hip(hipMemset(dP_, 0, sizeof(double) * 2 * K * N * N), "hipMemset");
+    dev_zero_async(dP_, sizeof(double) * 2 * K * N * N);
     h2d(dW_, bfweight_->wl_v.data(), sizeof(double) * 2 * K * N);
     have_P_ = true;
   }
@@ -2269,7 +2619,7 @@ void SubbandGSCRLS::set_precision_matrix(unsigned fbinX, gsl_matrix_complex* Pz)
       P[(size_t)a * N + b] = acc;
     }
   h2d(static_cast<double*>(dP_) + (size_t)2 * fbinX * N * N, P.data(), sizeof(double) * 2 * N * N);
-  Yhost_.clear(); block_ran_ = false;
+  out_valid_ = false; Yhost_valid_ = false; block_ran_ = false;
 }
 
 // The recursion over the current block of snapshots, from the state the block before left (P, w_a and the stream counters move
@@ -2277,19 +2627,16 @@ void SubbandGSCRLS::set_precision_matrix(unsigned fbinX, gsl_matrix_complex* Pz)
 void SubbandGSCRLS::run_block_()
 {
   const unsigned N = chanN(), K = fftLen2_ + 1;
-  void* dX = device_snapshots();
-  check_hip(hipMemcpy(dP0_, dP_, sizeof(double) * 2 * K * N * N, hipMemcpyDeviceToDevice), "hipMemcpy D2D");
-  check_hip(hipMemcpy(dW0_, dW_, sizeof(double) * 2 * K * N, hipMemcpyDeviceToDevice), "hipMemcpy D2D");
-  check_hip(hipMemcpy(dSS0_, dSS_, sizeof(double) * 4, hipMemcpyDeviceToDevice), "hipMemcpy D2D");
-  void* dY = dev_alloc(sizeof(float) * 2 * K * (T_ ? T_ : 1));
+  void* dX = snapshots_();
+  d2d_async(dP0_, dP_, sizeof(double) * 2 * K * N * N);
+  d2d_async(dW0_, dW_, sizeof(double) * 2 * K * N);
+  d2d_async(dSS0_, dSS_, sizeof(double) * 4);
+  void* dY = dYBuf_.ensure(sizeof(float) * 2 * K * (T_ ? T_ : 1));          // the block's output lives where the static apply's would
   const double params[6] = { (double)mu_, (double)diagonal_weight_, (double)(int)qctype_, (double)alpha_,
                              normalize_weight_ ? 1.0 : 0.0, is_wa_updated_ ? 1.0 : 0.0 };
-  void* ws = dev_alloc((size_t)btk_rls_workspace_bytes(1, T_ ? T_ : 1));
-  check_abi(btk_rls_process_nc(0, params, dV_, 0, dCx_, (int)bfweight_->NC(), dX, dY, 1, (int)fftLen_, (int)N, T_, T_, dP_, dW_, (double*)dSS_, ws, NULL));
-  check_abi(btk_synchronize(NULL));
-  Yhost_.assign((size_t)2 * K * T_, 0.f);
-  if (T_) d2h(Yhost_.data(), dY, sizeof(float) * Yhost_.size());
-  dev_free(dY); dev_free(ws);
+  void* ws = dWs_.ensure((size_t)btk_rls_workspace_bytes(1, T_ ? T_ : 1));
+  check_abi(btk_rls_process_nc(0, params, dV_, 0, dCx_, (int)bfweight_->NC(), dX, dY, 1, (int)fftLen_, (int)N, T_, T_, dP_, dW_, (double*)dSS_, ws, nstream()));
+  out_valid_ = true; Yhost_valid_ = false;
   // export wl / wa of bins 1..M/2 as calcSidelobeCancellerU_f leaves them (beamformer.cc:1643)
   std::vector<cd> wl((size_t)K * N);
   d2h(wl.data(), dW_, sizeof(double) * 2 * K * N);
@@ -2312,15 +2659,38 @@ const std::vector<float>& SubbandGSCRLS::block(long& T)
   if (!bfweight_) throw j_error("call calc_gsc_weights_x() once\n");
   if (!have_P_) throw j_error("set the precision matrix with init_precision_matrix() or set_precision_matrix()\n");
   if (halfBandShift_) throw j_error("halfBandShift==true is not yet supported\n");
-  device_snapshots();
+  ensure_chunk_();
   refresh_block_();
+  rls_host_output_();
   T = T_;
   return Yhost_;
 }
 
+const void* SubbandGSCRLS::device_block(long& T, long& T_stride)
+{
+  if (!bfweight_) throw j_error("call calc_gsc_weights_x() once\n");
+  if (!have_P_) throw j_error("set the precision matrix with init_precision_matrix() or set_precision_matrix()\n");
+  if (halfBandShift_) throw j_error("halfBandShift==true is not yet supported\n");
+  ensure_chunk_();
+  refresh_block_();
+  T = T_; T_stride = T_;
+  return dYBuf_.get();
+}
+
+// the block of the recursion mirrored on the host (SubbandDS::host_output_ would run the static apply)
+const float* SubbandGSCRLS::rls_host_output_()
+{
+  if (!Yhost_valid_) {
+    Yhost_.assign((size_t)2 * (fftLen2_ + 1) * T_, 0.f);
+    if (T_) d2h(Yhost_.data(), dYBuf_.get(), sizeof(float) * Yhost_.size());
+    Yhost_valid_ = true;
+  }
+  return Yhost_.data();
+}
+
 bool SubbandGSCRLS::advance_chunk_()
 {
-  Yhost_.clear(); block_ran_ = false;
+  out_valid_ = false; Yhost_valid_ = false; block_ran_ = false;
   return next_chunk();
 }
 
@@ -2336,9 +2706,9 @@ void SubbandGSCRLS::refresh_block_()
     if (kept_frames(frame_no_, handed_, chunk_base_, T_) > 0)
       throw jconsistency_error("SubbandGSCRLS: the weights changed after frames of this block were served; reset() first\n");
     const unsigned N = chanN(), K = fftLen2_ + 1;
-    check_hip(hipMemcpy(dP_, dP0_, sizeof(double) * 2 * K * N * N, hipMemcpyDeviceToDevice), "hipMemcpy D2D");
-    check_hip(hipMemcpy(dW_, dW0_, sizeof(double) * 2 * K * N, hipMemcpyDeviceToDevice), "hipMemcpy D2D");
-    check_hip(hipMemcpy(dSS_, dSS0_, sizeof(double) * 4, hipMemcpyDeviceToDevice), "hipMemcpy D2D");
+    d2d_async(dP_, dP0_, sizeof(double) * 2 * K * N * N);
+    d2d_async(dW_, dW0_, sizeof(double) * 2 * K * N);
+    d2d_async(dSS_, dSS0_, sizeof(double) * 4);
   }
   if (uploaded_version_ != weights_version_) {
     const bool had_state = !wq_uploaded_.empty();
@@ -2355,12 +2725,12 @@ const gsl_vector_complex* SubbandGSCRLS::next(int frame_no)
   if (!bfweight_) throw j_error("call calc_gsc_weights_x() once\n");
   if (!have_P_) throw j_error("set the precision matrix with init_precision_matrix() or set_precision_matrix()\n");
   if (halfBandShift_) throw j_error("halfBandShift==true is not yet supported\n");          // reference beamformer.cc:1528-1530
-  device_snapshots();
+  ensure_chunk_();
   const long idx = frame_no_ + 1;
   while (idx >= chunk_base_ + T_)
     if (!advance_chunk_()) { is_end_ = true; throw jiterator_error("end of samples!"); }
   refresh_block_();
-  serve_frame(Yhost_, T_, fftLen_, idx - chunk_base_, vector_);
+  serve_frame(rls_host_output_(), T_, fftLen_, idx - chunk_base_, vector_);
   increment_();
   return vector_;
 }
@@ -2416,7 +2786,7 @@ void MultiChannelWPEDereverberation::next_speaker()
   reset();
   if (dG_) {
     const unsigned K = subbandsN_ / 2 + 1, P = channelsN_ * (upperN_ - lowerN_ + 1);
-    check_hip(hipMemset(dG_, 0, sizeof(float) * 2 * channelsN_ * K * P), "hipMemset");
+    dev_zero_async(dG_, sizeof(float) * 2 * channelsN_ * K * P);
   }
 }
 
@@ -2456,17 +2826,17 @@ unsigned MultiChannelWPEDereverberation::estimate_filter(int start_frame_no, int
   }
   if (!dG_) {
     dG_ = dev_alloc(sizeof(float) * 2 * C * K * P);
-    check_hip(hipMemset(dG_, 0, sizeof(float) * 2 * C * K * P), "hipMemset");
+    dev_zero_async(dG_, sizeof(float) * 2 * C * K * P);
   }
   const long wsb = btk_wpe_workspace_bytes(1, (int)K, (int)C, (int)lowerN_, (int)upperN_, T > 0 ? T : 1);
   void* ws = dev_alloc((size_t)(wsb > 0 ? wsb : 16));
   void* dfail = dev_alloc(sizeof(int));
-  check_hip(hipMemset(dfail, 0, sizeof(int)), "hipMemset");
+  dev_zero_async(dfail, sizeof(int));
   int fail = 0;
   try {
     check_abi(btk_wpe_estimate(dX, 1, (int)K, (int)C, T > 0 ? T : 1, n, (int)lowerN_, (int)upperN_, (int)iterationsN_, load_db_,
-                               diagonal_bias_, (int)lower_bw_, (int)upper_bw_, dG_, ws, (int*)dfail, NULL));
-    check_abi(btk_synchronize(NULL));
+                               diagonal_bias_, (int)lower_bw_, (int)upper_bw_, dG_, ws, (int*)dfail, nstream()));
+    nsync();
     d2h(&fail, dfail, sizeof(int));
   } catch (...) {
     dev_free(dX); dev_free(ws); dev_free(dfail);
@@ -2493,8 +2863,8 @@ void MultiChannelWPEDereverberation::prepare_output_()
   if (T_ > 0) {
     void* dO = dev_alloc(sizeof(float) * out_.size());
     try {
-      check_abi(btk_wpe_apply(dX, dG_, dO, 1, (int)K, (int)C, T_, T_, (int)lowerN_, (int)upperN_, (int)lower_bw_, (int)upper_bw_, NULL));
-      check_abi(btk_synchronize(NULL));
+      check_abi(btk_wpe_apply(dX, dG_, dO, 1, (int)K, (int)C, T_, T_, (int)lowerN_, (int)upperN_, (int)lower_bw_, (int)upper_bw_, nstream()));
+      nsync();
       d2h(out_.data(), dO, sizeof(float) * out_.size());
     } catch (...) { dev_free(dX); dev_free(dO); throw; }
     dev_free(dO);
@@ -2604,4 +2974,194 @@ void SingleChannelWPEDereverberationFeature::next_speaker()
 {
   core_->next_speaker();
   VectorComplexFeatureStream::reset();
+}
+
+// ================================================================================ SubbandGraphPool
+SubbandGraphPool::SubbandGraphPool()
+    : rounds_(0), base_(0), prev_T_(0), prev_Lw_(0), prev_Lp_(0), prev_hist_(0), blk_base_(0), out_stride_(0), first_round_(true) {}
+
+SubbandGraphPool::~SubbandGraphPool()
+{
+  for (size_t g = 0; g < graphs_.size(); g++) gsl_vector_float_free(graphs_[g].out);
+}
+
+void SubbandGraphPool::add(SubbandDSPtr& beamformer, OverSampledDFTSynthesisBankPtr& synthesis)
+{
+  if (!first_round_) throw jconsistency_error("SubbandGraphPool: graphs are added before the first next()\n");
+  SubbandDS* bf = beamformer.operator->();
+  if (!bf->banks_only()) throw jconsistency_error("SubbandGraphPool: the channels of %s must be analysis banks of one geometry\n", bf->name().c_str());
+  if (bf->is_half_band_shift()) throw jconsistency_error("SubbandGraphPool: halfBandShift==true is not batched\n");
+  if (dynamic_cast<SubbandGSCRLS*>(bf)) throw jconsistency_error("SubbandGraphPool: an adaptive canceller keeps its own recursion per graph and is not batched\n");
+  const OverSampledDFTAnalysisBank* a = bf->bank(0);
+  if (btk_fb_analysis_bf_fused(a->plan()) != 1)
+    throw jconsistency_error("SubbandGraphPool: no fused analysis -> apply kernel for M = %u, m = %u, r = %u\n", a->fftlen(), a->m(), a->r());
+  if (synthesis->fftlen() != a->fftlen() || synthesis->r() != a->r())
+    throw jdimension_error("SubbandGraphPool: synthesis bank (M = %u, r = %u) does not match the analysis banks (M = %u, r = %u)\n",
+                           synthesis->fftlen(), synthesis->r(), a->fftlen(), a->r());
+  if (!graphs_.empty()) {
+    SubbandDS* b0 = graphs_[0].bf.operator->();
+    const OverSampledDFTAnalysisBank* a0 = b0->bank(0);
+    const OverSampledDFTSynthesisBank* s0 = graphs_[0].syn.operator->();
+    if (bf->chanN() != b0->chanN() || a->fftlen() != a0->fftlen() || a->m() != a0->m() || a->r() != a0->r() ||
+        a->delay_compensation_type() != a0->delay_compensation_type() || a->block_frames() != a0->block_frames() ||
+        bf->block_quantum() != b0->block_quantum() || synthesis->m() != s0->m() ||
+        btk_fb_processing_delay(synthesis->plan()) != btk_fb_processing_delay(s0->plan()))
+      throw jdimension_error("SubbandGraphPool: every graph needs the same channel count, filter-bank geometry and block size\n");
+  }
+  Graph g;
+  g.bf = beamformer; g.syn = synthesis; g.live = true; g.T = 0; g.nblocks = 0; g.served = 0;
+  g.out = gsl_vector_float_calloc(synthesis->shiftlen()); g.has_out = false;
+  graphs_.push_back(g);
+}
+
+void SubbandGraphPool::reset()
+{
+  for (size_t g = 0; g < graphs_.size(); g++) {
+    graphs_[g].syn->reset();                                  // resets the whole graph behind it
+    graphs_[g].live = true; graphs_[g].T = 0; graphs_[g].nblocks = 0; graphs_[g].served = 0; graphs_[g].has_out = false;
+  }
+  rounds_ = 0; base_ = 0; prev_T_ = 0; prev_Lw_ = 0; prev_Lp_ = 0; prev_hist_ = 0; blk_base_ = 0; out_stride_ = 0; first_round_ = true;
+}
+
+// One round: every live graph's banks pull a block of input; one upload block, one fused launch, one synthesis launch.
+// false: no graph had a frame left.
+bool SubbandGraphPool::load_round_()
+{
+  const size_t G = graphs_.size();
+  if (G == 0) return false;
+  SubbandDS* b0 = graphs_[0].bf.operator->();
+  const OverSampledDFTSynthesisBank* s0 = graphs_[0].syn.operator->();
+  const unsigned N = b0->chanN(), M = b0->fftLen(), K = M / 2 + 1, D = s0->shiftlen(), R = 1u << s0->r();
+  const long pd = btk_fb_processing_delay(s0->plan());
+  const long H = std::max<long>((long)s0->m() * R + R, pd);    // frames of history a round's first block reaches back to
+  std::vector<SubbandBeamformer::BlockPlan> plans(G);
+  long Lmax = 0, Tmax = 0, t0 = -1, f0 = -1;
+  for (size_t g = 0; g < G; g++) {
+    Graph& gr = graphs_[g];
+    gr.T = 0; gr.nblocks = 0; gr.served = 0;
+    if (!gr.live) continue;
+    SubbandDS* bf = gr.bf.operator->();
+    if (!bf->banks_only()) throw jconsistency_error("SubbandGraphPool: the channels of %s changed\n", bf->name().c_str());
+    bf->plan_bank_block(plans[g]);
+    const SubbandBeamformer::BlockPlan& p = plans[g];
+    if (p.T > 0) {
+      if (f0 >= 0 && (p.f0 != f0 || p.f0 - p.b0 != t0))
+        throw jconsistency_error("SubbandGraphPool: graph %d is at frame %ld, the others at %ld -- the graphs of a pool advance in lock step\n", (int)g, p.f0, f0);
+      f0 = p.f0; t0 = p.f0 - p.b0;
+      Lmax = std::max(Lmax, p.L); Tmax = std::max(Tmax, p.T);
+    }
+    gr.T = p.T;
+    if (p.ended) gr.live = false;
+  }
+  if (Tmax == 0) return false;                                 // (a plan without frames is the end of its stream)
+  Lmax = (Lmax + 3) / 4 * 4;                                   // 16-byte rows for the fused kernel's vector loads
+  std::chrono::steady_clock::time_point tu0 = std::chrono::steady_clock::now();
+  // ---- the sample windows of every graph, [G][N][Lmax], zero behind a shorter (ending) stream
+  float* dPcm = static_cast<float*>(dPcm_.ensure(sizeof(float) * G * N * Lmax));
+  for (size_t g = 0; g < G; g++) {
+    if (graphs_[g].T <= 0) continue;
+    SubbandDS* bf = graphs_[g].bf.operator->();
+    const SubbandBeamformer::BlockPlan& p = plans[g];
+    float* slice = dPcm + g * (size_t)N * Lmax;
+    if (p.L < Lmax)
+      check_hip(hipMemset2DAsync(slice + p.L, sizeof(float) * Lmax, 0, sizeof(float) * (Lmax - p.L), N, nstream()), "hipMemset2DAsync");
+    for (unsigned c = 0; c < N; c++) h2d_async(slice + (size_t)c * Lmax, bf->bank(c)->window(p.b0), sizeof(float) * p.L);
+  }
+  // ---- per-stream weights [G][K][N], from the weight objects as they are now
+  float* hW = static_cast<float*>(hW_.ensure(sizeof(float) * 2 * G * K * N));
+  std::vector<float> w;
+  for (size_t g = 0; g < G; g++) {
+    if (graphs_[g].T <= 0) { memset(hW + g * (size_t)2 * K * N, 0, sizeof(float) * 2 * K * N); continue; }
+    graphs_[g].bf->effective_weights(w);
+    memcpy(hW + g * (size_t)2 * K * N, w.data(), sizeof(float) * 2 * K * N);
+  }
+  void* dW = dW_.ensure(sizeof(float) * 2 * G * K * N);
+  h2d_async(dW, hW, sizeof(float) * 2 * G * K * N);
+  nsync();                                                     // the uploads are done: the banks may move their windows on
+  std::chrono::steady_clock::time_point tu1 = std::chrono::steady_clock::now();
+  g_upload_ns += std::chrono::duration_cast<std::chrono::nanoseconds>(tu1 - tu0).count();
+  for (size_t g = 0; g < G; g++) if (graphs_[g].T > 0 || plans[g].ended) graphs_[g].bf->commit_bank_block(plans[g]);
+  // ---- the synthesis window of the round, [G][K][keep + Tmax] (rows an even number of frames apart): the last frames of the
+  //      window before as history (none in the first round: the stream's first blocks are computed as such, frames before the
+  //      stream read as zero), then the new frames -- the same windows, launch alignment included, as a synthesis node on its own
+  const long keep = first_round_ ? 0 : std::min(prev_hist_ + prev_T_, H);
+  const long Lw = keep + Tmax, Lp = even_pitch(Lw);
+  char* win = static_cast<char*>(dWinB_.ensure(std::max(sizeof(float) * 2 * G * K * Lp, sizeof(float) * 2 * G * K * (size_t)prev_Lp_)));
+  if (keep) d2d_2d_async(win, sizeof(float) * 2 * Lp, static_cast<const char*>(dWinA_.get()) + sizeof(float) * 2 * (prev_Lw_ - keep),
+                         sizeof(float) * 2 * prev_Lp_, sizeof(float) * 2 * keep, G * K);
+  base_ = f0;
+  dWinA_.swap(dWinB_);
+  const long sb = btk_fb_analysis_bf_scratch_bytes(b0->bank(0)->plan(), (int)G, (int)N, 1, Tmax);
+  void* scratch = dScratch_.ensure((size_t)(sb > 0 ? sb : 16));
+  check_abi(btk_fb_analysis_bf(b0->bank(0)->plan(), dPcm, Lmax, Lmax, (int)G, (int)N, dW, 1, win + sizeof(float) * 2 * keep, Lp, t0, Tmax,
+                               scratch, sb, nstream()));
+  // ---- the output blocks whose newest input frame lies in this round (block b reads the frames b + pd - (m R - 1) .. b + pd)
+  const long b_first = std::max<long>(0, base_ - pd), b_end = base_ + Tmax - pd;
+  const long nb = b_end > b_first ? b_end - b_first : 0;
+  blk_base_ = b_first; out_stride_ = nb * D;
+  if (nb > 0) {
+    // the window starts at stream frame base_ - keep: block b of the stream is block b - (base_ - keep) of the window; an aligned
+    // launch (see OverSampledDFTSynthesisBank::run_window_) may begin one block earlier, that block is dropped
+    const long bw = b_first - (base_ - keep);
+    const long lead = (btk_fb_synthesis_aligned_form(s0->plan()) == 1 && ((bw + pd) & 1)) ? 1 : 0;
+    const long ostride = ((nb + lead) * (long)D + 3) / 4 * 4;
+    float* dO = static_cast<float*>(dOut_.ensure(sizeof(float) * G * ostride));
+    float* hO = static_cast<float*>(hOut_.ensure(sizeof(float) * G * nb * D));
+    check_abi(btk_fb_synthesis(s0->plan(), win, Lw, Lp, (int)G, dO, ostride, bw - lead, nb + lead, nstream()));
+    check_hip(hipMemcpy2DAsync(hO, sizeof(float) * nb * D, dO + lead * (long)D, sizeof(float) * ostride, sizeof(float) * nb * D, G,
+                               hipMemcpyDeviceToHost, nstream()), "hipMemcpy2DAsync D2H");
+    nsync();
+    for (size_t g = 0; g < G; g++) {
+      const int gain = graphs_[g].syn->gain_factor();
+      if (gain > 1) for (long i = 0; i < nb * (long)D; i++) hO[g * (size_t)nb * D + i] *= (float)gain;
+    }
+  }
+  for (size_t g = 0; g < G; g++) {
+    const long e = base_ + graphs_[g].T - pd;
+    graphs_[g].nblocks = graphs_[g].T > 0 && e > b_first ? e - b_first : 0;
+  }
+  g_device_ns += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - tu1).count();
+  prev_T_ = Tmax; prev_Lw_ = Lw; prev_Lp_ = Lp; prev_hist_ = keep; first_round_ = false;
+  rounds_++;
+  return true;
+}
+
+bool SubbandGraphPool::next()
+{
+  if (graphs_.empty()) return false;
+  for (;;) {
+    bool any = false;
+    for (size_t g = 0; g < graphs_.size(); g++) if (graphs_[g].served < graphs_[g].nblocks) any = true;
+    if (any) break;
+    // the round is used up (or was too short to complete a block: a first round under the synthesis delay): the next one
+    bool more = false;
+    for (size_t g = 0; g < graphs_.size(); g++) if (graphs_[g].live) more = true;
+    if (!more || !load_round_()) {
+      for (size_t g = 0; g < graphs_.size(); g++) { graphs_[g].has_out = false; graphs_[g].nblocks = 0; graphs_[g].served = 0; }
+      return false;
+    }
+  }
+  const unsigned D = graphs_[0].syn->shiftlen();
+  const float* hO = static_cast<const float*>(hOut_.get());
+  for (size_t g = 0; g < graphs_.size(); g++) {
+    Graph& gr = graphs_[g];
+    gr.has_out = gr.served < gr.nblocks;
+    if (gr.has_out) {
+      memcpy(gr.out->data, hO + g * (size_t)out_stride_ + (size_t)gr.served * D, sizeof(float) * D);
+      gr.served++;
+    }
+  }
+  return true;
+}
+
+const gsl_vector_float* SubbandGraphPool::output(unsigned g) const
+{
+  if (g >= graphs_.size()) throw jindex_error("SubbandGraphPool: graph %d of %d\n", (int)g, (int)graphs_.size());
+  return graphs_[g].has_out ? graphs_[g].out : NULL;
+}
+
+bool SubbandGraphPool::is_end(unsigned g) const
+{
+  if (g >= graphs_.size()) throw jindex_error("SubbandGraphPool: graph %d of %d\n", (int)g, (int)graphs_.size());
+  return !graphs_[g].live && graphs_[g].served >= graphs_[g].nblocks;
 }

@@ -359,6 +359,8 @@ PYBIND11_MODULE(_btk20cpp, m)
       .def("fftlen", &SubbandBeamformer::fftLen)
       .def("fftLen", &SubbandBeamformer::fftLen)
       .def("dim", &SubbandBeamformer::dim)
+      .def("want_snapshots", &SubbandBeamformer::want_snapshots)   // every block from now on brings its snapshots along (staged path)
+      .def("snapshots_materialised", &SubbandBeamformer::snapshots_materialised)   // the current block's snapshots exist on the device
       .def("num_frames", &SubbandBeamformer::num_frames)                 // frames of the current block of snapshots
       .def("chunk_base", &SubbandBeamformer::chunk_base)                 // stream index of its first frame
       .def("set_block_frames", &SubbandBeamformer::set_block_frames, py::arg("n"))
@@ -419,6 +421,7 @@ PYBIND11_MODULE(_btk20cpp, m)
              return w ? py::cast(w, py::return_value_policy::reference) : py::object(py::none()); }, py::arg("srcX") = 0, py::keep_alive<0, 1>())
       // the block protocol a batching consumer uses (modulated/modulated.h BlockSource), under the names of the Python-side protocol
       .def("device_block", [](SubbandDS& b) { return block_of(b); })
+      .def("fused_path", &SubbandDS::fused_path)   // the node's blocks come from the fused analysis -> apply kernel
       .def("_output_version", [](SubbandDS& b) { return b.block_version(); })
       .def("_advance_to", [](SubbandDS& b, long idx) { b.advance_to(idx); })
       .def("_block_base", [](SubbandDS& b) { return b.block_base(); })
@@ -536,7 +539,9 @@ PYBIND11_MODULE(_btk20cpp, m)
       .def("divideAllNonDiagonalElements", &McCowanPostFilter::divide_all_nondiagonal_elements)
       .def("setNoiseSpatialSpectralMatrix", [](McCowanPostFilter& f, unsigned fbinX, py::array_t<cd, py::array::c_style | py::array::forcecast> Rnn) {
              GslCMat M(Rnn); return f.set_noise_spatial_spectral_matrix(fbinX, M.m); })
-      .def("getNoiseSpatialSpectralMatrix", [](McCowanPostFilter& f, unsigned fbinX) { return copy_of(f.noise_spatial_spectral_matrix(fbinX)); });
+      .def("getNoiseSpatialSpectralMatrix", [](McCowanPostFilter& f, unsigned fbinX) { return copy_of(f.noise_spatial_spectral_matrix(fbinX)); })
+      .def("set_svd_rule", [](McCowanPostFilter& f, const std::string& rule) { f.set_svd_rule(rule); }, py::arg("rule"))
+      .def("svd_rule", [](McCowanPostFilter& f) { return std::string(f.svd_rule()); });
   py::class_<LefkimmiatisPostFilter, McCowanPostFilter, cref<LefkimmiatisPostFilter>>(m, "LefkimmiatisPostFilterPtr")
       .def(py::init([](py::object output, unsigned fftlen, double min_sv, unsigned fbin_x1, double alpha, int type, int min_frames,
                        float threshold, const std::string& nm) {
@@ -545,6 +550,30 @@ PYBIND11_MODULE(_btk20cpp, m)
            }), py::arg("output"), py::arg("fftlen"), py::arg("min_sv") = 1.0E-8, py::arg("fbin_x1") = 0, py::arg("alpha") = 0.6, py::arg("type") = 2,
            py::arg("min_frames") = 0, py::arg("threshold") = 0.99f, py::arg("nm") = "LefkimmiatisPostFilter")
       .def("calc_inverse_noise_spatial_spectral_matrix", &LefkimmiatisPostFilter::calc_inverse_noise_spatial_spectral_matrix);
+
+  // ---- many utterance graphs advanced as one launch (beamformer/beamformer.h, SubbandGraphPool)
+  py::class_<SubbandGraphPool, cref<SubbandGraphPool>>(m, "SubbandGraphPoolPtr")
+      .def(py::init([]() { return new SubbandGraphPool(); }))
+      .def("add", [](SubbandGraphPool& p, SubbandDS& bf, OverSampledDFTSynthesisBank& syn) {
+             SubbandDSPtr b(&bf); OverSampledDFTSynthesisBankPtr s(&syn); p.add(b, s); }, py::arg("beamformer"), py::arg("synthesis"))
+      .def("size", &SubbandGraphPool::size)
+      .def("__len__", &SubbandGraphPool::size)
+      .def("rounds", &SubbandGraphPool::rounds)
+      .def("is_end", &SubbandGraphPool::is_end, py::arg("g"))
+      .def("reset", &SubbandGraphPool::reset)
+      // one output block per graph: a list with a numpy view of the pool's own buffer per graph, None for a graph that has ended;
+      // StopIteration when every graph has ended
+      .def("next", [](py::object self) {
+             SubbandGraphPool& p = self.cast<SubbandGraphPool&>();
+             bool ok; { py::gil_scoped_release rel; ok = p.next(); }
+             if (!ok) throw py::stop_iteration();
+             py::list out;
+             for (unsigned g = 0; g < p.size(); g++) { const gsl_vector_float* v = p.output(g); if (v) out.append(view(v, self)); else out.append(py::none()); }
+             return out; })
+      .def("__next__", [](py::object self) { return self.attr("next")(); })
+      .def("__iter__", [](py::object self) { self.attr("reset")(); return self; });
+  m.def("node_synchronize", []() { btk_node_synchronize(); });     // wait for everything this thread's nodes have launched
+  m.def("node_alloc_counts", []() { long d = 0, h = 0; btk_node_alloc_counts(&d, &h); return py::make_tuple(d, h); });   // (hipMalloc, hipHostMalloc) calls so far
 
   // ---- dereverberation/dereverberation.h
   py::class_<MultiChannelWPEDereverberation, cref<MultiChannelWPEDereverberation>>(m, "MultiChannelWPEDereverberationPtr")

@@ -83,6 +83,12 @@ int  btk_fb_analysis_polyphase(const btk_fb_t* fb, const float* pcm, long nsampl
  * zeroed ring, modulated.cc:615-621); out [dev] [S][out_stride], block b at offset (b-b0)*D. */
 int  btk_fb_synthesis(const btk_fb_t* fb, const void* Y, long nframes, long T_stride, int S,
                       float* out, long out_stride, long b0, long bcount, void* stream);
+/* 1: this plan's geometry has a wider kernel form that btk_fb_synthesis takes for ALIGNED launches -- b0 + processing_delay even,
+ * T_stride even, out_stride a multiple of 4, Y and out 16-byte aligned -- and whose results differ from the other form's by
+ * <= 2 ulp (another FFT factorisation, the same summation order per sample).  A caller that cuts one stream into several launches
+ * and needs the same bits for every partition keeps all of them aligned (b0 may be one less than the first block wanted, -1
+ * included: blocks before the stream are zeros) or none; 0: one form, every partition gives the same bits anyway.        */
+int  btk_fb_synthesis_aligned_form(const btk_fb_t* fb);
 
 /* ---- Sample formats on either side of the path ------------------------------------------------
  * SampleFeature hands the analysis bank UN-NORMALISED floats of 16-bit PCM (feature/feature.cc:265-269) and the reference's
@@ -113,6 +119,9 @@ int  btk_bf_apply(const void* W, int per_stream_weights, const void* X, void* Y,
  * (fused geometries); rows a multiple of 4 KiB apart are worth padding.  Use the staged calls when a post-filter, the
  * adaptive canceller or covariance accumulation needs the snapshots.                                          */
 long btk_fb_analysis_bf_scratch_bytes(const btk_fb_t* fb, int S, int N, int per_stream_weights, long tcount);
+/* 1: btk_fb_analysis_bf runs a fused kernel for this plan's geometry (any T_stride >= tcount); 0: the staged pair through
+ * `scratch` (a caller that keeps the snapshots anyway then calls btk_fb_analysis + btk_bf_apply itself); < 0: not an analysis plan. */
+int  btk_fb_analysis_bf_fused(const btk_fb_t* fb);
 int  btk_fb_analysis_bf(const btk_fb_t* fb, const float* pcm, long nsamples, long pcm_stride, int S, int N,
                         const void* W, int per_stream_weights, void* Y, long T_stride, long t0, long tcount,
                         void* scratch, long scratch_bytes, void* stream);
