@@ -132,6 +132,79 @@ def cpu_baseline(N, M, m, r, dct, frames, all_cores=True):
     return res
 
 
+def node_api_stage(h, g, N, M, m, r, engine_frames_per_s):
+    """What a drop-in caller of the reference's node API gets: host/examples/node_api_bench builds the graph of
+    src/beamformerDS.cc:144-223 (SampleFeature x N -> OverSampledDFTAnalysisBank x N -> SubbandGSC -> OverSampledDFTSynthesisBank)
+    on in-memory utterances and pulls it block by block through next(): one graph of 8192 frames, 32 graphs one after the other
+    and the same 32 graphs in a SubbandGraphPool (one S = 32 launch per round).  The binary reports where the host time goes; the
+    device work per frame is the engine's, the rest is the reference's own interface: every sample crosses SampleFeature::next()'s
+    float blocks and PCIe."""
+    import subprocess
+    import tempfile
+    exe = os.path.join(ROOT, "distant_speech_recognition_amd", "host", "examples", "node_api_bench")
+    if not os.path.exists(exe):
+        return {"error": "host/examples/node_api_bench is not built (make -C distant_speech_recognition_amd/host)"}
+    out = {"what": "C++ node graph of src/beamformerDS.cc at C0 (%d banks -> SubbandGSC -> synthesis), pulled with next() until "
+                   "jiterator_error; wall clock of the pull loop, inputs in host memory (SampleFeature), second pass timed" % N}
+    with tempfile.NamedTemporaryFile(suffix=".f64") as f:
+        np.concatenate([h, g]).astype(np.float64).tofile(f.name)
+        for key, frames, graphs, block, pool in (("one_graph", 8192, 1, 8192, 0), ("graphs_32_one_by_one", 2048, 32, 1024, 0),
+                                                 ("graph_pool_32", 2048, 32, 1024, 1)):
+            try:
+                res = subprocess.run([exe, f.name, str(M), str(m), str(r), str(N), str(frames), str(graphs), str(block), str(pool)],
+                                     capture_output=True, text=True, timeout=600)
+                if res.returncode != 0:
+                    out[key] = {"error": res.stderr.strip()[-300:]}
+                    continue
+                j = json.loads(res.stdout.strip().splitlines()[-1])
+                j["xRT"] = j["frames_per_s"] / (FS / (M >> r))
+                j["fraction_of_engine_rate"] = j["frames_per_s"] / engine_frames_per_s
+                out[key] = j
+            except (OSError, ValueError, subprocess.TimeoutExpired) as e:
+                out[key] = {"error": repr(e)}
+    return out
+
+
+def c5_frame_sharded_stage(torch, dist, dev, rank, world):
+    """First-contact kit for the multi-GPU node (every rank calls this; DESIGN.md section 6 predicts both curves): BASELINE's C5
+    shape -- 256 mics, 2048 bins, ONE stream, static weights -- partitioned by frame range over the ranks (sharding.
+    pipeline_frame_sharded: the fused kernel over this rank's frames, one all-gather of Y along the frame axis, synthesis on rank
+    0).  Times, max over ranks, for 512- and 4096-frame blocks: the whole block with the all-gather inside the timed region, and the
+    all-gather alone.  Strong scaling: the block is the same at every world size."""
+    from distant_speech_recognition_amd import engine as eng, prototypes, sharding
+    N, M, m, r, dct = 256, 2048, 4, 1, 2
+    D, K = M >> r, M // 2 + 1
+    h, g = prototypes.load(M, m, r)
+    afb = eng.FilterBank(h, M, m, r, dct)
+    sfb = eng.FilterBank(g, M, m, r, dct, synthesis=True)
+    gen = torch.Generator(device=dev).manual_seed(4)                 # the same PCM and weights on every rank (replicated input)
+    out = {"what": "C5 (256 mics x 2048 bins, 1 stream, static weights) by frame range: fused kernel on T / world frames per rank + ONE "
+                   "all-gather of Y (8 K T bytes) + synthesis on rank 0; ms = max over ranks", "world": world}
+    for T in (512, 4096):
+        L = (T - afb.processing_delay + afb.lookahead) * D
+        pcm = (torch.randn((1, N, L), device=dev, generator=gen) * 1000.0).round_()
+        W = (torch.randn((K, N), device=dev, generator=gen) + 1j * torch.randn((K, N), device=dev, generator=gen)).to(torch.complex64) / N
+        t0r, t1r = sharding.frame_range_for_rank(T, rank, world, 16)
+        Yl = torch.zeros((1, K, t1r - t0r), dtype=torch.complex64, device=dev)
+
+        def timed(fn, n=5):
+            for _ in range(2):
+                fn()
+            torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(n):
+                fn()
+            torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+            return sharding.max_over_ranks((time.perf_counter() - t0) / n, dev)
+        t_block = timed(lambda: sharding.pipeline_frame_sharded(afb, sfb, pcm, W, rank, world, synth_rank=0))
+        t_gather = timed(lambda: sharding.allgather_frames(Yl, T))
+        t_one = timed(lambda: afb.analysis_beamform(pcm, W, t0=t0r, tcount=t1r - t0r)) if t1r > t0r else 0.0
+        out["frames_%d" % T] = {"block_ms": t_block * 1e3, "allgather_alone_ms": t_gather * 1e3, "rank_kernel_ms": t_one * 1e3,
+                                "frames_per_s": T / t_block, "allgather_bytes": 8 * K * T, "frames_per_rank": t1r - t0r}
+        del pcm, W, Yl
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -240,13 +313,15 @@ def main():
     torch.cuda.synchronize()
     if dist: dist.barrier()
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(ev[i])
-    torch.cuda.synchronize()
-    if dist: dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
+    from bench_util import ClockPowerSampler
+    with ClockPowerSampler(torch, dev) as clk:              # shader clock and package power while the timed steps run (sysfs, 2 ms period)
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            step(ev[i])
+        torch.cuda.synchronize()
+        if dist: dist.barrier()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
     my_elapsed = elapsed
     per_rank = [S * T * args.steps / my_elapsed]
     rccl_world = None
@@ -273,6 +348,19 @@ def main():
         t_bf = _time(lambda: eng.bf_apply(W, X, out=Yc))
     else:
         t_ana, t_bf = t_a, t_b
+    # the same fused operator on the samples as they are stored -- 16-bit PCM, widened inside the kernel (btk_fb_analysis_bf_i16):
+    # reported BESIDE the float32 headline, with its own algorithmic bytes 2 D N + 8 K per frame; bit-identical output
+    pcm16 = pcm.to(torch.int16)
+    clk16 = ClockPowerSampler(torch, dev)
+    with clk16:
+        t_i16 = _time(lambda: afb.analysis_beamform(pcm16, W, out=Y)) if fused and afb.fused_i16() else None
+    i16_same = None
+    if t_i16 is not None:
+        Yf = afb.analysis_beamform(pcm, W)
+        Yi = afb.analysis_beamform(pcm16, W)
+        i16_same = bool(torch.equal(Yf[..., :T].contiguous().view(torch.float32).view(torch.int32), Yi[..., :T].contiguous().view(torch.float32).view(torch.int32)))
+        del Yf, Yi
+    del pcm16
     # the adaptive variant of the same beamformer (SubbandGSCLMSBeamformer: NLMS canceller on the snapshots), reported
     # next to the static-weight chain; the recursion is sequential in t, so its rate depends on the number of streams
     vs = torch.from_numpy(np.stack([np.exp(-2j * np.pi * k * (FS / M) * delays) / N for k in range(K)]).astype(np.complex64)).to(dev)
@@ -307,6 +395,14 @@ def main():
         adaptive_wide = {"streams": S2, "frames_per_stream": T2, "ms": t2 * 1e3, "frames_per_s": S2 * T2 / t2, "xRT": S2 * T2 / t2 / (FS / D)}
         del pcm2, X2, Yc2, out2
 
+    # multi-GPU runs also carry the strong-scaling partition of C5 (all ranks take part; RCCL only)
+    c5_sharded = None
+    if dist and backend == "nccl":
+        try:
+            c5_sharded = c5_frame_sharded_stage(torch, dist, dev, rank, world)
+        except Exception as e:                                  # never let the extra stage cost the driver its headline line
+            c5_sharded = {"error": repr(e)}
+
     if rank == 0:
         frames_per_step = S * T * world
         value = frames_per_step * args.steps / elapsed
@@ -339,6 +435,19 @@ def main():
                     return e["traffic_bytes"]
             traffic_note["why"] = "profiles/%s holds no kernel named *%s*: refused" % (TRAFFIC_JSON, kernel_substr)
             return None
+        def pmc_traffic_i16():
+            """PMC traffic of the int16 launch (same file, key kernels_i16), under the same staleness rules"""
+            path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", TRAFFIC_JSON)
+            try:
+                j = json.load(open(path))
+            except (OSError, ValueError):
+                return None
+            if (j.get("S"), j.get("T"), j.get("N"), j.get("M")) != (S, T, N, M) or j.get("kernel_source_sha256") != kernel_source_sha():
+                return None
+            for kname, e in j.get("kernels_i16", {}).items():
+                if "analysis512_bfz_kernel" in kname and "traffic_bytes" in e:
+                    return e["traffic_bytes"]
+            return None
         def compute_side(t_kernel):
             """What the dominant kernel does to the vector ALU next to what it does to HBM: packed instructions issued (ISA count x
             launches) against the issue slots of the launch's duration, and the flops they carry against the vector peak."""
@@ -361,7 +470,8 @@ def main():
         if fused:
             # algorithmic bytes of the FUSED operator: every PCM sample in once, every beamformed bin out once (4 D N + 8 K
             # per frame); the N x K snapshots that SURVEY 8(d) prices for the staged pair never exist in HBM
-            roof = {"bound": "hbm", "kernel": "analysis512_bfz_kernel (fused analysis bank + SubbandGSC apply)",
+            roof = {"bound": "power / issue", "roof": "hbm",
+                    "kernel": "analysis512_bfz_kernel (fused analysis bank + SubbandGSC apply)",
                     "achieved": b_fused_hbm / t_a / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                     "frac": b_fused_hbm / t_a / HBM_PEAK, "frac_survey_8d": (b_ana + b_bf) / t_a / HBM_PEAK,
                     "traffic": pmc_traffic("analysis512_bfz_kernel"), "traffic_source": None,
@@ -369,10 +479,13 @@ def main():
                     "compute": compute_side(t_a),
                     "staged_equivalent": {"bytes_per_launch": b_ana + b_bf, "GBps": (b_ana + b_bf) / t_a / 1e9,
                                           "frac": (b_ana + b_bf) / t_a / HBM_PEAK},
-                    "note": "bytes_per_launch = 4DN+8K per frame (PCM in, Y out): the fused kernel keeps the N x K snapshots on "
-                            "chip.  staged_equivalent prices the same launch with SURVEY 8(d)'s staged figures "
-                            "N(4D+8K)+8K(N+1) per frame (what analysis + apply through HBM would have to move in that time); "
-                            "the kernel is bounded by LDS traffic and issue latency, not by HBM (DESIGN.md)"}
+                    "clock_and_power_in_timed_region": clk.summary(),
+                    "note": "achieved / peak / frac are against the HBM roof (`roof`), bytes_per_launch = 4DN+8K per frame (PCM in, Y out): "
+                            "the fused kernel keeps the N x K snapshots on chip.  `bound` says what the counters say limits it: HBM "
+                            "traffic is at its floor (1.05 x algorithmic), the vector ALU issues ~40 % of its slots, and the package sits "
+                            "at its power cap with the shader clock pulled down (clock_and_power_in_timed_region; DESIGN.md 3.1b).  "
+                            "staged_equivalent prices the same launch with SURVEY 8(d)'s staged figures N(4D+8K)+8K(N+1) per frame "
+                            "(what analysis + apply through HBM would have to move in that time)"}
         else:
             roof = {"bound": "hbm", "kernel": "analysis512_kernel", "achieved": b_ana / t_ana / 1e9, "peak": HBM_PEAK / 1e9,
                     "unit": "GB/s", "frac": b_ana / t_ana / HBM_PEAK, "traffic": pmc_traffic("analysis512_kernel"),
@@ -395,6 +508,14 @@ def main():
             "stages": {
                 "fused_analysis_apply": ({"ms": t_a * 1e3, "frames_per_s": S * T / t_a,
                                           "hbm_GBps_actual": b_fused_hbm / t_a / 1e9} if fused else None),
+                "fused_i16": ({"ms": t_i16 * 1e3, "frames_per_s": S * T / t_i16, "bytes_per_launch": (2 * D * N + 8 * K) * S * T,
+                               "GBps": (2 * D * N + 8 * K) * S * T / t_i16 / 1e9, "frac": (2 * D * N + 8 * K) * S * T / t_i16 / HBM_PEAK,
+                               "speedup_vs_f32_entry": t_a / t_i16, "bit_identical_to_f32_entry": i16_same,
+                               "traffic": pmc_traffic_i16(),
+                               "clock_and_power": clk16.summary(),
+                               "what": "btk_fb_analysis_bf_i16: the same launch reading the PCM as int16 (as stored in a WAV and as it crosses "
+                                       "PCIe) and widening it in registers; algorithmic bytes 2DN+8K per frame; reported beside the float32 "
+                                       "headline, never instead of it"} if t_i16 is not None else None),
                 "analysis": {"ms": t_ana * 1e3, "GBps": b_ana / t_ana / 1e9, "frac": b_ana / t_ana / HBM_PEAK},
                 "gsc_apply": {"ms": t_bf * 1e3, "GBps": b_bf / t_bf / 1e9, "frac": b_bf / t_bf / HBM_PEAK,
                               "frames_per_s": S * T / t_bf},
@@ -411,7 +532,10 @@ def main():
                                                            "HIP stream (engine.AdaptiveGSCChain); bit-identical output"},
             },
         }
+        if c5_sharded is not None:
+            res["stages"]["c5_frame_sharded"] = c5_sharded
         if not args.no_cpu and world == 1:
+            res["stages"]["node_api"] = node_api_stage(h, g, N, M, m, r, value)
             res["cpu_baseline"] = cpu_baseline(N, M, m, r, dct, args.cpu_frames)
         else:
             res["cpu_baseline"] = None

@@ -61,3 +61,74 @@ def gpu_time(torch, fn, n=3, prewarm_ms=250.0, min_ms=60.0, max_calls=40):
     e1.record()
     torch.cuda.synchronize()
     return e0.elapsed_time(e1) * 1e-3 / reps, r
+
+
+class ClockPowerSampler:
+    """Shader clock and package power of one GPU, sampled from a thread while a timed region runs: the hwmon files of the amdgpu
+    driver (freq1_input = sclk in Hz, power1_input = package power in microwatts, power1_cap = the cap), readable by an ordinary
+    user.  The headline kernel sits at the package power cap, and what clock the cap leaves differs from box to box: a bench line
+    that carries the two makes a 0.39-against-0.41 run attributable.  Without the files (no GPU, another driver) the summary
+    says so and holds no numbers."""
+
+    def __init__(self, torch=None, device=None, period_s=0.002):
+        import glob
+        self.period = period_s
+        self.dir = None
+        want = None
+        try:                                            # the card that is the torch device, by PCI address
+            p = torch.cuda.get_device_properties(device)
+            want = "%04x:%02x:%02x" % (p.pci_domain_id, p.pci_bus_id, p.pci_device_id)
+        except Exception:
+            pass
+        cands = []
+        for d in sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*")):
+            if os.path.exists(os.path.join(d, "freq1_input")) and os.path.exists(os.path.join(d, "power1_input")):
+                real = os.path.realpath(os.path.join(d, "..", ".."))
+                cands.append((d, real))
+        for d, real in cands:
+            if want and want in real:
+                self.dir = d
+        if self.dir is None and cands:
+            self.dir = cands[0][0]
+        self.samples = []
+        self._stop = False
+        self._th = None
+
+    def _read(self, name):
+        try:
+            return float(open(os.path.join(self.dir, name)).read())
+        except (OSError, ValueError):
+            return None
+
+    def _loop(self):
+        import time
+        while not self._stop:
+            f, p = self._read("freq1_input"), self._read("power1_input")
+            if f is not None and p is not None:
+                self.samples.append((f * 1e-6, p * 1e-6))
+            time.sleep(self.period)
+
+    def __enter__(self):
+        if self.dir is not None:
+            import threading
+            self._th = threading.Thread(target=self._loop, daemon=True)
+            self._th.start()
+        return self
+
+    def __exit__(self, *a):
+        self._stop = True
+        if self._th is not None:
+            self._th.join()
+        return False
+
+    def summary(self):
+        if self.dir is None:
+            return {"sclk_MHz": None, "package_power_W": None, "why": "no amdgpu hwmon files (freq1_input / power1_input) on this box"}
+        if not self.samples:
+            return {"sclk_MHz": None, "package_power_W": None, "why": "the timed region was shorter than one sample"}
+        sc = sorted(s[0] for s in self.samples)
+        pw = sorted(s[1] for s in self.samples)
+        cap = self._read("power1_cap")
+        return {"sclk_MHz": {"median": sc[len(sc) // 2], "min": sc[0], "max": sc[-1]},
+                "package_power_W": {"median": pw[len(pw) // 2], "max": pw[-1], "cap": cap * 1e-6 if cap else None},
+                "samples": len(sc), "source": self.dir}

@@ -43,6 +43,8 @@ int btk_analysis512_try(const btk_fb* fb, const float* pcm, long nsamples, long 
                         long T_stride, long t0, long tcount, hipStream_t st);
 int btk_analysis512_bf_try(const btk_fb* fb, const float* pcm, long nsamples, long pcm_stride, int S, int N, const void* W,
                            int per_stream, void* Wt_scratch, void* Y, long T_stride, long t0, long tcount, hipStream_t st);
+int btk_analysis512_bf_i16_try(const btk_fb* fb, const short* pcm, long nsamples, long pcm_stride, int S, int N, const void* W,
+                               int per_stream, void* Wt_scratch, void* Y, long T_stride, long t0, long tcount, hipStream_t st);
 int btk_synthesis512_try(const btk_fb* fb, const void* Y, long nframes, long T_stride, int S, float* out, long out_stride,
                          long b0, long bcount, hipStream_t st);
 // fb_fast.hip: register-FFT kernels for M in {256,512,1024,2048}, m = 4
@@ -54,5 +56,7 @@ int btk_fast_analysis_bf_try(const btk_fb* fb, const float* pcm, long nsamples, 
 long btk_big_analysis_bf_scratch_bytes(const btk_fb* fb, int S, int N, int per_stream, long tcount);
 int btk_big_analysis_bf_try(const btk_fb* fb, const float* pcm, long nsamples, long pcm_stride, int S, int N, const void* W,
                             int per_stream, void* scratch, void* Y, long T_stride, long t0, long tcount, hipStream_t st);
+int btk_big_analysis_bf_i16_try(const btk_fb* fb, const short* pcm, long nsamples, long pcm_stride, int S, int N, const void* W,
+                                int per_stream, void* scratch, void* Y, long T_stride, long t0, long tcount, hipStream_t st);
 int btk_fast_synthesis_try(const btk_fb* fb, const void* Y, long nframes, long T_stride, int S, float* out, long out_stride,
                            long b0, long bcount, hipStream_t st);

@@ -269,9 +269,12 @@ int launch512(const btk_fb* fb, const float* pcm, long nsamples, long pcm_stride
 // the FFT lane that holds Z_n[q] (q = j + 16 k2, registers k2 = 0..15) accumulates A[q] and B'[q] = B[(256-q) & 255]
 // straight from its registers: no FFT result goes back to LDS, no cross-lane partner is needed per channel.
 // Wq [Sw][N][WSTR] float4: entry i < 256 = (w[i], w[(256-i) & 255]), entry 256 = (w[256], 0, 0), the rest 0.
-template <int R, int VAR, int TT = A_TT>       // TT frames per workgroup tile (16: four wavefronts; 8: two, four workgroups per CU)
+// PT = float: the samples as SampleFeature hands them out (un-normalised floats); PT = short: the 16-bit PCM they were read from
+// (feature/feature.cc:265-269), widened in registers -- half the bytes of the kernel's dominant stream, the same values, the same
+// bits out (btk_fb_analysis_bf_i16).
+template <int R, int VAR, int TT = A_TT, typename PT = float>       // TT frames per workgroup tile (16: four wavefronts; 8: two, four workgroups per CU)
 __global__ __launch_bounds__(TT * 16, 2)
-void analysis512_bfz_kernel(const float* __restrict__ pcm, long nsamples, long pcm_stride,
+void analysis512_bfz_kernel(const PT* __restrict__ pcm, long nsamples, long pcm_stride,
                             const float* __restrict__ proto, const float2* __restrict__ twg,
                             int laN, float gain, int N, int K, const float4* __restrict__ Wq, long w_stream_stride,
                             float2* __restrict__ Y, long T_stride, long t0, long tcount, int ntiles, int tiles_per_xcd, int S,
@@ -312,22 +315,30 @@ void analysis512_bfz_kernel(const float* __restrict__ pcm, long nsamples, long p
   const long tt0 = (long)tile * TT;
   const int fl = lane >> 4, j = lane & 15;
 
-  const bool vec_ok = ((pcm_stride & 3) == 0) && ((reinterpret_cast<uintptr_t>(pcm) & 15) == 0);
+  constexpr bool I16 = sizeof(PT) == 2;
+  const bool vec_ok = ((pcm_stride & 3) == 0) && ((reinterpret_cast<uintptr_t>(pcm) & (4 * sizeof(PT) - 1)) == 0);
   const long g0 = (t0 + tt0 + laN + 1) * (long)D - (long)A_MT * A_M;
   const bool inb = vec_ok && g0 >= 0 && g0 + SPAN <= nsamples;
   const float4* wts = Wq + (long)s * w_stream_stride;
   float4 pre[NV4];
   float4 wpre[256 / NT];
   float2 w256pre;
-  const float* pcm_e = pcm;                  // the edge path's own copies of the two base pointers: laundered through an
+  const PT* pcm_e = pcm;                     // the edge path's own copies of the two base pointers: laundered through an
   const float4* wts_e = wts;                 // asm at its entry so that hipcc cannot hoist its loads above the branch
   auto fetch = [&](int n) {
-    const float* src = pcm_e + ((long)s * N + n) * pcm_stride;
+    const PT* src = pcm_e + ((long)s * N + n) * pcm_stride;
     if (inb) {
 #pragma unroll
       for (int q = 0; q < NV4; q++) {
         const int l = (tid + q * NT) * 4;
-        if (l < SPAN) pre[q] = *reinterpret_cast<const float4*>(src + g0 + l);
+        if (l < SPAN) {
+          if constexpr (I16) {
+            const uint2 u = *reinterpret_cast<const uint2*>(src + g0 + l);      // four samples
+            pre[q] = make_float4((float)(short)(u.x & 0xffff), (float)((int)u.x >> 16), (float)(short)(u.y & 0xffff), (float)((int)u.y >> 16));
+          } else {
+            pre[q] = *reinterpret_cast<const float4*>(src + g0 + l);
+          }
+        }
       }
     } else {
 #pragma unroll
@@ -337,7 +348,7 @@ void analysis512_bfz_kernel(const float* __restrict__ pcm, long nsamples, long p
 #pragma unroll
         for (int e = 0; e < 4; e++) {
           const long g = g0 + l + e;
-          v[e] = (l + e < SPAN && g >= 0 && g < nsamples) ? src[g] : 0.0f;
+          v[e] = (l + e < SPAN && g >= 0 && g < nsamples) ? (float)src[g] : 0.0f;
         }
         pre[q] = make_float4(v[0], v[1], v[2], v[3]);
       }
@@ -407,7 +418,8 @@ void analysis512_bfz_kernel(const float* __restrict__ pcm, long nsamples, long p
   auto dma = [&](int n, auto fast) {
     if constexpr (decltype(fast)::value) {
       if constexpr (!GW) {
-        const float* src = pcm + ((long)s * N + n) * pcm_stride + g0;
+        static_assert(!I16 || !decltype(fast)::value || GW, "the LDS-DMA of the span copies float samples");
+        const PT* src = pcm + ((long)s * N + n) * pcm_stride + g0;
         constexpr int NCH = (SPAN * 4 + 1023) / 1024;
         constexpr int NI = (NCH + NWAVE - 1) / NWAVE;
 #pragma unroll
@@ -436,15 +448,24 @@ void analysis512_bfz_kernel(const float* __restrict__ pcm, long nsamples, long p
   // loads; no edge-path load can be pending in it) and edge tiles (register staging through the span region, guarded
   // loads, compiler-managed waits).  One loop with a runtime branch let hipcc hoist edge-path loads above the branch.
   float2 win[NWG];                            // polyphase window of the channel about to be transformed (GW: loaded a channel ahead)
+  unsigned wraw[I16 ? NWG : 1];               // int16 samples: the window as it was loaded, two samples per word
   auto channels = [&](auto fast) {
   constexpr bool FAST = decltype(fast)::value;
   constexpr bool GWF = GW && FAST;            // edge tiles of the GW form stage the span through the frame region (see below)
-  if constexpr (!FAST) asm volatile("" : "+s"(pcm_e), "+s"(wts_e));
+  // (the int16 forms without the direct window loads have this one loop only: nothing to hoist above a branch, and the backend
+  //  refuses the scalar constraint there -- "illegal VGPR to SGPR copy")
+  if constexpr (!FAST && (!I16 || GW)) asm volatile("" : "+s"(pcm_e), "+s"(wts_e));
   // GW: V[i] of channel n straight from HBM / L2 (8-byte loads, 512 contiguous bytes per wave-instruction)
   auto wload = [&](float2 (&win)[NWG], int n) {
-    const float* wsrc = pcm + ((long)s * N + n) * pcm_stride + g0 + (A_M - 2 - 2 * n0 - (G - 1) * (A_M / G)) + fg * FPT * D;
+    const PT* wsrc = pcm + ((long)s * N + n) * pcm_stride + g0 + (A_M - 2 - 2 * n0 - (G - 1) * (A_M / G)) + fg * FPT * D;
+    if constexpr (I16) {
+      // 15 four-byte loads (256 contiguous bytes per wave-instruction); widened when the channel's turn comes (top of the body)
 #pragma unroll
-    for (int i = 0; i < NWG; i++) win[i] = *reinterpret_cast<const float2*>(wsrc + i * D);
+      for (int i = 0; i < NWG; i++) wraw[i] = *reinterpret_cast<const unsigned*>(wsrc + i * D);
+    } else {
+#pragma unroll
+      for (int i = 0; i < NWG; i++) win[i] = *reinterpret_cast<const float2*>(wsrc + i * D);
+    }
   };
   // SHARED: the PCM span is staged through registers into the region the FFT frames overwrite (R = 1, and the edge
   // tiles of the GW form): four barriers per channel instead of two
@@ -474,6 +495,12 @@ void analysis512_bfz_kernel(const float* __restrict__ pcm, long nsamples, long p
     // ---- phase 1: registers -> LDS (PCM span + weight pairs)
     if (SHARED) stage(PIPE ? (n & 1) : 0);
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // the LDS-DMA of channel n (and, GW, its window) has landed
+    if constexpr (I16 && GWF) {
+      // v_cvt_f32_i32 with sign-extended word selects: exact, so the float path's bits follow (30 conversions per lane and
+      // channel, in front of the barrier: they are not part of the stage the other wavefronts wait for)
+#pragma unroll
+      for (int i = 0; i < NWG; i++) win[i] = make_float2((float)(short)(wraw[i] & 0xffff), (float)((int)wraw[i] >> 16));
+    }
     mark(1);                                                         // wait for memory
     if constexpr (ABL != 5) __syncthreads();
     mark(2);                                                         // barrier A
@@ -625,8 +652,12 @@ void analysis512_bfz_kernel(const float* __restrict__ pcm, long nsamples, long p
     }
   }
   };
-  if (PIPE && inb) channels(std::true_type{});
-  else channels(std::false_type{});
+  if constexpr (PIPE && (GW || !I16)) {
+    if (inb) channels(std::true_type{});
+    else channels(std::false_type{});
+  } else {
+    channels(std::false_type{});                // (int16 without the direct window loads: widened while staged through registers)
+  }
 
   if (PIPE) __syncthreads();
   // ---- once per tile: B[k] = B'[(256-k)&255] through the wave's own frame buffers, Hermitian post-pass,
@@ -683,10 +714,11 @@ __global__ void pair_weights_kernel(const float2* __restrict__ W, float4* __rest
   Wq[i] = o;
 }
 
-template <int R>
-int launch512_bf(const btk_fb* fb, const float* pcm, long nsamples, long pcm_stride, int S, int N, const float2* W,
+template <int R, typename PT = float>
+int launch512_bf(const btk_fb* fb, const PT* pcm, long nsamples, long pcm_stride, int S, int N, const float2* W,
                  int per_stream, void* scratch, float2* Y, long T_stride, long t0, long tcount, hipStream_t st)
 {
+  constexpr bool I16 = sizeof(PT) == 2;
   constexpr int D = A_M / R;
   constexpr int SPAN = (A_TT - 1) * D + A_MT * A_M;
   const int K = fb->K;
@@ -701,7 +733,9 @@ int launch512_bf(const btk_fb* fb, const float* pcm, long nsamples, long pcm_str
   // 33231 (default for R = 2) = 463 with the polyphase stage at wave priority 1
   const int var = btk_switches().fused_var >= 0 ? btk_switches().fused_var : (R == 2 ? 33231 : 3);
   const bool pipe = (var & 2) && R >= 2;
-  const bool gw = pipe && (var & 4) && R == 2;
+  // (int16 samples: the production forms only -- the default kernel of R = 2 (33231) and the staged forms 1 / 3; the other
+  //  diagnostic variants are float builds)
+  const bool gw = pipe && (var & 4) && R == 2 && (!I16 || ((var & 8) && !(var & 1024)));
   // (TT = 8 -- two wavefronts per workgroup, four workgroups per CU, the same occupancy with less barrier coupling -- measured
   //  1.50 ms against 1.47 for the 16-frame tile: BTK_FUSED_VAR=1031 in profiles/scripts/r02_fused_ab.sh)
   const bool t8 = gw && (var & 1024);
@@ -714,12 +748,16 @@ int launch512_bf(const btk_fb* fb, const float* pcm, long nsamples, long pcm_str
   const size_t lds = pipe ? (size_t)(gw ? 0 : SPAN * 4) + fbz + sizeof(float4) * WSTR * 2 : (size_t)regz + sizeof(float4) * WSTR;
   const long nw = (long)Sw * N * WSTR;
   hipLaunchKernelGGL(pair_weights_kernel, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, st, W, Wq, K, N, Sw);
-  auto kern = pipe ? analysis512_bfz_kernel<R, 3> : analysis512_bfz_kernel<R, 1>;
+  auto kern = pipe ? analysis512_bfz_kernel<R, 3, A_TT, PT> : analysis512_bfz_kernel<R, 1, A_TT, PT>;
+  if constexpr (I16) {
+    if (gw) kern = analysis512_bfz_kernel<2, 33231, A_TT, PT>;
+  } else {
   if (gw) kern = analysis512_bfz_kernel<2, 7>;
   if (t8) kern = analysis512_bfz_kernel<2, 7, 8>;
   if (gw && !t8 && (var & 8)) kern = (var & 16) ? analysis512_bfz_kernel<2, 31> : ((var & 64) ? ((var & 128) ? ((var & 256) ? ((var & 32768) ? analysis512_bfz_kernel<2, 33231> : analysis512_bfz_kernel<2, 463>) : analysis512_bfz_kernel<2, 207>) : analysis512_bfz_kernel<2, 79>) : analysis512_bfz_kernel<2, 15>);
+  }
 #ifdef BTK_FUSED_ABLATE
-  if (gw && !t8) switch ((var >> 12) & 7) {
+  if constexpr (!I16) if (gw && !t8) switch ((var >> 12) & 7) {
     case 1: kern = analysis512_bfz_kernel<2, 15 + 4096 * 1>; break;
     case 2: kern = analysis512_bfz_kernel<2, 15 + 4096 * 2>; break;
     case 3: kern = analysis512_bfz_kernel<2, 15 + 4096 * 3>; break;
@@ -731,7 +769,7 @@ int launch512_bf(const btk_fb* fb, const float* pcm, long nsamples, long pcm_str
   }
 #endif
   unsigned long long* phase = nullptr;
-  if (R == 2 && (var & 512)) {                       // diagnostics: per-phase shader cycles of wave 0, printed by every launch
+  if constexpr (!I16) if (R == 2 && (var & 512)) {   // diagnostics: per-phase shader cycles of wave 0, printed by every launch
     kern = gw ? analysis512_bfz_kernel<2, 33743> : analysis512_bfz_kernel<2, 515>;   // 33743 = the default form (33231) with the marks
     static unsigned long long* dbuf = nullptr;
     if (!dbuf) BTK_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&dbuf), 16 * sizeof(unsigned long long)));
@@ -1150,6 +1188,23 @@ int btk_analysis512_bf_try(const btk_fb* fb, const float* pcm, long nsamples, lo
     case 1: rc = launch512_bf<1>(fb, pcm, nsamples, pcm_stride, S, N, Wp, per_stream, Wt, Yp, T_stride, t0, tcount, st); break;
     case 2: rc = launch512_bf<2>(fb, pcm, nsamples, pcm_stride, S, N, Wp, per_stream, Wt, Yp, T_stride, t0, tcount, st); break;
     case 4: rc = launch512_bf<4>(fb, pcm, nsamples, pcm_stride, S, N, Wp, per_stream, Wt, Yp, T_stride, t0, tcount, st); break;
+    default: return 0;
+  }
+  return rc == BTK_OK ? 1 : rc;
+}
+
+// the same from 16-bit PCM (btk_fb_analysis_bf_i16)
+int btk_analysis512_bf_i16_try(const btk_fb* fb, const short* pcm, long nsamples, long pcm_stride, int S, int N, const void* W,
+                               int per_stream, void* Wt_scratch, void* Y, long T_stride, long t0, long tcount, hipStream_t st)
+{
+  if (fb->M != A_M || fb->m != A_MT) return 0;
+  const float2* Wp = static_cast<const float2*>(W);
+  float2* Yp = static_cast<float2*>(Y);
+  int rc;
+  switch (fb->R) {
+    case 1: rc = launch512_bf<1, short>(fb, pcm, nsamples, pcm_stride, S, N, Wp, per_stream, Wt_scratch, Yp, T_stride, t0, tcount, st); break;
+    case 2: rc = launch512_bf<2, short>(fb, pcm, nsamples, pcm_stride, S, N, Wp, per_stream, Wt_scratch, Yp, T_stride, t0, tcount, st); break;
+    case 4: rc = launch512_bf<4, short>(fb, pcm, nsamples, pcm_stride, S, N, Wp, per_stream, Wt_scratch, Yp, T_stride, t0, tcount, st); break;
     default: return 0;
   }
   return rc == BTK_OK ? 1 : rc;

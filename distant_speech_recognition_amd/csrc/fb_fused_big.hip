@@ -97,9 +97,11 @@ __device__ __forceinline__ void swap16(f2& a, f2& b)
 __device__ __forceinline__ void rows4(f2* u) { swap32(u[0], u[2]); swap32(u[1], u[3]); swap16(u[0], u[1]); swap16(u[2], u[3]); }
 __device__ __forceinline__ void rows2(f2* u) { swap16(u[0], u[1]); }
 
-template <int LOG2M, int VAR>     // VAR & 4: pass 1a -> 1b through rows4 / rows2 instead of LDS; VAR & 1: the window loads of the next channel are issued unconditionally and interleaved with the transform; VAR & 2: see the polyphase stage
+// PT = float: un-normalised float samples; PT = short: the 16-bit PCM itself, widened in registers (btk_fb_analysis_bf_i16: half the
+// bytes of the dominant stream, the same bits out)
+template <int LOG2M, int VAR, typename PT = float>     // VAR & 4: pass 1a -> 1b through rows4 / rows2 instead of LDS; VAR & 1: the window loads of the next channel are issued unconditionally and interleaved with the transform; VAR & 2: see the polyphase stage
 __global__ __launch_bounds__(BG<LOG2M>::NT, (LOG2M == 10) ? 2 : 1)
-void analysis_bfz_big_kernel(const float* __restrict__ pcm, long nsamples, long pcm_stride,
+void analysis_bfz_big_kernel(const PT* __restrict__ pcm, long nsamples, long pcm_stride,
                              const float* __restrict__ proto, const float2* __restrict__ twg,
                              int laN, float gain, int N, int K, const float4* __restrict__ Wq, long w_stream_stride,
                              float2* __restrict__ Yout, long T_stride, long part_stride /* float2 between channel-group blocks (0: one group) */,
@@ -126,7 +128,8 @@ void analysis_bfz_big_kernel(const float* __restrict__ pcm, long nsamples, long 
   const int nbeg = cg * nper, nend = (nbeg + nper < N) ? nbeg + nper : N;    // this workgroup's channels
 
   const long g0 = (t0 + tt0 + laN + 1) * (long)D - (long)B_MT * M;
-  const bool vec_ok = ((pcm_stride & 1) == 0) && ((reinterpret_cast<uintptr_t>(pcm) & 7) == 0);
+  constexpr bool I16 = sizeof(PT) == 2;
+  const bool vec_ok = ((pcm_stride & 1) == 0) && ((reinterpret_cast<uintptr_t>(pcm) & (2 * sizeof(PT) - 1)) == 0);
   const bool inb = vec_ok && g0 >= 0 && g0 + SPAN <= nsamples;
   const float4* wts = Wq + (long)s * w_stream_stride;
 
@@ -182,26 +185,31 @@ void analysis_bfz_big_kernel(const float* __restrict__ pcm, long nsamples, long 
   float2 accN = make_float2(0.f, 0.f);
 
   float2 win[NWG];
+  unsigned wraw[I16 ? NWG : 1];                                              // int16 samples: the rows as loaded, two samples per word
   f4 wpre[NWP];
   // window rows of channel n: interior tiles take them unguarded (the loop of an interior tile holds no bounds test)
   auto wload = [&](int n, auto fast) {
-    const float* src = pcm + ((long)s * N + n) * pcm_stride;
+    const PT* src = pcm + ((long)s * N + n) * pcm_stride;
     if constexpr (decltype(fast)::value) {
       // buffer loads: the channel's row base is a scalar resource, the row a scalar offset, the thread's part one 32-bit register --
       // no vector address arithmetic per load (plain pointers cost the loop 32 v_add_co / v_addc per channel)
-      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src + g0), 0, 0x7fffffff, 0x00020000);
-      const unsigned vo = (unsigned)woff * 4u;                               // woff >= 0: M / 2 - 2 - 2 n0, n0 < M / 4
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<PT*>(src + g0), 0, 0x7fffffff, 0x00020000);
+      const unsigned vo = (unsigned)woff * (unsigned)sizeof(PT);             // woff >= 0: M / 2 - 2 - 2 n0, n0 < M / 4
 #pragma unroll
       for (int i = 0; i < NWG; i++) {
-        const u2 t = __builtin_amdgcn_raw_buffer_load_b64(rs, vo, i * D * 4, 0);
-        win[i] = make_float2(__uint_as_float(t.x), __uint_as_float(t.y));
+        if constexpr (I16) {
+          wraw[i] = __builtin_amdgcn_raw_buffer_load_b32(rs, vo, i * D * 2, 0);    // widened when the channel's turn comes
+        } else {
+          const u2 t = __builtin_amdgcn_raw_buffer_load_b64(rs, vo, i * D * 4, 0);
+          win[i] = make_float2(__uint_as_float(t.x), __uint_as_float(t.y));
+        }
       }
     } else {
 #pragma unroll
       for (int i = 0; i < NWG; i++) {
         const long g = g0 + woff + (long)i * D;
-        win[i].x = (g >= 0 && g < nsamples) ? src[g] : 0.0f;
-        win[i].y = (g + 1 >= 0 && g + 1 < nsamples) ? src[g + 1] : 0.0f;
+        win[i].x = (g >= 0 && g < nsamples) ? (float)src[g] : 0.0f;
+        win[i].y = (g + 1 >= 0 && g + 1 < nsamples) ? (float)src[g + 1] : 0.0f;
       }
     }
   };
@@ -228,6 +236,11 @@ void analysis_bfz_big_kernel(const float* __restrict__ pcm, long nsamples, long 
     if (nbeg < nend) { wload(nbeg, fast); wfetch(nbeg); wstage(0); }
     for (int n = nbeg; n < nend; n++) {
       const int wbuf = (n - nbeg) & 1;
+      if constexpr (I16 && decltype(fast)::value) {
+        // v_cvt_f32_i32 with sign-extended word selects: exact, so the float kernel's bits follow; in front of barrier A
+#pragma unroll
+        for (int i = 0; i < NWG; i++) win[i] = make_float2((float)(short)(wraw[i] & 0xffff), (float)((int)wraw[i] >> 16));
+      }
 #if !defined(BTK_BIG_ABLATE) || !(BTK_BIG_ABLATE & 3)                        // ablation builds (profiles/; results WRONG by design): 1 = no barriers in the channel loop, 2 = no barrier A
       __syncthreads();                                                       // A: frames and weight buffer of channel n - 1 are consumed
 #endif
@@ -402,8 +415,8 @@ inline int big_cg(int S, int N, long tcount)
   return cg;
 }
 
-template <int LOG2M>
-int launch_big(const btk_fb* fb, const float* pcm, long nsamples, long pcm_stride, int S, int N, const float2* W, int per_stream,
+template <int LOG2M, typename PT = float>
+int launch_big(const btk_fb* fb, const PT* pcm, long nsamples, long pcm_stride, int S, int N, const float2* W, int per_stream,
                void* scratch, float2* Y, long T_stride, long t0, long tcount, hipStream_t st)
 {
   using G = BG<LOG2M>;
@@ -424,10 +437,13 @@ int launch_big(const btk_fb* fb, const float* pcm, long nsamples, long pcm_strid
   //   2  polyphase stage at wave priority 1              M = 2048 -0.6 ... -1.0 %
   //   4  pass 1a -> 1b through v_permlane32/16_swap instead of LDS (round 5): M = 1024 -7.5 %, M = 2048 -2 %, bit-identical
   const int var = btk_switches().fused_var >= 0 ? (btk_switches().fused_var & 7) : 7;
-  using KernT = decltype(&analysis_bfz_big_kernel<LOG2M, 0>);
-  static const KernT kerns[8] = {analysis_bfz_big_kernel<LOG2M, 0>, analysis_bfz_big_kernel<LOG2M, 1>, analysis_bfz_big_kernel<LOG2M, 2>, analysis_bfz_big_kernel<LOG2M, 3>,
-                                 analysis_bfz_big_kernel<LOG2M, 4>, analysis_bfz_big_kernel<LOG2M, 5>, analysis_bfz_big_kernel<LOG2M, 6>, analysis_bfz_big_kernel<LOG2M, 7>};
-  const KernT kern = kerns[var];
+  using KernT = decltype(&analysis_bfz_big_kernel<LOG2M, 7, PT>);
+  KernT kern = analysis_bfz_big_kernel<LOG2M, 7, PT>;                       // (the int16 entry has the production form only)
+  if constexpr (sizeof(PT) == 4) {
+    static const KernT kerns[8] = {analysis_bfz_big_kernel<LOG2M, 0>, analysis_bfz_big_kernel<LOG2M, 1>, analysis_bfz_big_kernel<LOG2M, 2>, analysis_bfz_big_kernel<LOG2M, 3>,
+                                   analysis_bfz_big_kernel<LOG2M, 4>, analysis_bfz_big_kernel<LOG2M, 5>, analysis_bfz_big_kernel<LOG2M, 6>, analysis_bfz_big_kernel<LOG2M, 7>};
+    kern = kerns[var];
+  }
   BTK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(kern, dim3((unsigned)nblocks), dim3(G::NT), lds, st, pcm, nsamples, pcm_stride, fb->d_proto, fb->d_tw, fb->laN, gain,
                      N, K, Wq, per_stream ? (long)N * G::WSTRB : 0L, CG > 1 ? part : Y, CG > 1 ? tcount : T_stride,
@@ -461,5 +477,18 @@ int btk_big_analysis_bf_try(const btk_fb* fb, const float* pcm, long nsamples, l
   int rc;
   if (fb->M == 1024) rc = launch_big<10>(fb, pcm, nsamples, pcm_stride, S, N, Wp, per_stream, scratch, Yp, T_stride, t0, tcount, st);
   else rc = launch_big<11>(fb, pcm, nsamples, pcm_stride, S, N, Wp, per_stream, scratch, Yp, T_stride, t0, tcount, st);
+  return rc == BTK_OK ? 1 : rc;
+}
+
+// the same from 16-bit PCM (btk_fb_analysis_bf_i16)
+int btk_big_analysis_bf_i16_try(const btk_fb* fb, const short* pcm, long nsamples, long pcm_stride, int S, int N, const void* W,
+                                int per_stream, void* scratch, void* Y, long T_stride, long t0, long tcount, hipStream_t st)
+{
+  if (btk_big_analysis_bf_scratch_bytes(fb, S, N, per_stream, tcount) == 0) return 0;
+  const float2* Wp = static_cast<const float2*>(W);
+  float2* Yp = static_cast<float2*>(Y);
+  int rc;
+  if (fb->M == 1024) rc = launch_big<10, short>(fb, pcm, nsamples, pcm_stride, S, N, Wp, per_stream, scratch, Yp, T_stride, t0, tcount, st);
+  else rc = launch_big<11, short>(fb, pcm, nsamples, pcm_stride, S, N, Wp, per_stream, scratch, Yp, T_stride, t0, tcount, st);
   return rc == BTK_OK ? 1 : rc;
 }

@@ -477,6 +477,36 @@ int btk_fb_analysis_bf_fused(const btk_fb_t* fb)
   return (fb->M == 1024 || fb->M == 2048) && fb->R == 2;                      // fb_fused_big.hip
 }
 
+int btk_fb_analysis_bf_i16_fused(const btk_fb_t* fb)
+{
+  if (!fb || fb->synthesis) return btk_set_error(BTK_ERR_PARAMETER, "btk_fb_analysis_bf_i16_fused: not an analysis plan");
+  if (btk_switches().disable_fused || fb->m != 4 || fb->kx0 != 0 || fb->kx1 != fb->K) return 0;
+  if (fb->M == 512) return fb->R == 1 || fb->R == 2 || fb->R == 4;
+  return (fb->M == 1024 || fb->M == 2048) && fb->R == 2;
+}
+
+int btk_fb_analysis_bf_i16(const btk_fb_t* fb, const short* pcm, long nsamples, long pcm_stride, int S, int N,
+                           const void* W, int per_stream_weights, void* Y, long T_stride, long t0, long tcount,
+                           void* scratch, long scratch_bytes, void* stream)
+{
+  if (!fb || fb->synthesis) return btk_set_error(BTK_ERR_PARAMETER, "btk_fb_analysis_bf_i16: not an analysis plan");
+  if (!pcm || !W || !Y || !scratch) return btk_set_error(BTK_ERR_PARAMETER, "btk_fb_analysis_bf_i16: null argument");
+  if (S <= 0 || N <= 0 || tcount < 0 || T_stride < tcount || pcm_stride < nsamples)
+    return btk_set_error(BTK_ERR_DIMENSION, "btk_fb_analysis_bf_i16: bad sizes S=%d N=%d tcount=%ld T_stride=%ld", S, N, tcount, T_stride);
+  if (tcount == 0) return BTK_OK;
+  if (reinterpret_cast<uintptr_t>(scratch) & 15) return btk_set_error(BTK_ERR_PARAMETER, "btk_fb_analysis_bf_i16: scratch must be 16-byte aligned");
+  if (reinterpret_cast<uintptr_t>(pcm) & 3) return btk_set_error(BTK_ERR_PARAMETER, "btk_fb_analysis_bf_i16: pcm must be 4-byte aligned");
+  if (btk_fb_analysis_bf_i16_fused(fb) != 1)
+    return btk_set_error(BTK_ERR_PARAMETER, "btk_fb_analysis_bf_i16: no int16 kernel for M=%d m=%d r=%d (btk_pcm_i16_to_f32 + btk_fb_analysis_bf)", fb->M, fb->m, fb->r);
+  const long need = btk_fb_analysis_bf_scratch_bytes(fb, S, N, per_stream_weights, tcount);
+  if (scratch_bytes < need) return btk_set_error(BTK_ERR_PARAMETER, "btk_fb_analysis_bf_i16: scratch too small (%ld < %ld)", scratch_bytes, need);
+  hipStream_t st = as_stream(stream);
+  int rc = btk_analysis512_bf_i16_try(fb, pcm, nsamples, pcm_stride, S, N, W, per_stream_weights, scratch, Y, T_stride, t0, tcount, st);
+  if (rc == 0) rc = btk_big_analysis_bf_i16_try(fb, pcm, nsamples, pcm_stride, S, N, W, per_stream_weights, scratch, Y, T_stride, t0, tcount, st);
+  if (rc == 0) return btk_set_error(BTK_ERR_PARAMETER, "btk_fb_analysis_bf_i16: geometry not covered");
+  return rc > 0 ? BTK_OK : rc;
+}
+
 long btk_fb_analysis_bf_scratch_bytes(const btk_fb_t* fb, int S, int N, int per_stream_weights, long tcount)
 {
   if (!fb) return -1;

@@ -653,8 +653,10 @@ void wpe_lp_scale_kernel(const float2* __restrict__ X, const float* __restrict__
     int ea = 0, eb = 0;
     if (wm > 0.f && wm < 3.0e38f) (void)frexpf(wm, &ea);                     // wm < 2^ea
     if (ym > 0.f && ym < 3.0e38f) (void)frexpf(ym, &eb);
-    scales[((long)s * g.K + k) * 2 + 0] = ldexpf(1.f, 14 - ea);
-    scales[((long)s * g.K + k) * 2 + 1] = ldexpf(1.f, 14 - eb);
+    // (clamped: a bin of near-silence must not drive 2^(14 - e) -- or 1 / (sa sb) at the store -- out of float32's range)
+    const int xa = 14 - ea < -60 ? -60 : (14 - ea > 60 ? 60 : 14 - ea), xb = 14 - eb < -60 ? -60 : (14 - eb > 60 ? 60 : 14 - eb);
+    scales[((long)s * g.K + k) * 2 + 0] = ldexpf(1.f, xa);
+    scales[((long)s * g.K + k) * 2 + 1] = ldexpf(1.f, xb);
   }
 }
 
@@ -689,7 +691,7 @@ __device__ __forceinline__ void split2m(float a, float b, unsigned& hi, unsigned
 template <int C, int NR, int NCW>
 __device__ __forceinline__ void lagprod16_task(const float2* __restrict__ Xk, const float* __restrict__ Wk, const WpeGeom& g, float2* __restrict__ R,
                                                int ys_ld, int ws_ld, int d, int la, int s, int k, float2* ys, float* ws, uint4* wcp,
-                                               float sa, float sb)
+                                               float sa, float sb, float* tmx)
 {
   static_assert(C == 8 && (NCW == 1 || NCW == 2), "4 / NCW wavefronts x NCW column blocks");   // column blocks per wavefront: col = 2 (c1 C + c2) + (0 re | 1 im)
   constexpr int RL = 32 / C;                                       // l1 values per 32-row block: row m of block j -> (l1 = la + RL j + m / C, c = m % C)
@@ -738,19 +740,40 @@ __device__ __forceinline__ void lagprod16_task(const float2* __restrict__ Xk, co
   // accumulators are flushed to R every LP16_SEG frames (first segment: store, later ones: add -- same task, fixed order).
   for (long seg0 = 0; seg0 < g.T; seg0 += LP16_SEG) {
   const long seg1 = seg0 + LP16_SEG < g.T ? seg0 + LP16_SEG : g.T;
-  for (long u0 = seg0; u0 < seg1; u0 += LP_WT) {
+  int tpar = 0;
+  for (long u0 = seg0; u0 < seg1; u0 += LP_WT, tpar ^= 1) {
+    // Exponent balance of the tile (round 6).  The weights are 1 / |y|^2: in a quiet stretch of a non-stationary signal a large weight
+    // meets tiny products, in a loud one the reverse, and with the one scale per (stream, bin) and operand above the small operand of
+    // either kind sits so low in float16's range that its low part is subnormal or gone -- 11 bits instead of 22 on terms that are NOT
+    // small (measured, segments 40 / 60 dB apart: taps 1.4e-3 / 1.9e-3 of the largest against the float64 oracle, the float32 kernel
+    // 3e-5 / 1.5e-4; profiles/r06_wpe_envelope.txt).  Per tile the two operands trade a power of two, a 2^-e and b 2^+e with
+    // e = half the distance between the exponents of the tile's largest weight and largest product bound: both then peak at the same
+    // height (<= 2^14), the product -- hence the accumulators' scale -- is unchanged, and nothing is rounded by it.
+    if (tid < 128) {
+      float wm = 0.f, ym = 0.f;
+#pragma unroll
+      for (int c = 0; c < C; c++) { wm = fmaxf(wm, wpf[c]); ym = fmaxf(ym, fmaf(ypf[c].x, ypf[c].x, ypf[c].y * ypf[c].y)); }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) { wm = fmaxf(wm, __shfl_xor(wm, o)); ym = fmaxf(ym, __shfl_xor(ym, o)); }
+      if (lane == 0) { tmx[tpar * 4 + 2 * wv] = wm; tmx[tpar * 4 + 2 * wv + 1] = ym * sb; }    // (slots of this tile's parity: the last tile's are still being read)
+    }
     __syncthreads();                                               // the reads of the last tile are done
     if (tid < 128) {
+      const float wm = fmaxf(tmx[tpar * 4], tmx[tpar * 4 + 2]), bm = fmaxf(tmx[tpar * 4 + 1], tmx[tpar * 4 + 3]);
+      int ea = 0, eb = 0;
+      if (wm > 0.f && bm > 0.f) { (void)frexpf(wm, &ea); (void)frexpf(bm, &eb); }
+      const int eh = (ea - eb) >> 1;                               // |eh| <= 64: exact powers of two
+      const float fa = ldexpf(1.f, -eh), fb = sb * ldexpf(1.f, eh);
       const int e = tid;
 #pragma unroll
       for (int c = 0; c < C; c++) {
         if (e < YN) {
           const float2 v = ypf[c];
           ys[c * ys_ld + e] = v;
-          ysp[c * ys_ld + e] = make_float2(v.x * sb, v.y * sb);
-          ysp[(C + c) * ys_ld + e] = make_float2(-v.y * sb, v.x * sb);
+          ysp[c * ys_ld + e] = make_float2(v.x * fb, v.y * fb);
+          ysp[(C + c) * ys_ld + e] = make_float2(-v.y * fb, v.x * fb);
         }
-        if (e < WN) ws[c * ws_ld + e] = wpf[c];
+        if (e < WN) ws[c * ws_ld + e] = wpf[c] * fa;
         else if (e < ws_ld) ws[c * ws_ld + e] = 0.f;               // (the shifted copies read up to 14 values past a block's start)
       }
     }
@@ -871,6 +894,7 @@ __device__ __forceinline__ void wpe_lagprod16_body(const float2* __restrict__ X,
   uint4* wcp = reinterpret_cast<uint4*>(smem);                     // [2 (high | low)][8 shifts][C][LP16_NB] x 8 float16
   float2* ys = reinterpret_cast<float2*>(wcp + 2 * 8 * C * LP16_NB);   // [C][ys_ld]: sample u0 + e of channel c'
   float* ws = reinterpret_cast<float*>(ys + 3 * C * ys_ld);        // (ys is followed by the two pre-multiplied forms of the second factor) [C][ws_ld]: w_c(u0 + lowerN + la + e), scaled
+  float* tmx = ws + C * ws_ld;                                     // [2 (tile parity)][2 staging wavefronts][2]: largest weight / product bound of a tile
   const int k = blockIdx.y, s = blockIdx.z;
   if (!bin_active(g, k)) return;
   const int L = g.L;
@@ -886,10 +910,10 @@ __device__ __forceinline__ void wpe_lagprod16_body(const float2* __restrict__ X,
   const float* Wk = Winv + ((long)s * C * g.K + k) * g.T_stride;
   const float sa = scales[((long)s * g.K + k) * 2], sb = scales[((long)s * g.K + k) * 2 + 1];
   switch (nb) {
-    case 4: lagprod16_task<C, 4, NCW>(Xk, Wk, g, R, ys_ld, ws_ld, d, la, s, k, ys, ws, wcp, sa, sb); break;
-    case 3: lagprod16_task<C, 3, NCW>(Xk, Wk, g, R, ys_ld, ws_ld, d, la, s, k, ys, ws, wcp, sa, sb); break;
-    case 2: lagprod16_task<C, 2, NCW>(Xk, Wk, g, R, ys_ld, ws_ld, d, la, s, k, ys, ws, wcp, sa, sb); break;
-    default: lagprod16_task<C, 1, NCW>(Xk, Wk, g, R, ys_ld, ws_ld, d, la, s, k, ys, ws, wcp, sa, sb); break;
+    case 4: lagprod16_task<C, 4, NCW>(Xk, Wk, g, R, ys_ld, ws_ld, d, la, s, k, ys, ws, wcp, sa, sb, tmx); break;
+    case 3: lagprod16_task<C, 3, NCW>(Xk, Wk, g, R, ys_ld, ws_ld, d, la, s, k, ys, ws, wcp, sa, sb, tmx); break;
+    case 2: lagprod16_task<C, 2, NCW>(Xk, Wk, g, R, ys_ld, ws_ld, d, la, s, k, ys, ws, wcp, sa, sb, tmx); break;
+    default: lagprod16_task<C, 1, NCW>(Xk, Wk, g, R, ys_ld, ws_ld, d, la, s, k, ys, ws, wcp, sa, sb, tmx); break;
   }
 }
 
@@ -1184,7 +1208,7 @@ int btk_wpe_estimate(const void* X, int S, int K, int C, long T_stride, long T, 
         // round 5: float16-split operands on the 16 x faster matrix instruction (see lagprod16_task)
         const int nb16 = lp16_nb(C);
         const int ws16 = 8 * nb16 + 8;                                         // >= 8 (nb16 - 1) + 15 values (40 KB of LDS per task with this: four tasks per CU)
-        const size_t lds16p = sizeof(uint4) * 2 * 8 * (size_t)C * nb16 + sizeof(float2) * 3 * (size_t)C * ys_ld + sizeof(float) * (size_t)C * ws16;
+        const size_t lds16p = sizeof(uint4) * 2 * 8 * (size_t)C * nb16 + sizeof(float2) * 3 * (size_t)C * ys_ld + sizeof(float) * (size_t)C * ws16 + sizeof(float) * 8;
         hipLaunchKernelGGL(wpe_lp_scale_kernel, dim3((unsigned)K, (unsigned)S), dim3(256), 0, st, Xp, Winv, g, lp_scales);
         if (btk_switches().wpe_lagprod_waves == 2)
           hipLaunchKernelGGL(wpe_lagprod16_w2_kernel, dim3(ntask, (unsigned)K, (unsigned)S), dim3(128), lds16p, st, Xp, Winv, g, R, ys_ld, ws16, lp_scales);

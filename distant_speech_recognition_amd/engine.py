@@ -163,8 +163,13 @@ class FilterBank:
 
     def analysis_beamform(self, pcm, W, nsamples=None, t0=0, tcount=None, out=None):
         """Fused analysis -> fixed-weight beamformer: pcm [S][N][L], W complex64 [S|1][K][N] -> Y [S][K][T]
-        (the N x K snapshots are not written to HBM)."""
-        _check(pcm, "pcm", torch.float32, 3)
+        (the N x K snapshots are not written to HBM).  pcm float32, or int16 -- the samples as a WAV stores them
+        (feature/feature.cc:265-269): widened inside the kernel, half the bytes, the same bits out (btk_fb_analysis_bf_i16;
+        geometries with an int16 kernel: fused_i16())."""
+        i16 = pcm.dtype == torch.int16
+        _check(pcm, "pcm", torch.int16 if i16 else torch.float32, 3)
+        if i16 and not self.fused_i16():
+            raise _lib.BtkError(_lib.BTK_ERR_PARAMETER, "no int16 fused kernel for M=%d m=%d r=%d: widen with pcm_i16_to_f32 first" % (self.M, self.m, self.r))
         S, N, L = pcm.shape
         nsamples = L if nsamples is None else nsamples
         if tcount is None:
@@ -200,9 +205,13 @@ class FilterBank:
         cache[key] = buf
         while len(cache) > 8:
             cache.popitem(last=False)
-        check(_lib.lib().btk_fb_analysis_bf(self._h, _ptr(pcm), nsamples, L, S, N, _ptr(W), per_stream, _ptr(out), t_stride,
-                                            t0, tcount, _ptr(buf), buf.numel(), _stream()))
+        fn = _lib.lib().btk_fb_analysis_bf_i16 if i16 else _lib.lib().btk_fb_analysis_bf
+        check(fn(self._h, _ptr(pcm), nsamples, L, S, N, _ptr(W), per_stream, _ptr(out), t_stride, t0, tcount, _ptr(buf), buf.numel(), _stream()))
         return out
+
+    def fused_i16(self):
+        """True when analysis_beamform takes int16 samples for this geometry (btk_fb_analysis_bf_i16_fused)."""
+        return _lib.lib().btk_fb_analysis_bf_i16_fused(self._h) == 1
 
     # ---- synthesis
     def num_blocks(self, nframes):

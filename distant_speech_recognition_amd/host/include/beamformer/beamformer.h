@@ -162,6 +162,8 @@ class SubbandBeamformer : public VectorComplexFeatureStream {
   OverSampledDFTAnalysisBank* bank(unsigned c) { return banks_[c]; }
  protected:
   bool load_chunk_();
+  void pull_bank_(size_t c);
+  void plan_from_pulled_(BlockPlan& p, size_t nbanks) const;
   void ensure_chunk_() { if (!chunk_loaded_) load_chunk_(); }
   void* snapshots_();             // the block's snapshots, launched on the node stream (not waited for)
   void free_device_();

@@ -1243,23 +1243,35 @@ bool SubbandBeamformer::banks_only()
 
 // every bank pulls one round of input blocks (its block_frames()); the channels advance in lock step, the shortest one ends
 // the stream (its zero-padded tail frames included, like a per-frame graph whose first exhausted channel ends it)
-void SubbandBeamformer::plan_bank_block(BlockPlan& p)
+void SubbandBeamformer::pull_bank_(size_t c)
 {
   ScopedNs timer(g_pull_ns);
   const long f0 = chunk_loaded_ ? chunk_base_ + T_ : 0;
-  const long laN = btk_fb_lookahead(banks_[0]->plan()), pd = btk_fb_processing_delay(banks_[0]->plan());
   const long want = (f0 / quantum_ + 1) * quantum_;            // a block ends on a multiple of the quantum (or with the stream)
-  for (size_t c = 0; c < banks_.size(); c++)
-    while (!banks_[c]->at_end() && banks_[c]->frames_ready() < want) banks_[c]->pull_more();
+  while (!banks_[c]->at_end() && banks_[c]->frames_ready() < want) banks_[c]->pull_more();
+}
+
+// the block the first nbanks banks allow (all of them: the block itself; the first one alone: what the block will be unless a
+// later channel turns out shorter)
+void SubbandBeamformer::plan_from_pulled_(BlockPlan& p, size_t nbanks) const
+{
+  const long f0 = chunk_loaded_ ? chunk_base_ + T_ : 0;
+  const long laN = btk_fb_lookahead(banks_[0]->plan()), pd = btk_fb_processing_delay(banks_[0]->plan());
   long nblk = -1; bool ended = false;
-  for (size_t c = 0; c < banks_.size(); c++) { const long n = banks_[c]->blocks_pulled(); if (nblk < 0 || n < nblk) nblk = n; }
-  for (size_t c = 0; c < banks_.size(); c++) if (banks_[c]->at_end() && banks_[c]->blocks_pulled() == nblk) ended = true;
+  for (size_t c = 0; c < nbanks; c++) { const long n = banks_[c]->blocks_pulled(); if (nblk < 0 || n < nblk) nblk = n; }
+  for (size_t c = 0; c < nbanks; c++) if (banks_[c]->at_end() && banks_[c]->blocks_pulled() == nblk) ended = true;
   long f1 = ended ? (nblk < laN ? 0 : nblk - laN + pd) : (nblk > laN ? nblk - laN : 0);
   if (!ended) f1 = f1 / quantum_ * quantum_;
   long b0 = banks_[0]->first_block_of_frame(f0);
-  for (size_t c = 0; c < banks_.size(); c++) b0 = std::max(b0, banks_[c]->window_first_block());
+  for (size_t c = 0; c < nbanks; c++) b0 = std::max(b0, banks_[c]->window_first_block());
   b0 = std::min(b0, nblk);
   p.f0 = f0; p.T = f1 > f0 ? f1 - f0 : 0; p.b0 = b0; p.L = (nblk - b0) * (long)banks_[0]->shiftlen(); p.ended = ended;
+}
+
+void SubbandBeamformer::plan_bank_block(BlockPlan& p)
+{
+  for (size_t c = 0; c < banks_.size(); c++) pull_bank_(c);
+  plan_from_pulled_(p, banks_.size());
 }
 
 void SubbandBeamformer::commit_bank_block(const BlockPlan& p)
@@ -1277,15 +1289,31 @@ bool SubbandBeamformer::load_chunk_()
   const unsigned N = chanN(), K = fftLen2_ + 1;
   if (N == 0) throw j_error("set channels first\n");
   if (banks_only()) {
-    BlockPlan p;
-    plan_bank_block(p);
+    // The banks keep their windows in pinned memory: N asynchronous copies, one per channel, and the block's samples are resident
+    // -- for the fused kernel (SubbandDS::compute_output_) or for snapshots_().  The copy of a channel starts as soon as that
+    // channel has pulled its input, under the pulling of the next ones: the first bank says what the block will be, and only
+    // if a later channel turns out shorter (the end of a stream with ragged channels) the copies are made again.
+    BlockPlan p, p0;
     float* dp = NULL;
-    if (p.T > 0) {
+    pull_bank_(0);
+    plan_from_pulled_(p0, 1);
+    if (p0.T > 0) {
+      dp = static_cast<float*>(dPcmBuf_.ensure(sizeof(float) * N * (p0.L ? p0.L : 1)));
+      h2d_async(dp, banks_[0]->window(p0.b0), sizeof(float) * p0.L);
+    }
+    for (unsigned c = 1; c < N; c++) {
+      pull_bank_(c);
+      if (p0.T > 0 && banks_[c]->window_first_block() <= p0.b0 && (banks_[c]->blocks_pulled() - p0.b0) * (long)banks_[c]->shiftlen() >= p0.L)
+        h2d_async(dp + (size_t)c * p0.L, banks_[c]->window(p0.b0), sizeof(float) * p0.L);
+    }
+    plan_from_pulled_(p, N);
+    {
       ScopedNs timer(g_upload_ns);
-      // the banks keep their windows in pinned memory: N asynchronous copies, one per channel, and the block's samples are
-      // resident -- for the fused kernel (SubbandDS::compute_output_) or for snapshots_()
-      dp = static_cast<float*>(dPcmBuf_.ensure(sizeof(float) * N * (p.L ? p.L : 1)));
-      for (unsigned c = 0; c < N; c++) h2d_async(dp + (size_t)c * p.L, banks_[c]->window(p.b0), sizeof(float) * p.L);
+      if (p.T > 0 && (p0.T <= 0 || p.b0 != p0.b0 || p.L != p0.L)) {
+        nsync();
+        dp = static_cast<float*>(dPcmBuf_.ensure(sizeof(float) * N * (p.L ? p.L : 1)));
+        for (unsigned c = 0; c < N; c++) h2d_async(dp + (size_t)c * p.L, banks_[c]->window(p.b0), sizeof(float) * p.L);
+      }
       nsync();                                                   // before the banks move their windows on
     }
     commit_bank_block(p);
@@ -3035,7 +3063,20 @@ bool SubbandGraphPool::load_round_()
   const long pd = btk_fb_processing_delay(s0->plan());
   const long H = std::max<long>((long)s0->m() * R + R, pd);    // frames of history a round's first block reaches back to
   std::vector<SubbandBeamformer::BlockPlan> plans(G);
-  long Lmax = 0, Tmax = 0, t0 = -1, f0 = -1;
+  long Lmax = 0, Tmax = 0, t0 = -1, f0 = -1, Lprov = 0;
+  float* dPcm = NULL;
+  // the sample windows of every graph go into one block [G][N][Lmax] (rows of 16 bytes for the fused kernel's vector loads, zero
+  // behind a shorter -- ending -- stream).  A graph's windows start their way up as soon as its banks have pulled their input,
+  // under the pulling of the next graph: the first graph says how long the rows will be, and only if a later one turns out longer
+  // the copies are made again.
+  auto upload = [&](size_t g, long pitch) {
+    SubbandDS* bf = graphs_[g].bf.operator->();
+    const SubbandBeamformer::BlockPlan& p = plans[g];
+    float* slice = dPcm + g * (size_t)N * pitch;
+    if (p.L < pitch)
+      check_hip(hipMemset2DAsync(slice + p.L, sizeof(float) * pitch, 0, sizeof(float) * (pitch - p.L), N, nstream()), "hipMemset2DAsync");
+    for (unsigned c = 0; c < N; c++) h2d_async(slice + (size_t)c * pitch, bf->bank(c)->window(p.b0), sizeof(float) * p.L);
+  };
   for (size_t g = 0; g < G; g++) {
     Graph& gr = graphs_[g];
     gr.T = 0; gr.nblocks = 0; gr.served = 0;
@@ -3049,23 +3090,19 @@ bool SubbandGraphPool::load_round_()
         throw jconsistency_error("SubbandGraphPool: graph %d is at frame %ld, the others at %ld -- the graphs of a pool advance in lock step\n", (int)g, p.f0, f0);
       f0 = p.f0; t0 = p.f0 - p.b0;
       Lmax = std::max(Lmax, p.L); Tmax = std::max(Tmax, p.T);
+      if (!dPcm) { Lprov = (p.L + 3) / 4 * 4; dPcm = static_cast<float*>(dPcm_.ensure(sizeof(float) * G * N * (Lprov ? Lprov : 4))); }
+      if (p.L <= Lprov) upload(g, Lprov);
     }
     gr.T = p.T;
     if (p.ended) gr.live = false;
   }
   if (Tmax == 0) return false;                                 // (a plan without frames is the end of its stream)
-  Lmax = (Lmax + 3) / 4 * 4;                                   // 16-byte rows for the fused kernel's vector loads
+  Lmax = (Lmax + 3) / 4 * 4;
   std::chrono::steady_clock::time_point tu0 = std::chrono::steady_clock::now();
-  // ---- the sample windows of every graph, [G][N][Lmax], zero behind a shorter (ending) stream
-  float* dPcm = static_cast<float*>(dPcm_.ensure(sizeof(float) * G * N * Lmax));
-  for (size_t g = 0; g < G; g++) {
-    if (graphs_[g].T <= 0) continue;
-    SubbandDS* bf = graphs_[g].bf.operator->();
-    const SubbandBeamformer::BlockPlan& p = plans[g];
-    float* slice = dPcm + g * (size_t)N * Lmax;
-    if (p.L < Lmax)
-      check_hip(hipMemset2DAsync(slice + p.L, sizeof(float) * Lmax, 0, sizeof(float) * (Lmax - p.L), N, nstream()), "hipMemset2DAsync");
-    for (unsigned c = 0; c < N; c++) h2d_async(slice + (size_t)c * Lmax, bf->bank(c)->window(p.b0), sizeof(float) * p.L);
+  if (Lmax != Lprov) {
+    nsync();
+    dPcm = static_cast<float*>(dPcm_.ensure(sizeof(float) * G * N * Lmax));
+    for (size_t g = 0; g < G; g++) if (graphs_[g].T > 0) upload(g, Lmax);
   }
   // ---- per-stream weights [G][K][N], from the weight objects as they are now
   float* hW = static_cast<float*>(hW_.ensure(sizeof(float) * 2 * G * K * N));

@@ -2,9 +2,11 @@
 feature/feature.cc:265-269), leave as beamformed PCM, and the GPU chain in between (fused analysis + SubbandDS/GSC/MVDR apply,
 synthesis) runs 50x faster than PCIe can feed it -- so the pipeline is built around the link:
 
-  * samples cross PCIe as int16 (half the bytes of the floats the kernels compute on) from pinned buffers and are widened on the
-    device (`btk_pcm_i16_to_f32`); the single-channel output comes back as float32 or int16 (`btk_pcm_f32_to_i16`, the
-    reference scripts' `numpy.array(buf, numpy.int16)`);
+  * samples cross PCIe as int16 (half the bytes of the floats the kernels compute on) from pinned buffers and STAY int16 in HBM:
+    the fused kernel reads them as they are and widens them in registers (`btk_fb_analysis_bf_i16`: no widening pass, no float
+    copy of the PCM, the same bits out); geometries without an int16 kernel and interleaved frames are widened on the device first
+    (`btk_pcm_i16_to_f32` / `btk_pcm_i16_deinterleave`); the single-channel output comes back as float32 or int16
+    (`btk_pcm_f32_to_i16`, the reference scripts' `numpy.array(buf, numpy.int16)`);
   * three HIP streams -- upload, compute, download -- and `depth` device buffer sets: batch b+1 uploads while batch b is
     transformed and batch b-1 downloads; events order the hand-overs, the host only waits for finished downloads;
   * utterance streams are independent (unit_test/test_online_beamforming.py:80-88 builds one graph per utterance), so a batch is
@@ -45,6 +47,8 @@ class BatchBeamformerPipeline:
         self.interleaved = bool(interleaved)               # host PCM as stored in a multi-channel WAV: [S][L][N] int16
         if self.interleaved and not self.int16_in:
             raise _lib.BtkError(_lib.BTK_ERR_PARAMETER, "interleaved input is int16 (the frames of a multi-channel WAV)")
+        # planar int16 input goes to the fused kernel as it is when the geometry has an int16 kernel
+        self.direct_i16 = self.int16_in and not self.interleaved and afb.fused_i16() and self.L % 2 == 0
         self.T = afb.num_frames(self.L)
         self.nblk = sfb.num_blocks(self.T)
         self.out_len = self.nblk * sfb.D
@@ -55,7 +59,7 @@ class BatchBeamformerPipeline:
             st = {
                 "raw": torch.empty((self.B, self.L, self.N) if self.interleaved else (self.B, self.N, self.L),
                                    dtype=torch.int16 if self.int16_in else torch.float32, device=self.dev),
-                "pcm": torch.empty((self.B, self.N, self.L), dtype=torch.float32, device=self.dev) if self.int16_in else None,
+                "pcm": torch.empty((self.B, self.N, self.L), dtype=torch.float32, device=self.dev) if (self.int16_in and not self.direct_i16) else None,
                 "Y": engine.padded_rows((self.B, K, self.T), torch.complex64, self.dev),
                 "out": torch.empty((self.B, self.out_len), dtype=torch.float32, device=self.dev),
                 "out16": torch.empty((self.B, self.out_len), dtype=torch.int16, device=self.dev) if self.int16_out else None,
@@ -79,16 +83,17 @@ class BatchBeamformerPipeline:
             if self.interleaved:
                 for u in range(nb):                                # [L][N] frames -> planar float channels, all channels per launch
                     check(_lib.lib().btk_pcm_i16_deinterleave(_ptr(st["raw"][u]), _ptr(st["pcm"][u]), self.L, self.N, self.L, self.s_cmp.cuda_stream))
-            elif self.int16_in:
+            elif self.int16_in and not self.direct_i16:
                 check(_lib.lib().btk_pcm_i16_to_f32(_ptr(st["raw"]), _ptr(st["pcm"]), nb * self.N * self.L, self.s_cmp.cuda_stream))
-            if self.int16_in:
+            widened = self.int16_in and not self.direct_i16
+            if widened:
                 pcm = st["pcm"][:nb]
                 st["free"].record(self.s_cmp)                      # `raw` may be overwritten by the next upload once widened ...
             else:
-                pcm = st["raw"][:nb]
+                pcm = st["raw"][:nb]                               # float32, or int16 read by the fused kernel itself
             Y = st["Y"][:nb]
             self.afb.analysis_beamform(pcm, self.W, out=Y)
-            if not self.int16_in:
+            if not widened:
                 st["free"].record(self.s_cmp)                      # ... or, without widening, once the analysis has read it
             self.sfb.synthesize(Y, out=st["out"][:nb])
             if self.int16_out:

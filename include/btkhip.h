@@ -126,6 +126,17 @@ int  btk_fb_analysis_bf(const btk_fb_t* fb, const float* pcm, long nsamples, lon
                         const void* W, int per_stream_weights, void* Y, long T_stride, long t0, long tcount,
                         void* scratch, long scratch_bytes, void* stream);
 
+/* The same operator on the samples AS THEY ARE STORED: 16-bit PCM (SampleFeature::read turns a WAV's int16 samples into
+ * un-normalised floats, feature/feature.cc:265-269; over PCIe and in HBM they can stay int16).  pcm [dev] int16 [S*N][pcm_stride],
+ * widened in registers inside the fused kernel: 2 D N + 8 K bytes per beamformed frame instead of 4 D N + 8 K, and -- the
+ * conversion is exact -- the SAME BITS as btk_fb_analysis_bf on the float copies of the same samples.  Geometries:
+ * btk_fb_analysis_bf_i16_fused() == 1 (M = 512 with m = 4, r <= 2, and M = 1024 / 2048 with m = 4, r = 1); for the others widen
+ * with btk_pcm_i16_to_f32 and call btk_fb_analysis_bf (BTK_ERR_PARAMETER here).  scratch: btk_fb_analysis_bf_scratch_bytes.   */
+int  btk_fb_analysis_bf_i16_fused(const btk_fb_t* fb);
+int  btk_fb_analysis_bf_i16(const btk_fb_t* fb, const short* pcm, long nsamples, long pcm_stride, int S, int N,
+                            const void* W, int per_stream_weights, void* Y, long T_stride, long t0, long tcount,
+                            void* scratch, long scratch_bytes, void* stream);
+
 /* ---- Adaptive GSC canceller: leaky power-normalised NLMS ----------------------------------
  * Replaces SubbandGSCLMSBeamformer.__iter__ / reset_stats (lib/pybeamformer.py:659-762), Nc = 1.
  * params [host] 8 floats: beta, gamma(init), regularization_param, energy_floor, sil_thresh,

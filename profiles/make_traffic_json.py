@@ -16,7 +16,8 @@ for f in sorted(glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), rec
         k = r["Kernel_Name"].replace("void (anonymous namespace)::", "").split("(")[0]
         acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
 # bench.py only quotes these numbers while the kernel sources are the ones they were measured on
-res = {"S": S, "T": T, "N": 64, "M": 512, "kernel_source_sha256": kernel_source_sha(), "correction": "read = 2 * FETCH_SIZE KiB * 1024; write = WRITE_SIZE KiB * 1024", "kernels": {}}
+res = {"S": S, "T": T, "N": 64, "M": 512, "kernel_source_sha256": kernel_source_sha(), "correction": "read = 2 * FETCH_SIZE KiB * 1024; write = WRITE_SIZE KiB * 1024", "kernels": {},
+       "kernels_i16": {}}      # the instances that read 16-bit PCM (btk_fb_analysis_bf_i16) are kept apart: bench.py stages.fused_i16
 for k, c in acc.items():
     if not any(s in k for s in ("analysis", "bf_apply", "synthesis")):
         continue
@@ -27,6 +28,6 @@ for k, c in acc.items():
         e["write_bytes"] = 1024.0 * sum(c["WRITE_SIZE"]) / len(c["WRITE_SIZE"])
     if "read_bytes" in e and "write_bytes" in e:
         e["traffic_bytes"] = e["read_bytes"] + e["write_bytes"]
-    res["kernels"][k] = e
+    res["kernels_i16" if ", short>" in k else "kernels"][k] = e
 json.dump(res, open(out, "w"), indent=1)
 print(json.dumps(res, indent=1))

@@ -17,11 +17,13 @@ pcm = (torch.randn((S, N, L), device=dev) * 1000).round_()
 W = torch.randn((257, N), dtype=torch.complex64, device=dev) / N
 X = torch.empty((S, 257, N, T), dtype=torch.complex64, device=dev)
 Y = torch.empty((S, 257, T), dtype=torch.complex64, device=dev)
+pcm16 = pcm.to(torch.int16)
 for _ in range(2):
     afb.analysis(pcm, out=X)
     eng.bf_apply(W, X, out=Y)
     sfb.synthesize(Y)
     afb.analysis_beamform(pcm, W, out=Y)
+    afb.analysis_beamform(pcm16, W, out=Y)            # the int16 entry (its instance name ends in ", short>")
 torch.cuda.synchronize()
 print("pmc workload done: S=%d T=%d algorithmic bytes analysis=%d apply=%d fused(min traffic)=%d"
       % (S, T, (4 * 256 + 8 * 257) * N * S * T, 8 * 257 * (N + 1) * S * T, (4 * 256 * N + 8 * 257) * S * T))

@@ -144,3 +144,52 @@ def test_wpe_long_utterance_accumulators_are_flushed(orc, dev):
     Gref = orc.wpe_estimate(Y, 0, 7, 2, -18.0, 0.0, 1e-4)[:, :K]
     assert np.max(np.abs(Gref)) > 1e-2
     assert np.max(np.abs(G - Gref)) <= 2e-3 * np.max(np.abs(Gref))
+
+
+@pytest.mark.parametrize("db", [40, 60])
+def test_wpe_non_stationary_envelope(orc, dev, db):
+    """Speech-like dynamics: loud and quiet segments `db` apart, each longer than the lag span.  The weights are 1 / |y|^2, so a
+    quiet segment pairs large weights with tiny products and a loud one the reverse; the float16-split lag-product kernel keeps
+    both operands in float16's normal range by trading a power of two between them per 64-frame tile (wpe_kernels.hip,
+    lagprod16_task).  With one scale per (stream, bin) the taps were 1.4e-3 / 1.9e-3 of the largest off the float64 oracle at
+    40 / 60 dB -- the test bound of the stationary cases -- against 3e-5 / 1.5e-4 for float32 products; balanced: 1.3e-4 / 2.3e-4."""
+    import torch
+    from distant_speech_recognition_amd import engine as eng
+    C, M, T, lower, upper = 8, 16, 2400, 1, 10
+    K = M // 2 + 1
+    rng = np.random.default_rng(7)
+    src = (rng.normal(size=(T + 16, K)) + 1j * rng.normal(size=(T + 16, K)))
+    env = np.ones(T + 16)
+    seg = 150
+    for i in range(0, T + 16, seg):
+        env[i:i + seg] = 1.0 if (i // seg) % 2 == 0 else 10.0 ** (-db / 20.0)
+    src *= (env * 8000.0)[:, None]                          # int16-scale loud segments
+    Y = np.zeros((T, C, M), np.complex128)
+    for c in range(C):
+        taps = (rng.normal(size=(8, K)) + 1j * rng.normal(size=(8, K))) * (0.6 ** np.arange(8))[:, None]
+        for t in range(T):
+            Y[t, c, :K] = sum(taps[d] * src[t + 16 - d] for d in range(8))
+    Y[:, :, :K] += (rng.normal(size=(T, C, K)) + 1j * rng.normal(size=(T, C, K))) * 0.05      # sensor noise, well above the 1e-3 floor
+    Xe = np.ascontiguousarray(np.transpose(Y[:, :, :K], (2, 1, 0))[None]).astype(np.complex64)
+    Yo = np.zeros((T, C, M), np.complex128)
+    Yo[:, :, :K] = np.transpose(Xe[0].astype(np.complex128), (2, 1, 0))
+    Yo[:, :, K:] = np.conj(Yo[:, :, M // 2 - 1:0:-1])
+    Gref = orc.wpe_estimate(Yo, lower, upper, 2, -18.0, 0.0, 1e-4)[:, :K]
+    G = eng.wpe_estimate(torch.from_numpy(Xe).to(dev), M, lower_num=lower, upper_num=upper, iterations_num=2, load_db=-18.0,
+                         diagonal_bias=1e-4).cpu().numpy()[0]
+    assert np.max(np.abs(Gref)) > 1e-4                      # (delayed prediction of a nearly white source: small taps, but not noise)
+    assert np.max(np.abs(G - Gref)) <= 5e-4 * np.max(np.abs(Gref))
+
+
+def test_wpe_near_silent_bin_stays_finite(dev):
+    """a bin whose samples are ~1e-20 must not drive the power-of-two scales of the float16-split kernel to inf (NaN in R)"""
+    import torch
+    from distant_speech_recognition_amd import engine as eng
+    C, M, T = 8, 16, 300
+    K = M // 2 + 1
+    g = torch.Generator(device=dev).manual_seed(5)
+    X = ((torch.randn((1, K, C, T), device=dev, generator=g) + 1j * torch.randn((1, K, C, T), device=dev, generator=g)) * 300).to(torch.complex64)
+    X[0, 3] *= 1e-22
+    X[0, 5] = 0
+    G = eng.wpe_estimate(X, M, lower_num=1, upper_num=6, iterations_num=2, load_db=-18.0, diagonal_bias=1e-4)
+    assert bool(torch.isfinite(torch.view_as_real(G)).all())
