@@ -4,8 +4,11 @@ btk20.{stream,feature,modulated,beamformer,postfilter,dereverberation}.
 
 There is ONE host layer: the C++ node layer of host/ (libbtk20hip.so, linked against the C-ABI of include/btkhip.h), bound to Python
 with pybind11 (distant_speech_recognition_amd.btk20cpp).  This package and its sub-modules only give it the reference's import names;
-a node pulls its finite upstream once, runs the whole block through the HIP kernels and serves frames from a host mirror, so `next()`
-keeps the reference's per-frame semantics (node-owned buffer, same-frame caching, end-of-stream)."""
+a node pulls its upstream in bounded blocks (at most block_frames frames: set_block_frames / BTK_BLOCK_FRAMES, default 8192), runs each
+block through the HIP kernels -- a fixed-weight beamformer over analysis banks that nobody asks for snapshots through the FUSED
+analysis -> apply kernel, its block handed to the synthesis bank on the device -- and serves frames from a host mirror, so `next()` keeps
+the reference's per-frame semantics (node-owned buffer, same-frame caching, end-of-stream); `SubbandGraphPoolPtr` advances many such
+graphs with one launch per block."""
 from ..btk20cpp import *   # noqa: F401,F403
 from ..btk20cpp import __all__  # noqa: F401
 

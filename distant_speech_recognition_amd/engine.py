@@ -432,6 +432,10 @@ class AdaptiveGSCChain:
         T = X.shape[-1]
         if self._sa is None:
             self._sa, self._sb = torch.cuda.Stream(device=pcm.device), torch.cuda.Stream(device=pcm.device)
+        if out is None:
+            # allocated on the CALLER's stream, where it is consumed: a block taken inside the side stream's context would belong to
+            # that stream's pool and could be handed on while the caller still reads it
+            out = torch.empty((X.shape[0], self.sfb.num_blocks(T) * self.sfb.D), dtype=torch.float32, device=pcm.device)
         cur = torch.cuda.current_stream()
         ev0 = torch.cuda.Event()
         ev0.record(cur)

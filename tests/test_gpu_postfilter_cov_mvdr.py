@@ -203,6 +203,40 @@ def test_mvdr_pinv_fallback_matches_oracle(orc, dev, N):
     assert np.allclose(W[3], d[3] / (N * np.vdot(d[3], d[3])), atol=1e-6)   # invR = I
 
 
+@pytest.mark.parametrize("N", [8, 64])
+def test_dead_channel_in_the_middle_of_the_array_is_a_stated_deviation(orc, dev, N):
+    """DESIGN.md 3.7's one stated deviation of the MVDR design, pinned.  A dead channel (zero row and column of R) at the END of
+    the array leaves LINPACK's Householder steps an exact zero: sigma = 0 < threshold, pseudoinverse() returns false, identity --
+    reference and engine agree (test above).  In the MIDDLE of the array the reference's float32 csvdc returns sigma ~ 2e-8, just
+    above the 1e-8 threshold, pseudoinverse() returns TRUE and the reference inverts that rounding noise (1 / sigma ~ 5e7,
+    beamformer/beamformer.cc:262-270); the engine's solve finds the exact zero and takes the identity.  The engine's answer is the
+    one a user wants; the reference's is an accident of rounding -- kept as a deviation, not reproduced (it would take csvdc's
+    singular VECTORS in float32 rounding order, not only its values)."""
+    import torch
+    from distant_speech_recognition_amd import engine as eng
+    rng = np.random.default_rng(N)
+    X = rng.normal(size=(N, 3 * N)) + 1j * rng.normal(size=(N, 3 * N))
+    R0 = (X @ X.conj().T / (3 * N) + 0.01 * np.eye(N)).astype(np.complex64)
+    d = (np.exp(-2j * np.pi * rng.uniform(size=(3, N))) / N).astype(np.complex64)
+    R = np.stack([R0, R0, R0]).copy()
+    mid = N // 2
+    R[1][:, mid] = 0; R[1][mid, :] = 0                                      # dead channel in the middle
+    R[2][:, N - 1] = 0; R[2][N - 1, :] = 0                                  # ... at the end
+    # the reference (oracle pseudoinverse == the compiled csvdc): middle -> "ok", inverse of rounding noise; end -> false
+    inv_mid, ok_mid = orc.pseudoinverse(R[1].astype(np.complex128), 1.0e-8)
+    inv_end, ok_end = orc.pseudoinverse(R[2].astype(np.complex128), 1.0e-8)
+    assert ok_mid and not ok_end
+    assert np.max(np.abs(inv_mid)) > 1e6                                    # 1 / sigma of the dead direction
+    W, nident = eng.mvdr_weights(torch.from_numpy(R).to(dev), torch.from_numpy(d).to(dev))
+    W = W.cpu().numpy()
+    assert nident == 2                                                      # the engine: identity for BOTH dead-channel bins
+    for k in (1, 2):
+        assert np.allclose(W[k], d[k] / (N * np.vdot(d[k], d[k])), atol=1e-6)
+    # what the reference would have used for the middle case is a different vector altogether
+    w_ref = _oracle_mvdr_bin(orc, R[1].astype(np.complex128), d[1].astype(np.complex128))
+    assert np.linalg.norm(W[1] - w_ref) > 0.1 * np.linalg.norm(w_ref)
+
+
 def _pinv_fallback_both(eng, R, d, threshold, first_bin=0):
     """(W_gpu, nident_gpu, ms_gpu), (W_host, nident_host): every bin flagged, the batched GPU Jacobi solve against the
     bin-by-bin host solve (btk_mvdr_pinv_fallback_host, the round-2 product path, itself pinned by the compiled csvdc)"""
