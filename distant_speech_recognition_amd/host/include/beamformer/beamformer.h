@@ -163,6 +163,7 @@ class SubbandBeamformer : public VectorComplexFeatureStream {
  protected:
   bool load_chunk_();
   void pull_bank_(size_t c);
+  void pull_banks_(size_t c0, size_t c1);
   void plan_from_pulled_(BlockPlan& p, size_t nbanks) const;
   void ensure_chunk_() { if (!chunk_loaded_) load_chunk_(); }
   void* snapshots_();             // the block's snapshots, launched on the node stream (not waited for)

@@ -54,6 +54,8 @@ class OverSampledDFTAnalysisBank : public VectorComplexFeatureStream {
   long block_frames() const { return block_frames_; }
   // engine hooks used by the beamformer nodes to batch all channels into one launch: the bank as a sliding window of samples
   bool pull_more();                                     // up to block_frames() more input blocks (all of them for 0); false: nothing came
+  void reserve_round();                                 // the window sized for one more round of pull_more()
+  bool parallel_pull_ok() const;                        // pull_more() of this bank may run next to other banks' (SampleFeature source, bounded rounds)
   bool at_end() const { return eos_; }                  // the upstream node has ended
   long blocks_pulled() const { return nblk_; }
   long frames_ready() const;                            // frames 0 .. frames_ready() - 1 can be computed from what was pulled

@@ -8,10 +8,16 @@
 // asynchronous copies from / to pinned memory; a beamformer over analysis banks whose snapshots nobody asks for runs the
 // FUSED analysis -> apply kernel (btk_fb_analysis_bf) and hands its block to the synthesis bank on the device.
 #include <cstdlib>
+#include <sched.h>
 #include <hip/hip_runtime_api.h>
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
+#include <exception>
+#include <functional>
+#include <mutex>
+#include <thread>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -47,6 +53,80 @@ void check_hip(hipError_t e, const char* what)
   if (e == hipErrorOutOfMemory) throw jallocation_error("%s: %s", what, hipGetErrorString(e));
   throw j_error("%s: %s", what, hipGetErrorString(e));
 }
+
+// Helper threads for the one bulk job of the node layer that is pure host memory traffic: analysis banks drawing a round of input
+// blocks out of SampleFeature sources into their pinned windows (64 channels x 8192 blocks x 1 KB = 537 MB per block at C0: 30 ms
+// on one core, which is what a drop-in caller's frame rate was made of).  The reference is single-threaded and so is every node's
+// interface; the helpers only ever run SampleFeature::next_blocks of DIFFERENT source objects side by side, never a Python source,
+// and the caller waits for them.  BTK_NODE_THREADS sets the number (default: the cores this process may use, at most 8; 1 = none).
+class PullPool {
+ public:
+  static PullPool& get() { static PullPool* p = new PullPool(); return *p; }     // (never destroyed: no join at process exit)
+  int threads() const { return nthreads_; }
+  // fn(i) for i in [0, n): the calling thread takes part; the first exception of any of them is rethrown here
+  void parallel_for(int n, const std::function<void(int)>& fn)
+  {
+    if (n <= 0) return;
+    if (nthreads_ <= 1 || n == 1) { for (int i = 0; i < n; i++) fn(i); return; }
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      fn_ = &fn; n_ = n; next_ = 0; done_ = 0; err_ = nullptr; gen_++;
+    }
+    cv_.notify_all();
+    work();
+    std::unique_lock<std::mutex> lk(mu_);
+    cv_done_.wait(lk, [&] { return done_ == n_; });
+    fn_ = NULL;
+    if (err_) { std::exception_ptr e = err_; err_ = nullptr; lk.unlock(); std::rethrow_exception(e); }
+  }
+ private:
+  PullPool() : nthreads_(1), fn_(NULL), n_(0), next_(0), done_(0), gen_(0)
+  {
+    int n = (int)std::thread::hardware_concurrency();
+#ifdef __linux__
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof(set), &set) == 0) n = std::min(n > 0 ? n : 1, CPU_COUNT(&set));
+#endif
+    n = n < 1 ? 1 : (n > 8 ? 8 : n);
+    const char* e = getenv("BTK_NODE_THREADS");
+    if (e && *e) n = std::max(1, atoi(e));
+    nthreads_ = n;
+    for (int i = 1; i < nthreads_; i++) std::thread([this] { loop(); }).detach();
+  }
+  void work()
+  {
+    for (;;) {
+      int i;
+      {
+        std::lock_guard<std::mutex> lk(mu_);
+        if (!fn_ || next_ >= n_) return;
+        i = next_++;
+      }
+      try { (*fn_)(i); } catch (...) { std::lock_guard<std::mutex> lk(mu_); if (!err_) err_ = std::current_exception(); }
+      std::lock_guard<std::mutex> lk(mu_);
+      if (++done_ == n_) cv_done_.notify_all();
+    }
+  }
+  void loop()
+  {
+    unsigned long seen = 0;
+    for (;;) {
+      {
+        std::unique_lock<std::mutex> lk(mu_);
+        cv_.wait(lk, [&] { return gen_ != seen; });
+        seen = gen_;
+      }
+      work();
+    }
+  }
+  int nthreads_;
+  std::mutex mu_;
+  std::condition_variable cv_, cv_done_;
+  const std::function<void(int)>* fn_;
+  int n_, next_, done_;
+  unsigned long gen_;
+  std::exception_ptr err_;
+};
 
 std::atomic<long> g_device_allocs(0), g_pinned_allocs(0);
 std::atomic<long long> g_pull_ns(0), g_upload_ns(0), g_device_ns(0);
@@ -500,16 +580,28 @@ void OverSampledDFTAnalysisBank::append_(const float* blocks, long n)
   nblk_ += n;
 }
 
+// the window sized for one more round (+ the m R blocks of history + a beamformer's block quantum): a steady-state round then
+// allocates nothing; an unbounded round (block_frames() == 0) grows geometrically as it pulls
+void OverSampledDFTAnalysisBank::reserve_round()
+{
+  const size_t have = (size_t)(nblk_ - win_b0_) * D_;
+  if (block_frames_ > 0)
+    win_.ensure_keep(sizeof(float) * (have + (size_t)(block_frames_ + (long)m_ * (1L << r_) + 64) * D_), sizeof(float) * have);
+}
+
+// the source is a SampleFeature and rounds are bounded: pull_more() is then plain host memory traffic on objects no other bank
+// shares, and a beamformer node may run the pull_more() of several of its banks side by side (PullPool)
+bool OverSampledDFTAnalysisBank::parallel_pull_ok() const
+{
+  return block_frames_ > 0 && dynamic_cast<SampleFeature*>(samp_.operator->()) != NULL;
+}
+
 // one round of input: at most block_frames() blocks of D samples from the upstream node (modulated.cc:419-438 pulls one per frame)
 bool OverSampledDFTAnalysisBank::pull_more()
 {
   if (eos_) return false;
   long got = 0;
-  // the window is sized once for a whole round (+ the m R blocks of history + a beamformer's block quantum), so that a steady-
-  // state round allocates nothing; an unbounded round (block_frames() == 0) grows geometrically
-  const size_t have = (size_t)(nblk_ - win_b0_) * D_;
-  if (block_frames_ > 0)
-    win_.ensure_keep(sizeof(float) * (have + (size_t)(block_frames_ + (long)m_ * (1L << r_) + 64) * D_), sizeof(float) * have);
+  reserve_round();
   SampleFeature* sf = dynamic_cast<SampleFeature*>(samp_.operator->());
   if (sf && sf->size() == D_) {
     // a SampleFeature hands its blocks over in bulk, straight into the window (SampleFeature::next_blocks == the loop below)
@@ -1245,7 +1337,6 @@ bool SubbandBeamformer::banks_only()
 // the stream (its zero-padded tail frames included, like a per-frame graph whose first exhausted channel ends it)
 void SubbandBeamformer::pull_bank_(size_t c)
 {
-  ScopedNs timer(g_pull_ns);
   const long f0 = chunk_loaded_ ? chunk_base_ + T_ : 0;
   const long want = (f0 / quantum_ + 1) * quantum_;            // a block ends on a multiple of the quantum (or with the stream)
   while (!banks_[c]->at_end() && banks_[c]->frames_ready() < want) banks_[c]->pull_more();
@@ -1268,9 +1359,20 @@ void SubbandBeamformer::plan_from_pulled_(BlockPlan& p, size_t nbanks) const
   p.f0 = f0; p.T = f1 > f0 ? f1 - f0 : 0; p.b0 = b0; p.L = (nblk - b0) * (long)banks_[0]->shiftlen(); p.ended = ended;
 }
 
+// banks [c0, c1) pull their round: side by side when every one of them may (SampleFeature sources, bounded rounds)
+void SubbandBeamformer::pull_banks_(size_t c0, size_t c1)
+{
+  ScopedNs timer(g_pull_ns);
+  bool par = PullPool::get().threads() > 1 && c1 - c0 > 1;
+  for (size_t c = c0; c < c1 && par; c++) par = banks_[c]->parallel_pull_ok();
+  if (!par) { for (size_t c = c0; c < c1; c++) pull_bank_(c); return; }
+  for (size_t c = c0; c < c1; c++) banks_[c]->reserve_round();                 // (allocation, if any, stays on this thread)
+  PullPool::get().parallel_for((int)(c1 - c0), [&](int i) { pull_bank_(c0 + (size_t)i); });
+}
+
 void SubbandBeamformer::plan_bank_block(BlockPlan& p)
 {
-  for (size_t c = 0; c < banks_.size(); c++) pull_bank_(c);
+  pull_banks_(0, banks_.size());
   plan_from_pulled_(p, banks_.size());
 }
 
@@ -1295,16 +1397,17 @@ bool SubbandBeamformer::load_chunk_()
     // if a later channel turns out shorter (the end of a stream with ragged channels) the copies are made again.
     BlockPlan p, p0;
     float* dp = NULL;
-    pull_bank_(0);
+    // (groups of as many banks as there are helper threads pull side by side; a group's copies start when the group is done)
+    const unsigned G = (unsigned)std::max(1, PullPool::get().threads());
+    pull_banks_(0, std::min(G, N));
     plan_from_pulled_(p0, 1);
-    if (p0.T > 0) {
-      dp = static_cast<float*>(dPcmBuf_.ensure(sizeof(float) * N * (p0.L ? p0.L : 1)));
-      h2d_async(dp, banks_[0]->window(p0.b0), sizeof(float) * p0.L);
-    }
-    for (unsigned c = 1; c < N; c++) {
-      pull_bank_(c);
-      if (p0.T > 0 && banks_[c]->window_first_block() <= p0.b0 && (banks_[c]->blocks_pulled() - p0.b0) * (long)banks_[c]->shiftlen() >= p0.L)
-        h2d_async(dp + (size_t)c * p0.L, banks_[c]->window(p0.b0), sizeof(float) * p0.L);
+    if (p0.T > 0) dp = static_cast<float*>(dPcmBuf_.ensure(sizeof(float) * N * (p0.L ? p0.L : 1)));
+    for (unsigned g0 = 0; g0 < N; g0 += G) {
+      const unsigned g1 = std::min(g0 + G, N);
+      if (g0 > 0) pull_banks_(g0, g1);
+      for (unsigned c = g0; c < g1; c++)
+        if (p0.T > 0 && banks_[c]->window_first_block() <= p0.b0 && (banks_[c]->blocks_pulled() - p0.b0) * (long)banks_[c]->shiftlen() >= p0.L)
+          h2d_async(dp + (size_t)c * p0.L, banks_[c]->window(p0.b0), sizeof(float) * p0.L);
     }
     plan_from_pulled_(p, N);
     {

@@ -1,0 +1,45 @@
+#!/bin/bash
+# Round-6 measurement set (one gpurun call; order: final sources -> PMC traffic -> bench): smoke, PMC traffic passes of the headline
+# launch incl. the int16 entry (FETCH_SIZE / WRITE_SIZE separately), bench default (with stages.node_api / fused_i16), profiled bench
+# (rocprofv3 --kernel-trace --stats), HIP-API traces of the node-API bench at two stream lengths (allocations per block), stage /
+# config / bin-shard benches, WPE profile + non-stationary probe, partition probe.  Everything lands under gpurun_out/r06/;
+# profiles/scripts/r06_collect.sh copies the summaries that are committed.
+cd /tmp && export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r06; rm -rf $O; mkdir -p $O
+cd $R
+python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/smoke.log 2>&1
+cd /tmp
+PMC_S=32 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -o p -- python $R/profiles/pmc_workload.py > $O/pmc_fetch.log 2>&1
+PMC_S=32 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -o p -- python $R/profiles/pmc_workload.py > $O/pmc_write.log 2>&1
+mkdir -p $O/pmc_rw && cp -r $O/pmc_fetch $O/pmc_rw/ && cp -r $O/pmc_write $O/pmc_rw/
+python $R/profiles/make_traffic_json.py $O/pmc_rw $O/pmc_traffic.json 32 4096 > /dev/null 2>&1
+cp $O/pmc_traffic.json $R/profiles/r06_pmc_traffic.json          # bench.py below quotes it (same sources, same launch)
+cd $R
+python bench.py > $O/bench_default.json 2> $O/bench_default.err
+python bench.py --steps 20 --warmup 5 > $O/bench_driver_flags.json 2> $O/bench_driver_flags.err      # the driver's flags
+cd /tmp
+rocprofv3 --kernel-trace --stats -d $O/prof -o bench -- python $R/bench.py --no-cpu > $O/bench_profiled.json 2> $O/prof.err
+DB=$(find $O/prof -name "*.db" | head -1)
+[ -n "$DB" ] && python $R/profiles/summarize_rocpd.py $DB $O/bench_kernel_stats.txt > /dev/null 2>&1
+# the node API: HIP-API trace at two stream lengths (8 and 32 blocks of 1024 frames per pass): what is called per block
+python - <<PY
+import numpy as np, sys
+sys.path.insert(0, "$R")
+from bench_util import design_prototype
+np.concatenate([design_prototype(512, 4), design_prototype(512, 4, "g")]).astype(np.float64).tofile("/tmp/c512.f64")
+PY
+B=$R/distant_speech_recognition_amd/host/examples/node_api_bench
+for F in 8192 32768; do
+  rocprofv3 --hip-trace --stats --output-format csv -d $O/hip_$F -o t -- $B /tmp/c512.f64 512 4 1 64 $F 1 1024 0 > $O/hip_$F.json 2> $O/hip_$F.err
+done
+for t in 1 2 4 8; do BTK_NODE_THREADS=$t $B /tmp/c512.f64 512 4 1 64 8192 1 8192 0; done > $O/node_api_threads.txt 2>&1
+cd $R
+python bench_stages.py > $O/bench_stages.json 2> $O/bench_stages.err
+python bench_configs.py > $O/bench_configs.json 2> $O/bench_configs.err
+python bench_bin_sharded.py > $O/bench_bin_sharded.json 2> $O/bench_bin_sharded.err
+python profiles/partition_probe.py > $O/partition_probe.txt 2>/dev/null
+python profiles/wpe_envelope_probe.py 2>/dev/null | tail -1 > $O/wpe_envelope.txt
+BTK_WPE_LAGPROD_F32=1 python profiles/wpe_envelope_probe.py 2>/dev/null | tail -1 >> $O/wpe_envelope.txt
+WPE_S=2 bash profiles/scripts/r02_wpe_profile.sh > $O/wpe_profile.txt 2>&1
+python profiles/fused_big_ab.py > $O/fused_big_ab.txt 2>/dev/null
+tail -1 $O/smoke.log; ls $O
