@@ -43,6 +43,10 @@ def test_c0_full_launch_properties(dev):
     parts = [afb.analysis_beamform(pcm, W, t0=a, tcount=min(1000, T - a)) for a in range(0, T, 1000)]
     assert torch.equal(torch.cat(parts, dim=-1), Yf)
     assert abs(sum(float(p.abs().double().sum()) for p in parts) - float(Yf.abs().double().sum())) <= 1e-9 * float(Yf.abs().double().sum())
+    # 5b. the int16 entry at the full launch: the same samples as 16-bit PCM -> the same bits (btk_fb_analysis_bf_i16)
+    Yi = afb.analysis_beamform(pcm.to(torch.int16), W)
+    assert torch.equal(Yi.contiguous().view(torch.float32).view(torch.int32), Yf.contiguous().view(torch.float32).view(torch.int32))
+    del Yi
     # 6. synthesis blocks: number and stream independence
     assert o1.shape == (S, sfb.num_blocks(T) * D)
     assert torch.equal(sfb.synthesize(Yf[3:4].contiguous()), o1[3:4])
