@@ -38,6 +38,14 @@ const btk_switches_t& btk_switches();
 
 static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
+// Two consecutive 16-bit PCM samples as two floats, converted by the LOAD: a typed buffer load (buffer_load_format_xy) through a
+// resource whose descriptor says DATA_FORMAT 16_16, NUM_FORMAT SSCALED -- signed integers delivered as their float values, exact.
+// hipcc has no builtin for the format loads; the LLVM intrinsic is reached by its name (the compiler keeps track of the load like
+// of any other: no hand-written waits).  Descriptor word 3 for __builtin_amdgcn_make_buffer_rsrc: dst_sel x = R, y = G, SSCALED, 16_16.
+typedef float btk_f2v __attribute__((ext_vector_type(2)));
+__device__ btk_f2v btk_buffer_load_i16x2_f32(__amdgpu_buffer_rsrc_t rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.ptr.buffer.load.format.v2f32");
+constexpr int BTK_RSRC_I16X2_SSCALED = 0x0002B02C;
+
 // fb_analysis512.hip: specialised analysis kernel (M=512, m=4); returns 1 handled / 0 not covered / <0 error
 int btk_analysis512_try(const btk_fb* fb, const float* pcm, long nsamples, long pcm_stride, int S, int N, void* X,
                         long T_stride, long t0, long tcount, hipStream_t st);

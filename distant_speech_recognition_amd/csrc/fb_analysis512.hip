@@ -448,7 +448,6 @@ void analysis512_bfz_kernel(const PT* __restrict__ pcm, long nsamples, long pcm_
   // loads; no edge-path load can be pending in it) and edge tiles (register staging through the span region, guarded
   // loads, compiler-managed waits).  One loop with a runtime branch let hipcc hoist edge-path loads above the branch.
   float2 win[NWG];                            // polyphase window of the channel about to be transformed (GW: loaded a channel ahead)
-  unsigned wraw[I16 ? NWG : 1];               // int16 samples: the window as it was loaded, two samples per word
   auto channels = [&](auto fast) {
   constexpr bool FAST = decltype(fast)::value;
   constexpr bool GWF = GW && FAST;            // edge tiles of the GW form stage the span through the frame region (see below)
@@ -459,9 +458,16 @@ void analysis512_bfz_kernel(const PT* __restrict__ pcm, long nsamples, long pcm_
   auto wload = [&](float2 (&win)[NWG], int n) {
     const PT* wsrc = pcm + ((long)s * N + n) * pcm_stride + g0 + (A_M - 2 - 2 * n0 - (G - 1) * (A_M / G)) + fg * FPT * D;
     if constexpr (I16) {
-      // 15 four-byte loads (256 contiguous bytes per wave-instruction); widened when the channel's turn comes (top of the body)
+      // 15 four-byte TYPED buffer loads (256 contiguous bytes per wave-instruction): the load unit delivers the two samples as
+      // floats (btk_internal.h), so the loop has not one instruction more than the float kernel's -- and moves half its bytes.
+      // (A first form loaded the words raw and widened them with 30 v_cvt_f32_i32 per lane and channel: 7 % SLOWER than the float
+      // kernel although it drew 350 W less, profiles/r06_fused_i16_forms.txt: the vector ALU is the co-limiter.)
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<PT*>(pcm + ((long)s * N + n) * pcm_stride + g0), 0, 0x7fffffff,
+                                                                          BTK_RSRC_I16X2_SSCALED);
+      const int vo = ((A_M - 2 - 2 * n0 - (G - 1) * (A_M / G)) + fg * FPT * D) * 2;
 #pragma unroll
-      for (int i = 0; i < NWG; i++) wraw[i] = *reinterpret_cast<const unsigned*>(wsrc + i * D);
+      for (int i = 0; i < NWG; i++) { const btk_f2v t = btk_buffer_load_i16x2_f32(rs, vo, i * D * 2, 0); win[i] = make_float2(t.x, t.y); }
+      (void)wsrc;
     } else {
 #pragma unroll
       for (int i = 0; i < NWG; i++) win[i] = *reinterpret_cast<const float2*>(wsrc + i * D);
@@ -495,12 +501,6 @@ void analysis512_bfz_kernel(const PT* __restrict__ pcm, long nsamples, long pcm_
     // ---- phase 1: registers -> LDS (PCM span + weight pairs)
     if (SHARED) stage(PIPE ? (n & 1) : 0);
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // the LDS-DMA of channel n (and, GW, its window) has landed
-    if constexpr (I16 && GWF) {
-      // v_cvt_f32_i32 with sign-extended word selects: exact, so the float path's bits follow (30 conversions per lane and
-      // channel, in front of the barrier: they are not part of the stage the other wavefronts wait for)
-#pragma unroll
-      for (int i = 0; i < NWG; i++) win[i] = make_float2((float)(short)(wraw[i] & 0xffff), (float)((int)wraw[i] >> 16));
-    }
     mark(1);                                                         // wait for memory
     if constexpr (ABL != 5) __syncthreads();
     mark(2);                                                         // barrier A

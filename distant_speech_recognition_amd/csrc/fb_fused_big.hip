@@ -185,7 +185,6 @@ void analysis_bfz_big_kernel(const PT* __restrict__ pcm, long nsamples, long pcm
   float2 accN = make_float2(0.f, 0.f);
 
   float2 win[NWG];
-  unsigned wraw[I16 ? NWG : 1];                                              // int16 samples: the rows as loaded, two samples per word
   f4 wpre[NWP];
   // window rows of channel n: interior tiles take them unguarded (the loop of an interior tile holds no bounds test)
   auto wload = [&](int n, auto fast) {
@@ -193,12 +192,14 @@ void analysis_bfz_big_kernel(const PT* __restrict__ pcm, long nsamples, long pcm
     if constexpr (decltype(fast)::value) {
       // buffer loads: the channel's row base is a scalar resource, the row a scalar offset, the thread's part one 32-bit register --
       // no vector address arithmetic per load (plain pointers cost the loop 32 v_add_co / v_addc per channel)
-      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<PT*>(src + g0), 0, 0x7fffffff, 0x00020000);
+      // (int16: a TYPED resource -- 16_16 SSCALED -- whose loads deliver the two samples as floats: btk_internal.h)
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<PT*>(src + g0), 0, 0x7fffffff, I16 ? BTK_RSRC_I16X2_SSCALED : 0x00020000);
       const unsigned vo = (unsigned)woff * (unsigned)sizeof(PT);             // woff >= 0: M / 2 - 2 - 2 n0, n0 < M / 4
 #pragma unroll
       for (int i = 0; i < NWG; i++) {
         if constexpr (I16) {
-          wraw[i] = __builtin_amdgcn_raw_buffer_load_b32(rs, vo, i * D * 2, 0);    // widened when the channel's turn comes
+          const btk_f2v t = btk_buffer_load_i16x2_f32(rs, (int)vo, i * D * 2, 0);
+          win[i] = make_float2(t.x, t.y);
         } else {
           const u2 t = __builtin_amdgcn_raw_buffer_load_b64(rs, vo, i * D * 4, 0);
           win[i] = make_float2(__uint_as_float(t.x), __uint_as_float(t.y));
@@ -236,11 +237,6 @@ void analysis_bfz_big_kernel(const PT* __restrict__ pcm, long nsamples, long pcm
     if (nbeg < nend) { wload(nbeg, fast); wfetch(nbeg); wstage(0); }
     for (int n = nbeg; n < nend; n++) {
       const int wbuf = (n - nbeg) & 1;
-      if constexpr (I16 && decltype(fast)::value) {
-        // v_cvt_f32_i32 with sign-extended word selects: exact, so the float kernel's bits follow; in front of barrier A
-#pragma unroll
-        for (int i = 0; i < NWG; i++) win[i] = make_float2((float)(short)(wraw[i] & 0xffff), (float)((int)wraw[i] >> 16));
-      }
 #if !defined(BTK_BIG_ABLATE) || !(BTK_BIG_ABLATE & 3)                        // ablation builds (profiles/; results WRONG by design): 1 = no barriers in the channel loop, 2 = no barrier A
       __syncthreads();                                                       // A: frames and weight buffer of channel n - 1 are consumed
 #endif
