@@ -160,6 +160,13 @@ class SubbandBeamformer : public VectorComplexFeatureStream {
   void plan_bank_block(BlockPlan& p);
   void commit_bank_block(const BlockPlan& p);
   OverSampledDFTAnalysisBank* bank(unsigned c) { return banks_[c]; }
+  // 16-bit streaming (modulated/modulated.h): at the start of a stream, when every bank's source holds 16-bit PCM, the node
+  // switches its banks to it -- the block's samples then go up as int16 [N][pitch] and are widened on the device, inside the
+  // fused kernel where it has an int16 entry (btk_fb_analysis_bf_i16), by btk_pcm_i16_to_f32 for every other consumer.
+  // BTK_NODE_I16=0 in the environment keeps the float path (the two give the same bits: tests/test_gpu_node_i16.py).
+  bool i16_stream_possible();
+  void begin_i16_stream();
+  bool i16_stream() const { return pcm_i16_; }
  protected:
   bool load_chunk_();
   void pull_bank_(size_t c);
@@ -182,7 +189,10 @@ class SubbandBeamformer : public VectorComplexFeatureStream {
   std::vector<float> Xhost_;      // lazily fetched host copy for snapshot_array()
   std::vector<OverSampledDFTAnalysisBank*> banks_;   // the channels as analysis banks (banks_only_)
   bool banks_only_;
-  DeviceBuffer dPcmBuf_, dXBuf_, dXfullBuf_;
+  DeviceBuffer dPcmBuf_, dPcm16Buf_, dXBuf_, dXfullBuf_;
+  const float* pcm_f32_();        // the resident windows as float32 [N][pcm_pitch_] (widened once per block in a 16-bit stream)
+  bool pcm_i16_, pcm_f32_valid_;  // the current stream's samples are resident as int16 (dPcm16Buf_); dPcmBuf_ holds their float copy
+  long pcm_pitch_;                // samples between the rows of the resident windows
   PinnedBuffer hStage_;           // channels that are pulled frame by frame: the transposed block on its way up
   long pcm_L_, pcm_t0_;           // the resident PCM windows [N][pcm_L_]; stream frame chunk_base_ is frame pcm_t0_ of the window
   bool pcm_valid_, snap_valid_, snapshots_wanted_;
@@ -425,6 +435,7 @@ class SubbandGraphPool : public Countable {
   std::vector<Graph> graphs_;
   long rounds_, base_, prev_T_, prev_Lw_, prev_Lp_, prev_hist_, blk_base_, out_stride_;
   bool first_round_;
+  bool i16_;                      // the current streams go up as 16-bit PCM (every graph's sources hold it; decided in the first round)
   DeviceBuffer dPcm_, dW_, dWinA_, dWinB_, dOut_, dScratch_;
   PinnedBuffer hW_, hOut_;
 };

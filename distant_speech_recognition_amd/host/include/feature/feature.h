@@ -6,6 +6,7 @@
 #pragma once
 #include <vector>
 #include "stream/stream.h"
+#include "common/devmem.h"
 
 namespace sndfile {      // the two libsndfile constants callers of write() spell out (sndfile.h values)
 enum { SF_FORMAT_WAV = 0x010000, SF_FORMAT_PCM_16 = 0x0002 };
@@ -43,6 +44,19 @@ class SampleFeature : public VectorFloatFeatureStream {
   // engine hook: up to nmax consecutive next() calls at once, the blocks stored back to back in dst (nmax * size() floats);
   // returns how many there were -- fewer than nmax: the stream has ended exactly as the throwing next() would have ended it
   long next_blocks(float* dst, long nmax);
+  // engine hooks (round 6): the utterance AS 16-BIT PCM.  A WAV holds int16 samples and read() with norm == 0 hands them out as
+  // un-normalised floats (feature/feature.cc:265-269), so an analysis bank on the device may take the samples as they were stored:
+  // half the bytes through host memory and PCIe, and -- the widening is exact -- the same bits out of the filter bank.
+  // pcm16(): the loaded samples as int16 in pinned memory, zero-padded by at least two blocks behind the last sample; NULL when a
+  // sample is not an integer of the int16 range (normalised reads, randomize(), noise that overflowed) or blocks overlap
+  // (shiftLen != blockLen).  Built when first asked for after the samples changed; stays where it is until they change again.
+  const short* pcm16();
+  // the state transitions of up to nmax next() calls WITHOUT the copies (the caller reads the blocks out of pcm16()): returns how
+  // many there were and the sample index the first of them starts at; fewer than nmax: the stream has ended as next() ends it
+  long advance_blocks(long nmax, size_t* first_sample);
+  unsigned shiftlen() const { return shiftLen_; }
+  // counts the changes of the samples (a reader that keeps the pcm16() pointer compares it before every use)
+  unsigned long samples_generation() const { return samples_gen_; }
  private:
   SampleFeature(const SampleFeature&);
   SampleFeature& operator=(const SampleFeature&);
@@ -55,4 +69,8 @@ class SampleFeature : public VectorFloatFeatureStream {
   int samplerate_, nChan_, format_;
   gsl_vector_float* copy_fsamples_;
   gsl_vector* copy_dsamples_;
+  PinnedBuffer pcm16_;           // int16 shadow of samples_ (pcm16())
+  int pcm16_state_;              // 0: not built for the current samples, 1: valid, -1: the samples are not 16-bit PCM
+  unsigned long samples_gen_;
+  void samples_changed_() { pcm16_state_ = 0; samples_gen_++; }
 };

@@ -63,6 +63,14 @@ class OverSampledDFTAnalysisBank : public VectorComplexFeatureStream {
   const float* window(long b0) const { return static_cast<const float*>(win_.get()) + (size_t)(b0 - win_b0_) * D_; }   // samples of blocks b0 .. blocks_pulled() - 1 (pinned host memory)
   long first_block_of_frame(long t) const;              // oldest input block frame t reads (>= 0)
   void release_before(long t);                          // frames < t are done: drop the samples only they needed
+  // 16-bit streaming (round 6): when the source is a SampleFeature that holds 16-bit PCM (SampleFeature::pcm16), a beamformer
+  // node may switch the bank -- at the start of a stream, before the first pull -- to reading the utterance where it lies: a
+  // round then moves no samples on the host at all (pull_more() only advances the source's state), window16() points into the
+  // source's pinned int16 copy, nothing is ever released, and the node uploads 2 bytes per sample.  reset() ends the mode.
+  bool i16_source_ok() const;                           // ... and nothing has been pulled yet
+  void begin_i16();
+  bool i16_mode() const { return src16_ != NULL; }
+  const short* window16(long b0) const { return src16_ + src16_pos0_ + (size_t)b0 * D_; }
   const btk_fb_t* plan() const { return plan_; }
   unsigned delay_compensation_type() const { return dct_; }
   unsigned m() const { return m_; }
@@ -72,6 +80,9 @@ class OverSampledDFTAnalysisBank : public VectorComplexFeatureStream {
   VectorFloatFeatureStreamPtr samp_;
   unsigned M_, m_, r_, D_, dct_;
   btk_fb_t* plan_;
+  const short* src16_;                                  // 16-bit mode: the source's int16 samples; block b of the stream starts at
+  size_t src16_pos0_;                                   //   src16_[src16_pos0_ + b D]
+  unsigned long src16_gen_;                             //   (the source's samples_generation() when the stream began)
   long block_frames_;
   void append_(const float* blocks, long n);            // n more input blocks into the window
   PinnedBuffer win_;                                    // samples of input blocks win_b0_ .. nblk_ - 1 (pinned: uploaded as they lie)

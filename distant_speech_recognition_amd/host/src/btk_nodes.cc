@@ -280,7 +280,7 @@ void PinnedBuffer::release() { if (p_) (void)hipHostFree(p_); p_ = NULL; cap_ = 
 SampleFeature::SampleFeature(const String& fn, unsigned blockLen, unsigned shiftLen, bool padZeros, const String& nm)
     : VectorFloatFeatureStream(blockLen, nm), have_samples_(false), norm_(0.0f), shiftLen_(shiftLen), cur_(0),
       pad_zeros_(padZeros), samplerate_(0), nChan_(1), format_(sndfile::SF_FORMAT_WAV | sndfile::SF_FORMAT_PCM_16),
-      copy_fsamples_(NULL), copy_dsamples_(NULL)
+      copy_fsamples_(NULL), copy_dsamples_(NULL), pcm16_state_(0), samples_gen_(0)
 {
   if (fn != "") read(fn);
   is_end_ = false;
@@ -379,6 +379,34 @@ void SampleFeature::set_samples(const float* samples, size_t n)
   cur_ = 0;
   reset();
   is_end_ = false;
+  samples_changed_();
+  (void)pcm16();                       // load time, like read(): the 16-bit view of the utterance (a WAV is 16-bit PCM to begin with)
+}
+
+// The loaded samples as 16-bit PCM (feature/feature.h): every sample must be an integer of the int16 range for the filter bank
+// to see the same values either way.  (-0.0f counts as 0: a WAV read never produces it, numpy.rint does.  The only trace it could
+// leave is the SIGN of an exactly-zero polyphase sum -- all m samples of a tap column zero and at least one of them -0.0f.)
+const short* SampleFeature::pcm16()
+{
+  const size_t sz = size();
+  if (!have_samples_ || samples_.empty() || shiftLen_ != sz || sz == 0) return NULL;
+  if (pcm16_state_ == 0) {
+    const size_t n = samples_.size(), padded = (n / sz + 3) * sz;
+    short* q = NULL;
+    try { q = static_cast<short*>(pcm16_.ensure(sizeof(short) * padded)); } catch (j_error&) { q = NULL; }
+    if (!q) { pcm16_state_ = -1; return NULL; }              // no pinned memory (a host without a device): the float path remains
+    const float* x = samples_.data();
+    unsigned bad = 0;
+    for (size_t i = 0; i < n; i++) {
+      const float v = x[i], c = fminf(fmaxf(v, -32768.0f), 32767.0f);
+      const int iv = (int)c;
+      bad |= (unsigned)((float)iv != v);
+      q[i] = (short)iv;
+    }
+    memset(q + n, 0, sizeof(short) * (padded - n));
+    pcm16_state_ = bad ? -1 : 1;
+  }
+  return pcm16_state_ == 1 ? static_cast<const short*>(pcm16_.get()) : NULL;
 }
 
 void SampleFeature::setSamples(const gsl_vector* samples, unsigned sampleRate)      // feature.cc:669-679
@@ -387,6 +415,7 @@ void SampleFeature::setSamples(const gsl_vector* samples, unsigned sampleRate)  
   samples_.resize(samples->size);
   for (size_t i = 0; i < samples->size; i++) samples_[i] = (float)gsl_vector_get(samples, i);
   have_samples_ = true;
+  samples_changed_();
   reset();
 }
 
@@ -404,6 +433,7 @@ void SampleFeature::copySamples(SampleFeaturePtr& src, unsigned cfrom, unsigned 
   std::vector<float> tmp(src->samples_.begin() + cfrom, src->samples_.begin() + cfrom + n);
   samples_.swap(tmp);
   have_samples_ = true;
+  samples_changed_();
 }
 
 const gsl_vector_float* SampleFeature::data()
@@ -432,6 +462,7 @@ void SampleFeature::zeroMean()                                       // feature.
     const double x = samples_[i] - mean;
     samples_[i] = (float)(int)(x < -32768.0 ? -32768.0 : (x < 32767.0 ? x : 32767.0));
   }
+  samples_changed_();
 }
 
 void SampleFeature::cut(unsigned cfrom, unsigned cto)                // feature.cc:572-586 (both bounds inclusive)
@@ -440,6 +471,7 @@ void SampleFeature::cut(unsigned cfrom, unsigned cto)                // feature.
   if (cto >= samples_.size()) throw j_error("Do not have enough samples (%d,%d).", cto, (int)samples_.size());
   std::vector<float> tmp(samples_.begin() + cfrom, samples_.begin() + cto + 1);
   samples_.swap(tmp);
+  samples_changed_();
 }
 
 // feature.cc:589-603: gsl_rng_default (mt19937, default seed: GSL turns seed 0 into 4357) and gsl_ran_gaussian (polar
@@ -471,6 +503,7 @@ void SampleFeature::randomize(int startX, int endX, double sigma2)
     do { x = -1 + 2 * uniform(); y = -1 + 2 * uniform(); r2 = x * x + y * y; } while (r2 > 1.0 || r2 == 0);
     samples_[(size_t)n] = (float)(sigma2 * y * sqrt(-2.0 * log(r2) / r2));
   }
+  samples_changed_();
 }
 
 // feature.cc:391-427, literally: the noise is drawn into SHORT integers (rand() truncated, then (x / max - 0.5) truncated
@@ -491,6 +524,7 @@ void SampleFeature::addWhiteNoise(float snr)
   const double desiredNoA = avgSig / pow(10.0, snr / 20.0);
   for (size_t i = 0; i < n; i++) noise[i] = (short)(desiredNoA * noise[i] / avgNoi);
   for (size_t i = 0; i < n; i++) samples_[i] += noise[i];
+  samples_changed_();
 }
 
 const gsl_vector_float* SampleFeature::next(int frame_no)
@@ -548,6 +582,31 @@ long SampleFeature::next_blocks(float* dst, long nmax)
   return n;
 }
 
+// next() nmax times in a row without handing the blocks out: the caller (an analysis bank that uploads the utterance as 16-bit
+// PCM) reads them from pcm16() -- block j of this call is the samples first_sample + j shiftLen ... of it, the zero padding of
+// the last block included.  State transitions as in next_blocks(); vector_ holds the last block, as after next().
+long SampleFeature::advance_blocks(long nmax, size_t* first_sample)
+{
+  long n = 0;
+  const unsigned sz = size();
+  const short* q = pcm16();
+  if (!q && !is_end_ && have_samples_ && !samples_.empty())
+    throw jconsistency_error("SampleFeature %s: advance_blocks() without a 16-bit view of the samples\n", name().c_str());
+  if (first_sample) *first_sample = cur_;
+  size_t last = 0;
+  while (n < nmax) {
+    if (is_end_) break;
+    const size_t ttl = samples_.size();
+    if (!have_samples_ || cur_ >= ttl || (cur_ + sz >= ttl && !pad_zeros_)) { is_end_ = true; have_samples_ = false; samples_.clear(); break; }
+    last = cur_;
+    cur_ += shiftLen_;
+    increment_();
+    n++;
+  }
+  if (n > 0 && q) for (unsigned i = 0; i < sz; i++) vector_->data[i] = (float)q[last + i];
+  return n;
+}
+
 // ================================================================================ analysis bank
 long btk_default_block_frames()
 {
@@ -560,7 +619,8 @@ long btk_default_block_frames()
 OverSampledDFTAnalysisBank::OverSampledDFTAnalysisBank(VectorFloatFeatureStreamPtr& samp, gsl_vector* prototype, unsigned M,
                                                        unsigned m, unsigned r, unsigned delayCompensationType, const String& nm)
     : VectorComplexFeatureStream(M, nm), samp_(samp), M_(M), m_(m), r_(r), D_(M >> r), dct_(delayCompensationType),
-      plan_(NULL), block_frames_(btk_default_block_frames()), win_b0_(0), nblk_(0), eos_(false), chunk_base_(0), chunk_len_(0)
+      plan_(NULL), src16_(NULL), src16_pos0_(0), src16_gen_(0), block_frames_(btk_default_block_frames()), win_b0_(0), nblk_(0), eos_(false),
+      chunk_base_(0), chunk_len_(0)
 {
   if (prototype->size != (size_t)M * m)
     throw jconsistency_error("Prototype sizes do not match (%d vs. %d).", (int)prototype->size, (int)(M * m));
@@ -593,7 +653,24 @@ void OverSampledDFTAnalysisBank::reserve_round()
 // shares, and a beamformer node may run the pull_more() of several of its banks side by side (PullPool)
 bool OverSampledDFTAnalysisBank::parallel_pull_ok() const
 {
-  return block_frames_ > 0 && dynamic_cast<SampleFeature*>(samp_.operator->()) != NULL;
+  return block_frames_ > 0 && !src16_ && dynamic_cast<SampleFeature*>(samp_.operator->()) != NULL;
+}
+
+bool OverSampledDFTAnalysisBank::i16_source_ok() const
+{
+  SampleFeature* sf = dynamic_cast<SampleFeature*>(samp_.operator->());
+  return sf && nblk_ == 0 && !eos_ && sf->size() == D_ && sf->shiftlen() == D_ && sf->pcm16() != NULL;
+}
+
+void OverSampledDFTAnalysisBank::begin_i16()
+{
+  SampleFeature* sf = dynamic_cast<SampleFeature*>(samp_.operator->());
+  if (!i16_source_ok()) throw jconsistency_error("OverSampledDFTAnalysisBank %s: the source holds no 16-bit PCM\n", name().c_str());
+  src16_ = sf->pcm16();
+  size_t pos = 0;
+  (void)sf->advance_blocks(0, &pos);                    // where the source stands: block 0 of this stream
+  src16_pos0_ = pos;
+  src16_gen_ = sf->samples_generation();
 }
 
 // one round of input: at most block_frames() blocks of D samples from the upstream node (modulated.cc:419-438 pulls one per frame)
@@ -601,8 +678,23 @@ bool OverSampledDFTAnalysisBank::pull_more()
 {
   if (eos_) return false;
   long got = 0;
-  reserve_round();
   SampleFeature* sf = dynamic_cast<SampleFeature*>(samp_.operator->());
+  if (src16_) {
+    // 16-bit mode: the blocks stay where they are (SampleFeature::pcm16); the source only moves on
+    for (;;) {
+      const long ask = block_frames_ == 0 ? (1L << 20) : block_frames_ - got;
+      if (ask <= 0) break;
+      size_t pos = 0;
+      const long n = sf->advance_blocks(ask, &pos);
+      if (n > 0 && (pos != src16_pos0_ + (size_t)nblk_ * D_ || sf->samples_generation() != src16_gen_))
+        throw jconsistency_error("OverSampledDFTAnalysisBank %s: the source was moved or its samples changed while the bank streamed "
+                                 "them as 16-bit PCM; reset() the graph after changing an utterance\n", name().c_str());
+      nblk_ += n; got += n;
+      if (n < ask) { eos_ = true; break; }
+    }
+    return got > 0;
+  }
+  reserve_round();
   if (sf && sf->size() == D_) {
     // a SampleFeature hands its blocks over in bulk, straight into the window (SampleFeature::next_blocks == the loop below)
     for (;;) {
@@ -642,6 +734,7 @@ long OverSampledDFTAnalysisBank::first_block_of_frame(long t) const
 
 void OverSampledDFTAnalysisBank::release_before(long t)
 {
+  if (src16_) return;                                   // the utterance stays with its source
   const long keep = std::min(first_block_of_frame(t), nblk_);
   if (keep > win_b0_) {
     float* w = static_cast<float*>(win_.get());
@@ -658,6 +751,9 @@ bool OverSampledDFTAnalysisBank::load_chunk_()
   while (!eos_ && frames_ready() <= f0) pull_more();
   const long f1 = frames_ready();
   if (f1 <= f0) return false;
+  if (src16_)
+    throw jconsistency_error("OverSampledDFTAnalysisBank %s is a channel of a beamformer node that streams it as 16-bit PCM; pull the "
+                             "bank through the beamformer or on its own, not both\n", name().c_str());
   // a bank is either a channel of a beamformer node (which releases the samples its blocks are done with) or pulled frame by
   // frame; both at once would find the window already cut -- frames computed as if the stream began later: refuse instead
   if (win_b0_ > first_block_of_frame(f0))
@@ -701,6 +797,7 @@ void OverSampledDFTAnalysisBank::reset()
   samp_->reset();
   VectorComplexFeatureStream::reset();
   win_b0_ = 0; nblk_ = 0; eos_ = false; frames_.clear(); chunk_base_ = 0; chunk_len_ = 0;
+  src16_ = NULL; src16_pos0_ = 0;
 }
 
 // ================================================================================ synthesis bank
@@ -1255,7 +1352,8 @@ void BeamformerWeights::calcSidelobeCancellerP_f(unsigned fbinX, const gsl_vecto
 SubbandBeamformer::SubbandBeamformer(unsigned fftLen, bool halfBandShift, const String& nm)
     : VectorComplexFeatureStream(fftLen, nm), chunk_base_(0), block_frames_(btk_default_block_frames()), chunk_loaded_(false),
       channels_ended_(false), quantum_(1), halfBandShift_(halfBandShift), dXfull_(NULL), snapshot_array_(NULL), fftLen_(fftLen),
-      fftLen2_(fftLen / 2), dX_(NULL), T_(0), banks_only_(false), pcm_L_(0), pcm_t0_(0), pcm_valid_(false), snap_valid_(false),
+      fftLen2_(fftLen / 2), dX_(NULL), T_(0), banks_only_(false), pcm_i16_(false), pcm_f32_valid_(false), pcm_pitch_(0),
+      pcm_L_(0), pcm_t0_(0), pcm_valid_(false), snap_valid_(false),
       snapshots_wanted_(false) {}
 SubbandBeamformer::~SubbandBeamformer() {}
 // the block state starts over; the device buffers stay (they only ever grow: common/devmem.h)
@@ -1263,6 +1361,7 @@ void SubbandBeamformer::free_device_()
 {
   dX_ = NULL; dXfull_ = NULL; T_ = 0; Xhost_.clear();
   chunk_base_ = 0; chunk_loaded_ = false; channels_ended_ = false; pcm_valid_ = false; snap_valid_ = false; pcm_L_ = 0; pcm_t0_ = 0;
+  pcm_i16_ = false; pcm_f32_valid_ = false; pcm_pitch_ = 0;
 }
 void SubbandBeamformer::set_channel(VectorComplexFeatureStreamPtr& chan) { channelList_.push_back(chan); }
 void SubbandBeamformer::clear_channel() { channelList_.clear(); banks_.clear(); banks_only_ = false; snapshot_array_ = NULL; free_device_(); }
@@ -1296,12 +1395,42 @@ void* SubbandBeamformer::snapshots_()
       if (!pcm_valid_) throw jconsistency_error("SubbandBeamformer %s: the samples of the current block are gone\n", name().c_str());
       // the windows start at input block b0: stream frame t is frame t - b0 of the window (csrc/fb_kernels.hip: frame t ends at
       // sample (t + laN + 1) D - 1), and no frame of this block reads a sample before it
-      check_abi(btk_fb_analysis(banks_[0]->plan(), static_cast<const float*>(dPcmBuf_.get()), pcm_L_, pcm_L_ ? pcm_L_ : 1, 1, (int)N, dX_, T_,
-                                pcm_t0_, T_, nstream()));
+      check_abi(btk_fb_analysis(banks_[0]->plan(), pcm_f32_(), pcm_L_, pcm_pitch_ ? pcm_pitch_ : 1, 1, (int)N, dX_, T_, pcm_t0_, T_, nstream()));
     }
     snap_valid_ = true;
   }
   return dX_;
+}
+
+const float* SubbandBeamformer::pcm_f32_()
+{
+  if (!pcm_i16_) return static_cast<const float*>(dPcmBuf_.get());
+  const size_t n = (size_t)chanN() * (size_t)(pcm_pitch_ ? pcm_pitch_ : 1);
+  float* d = static_cast<float*>(dPcmBuf_.ensure(sizeof(float) * n));
+  if (!pcm_f32_valid_) {
+    check_abi(btk_pcm_i16_to_f32(static_cast<const short*>(dPcm16Buf_.get()), d, (long)n, nstream()));
+    pcm_f32_valid_ = true;
+  }
+  return d;
+}
+
+static bool node_i16_enabled()
+{
+  const char* e = getenv("BTK_NODE_I16");
+  return !(e && *e == '0');
+}
+
+bool SubbandBeamformer::i16_stream_possible()
+{
+  if (chunk_loaded_ || !node_i16_enabled() || !banks_only()) return false;
+  for (size_t c = 0; c < banks_.size(); c++) if (!banks_[c]->i16_source_ok()) return false;
+  return true;
+}
+
+void SubbandBeamformer::begin_i16_stream()
+{
+  for (size_t c = 0; c < banks_.size(); c++) banks_[c]->begin_i16();
+  pcm_i16_ = true;
 }
 
 void* SubbandBeamformer::device_snapshots()
@@ -1396,31 +1525,42 @@ bool SubbandBeamformer::load_chunk_()
     // channel has pulled its input, under the pulling of the next ones: the first bank says what the block will be, and only
     // if a later channel turns out shorter (the end of a stream with ragged channels) the copies are made again.
     BlockPlan p, p0;
-    float* dp = NULL;
+    char* dp = NULL;
+    if (!chunk_loaded_ && !pcm_i16_ && i16_stream_possible()) begin_i16_stream();     // a stream begins: 16-bit PCM if every source has it
+    // (16-bit streams: rows of int16 a multiple of 16 bytes apart, straight out of the sources' pinned copies -- nothing to pull)
+    const size_t es = pcm_i16_ ? sizeof(short) : sizeof(float);
+    DeviceBuffer& dbuf = pcm_i16_ ? dPcm16Buf_ : dPcmBuf_;
+    auto pitch_of = [&](long L) { return pcm_i16_ ? (L + 7) / 8 * 8 : L; };
+    auto row = [&](unsigned c, long b0) {
+      return pcm_i16_ ? static_cast<const void*>(banks_[c]->window16(b0)) : static_cast<const void*>(banks_[c]->window(b0));
+    };
     // (groups of as many banks as there are helper threads pull side by side; a group's copies start when the group is done)
     const unsigned G = (unsigned)std::max(1, PullPool::get().threads());
     pull_banks_(0, std::min(G, N));
     plan_from_pulled_(p0, 1);
-    if (p0.T > 0) dp = static_cast<float*>(dPcmBuf_.ensure(sizeof(float) * N * (p0.L ? p0.L : 1)));
+    const long pitch0 = pitch_of(p0.L);
+    if (p0.T > 0) dp = static_cast<char*>(dbuf.ensure(es * N * (pitch0 ? pitch0 : 8)));
     for (unsigned g0 = 0; g0 < N; g0 += G) {
       const unsigned g1 = std::min(g0 + G, N);
       if (g0 > 0) pull_banks_(g0, g1);
       for (unsigned c = g0; c < g1; c++)
         if (p0.T > 0 && banks_[c]->window_first_block() <= p0.b0 && (banks_[c]->blocks_pulled() - p0.b0) * (long)banks_[c]->shiftlen() >= p0.L)
-          h2d_async(dp + (size_t)c * p0.L, banks_[c]->window(p0.b0), sizeof(float) * p0.L);
+          h2d_async(dp + es * (size_t)c * pitch0, row(c, p0.b0), es * p0.L);
     }
     plan_from_pulled_(p, N);
+    long pitch = pitch0;
     {
       ScopedNs timer(g_upload_ns);
       if (p.T > 0 && (p0.T <= 0 || p.b0 != p0.b0 || p.L != p0.L)) {
         nsync();
-        dp = static_cast<float*>(dPcmBuf_.ensure(sizeof(float) * N * (p.L ? p.L : 1)));
-        for (unsigned c = 0; c < N; c++) h2d_async(dp + (size_t)c * p.L, banks_[c]->window(p.b0), sizeof(float) * p.L);
+        pitch = pitch_of(p.L);
+        dp = static_cast<char*>(dbuf.ensure(es * N * (pitch ? pitch : 8)));
+        for (unsigned c = 0; c < N; c++) h2d_async(dp + es * (size_t)c * pitch, row(c, p.b0), es * p.L);
       }
       nsync();                                                   // before the banks move their windows on
     }
     commit_bank_block(p);
-    pcm_L_ = p.L; pcm_t0_ = p.f0 - p.b0; pcm_valid_ = p.T > 0;
+    pcm_L_ = p.L; pcm_pitch_ = pitch; pcm_t0_ = p.f0 - p.b0; pcm_valid_ = p.T > 0; pcm_f32_valid_ = false;
     if (snapshots_wanted_) snapshots_();
   } else {
     // channels of any other kind are pulled frame by frame, at most block_frames() frames per block; with halfBandShift the
@@ -1588,8 +1728,12 @@ void SubbandDS::compute_output_(long from_frame)
         // kernel: the block's samples in, the beamformed frames out
         const long sb = btk_fb_analysis_bf_scratch_bytes(banks_[0]->plan(), 1, (int)N, 0, Tn);
         void* scratch = dScratchBuf_.ensure((size_t)(sb > 0 ? sb : 16));
-        check_abi(btk_fb_analysis_bf(banks_[0]->plan(), static_cast<const float*>(dPcmBuf_.get()), pcm_L_, pcm_L_ ? pcm_L_ : 1, 1, (int)N,
-                                     dWBuf_.get(), 0, dY + 2 * from_frame, T_, pcm_t0_ + from_frame, Tn, scratch, sb, nstream()));
+        if (pcm_i16_ && btk_fb_analysis_bf_i16_fused(banks_[0]->plan()) == 1)
+          check_abi(btk_fb_analysis_bf_i16(banks_[0]->plan(), static_cast<const short*>(dPcm16Buf_.get()), pcm_L_, pcm_pitch_ ? pcm_pitch_ : 8, 1,
+                                           (int)N, dWBuf_.get(), 0, dY + 2 * from_frame, T_, pcm_t0_ + from_frame, Tn, scratch, sb, nstream()));
+        else
+          check_abi(btk_fb_analysis_bf(banks_[0]->plan(), pcm_f32_(), pcm_L_, pcm_pitch_ ? pcm_pitch_ : 1, 1, (int)N,
+                                       dWBuf_.get(), 0, dY + 2 * from_frame, T_, pcm_t0_ + from_frame, Tn, scratch, sb, nstream()));
       } else {
         // frames [from_frame, T): the frame axis offset by pointer arithmetic, strides stay T_
         const float* dX = static_cast<const float*>(snapshots_());
@@ -3109,7 +3253,7 @@ void SingleChannelWPEDereverberationFeature::next_speaker()
 
 // ================================================================================ SubbandGraphPool
 SubbandGraphPool::SubbandGraphPool()
-    : rounds_(0), base_(0), prev_T_(0), prev_Lw_(0), prev_Lp_(0), prev_hist_(0), blk_base_(0), out_stride_(0), first_round_(true) {}
+    : rounds_(0), base_(0), prev_T_(0), prev_Lw_(0), prev_Lp_(0), prev_hist_(0), blk_base_(0), out_stride_(0), first_round_(true), i16_(false) {}
 
 SubbandGraphPool::~SubbandGraphPool()
 {
@@ -3152,6 +3296,7 @@ void SubbandGraphPool::reset()
     graphs_[g].live = true; graphs_[g].T = 0; graphs_[g].nblocks = 0; graphs_[g].served = 0; graphs_[g].has_out = false;
   }
   rounds_ = 0; base_ = 0; prev_T_ = 0; prev_Lw_ = 0; prev_Lp_ = 0; prev_hist_ = 0; blk_base_ = 0; out_stride_ = 0; first_round_ = true;
+  i16_ = false;
 }
 
 // One round: every live graph's banks pull a block of input; one upload block, one fused launch, one synthesis launch.
@@ -3167,7 +3312,15 @@ bool SubbandGraphPool::load_round_()
   const long H = std::max<long>((long)s0->m() * R + R, pd);    // frames of history a round's first block reaches back to
   std::vector<SubbandBeamformer::BlockPlan> plans(G);
   long Lmax = 0, Tmax = 0, t0 = -1, f0 = -1, Lprov = 0;
-  float* dPcm = NULL;
+  char* dPcm = NULL;
+  if (first_round_) {
+    // the streams begin: 16-bit PCM if every source of every graph holds it (SampleFeature::pcm16) and the geometry has the entry
+    i16_ = btk_fb_analysis_bf_i16_fused(b0->bank(0)->plan()) == 1;
+    for (size_t g = 0; g < G && i16_; g++) i16_ = graphs_[g].bf->i16_stream_possible();
+    if (i16_) for (size_t g = 0; g < G; g++) graphs_[g].bf->begin_i16_stream();
+  }
+  const size_t es = i16_ ? sizeof(short) : sizeof(float);
+  const long q = i16_ ? 8 : 4;                                 // rows of 16 bytes
   // the sample windows of every graph go into one block [G][N][Lmax] (rows of 16 bytes for the fused kernel's vector loads, zero
   // behind a shorter -- ending -- stream).  A graph's windows start their way up as soon as its banks have pulled their input,
   // under the pulling of the next graph: the first graph says how long the rows will be, and only if a later one turns out longer
@@ -3175,10 +3328,12 @@ bool SubbandGraphPool::load_round_()
   auto upload = [&](size_t g, long pitch) {
     SubbandDS* bf = graphs_[g].bf.operator->();
     const SubbandBeamformer::BlockPlan& p = plans[g];
-    float* slice = dPcm + g * (size_t)N * pitch;
+    char* slice = dPcm + es * g * (size_t)N * pitch;
     if (p.L < pitch)
-      check_hip(hipMemset2DAsync(slice + p.L, sizeof(float) * pitch, 0, sizeof(float) * (pitch - p.L), N, nstream()), "hipMemset2DAsync");
-    for (unsigned c = 0; c < N; c++) h2d_async(slice + (size_t)c * pitch, bf->bank(c)->window(p.b0), sizeof(float) * p.L);
+      check_hip(hipMemset2DAsync(slice + es * p.L, es * pitch, 0, es * (pitch - p.L), N, nstream()), "hipMemset2DAsync");
+    for (unsigned c = 0; c < N; c++)
+      h2d_async(slice + es * (size_t)c * pitch, i16_ ? static_cast<const void*>(bf->bank(c)->window16(p.b0)) : static_cast<const void*>(bf->bank(c)->window(p.b0)),
+                es * p.L);
   };
   for (size_t g = 0; g < G; g++) {
     Graph& gr = graphs_[g];
@@ -3193,18 +3348,18 @@ bool SubbandGraphPool::load_round_()
         throw jconsistency_error("SubbandGraphPool: graph %d is at frame %ld, the others at %ld -- the graphs of a pool advance in lock step\n", (int)g, p.f0, f0);
       f0 = p.f0; t0 = p.f0 - p.b0;
       Lmax = std::max(Lmax, p.L); Tmax = std::max(Tmax, p.T);
-      if (!dPcm) { Lprov = (p.L + 3) / 4 * 4; dPcm = static_cast<float*>(dPcm_.ensure(sizeof(float) * G * N * (Lprov ? Lprov : 4))); }
+      if (!dPcm) { Lprov = (p.L + q - 1) / q * q; dPcm = static_cast<char*>(dPcm_.ensure(es * G * N * (Lprov ? Lprov : q))); }
       if (p.L <= Lprov) upload(g, Lprov);
     }
     gr.T = p.T;
     if (p.ended) gr.live = false;
   }
   if (Tmax == 0) return false;                                 // (a plan without frames is the end of its stream)
-  Lmax = (Lmax + 3) / 4 * 4;
+  Lmax = (Lmax + q - 1) / q * q;
   std::chrono::steady_clock::time_point tu0 = std::chrono::steady_clock::now();
   if (Lmax != Lprov) {
     nsync();
-    dPcm = static_cast<float*>(dPcm_.ensure(sizeof(float) * G * N * Lmax));
+    dPcm = static_cast<char*>(dPcm_.ensure(es * G * N * Lmax));
     for (size_t g = 0; g < G; g++) if (graphs_[g].T > 0) upload(g, Lmax);
   }
   // ---- per-stream weights [G][K][N], from the weight objects as they are now
@@ -3233,8 +3388,12 @@ bool SubbandGraphPool::load_round_()
   dWinA_.swap(dWinB_);
   const long sb = btk_fb_analysis_bf_scratch_bytes(b0->bank(0)->plan(), (int)G, (int)N, 1, Tmax);
   void* scratch = dScratch_.ensure((size_t)(sb > 0 ? sb : 16));
-  check_abi(btk_fb_analysis_bf(b0->bank(0)->plan(), dPcm, Lmax, Lmax, (int)G, (int)N, dW, 1, win + sizeof(float) * 2 * keep, Lp, t0, Tmax,
-                               scratch, sb, nstream()));
+  if (i16_)
+    check_abi(btk_fb_analysis_bf_i16(b0->bank(0)->plan(), reinterpret_cast<const short*>(dPcm), Lmax, Lmax, (int)G, (int)N, dW, 1,
+                                     win + sizeof(float) * 2 * keep, Lp, t0, Tmax, scratch, sb, nstream()));
+  else
+    check_abi(btk_fb_analysis_bf(b0->bank(0)->plan(), reinterpret_cast<const float*>(dPcm), Lmax, Lmax, (int)G, (int)N, dW, 1,
+                                 win + sizeof(float) * 2 * keep, Lp, t0, Tmax, scratch, sb, nstream()));
   // ---- the output blocks whose newest input frame lies in this round (block b reads the frames b + pd - (m R - 1) .. b + pd)
   const long b_first = std::max<long>(0, base_ - pd), b_end = base_ + Tmax - pd;
   const long nb = b_end > b_first ? b_end - b_first : 0;

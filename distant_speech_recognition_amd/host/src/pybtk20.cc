@@ -256,6 +256,7 @@ PYBIND11_MODULE(_btk20cpp, m)
            }, py::arg("fn"), py::arg("format") = 0, py::arg("samplerate") = 16000, py::arg("chX") = 1, py::arg("chN") = 1, py::arg("cfrom") = 0,
            py::arg("to") = -1, py::arg("outsamplerate") = -1, py::arg("norm") = 0.0f)
       .def("set_samples", [](SampleFeature& s, py::array_t<float, py::array::c_style | py::array::forcecast> a) { s.set_samples(a.data(), (size_t)a.size()); })
+      .def("holds_pcm16", [](SampleFeature& s) { return s.pcm16() != NULL; })   // every loaded sample is an integer of the int16 range
       .def("samplerate", &SampleFeature::getSampleRate)
       .def("getSampleRate", &SampleFeature::getSampleRate)
       .def("getChanN", &SampleFeature::getChanN)
@@ -360,6 +361,7 @@ PYBIND11_MODULE(_btk20cpp, m)
       .def("fftLen", &SubbandBeamformer::fftLen)
       .def("dim", &SubbandBeamformer::dim)
       .def("want_snapshots", &SubbandBeamformer::want_snapshots)   // every block from now on brings its snapshots along (staged path)
+      .def("i16_stream", &SubbandBeamformer::i16_stream)   // the current stream's samples go up as 16-bit PCM (every source holds it)
       .def("snapshots_materialised", &SubbandBeamformer::snapshots_materialised)   // the current block's snapshots exist on the device
       .def("num_frames", &SubbandBeamformer::num_frames)                 // frames of the current block of snapshots
       .def("chunk_base", &SubbandBeamformer::chunk_base)                 // stream index of its first frame
