@@ -137,8 +137,10 @@ def node_api_stage(h, g, N, M, m, r, engine_frames_per_s):
     src/beamformerDS.cc:144-223 (SampleFeature x N -> OverSampledDFTAnalysisBank x N -> SubbandGSC -> OverSampledDFTSynthesisBank)
     on in-memory utterances and pulls it block by block through next(): one graph of 8192 frames, 32 graphs one after the other
     and the same 32 graphs in a SubbandGraphPool (one S = 32 launch per round).  The binary reports where the host time goes; the
-    device work per frame is the engine's, the rest is the reference's own interface: every sample crosses SampleFeature::next()'s
-    float blocks and PCIe."""
+    device work per frame is the engine's, the rest is the reference's own interface: every sample lives in a SampleFeature in
+    host memory and crosses PCIe.  Round 6: utterances of 16-bit PCM (what a WAV read delivers) go up AS int16, from where the
+    source keeps them (SampleFeature::pcm16: no host copies, 2 B per sample, the same bits out); `float_path` repeats the runs with
+    BTK_NODE_I16=0 -- the samples through SampleFeature's float blocks, as in round 5."""
     import subprocess
     import tempfile
     exe = os.path.join(ROOT, "distant_speech_recognition_amd", "host", "examples", "node_api_bench")
@@ -150,18 +152,22 @@ def node_api_stage(h, g, N, M, m, r, engine_frames_per_s):
         np.concatenate([h, g]).astype(np.float64).tofile(f.name)
         for key, frames, graphs, block, pool in (("one_graph", 8192, 1, 8192, 0), ("graphs_32_one_by_one", 2048, 32, 1024, 0),
                                                  ("graph_pool_32", 2048, 32, 1024, 1)):
-            try:
-                res = subprocess.run([exe, f.name, str(M), str(m), str(r), str(N), str(frames), str(graphs), str(block), str(pool)],
-                                     capture_output=True, text=True, timeout=600)
-                if res.returncode != 0:
-                    out[key] = {"error": res.stderr.strip()[-300:]}
-                    continue
-                j = json.loads(res.stdout.strip().splitlines()[-1])
-                j["xRT"] = j["frames_per_s"] / (FS / (M >> r))
-                j["fraction_of_engine_rate"] = j["frames_per_s"] / engine_frames_per_s
-                out[key] = j
-            except (OSError, ValueError, subprocess.TimeoutExpired) as e:
-                out[key] = {"error": repr(e)}
+            for i16 in (1, 0):
+                dst = out if i16 else out.setdefault("float_path", {"what": "the same runs with BTK_NODE_I16=0: float samples through "
+                                                                            "SampleFeature::next_blocks and over PCIe (4 B per sample)"})
+                try:
+                    res = subprocess.run([exe, f.name, str(M), str(m), str(r), str(N), str(frames), str(graphs), str(block), str(pool)],
+                                         capture_output=True, text=True, timeout=600, env=dict(os.environ, BTK_NODE_I16=str(i16)))
+                    if res.returncode != 0:
+                        dst[key] = {"error": res.stderr.strip()[-300:]}
+                        continue
+                    j = json.loads(res.stdout.strip().splitlines()[-1])
+                    j["xRT"] = j["frames_per_s"] / (FS / (M >> r))
+                    j["fraction_of_engine_rate"] = j["frames_per_s"] / engine_frames_per_s
+                    j["pcm_over_pcie"] = "int16" if i16 else "float32"
+                    dst[key] = j
+                except (OSError, ValueError, subprocess.TimeoutExpired) as e:
+                    dst[key] = {"error": repr(e)}
     return out
 
 

@@ -225,13 +225,58 @@ LPK_FN int qr_iterate(int m, float* s, float* e)
   return info;
 }
 
+// Column j of x, rows [i0, i1): y_i += t v_i (caxpy) and sum_i conj(v_i) y_i (cdotc, i ascending).  Element for element the
+// plain loops; written in batches of eight rows -- the eight loads first -- because the rows are `ld` elements apart in memory the
+// compiler cannot tell apart: a load-modify-store loop otherwise waits for every element's round trip (a matrix in L2) in turn.
+LPK_FN void axpy_rows(cf* y, int ld, int i0, int i1, cf t, const cf* v)
+{
+  int i = i0;
+  for (; i + 8 <= i1; i += 8) {
+    cf a[8];
+    for (int u = 0; u < 8; ++u) a[u] = y[(long)(i + u) * ld];
+    for (int u = 0; u < 8; ++u) y[(long)(i + u) * ld] = cadd(a[u], cmul(t, v[i + u]));
+  }
+  for (; i < i1; ++i) y[(long)i * ld] = cadd(y[(long)i * ld], cmul(t, v[i]));
+}
+LPK_FN cf dot_rows(const cf* y, int ld, int i0, int i1, const cf* v)
+{
+  cf dot = mk(0.0f, 0.0f);
+  int i = i0;
+  for (; i + 8 <= i1; i += 8) {
+    cf a[8];
+    for (int u = 0; u < 8; ++u) a[u] = y[(long)(i + u) * ld];
+    for (int u = 0; u < 8; ++u) dot = cadd(dot, cmul(conj(v[i + u]), a[u]));
+  }
+  for (; i < i1; ++i) dot = cadd(dot, cmul(conj(v[i]), y[(long)i * ld]));
+  return dot;
+}
+
+// work_i = sum_{j >= i0} e_j x(i, j) for the rows i >= i0, j ascending, zero e_j skipped (linpack_c.cc:9806-9816: one caxpy per
+// column, so each row's sum runs over j); a thread per row
+template <class Ctx>
+LPK_FN void row_sums(const Ctx& cx, const cf* x, int ld, int i0, int n, int p, const cf* ev, cf* work)
+{
+  for (int i = i0 + cx.tid(); i < n; i += cx.nthreads()) {
+    cf acc = mk(0.0f, 0.0f);
+    const cf* xr = x + (long)i * ld;
+    for (int j = i0; j < p; ++j) {
+      const cf ej = ev[j];
+      if (cabs1(ej) != 0.0f) acc = cadd(acc, cmul(ej, xr[j]));
+    }
+    work[i] = acc;
+  }
+  cx.barrier();
+}
+
 // Work arrays of one matrix (LDS in the kernel).  Sizes: col, work: n; ev: p; sc, ec: max(n + 1, p) + 1; t: 2.
 struct Work { cf *col, *ev, *work, *sc, *ec, *t; int* flag; };
 
 // csvdc with job = 0 on the n x p matrix x (element (i, j) at x[i * ld + j], destroyed), linpack_c.cc:9676-9867 for the
 // reduction.  s, e: min(n + 1, p) floats each (thread 0 writes them); returns INFO on thread 0 (other threads: undefined).
+// csvdc_reduce: the Householder reduction to the real bidiagonal (s, e; thread 0 writes them, complete behind the final barrier);
+// csvdc_values = csvdc_reduce + the QR iteration on it.
 template <class Ctx>
-LPK_FN int csvdc_values(Ctx& cx, cf* x, int ld, int n, int p, Work w, float* s, float* e)
+LPK_FN void csvdc_reduce(Ctx& cx, cf* x, int ld, int n, int p, Work w, float* s, float* e)
 {
   const int tid = cx.tid(), nth = cx.nthreads();
   const int nct = (n - 1 < p) ? n - 1 : p;
@@ -243,8 +288,9 @@ LPK_FN int csvdc_values(Ctx& cx, cf* x, int ld, int n, int p, Work w, float* s, 
     if (colstep) {
       for (int i = L + tid; i < n; i += nth) w.col[i] = x[(long)i * ld + L];
       cx.barrier();
+      const float nrm_col = cx.nrm2(n - L, w.col + L);       // (every thread calls; thread 0 gets the value)
       if (tid == 0) {
-        cf sl = mk(nrm2(n - L, w.col + L), 0.0f);
+        cf sl = mk(nrm_col, 0.0f);
         int scaled = 0;
         if (cabs1(sl) != 0.0f) {
           if (cabs1(w.col[L]) != 0.0f) sl = csign2(sl, w.col[L]);
@@ -270,19 +316,18 @@ LPK_FN int csvdc_values(Ctx& cx, cf* x, int ld, int n, int p, Work w, float* s, 
       const bool reflect = colstep && w.flag[0];
       for (int j = L + 1 + tid; j < p; j += nth) {
         if (reflect) {
-          cf dot = mk(0.0f, 0.0f);
-          for (int i = L; i < n; ++i) dot = cadd(dot, cmul(conj(w.col[i]), x[(long)i * ld + j]));
+          const cf dot = dot_rows(x + j, ld, L, n, w.col);
           const cf t = cdiv(cneg(dot), w.col[L]);
-          if (cabs1(t) != 0.0f)
-            for (int i = L; i < n; ++i) { cf* y = &x[(long)i * ld + j]; *y = cadd(*y, cmul(t, w.col[i])); }
+          if (cabs1(t) != 0.0f) axpy_rows(x + j, ld, L, n, t, w.col);
         }
         w.ev[j] = conj(x[(long)L * ld + j]);
       }
     }
     cx.barrier();
     if (L < nrt) {
+      const float nrm_row = cx.nrm2(p - L - 1, w.ev + L + 1);
       if (tid == 0) {
-        cf el = mk(nrm2(p - L - 1, w.ev + L + 1), 0.0f);
+        cf el = mk(nrm_row, 0.0f);
         int scaled = 0;
         if (cabs1(el) != 0.0f) {
           if (cabs1(w.ev[L + 1]) != 0.0f) el = csign2(el, w.ev[L + 1]);
@@ -306,36 +351,33 @@ LPK_FN int csvdc_values(Ctx& cx, cf* x, int ld, int n, int p, Work w, float* s, 
       cx.barrier();
       if (w.flag[1]) {
         // work_i = sum_j e_j x(i, j), j ascending (one caxpy per column in the source: the order of each row's sum is j)
-        for (int i = L + 1 + tid; i < n; i += nth) {
-          cf acc = mk(0.0f, 0.0f);
-          const cf* xr = x + (long)i * ld;
-          for (int j = L + 1; j < p; ++j) {
-            const cf ej = w.ev[j];
-            if (cabs1(ej) != 0.0f) acc = cadd(acc, cmul(ej, xr[j]));
-          }
-          w.work[i] = acc;
-        }
-        cx.barrier();
+        cx.row_sums(x, ld, L + 1, n, p, w.ev, w.work);        // (ends with a barrier)
         const cf e1 = w.ev[L + 1];
         for (int j = L + 1 + tid; j < p; j += nth) {
           const cf c = conj(cdiv(cneg(w.ev[j]), e1));
-          if (cabs1(c) != 0.0f)
-            for (int i = L + 1; i < n; ++i) { cf* y = &x[(long)i * ld + j]; *y = cadd(*y, cmul(c, w.work[i])); }
+          if (cabs1(c) != 0.0f) axpy_rows(x + j, ld, L + 1, n, c, w.work);
         }
       }
       cx.barrier();
     }
   }
-  int info = 0;
+  const int m = (p < n + 1) ? p : n + 1;
   if (tid == 0) {
-    const int m = (p < n + 1) ? p : n + 1;
     if (nct < p) w.sc[nct] = x[(long)nct * ld + nct];
     if (n < m) w.sc[m - 1] = mk(0.0f, 0.0f);
     if (nrt + 1 < m) w.ec[nrt] = x[(long)nrt * ld + (m - 1)];
     w.ec[m - 1] = mk(0.0f, 0.0f);
     realify(m, w.sc, w.ec, s, e);
-    info = qr_iterate(m, s, e);
   }
+  cx.barrier();
+}
+
+template <class Ctx>
+LPK_FN int csvdc_values(Ctx& cx, cf* x, int ld, int n, int p, Work w, float* s, float* e)
+{
+  csvdc_reduce(cx, x, ld, n, p, w, s, e);
+  // the serial recurrence: one thread in the host build; in the kernel the first wavefront walks it together (Ctx::qr)
+  const int info = cx.qr((p < n + 1) ? p : n + 1, s, e);
   cx.barrier();
   return info;
 }
@@ -344,6 +386,9 @@ struct SerialCtx {
   LPK_MEMFN int tid() const { return 0; }
   LPK_MEMFN int nthreads() const { return 1; }
   LPK_MEMFN void barrier() const {}
+  LPK_MEMFN int qr(int m, float* s, float* e) const { return qr_iterate(m, s, e); }
+  LPK_MEMFN float nrm2(int n, const cf* x) const { return lpk::nrm2(n, x); }
+  LPK_MEMFN void row_sums(const cf* x, int ld, int i0, int n, int p, const cf* ev, cf* work) const { lpk::row_sums(*this, x, ld, i0, n, p, ev, work); }
 };
 
 }  // namespace lpk

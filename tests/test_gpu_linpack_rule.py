@@ -37,6 +37,41 @@ def test_csvdc_values_bit_exact_small_and_nonsquare(orc, dev):
             assert np.array_equal(_bits(s[i]), _bits(sr)) and np.array_equal(_bits(e[i]), _bits(er)), (shape, i)
 
 
+def test_csvdc_batch_forms_and_extreme_scales_same_bits(orc, dev):
+    """round 6: (a) a batch whose matrices fit LDS singly but not all at once is reduced in LDS rounds and iterated in a second
+    launch (csvdc_values_kernel PHASE 1 + qr_phase_kernel): the same bits as the same matrices in LDS-resident batches, and as the
+    reference's csvdc on a sample; (b) matrices scaled by 2^-70 / 2^+70 / with tiny entries leave the FMA-only division of the
+    wavefront's srotg (|sa|, |sb| outside [2^-60, 2^60] take the plain IEEE path): still the reference's bits"""
+    import torch
+    from distant_speech_recognition_amd import engine as eng
+    rng = np.random.default_rng(5)
+    K, N = 1100, 40                                                    # 1100 > 4 per CU x 256 CUs
+    A = (rng.standard_normal((K, N, N + 6)) + 1j * rng.standard_normal((K, N, N + 6)))
+    R = (A @ np.conj(np.transpose(A, (0, 2, 1))) / (N + 6)).astype(np.complex64)
+    R[7, :, 3] = 0; R[7, 3, :] = 0                                     # a dead channel
+    R[11] = np.diag(np.arange(1, N + 1)).astype(np.complex64)
+    Rd = torch.from_numpy(R).to(dev)
+    s, e, info = [x.cpu().numpy() for x in eng.csvdc_values(Rd)]
+    for lo in range(0, K, 400):
+        s2, e2, i2 = [x.cpu().numpy() for x in eng.csvdc_values(Rd[lo:lo + 400].contiguous())]
+        assert np.array_equal(info[lo:lo + 400], i2)
+        assert np.array_equal(_bits(s[lo:lo + 400]), _bits(s2)) and np.array_equal(_bits(e[lo:lo + 400]), _bits(e2)), lo
+    ref = (lambda M: lh.ref_csvdc(orc, M)) if orc.ref_lib() is not None else lh.csvdc_values
+    for i in (0, 7, 11, 555, 1099):
+        sr, er, ir = ref(R[i])
+        assert int(info[i]) == ir and np.array_equal(_bits(s[i]), _bits(sr)) and np.array_equal(_bits(e[i]), _bits(er)), i
+    X = []
+    for i, sc in enumerate((2.0 ** -70, 2.0 ** 70, 2.0 ** -100, 2.0 ** 40)):
+        X.append((R[20 + i].astype(np.complex128) * sc).astype(np.complex64))
+    Z = R[30].copy(); Z[:, 5] *= np.float32(2.0 ** -80); Z[5, :] *= np.float32(2.0 ** -80); X.append(Z)      # one tiny singular value
+    X = np.stack(X)
+    s, e, info = [x.cpu().numpy() for x in eng.csvdc_values(torch.from_numpy(X).to(dev))]
+    for i in range(len(X)):
+        sr, er, ir = ref(X[i])
+        assert int(info[i]) == ir, (i, int(info[i]), ir)
+        assert np.array_equal(_bits(s[i]), _bits(sr)) and np.array_equal(_bits(e[i]), _bits(er)), i
+
+
 @pytest.mark.parametrize("g", [0, 1])
 def test_c5_info_vector_all_bins(orc, dev, g):
     """All 1024 designed bins of BASELINE config C5 (256 microphones, 2048 sub-bands, loading 1e-2): INFO and the singular
