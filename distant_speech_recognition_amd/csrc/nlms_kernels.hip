@@ -315,8 +315,11 @@ template <int GROUP> __device__ __forceinline__ float group_sum2(float v)
 // thousands of rows 64 bytes at a time runs HBM at 2.8-3.6 TB/s whatever the kernel does with the data
 // (profiles/ubench/strided_rows.hip); requesting both halves of every 128-byte line back to back reads at 5.4-5.9 TB/s.
 // NPF = 2 keeps the 8-frame LDS tile (two wavefronts per SIMD) and holds the second half in registers until its turn.
-template <int GROUP, int CPL, int TBF, int NC = 1, int NPF = 1>
-__global__ __launch_bounds__(64)
+// UNR / MINW (round 6, diagnostics): the steps of a tile unrolled UNR-fold and the register budget of MINW wavefronts per SIMD.  The
+// default form <16, 4, 8, 1, 2> holds two prefetched tiles in registers (249 VGPRs: TWO wavefronts per SIMD, 2 048 on the chip);
+// <.., NPF = 1, UNR = 4, MINW = 3> fits 166 VGPRs without spills (three per SIMD) and is slower per wavefront (BTK_NLMS_ALT=7).
+template <int GROUP, int CPL, int TBF, int NC = 1, int NPF = 1, int UNR = TBF, int MINW = 1>
+__global__ __launch_bounds__(64, MINW)
 void nlms_bin2_kernel(const float2* __restrict__ X, const float2* __restrict__ VS, float2* __restrict__ Y,
                       int K, int N, long T_stride, long T, const float* __restrict__ ctrl,
                       const double* __restrict__ stream_state_before, NlmsParams p,
@@ -325,12 +328,17 @@ void nlms_bin2_kernel(const float2* __restrict__ X, const float2* __restrict__ V
   constexpr int NX = NC > 1 ? NC - 1 : 1;
   constexpr int BPW = 64 / GROUP;
   constexpr int NR = GROUP * CPL;
-  constexpr int LDWv = TBF + 1;
+  // LDS tile [64 CPL rows][TBF frames], unpadded (round 6), the frame slot of a row XOR-ed with bits of the row index: column reads
+  // (the 64 lanes of a step read 64 different rows at one frame) and the loader's row writes both spread over all banks (4 passes
+  // for 64 8-byte accesses, the minimum) as with the 9-slot rows of rounds 2-5, in 16 KB instead of 18 (ten workgroups per CU by
+  // LDS; what bounds the residency of the default form is its 249 VGPRs, see btk_nlms_process_nc).
+  constexpr int SH = TBF >= 16 ? 0 : (TBF == 8 ? 1 : 2);  // slot = t ^ ((row >> SH) & (TBF - 1)): with the row pitch of 2 TBF dwords
+  constexpr bool FX1 = GROUP >= 16 || CPL == 1;           // the swizzle of a lane's rows does not depend on the channel index
   constexpr int LPR = TBF / 2;                          // lanes per row (float4 = 2 frames)
   constexpr int RPP = 64 / LPR;                         // rows per wave-load
   constexpr int NPASS = 64 * CPL / RPP;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  float2* tile = reinterpret_cast<float2*>(smem);      // [64*CPL rows][LDWv]
+  float2* tile = reinterpret_cast<float2*>(smem);      // [64*CPL rows][TBF], swizzled
   const int lane = threadIdx.x;
   const int s = blockIdx.y;
   const int kb = blockIdx.x * BPW;
@@ -338,6 +346,8 @@ void nlms_bin2_kernel(const float2* __restrict__ X, const float2* __restrict__ V
   const int k = kb + gi;
   const bool kvalid = k < K;
   const long isamp0 = (long)stream_state_before[4 * (long)s + 2];
+  const int rd_row = gi * NR + gl;                      // this lane's row of channel c: rd_row + GROUP c
+  const int rd_fx = (rd_row >> SH) & (TBF - 1);
 
   f2 vs[CPL], u[CPL];
   float vvp = 0.f;
@@ -410,9 +420,11 @@ void nlms_bin2_kernel(const float2* __restrict__ X, const float2* __restrict__ V
   auto commit = [&](const float4 (&pr)[NPASS]) {
 #pragma unroll
     for (int q = 0; q < NPASS; q++) {
-      float2* d = tile + (q * RPP + lrow) * LDWv + 2 * lc4;
-      d[0] = make_float2(pr[q].x, pr[q].y);
-      d[1] = make_float2(pr[q].z, pr[q].w);
+      const int r = q * RPP + lrow;
+      const int f = (r >> SH) & (TBF - 1);
+      float2* d = tile + r * TBF;
+      d[(2 * lc4) ^ f] = make_float2(pr[q].x, pr[q].y);
+      d[(2 * lc4 + 1) ^ f] = make_float2(pr[q].z, pr[q].w);
     }
   };
 
@@ -432,7 +444,7 @@ void nlms_bin2_kernel(const float2* __restrict__ X, const float2* __restrict__ V
     const int nsteps = (T - t0) < TBF ? (int)(T - t0) : TBF;
     // every tile runs all TBF steps: beyond the end of the block the tile holds zeros and the step size read from ctrl is 0
     // (no update, nothing stored), so the steps need no branch
-#pragma unroll
+#pragma unroll UNR
     for (int tt = 0; tt < TBF; tt++) {
       {
         // complex arithmetic in packed float32 (v_pk_fma_f32 with op_sel / neg modifiers): 5 packed FMAs per channel for the
@@ -441,7 +453,8 @@ void nlms_bin2_kernel(const float2* __restrict__ X, const float2* __restrict__ V
         f2 yc = {0.f, 0.f}, pp = {0.f, 0.f}, xx2 = {0.f, 0.f};
 #pragma unroll
         for (int c = 0; c < CPL; c++) {
-          const float2 xv = tile[(gi * NR + gl + GROUP * c) * LDWv + tt];
+          const int fx = FX1 ? rd_fx : (((rd_row + GROUP * c) >> SH) & (TBF - 1));
+          const float2 xv = tile[(rd_row + GROUP * c) * TBF + (tt ^ fx)];
           x[c] = f2{xv.x, xv.y};
           acc_conjw_z(yc, vs[c], x[c]);                              // Yc = vs^H x
           acc_w_z(pp, u[c], x[c]);                                   // p = u x
@@ -525,15 +538,15 @@ void nlms_bin2_kernel(const float2* __restrict__ X, const float2* __restrict__ V
   }
 }
 
-template <int GROUP, int CPL, int TBF, int NC = 1, int NPF = 1>
+template <int GROUP, int CPL, int TBF, int NC = 1, int NPF = 1, int UNR = TBF, int MINW = 1>
 int launch_bin2(const float2* X, const float2* VS, float2* Y, int S, int K, int N, long T_stride, long T,
                 const float* ctrl, const double* state_before, NlmsParams p, float2* U, float* sigma2, hipStream_t st,
                 const float2* CX = nullptr)
 {
   constexpr int BPW = 64 / GROUP;
-  const size_t lds = sizeof(float2) * (size_t)64 * CPL * (TBF + 1);
+  const size_t lds = sizeof(float2) * (size_t)64 * CPL * TBF;
   dim3 grid((unsigned)((K + BPW - 1) / BPW), (unsigned)S);
-  hipLaunchKernelGGL((nlms_bin2_kernel<GROUP, CPL, TBF, NC, NPF>), grid, dim3(64), lds, st, X, VS, Y, K, N, T_stride, T,
+  hipLaunchKernelGGL((nlms_bin2_kernel<GROUP, CPL, TBF, NC, NPF, UNR, MINW>), grid, dim3(64), lds, st, X, VS, Y, K, N, T_stride, T,
                      ctrl, state_before, p, U, sigma2, CX);
   BTK_HIP_CHECK(hipGetLastError());
   return BTK_OK;
@@ -647,7 +660,14 @@ int btk_nlms_process_nc(const float* params /* host, 8 floats */, const void* vs
       if (alt == 3) return launch_bin2<16, 4, 16>(Xp, VS, Yp, S, K, N, T_stride, T, ctrl, state_before, p, U, sigma2, st);
       if (alt == 4) return launch_bin2<32, 2, 16>(Xp, VS, Yp, S, K, N, T_stride, T, ctrl, state_before, p, U, sigma2, st);
       if (alt == 6) return launch_bin2<16, 4, 8>(Xp, VS, Yp, S, K, N, T_stride, T, ctrl, state_before, p, U, sigma2, st);
-      return launch_bin2<16, 4, 8, 1, 2>(Xp, VS, Yp, S, K, N, T_stride, T, ctrl, state_before, p, U, sigma2, st);     // 6.49 -> 6.05 ms at 32 streams
+      // One wavefront per workgroup, every wavefront walks all T frames: a launch costs (rounds of resident wavefronts) x (a
+      // wavefront's walk).  The two-tile form (6.49 -> 6.05 ms at 32 streams in round 2) has 249 VGPRs: two wavefronts per SIMD,
+      // 2 048 on the chip -- and the C0 launch has 32 streams x 65 bin groups = 2 080: the last 32 run as a second round (5.3 ms
+      // where 31 streams take 3.85, profiles/r06_nlms_residency.txt).  BTK_NLMS_ALT=7 is the form that fits three per SIMD (one
+      // tile in registers, steps unrolled 4-fold, 166 VGPRs, no spills): 14-24 % slower per wavefront, 5.8 ms at 32 streams, and
+      // not bit-identical to the default form (other fused multiply-add contractions) -- measured, not selected.
+      if (alt == 7) return launch_bin2<16, 4, 8, 1, 1, 4, 3>(Xp, VS, Yp, S, K, N, T_stride, T, ctrl, state_before, p, U, sigma2, st);
+      return launch_bin2<16, 4, 8, 1, 2>(Xp, VS, Yp, S, K, N, T_stride, T, ctrl, state_before, p, U, sigma2, st);
     }
     else if (N <= 128) return launch_bin2<32, 4, 8, 1, 2>(Xp, VS, Yp, S, K, N, T_stride, T, ctrl, state_before, p, U, sigma2, st);
     return launch_bin2<64, 4, 8, 1, 2>(Xp, VS, Yp, S, K, N, T_stride, T, ctrl, state_before, p, U, sigma2, st);
