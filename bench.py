@@ -135,7 +135,8 @@ def cpu_baseline(N, M, m, r, dct, frames, all_cores=True):
 def node_api_stage(h, g, N, M, m, r, engine_frames_per_s):
     """What a drop-in caller of the reference's node API gets: host/examples/node_api_bench builds the graph of
     src/beamformerDS.cc:144-223 (SampleFeature x N -> OverSampledDFTAnalysisBank x N -> SubbandGSC -> OverSampledDFTSynthesisBank)
-    on in-memory utterances and pulls it block by block through next(): one graph of 8192 frames, 32 graphs one after the other
+    on in-memory utterances and pulls it block by block through next(): one graph of 32768 frames (four blocks: the upload of a
+    block runs under the computing and serving of the one before), 32 graphs of 2048 frames one after the other
     and the same 32 graphs in a SubbandGraphPool (one S = 32 launch per round).  The binary reports where the host time goes; the
     device work per frame is the engine's, the rest is the reference's own interface: every sample lives in a SampleFeature in
     host memory and crosses PCIe.  Round 6: utterances of 16-bit PCM (what a WAV read delivers) go up AS int16, from where the
@@ -150,7 +151,7 @@ def node_api_stage(h, g, N, M, m, r, engine_frames_per_s):
                    "jiterator_error; wall clock of the pull loop, inputs in host memory (SampleFeature), second pass timed" % N}
     with tempfile.NamedTemporaryFile(suffix=".f64") as f:
         np.concatenate([h, g]).astype(np.float64).tofile(f.name)
-        for key, frames, graphs, block, pool in (("one_graph", 8192, 1, 8192, 0), ("graphs_32_one_by_one", 2048, 32, 1024, 0),
+        for key, frames, graphs, block, pool in (("one_graph", 32768, 1, 8192, 0), ("graphs_32_one_by_one", 2048, 32, 1024, 0),
                                                  ("graph_pool_32", 2048, 32, 1024, 1)):
             for i16 in (1, 0):
                 dst = out if i16 else out.setdefault("float_path", {"what": "the same runs with BTK_NODE_I16=0: float samples through "

@@ -193,6 +193,12 @@ class SubbandBeamformer : public VectorComplexFeatureStream {
   const float* pcm_f32_();        // the resident windows as float32 [N][pcm_pitch_] (widened once per block in a 16-bit stream)
   bool pcm_i16_, pcm_f32_valid_;  // the current stream's samples are resident as int16 (dPcm16Buf_); dPcmBuf_ holds their float copy
   long pcm_pitch_;                // samples between the rows of the resident windows
+  // 16-bit streams: the block after the current one, planned and on its way up (prefetch_next_)
+  void prefetch_next_(const BlockPlan& cur);
+  DeviceBuffer dPcm16Next_;
+  bool pre_valid_;
+  BlockPlan pre_plan_;
+  long pre_pitch_;
   PinnedBuffer hStage_;           // channels that are pulled frame by frame: the transposed block on its way up
   long pcm_L_, pcm_t0_;           // the resident PCM windows [N][pcm_L_]; stream frame chunk_base_ is frame pcm_t0_ of the window
   bool pcm_valid_, snap_valid_, snapshots_wanted_;

@@ -138,6 +138,13 @@ struct ScopedNs {                                   // adds the scope's wall tim
 };
 
 hipStream_t nstream() { return static_cast<hipStream_t>(btk_node_stream()); }
+// a host thread's second stream: uploads of the block AFTER the current one (16-bit streams, SubbandBeamformer::prefetch_next_)
+hipStream_t cstream()
+{
+  static thread_local hipStream_t st = NULL;
+  if (!st) check_hip(hipStreamCreateWithFlags(&st, hipStreamNonBlocking), "hipStreamCreateWithFlags");
+  return st;
+}
 void nsync() { check_hip(hipStreamSynchronize(nstream()), "hipStreamSynchronize"); }
 
 // one-off device blocks of the design-time paths (weight design, WPE estimate, CSD rebuild): not the per-block steady state
@@ -593,17 +600,21 @@ long SampleFeature::advance_blocks(long nmax, size_t* first_sample)
   if (!q && !is_end_ && have_samples_ && !samples_.empty())
     throw jconsistency_error("SampleFeature %s: advance_blocks() without a 16-bit view of the samples\n", name().c_str());
   if (first_sample) *first_sample = cur_;
-  size_t last = 0;
-  while (n < nmax) {
-    if (is_end_) break;
-    const size_t ttl = samples_.size();
-    if (!have_samples_ || cur_ >= ttl || (cur_ + sz >= ttl && !pad_zeros_)) { is_end_ = true; have_samples_ = false; samples_.clear(); break; }
-    last = cur_;
-    cur_ += shiftLen_;
-    increment_();
-    n++;
+  if (nmax <= 0 || is_end_) return 0;
+  // closed form of the loop of next() calls: block j starts at cur_ + j shiftLen_ and is handed out while it starts inside the
+  // samples (zero-padded tail) or, without padding, while it ENDS before the last sample (next(): `cur_ + size() >= ttl` ends it)
+  const size_t ttl = samples_.size();
+  long avail = 0;
+  if (have_samples_ && cur_ < ttl) {
+    if (pad_zeros_) avail = (long)((ttl - cur_ + shiftLen_ - 1) / shiftLen_);
+    else if (cur_ + sz < ttl) avail = (long)((ttl - sz - cur_ + shiftLen_ - 1) / shiftLen_);
   }
+  n = avail < nmax ? avail : nmax;
+  const size_t last = cur_ + (size_t)(n > 0 ? n - 1 : 0) * shiftLen_;
+  cur_ += (size_t)n * shiftLen_;
+  frame_no_ += (int)n;
   if (n > 0 && q) for (unsigned i = 0; i < sz; i++) vector_->data[i] = (float)q[last + i];
+  if (n < nmax) { is_end_ = true; have_samples_ = false; samples_.clear(); }       // the call after the last block: next() ends the stream
   return n;
 }
 
@@ -1353,15 +1364,20 @@ SubbandBeamformer::SubbandBeamformer(unsigned fftLen, bool halfBandShift, const 
     : VectorComplexFeatureStream(fftLen, nm), chunk_base_(0), block_frames_(btk_default_block_frames()), chunk_loaded_(false),
       channels_ended_(false), quantum_(1), halfBandShift_(halfBandShift), dXfull_(NULL), snapshot_array_(NULL), fftLen_(fftLen),
       fftLen2_(fftLen / 2), dX_(NULL), T_(0), banks_only_(false), pcm_i16_(false), pcm_f32_valid_(false), pcm_pitch_(0),
+      pre_valid_(false), pre_pitch_(0),
       pcm_L_(0), pcm_t0_(0), pcm_valid_(false), snap_valid_(false),
       snapshots_wanted_(false) {}
-SubbandBeamformer::~SubbandBeamformer() {}
+SubbandBeamformer::~SubbandBeamformer()
+{
+  if (pre_valid_) (void)hipStreamSynchronize(cstream());
+}
 // the block state starts over; the device buffers stay (they only ever grow: common/devmem.h)
 void SubbandBeamformer::free_device_()
 {
   dX_ = NULL; dXfull_ = NULL; T_ = 0; Xhost_.clear();
   chunk_base_ = 0; chunk_loaded_ = false; channels_ended_ = false; pcm_valid_ = false; snap_valid_ = false; pcm_L_ = 0; pcm_t0_ = 0;
   pcm_i16_ = false; pcm_f32_valid_ = false; pcm_pitch_ = 0;
+  if (pre_valid_) { (void)hipStreamSynchronize(cstream()); pre_valid_ = false; }     // copies of a block nobody will ask for
 }
 void SubbandBeamformer::set_channel(VectorComplexFeatureStreamPtr& chan) { channelList_.push_back(chan); }
 void SubbandBeamformer::clear_channel() { channelList_.clear(); banks_.clear(); banks_only_ = false; snapshot_array_ = NULL; free_device_(); }
@@ -1513,6 +1529,35 @@ void SubbandBeamformer::commit_bank_block(const BlockPlan& p)
   for (size_t c = 0; c < banks_.size(); c++) banks_[c]->release_before(p.f0 + p.T);
 }
 
+// 16-bit streams: the block AFTER the one just committed is planned now -- the sources only move on, nothing is copied on the host
+// -- and its samples start their way up on the thread's second stream into the other device buffer, under the kernels, the
+// download and the serving of the current block: a block then costs max(PCIe, everything else) instead of their sum.  `cur` is the
+// block just committed.  The buffer being filled was the current one of the block BEFORE it: the copies wait for what the node
+// stream has queued so far.  (The sources run one block further ahead of the frames served than without -- they already ran a
+// block ahead.)  BTK_NODE_PREFETCH=0 switches it off.
+void SubbandBeamformer::prefetch_next_(const BlockPlan& cur)
+{
+  static const bool off = getenv("BTK_NODE_PREFETCH") && atoi(getenv("BTK_NODE_PREFETCH")) == 0;
+  if (off || !pcm_i16_ || cur.ended || cur.T <= 0) return;
+  const unsigned N = chanN();
+  BlockPlan pn;
+  pull_banks_(0, N);
+  plan_from_pulled_(pn, N);
+  pre_plan_ = pn;
+  pre_pitch_ = (pn.L + 7) / 8 * 8;
+  if (pn.T > 0) {
+    // the buffer being filled was the current one of the block BEFORE `cur`: that block has been served to its last frame, i.e.
+    // the host has waited for everything the node stream did with it -- no stream-side dependency is needed (and none is made:
+    // copies that wait on an event of another stream ran at 37 instead of 53 GB/s)
+    char* dp = static_cast<char*>(dPcm16Next_.ensure(sizeof(short) * N * (pre_pitch_ ? pre_pitch_ : 8)));
+    nsync();                                                       // (cheap: the stream is idle at this point in a pulled graph)
+    for (unsigned c = 0; c < N; c++)
+      check_hip(hipMemcpyAsync(dp + sizeof(short) * (size_t)c * pre_pitch_, banks_[c]->window16(pn.b0), sizeof(short) * pn.L,
+                               hipMemcpyHostToDevice, cstream()), "hipMemcpyAsync H2D");
+  }
+  pre_valid_ = true;
+}
+
 // The block after the current one (the first one when none is loaded): frames chunk_base_ .. chunk_base_ + T_ - 1.
 // Returns false when the channels have no further frame (the block is then empty).
 bool SubbandBeamformer::load_chunk_()
@@ -1526,6 +1571,19 @@ bool SubbandBeamformer::load_chunk_()
     // if a later channel turns out shorter (the end of a stream with ragged channels) the copies are made again.
     BlockPlan p, p0;
     char* dp = NULL;
+    if (pre_valid_) {
+      // a 16-bit stream: this block was planned and sent on its way while the one before was computed and served (prefetch_next_)
+      ScopedNs timer(g_upload_ns);
+      check_hip(hipStreamSynchronize(cstream()), "hipStreamSynchronize");      // (the host waits: a stream-side wait on an event made the copies slower)
+      dPcm16Buf_.swap(dPcm16Next_);
+      pre_valid_ = false;
+      p = pre_plan_;
+      commit_bank_block(p);
+      pcm_L_ = p.L; pcm_pitch_ = pre_pitch_; pcm_t0_ = p.f0 - p.b0; pcm_valid_ = p.T > 0; pcm_f32_valid_ = false;
+      if (snapshots_wanted_) snapshots_();
+      prefetch_next_(p);
+      return T_ > 0;
+    }
     if (!chunk_loaded_ && !pcm_i16_ && i16_stream_possible()) begin_i16_stream();     // a stream begins: 16-bit PCM if every source has it
     // (16-bit streams: rows of int16 a multiple of 16 bytes apart, straight out of the sources' pinned copies -- nothing to pull)
     const size_t es = pcm_i16_ ? sizeof(short) : sizeof(float);
@@ -1562,6 +1620,7 @@ bool SubbandBeamformer::load_chunk_()
     commit_bank_block(p);
     pcm_L_ = p.L; pcm_pitch_ = pitch; pcm_t0_ = p.f0 - p.b0; pcm_valid_ = p.T > 0; pcm_f32_valid_ = false;
     if (snapshots_wanted_) snapshots_();
+    prefetch_next_(p);
   } else {
     // channels of any other kind are pulled frame by frame, at most block_frames() frames per block; with halfBandShift the
     // reference dots every one of the M snapshots as supplied (beamformer.cc:1113-1128): a generic source owes no conjugate
