@@ -359,6 +359,8 @@ class NLMSState:
         self.stream_state = torch.empty((S, 4), dtype=torch.float64, device=device)
         self.reset_stats()
         self._ws = None
+        self._ws_groups = {}                   # interleaved launches: a workspace per stream group
+        self._streams = None                   # ... and their HIP streams
 
     def set_constraints(self, vs):
         """Nc > 1: derive the extra projector directions from the array manifold vs complex [K][N] (host)."""
@@ -372,6 +374,7 @@ class NLMSState:
         self.stream_state[:, 1] = self.p["gamma"]
         self.stream_state[:, 2] = 0
         self.stream_state[:, 3] = 0
+        self.frames_done = 0                   # host copy of the streams' frame counter (every stream advances by T per call)
 
     def params_array(self):
         p = self.p
@@ -384,10 +387,24 @@ class NLMSState:
             self._ws = torch.empty(need, dtype=torch.uint8, device=self.u.device)
         return self._ws
 
+    def group_workspace(self, g, Sg, T):
+        need = _lib.lib().btk_nlms_workspace_bytes(Sg, T)
+        w = self._ws_groups.get(g)
+        if w is None or w.numel() < need:
+            w = self._ws_groups[g] = torch.empty(need, dtype=torch.uint8, device=self.u.device)
+        return w
 
-def nlms_process(vs, X, state, out=None):
+    def group_streams(self, G):
+        if self._streams is None or len(self._streams) < G:
+            self._streams = [torch.cuda.Stream(device=self.u.device) for _ in range(G)]
+        return self._streams[:G]
+
+
+def nlms_process(vs, X, state, out=None, interleave=None):
     """Adaptive GSC over a block: vs complex64 [K][N] (cuda), X [S][K][N][T] -> Y [S][K][T]; state updated in place.
-    X may be a row-padded view (analysis(pad_rows=True)); Y then shares its row stride."""
+    X may be a row-padded view (analysis(pad_rows=True)); Y then shares its row stride.
+    interleave: None = decide by the launch shape (_nlms_interleave_plan), (1, T) = one launch, (G, chunk) = G stream groups on G
+    HIP streams in chunks of `chunk` frames (a multiple of 64)."""
     ts = _check(X, "X", torch.complex64, 4, rows=True)
     S, K, N, T = X.shape
     _check(vs, "vs", torch.complex64, (K, N))
@@ -405,10 +422,69 @@ def nlms_process(vs, X, state, out=None):
         if cx is None:
             raise _lib.BtkError(_lib.BTK_ERR_PARAMETER, "nlms_process: Nc = %d needs state.set_constraints(vs) first" % Nc)
         _check(cx, "cextra", torch.complex64, (K, Nc - 1, N))
-    check(_lib.lib().btk_nlms_process_nc(_np_ptr(params), _ptr(vs), _ptr(state.cextra) if Nc > 1 else None, Nc, _ptr(X), _ptr(out),
-                                         S, state.M, N, ts, T, _ptr(state.u), _ptr(state.sigma2), _ptr(state.stream_state),
-                                         _ptr(ws), _stream()))
+    cxp = _ptr(state.cextra) if Nc > 1 else None
+    G, chunk = _nlms_interleave_plan(S, K, N, T, state) if interleave is None else interleave
+    if G <= 1:
+        check(_lib.lib().btk_nlms_process_nc(_np_ptr(params), _ptr(vs), cxp, Nc, _ptr(X), _ptr(out),
+                                             S, state.M, N, ts, T, _ptr(state.u), _ptr(state.sigma2), _ptr(state.stream_state),
+                                             _ptr(ws), _stream()))
+    else:
+        # G groups of streams on G HIP streams, frame chunk after frame chunk: every stream is its own recursion and the kernels
+        # carry their state from launch to launch (chunks are multiples of 64 frames: the same bits), so the groups may drift
+        # apart -- and they do, which is the point (see _nlms_interleave_plan)
+        cur = torch.cuda.current_stream()
+        streams = state.group_streams(G)
+        e0 = torch.cuda.Event()
+        e0.record(cur)
+        bounds = [(g * S) // G for g in range(G + 1)]
+        lib = _lib.lib()
+        for st in streams:
+            st.wait_event(e0)
+        for a in range(0, T, chunk):
+            n = min(chunk, T - a)
+            for g, st in enumerate(streams):
+                _nlms_group_launch(lib, params, vs, cxp, Nc, X, out, ts, state, bounds[g], bounds[g + 1], a, n, g, chunk, st)
+        for st in streams:
+            e = torch.cuda.Event()
+            e.record(st)
+            cur.wait_event(e)
+            for t in (X, out, vs, state.u, state.sigma2, state.stream_state):
+                t.record_stream(st)
+    state.frames_done = getattr(state, "frames_done", 0) + T
     return out
+
+
+def _nlms_group_launch(lib, params, vs, cxp, Nc, X, out, ts, state, s0, s1, a, n, g, chunk_cap, st):
+    """frames [a, a + n) of the streams [s0, s1) on the HIP stream st (group g's own workspace, sized for chunk_cap frames)"""
+    if s1 <= s0 or n <= 0:
+        return
+    wg = state.group_workspace(g, s1 - s0, max(chunk_cap, n))
+    check(lib.btk_nlms_process_nc(_np_ptr(params), _ptr(vs), cxp, Nc, _ptr(X[s0:s1, :, :, a:a + n]), _ptr(out[s0:s1, :, a:a + n]),
+                                  s1 - s0, state.M, X.shape[2], ts, n, _ptr(state.u[s0:s1]), _ptr(state.sigma2[s0:s1]),
+                                  _ptr(state.stream_state[s0:s1]), _ptr(wg), C.c_void_p(st.cuda_stream)))
+
+
+# Wavefronts the canceller kernel of a channel count keeps resident on an MI355X (csrc/nlms_kernels.hip: one single-wavefront
+# workgroup per (stream, group of bins); 256 CUs x 4 SIMDs x wavefronts per SIMD at the kernel's register count) and bins per
+# wavefront.  Every wavefront walks all frames of the launch, so a launch costs (residency rounds) x (one walk): 32 streams x 65
+# bin groups = 2 080 workgroups at 64 channels are a round of 2 048 and a round of 32 that takes as long -- 5.0-5.3 ms where 31
+# streams take 3.85 (profiles/r06_nlms_residency.txt).  Cut into frame chunks and a few independent groups of streams on their own
+# HIP streams, the groups drift out of step, a group's stragglers run beside the next chunk of the others, and the chip stays
+# full: 3.8-4.1 ms, bit-identical (profiles/r06_nlms_interleave.txt; when the groups happen to stay in step it is the 5.3 again).
+_NLMS_RESIDENT = ((8, 8, 3072), (16, 4, 3072), (32, 4, 2048), (64, 4, 2048), (128, 2, 2048), (1 << 30, 1, 2048))
+
+
+def _nlms_interleave_plan(S, K, N, T, state):
+    """(groups, chunk_frames) for nlms_process: (1, T) = one launch"""
+    if os.environ.get("BTK_NLMS_INTERLEAVE", "1") == "0" or S < 4 or T < 512:
+        return 1, T
+    if getattr(state, "frames_done", 0) % 64:
+        return 1, T                            # chunk boundaries must be multiples of 64 of the streams' frame counter
+    bpw, slots = next((b, r) for n, b, r in _NLMS_RESIDENT if N <= n)
+    nwg = S * ((K + bpw - 1) // bpw)
+    if nwg <= slots:
+        return 1, T
+    return (4 if S >= 8 else 2), (512 if T >= 1024 else 256)
 
 
 class AdaptiveGSCChain:
@@ -421,10 +497,11 @@ class AdaptiveGSCChain:
     (profiles/adaptive_overlap_ab.py: 10.4 -> 9.7 ms per 32 x 4096 frames at C0).  Chunks are multiples of 64 frames, so the
     output is bit-identical to the one-launch-per-kernel chain (state and scan chunks carry, csrc/nlms_kernels.hip)."""
 
-    def __init__(self, afb, sfb, chunk_frames=512):
+    def __init__(self, afb, sfb, chunk_frames=512, groups=None):
         if chunk_frames < 64 or chunk_frames % 64:
             raise _lib.BtkError(_lib.BTK_ERR_PARAMETER, "chunk_frames must be a multiple of 64, got %r" % (chunk_frames,))
         self.afb, self.sfb, self.chunk = afb, sfb, int(chunk_frames)
+        self.groups = groups                   # canceller stream groups per chunk: None = by the launch shape, 1 = the round-5 form
         self._sa = self._sb = None
 
     def __call__(self, pcm, vs, state, X, Y, out=None, nsamples=None):
@@ -441,23 +518,54 @@ class AdaptiveGSCChain:
         ev0.record(cur)
         self._sa.wait_event(ev0)
         self._sb.wait_event(ev0)
+        S, K, N = X.shape[0], X.shape[1], X.shape[2]
+        # round 6 (groups > 1, not the default): the canceller of a chunk as G independent groups of streams, each on its own HIP
+        # stream behind the bank's chunk.  It is what makes the canceller ALONE 25 % faster at 32 streams (_nlms_interleave_plan);
+        # in the chain the bank's launches already run in the canceller's residency gaps: 9.5 ms with 1 or 2 groups, 10.7-11.8
+        # with 4 or 8 (profiles/r06_nlms_interleave.txt).
+        G = 1 if self.groups is None else int(self.groups)    # (measured: no gain inside the chain, the bank's kernels already fill the gaps)
+        if state.frames_done % 64:
+            G = 1
+        gstreams = state.group_streams(G) if G > 1 else []
+        for st in gstreams:
+            st.wait_event(ev0)
+        if G > 1:
+            ts = _check(X, "X", torch.complex64, 4, rows=True)
+            params, lib = state.params_array(), _lib.lib()
+            Nc = getattr(state, "Nc", 1)
+            cxp = _ptr(state.cextra) if Nc > 1 else None
+            bounds = [(g * S) // G for g in range(G + 1)]
         for a in range(0, T, self.chunk):
             n = min(self.chunk, T - a)
             with torch.cuda.stream(self._sa):
                 self.afb.analysis(pcm, nsamples=nsamples, t0=a, tcount=n, out=X[..., a:a + n])
                 e = torch.cuda.Event()
                 e.record(self._sa)
-            self._sb.wait_event(e)
-            with torch.cuda.stream(self._sb):
-                nlms_process(vs, X[..., a:a + n], state, out=Y[..., a:a + n])
+            if G > 1:
+                for g, st in enumerate(gstreams):
+                    st.wait_event(e)
+                    _nlms_group_launch(lib, params, vs, cxp, Nc, X, Y, ts, state, bounds[g], bounds[g + 1], a, n, g, self.chunk, st)
+            else:
+                self._sb.wait_event(e)
+                with torch.cuda.stream(self._sb):
+                    nlms_process(vs, X[..., a:a + n], state, out=Y[..., a:a + n], interleave=(1, n))
+        if G > 1:
+            state.frames_done += T
+            for st in gstreams:
+                e = torch.cuda.Event()
+                e.record(st)
+                self._sb.wait_event(e)
         with torch.cuda.stream(self._sb):
             out = self.sfb.synthesize(Y, out=out)
             e = torch.cuda.Event()
             e.record(self._sb)
         cur.wait_event(e)
         for t in (pcm, X, Y, out):                      # the caching allocator must not hand these blocks on before the side streams are done
-            t.record_stream(self._sa)
-            t.record_stream(self._sb)
+            for st in [self._sa, self._sb] + list(gstreams):
+                t.record_stream(st)
+        for st in gstreams:
+            for t in (vs, state.u, state.sigma2, state.stream_state):
+                t.record_stream(st)
         return out
 
 
