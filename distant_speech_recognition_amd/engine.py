@@ -395,9 +395,7 @@ class NLMSState:
         return w
 
     def group_streams(self, G):
-        if self._streams is None or len(self._streams) < G:
-            self._streams = [torch.cuda.Stream(device=self.u.device) for _ in range(G)]
-        return self._streams[:G]
+        return side_streams(self.u.device, G)
 
 
 def nlms_process(vs, X, state, out=None, interleave=None):
@@ -423,7 +421,8 @@ def nlms_process(vs, X, state, out=None, interleave=None):
             raise _lib.BtkError(_lib.BTK_ERR_PARAMETER, "nlms_process: Nc = %d needs state.set_constraints(vs) first" % Nc)
         _check(cx, "cextra", torch.complex64, (K, Nc - 1, N))
     cxp = _ptr(state.cextra) if Nc > 1 else None
-    G, chunk = _nlms_interleave_plan(S, K, N, T, state) if interleave is None else interleave
+    plan = _nlms_interleave_plan(S, K, N, T, state) if interleave is None else tuple(interleave)
+    G, chunk, stagger = plan[0], plan[1], (plan[2] if len(plan) > 2 else True)
     if G <= 1:
         check(_lib.lib().btk_nlms_process_nc(_np_ptr(params), _ptr(vs), cxp, Nc, _ptr(X), _ptr(out),
                                              S, state.M, N, ts, T, _ptr(state.u), _ptr(state.sigma2), _ptr(state.stream_state),
@@ -440,10 +439,18 @@ def nlms_process(vs, X, state, out=None, interleave=None):
         lib = _lib.lib()
         for st in streams:
             st.wait_event(e0)
-        for a in range(0, T, chunk):
-            n = min(chunk, T - a)
-            for g, st in enumerate(streams):
-                _nlms_group_launch(lib, params, vs, cxp, Nc, X, out, ts, state, bounds[g], bounds[g + 1], a, n, g, chunk, st)
+        # group g's first chunk is (g + 1) / G of a chunk (in units of 64 frames): the groups' launch boundaries start out spread
+        # over the chunk period instead of coinciding
+        segs = []
+        for g in range(G):
+            first = max(64, (chunk * (g + 1) // G) // 64 * 64) if stagger else chunk
+            a = 0
+            while a < T:
+                n = min(first if a == 0 else chunk, T - a)
+                segs.append((a, g, n))
+                a += n
+        for a, g, n in sorted(segs):
+            _nlms_group_launch(lib, params, vs, cxp, Nc, X, out, ts, state, bounds[g], bounds[g + 1], a, n, g, chunk, streams[g])
         for st in streams:
             e = torch.cuda.Event()
             e.record(st)
@@ -452,6 +459,21 @@ def nlms_process(vs, X, state, out=None, interleave=None):
                 t.record_stream(st)
     state.frames_done = getattr(state, "frames_done", 0) + T
     return out
+
+
+# The engine's side HIP streams, ONE set per device shared by everything that forks work (interleaved canceller launches,
+# AdaptiveGSCChain): the runtime maps streams onto a handful of hardware queues (GPU_MAX_HW_QUEUES, 4 by default), and two streams
+# that land on one queue run their kernels in turn -- a second pair of streams created after the first made the chain's bank and
+# canceller share a queue (9.6 -> 10.7 ms in bench.py, 9.95 with 8 queues).
+_SIDE_STREAMS = {}
+
+
+def side_streams(device, n):
+    key = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
+    pool = _SIDE_STREAMS.setdefault(key, [])
+    while len(pool) < n:
+        pool.append(torch.cuda.Stream(device=device))
+    return pool[:n]
 
 
 def _nlms_group_launch(lib, params, vs, cxp, Nc, X, out, ts, state, s0, s1, a, n, g, chunk_cap, st):
@@ -470,21 +492,23 @@ def _nlms_group_launch(lib, params, vs, cxp, Nc, X, out, ts, state, s0, s1, a, n
 # bin groups = 2 080 workgroups at 64 channels are a round of 2 048 and a round of 32 that takes as long -- 5.0-5.3 ms where 31
 # streams take 3.85 (profiles/r06_nlms_residency.txt).  Cut into frame chunks and a few independent groups of streams on their own
 # HIP streams, the groups drift out of step, a group's stragglers run beside the next chunk of the others, and the chip stays
-# full: 3.8-4.1 ms, bit-identical (profiles/r06_nlms_interleave.txt; when the groups happen to stay in step it is the 5.3 again).
+# full: 3.75 ms, bit-identical.  Left to themselves the groups sometimes stay in step (one run in five: 5.3-5.6 ms again), so group g's
+# first chunk is shortened to (g + 1) / G of a chunk: two groups x 512 frames, staggered, 3.74-3.77 ms five times out of five
+# (profiles/r06_nlms_interleave.txt).
 _NLMS_RESIDENT = ((8, 8, 3072), (16, 4, 3072), (32, 4, 2048), (64, 4, 2048), (128, 2, 2048), (1 << 30, 1, 2048))
 
 
 def _nlms_interleave_plan(S, K, N, T, state):
-    """(groups, chunk_frames) for nlms_process: (1, T) = one launch"""
+    """(groups, chunk_frames, stagger) for nlms_process: (1, T, False) = one launch"""
     if os.environ.get("BTK_NLMS_INTERLEAVE", "1") == "0" or S < 4 or T < 512:
-        return 1, T
+        return 1, T, False
     if getattr(state, "frames_done", 0) % 64:
-        return 1, T                            # chunk boundaries must be multiples of 64 of the streams' frame counter
+        return 1, T, False                     # chunk boundaries must be multiples of 64 of the streams' frame counter
     bpw, slots = next((b, r) for n, b, r in _NLMS_RESIDENT if N <= n)
     nwg = S * ((K + bpw - 1) // bpw)
     if nwg <= slots:
-        return 1, T
-    return (4 if S >= 8 else 2), (512 if T >= 1024 else 256)
+        return 1, T, False
+    return 2, (512 if T >= 1024 else 256), True
 
 
 class AdaptiveGSCChain:
@@ -508,7 +532,7 @@ class AdaptiveGSCChain:
         """pcm [S][N][L]; X [S][K][N][T] and Y [S][K][T] (row-padded views allowed, same row pitch); returns the PCM blocks."""
         T = X.shape[-1]
         if self._sa is None:
-            self._sa, self._sb = torch.cuda.Stream(device=pcm.device), torch.cuda.Stream(device=pcm.device)
+            self._sa, self._sb = side_streams(pcm.device, 2)
         if out is None:
             # allocated on the CALLER's stream, where it is consumed: a block taken inside the side stream's context would belong to
             # that stream's pool and could be handed on while the caller still reads it
@@ -526,7 +550,7 @@ class AdaptiveGSCChain:
         G = 1 if self.groups is None else int(self.groups)    # (measured: no gain inside the chain, the bank's kernels already fill the gaps)
         if state.frames_done % 64:
             G = 1
-        gstreams = state.group_streams(G) if G > 1 else []
+        gstreams = side_streams(pcm.device, 2 + G)[2:] if G > 1 else []
         for st in gstreams:
             st.wait_event(ev0)
         if G > 1:

@@ -204,6 +204,15 @@ def test_c0_adaptive_chain_full_launch_properties(dev):
         assert torch.equal(out2, out) and torch.equal(Y2, Y) and torch.equal(st2.u, st.u) and torch.equal(st2.sigma2, st.sigma2)
         assert torch.equal(st2.stream_state, st.stream_state)
     del X2, Y2
+    # 1b. round 6: this launch (2 080 single-wavefront workgroups, 2 048 resident) runs by default as two staggered groups of streams
+    #     on two HIP streams in 512-frame chunks (engine._nlms_interleave_plan) -- the one-launch form and other groupings: same bits
+    assert eng._nlms_interleave_plan(S, K, N, T, fresh())[0] == 2
+    for plan in ((1, T), (4, 256, True), (2, 1024, False), (3, 448, True)):
+        st2 = fresh()
+        Y2 = eng.nlms_process(vs, X, st2, interleave=plan)
+        torch.cuda.synchronize()
+        assert torch.equal(Y2, Y) and torch.equal(st2.u, st.u) and torch.equal(st2.sigma2, st.sigma2) and torch.equal(st2.stream_state, st.stream_state), plan
+    del Y2
     # 2. a split in time (blocks of 1024 + 3072 frames) continues the recursion exactly
     st3 = fresh()
     Y3 = torch.cat([eng.nlms_process(vs, X[..., :1024].contiguous(), st3), eng.nlms_process(vs, X[..., 1024:].contiguous(), st3)], dim=-1)
