@@ -32,7 +32,14 @@ B=$R/distant_speech_recognition_amd/host/examples/node_api_bench
 for F in 8192 32768; do
   rocprofv3 --hip-trace --stats --output-format csv -d $O/hip_$F -o t -- $B /tmp/c512.f64 512 4 1 64 $F 1 1024 0 > $O/hip_$F.json 2> $O/hip_$F.err
 done
-for t in 1 2 4 8; do BTK_NODE_THREADS=$t $B /tmp/c512.f64 512 4 1 64 8192 1 8192 0; done > $O/node_api_threads.txt 2>&1
+for t in 1 2 4 8; do BTK_NODE_I16=0 BTK_NODE_THREADS=$t $B /tmp/c512.f64 512 4 1 64 8192 1 8192 0; done > $O/node_api_threads.txt 2>&1
+# the node API on 16-bit streams against the float path, with and without the next block's upload under the current one
+( for cfg in "1 1" "1 0" "0 0"; do set -- $cfg
+    echo "BTK_NODE_I16=$1 BTK_NODE_PREFETCH=$2: one graph, 32768 frames in blocks of 8192 | 8 graphs in a pool | 8 graphs one by one (8192 frames, blocks of 2048)"
+    BTK_NODE_I16=$1 BTK_NODE_PREFETCH=$2 $B /tmp/c512.f64 512 4 1 64 32768 1 8192 0
+    BTK_NODE_I16=$1 BTK_NODE_PREFETCH=$2 $B /tmp/c512.f64 512 4 1 64 8192 8 2048 1
+    BTK_NODE_I16=$1 BTK_NODE_PREFETCH=$2 $B /tmp/c512.f64 512 4 1 64 8192 8 2048 0
+  done ) > $O/node_api_i16.txt 2>&1
 cd $R
 python bench_stages.py > $O/bench_stages.json 2> $O/bench_stages.err
 python bench_configs.py > $O/bench_configs.json 2> $O/bench_configs.err
@@ -42,4 +49,9 @@ python profiles/wpe_envelope_probe.py 2>/dev/null | tail -1 > $O/wpe_envelope.tx
 BTK_WPE_LAGPROD_F32=1 python profiles/wpe_envelope_probe.py 2>/dev/null | tail -1 >> $O/wpe_envelope.txt
 WPE_S=2 bash profiles/scripts/r02_wpe_profile.sh > $O/wpe_profile.txt 2>&1
 python profiles/fused_big_ab.py > $O/fused_big_ab.txt 2>/dev/null
+python profiles/linpack_rule_time.py > $O/linpack_rule_time.json 2>/dev/null
+python profiles/csvdc_split.py > $O/csvdc_split.txt 2>/dev/null
+python profiles/nlms_residency_probe.py > $O/nlms_residency_probe.txt 2>/dev/null
+python profiles/nlms_stagger_probe.py > $O/nlms_stagger_probe.txt 2>/dev/null
+python profiles/adaptive_groups_ab.py > $O/adaptive_groups_ab.txt 2>/dev/null
 tail -1 $O/smoke.log; ls $O
