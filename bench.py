@@ -373,6 +373,7 @@ def main():
     vs = torch.from_numpy(np.stack([np.exp(-2j * np.pi * k * (FS / M) * delays) / N for k in range(K)]).astype(np.complex64)).to(dev)
     nst = eng.NLMSState(S, M, N, dev)
     t_nlms = _time(lambda: eng.nlms_process(vs, X, nst, out=Yc))
+    t_nlms_one = _time(lambda: eng.nlms_process(vs, X, nst, out=Yc, interleave=(1, T)))
 
     # the ADAPTIVE chain end to end (north_star's GSC with the NLMS canceller: analysis -> snapshots in HBM -> canceller ->
     # synthesis), at the headline launch and with the same number of frames laid out as four times as many, shorter streams (the
@@ -529,7 +530,11 @@ def main():
                 "synthesis": {"ms": t_syn * 1e3, "GBps": b_syn / t_syn / 1e9, "frac": b_syn / t_syn / HBM_PEAK},
                 "adaptive_nlms_canceller": {"ms": t_nlms * 1e3, "GBps": b_bf / t_nlms / 1e9, "frac": b_bf / t_nlms / HBM_PEAK,
                                             "frames_per_s": S * T / t_nlms,
-                                            "note": "sequential recursion per (stream, bin): %d streams = %.1f wavefronts per SIMD" % (S, S * K / 4 / 1024.0)},
+                                            "one_launch_ms": t_nlms_one * 1e3,
+                                            "note": "sequential recursion per (stream, bin): %d streams x %d bin groups = %d single-wavefront workgroups, "
+                                                    "2048 resident (249 VGPRs); engine.nlms_process runs a launch beyond that as two staggered groups of "
+                                                    "streams on two HIP streams in 512-frame chunks (bit-identical); one_launch_ms = the same work as ONE "
+                                                    "launch (rounds 2-5)" % (S, (K + 3) // 4, S * ((K + 3) // 4))},
                 "adaptive_chain": {"ms": t_chain * 1e3, "frames_per_s": S * T / t_chain, "xRT": S * T / t_chain / (FS / D),
                                    "what": "analysis -> snapshots [S][K][N][T] in HBM -> NLMS sidelobe canceller -> synthesis, end to end, "
                                            "%d streams x %d frames" % (S, T),
