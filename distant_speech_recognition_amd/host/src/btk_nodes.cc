@@ -390,13 +390,19 @@ void SampleFeature::set_samples(const float* samples, size_t n)
   (void)pcm16();                       // load time, like read(): the 16-bit view of the utterance (a WAV is 16-bit PCM to begin with)
 }
 
+static bool node_i16_enabled()                        // BTK_NODE_I16=0: no 16-bit views, no 16-bit streams (read whenever it matters)
+{
+  const char* e = getenv("BTK_NODE_I16");
+  return !(e && *e == '0');
+}
+
 // The loaded samples as 16-bit PCM (feature/feature.h): every sample must be an integer of the int16 range for the filter bank
 // to see the same values either way.  (-0.0f counts as 0: a WAV read never produces it, numpy.rint does.  The only trace it could
 // leave is the SIGN of an exactly-zero polyphase sum -- all m samples of a tap column zero and at least one of them -0.0f.)
 const short* SampleFeature::pcm16()
 {
   const size_t sz = size();
-  if (!have_samples_ || samples_.empty() || shiftLen_ != sz || sz == 0) return NULL;
+  if (!have_samples_ || samples_.empty() || shiftLen_ != sz || sz == 0 || !node_i16_enabled()) return NULL;
   if (pcm16_state_ == 0) {
     const size_t n = samples_.size(), padded = (n / sz + 3) * sz;
     short* q = NULL;
@@ -1430,11 +1436,6 @@ const float* SubbandBeamformer::pcm_f32_()
   return d;
 }
 
-static bool node_i16_enabled()
-{
-  const char* e = getenv("BTK_NODE_I16");
-  return !(e && *e == '0');
-}
 
 bool SubbandBeamformer::i16_stream_possible()
 {
