@@ -438,6 +438,17 @@ class SubbandGraphPool : public Countable {
     bool has_out;
   };
   bool load_round_();
+  // one round's input on its way to the device: every live graph's block plan and its sample windows in one block [G][N][Lmax]
+  struct Stage {
+    std::vector<SubbandBeamformer::BlockPlan> plans;
+    std::vector<long> T;          // frames of graph g in the round (0: none)
+    long Lmax, Tmax, t0, f0;
+    bool valid;
+    Stage() : Lmax(0), Tmax(0), t0(-1), f0(-1), valid(false) {}
+  };
+  void stage_round_(Stage& st, DeviceBuffer& buf, void* stream);   // pulls the banks, plans, issues the uploads on `stream`
+  Stage pre_;                     // 16-bit streams: the round after the current one, staged while the current one is served
+  DeviceBuffer dPcmNext_;
   std::vector<Graph> graphs_;
   long rounds_, base_, prev_T_, prev_Lw_, prev_Lp_, prev_hist_, blk_base_, out_stride_;
   bool first_round_;

@@ -3317,6 +3317,7 @@ SubbandGraphPool::SubbandGraphPool()
 
 SubbandGraphPool::~SubbandGraphPool()
 {
+  if (pre_.valid) (void)hipStreamSynchronize(cstream());
   for (size_t g = 0; g < graphs_.size(); g++) gsl_vector_float_free(graphs_[g].out);
 }
 
@@ -3351,6 +3352,7 @@ void SubbandGraphPool::add(SubbandDSPtr& beamformer, OverSampledDFTSynthesisBank
 
 void SubbandGraphPool::reset()
 {
+  if (pre_.valid) { (void)hipStreamSynchronize(cstream()); pre_.valid = false; }      // copies of a round nobody will ask for
   for (size_t g = 0; g < graphs_.size(); g++) {
     graphs_[g].syn->reset();                                  // resets the whole graph behind it
     graphs_[g].live = true; graphs_[g].T = 0; graphs_[g].nblocks = 0; graphs_[g].served = 0; graphs_[g].has_out = false;
@@ -3359,7 +3361,62 @@ void SubbandGraphPool::reset()
   i16_ = false;
 }
 
-// One round: every live graph's banks pull a block of input; one upload block, one fused launch, one synthesis launch.
+// The input of one round: every live graph's banks pull a block of input and the sample windows of all graphs go into one block
+// [G][N][Lmax] of `buf` (rows of 16 bytes for the fused kernel's vector loads, zero behind a shorter -- ending -- stream), copies
+// issued on `stream`.  A graph's windows start their way up as soon as its banks have pulled their input, under the pulling of
+// the next graph: the first graph says how long the rows will be, and only if a later one turns out longer the copies are made
+// again.  Marks graphs whose stream ends with this round as no longer live.
+void SubbandGraphPool::stage_round_(Stage& st, DeviceBuffer& buf, void* stream_v)
+{
+  hipStream_t stream = static_cast<hipStream_t>(stream_v);
+  const size_t G = graphs_.size();
+  SubbandDS* b0 = graphs_[0].bf.operator->();
+  const unsigned N = b0->chanN();
+  const size_t es = i16_ ? sizeof(short) : sizeof(float);
+  const long q = i16_ ? 8 : 4;                                 // rows of 16 bytes
+  st.plans.assign(G, SubbandBeamformer::BlockPlan());
+  st.T.assign(G, 0);
+  st.Lmax = 0; st.Tmax = 0; st.t0 = -1; st.f0 = -1; st.valid = true;
+  long Lprov = 0;
+  char* dPcm = NULL;
+  auto upload = [&](size_t g, long pitch) {
+    SubbandDS* bf = graphs_[g].bf.operator->();
+    const SubbandBeamformer::BlockPlan& p = st.plans[g];
+    char* slice = dPcm + es * g * (size_t)N * pitch;
+    if (p.L < pitch)
+      check_hip(hipMemset2DAsync(slice + es * p.L, es * pitch, 0, es * (pitch - p.L), N, stream), "hipMemset2DAsync");
+    for (unsigned c = 0; c < N; c++)
+      check_hip(hipMemcpyAsync(slice + es * (size_t)c * pitch,
+                               i16_ ? static_cast<const void*>(bf->bank(c)->window16(p.b0)) : static_cast<const void*>(bf->bank(c)->window(p.b0)),
+                               es * p.L, hipMemcpyHostToDevice, stream), "hipMemcpyAsync H2D");
+  };
+  for (size_t g = 0; g < G; g++) {
+    Graph& gr = graphs_[g];
+    if (!gr.live) continue;
+    SubbandDS* bf = gr.bf.operator->();
+    if (!bf->banks_only()) throw jconsistency_error("SubbandGraphPool: the channels of %s changed\n", bf->name().c_str());
+    bf->plan_bank_block(st.plans[g]);
+    const SubbandBeamformer::BlockPlan& p = st.plans[g];
+    if (p.T > 0) {
+      if (st.f0 >= 0 && (p.f0 != st.f0 || p.f0 - p.b0 != st.t0))
+        throw jconsistency_error("SubbandGraphPool: graph %d is at frame %ld, the others at %ld -- the graphs of a pool advance in lock step\n", (int)g, p.f0, st.f0);
+      st.f0 = p.f0; st.t0 = p.f0 - p.b0;
+      st.Lmax = std::max(st.Lmax, p.L); st.Tmax = std::max(st.Tmax, p.T);
+      if (!dPcm) { Lprov = (p.L + q - 1) / q * q; dPcm = static_cast<char*>(buf.ensure(es * G * N * (Lprov ? Lprov : q))); }
+      if (p.L <= Lprov) upload(g, Lprov);
+    }
+    st.T[g] = p.T;
+    if (p.ended) gr.live = false;
+  }
+  st.Lmax = (st.Lmax + q - 1) / q * q;
+  if (st.Tmax > 0 && st.Lmax != Lprov) {
+    check_hip(hipStreamSynchronize(stream), "hipStreamSynchronize");
+    dPcm = static_cast<char*>(buf.ensure(es * G * N * st.Lmax));
+    for (size_t g = 0; g < G; g++) if (st.T[g] > 0) upload(g, st.Lmax);
+  }
+}
+
+// One round: the staged input (stage_round_ -- staged ahead in a 16-bit stream), one fused launch, one synthesis launch.
 // false: no graph had a frame left.
 bool SubbandGraphPool::load_round_()
 {
@@ -3370,58 +3427,30 @@ bool SubbandGraphPool::load_round_()
   const unsigned N = b0->chanN(), M = b0->fftLen(), K = M / 2 + 1, D = s0->shiftlen(), R = 1u << s0->r();
   const long pd = btk_fb_processing_delay(s0->plan());
   const long H = std::max<long>((long)s0->m() * R + R, pd);    // frames of history a round's first block reaches back to
-  std::vector<SubbandBeamformer::BlockPlan> plans(G);
-  long Lmax = 0, Tmax = 0, t0 = -1, f0 = -1, Lprov = 0;
-  char* dPcm = NULL;
   if (first_round_) {
     // the streams begin: 16-bit PCM if every source of every graph holds it (SampleFeature::pcm16) and the geometry has the entry
     i16_ = btk_fb_analysis_bf_i16_fused(b0->bank(0)->plan()) == 1;
     for (size_t g = 0; g < G && i16_; g++) i16_ = graphs_[g].bf->i16_stream_possible();
     if (i16_) for (size_t g = 0; g < G; g++) graphs_[g].bf->begin_i16_stream();
+    pre_.valid = false;
   }
-  const size_t es = i16_ ? sizeof(short) : sizeof(float);
-  const long q = i16_ ? 8 : 4;                                 // rows of 16 bytes
-  // the sample windows of every graph go into one block [G][N][Lmax] (rows of 16 bytes for the fused kernel's vector loads, zero
-  // behind a shorter -- ending -- stream).  A graph's windows start their way up as soon as its banks have pulled their input,
-  // under the pulling of the next graph: the first graph says how long the rows will be, and only if a later one turns out longer
-  // the copies are made again.
-  auto upload = [&](size_t g, long pitch) {
-    SubbandDS* bf = graphs_[g].bf.operator->();
-    const SubbandBeamformer::BlockPlan& p = plans[g];
-    char* slice = dPcm + es * g * (size_t)N * pitch;
-    if (p.L < pitch)
-      check_hip(hipMemset2DAsync(slice + es * p.L, es * pitch, 0, es * (pitch - p.L), N, nstream()), "hipMemset2DAsync");
-    for (unsigned c = 0; c < N; c++)
-      h2d_async(slice + es * (size_t)c * pitch, i16_ ? static_cast<const void*>(bf->bank(c)->window16(p.b0)) : static_cast<const void*>(bf->bank(c)->window(p.b0)),
-                es * p.L);
-  };
-  for (size_t g = 0; g < G; g++) {
-    Graph& gr = graphs_[g];
-    gr.T = 0; gr.nblocks = 0; gr.served = 0;
-    if (!gr.live) continue;
-    SubbandDS* bf = gr.bf.operator->();
-    if (!bf->banks_only()) throw jconsistency_error("SubbandGraphPool: the channels of %s changed\n", bf->name().c_str());
-    bf->plan_bank_block(plans[g]);
-    const SubbandBeamformer::BlockPlan& p = plans[g];
-    if (p.T > 0) {
-      if (f0 >= 0 && (p.f0 != f0 || p.f0 - p.b0 != t0))
-        throw jconsistency_error("SubbandGraphPool: graph %d is at frame %ld, the others at %ld -- the graphs of a pool advance in lock step\n", (int)g, p.f0, f0);
-      f0 = p.f0; t0 = p.f0 - p.b0;
-      Lmax = std::max(Lmax, p.L); Tmax = std::max(Tmax, p.T);
-      if (!dPcm) { Lprov = (p.L + q - 1) / q * q; dPcm = static_cast<char*>(dPcm_.ensure(es * G * N * (Lprov ? Lprov : q))); }
-      if (p.L <= Lprov) upload(g, Lprov);
-    }
-    gr.T = p.T;
-    if (p.ended) gr.live = false;
-  }
-  if (Tmax == 0) return false;                                 // (a plan without frames is the end of its stream)
-  Lmax = (Lmax + q - 1) / q * q;
+  for (size_t g = 0; g < G; g++) { graphs_[g].T = 0; graphs_[g].nblocks = 0; graphs_[g].served = 0; }
+  Stage cur;
   std::chrono::steady_clock::time_point tu0 = std::chrono::steady_clock::now();
-  if (Lmax != Lprov) {
-    nsync();
-    dPcm = static_cast<char*>(dPcm_.ensure(es * G * N * Lmax));
-    for (size_t g = 0; g < G; g++) if (graphs_[g].T > 0) upload(g, Lmax);
+  if (pre_.valid) {
+    // staged while the round before was served (16-bit streams): the copies run on the thread's second stream
+    check_hip(hipStreamSynchronize(cstream()), "hipStreamSynchronize");
+    cur = pre_;
+    pre_.valid = false;
+    dPcm_.swap(dPcmNext_);
+  } else {
+    stage_round_(cur, dPcm_, nstream());
   }
+  if (cur.Tmax == 0) return false;                             // (a plan without frames is the end of its stream)
+  const std::vector<SubbandBeamformer::BlockPlan>& plans = cur.plans;
+  const long Lmax = cur.Lmax, Tmax = cur.Tmax, t0 = cur.t0, f0 = cur.f0;
+  const char* dPcm = static_cast<const char*>(dPcm_.get());
+  for (size_t g = 0; g < G; g++) graphs_[g].T = cur.T[g];
   // ---- per-stream weights [G][K][N], from the weight objects as they are now
   float* hW = static_cast<float*>(hW_.ensure(sizeof(float) * 2 * G * K * N));
   std::vector<float> w;
@@ -3454,6 +3483,14 @@ bool SubbandGraphPool::load_round_()
   else
     check_abi(btk_fb_analysis_bf(b0->bank(0)->plan(), reinterpret_cast<const float*>(dPcm), Lmax, Lmax, (int)G, (int)N, dW, 1,
                                  win + sizeof(float) * 2 * keep, Lp, t0, Tmax, scratch, sb, nstream()));
+  // ---- 16-bit streams: the NEXT round's input is staged now -- its sources only move on, the copies go to the other buffer on the
+  //      thread's second stream -- under this round's kernels, download and the serving of its blocks (BTK_NODE_PREFETCH=0: off)
+  {
+    static const bool off = getenv("BTK_NODE_PREFETCH") && atoi(getenv("BTK_NODE_PREFETCH")) == 0;
+    bool more = false;
+    for (size_t g = 0; g < G; g++) if (graphs_[g].live) more = true;
+    if (i16_ && more && !off) stage_round_(pre_, dPcmNext_, cstream());
+  }
   // ---- the output blocks whose newest input frame lies in this round (block b reads the frames b + pd - (m R - 1) .. b + pd)
   const long b_first = std::max<long>(0, base_ - pd), b_end = base_ + Tmax - pd;
   const long nb = b_end > b_first ? b_end - b_first : 0;
@@ -3493,7 +3530,7 @@ bool SubbandGraphPool::next()
     for (size_t g = 0; g < graphs_.size(); g++) if (graphs_[g].served < graphs_[g].nblocks) any = true;
     if (any) break;
     // the round is used up (or was too short to complete a block: a first round under the synthesis delay): the next one
-    bool more = false;
+    bool more = pre_.valid;                                   // (a staged round may be the last one of streams that are no longer live)
     for (size_t g = 0; g < graphs_.size(); g++) if (graphs_[g].live) more = true;
     if (!more || !load_round_()) {
       for (size_t g = 0; g < graphs_.size(); g++) { graphs_[g].has_out = false; graphs_[g].nblocks = 0; graphs_[g].served = 0; }
