@@ -77,6 +77,7 @@ SIGNATURES = {
     "btk_pcm_i16_to_f32": (_i, [_vp, _vp, _l, _vp]),
     "btk_pcm_f32_to_i16": (_i, [_vp, _vp, _l, _vp]),
     "btk_pcm_i16_deinterleave": (_i, [_vp, _vp, _l, _i, _l, _vp]),
+    "btk_gather_rows": (_i, [_vp, _vp, _i, _l, _vp]),
     "btk_cov_frame_gate": (_i, [_vp, _vp, _i, _l, _l, _f, _vp, _vp, _vp]),
     "btk_cov_accumulate": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _l, _l, _i, _vp]),
     "btk_cov_finalize": (_i, [_vp, _vp, _i, _i, _i, _i, _f, _vp]),

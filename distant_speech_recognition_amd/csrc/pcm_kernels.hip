@@ -57,7 +57,67 @@ void pcm_i16_deinterleave_kernel(const short* __restrict__ in, float* __restrict
   }
 }
 
+// Rows that lie in SEPARATE host allocations (one per channel node: every SampleFeature owns its utterance) -> one device block.
+// A hipMemcpyAsync per row costs the API call and the DMA engine's set-up per row: 2 048 rows of 0.5 MB (32 graphs x 64 channels
+// of a round) arrive at 27 GB/s, rows of 4 MB at 49 (profiles/r06_ubench_host_gather.txt).  One kernel that reads the pinned host
+// memory itself, through a table of row pointers that also lies in pinned memory, runs at the link's 57 GB/s whatever the rows'
+// length: 16-byte loads, four in flight per thread, the bytes behind a shorter row zeroed.
+// The launch is a FIXED, small number of workgroups that walk the (row, 16 KB piece) items in contiguous runs: the kernel's
+// wavefronts wait on the link for milliseconds, and a grid that fills every wavefront slot of the chip (the first form: 2 048
+// workgroups) keeps the kernels of the block BEFORE from starting -- the upload is there to run under them.
+__global__ __launch_bounds__(256)
+void gather_rows_kernel(const btk_row_t* __restrict__ table, char* __restrict__ dst, long dst_pitch, long pieces_per_row, long items)
+{
+  const long per_wg = (items + gridDim.x - 1) / gridDim.x;
+  const long it0 = blockIdx.x * per_wg, it1 = it0 + per_wg < items ? it0 + per_wg : items;
+  const long p16 = dst_pitch >> 4;
+  long row = -1, n16 = 0, tail = 0, skip = -1;
+  const uint4* s = nullptr;
+  uint4* d = nullptr;
+  for (long it = it0; it < it1; it++) {
+    const long r = it / pieces_per_row, piece = it - r * pieces_per_row;
+    if (r != row) {                                            // (a table entry crosses the link once per run of a row's pieces)
+      row = r;
+      const btk_row_t e = table[row];
+      n16 = e.bytes >> 4; tail = e.bytes & 15;
+      skip = tail ? n16 : -1;                                  // the partial word of the row is written below, by one place only
+      s = static_cast<const uint4*>(e.src);
+      d = reinterpret_cast<uint4*>(dst + row * dst_pitch);
+    }
+    const long i = piece * 1024 + threadIdx.x;
+    uint4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) { const long j = i + 256 * u; v[u] = j < n16 ? s[j] : make_uint4(0u, 0u, 0u, 0u); }
+#pragma unroll
+    for (int u = 0; u < 4; u++) { const long j = i + 256 * u; if (j < p16 && j != skip) d[j] = v[u]; }
+    // the last, partial 16-byte word of a row whose length is no multiple of 16 (its 2-byte samples one by one; zeros behind them)
+    if (tail && piece == n16 / 1024 && threadIdx.x < 8) {
+      const unsigned short* s2 = reinterpret_cast<const unsigned short*>(s + n16);
+      unsigned short* d2 = reinterpret_cast<unsigned short*>(d + n16);
+      d2[threadIdx.x] = (long)threadIdx.x * 2 < tail ? s2[threadIdx.x] : (unsigned short)0;
+    }
+  }
+}
+
 }  // namespace
+
+extern "C" int btk_gather_rows(const btk_row_t* table, void* dst, int nrows, long dst_pitch_bytes, void* stream)
+{
+  if (nrows < 0 || dst_pitch_bytes < 0 || (nrows > 0 && (!table || !dst))) return btk_set_error(BTK_ERR_PARAMETER, "btk_gather_rows: bad argument");
+  if ((dst_pitch_bytes & 15) || (reinterpret_cast<uintptr_t>(dst) & 15))
+    return btk_set_error(BTK_ERR_PARAMETER, "btk_gather_rows: dst and dst_pitch_bytes must be multiples of 16");
+  if (nrows == 0 || dst_pitch_bytes == 0) return BTK_OK;
+  // 16 KB pieces, walked by a fixed number of workgroups (BTK_GATHER_WGS: measurement knob)
+  static const int wgs_env = getenv("BTK_GATHER_WGS") ? atoi(getenv("BTK_GATHER_WGS")) : 0;
+  const long ppr = (dst_pitch_bytes / 16 + 1023) / 1024;
+  const long items = (long)nrows * ppr;
+  long wgs = wgs_env > 0 ? wgs_env : 64;     // (32 ... 128 measure alike and best, 256 and more get in the kernels' way: profiles/r06_node_api_gather.txt)
+  if (wgs > items) wgs = items;
+  hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)wgs), dim3(256), 0, as_stream(stream), table, static_cast<char*>(dst),
+                     dst_pitch_bytes, ppr, items);
+  BTK_HIP_CHECK(hipGetLastError());
+  return BTK_OK;
+}
 
 extern "C" int btk_pcm_i16_deinterleave(const short* in, float* out, long L, int N, long out_stride, void* stream)
 {

@@ -200,6 +200,7 @@ class SubbandBeamformer : public VectorComplexFeatureStream {
   BlockPlan pre_plan_;
   long pre_pitch_;
   PinnedBuffer hStage_;           // channels that are pulled frame by frame: the transposed block on its way up
+  PinnedBuffer hRows_;            // where the channels' sample rows lie on the host: the table of the upload (btk_gather_rows)
   long pcm_L_, pcm_t0_;           // the resident PCM windows [N][pcm_L_]; stream frame chunk_base_ is frame pcm_t0_ of the window
   bool pcm_valid_, snap_valid_, snapshots_wanted_;
 };
@@ -454,6 +455,6 @@ class SubbandGraphPool : public Countable {
   bool first_round_;
   bool i16_;                      // the current streams go up as 16-bit PCM (every graph's sources hold it; decided in the first round)
   DeviceBuffer dPcm_, dW_, dWinA_, dWinB_, dOut_, dScratch_;
-  PinnedBuffer hW_, hOut_;
+  PinnedBuffer hW_, hOut_, hRows_;
 };
 typedef refcountable_ptr<SubbandGraphPool> SubbandGraphPoolPtr;

@@ -182,6 +182,28 @@ void d2d_async(void* dst, const void* src, size_t n)
 {
   if (n) check_hip(hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToDevice, nstream()), "hipMemcpyAsync D2D");
 }
+// n rows of `bytes` bytes that lie in SEPARATE pinned allocations (every channel's source owns its utterance) -> rows `pitch` bytes
+// apart of one device block, on `stream`; the bytes of a row behind `bytes` are zeroed.  `tab` [pinned, n entries, src filled in by
+// the caller] and the rows stay untouched until the stream has passed the call.  ONE kernel that reads the host memory through the
+// table (btk_gather_rows: the link's 57 GB/s whatever the rows' length) where a copy per row reaches 27 GB/s at 0.5 MB per row and
+// 49 at 4 MB (profiles/r06_ubench_host_gather.txt); rows that are not 16-byte aligned -- a shift length that is no multiple of 8
+// samples -- take the copies.  BTK_NODE_GATHER=0: always the copies.
+void upload_rows(btk_row_t* tab, unsigned n, size_t bytes, char* dst, size_t pitch, hipStream_t stream)
+{
+  static const bool off = getenv("BTK_NODE_GATHER") && atoi(getenv("BTK_NODE_GATHER")) == 0;
+  if (!n || !pitch) return;
+  bool aligned = !off && ((reinterpret_cast<uintptr_t>(dst) | pitch) & 15) == 0;
+  for (unsigned c = 0; c < n && aligned; c++) aligned = (reinterpret_cast<uintptr_t>(tab[c].src) & 15) == 0;
+  if (aligned) {
+    for (unsigned c = 0; c < n; c++) tab[c].bytes = (long)bytes;
+    check_abi(btk_gather_rows(tab, dst, (int)n, (long)pitch, stream));
+    return;
+  }
+  if (bytes < pitch) check_hip(hipMemset2DAsync(dst + bytes, pitch, 0, pitch - bytes, n, stream), "hipMemset2DAsync");
+  if (bytes)
+    for (unsigned c = 0; c < n; c++)
+      check_hip(hipMemcpyAsync(dst + (size_t)c * pitch, tab[c].src, bytes, hipMemcpyHostToDevice, stream), "hipMemcpyAsync H2D");
+}
 // rows x width bytes between two pitched device arrays
 void d2d_2d_async(void* dst, size_t dpitch, const void* src, size_t spitch, size_t width, size_t rows)
 {
@@ -1552,9 +1574,9 @@ void SubbandBeamformer::prefetch_next_(const BlockPlan& cur)
     // copies that wait on an event of another stream ran at 37 instead of 53 GB/s)
     char* dp = static_cast<char*>(dPcm16Next_.ensure(sizeof(short) * N * (pre_pitch_ ? pre_pitch_ : 8)));
     nsync();                                                       // (cheap: the stream is idle at this point in a pulled graph)
-    for (unsigned c = 0; c < N; c++)
-      check_hip(hipMemcpyAsync(dp + sizeof(short) * (size_t)c * pre_pitch_, banks_[c]->window16(pn.b0), sizeof(short) * pn.L,
-                               hipMemcpyHostToDevice, cstream()), "hipMemcpyAsync H2D");
+    btk_row_t* tab = static_cast<btk_row_t*>(hRows_.ensure(sizeof(btk_row_t) * N));   // (no upload of this node is in flight here)
+    for (unsigned c = 0; c < N; c++) tab[c].src = banks_[c]->window16(pn.b0);
+    upload_rows(tab, N, sizeof(short) * pn.L, dp, sizeof(short) * pre_pitch_, cstream());
   }
   pre_valid_ = true;
 }
@@ -1599,12 +1621,19 @@ bool SubbandBeamformer::load_chunk_()
     plan_from_pulled_(p0, 1);
     const long pitch0 = pitch_of(p0.L);
     if (p0.T > 0) dp = static_cast<char*>(dbuf.ensure(es * N * (pitch0 ? pitch0 : 8)));
+    // (the table of the rows' addresses: no upload of this node is in flight when a block begins -- the one before ended with a wait)
+    btk_row_t* tab = static_cast<btk_row_t*>(hRows_.ensure(sizeof(btk_row_t) * N));
     for (unsigned g0 = 0; g0 < N; g0 += G) {
       const unsigned g1 = std::min(g0 + G, N);
       if (g0 > 0) pull_banks_(g0, g1);
-      for (unsigned c = g0; c < g1; c++)
-        if (p0.T > 0 && banks_[c]->window_first_block() <= p0.b0 && (banks_[c]->blocks_pulled() - p0.b0) * (long)banks_[c]->shiftlen() >= p0.L)
-          h2d_async(dp + es * (size_t)c * pitch0, row(c, p0.b0), es * p0.L);
+      bool whole = p0.T > 0;
+      for (unsigned c = g0; c < g1 && whole; c++)
+        whole = banks_[c]->window_first_block() <= p0.b0 && (banks_[c]->blocks_pulled() - p0.b0) * (long)banks_[c]->shiftlen() >= p0.L;
+      if (whole) {
+        // (a group whose every bank holds the first bank's block: one gather of its rows; any other group waits for the final plan)
+        for (unsigned c = g0; c < g1; c++) tab[c].src = row(c, p0.b0);
+        upload_rows(tab + g0, g1 - g0, es * p0.L, dp + es * (size_t)g0 * pitch0, es * pitch0, nstream());
+      }
     }
     plan_from_pulled_(p, N);
     long pitch = pitch0;
@@ -1614,7 +1643,8 @@ bool SubbandBeamformer::load_chunk_()
         nsync();
         pitch = pitch_of(p.L);
         dp = static_cast<char*>(dbuf.ensure(es * N * (pitch ? pitch : 8)));
-        for (unsigned c = 0; c < N; c++) h2d_async(dp + es * (size_t)c * pitch, row(c, p.b0), es * p.L);
+        for (unsigned c = 0; c < N; c++) tab[c].src = row(c, p.b0);
+        upload_rows(tab, N, es * p.L, dp, es * pitch, nstream());
       }
       nsync();                                                   // before the banks move their windows on
     }
@@ -3379,16 +3409,16 @@ void SubbandGraphPool::stage_round_(Stage& st, DeviceBuffer& buf, void* stream_v
   st.Lmax = 0; st.Tmax = 0; st.t0 = -1; st.f0 = -1; st.valid = true;
   long Lprov = 0;
   char* dPcm = NULL;
+  // (the table of the rows' addresses, a segment per graph: no upload of the pool is in flight when a round is staged -- the round
+  //  staged before has been waited for, on whichever stream it went)
+  btk_row_t* tab = static_cast<btk_row_t*>(hRows_.ensure(sizeof(btk_row_t) * G * N));
   auto upload = [&](size_t g, long pitch) {
     SubbandDS* bf = graphs_[g].bf.operator->();
     const SubbandBeamformer::BlockPlan& p = st.plans[g];
-    char* slice = dPcm + es * g * (size_t)N * pitch;
-    if (p.L < pitch)
-      check_hip(hipMemset2DAsync(slice + es * p.L, es * pitch, 0, es * (pitch - p.L), N, stream), "hipMemset2DAsync");
+    btk_row_t* t = tab + g * (size_t)N;
     for (unsigned c = 0; c < N; c++)
-      check_hip(hipMemcpyAsync(slice + es * (size_t)c * pitch,
-                               i16_ ? static_cast<const void*>(bf->bank(c)->window16(p.b0)) : static_cast<const void*>(bf->bank(c)->window(p.b0)),
-                               es * p.L, hipMemcpyHostToDevice, stream), "hipMemcpyAsync H2D");
+      t[c].src = i16_ ? static_cast<const void*>(bf->bank(c)->window16(p.b0)) : static_cast<const void*>(bf->bank(c)->window(p.b0));
+    upload_rows(t, N, es * p.L, dPcm + es * g * (size_t)N * pitch, es * pitch, stream);
   };
   for (size_t g = 0; g < G; g++) {
     Graph& gr = graphs_[g];

@@ -101,6 +101,16 @@ int  btk_pcm_f32_to_i16(const float* in, short* out, long n, void* stream);
  * one pass (SampleFeature::read copies channel chX out of the interleaved frames, once per channel node: feature/feature.cc:333-334). */
 int  btk_pcm_i16_deinterleave(const short* in, float* out, long L, int N, long out_stride, void* stream);
 
+/* Rows of samples that lie in SEPARATE host allocations -> one device block, by ONE kernel that reads the host memory itself
+ * (round 6; the node layer's 16-bit streams: every channel's SampleFeature owns its utterance, feature/feature.cc:238-389, and a
+ * block of a 64-channel graph -- or of 32 graphs -- is 64 ... 2 048 rows; a hipMemcpyAsync per row reaches 27 GB/s at 0.5 MB per row,
+ * the kernel the link's 57 GB/s at any row length).  table [PINNED host memory (hipHostMalloc: device-accessible) or dev]: nrows
+ * entries; src [pinned host or dev], 16-byte aligned, `bytes` valid bytes (a multiple of 2) -- it must stay untouched until the
+ * stream has passed the call, like the source of an asynchronous copy.  Row r goes to dst + r * dst_pitch_bytes [dev]; the bytes
+ * from `bytes` up to dst_pitch_bytes are zeroed (bytes <= dst_pitch_bytes).  dst and dst_pitch_bytes multiples of 16.            */
+typedef struct { const void* src; long bytes; } btk_row_t;
+int  btk_gather_rows(const btk_row_t* table, void* dst, int nrows, long dst_pitch_bytes, void* stream);
+
 /* ---- Fixed-weight beamformer apply ------------------------------------------------------
  * SubbandDS::next (beamformer/beamformer.cc:1095-1157), SubbandGSC::next + calc_gsc_output
  * (:1208-1316), SubbandMVDR::next (:2537-2587), SubbandMVDRGSC::next (:2720-2773):

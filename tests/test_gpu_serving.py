@@ -78,3 +78,45 @@ def test_pcm_deinterleave_kernel(dev):
         got = o.cpu().numpy()
         assert np.array_equal(got[:, :L], a.T.astype(np.float32))
         assert np.all(got[:, L:] == -7.0)                           # the padding of a row is not touched
+
+
+def test_gather_rows_kernel(dev):
+    """btk_gather_rows: rows in SEPARATE pinned host allocations -> one device block by one kernel that reads the host memory
+    through a pinned table: ragged lengths (0, below one 16-byte word, partial last word, exactly the pitch), the bytes behind a
+    row zeroed, many workgroups per row and one; device-resident rows work the same"""
+    import ctypes
+    import torch
+    from distant_speech_recognition_amd import _lib
+    rng = np.random.default_rng(5)
+    for nrows, pitch, lens in ((1, 16, [2]), (3, 64, [0, 14, 64]), (5, 4096 + 16, [4096 + 16, 4096 + 2, 4000, 18, 16]),
+                               (64, 1 << 20, None), (2048, 8192, None)):
+        if lens is None:
+            lens = [int(x) * 2 for x in rng.integers(0, pitch // 2 + 1, size=nrows)]
+            lens[0] = pitch
+        rows = [torch.from_numpy(rng.integers(0, 256, size=max(n, 2), dtype=np.uint8)).pin_memory() for n in lens]
+        tab = torch.zeros((nrows, 2), dtype=torch.int64).pin_memory()
+        for r, (t, n) in enumerate(zip(rows, lens)):
+            tab[r, 0] = t.data_ptr()
+            tab[r, 1] = n
+        out = torch.full((nrows, pitch), 0xAB, dtype=torch.uint8, device=dev)
+        _lib.check(_lib.lib().btk_gather_rows(tab.data_ptr(), out.data_ptr(), nrows, pitch, None))
+        torch.cuda.synchronize()
+        got = out.cpu().numpy()
+        for r, (t, n) in enumerate(zip(rows, lens)):
+            assert np.array_equal(got[r, :n], t.numpy()[:n]), (nrows, r, n)
+            assert not got[r, n:].any(), (nrows, r, n)
+        # the same rows resident on the device, the table too
+        drows = [t.to(dev) for t in rows]
+        dtab = tab.clone()
+        for r, t in enumerate(drows):
+            dtab[r, 0] = t.data_ptr()
+        dtab = dtab.to(dev)
+        out2 = torch.full((nrows, pitch), 0xCD, dtype=torch.uint8, device=dev)
+        _lib.check(_lib.lib().btk_gather_rows(dtab.data_ptr(), out2.data_ptr(), nrows, pitch, None))
+        assert torch.equal(out, out2)
+    # argument checks: a pitch or a destination that is no multiple of 16
+    out = torch.zeros(64, dtype=torch.uint8, device=dev)
+    tab = torch.zeros((1, 2), dtype=torch.int64).pin_memory()
+    assert _lib.lib().btk_gather_rows(tab.data_ptr(), out.data_ptr(), 1, 24, None) != 0
+    assert _lib.lib().btk_gather_rows(tab.data_ptr(), out.data_ptr() + 8, 1, 16, None) != 0
+    assert _lib.lib().btk_gather_rows(None, None, 0, 16, None) == 0
