@@ -213,6 +213,32 @@ def c5_frame_sharded_stage(torch, dist, dev, rank, world):
     return out
 
 
+def guarded_c5_stage(torch, dist, dev, rank, world, res, limit_s=300.0):
+    """c5_frame_sharded_stage under a timer.  The stage is made of collectives: a rank that fails alone leaves the others waiting
+    inside one, and the line would never be printed.  When the timer fires rank 0 prints the line it already holds (`res`) with the
+    stage marked as timed out, and every rank ends its process."""
+    import threading
+    done = threading.Event()
+
+    def fire():
+        if done.is_set():
+            return
+        if rank == 0:
+            res["stages"]["c5_frame_sharded"] = {"error": "no result within %.0f s (a rank failed or a collective hung): stage dropped" % limit_s}
+            print(json.dumps(res), flush=True)
+        os._exit(0)
+    timer = threading.Timer(limit_s, fire)
+    timer.daemon = True
+    timer.start()
+    try:
+        out = c5_frame_sharded_stage(torch, dist, dev, rank, world)
+    except Exception as e:
+        out = {"error": repr(e)}
+    done.set()
+    timer.cancel()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -404,14 +430,7 @@ def main():
         adaptive_wide = {"streams": S2, "frames_per_stream": T2, "ms": t2 * 1e3, "frames_per_s": S2 * T2 / t2, "xRT": S2 * T2 / t2 / (FS / D)}
         del pcm2, X2, Yc2, out2
 
-    # multi-GPU runs also carry the strong-scaling partition of C5 (all ranks take part; RCCL only)
-    c5_sharded = None
-    if dist and backend == "nccl":
-        try:
-            c5_sharded = c5_frame_sharded_stage(torch, dist, dev, rank, world)
-        except Exception as e:                                  # never let the extra stage cost the driver its headline line
-            c5_sharded = {"error": repr(e)}
-
+    res = None
     if rank == 0:
         frames_per_step = S * T * world
         value = frames_per_step * args.steps / elapsed
@@ -545,15 +564,22 @@ def main():
                                                            "HIP stream (engine.AdaptiveGSCChain); bit-identical output"},
             },
         }
-        if c5_sharded is not None:
-            res["stages"]["c5_frame_sharded"] = c5_sharded
         if not args.no_cpu and world == 1:
             res["stages"]["node_api"] = node_api_stage(h, g, N, M, m, r, value)
             res["cpu_baseline"] = cpu_baseline(N, M, m, r, dct, args.cpu_frames)
         else:
             res["cpu_baseline"] = None
-        print(json.dumps(res))
+    # multi-GPU runs also carry the strong-scaling partition of C5 (all ranks take part; RCCL only).  It runs LAST, with the line
+    # already complete on rank 0 and a timer armed: the extra stage must never cost the driver its headline line
+    if dist and backend == "nccl":
+        c5_sharded = guarded_c5_stage(torch, dist, dev, rank, world, res)
+        if rank == 0:
+            res["stages"]["c5_frame_sharded"] = c5_sharded
+    if rank == 0:
+        print(json.dumps(res), flush=True)
     if dist:
+        if backend == "nccl" and isinstance(c5_sharded, dict) and "error" in c5_sharded:
+            os._exit(0)                                         # (other ranks may still sit in a collective: no orderly shutdown to wait for)
         dist.destroy_process_group()
 
 

@@ -469,8 +469,12 @@ void analysis512_bfz_kernel(const PT* __restrict__ pcm, long nsamples, long pcm_
       for (int i = 0; i < NWG; i++) { const btk_f2v t = btk_buffer_load_i16x2_f32(rs, vo, i * D * 2, 0); win[i] = make_float2(t.x, t.y); }
       (void)wsrc;
     } else {
+      // (VAR & 2048, measurement: the window loads as non-temporal loads -- every sample is read once, the halo by a neighbour)
 #pragma unroll
-      for (int i = 0; i < NWG; i++) win[i] = *reinterpret_cast<const float2*>(wsrc + i * D);
+      for (int i = 0; i < NWG; i++) {
+        if constexpr ((VAR & 2048) != 0) { const f2 t = __builtin_nontemporal_load(reinterpret_cast<const f2*>(wsrc + i * D)); win[i] = make_float2(t.x, t.y); }
+        else win[i] = *reinterpret_cast<const float2*>(wsrc + i * D);
+      }
     }
   };
   // SHARED: the PCM span is staged through registers into the region the FFT frames overwrite (R = 1, and the edge
@@ -690,7 +694,10 @@ void analysis512_bfz_kernel(const PT* __restrict__ pcm, long nsamples, long pcm_
       float2* yo = Y + (long)s * K * T_stride + tt0 + f;
       const float2* zf = fbuf + f * FRZ;
 #pragma unroll 4
-      for (int it = 0; it < 16; it++) yo[(long)(kq + 16 * it) * T_stride] = zf[it * 17 + kq];
+      for (int it = 0; it < 16; it++) {
+        if constexpr ((VAR & 65536) != 0) __builtin_nontemporal_store(f2{zf[it * 17 + kq].x, zf[it * 17 + kq].y}, reinterpret_cast<f2*>(yo + (long)(kq + 16 * it) * T_stride));   // (measurement)
+        else yo[(long)(kq + 16 * it) * T_stride] = zf[it * 17 + kq];
+      }
       if (kq == 0) yo[(long)A_NF * T_stride] = reinterpret_cast<const float2*>(wq)[f];
     }
   }
@@ -755,6 +762,12 @@ int launch512_bf(const btk_fb* fb, const PT* pcm, long nsamples, long pcm_stride
   if (gw) kern = analysis512_bfz_kernel<2, 7>;
   if (t8) kern = analysis512_bfz_kernel<2, 7, 8>;
   if (gw && !t8 && (var & 8)) kern = (var & 16) ? analysis512_bfz_kernel<2, 31> : ((var & 64) ? ((var & 128) ? ((var & 256) ? ((var & 32768) ? analysis512_bfz_kernel<2, 33231> : analysis512_bfz_kernel<2, 463>) : analysis512_bfz_kernel<2, 207>) : analysis512_bfz_kernel<2, 79>) : analysis512_bfz_kernel<2, 15>);
+  }
+  // (measurement forms of the default kernel: 2048 = non-temporal window loads, 65536 = non-temporal stores of Y; profiles/r06_fused_nt.txt)
+  if constexpr (!I16) if (gw && !t8 && (var & 33231) == 33231) {
+    if ((var & 2048) && (var & 65536)) kern = analysis512_bfz_kernel<2, 33231 + 2048 + 65536>;
+    else if (var & 2048) kern = analysis512_bfz_kernel<2, 33231 + 2048>;
+    else if (var & 65536) kern = analysis512_bfz_kernel<2, 33231 + 65536>;
   }
 #ifdef BTK_FUSED_ABLATE
   if constexpr (!I16) if (gw && !t8) switch ((var >> 12) & 7) {
