@@ -695,7 +695,10 @@ void analysis512_bfz_kernel(const PT* __restrict__ pcm, long nsamples, long pcm_
       const float2* zf = fbuf + f * FRZ;
 #pragma unroll 4
       for (int it = 0; it < 16; it++) {
-        if constexpr ((VAR & 65536) != 0) __builtin_nontemporal_store(f2{zf[it * 17 + kq].x, zf[it * 17 + kq].y}, reinterpret_cast<f2*>(yo + (long)(kq + 16 * it) * T_stride));   // (measurement)
+        // non-temporal stores (round 6): Y is written once and read by another kernel -- 2.2 % faster when the rows are a multiple of
+        // 4 KiB apart (a C-ABI caller's contiguous [S][K][T] block with T a power of two), nothing when they are padded
+        // (engine.padded_rows); VAR & 65536 = plain stores, for measurement (profiles/r06_fused_nt.txt)
+        if constexpr ((VAR & 65536) == 0) __builtin_nontemporal_store(f2{zf[it * 17 + kq].x, zf[it * 17 + kq].y}, reinterpret_cast<f2*>(yo + (long)(kq + 16 * it) * T_stride));
         else yo[(long)(kq + 16 * it) * T_stride] = zf[it * 17 + kq];
       }
       if (kq == 0) yo[(long)A_NF * T_stride] = reinterpret_cast<const float2*>(wq)[f];
@@ -763,7 +766,8 @@ int launch512_bf(const btk_fb* fb, const PT* pcm, long nsamples, long pcm_stride
   if (t8) kern = analysis512_bfz_kernel<2, 7, 8>;
   if (gw && !t8 && (var & 8)) kern = (var & 16) ? analysis512_bfz_kernel<2, 31> : ((var & 64) ? ((var & 128) ? ((var & 256) ? ((var & 32768) ? analysis512_bfz_kernel<2, 33231> : analysis512_bfz_kernel<2, 463>) : analysis512_bfz_kernel<2, 207>) : analysis512_bfz_kernel<2, 79>) : analysis512_bfz_kernel<2, 15>);
   }
-  // (measurement forms of the default kernel: 2048 = non-temporal window loads, 65536 = non-temporal stores of Y; profiles/r06_fused_nt.txt)
+  // (measurement forms of the default kernel: 2048 = non-temporal window loads (7 % slower: the halo a neighbouring tile re-reads
+  //  no longer comes from L2), 65536 = plain instead of non-temporal stores of Y; profiles/r06_fused_nt.txt)
   if constexpr (!I16) if (gw && !t8 && (var & 33231) == 33231) {
     if ((var & 2048) && (var & 65536)) kern = analysis512_bfz_kernel<2, 33231 + 2048 + 65536>;
     else if (var & 2048) kern = analysis512_bfz_kernel<2, 33231 + 2048>;
