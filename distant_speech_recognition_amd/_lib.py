@@ -8,7 +8,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libbtkhip.so")
+# (BTK_LIB_PATH: a measurement build of the same library -- e.g. one compiled with -DBTK_EXP=...; never a fallback)
+LIB_PATH = os.environ.get("BTK_LIB_PATH") or os.path.join(_HERE, "csrc", "libbtkhip.so")
 
 _lib = None
 

@@ -32,7 +32,9 @@ void bf_apply_kernel(const float2* __restrict__ W, long w_stream_stride, const f
     float4 v[UNROLL];
 #pragma unroll
     for (int u = 0; u < UNROLL; u++) {
-      if (VEC == 2) v[u] = *reinterpret_cast<const float4*>(x + (long)(n + u) * T_stride);
+      // (non-temporal loads and stores: every snapshot is read once, Y is read by another kernel; C0 launch 2.91 -> 2.77 ms by the
+      //  loads, a further 3 % by the stores: profiles/r06_nt_hints.txt)
+      if (VEC == 2) v[u] = btk_ld<true>(reinterpret_cast<const float4*>(x + (long)(n + u) * T_stride));
       else { const float2 q = x[(long)(n + u) * T_stride]; v[u] = make_float4(q.x, q.y, 0.f, 0.f); }
     }
 #pragma unroll
@@ -63,7 +65,7 @@ void bf_apply_kernel(const float2* __restrict__ W, long w_stream_stride, const f
   }
   float2* y = Y + ((long)s * K + k) * T_stride + t;
   if (VEC == 2) {
-    if (t + 1 < T) *reinterpret_cast<float4*>(y) = make_float4(acc0.x, acc0.y, acc1.x, acc1.y);
+    if (t + 1 < T) btk_st<true>(reinterpret_cast<float4*>(y), make_float4(acc0.x, acc0.y, acc1.x, acc1.y));
     else y[0] = acc0;
   } else {
     y[0] = acc0;

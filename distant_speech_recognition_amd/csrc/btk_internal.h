@@ -43,6 +43,34 @@ static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream
 // hipcc has no builtin for the format loads; the LLVM intrinsic is reached by its name (the compiler keeps track of the load like
 // of any other: no hand-written waits).  Descriptor word 3 for __builtin_amdgcn_make_buffer_rsrc: dst_sel x = R, y = G, SSCALED, 16_16.
 typedef float btk_f2v __attribute__((ext_vector_type(2)));
+typedef float btk_f4v __attribute__((ext_vector_type(4)));
+// Cache-hint experiments (profiles/r06_nt_hints.txt): -DBTK_EXP=<bits> builds a library in which single global streams of the
+// bandwidth-bound kernels are non-temporal.  btk_ld<NT> / btk_st<NT>: a plain or a non-temporal 8- / 16-byte access.
+#ifndef BTK_EXP
+#define BTK_EXP 0
+#endif
+#if defined(__HIPCC__)
+template <bool NT> __device__ __forceinline__ float4 btk_ld(const float4* p)
+{
+  if constexpr (NT) { const btk_f4v t = __builtin_nontemporal_load(reinterpret_cast<const btk_f4v*>(p)); return make_float4(t.x, t.y, t.z, t.w); }
+  else return *p;
+}
+template <bool NT> __device__ __forceinline__ float2 btk_ld(const float2* p)
+{
+  if constexpr (NT) { const btk_f2v t = __builtin_nontemporal_load(reinterpret_cast<const btk_f2v*>(p)); return make_float2(t.x, t.y); }
+  else return *p;
+}
+template <bool NT> __device__ __forceinline__ void btk_st(float2* p, float2 v)
+{
+  if constexpr (NT) __builtin_nontemporal_store(btk_f2v{v.x, v.y}, reinterpret_cast<btk_f2v*>(p));
+  else *p = v;
+}
+template <bool NT> __device__ __forceinline__ void btk_st(float4* p, float4 v)
+{
+  if constexpr (NT) __builtin_nontemporal_store(btk_f4v{v.x, v.y, v.z, v.w}, reinterpret_cast<btk_f4v*>(p));
+  else *p = v;
+}
+#endif
 __device__ btk_f2v btk_buffer_load_i16x2_f32(__amdgpu_buffer_rsrc_t rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.ptr.buffer.load.format.v2f32");
 constexpr int BTK_RSRC_I16X2_SSCALED = 0x0002B02C;
 

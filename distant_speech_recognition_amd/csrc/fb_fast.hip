@@ -341,7 +341,7 @@ void fast_analysis_kernel(const float* __restrict__ pcm, long nsamples, long pcm
         const float2 o = make_float2(hg * (zk.y + zq.y), -hg * (zk.x - zq.x));
         const float2 w = twg[k];                                  // e^{+j 2 pi k / M}, L1-resident
         if (live && (!SHARD || (k >= k0 && k < k1)))
-          xo[(long)(k - (SHARD ? k0 : 0)) * kstride] = make_float2(e.x + (w.x * o.x - w.y * o.y), e.y + (w.x * o.y + w.y * o.x));
+          btk_st<false>(xo + (long)(k - (SHARD ? k0 : 0)) * kstride, make_float2(e.x + (w.x * o.x - w.y * o.y), e.y + (w.x * o.y + w.y * o.x)));
       }
       if (kq == 0 && live && (!SHARD || (NF >= k0 && NF < k1))) {
         const float2 z0 = zf[0];
@@ -959,7 +959,7 @@ void fast_synthesis_w_kernel(const float2* __restrict__ Y, long nframes, long T_
             }
             if (bglob >= bt0 && bglob < bend) {
               float* o = os + (bglob - b0) * D + (D - SPL - d0);
-              if constexpr (SPL == 4) *reinterpret_cast<float4*>(o) = make_float4(acc[3], acc[2], acc[1], acc[0]);
+              if constexpr (SPL == 4) btk_st<false>(reinterpret_cast<float4*>(o), make_float4(acc[3], acc[2], acc[1], acc[0]));
               else *reinterpret_cast<float2*>(o) = make_float2(acc[1], acc[0]);
             }
           }

@@ -388,7 +388,7 @@ void nlms_bin2_kernel(const float2* __restrict__ X, const float2* __restrict__ V
       for (int q = 0; q < NPASS; q++) {
 #pragma unroll
         for (int h = 0; h < NPF; h++)
-          pre[h][q] = *reinterpret_cast<const float4*>(base + (long)(q * RPP) * T_stride + h * TBF);
+          pre[h][q] = btk_ld<false>(reinterpret_cast<const float4*>(base + (long)(q * RPP) * T_stride + h * TBF));
       }
 #pragma unroll
       for (int h = 0; h < NPF; h++) creg[h] = ctrl[(long)s * T + tp + h * TBF + (lane % TBF)];

@@ -56,7 +56,7 @@ void bf_apply_stats_kernel(const float2* __restrict__ W, long w_stream_stride,
   for (; n + PF_UNROLL <= N; n += PF_UNROLL) {
     float2 v[PF_UNROLL];
 #pragma unroll
-    for (int u = 0; u < PF_UNROLL; u++) v[u] = x[(long)(n + u) * T_stride];
+    for (int u = 0; u < PF_UNROLL; u++) v[u] = btk_ld<true>(x + (long)(n + u) * T_stride);
 #pragma unroll
     for (int u = 0; u < PF_UNROLL; u++) step(n + u, v[u]);
   }
