@@ -12,6 +12,7 @@ cp $R/linpack_rule_time.json profiles/r06_linpack_rule_time.json
 (echo "# host/examples/node_api_bench (C0 graph: 64 SampleFeature -> 64 banks -> SubbandGSC -> synthesis, pulled with next()), second pass timed."; echo "# BTK_NODE_I16=1: utterances of 16-bit PCM go up as int16 from the sources' pinned copies (round 6); =0: float blocks through SampleFeature::next_blocks (round 5)."; echo "# BTK_NODE_PREFETCH=1: the next block's upload runs under the current block's kernels, download and serving."; cat $R/node_api_i16.txt) > profiles/r06_node_api_i16.txt
 (echo "# the float path of the node API against the number of helper threads that pull the SampleFeature sources (BTK_NODE_THREADS)"; cat $R/node_api_threads.txt) > profiles/r06_node_api_threads.txt
 (echo "# WPE estimate, reference configuration (8 ch x lags 0..32, 2 iterations, 1000 frames), 2 streams per call: rocprofv3 --kernel-trace --stats"; cat $R/wpe_profile.txt) > profiles/r06_wpe_kernel_stats.txt
+(echo "# final sources: node_api_bench with the block's rows going up by ONE gather kernel (BTK_NODE_GATHER=1, default) against one hipMemcpyAsync per row (=0); sweep of the kernel's launch: profiles/r06_node_api_gather.txt"; cat $R/node_api_gather.txt) > profiles/r06_node_api_gather_final.txt
 python - <<'PY'
 import csv, collections, json
 # HIP-API traces of the node-API bench at two stream lengths: calls per API and what a block costs in calls

@@ -40,6 +40,14 @@ for t in 1 2 4 8; do BTK_NODE_I16=0 BTK_NODE_THREADS=$t $B /tmp/c512.f64 512 4 1
     BTK_NODE_I16=$1 BTK_NODE_PREFETCH=$2 $B /tmp/c512.f64 512 4 1 64 8192 8 2048 1
     BTK_NODE_I16=$1 BTK_NODE_PREFETCH=$2 $B /tmp/c512.f64 512 4 1 64 8192 8 2048 0
   done ) > $O/node_api_i16.txt 2>&1
+# the rows of a block by one gather kernel (btk_gather_rows) against one copy per row
+( for g in 1 0; do
+    echo "BTK_NODE_GATHER=$g: one graph 32768 frames blocks of 8192 | 32 graphs x 2048 pool blocks 1024 | 8 graphs x 8192 pool blocks 2048 | 8 graphs one by one"
+    BTK_NODE_GATHER=$g $B /tmp/c512.f64 512 4 1 64 32768 1 8192 0
+    BTK_NODE_GATHER=$g $B /tmp/c512.f64 512 4 1 64 2048 32 1024 1
+    BTK_NODE_GATHER=$g $B /tmp/c512.f64 512 4 1 64 8192 8 2048 1
+    BTK_NODE_GATHER=$g $B /tmp/c512.f64 512 4 1 64 8192 8 2048 0
+  done ) > $O/node_api_gather.txt 2>&1
 cd $R
 python bench_stages.py > $O/bench_stages.json 2> $O/bench_stages.err
 python bench_configs.py > $O/bench_configs.json 2> $O/bench_configs.err
