@@ -190,7 +190,8 @@ void d2d_async(void* dst, const void* src, size_t n)
 // samples -- take the copies.  BTK_NODE_GATHER=0: always the copies.
 void upload_rows(btk_row_t* tab, unsigned n, size_t bytes, char* dst, size_t pitch, hipStream_t stream)
 {
-  static const bool off = getenv("BTK_NODE_GATHER") && atoi(getenv("BTK_NODE_GATHER")) == 0;
+  const char* env = getenv("BTK_NODE_GATHER");                      // (read per upload: a test switches it inside one process)
+  const bool off = env && atoi(env) == 0;
   if (!n || !pitch) return;
   bool aligned = !off && ((reinterpret_cast<uintptr_t>(dst) | pitch) & 15) == 0;
   for (unsigned c = 0; c < n && aligned; c++) aligned = (reinterpret_cast<uintptr_t>(tab[c].src) & 15) == 0;

@@ -276,3 +276,46 @@ def test_changing_the_samples_under_a_16_bit_stream_is_refused(dev):
     _, bf2, sfb2 = _graph(pcm2[0], h, g, M, m, r, delays, 32)
     ref = _pull(sfb2)
     assert bf.i16_stream() and _same_bits(out, ref)
+
+
+class _copies_per_row:
+    """BTK_NODE_GATHER=0: the rows of a block go up by one hipMemcpyAsync each instead of the gather kernel (read per upload)"""
+
+    def __enter__(self):
+        self.old = os.environ.get("BTK_NODE_GATHER")
+        os.environ["BTK_NODE_GATHER"] = "0"
+
+    def __exit__(self, *a):
+        if self.old is None:
+            del os.environ["BTK_NODE_GATHER"]
+        else:
+            os.environ["BTK_NODE_GATHER"] = self.old
+
+
+@pytest.mark.parametrize("i16", [True, False])
+@pytest.mark.parametrize("M,N,block_frames", [(512, 8, 37), (512, 64, 0), (1024, 8, 40)])
+def test_gather_upload_same_bits_as_copies_per_row(dev, M, N, block_frames, i16):
+    """the upload of a block's sample rows -- every row in its source's own pinned allocation -- by btk_gather_rows (one kernel that
+    reads the host memory through a table) and by one copy per row: the same bits, 16-bit and float streams, ragged last blocks"""
+    from tests.util import design_prototype, synthetic_pcm
+    m, r = 4, 1
+    D = M >> r
+    h, g = design_prototype(M, m), design_prototype(M, m, "g")
+    pcm, delays = synthetic_pcm(1, N, (70 if N <= 8 else 40) * D + 33, seed=5 + M + N)
+    pcm = pcm[0]
+
+    def run():
+        _, bf, sfb = _graph(pcm, h, g, M, m, r, delays, block_frames)
+        out = _pull(sfb)
+        assert bf.i16_stream() == i16
+        return out
+    if i16:
+        a = run()
+        with _copies_per_row():
+            b = run()
+    else:
+        with _float_path():
+            a = run()
+            with _copies_per_row():
+                b = run()
+    assert _same_bits(a, b)
