@@ -108,6 +108,12 @@ class OverSampledDFTSynthesisBank : public VectorFloatFeatureStream {
                               int gainFactor = 1, const String& nm = "OverSampledDFTSynthesisBank");
   ~OverSampledDFTSynthesisBank();
   virtual const gsl_vector_float* next(int frame_no = -5);
+  // Engine extension (not in the reference): the blocks the next calls of next() would hand out, as many as the round that is
+  // resident still holds (at most max_blocks; 0: all of them) -- one call, no copy.  Returns their number (0: the stream has ended;
+  // is_end() is then set, as after next()'s jiterator_error) and points *blocks at n x shiftlen() floats that stay valid until the
+  // next call of either kind; current() is the last of them.  A Python caller pays its per-call cost once per round instead of
+  // once per 16 ms block.
+  long next_blocks(long max_blocks, const float** blocks);
   virtual void reset();
   void input_source_vector(const gsl_vector_complex* block);
   void no_stream_feature(bool flag = true) { no_stream_feature_ = flag; }

@@ -1107,6 +1107,25 @@ const gsl_vector_float* OverSampledDFTSynthesisBank::next(int frame_no)
   return vector_;
 }
 
+long OverSampledDFTSynthesisBank::next_blocks(long max_blocks, const float** blocks)
+{
+  if (no_stream_feature_) throw jconsistency_error("OverSampledDFTSynthesisBank::next_blocks: a source-less bank is pulled block by block with next()\n");
+  if (samp_.is_null()) throw jconsistency_error("OverSampledDFTSynthesisBank: no source stream (no_stream_feature(false) on a source-less bank)\n");
+  if (!blocks) throw j_error("OverSampledDFTSynthesisBank::next_blocks: null argument\n");
+  if (!prepared_ || (bsrc_ && bsrc_->block_version() != src_version_)) prepare_();
+  const long idx = frame_no_ + 1;
+  while (idx >= blk_base_ + nblocks_)
+    if (!fetch_round_()) { is_end_ = true; *blocks = NULL; return 0; }
+  long n = blk_base_ + nblocks_ - idx;
+  if (max_blocks > 0 && n > max_blocks) n = max_blocks;
+  const float* p = static_cast<const float*>(blocks_.get()) + (size_t)(idx - blk_base_) * D_;
+  memcpy(vector_->data, p + (size_t)(n - 1) * D_, sizeof(float) * D_);
+  frame_no_ += (int)n;
+  if (bsrc_) bsrc_->advance_to((long)btk_fb_processing_delay(plan_) + idx + n - 1);
+  *blocks = p;
+  return n;
+}
+
 void OverSampledDFTSynthesisBank::reset()
 {
   if (!no_stream_feature_ && !samp_.is_null()) samp_->reset();

@@ -322,7 +322,15 @@ PYBIND11_MODULE(_btk20cpp, m)
       .def("no_stream_feature", &OverSampledDFTSynthesisBank::no_stream_feature, py::arg("flag") = true)
       .def("doNotUseStreamFeature", &OverSampledDFTSynthesisBank::no_stream_feature, py::arg("flag") = true)
       .def("set_block_frames", &OverSampledDFTSynthesisBank::set_block_frames, py::arg("n"))
-      .def("block_frames", &OverSampledDFTSynthesisBank::block_frames);
+      .def("block_frames", &OverSampledDFTSynthesisBank::block_frames)
+      // engine extension: the blocks the next calls of next() would return, as one float32 array [n][shiftlen] (n = 0: end of stream)
+      .def("next_blocks", [](OverSampledDFTSynthesisBank& b, long max_blocks) {
+             const float* p = NULL;
+             const long n = b.next_blocks(max_blocks, &p);
+             py::array_t<float> a({(py::ssize_t)n, (py::ssize_t)b.size()});
+             if (n > 0) memcpy(a.mutable_data(), p, sizeof(float) * (size_t)n * b.size());
+             return a;
+           }, py::arg("max_blocks") = 0);
 
   // ---- beamformer/beamformer.h
   py::class_<SnapShotArray, cref<SnapShotArray>>(m, "SnapShotArrayPtr")
