@@ -30,7 +30,7 @@ SCLK_PEAK = 2.4e9          # Hz, nominal peak engine clock; under the 1 400 W ca
 # Interior loop of analysis512_bfz_kernel<2,33231,16>, per wavefront (= 4 frames) and channel, counted in the ISA of the sources
 # with this sha256 (tools/isa_loop_count.py on `hipcc -S --cuda-device-only fb_analysis512.hip`, the loop that holds
 # the 15 window loads of a channel): packed float32 instructions; a wave64 packed instruction occupies its SIMD for 4 cycles.
-FUSED_ISA = {"kernel_source_sha256": "eb1650f77df907b941bc5d8badc87b061b2fe13e554d200e6c0d8e2019d89cd5",
+FUSED_ISA = {"kernel_source_sha256": "cc9d72e4fb166077135b0dbb4b88f2a74712a3c1785df8aead43267fa224d26e",
              "v_pk_fma_f32": 184, "v_pk_add_f32": 89, "v_pk_mul_f32": 23, "frames_per_wave": 4}
 TRAFFIC_JSON = "r06_pmc_traffic.json"      # profiles/: PMC traffic of the kernels below, with the launch size and kernel-source hash it holds for
 FS = 16000.0

@@ -346,3 +346,17 @@ def test_snapshot_array_set_snapshots_and_legacy_aliases():
         a.newSample(np.arange(M) * (c + 1) + 1j * c, c)
     a.update()
     assert np.array_equal(a.getSnapShot(5), np.array([5 * (c + 1) + 1j * c for c in range(N)]))
+
+
+def test_bench_measurement_records_match_the_kernel_sources():
+    """bench.py quotes two records that were taken on particular sources of the headline kernel -- the ISA count of its interior loop
+    (FUSED_ISA) and the PMC traffic passes (profiles/<TRAFFIC_JSON>) -- and refuses either (null in the line) when the sources have
+    changed since.  A checkout whose records are stale should fail HERE, not print a line with holes at round end."""
+    import json
+    import bench
+    from bench_util import kernel_source_sha
+    sha = kernel_source_sha()
+    assert bench.FUSED_ISA["kernel_source_sha256"] == sha, "re-count with tools/isa_loop_count.py and update bench.FUSED_ISA"
+    j = json.load(open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", bench.TRAFFIC_JSON)))
+    assert j["kernel_source_sha256"] == sha, "re-take the PMC passes (profiles/scripts/r06_run_all.sh) and commit profiles/%s" % bench.TRAFFIC_JSON
+    assert (j["S"], j["T"], j["N"], j["M"]) == (32, 4096, 64, 512)
