@@ -44,7 +44,7 @@ for mode in ("per_block_loop", "next_blocks"):
         if mode == "per_block_loop":
             for b in sfb:
                 n += 1
-                acc += b[0]
+                acc += float(np.asarray(b)[0])
         else:
             while True:
                 a = sfb.next_blocks()

@@ -73,6 +73,27 @@ def test_pool_equals_graphs_pulled_one_by_one(dev, M, N, block_frames, dct):
                 again[i].append(np.array(o))
     for i in range(3):
         assert np.array_equal(np.concatenate(again[i]).view(np.uint32), singles[i].view(np.uint32))
+    # a third pass with the rows of a round going up by one copy each instead of the gather kernel (BTK_NODE_GATHER=0): same blocks
+    import os
+    old = os.environ.get("BTK_NODE_GATHER")
+    os.environ["BTK_NODE_GATHER"] = "0"
+    try:
+        for i in range(3):
+            pcm, _ = synthetic_pcm(1, N, lens[i], seed=100 + i)
+            for c in range(N):
+                keepalive[6 * i + 3][2 * c].set_samples(np.ascontiguousarray(pcm[0][c], np.float32))
+        third = [[] for _ in range(3)]
+        for outs in pool:
+            for i, o in enumerate(outs):
+                if o is not None:
+                    third[i].append(np.array(o))
+    finally:
+        if old is None:
+            del os.environ["BTK_NODE_GATHER"]
+        else:
+            os.environ["BTK_NODE_GATHER"] = old
+    for i in range(3):
+        assert np.array_equal(np.concatenate(third[i]).view(np.uint32), singles[i].view(np.uint32))
 
 
 def test_pool_refuses_what_it_cannot_batch(dev):
@@ -95,24 +116,3 @@ def test_pool_refuses_what_it_cannot_batch(dev):
     k4, bf4, s4 = _graph(pcm[0][:, :4000], h128, g128, 128, 2, 0, delays, 32)
     with pytest.raises(j_error):
         SubbandGraphPoolPtr().add(bf4, s4)                  # a geometry without a fused kernel
-    # a third pass with the rows of a round going up by one copy each instead of the gather kernel (BTK_NODE_GATHER=0): same blocks
-    import os
-    old = os.environ.get("BTK_NODE_GATHER")
-    os.environ["BTK_NODE_GATHER"] = "0"
-    try:
-        for i in range(3):
-            pcm, _ = synthetic_pcm(1, N, lens[i], seed=100 + i)
-            for c in range(N):
-                keepalive[6 * i + 3][2 * c].set_samples(np.ascontiguousarray(pcm[0][c], np.float32))
-        third = [[] for _ in range(3)]
-        for outs in pool:
-            for i, o in enumerate(outs):
-                if o is not None:
-                    third[i].append(np.array(o))
-    finally:
-        if old is None:
-            del os.environ["BTK_NODE_GATHER"]
-        else:
-            os.environ["BTK_NODE_GATHER"] = old
-    for i in range(3):
-        assert np.array_equal(np.concatenate(third[i]).view(np.uint32), singles[i].view(np.uint32))
