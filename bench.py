@@ -280,7 +280,9 @@ def main():
     backend = os.environ.get("BTK_DIST_BACKEND", "nccl")
     dev = torch.device("cuda", local_rank % max(torch.cuda.device_count(), 1))
     torch.cuda.set_device(dev)
-    if world > 1:
+    # (BTK_BENCH_FORCE_DIST=1: a world of ONE rank still goes through torch.distributed / RCCL -- how a 1-GPU box runs the multi-GPU
+    #  code path of this script, the C5 stage included: tests/test_gpu_sharded_2rank.py)
+    if world > 1 or os.environ.get("BTK_BENCH_FORCE_DIST") == "1":
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":

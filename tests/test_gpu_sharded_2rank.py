@@ -105,6 +105,34 @@ def test_bench_two_ranks_contract(dev):
     assert len(pr) == 2 and all(v > 0 for v in pr) and d["value"] <= sum(pr) * (1 + 1e-9)
 
 
+def test_bench_rccl_world_of_one_runs_the_multi_gpu_stage(dev):
+    """bench.py's multi-GPU code path on RCCL with a world of ONE rank (BTK_BENCH_FORCE_DIST=1): the barrier / max-over-ranks /
+    all_gather of the headline AND stages.c5_frame_sharded (C5 by frame range: fused kernel, all-gather of Y along the frame
+    axis, synthesis) -- the stage first meets several GPUs on the driver's node, so everything in it that one GPU can run runs here"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, BTK_BENCH_FORCE_DIST="1")
+    env.pop("BTK_DIST_BACKEND", None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1",
+           "--streams", "4", "--frames", "1024", "--no-cpu"]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, res.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["config"]["rccl_world"] == 1 and d["config"]["dist_backend"] == "nccl"
+    c5 = d["stages"]["c5_frame_sharded"]
+    assert "error" not in c5, c5
+    assert c5["world"] == 1
+    for T in (512, 4096):
+        e = c5["frames_%d" % T]
+        assert e["frames_per_rank"] == T and e["allgather_bytes"] == 8 * 1025 * T
+        assert 0 < e["rank_kernel_ms"] <= e["block_ms"] * 1.05 and e["allgather_alone_ms"] >= 0 and e["frames_per_s"] > 0
+
+
 @pytest.mark.parametrize("M,r,N", [(512, 1, 5), (256, 1, 3), (2048, 1, 2), (64, 0, 4), (128, 2, 3)])
 def test_bin_range_analysis_equals_slice(dev, M, r, N):
     """btk_fb_analysis_bins (what a rank of a bin-sharded run launches): bit-identical to the bin slice of the whole
