@@ -344,13 +344,17 @@ def main():
             step()
         torch.cuda.synchronize()
         prewarm_steps += 8
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
-    if dist: dist.barrier()
-    torch.cuda.synchronize()
     from bench_util import ClockPowerSampler
-    with ClockPowerSampler(torch, dev) as clk:              # shader clock and package power while the timed steps run (sysfs, 2 ms period)
+    # shader clock and package power while the timed steps run (sysfs, 2 ms period).  The sampler is set up and its thread started
+    # BEFORE the warm-up: between the synchronisation that ends the warm-up and the first timed launch the GPU is idle, and its
+    # clock sags within a millisecond or two of idling
+    with ClockPowerSampler(torch, dev) as clk:
+        for _ in range(args.warmup):
+            step()
+        torch.cuda.synchronize()
+        if dist: dist.barrier()
+        torch.cuda.synchronize()
+        clk.begin()
         t0 = time.perf_counter()
         for i in range(args.steps):
             step(ev[i])

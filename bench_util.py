@@ -115,6 +115,11 @@ class ClockPowerSampler:
             self._th.start()
         return self
 
+    def begin(self):
+        """drop what was sampled so far: the region of interest starts now (the thread is started earlier so that nothing but the
+        time stamp lies between the synchronisation in front of a timed region and its first launch)"""
+        self.samples = []
+
     def __exit__(self, *a):
         self._stop = True
         if self._th is not None:
