@@ -30,7 +30,7 @@ SCLK_PEAK = 2.4e9          # Hz, nominal peak engine clock; under the 1 400 W ca
 # Interior loop of analysis512_bfz_kernel<2,33231,16>, per wavefront (= 4 frames) and channel, counted in the ISA of the sources
 # with this sha256 (tools/isa_loop_count.py on `hipcc -S --cuda-device-only fb_analysis512.hip`, the loop that holds
 # the 15 window loads of a channel): packed float32 instructions; a wave64 packed instruction occupies its SIMD for 4 cycles.
-FUSED_ISA = {"kernel_source_sha256": "cc9d72e4fb166077135b0dbb4b88f2a74712a3c1785df8aead43267fa224d26e",
+FUSED_ISA = {"kernel_source_sha256": "98cd814b2e72da2cb6b34596f639a17dff228c65bb3486bede0db4fc3363d9f9",
              "v_pk_fma_f32": 184, "v_pk_add_f32": 89, "v_pk_mul_f32": 23, "frames_per_wave": 4}
 TRAFFIC_JSON = "r06_pmc_traffic.json"      # profiles/: PMC traffic of the kernels below, with the launch size and kernel-source hash it holds for
 FS = 16000.0
@@ -400,7 +400,6 @@ def main():
         Yi = afb.analysis_beamform(pcm16, W)
         i16_same = bool(torch.equal(Yf[..., :T].contiguous().view(torch.float32).view(torch.int32), Yi[..., :T].contiguous().view(torch.float32).view(torch.int32)))
         del Yf, Yi
-    del pcm16
     # the adaptive variant of the same beamformer (SubbandGSCLMSBeamformer: NLMS canceller on the snapshots), reported
     # next to the static-weight chain; the recursion is sequential in t, so its rate depends on the number of streams
     vs = torch.from_numpy(np.stack([np.exp(-2j * np.pi * k * (FS / M) * delays) / N for k in range(K)]).astype(np.complex64)).to(dev)
@@ -418,6 +417,18 @@ def main():
             sfb.synthesize(Yc_, out=out_)
         return _time(chain)
     t_chain = adaptive(pcm, X, Yc, out, nst)
+    # the same chain on the samples as they are stored (16-bit PCM): the staged bank widens them on its way into LDS
+    # (btk_fb_analysis_i16, the same bits) -- reported BESIDE the float32 chain, with the bytes it moves
+    t_ana_i16 = t_chain_i16 = None
+    chain_i16_same = None
+    if afb.analysis_i16():
+        t_ana_i16 = _time(lambda: afb.analysis(pcm16, out=X))
+        nst_i = eng.NLMSState(S, M, N, dev)
+        t_chain_i16 = adaptive(pcm16, X, Yc, out, nst_i)
+        Xa = afb.analysis(pcm[:1]); Xb = afb.analysis(pcm16[:1])
+        chain_i16_same = bool(torch.equal(Xa.view(torch.float32).view(torch.int32), Xb.view(torch.float32).view(torch.int32)))
+        del Xa, Xb, nst_i
+    del pcm16
     # the same chain with the analysis bank running ahead of the canceller on a second HIP stream (engine.AdaptiveGSCChain):
     # identical output, the two kernels share the chip instead of taking turns
     pipe = eng.AdaptiveGSCChain(afb, sfb, chunk_frames=512)
@@ -565,6 +576,15 @@ def main():
                                    "what": "analysis -> snapshots [S][K][N][T] in HBM -> NLMS sidelobe canceller -> synthesis, end to end, "
                                            "%d streams x %d frames" % (S, T),
                                    "same_frames_as_more_streams": adaptive_wide},
+                "adaptive_chain_i16": (None if t_chain_i16 is None else
+                                       {"ms": t_chain_i16 * 1e3, "frames_per_s": S * T / t_chain_i16, "xRT": S * T / t_chain_i16 / (FS / D),
+                                        "analysis_ms": t_ana_i16 * 1e3, "analysis_bytes_per_launch": (2 * D + 8 * K) * N * S * T,
+                                        "analysis_GBps": (2 * D + 8 * K) * N * S * T / t_ana_i16 / 1e9,
+                                        "analysis_frac": (2 * D + 8 * K) * N * S * T / t_ana_i16 / HBM_PEAK,
+                                        "snapshots_bit_identical_to_f32_entry": chain_i16_same,
+                                        "what": "the adaptive chain from int16 PCM (as stored in a WAV and as it crosses PCIe): btk_fb_analysis_i16 "
+                                                "-> snapshots -> NLMS canceller -> synthesis; the bank reads 2 D instead of 4 D bytes per frame and "
+                                                "channel (algorithmic bytes 2D+8K per frame and channel); beside the float32 chain, never instead of it"}),
                 "adaptive_chain_two_hip_streams": {"ms": t_chain_pipe * 1e3, "frames_per_s": S * T / t_chain_pipe, "xRT": S * T / t_chain_pipe / (FS / D),
                                                    "what": "the same chain, the analysis bank running 512-frame chunks ahead of the canceller on a second "
                                                            "HIP stream (engine.AdaptiveGSCChain); bit-identical output"},

@@ -55,6 +55,8 @@ SIGNATURES = {
     "btk_fb_analysis_bf_fused": (_i, [_vp]),
     "btk_fb_analysis_bf": (_i, [_vp, _vp, _l, _l, _i, _i, _vp, _i, _vp, _l, _l, _l, _vp, _l, _vp]),
     "btk_fb_analysis_bf_i16_fused": (_i, [_vp]),
+    "btk_fb_analysis_i16_direct": (_i, [_vp]),
+    "btk_fb_analysis_i16": (_i, [_vp, _vp, _l, _l, _i, _i, _vp, _l, _l, _l, _vp]),
     "btk_fb_analysis_bf_i16": (_i, [_vp, _vp, _l, _l, _i, _i, _vp, _i, _vp, _l, _l, _l, _vp, _l, _vp]),
     "btk_nlms_workspace_bytes": (_l, [_i, _l]),
     "btk_nlms_process": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _l, _l, _vp, _vp, _vp, _vp, _vp]),

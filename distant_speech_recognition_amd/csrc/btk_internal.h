@@ -73,12 +73,17 @@ template <bool NT> __device__ __forceinline__ void btk_st(float4* p, float4 v)
 #endif
 __device__ btk_f2v btk_buffer_load_i16x2_f32(__amdgpu_buffer_rsrc_t rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.ptr.buffer.load.format.v2f32");
 constexpr int BTK_RSRC_I16X2_SSCALED = 0x0002B02C;
+// four samples: DATA_FORMAT 16_16_16_16 (12), NUM_FORMAT SSCALED (3), dst_sel x y z w
+__device__ btk_f4v btk_buffer_load_i16x4_f32(__amdgpu_buffer_rsrc_t rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.ptr.buffer.load.format.v4f32");
+constexpr int BTK_RSRC_I16X4_SSCALED = 0x00063FAC;
 
 // fb_analysis512.hip: specialised analysis kernel (M=512, m=4); returns 1 handled / 0 not covered / <0 error
 int btk_analysis512_try(const btk_fb* fb, const float* pcm, long nsamples, long pcm_stride, int S, int N, void* X,
                         long T_stride, long t0, long tcount, hipStream_t st);
 int btk_analysis512_bf_try(const btk_fb* fb, const float* pcm, long nsamples, long pcm_stride, int S, int N, const void* W,
                            int per_stream, void* Wt_scratch, void* Y, long T_stride, long t0, long tcount, hipStream_t st);
+int btk_analysis512_i16_try(const btk_fb* fb, const short* pcm, long nsamples, long pcm_stride, int S, int N, void* X,
+                            long T_stride, long t0, long tcount, hipStream_t st);
 int btk_analysis512_bf_i16_try(const btk_fb* fb, const short* pcm, long nsamples, long pcm_stride, int S, int N, const void* W,
                                int per_stream, void* Wt_scratch, void* Y, long T_stride, long t0, long tcount, hipStream_t st);
 int btk_synthesis512_try(const btk_fb* fb, const void* Y, long nframes, long T_stride, int S, float* out, long out_stride,

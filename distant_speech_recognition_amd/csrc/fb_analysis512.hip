@@ -38,9 +38,11 @@ constexpr int A_RUN = 16;             // consecutive tiles (16 frames each) one 
 // 1.72 -> 1.35 ms in profiles/fb_ab.py.
 constexpr int ANA512_WGS = 4;
 constexpr bool ANA512_PREFETCH = false;
-template <int R, bool SHARD>     // R = M / D in {1, 2, 4}; SHARD: only the bins [k0, k1) are stored
+// PT = float: the samples as SampleFeature hands them out; PT = short (round 6): the 16-bit PCM they were read from, widened on the
+// way into the LDS span (exact: the same bits) -- the bank reads 2 D instead of 4 D bytes per frame and channel of the 4 D + 8 K it moves
+template <int R, bool SHARD, typename PT = float>     // R = M / D in {1, 2, 4}; SHARD: only the bins [k0, k1) are stored
 __global__ __launch_bounds__(A_NT, ANA512_WGS)
-void analysis512_kernel(const float* __restrict__ pcm, long nsamples, long pcm_stride,
+void analysis512_kernel(const PT* __restrict__ pcm, long nsamples, long pcm_stride,
                         const float* __restrict__ proto, const float2* __restrict__ twg,
                         int laN, float gain, int N, int K, float2* __restrict__ X,
                         long T_stride, long t0, long tcount, int ntiles, int nruns, int nchan, int k0, int k1)
@@ -70,9 +72,12 @@ void analysis512_kernel(const float* __restrict__ pcm, long nsamples, long pcm_s
   float2* twj = tw + (A_NF + 1);                                              // [16 k1][16 j] W_256^{j k1} as (cos, tan): fft_packed.h tw_tangent
   { const float2 t = twg[(2 * (tid & 15) * (tid >> 4)) & 511]; const f2 ct = tw_tangent(t.x, t.y); twj[tid] = make_float2(ct.x, ct.y); }   // tid = k1*16 + j
 
-  const float* src = pcm + (long)chan * pcm_stride;
-  const bool vec_ok = ((pcm_stride & 3) == 0) && ((reinterpret_cast<uintptr_t>(pcm) & 15) == 0);
+  const PT* src = pcm + (long)chan * pcm_stride;
+  constexpr bool I16 = sizeof(PT) == 2;
+  const bool vec_ok = ((pcm_stride & 3) == 0) && ((reinterpret_cast<uintptr_t>(pcm) & (I16 ? 7 : 15)) == 0) &&
+                      (!I16 || nsamples < (1L << 30));                 // (the typed loads' byte offset within the row is a 32-bit register)
   float4 pre[NV4];
+  __amdgpu_buffer_rsrc_t rs16 = __builtin_amdgcn_make_buffer_rsrc(const_cast<PT*>(src), 0, 0x7fffffff, I16 ? BTK_RSRC_I16X4_SSCALED : 0);
   // PCM span of a tile -> registers (global loads stay in flight while the previous tile is computed)
   auto fetch = [&](int tile) {
     const long g0 = (t0 + (long)tile * A_TT + laN + 1) * (long)D - (long)A_MT * A_M;
@@ -80,7 +85,17 @@ void analysis512_kernel(const float* __restrict__ pcm, long nsamples, long pcm_s
 #pragma unroll
       for (int q = 0; q < NV4; q++) {
         const int l = (tid + q * A_NT) * 4;
-        if (l < SPAN) pre[q] = *reinterpret_cast<const float4*>(src + g0 + l);
+        if (l < SPAN) {
+          if constexpr (I16) {
+            // four samples in 8 bytes, widened by the load unit (typed buffer load, 16_16_16_16 SSCALED): no vector instruction
+            // (the form that loads the words raw and converts them -- 2 instructions per sample -- ran 5.43 ms against the
+            //  float bank's 5.09: the bank is co-limited by the vector ALU)
+            const btk_f4v w = btk_buffer_load_i16x4_f32(rs16, (int)((g0 + l) * 2), 0, 0);
+            pre[q] = make_float4(w.x, w.y, w.z, w.w);
+          } else {
+            pre[q] = *reinterpret_cast<const float4*>(src + g0 + l);
+          }
+        }
       }
     } else {
 #pragma unroll
@@ -90,7 +105,7 @@ void analysis512_kernel(const float* __restrict__ pcm, long nsamples, long pcm_s
 #pragma unroll
         for (int e = 0; e < 4; e++) {
           const long g = g0 + l + e;
-          v[e] = (l + e < SPAN && g >= 0 && g < nsamples) ? src[g] : 0.0f;
+          v[e] = (l + e < SPAN && g >= 0 && g < nsamples) ? (float)src[g] : 0.0f;
         }
         pre[q] = make_float4(v[0], v[1], v[2], v[3]);
       }
@@ -228,8 +243,8 @@ void analysis512_kernel(const float* __restrict__ pcm, long nsamples, long pcm_s
   }
 }
 
-template <int R>
-int launch512(const btk_fb* fb, const float* pcm, long nsamples, long pcm_stride, int S, int N, float2* X,
+template <int R, typename PT = float>
+int launch512(const btk_fb* fb, const PT* pcm, long nsamples, long pcm_stride, int S, int N, float2* X,
               long T_stride, long t0, long tcount, hipStream_t st)
 {
   constexpr int D = A_M / R;
@@ -242,7 +257,7 @@ int launch512(const btk_fb* fb, const float* pcm, long nsamples, long pcm_stride
   const int nruns = (ntiles + A_RUN - 1) / A_RUN;
   const long nblocks = (long)((nchan + 7) / 8) * nruns * 8;
   const bool shard = !(fb->kx0 == 0 && fb->kx1 == fb->K);
-  auto kern = shard ? analysis512_kernel<R, true> : analysis512_kernel<R, false>;
+  auto kern = shard ? analysis512_kernel<R, true, PT> : analysis512_kernel<R, false, PT>;
   // per launch: the attribute is per device, and one process may drive several GPUs (btk_set_device)
   BTK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const float gain = fb->gain_factor > 0 ? (float)fb->gain_factor : 1.0f;
@@ -1187,6 +1202,22 @@ int btk_analysis512_try(const btk_fb* fb, const float* pcm, long nsamples, long 
     case 1: rc = launch512<1>(fb, pcm, nsamples, pcm_stride, S, N, Xp, T_stride, t0, tcount, st); break;
     case 2: rc = launch512<2>(fb, pcm, nsamples, pcm_stride, S, N, Xp, T_stride, t0, tcount, st); break;
     case 4: rc = launch512<4>(fb, pcm, nsamples, pcm_stride, S, N, Xp, T_stride, t0, tcount, st); break;
+    default: return 0;
+  }
+  return rc == BTK_OK ? 1 : rc;
+}
+
+// the staged bank from 16-bit PCM (btk_fb_analysis_i16)
+int btk_analysis512_i16_try(const btk_fb* fb, const short* pcm, long nsamples, long pcm_stride, int S, int N, void* X,
+                            long T_stride, long t0, long tcount, hipStream_t st)
+{
+  if (fb->M != A_M || fb->m != A_MT) return 0;
+  float2* Xp = static_cast<float2*>(X);
+  int rc;
+  switch (fb->R) {
+    case 1: rc = launch512<1, short>(fb, pcm, nsamples, pcm_stride, S, N, Xp, T_stride, t0, tcount, st); break;
+    case 2: rc = launch512<2, short>(fb, pcm, nsamples, pcm_stride, S, N, Xp, T_stride, t0, tcount, st); break;
+    case 4: rc = launch512<4, short>(fb, pcm, nsamples, pcm_stride, S, N, Xp, T_stride, t0, tcount, st); break;
     default: return 0;
   }
   return rc == BTK_OK ? 1 : rc;

@@ -356,6 +356,28 @@ int btk_fb_analysis(const btk_fb_t* fb, const float* pcm, long nsamples, long pc
   return btk_set_error(BTK_ERR_PARAMETER, "unsupported M=%d", fb->M);
 }
 
+int btk_fb_analysis_i16_direct(const btk_fb_t* fb)
+{
+  if (!fb || fb->synthesis) return btk_set_error(BTK_ERR_PARAMETER, "btk_fb_analysis_i16_direct: not an analysis plan");
+  if (btk_switches().disable_analysis512) return 0;
+  return fb->M == 512 && fb->m == 4 && (fb->R == 1 || fb->R == 2 || fb->R == 4);
+}
+
+int btk_fb_analysis_i16(const btk_fb_t* fb, const short* pcm, long nsamples, long pcm_stride,
+                        int S, int N, void* X, long T_stride, long t0, long tcount, void* stream)
+{
+  if (!fb || fb->synthesis) return btk_set_error(BTK_ERR_PARAMETER, "btk_fb_analysis_i16: not an analysis plan");
+  if (S <= 0 || N <= 0 || tcount < 0 || T_stride < tcount || pcm_stride < nsamples)
+    return btk_set_error(BTK_ERR_DIMENSION, "btk_fb_analysis_i16: bad sizes S=%d N=%d tcount=%ld T_stride=%ld", S, N, tcount, T_stride);
+  if (tcount == 0) return BTK_OK;
+  if (!pcm || !X) return btk_set_error(BTK_ERR_PARAMETER, "btk_fb_analysis_i16: null argument");
+  if (btk_fb_analysis_i16_direct(fb) != 1)
+    return btk_set_error(BTK_ERR_PARAMETER, "btk_fb_analysis_i16: no int16 kernel for M=%d m=%d r=%d (btk_pcm_i16_to_f32 + btk_fb_analysis)", fb->M, fb->m, fb->r);
+  const int rc = btk_analysis512_i16_try(fb, pcm, nsamples, pcm_stride, S, N, X, T_stride, t0, tcount, as_stream(stream));
+  if (rc == 0) return btk_set_error(BTK_ERR_PARAMETER, "btk_fb_analysis_i16: geometry not covered");
+  return rc > 0 ? BTK_OK : rc;
+}
+
 int btk_fb_analysis_bins(const btk_fb_t* fb, const float* pcm, long nsamples, long pcm_stride, int S, int N, void* X,
                          long T_stride, long t0, long tcount, int k0, int k1, void* stream)
 {

@@ -128,8 +128,14 @@ class FilterBank:
         """pcm float32 [S][N][L] (cuda) -> X complex64 [S][K][N][T]; bins = (k0, k1): only that bin range is computed
         into X [S][k1-k0][N][T] (the bin shard of one rank, sharding.py).  pad_rows: allocate X with padded rows
         (padded_rows: power-of-two row pitches put a tile's rows on the same HBM channels) -- bf_apply and nlms_process
-        accept such a view, the other consumers want contiguous snapshots; `out` may itself be a row-padded view."""
-        _check(pcm, "pcm", torch.float32, 3)
+        accept such a view, the other consumers want contiguous snapshots; `out` may itself be a row-padded view.
+        pcm may be int16 -- the samples as a WAV stores them (feature/feature.cc:265-269) -- where the geometry has the int16 form of
+        the bank (analysis_i16(): btk_fb_analysis_i16, M = 512; the whole bin range): half the PCM bytes, the same bits out."""
+        i16 = pcm.dtype == torch.int16
+        _check(pcm, "pcm", torch.int16 if i16 else torch.float32, 3)
+        if i16 and (bins is not None or not self.analysis_i16()):
+            raise _lib.BtkError(_lib.BTK_ERR_PARAMETER, "no int16 analysis kernel for M=%d m=%d r=%d%s: widen with pcm_i16_to_f32 first"
+                                % (self.M, self.m, self.r, " on a bin range" if bins is not None else ""))
         S, N, L = pcm.shape
         nsamples = L if nsamples is None else nsamples
         if tcount is None:
@@ -143,7 +149,9 @@ class FilterBank:
         ts = _check(out, "X", torch.complex64, (S, k1 - k0, N, None), rows=True)
         if out.shape[3] < tcount:
             raise _lib.BtkError(_lib.BTK_ERR_DIMENSION, "X holds %d frames, %d requested" % (out.shape[3], tcount))
-        if bins is None:
+        if i16:
+            check(_lib.lib().btk_fb_analysis_i16(self._h, _ptr(pcm), nsamples, L, S, N, _ptr(out), ts, t0, tcount, _stream()))
+        elif bins is None:
             check(_lib.lib().btk_fb_analysis(self._h, _ptr(pcm), nsamples, L, S, N, _ptr(out), ts, t0, tcount, _stream()))
         else:
             check(_lib.lib().btk_fb_analysis_bins(self._h, _ptr(pcm), nsamples, L, S, N, _ptr(out), ts, t0, tcount,
@@ -208,6 +216,10 @@ class FilterBank:
         fn = _lib.lib().btk_fb_analysis_bf_i16 if i16 else _lib.lib().btk_fb_analysis_bf
         check(fn(self._h, _ptr(pcm), nsamples, L, S, N, _ptr(W), per_stream, _ptr(out), t_stride, t0, tcount, _ptr(buf), buf.numel(), _stream()))
         return out
+
+    def analysis_i16(self):
+        """True when analysis() takes int16 samples for this geometry (btk_fb_analysis_i16_direct)."""
+        return _lib.lib().btk_fb_analysis_i16_direct(self._h) == 1
 
     def fused_i16(self):
         """True when analysis_beamform takes int16 samples for this geometry (btk_fb_analysis_bf_i16_fused)."""

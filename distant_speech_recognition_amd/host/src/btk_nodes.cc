@@ -1459,7 +1459,14 @@ void* SubbandBeamformer::snapshots_()
       if (!pcm_valid_) throw jconsistency_error("SubbandBeamformer %s: the samples of the current block are gone\n", name().c_str());
       // the windows start at input block b0: stream frame t is frame t - b0 of the window (csrc/fb_kernels.hip: frame t ends at
       // sample (t + laN + 1) D - 1), and no frame of this block reads a sample before it
-      check_abi(btk_fb_analysis(banks_[0]->plan(), pcm_f32_(), pcm_L_, pcm_pitch_ ? pcm_pitch_ : 1, 1, (int)N, dX_, T_, pcm_t0_, T_, nstream()));
+      // (a 16-bit stream: the bank reads the int16 rows where the geometry has that form -- btk_fb_analysis_i16, the same bits --
+      //  and the widening pass with its 6 D bytes per frame and channel falls away; BTK_NODE_I16_STAGED=0: always widen first)
+      static const bool direct_off = getenv("BTK_NODE_I16_STAGED") && atoi(getenv("BTK_NODE_I16_STAGED")) == 0;
+      if (pcm_i16_ && !direct_off && btk_fb_analysis_i16_direct(banks_[0]->plan()) == 1)
+        check_abi(btk_fb_analysis_i16(banks_[0]->plan(), static_cast<const short*>(dPcm16Buf_.get()), pcm_L_, pcm_pitch_ ? pcm_pitch_ : 1, 1, (int)N,
+                                      dX_, T_, pcm_t0_, T_, nstream()));
+      else
+        check_abi(btk_fb_analysis(banks_[0]->plan(), pcm_f32_(), pcm_L_, pcm_pitch_ ? pcm_pitch_ : 1, 1, (int)N, dX_, T_, pcm_t0_, T_, nstream()));
     }
     snap_valid_ = true;
   }

@@ -94,3 +94,51 @@ def test_geometries_without_an_i16_kernel_say_so(dev):
     W = torch.zeros((1, afb.K, 4), dtype=torch.complex64, device=dev)
     with pytest.raises(_lib.BtkError):
         afb.analysis_beamform(pcm, W)
+
+
+@pytest.mark.parametrize("N,S,T,r", [(8, 2, 100, 1), (64, 2, 300, 1), (5, 1, 40, 0), (6, 2, 90, 2)])
+def test_staged_i16_analysis_equals_f32_analysis_bit_for_bit(dev, N, S, T, r):
+    """btk_fb_analysis_i16 (the STAGED bank on 16-bit PCM, M = 512): the snapshots of btk_fb_analysis on the float copies of the
+    same samples, bit for bit -- whole launches (runs of 16 tiles and the ragged last tile), pieces in the middle, a sample count
+    that ends inside a tile, contiguous and row-padded snapshot blocks"""
+    afb, pcm, _, _ = _setup(512, N, S, T, r, seed=7 + N, dev=dev)
+    assert afb.analysis_i16()
+    pf = torch.from_numpy(pcm).to(dev)
+    pi = torch.from_numpy(pcm.astype(np.int16)).to(dev)
+    nfr = afb.num_frames(pf.shape[-1])
+    Xf = afb.analysis(pf)
+    Xi = afb.analysis(pi)
+    assert Xf.shape == Xi.shape == (S, afb.K, N, nfr) and float(Xf.abs().max()) > 100
+    assert torch.equal(_bits(Xf), _bits(Xi))
+    Xp = afb.analysis(pi, pad_rows=True)
+    assert torch.equal(_bits(Xf), _bits(Xp[..., :nfr]))
+    for (t0, tc) in ((5, 23), (nfr - 21, 21), (16, 32)):
+        assert torch.equal(_bits(afb.analysis(pf, t0=t0, tcount=tc)), _bits(afb.analysis(pi, t0=t0, tcount=tc)))
+    L2 = pf.shape[-1] - 301
+    assert torch.equal(_bits(afb.analysis(pf, nsamples=L2)), _bits(afb.analysis(pi, nsamples=L2)))
+
+
+def test_staged_i16_analysis_unaligned_rows_and_other_geometries(dev):
+    """rows that are not 8-byte aligned / an odd row pitch take the guarded loads (same bits); a bin range or a geometry without
+    the int16 form is refused with a message that says what to do"""
+    from distant_speech_recognition_amd import engine as eng, _lib
+    from tests.util import design_prototype
+    afb, pcm, _, _ = _setup(512, 8, 2, 60, seed=5, dev=dev)
+    pf = torch.from_numpy(pcm).to(dev)
+    S, N, L = pf.shape
+    nfr = afb.num_frames(L)
+    Xf = afb.analysis(pf)
+    for pad, off in ((3, 0), (2, 1)):                        # odd pitch; even pitch with a 2-byte offset of the first row
+        buf = torch.zeros(S * N * (L + pad) + 8, dtype=torch.int16, device=dev)
+        view = buf[off:off + S * N * (L + pad)].view(S, N, L + pad)
+        view[..., :L] = torch.from_numpy(pcm.astype(np.int16)).to(dev)
+        X = torch.empty((S, afb.K, N, nfr), dtype=torch.complex64, device=dev)
+        eng.check(_lib.lib().btk_fb_analysis_i16(afb._h, view.data_ptr(), L, L + pad, S, N, X.data_ptr(), nfr, 0, nfr, 0))
+        torch.cuda.synchronize()
+        assert torch.equal(_bits(Xf), _bits(X)), (pad, off)
+    with pytest.raises(_lib.BtkError):
+        afb.analysis(torch.from_numpy(pcm.astype(np.int16)).to(dev), bins=(3, 40))
+    a256 = eng.FilterBank(design_prototype(256, 4), 256, 4, 1, 2)
+    assert not a256.analysis_i16()
+    with pytest.raises(_lib.BtkError):
+        a256.analysis(torch.zeros((1, 4, 128 * 40), dtype=torch.int16, device=dev))
