@@ -91,6 +91,10 @@ int btk_synthesis512_try(const btk_fb* fb, const void* Y, long nframes, long T_s
 // fb_fast.hip: register-FFT kernels for M in {256,512,1024,2048}, m = 4
 int btk_fast_analysis_try(const btk_fb* fb, const float* pcm, long nsamples, long pcm_stride, int S, int N, void* X,
                           long T_stride, long t0, long tcount, hipStream_t st);
+int btk_fast_analysis_i16_try(const btk_fb* fb, const short* pcm, long nsamples, long pcm_stride, int S, int N, void* X,
+                              long T_stride, long t0, long tcount, hipStream_t st);
+int btk_fast_analysis_bf_i16_try(const btk_fb* fb, const short* pcm, long nsamples, long pcm_stride, int S, int N, const void* W,
+                                 int per_stream, void* Wt_scratch, void* Y, long T_stride, long t0, long tcount, hipStream_t st);
 int btk_fast_analysis_bf_try(const btk_fb* fb, const float* pcm, long nsamples, long pcm_stride, int S, int N, const void* W,
                              int per_stream, void* Wt_scratch, void* Y, long T_stride, long t0, long tcount, hipStream_t st);
 // fb_fused_big.hip: fused analysis -> fixed-weight beamformer for M = 1024 / 2048 (m = 4, r = 1); scratch bytes 0 = geometry not covered

@@ -232,9 +232,11 @@ __device__ __forceinline__ void pp_emit(float2* __restrict__ fbuf, int tid, cons
 constexpr int F_RUN = 8;       // consecutive tiles a workgroup walks through
 
 // ------------------------------------------------------------------------------------------------ analysis
-template <int LOG2M, int R, bool SHARD>      // SHARD: only the bins [k0, k1) are stored (the full range needs no per-bin test)
+// PT = short (round 6): the 16-bit PCM the float samples were read from -- four samples per typed buffer load, widened by the load
+// unit (btk_internal.h: btk_buffer_load_i16x4_f32), the same bits as the float entry
+template <int LOG2M, int R, bool SHARD, typename PT = float>      // SHARD: only the bins [k0, k1) are stored (the full range needs no per-bin test)
 __global__ __launch_bounds__(F_NT, 2)
-void fast_analysis_kernel(const float* __restrict__ pcm, long nsamples, long pcm_stride,
+void fast_analysis_kernel(const PT* __restrict__ pcm, long nsamples, long pcm_stride,
                           const float* __restrict__ proto, const float2* __restrict__ twg,
                           int laN, float gain, int N, int K, float2* __restrict__ X,
                           long T_stride, long t0, long tcount, int ntiles, int nruns, int nchan, int k0, int k1)
@@ -263,8 +265,10 @@ void fast_analysis_kernel(const float* __restrict__ pcm, long nsamples, long pcm
 
   for (int i = tid; i < NF; i += F_NT) twj[i] = twg[(2 * (i % P2) * (i / P2)) & (M - 1)];     // i = k1*P2 + j
 
-  const float* src = pcm + (long)chan * pcm_stride;
-  const bool vec_ok = ((pcm_stride & 3) == 0) && ((reinterpret_cast<uintptr_t>(pcm) & 15) == 0);
+  const PT* src = pcm + (long)chan * pcm_stride;
+  constexpr bool I16 = sizeof(PT) == 2;
+  const bool vec_ok = ((pcm_stride & 3) == 0) && ((reinterpret_cast<uintptr_t>(pcm) & (I16 ? 7 : 15)) == 0) && (!I16 || nsamples < (1L << 30));
+  const __amdgpu_buffer_rsrc_t rs16 = __builtin_amdgcn_make_buffer_rsrc(const_cast<PT*>(src), 0, 0x7fffffff, I16 ? BTK_RSRC_I16X4_SSCALED : 0);
   float4 pre[NV4];
   auto fetch = [&](int tile) {
     const long g0 = (t0 + (long)tile * TT + laN + 1) * (long)D - (long)F_MT * M;
@@ -272,7 +276,10 @@ void fast_analysis_kernel(const float* __restrict__ pcm, long nsamples, long pcm
 #pragma unroll
       for (int q = 0; q < NV4; q++) {
         const int l = (tid + q * F_NT) * 4;
-        if (l < SPAN) pre[q] = *reinterpret_cast<const float4*>(src + g0 + l);
+        if (l < SPAN) {
+          if constexpr (I16) { const btk_f4v w = btk_buffer_load_i16x4_f32(rs16, (int)((g0 + l) * 2), 0, 0); pre[q] = make_float4(w.x, w.y, w.z, w.w); }
+          else pre[q] = *reinterpret_cast<const float4*>(src + g0 + l);
+        }
       }
     } else {
 #pragma unroll
@@ -282,7 +289,7 @@ void fast_analysis_kernel(const float* __restrict__ pcm, long nsamples, long pcm
 #pragma unroll
         for (int e = 0; e < 4; e++) {
           const long g = g0 + l + e;
-          v[e] = (l + e < SPAN && g >= 0 && g < nsamples) ? src[g] : 0.0f;
+          v[e] = (l + e < SPAN && g >= 0 && g < nsamples) ? (float)src[g] : 0.0f;
         }
         pre[q] = make_float4(v[0], v[1], v[2], v[3]);
       }
@@ -352,8 +359,8 @@ void fast_analysis_kernel(const float* __restrict__ pcm, long nsamples, long pcm
   }
 }
 
-template <int LOG2M, int R>
-int launch_fast_analysis(const btk_fb* fb, const float* pcm, long nsamples, long pcm_stride, int S, int N, float2* X,
+template <int LOG2M, int R, typename PT = float>
+int launch_fast_analysis(const btk_fb* fb, const PT* pcm, long nsamples, long pcm_stride, int S, int N, float2* X,
                          long T_stride, long t0, long tcount, hipStream_t st)
 {
   using G = FG<LOG2M>;
@@ -368,7 +375,7 @@ int launch_fast_analysis(const btk_fb* fb, const float* pcm, long nsamples, long
   const int nruns = (ntiles + F_RUN - 1) / F_RUN;
   const long nblocks = (long)((nchan + 7) / 8) * nruns * 8;
   const bool shard = !(fb->kx0 == 0 && fb->kx1 == fb->K);
-  auto kern = shard ? fast_analysis_kernel<LOG2M, R, true> : fast_analysis_kernel<LOG2M, R, false>;
+  auto kern = shard ? fast_analysis_kernel<LOG2M, R, true, PT> : fast_analysis_kernel<LOG2M, R, false, PT>;
   // per launch: the attribute is per device, and one process may drive several GPUs (btk_set_device)
   BTK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const float gain = fb->gain_factor > 0 ? (float)fb->gain_factor : 1.0f;
@@ -378,14 +385,14 @@ int launch_fast_analysis(const btk_fb* fb, const float* pcm, long nsamples, long
   return 1;
 }
 
-template <int LOG2M>
-int fast_analysis_r(const btk_fb* fb, const float* pcm, long nsamples, long pcm_stride, int S, int N, float2* X,
+template <int LOG2M, typename PT = float>
+int fast_analysis_r(const btk_fb* fb, const PT* pcm, long nsamples, long pcm_stride, int S, int N, float2* X,
                     long T_stride, long t0, long tcount, hipStream_t st)
 {
   switch (fb->R) {
-    case 1: return launch_fast_analysis<LOG2M, 1>(fb, pcm, nsamples, pcm_stride, S, N, X, T_stride, t0, tcount, st);
-    case 2: return launch_fast_analysis<LOG2M, 2>(fb, pcm, nsamples, pcm_stride, S, N, X, T_stride, t0, tcount, st);
-    case 4: return launch_fast_analysis<LOG2M, 4>(fb, pcm, nsamples, pcm_stride, S, N, X, T_stride, t0, tcount, st);
+    case 1: return launch_fast_analysis<LOG2M, 1, PT>(fb, pcm, nsamples, pcm_stride, S, N, X, T_stride, t0, tcount, st);
+    case 2: return launch_fast_analysis<LOG2M, 2, PT>(fb, pcm, nsamples, pcm_stride, S, N, X, T_stride, t0, tcount, st);
+    case 4: return launch_fast_analysis<LOG2M, 4, PT>(fb, pcm, nsamples, pcm_stride, S, N, X, T_stride, t0, tcount, st);
   }
   return 0;
 }
@@ -409,9 +416,9 @@ __global__ void f_transpose_weights_kernel(const float2* __restrict__ W, float2*
   Wt[(s * N + n) * K + k] = W[i];
 }
 
-template <int LOG2M, int R>
+template <int LOG2M, int R, typename PT = float>
 __global__ __launch_bounds__(F_NT, 2)
-void fast_analysis_bf_kernel(const float* __restrict__ pcm, long nsamples, long pcm_stride,
+void fast_analysis_bf_kernel(const PT* __restrict__ pcm, long nsamples, long pcm_stride,
                              const float* __restrict__ proto, const float2* __restrict__ twg,
                              int laN, float gain, int N, int K, const float2* __restrict__ Wt, long w_stream_stride,
                              float2* __restrict__ Y, long T_stride, long t0, long tcount, int ntiles, int tiles_per_xcd, int S)
@@ -441,19 +448,24 @@ void fast_analysis_bf_kernel(const float* __restrict__ pcm, long nsamples, long 
 
   for (int i = tid; i < NF; i += F_NT) twj[i] = twg[(2 * (i % P2) * (i / P2)) & (M - 1)];
 
-  const bool vec_ok = ((pcm_stride & 3) == 0) && ((reinterpret_cast<uintptr_t>(pcm) & 15) == 0);
+  constexpr bool I16 = sizeof(PT) == 2;
+  const bool vec_ok = ((pcm_stride & 3) == 0) && ((reinterpret_cast<uintptr_t>(pcm) & (I16 ? 7 : 15)) == 0) && (!I16 || nsamples < (1L << 30));
   const long g0 = (t0 + tt0 + laN + 1) * (long)D - (long)F_MT * M;
   const bool inb = vec_ok && g0 >= 0 && g0 + SPAN <= nsamples;
   const float2* wts = Wt + (long)s * w_stream_stride;
   float4 pre[NV4];
   float2 wpre[NWP];
   auto fetch = [&](int n) {
-    const float* src = pcm + ((long)s * N + n) * pcm_stride;
+    const PT* src = pcm + ((long)s * N + n) * pcm_stride;
     if (inb) {
+      const __amdgpu_buffer_rsrc_t rs16 = __builtin_amdgcn_make_buffer_rsrc(const_cast<PT*>(src), 0, 0x7fffffff, I16 ? BTK_RSRC_I16X4_SSCALED : 0);
 #pragma unroll
       for (int q = 0; q < NV4; q++) {
         const int l = (tid + q * F_NT) * 4;
-        if (l < SPAN) pre[q] = *reinterpret_cast<const float4*>(src + g0 + l);
+        if (l < SPAN) {
+          if constexpr (I16) { const btk_f4v w = btk_buffer_load_i16x4_f32(rs16, (int)((g0 + l) * 2), 0, 0); pre[q] = make_float4(w.x, w.y, w.z, w.w); }
+          else pre[q] = *reinterpret_cast<const float4*>(src + g0 + l);
+        }
       }
     } else {
 #pragma unroll
@@ -463,7 +475,7 @@ void fast_analysis_bf_kernel(const float* __restrict__ pcm, long nsamples, long 
 #pragma unroll
         for (int e = 0; e < 4; e++) {
           const long g = g0 + l + e;
-          v[e] = (l + e < SPAN && g >= 0 && g < nsamples) ? src[g] : 0.0f;
+          v[e] = (l + e < SPAN && g >= 0 && g < nsamples) ? (float)src[g] : 0.0f;
         }
         pre[q] = make_float4(v[0], v[1], v[2], v[3]);
       }
@@ -578,8 +590,8 @@ void fast_analysis_bf_kernel(const float* __restrict__ pcm, long nsamples, long 
   }
 }
 
-template <int LOG2M, int R>
-int launch_fast_analysis_bf(const btk_fb* fb, const float* pcm, long nsamples, long pcm_stride, int S, int N, const float2* W,
+template <int LOG2M, int R, typename PT = float>
+int launch_fast_analysis_bf(const btk_fb* fb, const PT* pcm, long nsamples, long pcm_stride, int S, int N, const float2* W,
                             int per_stream, float2* Wt, float2* Y, long T_stride, long t0, long tcount, hipStream_t st)
 {
   using G = FG<LOG2M>;
@@ -595,7 +607,7 @@ int launch_fast_analysis_bf(const btk_fb* fb, const float* pcm, long nsamples, l
   const int ntiles = (int)((tcount + G::TT - 1) / G::TT);
   const int tiles_per_xcd = (ntiles + 7) / 8;
   const long nblocks = (long)8 * tiles_per_xcd * S;
-  auto kern = fast_analysis_bf_kernel<LOG2M, R>;
+  auto kern = fast_analysis_bf_kernel<LOG2M, R, PT>;
   // per launch: the attribute is per device, and one process may drive several GPUs (btk_set_device)
   BTK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const float gain = fb->gain_factor > 0 ? (float)fb->gain_factor : 1.0f;
@@ -605,14 +617,14 @@ int launch_fast_analysis_bf(const btk_fb* fb, const float* pcm, long nsamples, l
   return 1;
 }
 
-template <int LOG2M>
-int fast_analysis_bf_r(const btk_fb* fb, const float* pcm, long nsamples, long pcm_stride, int S, int N, const float2* W,
+template <int LOG2M, typename PT = float>
+int fast_analysis_bf_r(const btk_fb* fb, const PT* pcm, long nsamples, long pcm_stride, int S, int N, const float2* W,
                        int per_stream, float2* Wt, float2* Y, long T_stride, long t0, long tcount, hipStream_t st)
 {
   switch (fb->R) {
-    case 1: return launch_fast_analysis_bf<LOG2M, 1>(fb, pcm, nsamples, pcm_stride, S, N, W, per_stream, Wt, Y, T_stride, t0, tcount, st);
-    case 2: return launch_fast_analysis_bf<LOG2M, 2>(fb, pcm, nsamples, pcm_stride, S, N, W, per_stream, Wt, Y, T_stride, t0, tcount, st);
-    case 4: return launch_fast_analysis_bf<LOG2M, 4>(fb, pcm, nsamples, pcm_stride, S, N, W, per_stream, Wt, Y, T_stride, t0, tcount, st);
+    case 1: return launch_fast_analysis_bf<LOG2M, 1, PT>(fb, pcm, nsamples, pcm_stride, S, N, W, per_stream, Wt, Y, T_stride, t0, tcount, st);
+    case 2: return launch_fast_analysis_bf<LOG2M, 2, PT>(fb, pcm, nsamples, pcm_stride, S, N, W, per_stream, Wt, Y, T_stride, t0, tcount, st);
+    case 4: return launch_fast_analysis_bf<LOG2M, 4, PT>(fb, pcm, nsamples, pcm_stride, S, N, W, per_stream, Wt, Y, T_stride, t0, tcount, st);
   }
   return 0;
 }
@@ -1034,6 +1046,30 @@ int btk_fast_analysis_try(const btk_fb* fb, const float* pcm, long nsamples, lon
     case 2048: return fast_analysis_r<11>(fb, pcm, nsamples, pcm_stride, S, N, Xp, T_stride, t0, tcount, st);
   }
   return 0;
+}
+
+// the same from 16-bit PCM (btk_fb_analysis_i16; M = 512 has its own kernel in fb_analysis512.hip)
+int btk_fast_analysis_i16_try(const btk_fb* fb, const short* pcm, long nsamples, long pcm_stride, int S, int N, void* X,
+                              long T_stride, long t0, long tcount, hipStream_t st)
+{
+  if (fb->m != F_MT) return 0;
+  float2* Xp = static_cast<float2*>(X);
+  switch (fb->M) {
+    case 256:  return fast_analysis_r<8, short>(fb, pcm, nsamples, pcm_stride, S, N, Xp, T_stride, t0, tcount, st);
+    case 512:  return fast_analysis_r<9, short>(fb, pcm, nsamples, pcm_stride, S, N, Xp, T_stride, t0, tcount, st);
+    case 1024: return fast_analysis_r<10, short>(fb, pcm, nsamples, pcm_stride, S, N, Xp, T_stride, t0, tcount, st);
+    case 2048: return fast_analysis_r<11, short>(fb, pcm, nsamples, pcm_stride, S, N, Xp, T_stride, t0, tcount, st);
+  }
+  return 0;
+}
+
+// fused analysis + fixed-weight beamformer for M = 256 from 16-bit PCM (btk_fb_analysis_bf_i16)
+int btk_fast_analysis_bf_i16_try(const btk_fb* fb, const short* pcm, long nsamples, long pcm_stride, int S, int N, const void* W,
+                                 int per_stream, void* Wt_scratch, void* Y, long T_stride, long t0, long tcount, hipStream_t st)
+{
+  if (fb->m != F_MT || fb->M != 256) return 0;
+  return fast_analysis_bf_r<8, short>(fb, pcm, nsamples, pcm_stride, S, N, static_cast<const float2*>(W), per_stream, static_cast<float2*>(Wt_scratch),
+                                      static_cast<float2*>(Y), T_stride, t0, tcount, st);
 }
 
 // fused analysis + fixed-weight beamformer for M = 256 (the reference's default geometry), m = 4; scratch: Sw K N complex64

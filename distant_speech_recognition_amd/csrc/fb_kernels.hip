@@ -359,8 +359,9 @@ int btk_fb_analysis(const btk_fb_t* fb, const float* pcm, long nsamples, long pc
 int btk_fb_analysis_i16_direct(const btk_fb_t* fb)
 {
   if (!fb || fb->synthesis) return btk_set_error(BTK_ERR_PARAMETER, "btk_fb_analysis_i16_direct: not an analysis plan");
-  if (btk_switches().disable_analysis512) return 0;
-  return fb->M == 512 && fb->m == 4 && (fb->R == 1 || fb->R == 2 || fb->R == 4);
+  if (fb->m != 4 || !(fb->R == 1 || fb->R == 2 || fb->R == 4)) return 0;
+  if (fb->M == 512 && !btk_switches().disable_analysis512) return 1;
+  return !btk_switches().disable_fast && (fb->M == 256 || fb->M == 512 || fb->M == 1024 || fb->M == 2048);
 }
 
 int btk_fb_analysis_i16(const btk_fb_t* fb, const short* pcm, long nsamples, long pcm_stride,
@@ -373,7 +374,8 @@ int btk_fb_analysis_i16(const btk_fb_t* fb, const short* pcm, long nsamples, lon
   if (!pcm || !X) return btk_set_error(BTK_ERR_PARAMETER, "btk_fb_analysis_i16: null argument");
   if (btk_fb_analysis_i16_direct(fb) != 1)
     return btk_set_error(BTK_ERR_PARAMETER, "btk_fb_analysis_i16: no int16 kernel for M=%d m=%d r=%d (btk_pcm_i16_to_f32 + btk_fb_analysis)", fb->M, fb->m, fb->r);
-  const int rc = btk_analysis512_i16_try(fb, pcm, nsamples, pcm_stride, S, N, X, T_stride, t0, tcount, as_stream(stream));
+  int rc = btk_switches().disable_analysis512 ? 0 : btk_analysis512_i16_try(fb, pcm, nsamples, pcm_stride, S, N, X, T_stride, t0, tcount, as_stream(stream));
+  if (rc == 0) rc = btk_fast_analysis_i16_try(fb, pcm, nsamples, pcm_stride, S, N, X, T_stride, t0, tcount, as_stream(stream));
   if (rc == 0) return btk_set_error(BTK_ERR_PARAMETER, "btk_fb_analysis_i16: geometry not covered");
   return rc > 0 ? BTK_OK : rc;
 }
@@ -503,7 +505,8 @@ int btk_fb_analysis_bf_i16_fused(const btk_fb_t* fb)
 {
   if (!fb || fb->synthesis) return btk_set_error(BTK_ERR_PARAMETER, "btk_fb_analysis_bf_i16_fused: not an analysis plan");
   if (btk_switches().disable_fused || fb->m != 4 || fb->kx0 != 0 || fb->kx1 != fb->K) return 0;
-  if (fb->M == 512) return fb->R == 1 || fb->R == 2 || fb->R == 4;
+  if (fb->M == 256 && btk_switches().disable_fast) return 0;
+  if (fb->M == 512 || fb->M == 256) return fb->R == 1 || fb->R == 2 || fb->R == 4;
   return (fb->M == 1024 || fb->M == 2048) && fb->R == 2;
 }
 
@@ -525,6 +528,7 @@ int btk_fb_analysis_bf_i16(const btk_fb_t* fb, const short* pcm, long nsamples, 
   hipStream_t st = as_stream(stream);
   int rc = btk_analysis512_bf_i16_try(fb, pcm, nsamples, pcm_stride, S, N, W, per_stream_weights, scratch, Y, T_stride, t0, tcount, st);
   if (rc == 0) rc = btk_big_analysis_bf_i16_try(fb, pcm, nsamples, pcm_stride, S, N, W, per_stream_weights, scratch, Y, T_stride, t0, tcount, st);
+  if (rc == 0 && !btk_switches().disable_fast) rc = btk_fast_analysis_bf_i16_try(fb, pcm, nsamples, pcm_stride, S, N, W, per_stream_weights, scratch, Y, T_stride, t0, tcount, st);
   if (rc == 0) return btk_set_error(BTK_ERR_PARAMETER, "btk_fb_analysis_bf_i16: geometry not covered");
   return rc > 0 ? BTK_OK : rc;
 }

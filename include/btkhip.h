@@ -140,7 +140,7 @@ int  btk_fb_analysis_bf(const btk_fb_t* fb, const float* pcm, long nsamples, lon
  * un-normalised floats, feature/feature.cc:265-269; over PCIe and in HBM they can stay int16).  pcm [dev] int16 [S*N][pcm_stride],
  * widened in registers inside the fused kernel: 2 D N + 8 K bytes per beamformed frame instead of 4 D N + 8 K, and -- the
  * conversion is exact -- the SAME BITS as btk_fb_analysis_bf on the float copies of the same samples.  Geometries:
- * btk_fb_analysis_bf_i16_fused() == 1 (M = 512 with m = 4, r <= 2, and M = 1024 / 2048 with m = 4, r = 1); for the others widen
+ * btk_fb_analysis_bf_i16_fused() == 1 (M = 256 / 512 with m = 4, r <= 2, and M = 1024 / 2048 with m = 4, r = 1); for the others widen
  * with btk_pcm_i16_to_f32 and call btk_fb_analysis_bf (BTK_ERR_PARAMETER here).  scratch: btk_fb_analysis_bf_scratch_bytes.   */
 int  btk_fb_analysis_bf_i16_fused(const btk_fb_t* fb);
 /* The STAGED bank on 16-bit PCM (round 6): btk_fb_analysis with pcm [dev] int16 [S*N][pcm_stride], widened on the way into the
@@ -148,7 +148,7 @@ int  btk_fb_analysis_bf_i16_fused(const btk_fb_t* fb);
  * channel, and no btk_pcm_i16_to_f32 pass in front of it (4 D + 2 D bytes per frame and channel more).  What the snapshot
  * consumers of a 16-bit stream run on: post-filters, adaptive cancellers, covariance, WPE (OverSampledDFTAnalysisBank::next over
  * SampleFeature::read, modulated/modulated.cc:375-409 over feature/feature.cc:265-269).  Geometries:
- * btk_fb_analysis_i16_direct() == 1 (M = 512, m = 4, r <= 2); BTK_ERR_PARAMETER for the others (widen, then btk_fb_analysis). */
+ * btk_fb_analysis_i16_direct() == 1 (M = 256 / 512 / 1024 / 2048, m = 4, r <= 2); BTK_ERR_PARAMETER for the others (widen, then btk_fb_analysis). */
 int  btk_fb_analysis_i16_direct(const btk_fb_t* fb);
 int  btk_fb_analysis_i16(const btk_fb_t* fb, const short* pcm, long nsamples, long pcm_stride,
                          int S, int N, void* X, long T_stride, long t0, long tcount, void* stream);

@@ -29,6 +29,7 @@ def _bits(t):
 
 
 @pytest.mark.parametrize("M,N,S,T,r", [(512, 8, 2, 100, 1), (512, 64, 3, 75, 1), (512, 5, 1, 40, 0), (512, 6, 2, 90, 2),
+                                       (256, 8, 2, 120, 1), (256, 5, 1, 70, 0), (256, 12, 2, 90, 2),
                                        (1024, 16, 2, 50, 1), (2048, 24, 1, 44, 1), (2048, 256, 1, 24, 1)])
 def test_i16_entry_equals_f32_entry_bit_for_bit(dev, M, N, S, T, r):
     afb, pcm, W, _ = _setup(M, N, S, T, r, seed=M + N, dev=dev)
@@ -88,20 +89,21 @@ def test_i16_entry_against_oracle(orc, dev):
 def test_geometries_without_an_i16_kernel_say_so(dev):
     from distant_speech_recognition_amd import engine as eng, _lib
     from tests.util import design_prototype
-    afb = eng.FilterBank(design_prototype(256, 4), 256, 4, 1, 2)
+    afb = eng.FilterBank(design_prototype(128, 4), 128, 4, 1, 2)
     assert not afb.fused_i16()
-    pcm = torch.zeros((1, 4, 128 * 40), dtype=torch.int16, device=dev)
+    pcm = torch.zeros((1, 4, 64 * 40), dtype=torch.int16, device=dev)
     W = torch.zeros((1, afb.K, 4), dtype=torch.complex64, device=dev)
     with pytest.raises(_lib.BtkError):
         afb.analysis_beamform(pcm, W)
 
 
-@pytest.mark.parametrize("N,S,T,r", [(8, 2, 100, 1), (64, 2, 300, 1), (5, 1, 40, 0), (6, 2, 90, 2)])
-def test_staged_i16_analysis_equals_f32_analysis_bit_for_bit(dev, N, S, T, r):
-    """btk_fb_analysis_i16 (the STAGED bank on 16-bit PCM, M = 512): the snapshots of btk_fb_analysis on the float copies of the
-    same samples, bit for bit -- whole launches (runs of 16 tiles and the ragged last tile), pieces in the middle, a sample count
+@pytest.mark.parametrize("M,N,S,T,r", [(512, 8, 2, 100, 1), (512, 64, 2, 300, 1), (512, 5, 1, 40, 0), (512, 6, 2, 90, 2),
+                                       (256, 8, 2, 150, 1), (256, 5, 1, 60, 0), (1024, 6, 2, 70, 1), (1024, 4, 1, 50, 2), (2048, 5, 1, 40, 1)])
+def test_staged_i16_analysis_equals_f32_analysis_bit_for_bit(dev, M, N, S, T, r):
+    """btk_fb_analysis_i16 (the STAGED bank on 16-bit PCM, M = 256 ... 2048): the snapshots of btk_fb_analysis on the float copies of
+    the same samples, bit for bit -- whole launches (runs of tiles and the ragged last tile), pieces in the middle, a sample count
     that ends inside a tile, contiguous and row-padded snapshot blocks"""
-    afb, pcm, _, _ = _setup(512, N, S, T, r, seed=7 + N, dev=dev)
+    afb, pcm, _, _ = _setup(M, N, S, T, r, seed=7 + N + M, dev=dev)
     assert afb.analysis_i16()
     pf = torch.from_numpy(pcm).to(dev)
     pi = torch.from_numpy(pcm.astype(np.int16)).to(dev)
@@ -138,7 +140,7 @@ def test_staged_i16_analysis_unaligned_rows_and_other_geometries(dev):
         assert torch.equal(_bits(Xf), _bits(X)), (pad, off)
     with pytest.raises(_lib.BtkError):
         afb.analysis(torch.from_numpy(pcm.astype(np.int16)).to(dev), bins=(3, 40))
-    a256 = eng.FilterBank(design_prototype(256, 4), 256, 4, 1, 2)
-    assert not a256.analysis_i16()
+    a128 = eng.FilterBank(design_prototype(128, 4), 128, 4, 1, 2)
+    assert not a128.analysis_i16()
     with pytest.raises(_lib.BtkError):
-        a256.analysis(torch.zeros((1, 4, 128 * 40), dtype=torch.int16, device=dev))
+        a128.analysis(torch.zeros((1, 4, 64 * 40), dtype=torch.int16, device=dev))
