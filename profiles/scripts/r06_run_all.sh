@@ -53,6 +53,8 @@ python bench_stages.py > $O/bench_stages.json 2> $O/bench_stages.err
 python bench_configs.py > $O/bench_configs.json 2> $O/bench_configs.err
 python bench_bin_sharded.py > $O/bench_bin_sharded.json 2> $O/bench_bin_sharded.err
 python profiles/partition_probe.py > $O/partition_probe.txt 2>/dev/null
+python profiles/i16_banks_ab.py > $O/i16_banks_ab.json 2>/dev/null
+python profiles/node_api_python.py > $O/node_api_python.txt 2>/dev/null
 python profiles/wpe_envelope_probe.py 2>/dev/null | tail -1 > $O/wpe_envelope.txt
 BTK_WPE_LAGPROD_F32=1 python profiles/wpe_envelope_probe.py 2>/dev/null | tail -1 >> $O/wpe_envelope.txt
 WPE_S=2 bash profiles/scripts/r02_wpe_profile.sh > $O/wpe_profile.txt 2>&1
