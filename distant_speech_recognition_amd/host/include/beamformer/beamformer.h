@@ -427,6 +427,12 @@ class SubbandGraphPool : public Countable {
   bool next();                                              // one more output block of every graph that has one; false: all have ended
   const gsl_vector_float* output(unsigned g) const;         // graph g's block of the last next(); NULL once that graph has ended
   bool is_end(unsigned g) const;
+  // The blocks the next calls of next() would hand out, a ROUND at a time: next_round() makes the blocks every graph still has in
+  // the resident round (a new round when none has any) available at once -- false: all graphs have ended -- and round_blocks(g, &p)
+  // says how many graph g got (0: that graph has ended or had no block in this round) and where they lie (n x shiftlen floats,
+  // valid until the next call of next() / next_round()).  output(g) is then the last of them.
+  bool next_round();
+  long round_blocks(unsigned g, const float** blocks) const;
   long rounds() const { return rounds_; }                   // batched rounds (= launches of each kind) so far
   void reset();
  private:
@@ -437,6 +443,7 @@ class SubbandGraphPool : public Countable {
     long T, nblocks, served;   // this round: valid frames, output blocks, blocks handed out
     gsl_vector_float* out;
     bool has_out;
+    long round_first, round_n;   // next_round(): the blocks of the current round handed out at once
   };
   bool load_round_();
   // one round's input on its way to the device: every live graph's block plan and its sample windows in one block [G][N][Lmax]

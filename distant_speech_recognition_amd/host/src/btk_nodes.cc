@@ -3403,7 +3403,7 @@ void SubbandGraphPool::add(SubbandDSPtr& beamformer, OverSampledDFTSynthesisBank
   }
   Graph g;
   g.bf = beamformer; g.syn = synthesis; g.live = true; g.T = 0; g.nblocks = 0; g.served = 0;
-  g.out = gsl_vector_float_calloc(synthesis->shiftlen()); g.has_out = false;
+  g.out = gsl_vector_float_calloc(synthesis->shiftlen()); g.has_out = false; g.round_first = 0; g.round_n = 0;
   graphs_.push_back(g);
 }
 
@@ -3605,6 +3605,41 @@ bool SubbandGraphPool::next()
     }
   }
   return true;
+}
+
+bool SubbandGraphPool::next_round()
+{
+  if (graphs_.empty()) return false;
+  for (size_t g = 0; g < graphs_.size(); g++) { graphs_[g].round_first = 0; graphs_[g].round_n = 0; }
+  for (;;) {
+    bool any = false;
+    for (size_t g = 0; g < graphs_.size(); g++) if (graphs_[g].served < graphs_[g].nblocks) any = true;
+    if (any) break;
+    bool more = pre_.valid;
+    for (size_t g = 0; g < graphs_.size(); g++) if (graphs_[g].live) more = true;
+    if (!more || !load_round_()) {
+      for (size_t g = 0; g < graphs_.size(); g++) { graphs_[g].has_out = false; graphs_[g].nblocks = 0; graphs_[g].served = 0; }
+      return false;
+    }
+  }
+  const unsigned D = graphs_[0].syn->shiftlen();
+  const float* hO = static_cast<const float*>(hOut_.get());
+  for (size_t g = 0; g < graphs_.size(); g++) {
+    Graph& gr = graphs_[g];
+    gr.round_first = gr.served; gr.round_n = gr.nblocks - gr.served;
+    gr.has_out = gr.round_n > 0;
+    if (gr.has_out) memcpy(gr.out->data, hO + g * (size_t)out_stride_ + (size_t)(gr.nblocks - 1) * D, sizeof(float) * D);
+    gr.served = gr.nblocks;
+  }
+  return true;
+}
+
+long SubbandGraphPool::round_blocks(unsigned g, const float** blocks) const
+{
+  if (g >= graphs_.size()) throw jindex_error("SubbandGraphPool: graph %d of %d\n", (int)g, (int)graphs_.size());
+  const Graph& gr = graphs_[g];
+  if (blocks) *blocks = gr.round_n > 0 ? static_cast<const float*>(hOut_.get()) + g * (size_t)out_stride_ + (size_t)gr.round_first * graphs_[0].syn->shiftlen() : NULL;
+  return gr.round_n;
 }
 
 const gsl_vector_float* SubbandGraphPool::output(unsigned g) const

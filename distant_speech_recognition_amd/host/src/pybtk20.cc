@@ -581,7 +581,22 @@ PYBIND11_MODULE(_btk20cpp, m)
              for (unsigned g = 0; g < p.size(); g++) { const gsl_vector_float* v = p.output(g); if (v) out.append(view(v, self)); else out.append(py::none()); }
              return out; })
       .def("__next__", [](py::object self) { return self.attr("next")(); })
-      .def("__iter__", [](py::object self) { self.attr("reset")(); return self; });
+      .def("__iter__", [](py::object self) { self.attr("reset")(); return self; })
+      // engine extension: a round at a time -- a list with one float32 array [n_g][shiftlen] per graph (n_g = 0: none in this round),
+      // None when every graph has ended
+      .def("next_round", [](SubbandGraphPool& p) -> py::object {
+             bool ok; { py::gil_scoped_release rel; ok = p.next_round(); }
+             if (!ok) return py::none();
+             py::list out;
+             for (unsigned g = 0; g < p.size(); g++) {
+               const float* q = NULL;
+               const long n = p.round_blocks(g, &q);
+               const py::ssize_t D = n > 0 ? (py::ssize_t)p.output(g)->size : 0;
+               py::array_t<float> a({(py::ssize_t)n, D});
+               if (n > 0) memcpy(a.mutable_data(), q, sizeof(float) * (size_t)n * (size_t)D);
+               out.append(a);
+             }
+             return out; });
   m.def("node_synchronize", []() { btk_node_synchronize(); });     // wait for everything this thread's nodes have launched
   m.def("node_alloc_counts", []() { long d = 0, h = 0; btk_node_alloc_counts(&d, &h); return py::make_tuple(d, h); });   // (hipMalloc, hipHostMalloc) calls so far
 

@@ -95,6 +95,29 @@ def test_pool_equals_graphs_pulled_one_by_one(dev, M, N, block_frames, dct):
     for i in range(3):
         assert np.array_equal(np.concatenate(third[i]).view(np.uint32), singles[i].view(np.uint32))
 
+    # a fourth pass a ROUND at a time (next_round: engine extension): per graph the same blocks, in far fewer calls
+    for i in range(3):
+        pcm, _ = synthetic_pcm(1, N, lens[i], seed=100 + i)
+        for c in range(N):
+            keepalive[6 * i + 3][2 * c].set_samples(np.ascontiguousarray(pcm[0][c], np.float32))
+    pool.reset()
+    fourth, calls = [[] for _ in range(3)], 0
+    while True:
+        outs = pool.next_round()
+        if outs is None:
+            break
+        calls += 1
+        assert len(outs) == 3
+        for i, a in enumerate(outs):
+            assert a.dtype == np.float32 and a.ndim == 2
+            if a.shape[0]:
+                assert a.shape[1] == D
+                fourth[i].append(a)
+    for i in range(3):
+        assert pool.is_end(i)
+        assert np.array_equal(np.concatenate(fourth[i]).reshape(-1).view(np.uint32), singles[i].view(np.uint32))
+    assert calls <= pool.rounds() + 1 and (block_frames == 0 or calls < singles[2].size // D // 8)
+
 
 def test_pool_refuses_what_it_cannot_batch(dev):
     from distant_speech_recognition_amd.btk20 import SubbandGraphPoolPtr, j_error
