@@ -294,7 +294,8 @@ void* PinnedBuffer::ensure_keep(size_t bytes, size_t keep_bytes)
   if (bytes <= cap_ && p_) return p_;
   const size_t want = std::max(bytes ? bytes : (size_t)16, cap_ + cap_ / 2);
   void* q = NULL;
-  check_hip(hipHostMalloc(&q, want, hipHostMallocDefault), "hipHostMalloc");
+  // (mapped: the gather kernel of upload_rows reads this memory itself; portable: whichever device of the process runs it)
+  check_hip(hipHostMalloc(&q, want, hipHostMallocPortable | hipHostMallocMapped), "hipHostMalloc");
   g_pinned_allocs++;
   if (p_) {
     nsync();                                                                // copies that still read the old block
