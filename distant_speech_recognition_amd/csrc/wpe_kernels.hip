@@ -628,9 +628,11 @@ __device__ __forceinline__ f16x8 mk8(unsigned a, unsigned b, unsigned c, unsigne
 
 // scales[(s K + k) 2 + {0, 1}] = power of two that brings the largest weight / the bound 2 max|y|^2 of the products to < 2^14
 __global__ __launch_bounds__(256)
-void wpe_lp_scale_kernel(const float2* __restrict__ X, const float* __restrict__ Winv, WpeGeom g, float* __restrict__ scales)
+void wpe_lp_scale_kernel(const float2* __restrict__ X, const float* __restrict__ Winv, WpeGeom g, float* __restrict__ scales,
+                         int* __restrict__ tile_exp /* [S][K][nt_stride] */, int nt_stride)
 {
   __shared__ float red[2][4];
+  __shared__ float sab[2];
   const int k = blockIdx.x, s = blockIdx.y, tid = threadIdx.x;
   float wm = 0.f, ym = 0.f;
   if (bin_active(g, k)) {
@@ -657,6 +659,75 @@ void wpe_lp_scale_kernel(const float2* __restrict__ X, const float* __restrict__
     const int xa = 14 - ea < -60 ? -60 : (14 - ea > 60 ? 60 : 14 - ea), xb = 14 - eb < -60 ? -60 : (14 - eb > 60 ? 60 : 14 - eb);
     scales[((long)s * g.K + k) * 2 + 0] = ldexpf(1.f, xa);
     scales[((long)s * g.K + k) * 2 + 1] = ldexpf(1.f, xb);
+    sab[0] = ldexpf(1.f, xa); sab[1] = ldexpf(1.f, xb);
+  }
+  __syncthreads();
+  // Exponent balance per 64-frame tile (round 6; see lagprod16_task): half the distance between the exponents of the largest scaled
+  // weight and the largest scaled product bound among the frames a task stages for the tile.  The samples' span does not depend on the
+  // task; the weights' span starts la frames in and is LP_WT + RL nb - 1 long (nb = the task's row blocks, 1 .. LP_RMAX): one value per
+  // (tile, q = (L - la) / RL, nb), the SAME numbers the tasks used to find themselves -- every tile, in the wavefronts that prepare the
+  // operands, 52 tasks per bin at L = 33: 7 % of the kernel.  te[(j NLA + q) LP_RMAX + nb - 1].
+  if (!bin_active(g, k)) return;
+  const float sa = sab[0], sb = sab[1];
+  const int RLs = 32 / g.C, NLA = (g.L + RLs - 1) / RLs + 1;
+  const long ntile = (g.T + LP_WT - 1) / LP_WT;
+  int* te = tile_exp + ((long)s * g.K + k) * nt_stride;
+  // (16 tiles at a time: the largest weight over the channels of every frame the 16 tiles' spans can touch goes to LDS first, the spans
+  //  of the (tile, q, nb) entries are then maxima over LDS words -- the table costs 30 us per launch instead of 70)
+  constexpr int WMX = 16 * LP_WT + 256;
+  __shared__ float wmx[WMX];
+  for (long j0 = 0; j0 < ntile; j0 += 16) {
+    long tA = j0 * LP_WT + g.lowerN - RLs, tB = (j0 + 16) * LP_WT + g.lowerN + g.L + RLs * LP_RMAX;
+    if (tA < g.lowerN) tA = g.lowerN;
+    if (tB > g.T) tB = g.T;
+    const bool in_lds = tB - tA <= WMX;                              // (L <= ~170 at 8 channels; beyond that the spans read global memory)
+    __syncthreads();
+    if (in_lds)
+      for (long i = tid; i < tB - tA; i += 256) {
+        float m = 0.f;
+        for (int c = 0; c < g.C; c++) m = fmaxf(m, Winv[(((long)s * g.C + c) * g.K + k) * g.T_stride + tA + i]);
+        wmx[i] = m;
+      }
+    __syncthreads();
+    const long j = j0 + (tid >> 4);
+    const int sub = tid & 15;
+    const long u0 = j * LP_WT;
+    float ymj = 0.f;
+    if (j < ntile) {
+      long ty1 = u0 + LP_WT + g.L - 1;
+      if (ty1 > g.T) ty1 = g.T;
+      for (int c = 0; c < g.C; c++) {
+        const float2* y = X + (((long)s * g.K + k) * g.C + c) * g.T_stride;
+        for (long u = u0 + sub; u < ty1; u += 16) { const float2 v = y[u]; ymj = fmaxf(ymj, fmaf(v.x, v.x, v.y * v.y)); }
+      }
+    }
+    for (int o = 8; o > 0; o >>= 1) ymj = fmaxf(ymj, __shfl_xor(ymj, o));
+    if (j < ntile) {
+      const float bm2 = ymj * sb;
+      for (int q = sub; q < NLA; q += 16) {
+        const long la = (long)g.L - (long)RLs * q;
+        long t = u0 + g.lowerN + la;                                 // first weight of the span (entries before lowerN / behind T are zeros)
+        float wmq = 0.f;
+        long t1 = t + LP_WT - 1;                                     // the span of nb row blocks ends at t + LP_WT + RL nb - 1
+        for (int nbk = 1; nbk <= LP_RMAX; nbk++) {
+          t1 += RLs;
+          const long lo = t < g.lowerN ? g.lowerN : t, hi = t1 < g.T ? t1 : g.T;
+          if (in_lds) {
+            for (long tt = lo; tt < hi; tt++) wmq = fmaxf(wmq, wmx[tt - tA]);
+          } else {
+            for (int c = 0; c < g.C; c++) {
+              const float* w = Winv + (((long)s * g.C + c) * g.K + k) * g.T_stride;
+              for (long tt = lo; tt < hi; tt++) wmq = fmaxf(wmq, w[tt]);
+            }
+          }
+          t = hi > t ? hi : t;                                       // the next, longer span adds only its tail
+          const float wm2 = wmq * sa;
+          int ea = 0, eb = 0;
+          if (wm2 > 0.f && bm2 > 0.f) { (void)frexpf(wm2, &ea); (void)frexpf(bm2, &eb); }
+          te[(j * NLA + q) * LP_RMAX + nbk - 1] = (ea - eb) >> 1;    // |e| <= 64: exact powers of two
+        }
+      }
+    }
   }
 }
 
@@ -691,7 +762,7 @@ __device__ __forceinline__ void split2m(float a, float b, unsigned& hi, unsigned
 template <int C, int NR, int NCW>
 __device__ __forceinline__ void lagprod16_task(const float2* __restrict__ Xk, const float* __restrict__ Wk, const WpeGeom& g, float2* __restrict__ R,
                                                int ys_ld, int ws_ld, int d, int la, int s, int k, float2* ys, float* ws, uint4* wcp,
-                                               float sa, float sb, float* tmx)
+                                               float sa, float sb, const int* __restrict__ te)
 {
   static_assert(C == 8 && (NCW == 1 || NCW == 2), "4 / NCW wavefronts x NCW column blocks");   // column blocks per wavefront: col = 2 (c1 C + c2) + (0 re | 1 im)
   constexpr int RL = 32 / C;                                       // l1 values per 32-row block: row m of block j -> (l1 = la + RL j + m / C, c = m % C)
@@ -749,20 +820,10 @@ __device__ __forceinline__ void lagprod16_task(const float2* __restrict__ Xk, co
     // 3e-5 / 1.5e-4; profiles/r06_wpe_envelope.txt).  Per tile the two operands trade a power of two, a 2^-e and b 2^+e with
     // e = half the distance between the exponents of the tile's largest weight and largest product bound: both then peak at the same
     // height (<= 2^14), the product -- hence the accumulators' scale -- is unchanged, and nothing is rounded by it.
-    if (tid < 128) {
-      float wm = 0.f, ym = 0.f;
-#pragma unroll
-      for (int c = 0; c < C; c++) { wm = fmaxf(wm, wpf[c]); ym = fmaxf(ym, fmaf(ypf[c].x, ypf[c].x, ypf[c].y * ypf[c].y)); }
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) { wm = fmaxf(wm, __shfl_xor(wm, o)); ym = fmaxf(ym, __shfl_xor(ym, o)); }
-      if (lane == 0) { tmx[tpar * 4 + 2 * wv] = wm; tmx[tpar * 4 + 2 * wv + 1] = ym * sb; }    // (slots of this tile's parity: the last tile's are still being read)
-    }
+    // (the exponent of the tile comes from wpe_lp_scale_kernel: one value per (stream, bin, tile), the same for every task)
     __syncthreads();                                               // the reads of the last tile are done
     if (tid < 128) {
-      const float wm = fmaxf(tmx[tpar * 4], tmx[tpar * 4 + 2]), bm = fmaxf(tmx[tpar * 4 + 1], tmx[tpar * 4 + 3]);
-      int ea = 0, eb = 0;
-      if (wm > 0.f && bm > 0.f) { (void)frexpf(wm, &ea); (void)frexpf(bm, &eb); }
-      const int eh = (ea - eb) >> 1;                               // |eh| <= 64: exact powers of two
+      const int eh = te[((u0 / LP_WT) * ((L + RL - 1) / RL + 1) + (L - la) / RL) * LP_RMAX + NR - 1];   // |eh| <= 64: exact powers of two (wpe_lp_scale_kernel)
       const float fa = ldexpf(1.f, -eh), fb = sb * ldexpf(1.f, eh);
       const int e = tid;
 #pragma unroll
@@ -886,7 +947,7 @@ __device__ __forceinline__ void lagprod16_task(const float2* __restrict__ Xk, co
 
 template <int C, int NCW>
 __device__ __forceinline__ void wpe_lagprod16_body(const float2* __restrict__ X, const float* __restrict__ Winv, WpeGeom g, float2* __restrict__ R, int ys_ld, int ws_ld,
-                          const float* __restrict__ scales)
+                          const float* __restrict__ scales, const int* __restrict__ tile_exp, int nt_stride)
 {
   constexpr int RL = 32 / C;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -894,7 +955,6 @@ __device__ __forceinline__ void wpe_lagprod16_body(const float2* __restrict__ X,
   uint4* wcp = reinterpret_cast<uint4*>(smem);                     // [2 (high | low)][8 shifts][C][LP16_NB] x 8 float16
   float2* ys = reinterpret_cast<float2*>(wcp + 2 * 8 * C * LP16_NB);   // [C][ys_ld]: sample u0 + e of channel c'
   float* ws = reinterpret_cast<float*>(ys + 3 * C * ys_ld);        // (ys is followed by the two pre-multiplied forms of the second factor) [C][ws_ld]: w_c(u0 + lowerN + la + e), scaled
-  float* tmx = ws + C * ws_ld;                                     // [2 (tile parity)][2 staging wavefronts][2]: largest weight / product bound of a tile
   const int k = blockIdx.y, s = blockIdx.z;
   if (!bin_active(g, k)) return;
   const int L = g.L;
@@ -909,26 +969,27 @@ __device__ __forceinline__ void wpe_lagprod16_body(const float2* __restrict__ X,
   const float2* Xk = X + ((long)s * g.K + k) * C * g.T_stride;
   const float* Wk = Winv + ((long)s * C * g.K + k) * g.T_stride;
   const float sa = scales[((long)s * g.K + k) * 2], sb = scales[((long)s * g.K + k) * 2 + 1];
+  const int* te = tile_exp + ((long)s * g.K + k) * nt_stride;
   switch (nb) {
-    case 4: lagprod16_task<C, 4, NCW>(Xk, Wk, g, R, ys_ld, ws_ld, d, la, s, k, ys, ws, wcp, sa, sb, tmx); break;
-    case 3: lagprod16_task<C, 3, NCW>(Xk, Wk, g, R, ys_ld, ws_ld, d, la, s, k, ys, ws, wcp, sa, sb, tmx); break;
-    case 2: lagprod16_task<C, 2, NCW>(Xk, Wk, g, R, ys_ld, ws_ld, d, la, s, k, ys, ws, wcp, sa, sb, tmx); break;
-    default: lagprod16_task<C, 1, NCW>(Xk, Wk, g, R, ys_ld, ws_ld, d, la, s, k, ys, ws, wcp, sa, sb, tmx); break;
+    case 4: lagprod16_task<C, 4, NCW>(Xk, Wk, g, R, ys_ld, ws_ld, d, la, s, k, ys, ws, wcp, sa, sb, te); break;
+    case 3: lagprod16_task<C, 3, NCW>(Xk, Wk, g, R, ys_ld, ws_ld, d, la, s, k, ys, ws, wcp, sa, sb, te); break;
+    case 2: lagprod16_task<C, 2, NCW>(Xk, Wk, g, R, ys_ld, ws_ld, d, la, s, k, ys, ws, wcp, sa, sb, te); break;
+    default: lagprod16_task<C, 1, NCW>(Xk, Wk, g, R, ys_ld, ws_ld, d, la, s, k, ys, ws, wcp, sa, sb, te); break;
   }
 }
 
 // two wavefronts x two column blocks (256 registers per lane: two wavefronts per SIMD) / four x one (168: three per SIMD)
 __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void wpe_lagprod16_w2_kernel(const float2* __restrict__ X, const float* __restrict__ Winv, WpeGeom g, float2* __restrict__ R, int ys_ld, int ws_ld,
-                             const float* __restrict__ scales)
+                             const float* __restrict__ scales, const int* __restrict__ tile_exp, int nt_stride)
 {
-  wpe_lagprod16_body<8, 2>(X, Winv, g, R, ys_ld, ws_ld, scales);
+  wpe_lagprod16_body<8, 2>(X, Winv, g, R, ys_ld, ws_ld, scales, tile_exp, nt_stride);
 }
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3)))
 void wpe_lagprod16_w4_kernel(const float2* __restrict__ X, const float* __restrict__ Winv, WpeGeom g, float2* __restrict__ R, int ys_ld, int ws_ld,
-                             const float* __restrict__ scales)
+                             const float* __restrict__ scales, const int* __restrict__ tile_exp, int nt_stride)
 {
-  wpe_lagprod16_body<8, 1>(X, Winv, g, R, ys_ld, ws_ld, scales);
+  wpe_lagprod16_body<8, 1>(X, Winv, g, R, ys_ld, ws_ld, scales, tile_exp, nt_stride);
 }
 
 template <int C>
@@ -1140,7 +1201,7 @@ long btk_wpe_workspace_bytes(int S, int K, int C, int lowerN, int upperN, long T
 {
   const long P = (long)C * (upperN - lowerN + 1);
   const long nb = (long)S * C * K;
-  return nb * P * P * 8 + nb * P * 8 + nb * T_stride * 4 + (long)S * K * 8 + 256;
+  return nb * P * P * 8 + nb * P * 8 + nb * T_stride * 4 + (long)S * K * 8 + (long)S * K * (T_stride / 64 + 2) * (((upperN - lowerN + 1) + 32 / (C > 0 && C <= 32 ? C : 32) - 1) / (32 / (C > 0 && C <= 32 ? C : 32)) + 1) * 4 * 4 + 256;
 }
 
 int btk_wpe_estimate(const void* X, int S, int K, int C, long T_stride, long T, int lowerN, int upperN, int iterations,
@@ -1159,6 +1220,9 @@ int btk_wpe_estimate(const void* X, int S, int K, int C, long T_stride, long T, 
   float2* rvec = R + nb * P * P;
   float* Winv = reinterpret_cast<float*>(rvec + nb * P);
   float* lp_scales = Winv + nb * T_stride;                          // [S][K][2]: operand scales of the float16 lag-product kernel
+  const int nla = C <= 32 ? ((g.L + 32 / C - 1) / (32 / C) + 1) : 1;
+  const int nt_stride = (int)(T_stride / 64 + 2) * nla * 4;          // per (stream, bin): [tiles][q][row blocks] (wpe_lp_scale_kernel)
+  int* lp_tile_exp = reinterpret_cast<int*>(lp_scales + (long)S * K * 2);   // [S][K][nt_stride]: its per-tile exponent trades
   const float2* Xp = static_cast<const float2*>(X);
   float2* Gp = static_cast<float2*>(G);
   const int ntile = (int)((P + 63) / 64);
@@ -1209,11 +1273,11 @@ int btk_wpe_estimate(const void* X, int S, int K, int C, long T_stride, long T, 
         const int nb16 = lp16_nb(C);
         const int ws16 = 8 * nb16 + 8;                                         // >= 8 (nb16 - 1) + 15 values (40 KB of LDS per task with this: four tasks per CU)
         const size_t lds16p = sizeof(uint4) * 2 * 8 * (size_t)C * nb16 + sizeof(float2) * 3 * (size_t)C * ys_ld + sizeof(float) * (size_t)C * ws16 + sizeof(float) * 8;
-        hipLaunchKernelGGL(wpe_lp_scale_kernel, dim3((unsigned)K, (unsigned)S), dim3(256), 0, st, Xp, Winv, g, lp_scales);
+        hipLaunchKernelGGL(wpe_lp_scale_kernel, dim3((unsigned)K, (unsigned)S), dim3(256), 0, st, Xp, Winv, g, lp_scales, lp_tile_exp, nt_stride);
         if (btk_switches().wpe_lagprod_waves == 2)
-          hipLaunchKernelGGL(wpe_lagprod16_w2_kernel, dim3(ntask, (unsigned)K, (unsigned)S), dim3(128), lds16p, st, Xp, Winv, g, R, ys_ld, ws16, lp_scales);
+          hipLaunchKernelGGL(wpe_lagprod16_w2_kernel, dim3(ntask, (unsigned)K, (unsigned)S), dim3(128), lds16p, st, Xp, Winv, g, R, ys_ld, ws16, lp_scales, lp_tile_exp, nt_stride);
         else
-          hipLaunchKernelGGL(wpe_lagprod16_w4_kernel, dim3(ntask, (unsigned)K, (unsigned)S), dim3(256), lds16p, st, Xp, Winv, g, R, ys_ld, ws16, lp_scales);
+          hipLaunchKernelGGL(wpe_lagprod16_w4_kernel, dim3(ntask, (unsigned)K, (unsigned)S), dim3(256), lds16p, st, Xp, Winv, g, R, ys_ld, ws16, lp_scales, lp_tile_exp, nt_stride);
       }
       else if (C == 8) hipLaunchKernelGGL(wpe_lagprod_kernel<8>, dim3(ntask, (unsigned)K, (unsigned)S), dim3(64), lds_lp, st, Xp, Winv, g, R, ys_ld, ws_ld);
       else        hipLaunchKernelGGL(wpe_lagprod_kernel<4>, dim3(ntask, (unsigned)K, (unsigned)S), dim3(64), lds_lp, st, Xp, Winv, g, R, ys_ld, ws_ld);
