@@ -764,7 +764,11 @@ __device__ __forceinline__ void lagprod16_task(const float2* __restrict__ Xk, co
                                                int ys_ld, int ws_ld, int d, int la, int s, int k, float2* ys, float* ws, uint4* wcp,
                                                float sa, float sb, const int* __restrict__ te)
 {
-  static_assert(C == 8 && (NCW == 1 || NCW == 2), "4 / NCW wavefronts x NCW column blocks");   // column blocks per wavefront: col = 2 (c1 C + c2) + (0 re | 1 im)
+  // Columns (round 6): the 2 C^2 = 128 columns are (re | im) x 64 channel pairs; a wavefront's column blocks are the REAL and the
+  // IMAGINARY parts of the same 32 pairs (NCW = 2: pairs 32 wv + m; NCW = 1: pairs 32 (wv >> 1) + m, part wv & 1), so both blocks form
+  // their products from the same sixteen LDS words -- x = y_c1(u), q = fb y_c2(u + d): re = x.x q.x + x.y q.y, im = x.y q.x - x.x q.y
+  // -- where the interleaved columns of the first form (col = 2 pair + part) read x per block and kept q in two pre-multiplied copies.
+  static_assert(C == 8 && (NCW == 1 || NCW == 2), "4 / NCW wavefronts x NCW column blocks");
   constexpr int RL = 32 / C;                                       // l1 values per 32-row block: row m of block j -> (l1 = la + RL j + m / C, c = m % C)
   constexpr int LP16_NB = lp16_nb(C);
   static_assert(LP_RMAX == 4, "lp16_nb");
@@ -772,12 +776,16 @@ __device__ __forceinline__ void lagprod16_task(const float2* __restrict__ Xk, co
   const int L = g.L, P = C * L;
   const int YN = LP_WT + L - 1;                                    // samples per channel span (<= 128: L <= 65)
   constexpr int WN = LP_WT + RL * NR - 1;                          // weights per target-channel span
-  float2* ysp = ys + C * ys_ld;                                    // the second factors ready to multiply: [2 (re | im column)][C][ys_ld], scaled
+  const int yq_ld = ys_ld - 1;                                     // (odd pitch: the eight rows x two lane halves of a 64-bit read fall on disjoint banks)
+  float2* ysq = ys + C * ys_ld;                                    // the second factors, scaled: [C][yq_ld]
   float2 ypf[C];
   float wpf[C];
+  int ehpf = 0;
+  const int teq = ((L + RL - 1) / RL + 1) * LP_RMAX, teo = ((L - la) / RL) * LP_RMAX + NR - 1;
   auto prefetch = [&](long u0) {                                   // threads 0 .. 127: one sample and one weight per channel and thread
     const int e = tid;
     if (e >= 128) return;
+    ehpf = te[(u0 / LP_WT) * teq + teo];                           // the tile's exponent trade, |eh| <= 64 (wpe_lp_scale_kernel)
     const long u = u0 + e;
     const long t = u0 + g.lowerN + la + e;
 #pragma unroll
@@ -792,19 +800,16 @@ __device__ __forceinline__ void lagprod16_task(const float2* __restrict__ Xk, co
 #pragma unroll
     for (int cb = 0; cb < NCW; cb++) acc[j][cb] = f32x16{0};
   const int m = lane & 31, lk = lane >> 5;
-  const bool im = lane & 1;
   // A of block j: the 8 weights w_c(u0 + lowerN + la + e), e = kk + 8 lk + sh .. + 7, sh = RL j + m / C: copy (sh & 7) at the aligned
   // offset kk + 8 lk + (sh & ~7).  wcp[((hl 8 + copy) C + c) LP16_NB + block] (uint4 = 8 float16)
   int aidx[NR];
 #pragma unroll
   for (int j = 0; j < NR; j++) { const int sh = RL * j + m / C; aidx[j] = ((sh & 7) * C + (m % C)) * LP16_NB + lk + (sh >> 3); }
-  // B: x = y_c1(u), y = y_c2(u + d), pair = 16 cbg + (lane & 31) / 2 = c1 C + c2 for the global column block cbg = 2 wv + cb
-  int boffx[NCW];
-#pragma unroll
-  for (int cb = 0; cb < NCW; cb++) boffx[cb] = (((16 * (NCW * wv + cb) + (m >> 1)) / C) * ys_ld) / 2 + 4 * lk;   // in float4 units (ys_ld is even)
-  // x conj(y): re = x.x y.x + x.y y.y, im = x.x (-y.y) + x.y y.x: the lane's column parity picks the staged (p, q) = sb (y.x, y.y) or sb (-y.y, y.x)
-  const int boffp = ((im ? C : 0) + (m >> 1) % C) * ys_ld + 8 * lk + d;
-  static_assert(16 % C == 0, "the second factor's channel must not depend on the column block");
+  // B: x = y_c1(u), q = fb y_c2(u + d) of the lane's pair c1 C + c2
+  const int pairl = 32 * (NCW == 2 ? wv : (wv >> 1)) + m;
+  const bool imw = (NCW == 1) && (wv & 1);                         // NCW = 1: the wavefront's part
+  const int boffx = ((pairl / C) * ys_ld) / 2 + 4 * lk;            // in float4 units (ys_ld is even)
+  const int boffq = (pairl % C) * yq_ld + 8 * lk + d;
   prefetch(0);
   // Segments of LP16_SEG frames: the low-part products are 2^-11 of the high-part ones and, on the diagonal of R, of one sign; added to
   // an accumulator that has grown over very many frames they would fall under half an ulp and vanish (a bias, not noise).  So the
@@ -823,7 +828,7 @@ __device__ __forceinline__ void lagprod16_task(const float2* __restrict__ Xk, co
     // (the exponent of the tile comes from wpe_lp_scale_kernel: one value per (stream, bin, tile), the same for every task)
     __syncthreads();                                               // the reads of the last tile are done
     if (tid < 128) {
-      const int eh = te[((u0 / LP_WT) * ((L + RL - 1) / RL + 1) + (L - la) / RL) * LP_RMAX + NR - 1];   // |eh| <= 64: exact powers of two (wpe_lp_scale_kernel)
+      const int eh = ehpf;                                         // (loaded with the tile's samples, a tile ahead)
       const float fa = ldexpf(1.f, -eh), fb = sb * ldexpf(1.f, eh);
       const int e = tid;
 #pragma unroll
@@ -831,8 +836,7 @@ __device__ __forceinline__ void lagprod16_task(const float2* __restrict__ Xk, co
         if (e < YN) {
           const float2 v = ypf[c];
           ys[c * ys_ld + e] = v;
-          ysp[c * ys_ld + e] = make_float2(v.x * fb, v.y * fb);
-          ysp[(C + c) * ys_ld + e] = make_float2(-v.y * fb, v.x * fb);
+          ysq[c * yq_ld + e] = make_float2(v.x * fb, v.y * fb);
         }
         if (e < WN) ws[c * ws_ld + e] = wpf[c] * fa;
         else if (e < ws_ld) ws[c * ws_ld + e] = 0.f;               // (the shifted copies read up to 14 values past a block's start)
@@ -878,17 +882,23 @@ __device__ __forceinline__ void lagprod16_task(const float2* __restrict__ Xk, co
         ah[j] = __builtin_bit_cast(f16x8, wcp[aidx[j] + kk / 8]);
         al[j] = __builtin_bit_cast(f16x8, wcp[8 * C * LP16_NB + aidx[j] + kk / 8]);
       }
-      float2 pq[8];
+      float2 yq[8];
 #pragma unroll
-      for (int i = 0; i < 8; i++) pq[i] = ysp[boffp + kk + i];    // (odd d: not 16-byte aligned)
+      for (int i = 0; i < 8; i++) yq[i] = ysq[boffq + kk + i];     // (odd d: not 16-byte aligned)
+      float4 x4[4];
+#pragma unroll
+      for (int i2 = 0; i2 < 4; i2++) x4[i2] = reinterpret_cast<const float4*>(ys)[boffx + kk / 2 + i2];
 #pragma unroll
       for (int cb = 0; cb < NCW; cb++) {
         unsigned bh[4], bl[4];
+        const bool imc = (NCW == 2) ? (cb == 1) : imw;
 #pragma unroll
         for (int i2 = 0; i2 < 4; i2++) {
-          const float4 x4 = reinterpret_cast<const float4*>(ys)[boffx[cb] + kk / 2 + i2];
-          const float b0 = fmaf(x4.x, pq[2 * i2].x, x4.y * pq[2 * i2].y);
-          const float b1 = fmaf(x4.z, pq[2 * i2 + 1].x, x4.w * pq[2 * i2 + 1].y);
+          const float4 x = x4[i2];
+          const float2 q0 = yq[2 * i2], q1 = yq[2 * i2 + 1];
+          // x conj(y): re = x.x q.x + x.y q.y, im = x.x (-q.y) + x.y q.x (the same two roundings as the pre-multiplied form)
+          const float b0 = imc ? fmaf(x.x, -q0.y, x.y * q0.x) : fmaf(x.x, q0.x, x.y * q0.y);
+          const float b1 = imc ? fmaf(x.z, -q1.y, x.w * q1.x) : fmaf(x.z, q1.x, x.w * q1.y);
           split2m(b0, b1, bh[i2], bl[i2]);
         }
         const f16x8 Bh = mk8(bh[0], bh[1], bh[2], bh[3]), Bl = mk8(bl[0], bl[1], bl[2], bl[3]);
@@ -909,24 +919,21 @@ __device__ __forceinline__ void lagprod16_task(const float2* __restrict__ Xk, co
   // ---- store the segment (as lagprod_task), with the two scales undone
   // (the lane indices pass through an opaque move: the addresses below are then computed here, per flush, instead of being hoisted
   // out of the segment loop and held in ~80 registers across the tile loop, which spilled the accumulators)
-  int ms = m, lks = lk;
+  int ms = pairl, lks = lk;
   asm volatile("" : "+v"(ms), "+v"(lks));
-  const bool ims = ms & 1;
   const float unscale = 1.0f / (sa * sb);
-  const int c1c2 = ms >> 1;
-  float* Rc[4];
+  float2* Rc[4];
 #pragma unroll
   for (int i = 0; i < 4; i++) {
     const int c = i + 4 * lks;                                     // row % C for row = i + 8 (r >> 2) + 4 lk
-    Rc[i] = reinterpret_cast<float*>(R + (((long)s * C + c) * g.K + k) * (long)P * P) + (ims ? 1 : 0);
+    Rc[i] = R + (((long)s * C + c) * g.K + k) * (long)P * P;
   }
-#pragma unroll
-  for (int cb = 0; cb < NCW; cb++) {
-    const int pair = 16 * (NCW * wv + cb) + c1c2, c1 = pair / C, c2 = pair % C;
+  {
+    const int c1 = ms / C, c2 = ms % C;
     const bool lower = c1 >= c2;
-    const bool skip = (d == 0 && c1 < c2);
+    const bool skip = (d == 0 && c1 < c2);                         // the swapped pair stores this entry
     const long off0 = lower ? (long)c1 * L * P + (long)c2 * L - d : ((long)c2 * L - d) * P + (long)c1 * L;
-    const float sgn = ((!lower && ims) ? -1.f : 1.f) * unscale;
+    const float sre = unscale, sim = lower ? unscale : -unscale;   // (the upper triangle holds the conjugate)
 #pragma unroll
     for (int j = 0; j < NR; j++) {
 #pragma unroll
@@ -934,10 +941,18 @@ __device__ __forceinline__ void lagprod16_task(const float2* __restrict__ Xk, co
         const int row = (reg & 3) + 8 * (reg >> 2) + 4 * lks;
         const int l1 = la + RL * j + row / C;
         if (l1 < d || skip) continue;
-        float* dst = &Rc[reg & 3][2 * (off0 + (long)l1 * (P + 1))];
-        const float v = sgn * acc[j][cb][reg];
-        *dst = seg0 > 0 ? *dst + v : v;
-        acc[j][cb][reg] = 0.f;
+        float2* dst = &Rc[reg & 3][off0 + (long)l1 * (P + 1)];
+        if constexpr (NCW == 2) {                                  // both parts of the entry are this lane's: one 8-byte store
+          const float2 v = make_float2(sre * acc[j][0][reg], sim * acc[j][1][reg]);
+          if (seg0 > 0) { const float2 o = *dst; *dst = make_float2(o.x + v.x, o.y + v.y); }
+          else *dst = v;
+          acc[j][0][reg] = 0.f; acc[j][1][reg] = 0.f;
+        } else {
+          float* dp = reinterpret_cast<float*>(dst) + (imw ? 1 : 0);
+          const float v = (imw ? sim : sre) * acc[j][0][reg];
+          *dp = seg0 > 0 ? *dp + v : v;
+          acc[j][0][reg] = 0.f;
+        }
       }
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -954,7 +969,7 @@ __device__ __forceinline__ void wpe_lagprod16_body(const float2* __restrict__ X,
   constexpr int LP16_NB = lp16_nb(C);
   uint4* wcp = reinterpret_cast<uint4*>(smem);                     // [2 (high | low)][8 shifts][C][LP16_NB] x 8 float16
   float2* ys = reinterpret_cast<float2*>(wcp + 2 * 8 * C * LP16_NB);   // [C][ys_ld]: sample u0 + e of channel c'
-  float* ws = reinterpret_cast<float*>(ys + 3 * C * ys_ld);        // (ys is followed by the two pre-multiplied forms of the second factor) [C][ws_ld]: w_c(u0 + lowerN + la + e), scaled
+  float* ws = reinterpret_cast<float*>(ys + C * ys_ld + C * (ys_ld - 1));   // (ys is followed by the scaled second factors, pitch ys_ld - 1) [C][ws_ld]: w_c(u0 + lowerN + la + e), scaled
   const int k = blockIdx.y, s = blockIdx.z;
   if (!bin_active(g, k)) return;
   const int L = g.L;
@@ -1272,12 +1287,13 @@ int btk_wpe_estimate(const void* X, int S, int K, int C, long T_stride, long T, 
         // round 5: float16-split operands on the 16 x faster matrix instruction (see lagprod16_task)
         const int nb16 = lp16_nb(C);
         const int ws16 = 8 * nb16 + 8;                                         // >= 8 (nb16 - 1) + 15 values (40 KB of LDS per task with this: four tasks per CU)
-        const size_t lds16p = sizeof(uint4) * 2 * 8 * (size_t)C * nb16 + sizeof(float2) * 3 * (size_t)C * ys_ld + sizeof(float) * (size_t)C * ws16 + sizeof(float) * 8;
+        int ys16 = LP_WT + g.L; while (ys16 % 32 != 2) ys16++;                 // float2 row pitch of the samples: the four rows x two lane halves of a 16-byte read on disjoint banks; the scaled second factors follow at pitch ys16 - 1
+        const size_t lds16p = sizeof(uint4) * 2 * 8 * (size_t)C * nb16 + sizeof(float2) * (size_t)C * (2 * ys16 - 1) + sizeof(float) * (size_t)C * ws16 + sizeof(float) * 8;
         hipLaunchKernelGGL(wpe_lp_scale_kernel, dim3((unsigned)K, (unsigned)S), dim3(256), 0, st, Xp, Winv, g, lp_scales, lp_tile_exp, nt_stride);
         if (btk_switches().wpe_lagprod_waves == 2)
-          hipLaunchKernelGGL(wpe_lagprod16_w2_kernel, dim3(ntask, (unsigned)K, (unsigned)S), dim3(128), lds16p, st, Xp, Winv, g, R, ys_ld, ws16, lp_scales, lp_tile_exp, nt_stride);
+          hipLaunchKernelGGL(wpe_lagprod16_w2_kernel, dim3(ntask, (unsigned)K, (unsigned)S), dim3(128), lds16p, st, Xp, Winv, g, R, ys16, ws16, lp_scales, lp_tile_exp, nt_stride);
         else
-          hipLaunchKernelGGL(wpe_lagprod16_w4_kernel, dim3(ntask, (unsigned)K, (unsigned)S), dim3(256), lds16p, st, Xp, Winv, g, R, ys_ld, ws16, lp_scales, lp_tile_exp, nt_stride);
+          hipLaunchKernelGGL(wpe_lagprod16_w4_kernel, dim3(ntask, (unsigned)K, (unsigned)S), dim3(256), lds16p, st, Xp, Winv, g, R, ys16, ws16, lp_scales, lp_tile_exp, nt_stride);
       }
       else if (C == 8) hipLaunchKernelGGL(wpe_lagprod_kernel<8>, dim3(ntask, (unsigned)K, (unsigned)S), dim3(64), lds_lp, st, Xp, Winv, g, R, ys_ld, ws_ld);
       else        hipLaunchKernelGGL(wpe_lagprod_kernel<4>, dim3(ntask, (unsigned)K, (unsigned)S), dim3(64), lds_lp, st, Xp, Winv, g, R, ys_ld, ws_ld);
