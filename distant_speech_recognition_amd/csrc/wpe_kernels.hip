@@ -731,8 +731,9 @@ void wpe_lp_scale_kernel(const float2* __restrict__ X, const float* __restrict__
   }
 }
 
-// 8-frame blocks of a shifted weight span: a row's shift within its task is at most RL LP_RMAX - 1 frames (15 at 8 channels, 31 at 4)
-__host__ __device__ constexpr int lp16_nb(int C) { return 8 + (32 / C * 4 - 1) / 8; }
+// 8-frame blocks of a shifted weight span: a lane's stream runs LP_WT + RL LP_RMAX frames from its copy's start (a row's shift within
+// its task is at most RL LP_RMAX - 1 frames: 15 at 8 channels)
+__host__ __device__ constexpr int lp16_nb(int C) { return (64 + 32 / C * 4 + 7) / 8; }
 
 // b - (float)h as ONE instruction: v_fma_mix_f32 reads the float16 operand in place (no separate conversion)
 __device__ __forceinline__ float sub_h_lo(float b, unsigned hpair)
@@ -752,6 +753,40 @@ __device__ __forceinline__ void split2m(float a, float b, unsigned& hi, unsigned
 {
   hi = pk_hi(a, b);
   lo = pk_hi(sub_h_lo(a, hi), sub_h_hi(b, hi));
+}
+
+constexpr int LP16_NCP = 4;                                        // shifted copies of the weight span kept in LDS
+typedef unsigned u32x12 __attribute__((ext_vector_type(12)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+// registers 0 .. 2 NR + 1 of a lane's operand stream from p[0], p[1], p[2]
+template <int NR>
+__device__ __forceinline__ void lp16_window(const uint4* p, u32x12& w)
+{
+  const u32x4 r0 = *reinterpret_cast<const u32x4*>(p);
+  if constexpr (NR == 1) w = __builtin_shufflevector(r0, r0, 0, 1, 2, 3, -1, -1, -1, -1, -1, -1, -1, -1);
+  if constexpr (NR == 2) {
+    const u32x2 t = *reinterpret_cast<const u32x2*>(p + 1);
+    const u32x4 r1 = __builtin_shufflevector(t, t, 0, 1, -1, -1);
+    w = __builtin_shufflevector(r0, r1, 0, 1, 2, 3, 4, 5, -1, -1, -1, -1, -1, -1);
+  }
+  if constexpr (NR >= 3) {
+    const u32x4 r1 = *reinterpret_cast<const u32x4*>(p + 1);
+    typedef unsigned u32x8 __attribute__((ext_vector_type(8)));
+    const u32x8 r01 = __builtin_shufflevector(r0, r1, 0, 1, 2, 3, 4, 5, 6, 7);
+    if constexpr (NR == 3) w = __builtin_shufflevector(r01, r01, 0, 1, 2, 3, 4, 5, 6, 7, -1, -1, -1, -1);
+    else {
+      const u32x2 t = *reinterpret_cast<const u32x2*>(p + 2);
+      const u32x8 r2 = __builtin_shufflevector(t, t, 0, 1, -1, -1, -1, -1, -1, -1);
+      w = __builtin_shufflevector(r01, r2, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, -1, -1);
+    }
+  }
+}
+
+template <int J>
+__device__ __forceinline__ f16x8 lp16_block(const u32x12& w)
+{
+  return __builtin_bit_cast(f16x8, __builtin_shufflevector(w, w, 2 * J, 2 * J + 1, 2 * J + 2, 2 * J + 3));
 }
 
 // One task = (lag difference d, up to four 32-row blocks) as before, but run by TWO wavefronts that share the staged tile: wavefront wv
@@ -800,16 +835,26 @@ __device__ __forceinline__ void lagprod16_task(const float2* __restrict__ Xk, co
 #pragma unroll
     for (int cb = 0; cb < NCW; cb++) acc[j][cb] = f32x16{0};
   const int m = lane & 31, lk = lane >> 5;
-  // A of block j: the 8 weights w_c(u0 + lowerN + la + e), e = kk + 8 lk + sh .. + 7, sh = RL j + m / C: copy (sh & 7) at the aligned
-  // offset kk + 8 lk + (sh & ~7).  wcp[((hl 8 + copy) C + c) LP16_NB + block] (uint4 = 8 float16)
-  int aidx[NR];
-#pragma unroll
-  for (int j = 0; j < NR; j++) { const int sh = RL * j + m / C; aidx[j] = ((sh & 7) * C + (m % C)) * LP16_NB + lk + (sh >> 3); }
+  // A of block j: the 8 weights w_c(u0 + lowerN + la + e), e = kk + 8 lk + sh .. + 7, sh = RL j + m / C.  With RL = 4 the row blocks of a
+  // lane are the windows 4 j .. 4 j + 7 of ONE stream -- copy m / C (a shift of 0 .. 3 frames) from the aligned offset kk + 8 lk on --,
+  // so the lane reads 4 + 2 (NR - 1) consecutive registers' worth once (two 16-byte words and an 8-byte one at NR = 4) and block j's
+  // operand is registers 2 j .. 2 j + 3 of that tuple: 5 LDS reads per 16 frames instead of 8, and only FOUR shifted copies to build.
+  // wcp[((hl LP16_NCP + copy) C + c) LP16_NB + block] (uint4 = 8 float16)
+  static_assert(RL == 4, "row blocks as windows of one shifted copy");
+#if defined(BTK_LP_ABLATE) && (BTK_LP_ABLATE & 4)              // ablation build: every lane of a half reads the same words
+  const int abase = lk;
+#else
+  const int abase = m * LP16_NB + lk;                              // (copy C + c = m)
+#endif
   // B: x = y_c1(u), q = fb y_c2(u + d) of the lane's pair c1 C + c2
   const int pairl = 32 * (NCW == 2 ? wv : (wv >> 1)) + m;
   const bool imw = (NCW == 1) && (wv & 1);                         // NCW = 1: the wavefront's part
+#if defined(BTK_LP_ABLATE) && (BTK_LP_ABLATE & 8)              // ablation build: every lane of a half reads the same words (no bank conflicts possible)
+  const int boffx = 4 * lk, boffq = 8 * lk + d;
+#else
   const int boffx = ((pairl / C) * ys_ld) / 2 + 4 * lk;            // in float4 units (ys_ld is even)
   const int boffq = (pairl % C) * yq_ld + 8 * lk + d;
+#endif
   prefetch(0);
   // Segments of LP16_SEG frames: the low-part products are 2^-11 of the high-part ones and, on the diagonal of R, of one sign; added to
   // an accumulator that has grown over very many frames they would fall under half an ulp and vanish (a bias, not noise).  So the
@@ -827,7 +872,11 @@ __device__ __forceinline__ void lagprod16_task(const float2* __restrict__ Xk, co
     // height (<= 2^14), the product -- hence the accumulators' scale -- is unchanged, and nothing is rounded by it.
     // (the exponent of the tile comes from wpe_lp_scale_kernel: one value per (stream, bin, tile), the same for every task)
     __syncthreads();                                               // the reads of the last tile are done
+#if defined(BTK_LP_ABLATE) && (BTK_LP_ABLATE & 16)             // ablation build: tiles after the first are neither staged nor copied
+    if (tid < 128 && u0 == 0) {
+#else
     if (tid < 128) {
+#endif
       const int eh = ehpf;                                         // (loaded with the tile's samples, a tile ahead)
       const float fa = ldexpf(1.f, -eh), fb = sb * ldexpf(1.f, eh);
       const int e = tid;
@@ -843,44 +892,53 @@ __device__ __forceinline__ void lagprod16_task(const float2* __restrict__ Xk, co
       }
     }
     __syncthreads();
+#if defined(BTK_LP_ABLATE) && (BTK_LP_ABLATE & 64)             // ablation build: no global loads after the first tile
+    if (false) prefetch(u0 + LP_WT);
+#else
     if (u0 + LP_WT < g.T) prefetch(u0 + LP_WT);
-    // the weight span of every channel as its eight one-frame shifts, each split into float16 high / low parts: unit (c, block b)
-    // reads w[8 b .. 8 b + 14] and writes copy_s[8 b .. 8 b + 7] = w[8 b + s ..] for s = 0 .. 7
-#if defined(BTK_LP_ABLATE) && (BTK_LP_ABLATE & 2)              // ablation build: the shifted copies are built for the first tile only
+#endif
+    // the weight span of every channel as its four one-frame shifts, each split into float16 high / low parts: unit (c, block b)
+    // reads w[8 b .. 8 b + 11] and writes copy_s[8 b .. 8 b + 7] = w[8 b + s ..] for s = 0 .. 3
+#if defined(BTK_LP_ABLATE) && (BTK_LP_ABLATE & (2 | 16))       // ablation build: the shifted copies are built for the first tile only
     if (tid < C * LP16_NB && u0 == 0) {
 #else
     if (tid < C * LP16_NB) {
 #endif
       const int c = tid / LP16_NB, b = tid % LP16_NB;
-      float wv16[16];
+      float wv16[12];
 #pragma unroll
-      for (int i = 0; i < 16; i++) { const int e = 8 * b + i; wv16[i] = (e < ws_ld && i < 15) ? ws[c * ws_ld + e] : 0.f; }
-      unsigned he[8], le[8], ho[7], lo_[7];                         // pairs (2 i, 2 i + 1) and (2 i + 1, 2 i + 2)
+      for (int i = 0; i < 12; i++) { const int e = 8 * b + i; wv16[i] = (e < ws_ld) ? ws[c * ws_ld + e] : 0.f; }
+      unsigned he[6], le[6], ho[5], lo_[5];                         // pairs (2 i, 2 i + 1) and (2 i + 1, 2 i + 2)
 #pragma unroll
-      for (int i = 0; i < 8; i++) { he[i] = pk_hi(wv16[2 * i], wv16[2 * i + 1]); le[i] = pk_hi(sub_h_lo(wv16[2 * i], he[i]), sub_h_hi(wv16[2 * i + 1], he[i])); }
+      for (int i = 0; i < 6; i++) { he[i] = pk_hi(wv16[2 * i], wv16[2 * i + 1]); le[i] = pk_hi(sub_h_lo(wv16[2 * i], he[i]), sub_h_hi(wv16[2 * i + 1], he[i])); }
 #pragma unroll
-      for (int i = 0; i < 7; i++) {
+      for (int i = 0; i < 5; i++) {
         ho[i] = pk_hi(wv16[2 * i + 1], wv16[2 * i + 2]);
         lo_[i] = (le[i] >> 16) | (le[i + 1] << 16);                 // (the parts of a value do not depend on its partner in the pair)
       }
 #pragma unroll
-      for (int sft = 0; sft < 8; sft++) {
+      for (int sft = 0; sft < LP16_NCP; sft++) {
         const int h = sft >> 1;
         uint4 vh, vl;
         if (sft & 1) { vh = make_uint4(ho[h], ho[h + 1], ho[h + 2], ho[h + 3]); vl = make_uint4(lo_[h], lo_[h + 1], lo_[h + 2], lo_[h + 3]); }
         else         { vh = make_uint4(he[h], he[h + 1], he[h + 2], he[h + 3]); vl = make_uint4(le[h], le[h + 1], le[h + 2], le[h + 3]); }
-        wcp[((0 * 8 + sft) * C + c) * LP16_NB + b] = vh;
-        wcp[((1 * 8 + sft) * C + c) * LP16_NB + b] = vl;
+        wcp[((0 * LP16_NCP + sft) * C + c) * LP16_NB + b] = vh;
+        wcp[((1 * LP16_NCP + sft) * C + c) * LP16_NB + b] = vl;
       }
     }
     __syncthreads();
 #pragma unroll 1
     for (int kk = 0; kk < LP_WT; kk += 16) {
       f16x8 ah[NR], al[NR];
-#pragma unroll
-      for (int j = 0; j < NR; j++) {
-        ah[j] = __builtin_bit_cast(f16x8, wcp[aidx[j] + kk / 8]);
-        al[j] = __builtin_bit_cast(f16x8, wcp[8 * C * LP16_NB + aidx[j] + kk / 8]);
+      {
+        u32x12 wh, wl;                                             // the lane's stream, 2 NR + 2 registers of it
+        lp16_window<NR>(wcp + abase + kk / 8, wh);
+        lp16_window<NR>(wcp + LP16_NCP * C * LP16_NB + abase + kk / 8, wl);
+        if constexpr (NR > 1) asm volatile("" : "+v"(wh), "+v"(wl));   // (one register tuple each: the blocks' operands are sub-ranges of it, not copies)
+        ah[0] = lp16_block<0>(wh); al[0] = lp16_block<0>(wl);
+        if constexpr (NR > 1) { ah[1] = lp16_block<1>(wh); al[1] = lp16_block<1>(wl); }
+        if constexpr (NR > 2) { ah[2] = lp16_block<2>(wh); al[2] = lp16_block<2>(wl); }
+        if constexpr (NR > 3) { ah[3] = lp16_block<3>(wh); al[3] = lp16_block<3>(wl); }
       }
       float2 yq[8];
 #pragma unroll
@@ -940,7 +998,11 @@ __device__ __forceinline__ void lagprod16_task(const float2* __restrict__ Xk, co
       for (int reg = 0; reg < 16; reg++) {
         const int row = (reg & 3) + 8 * (reg >> 2) + 4 * lks;
         const int l1 = la + RL * j + row / C;
+#if defined(BTK_LP_ABLATE) && (BTK_LP_ABLATE & 32)             // ablation build: nothing is stored (the condition is never true)
+        if (l1 < d || skip || g.T > 0) continue;
+#else
         if (l1 < d || skip) continue;
+#endif
         float2* dst = &Rc[reg & 3][off0 + (long)l1 * (P + 1)];
         if constexpr (NCW == 2) {                                  // both parts of the entry are this lane's: one 8-byte store
           const float2 v = make_float2(sre * acc[j][0][reg], sim * acc[j][1][reg]);
@@ -962,18 +1024,24 @@ __device__ __forceinline__ void lagprod16_task(const float2* __restrict__ Xk, co
 
 template <int C, int NCW>
 __device__ __forceinline__ void wpe_lagprod16_body(const float2* __restrict__ X, const float* __restrict__ Winv, WpeGeom g, float2* __restrict__ R, int ys_ld, int ws_ld,
-                          const float* __restrict__ scales, const int* __restrict__ tile_exp, int nt_stride)
+                          const float* __restrict__ scales, const int* __restrict__ tile_exp, int nt_stride, int nstreams)
 {
   constexpr int RL = 32 / C;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int LP16_NB = lp16_nb(C);
-  uint4* wcp = reinterpret_cast<uint4*>(smem);                     // [2 (high | low)][8 shifts][C][LP16_NB] x 8 float16
-  float2* ys = reinterpret_cast<float2*>(wcp + 2 * 8 * C * LP16_NB);   // [C][ys_ld]: sample u0 + e of channel c'
+  uint4* wcp = reinterpret_cast<uint4*>(smem);                     // [2 (high | low)][LP16_NCP shifts][C][LP16_NB] x 8 float16
+  float2* ys = reinterpret_cast<float2*>(wcp + 2 * LP16_NCP * C * LP16_NB);   // [C][ys_ld]: sample u0 + e of channel c'
   float* ws = reinterpret_cast<float*>(ys + C * ys_ld + C * (ys_ld - 1));   // (ys is followed by the scaled second factors, pitch ys_ld - 1) [C][ws_ld]: w_c(u0 + lowerN + la + e), scaled
-  const int k = blockIdx.y, s = blockIdx.z;
+  // Launch order (round 6): the tasks of a (stream, bin) write the diagonals of the same eight matrices -- every 128-byte line of R takes
+  // its sixteen entries from sixteen different tasks.  Workgroups go to the eight XCDs in turn, so with one grid row per bin a line was
+  // assembled in eight L2s and left each of them partly written; here blockIdx.x = XCD + 8 task and blockIdx.y = a group of eight bins,
+  // one per XCD: a bin's tasks run on ONE XCD, back to back, and its lines fill up in that L2.
+  const int bin = 8 * (int)blockIdx.y + (int)(blockIdx.x & 7);
+  if (bin >= g.K * nstreams) return;
+  const int k = bin % g.K, s = bin / g.K;
   if (!bin_active(g, k)) return;
   const int L = g.L;
-  int d = 0, grp = blockIdx.x;
+  int d = 0, grp = blockIdx.x >> 3;
   auto nblk = [&](int dd) { return (L - dd + RL - 1) / RL; };
   auto ngrp = [&](int dd) { return (nblk(dd) + LP_RMAX - 1) / LP_RMAX; };
   while (grp >= ngrp(d)) { grp -= ngrp(d); d++; }
@@ -996,15 +1064,15 @@ __device__ __forceinline__ void wpe_lagprod16_body(const float2* __restrict__ X,
 // two wavefronts x two column blocks (256 registers per lane: two wavefronts per SIMD) / four x one (168: three per SIMD)
 __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void wpe_lagprod16_w2_kernel(const float2* __restrict__ X, const float* __restrict__ Winv, WpeGeom g, float2* __restrict__ R, int ys_ld, int ws_ld,
-                             const float* __restrict__ scales, const int* __restrict__ tile_exp, int nt_stride)
+                             const float* __restrict__ scales, const int* __restrict__ tile_exp, int nt_stride, int nstreams)
 {
-  wpe_lagprod16_body<8, 2>(X, Winv, g, R, ys_ld, ws_ld, scales, tile_exp, nt_stride);
+  wpe_lagprod16_body<8, 2>(X, Winv, g, R, ys_ld, ws_ld, scales, tile_exp, nt_stride, nstreams);
 }
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3)))
 void wpe_lagprod16_w4_kernel(const float2* __restrict__ X, const float* __restrict__ Winv, WpeGeom g, float2* __restrict__ R, int ys_ld, int ws_ld,
-                             const float* __restrict__ scales, const int* __restrict__ tile_exp, int nt_stride)
+                             const float* __restrict__ scales, const int* __restrict__ tile_exp, int nt_stride, int nstreams)
 {
-  wpe_lagprod16_body<8, 1>(X, Winv, g, R, ys_ld, ws_ld, scales, tile_exp, nt_stride);
+  wpe_lagprod16_body<8, 1>(X, Winv, g, R, ys_ld, ws_ld, scales, tile_exp, nt_stride, nstreams);
 }
 
 template <int C>
@@ -1288,12 +1356,12 @@ int btk_wpe_estimate(const void* X, int S, int K, int C, long T_stride, long T, 
         const int nb16 = lp16_nb(C);
         const int ws16 = 8 * nb16 + 8;                                         // >= 8 (nb16 - 1) + 15 values (40 KB of LDS per task with this: four tasks per CU)
         int ys16 = LP_WT + g.L; while (ys16 % 32 != 2) ys16++;                 // float2 row pitch of the samples: the four rows x two lane halves of a 16-byte read on disjoint banks; the scaled second factors follow at pitch ys16 - 1
-        const size_t lds16p = sizeof(uint4) * 2 * 8 * (size_t)C * nb16 + sizeof(float2) * (size_t)C * (2 * ys16 - 1) + sizeof(float) * (size_t)C * ws16 + sizeof(float) * 8;
+        const size_t lds16p = sizeof(uint4) * 2 * LP16_NCP * (size_t)C * nb16 + sizeof(float2) * (size_t)C * (2 * ys16 - 1) + sizeof(float) * (size_t)C * ws16 + sizeof(float) * 8;
         hipLaunchKernelGGL(wpe_lp_scale_kernel, dim3((unsigned)K, (unsigned)S), dim3(256), 0, st, Xp, Winv, g, lp_scales, lp_tile_exp, nt_stride);
         if (btk_switches().wpe_lagprod_waves == 2)
-          hipLaunchKernelGGL(wpe_lagprod16_w2_kernel, dim3(ntask, (unsigned)K, (unsigned)S), dim3(128), lds16p, st, Xp, Winv, g, R, ys16, ws16, lp_scales, lp_tile_exp, nt_stride);
+          hipLaunchKernelGGL(wpe_lagprod16_w2_kernel, dim3(8 * ntask, (unsigned)((K * S + 7) / 8)), dim3(128), lds16p, st, Xp, Winv, g, R, ys16, ws16, lp_scales, lp_tile_exp, nt_stride, S);
         else
-          hipLaunchKernelGGL(wpe_lagprod16_w4_kernel, dim3(ntask, (unsigned)K, (unsigned)S), dim3(256), lds16p, st, Xp, Winv, g, R, ys16, ws16, lp_scales, lp_tile_exp, nt_stride);
+          hipLaunchKernelGGL(wpe_lagprod16_w4_kernel, dim3(8 * ntask, (unsigned)((K * S + 7) / 8)), dim3(256), lds16p, st, Xp, Winv, g, R, ys16, ws16, lp_scales, lp_tile_exp, nt_stride, S);
       }
       else if (C == 8) hipLaunchKernelGGL(wpe_lagprod_kernel<8>, dim3(ntask, (unsigned)K, (unsigned)S), dim3(64), lds_lp, st, Xp, Winv, g, R, ys_ld, ws_ld);
       else        hipLaunchKernelGGL(wpe_lagprod_kernel<4>, dim3(ntask, (unsigned)K, (unsigned)S), dim3(64), lds_lp, st, Xp, Winv, g, R, ys_ld, ws_ld);
