@@ -755,6 +755,14 @@ __device__ __forceinline__ void split2m(float a, float b, unsigned& hi, unsigned
   lo = pk_hi(sub_h_lo(a, hi), sub_h_hi(b, hi));
 }
 
+// BTK_LP_TIMING build (profiles/): shader cycles of wavefront 0 of every task by phase -- 0 waiting for the partner wavefront at the top of a
+// tile, 1 staging, 2 shifted copies, 3 the products, 4 the epilogue -- summed into lp_phase_cycles (read back by btk_wpe_estimate, BTK_WPE_TIMING=1)
+#ifdef BTK_LP_TIMING
+__device__ unsigned long long lp_phase_cycles[8];
+#define LP_MARK(i) do { const long long cy_ = __builtin_readcyclecounter(); lp_tm[i] += cy_ - lp_last; lp_last = cy_; } while (0)
+#else
+#define LP_MARK(i) do { } while (0)
+#endif
 constexpr int LP16_NCP = 4;                                        // shifted copies of the weight span kept in LDS
 typedef unsigned u32x12 __attribute__((ext_vector_type(12)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -816,17 +824,25 @@ __device__ __forceinline__ void lagprod16_task(const float2* __restrict__ Xk, co
   float2 ypf[C];
   float wpf[C];
   int ehpf = 0;
+  bool yok = false, wok = false;                                   // the prefetched sample / weight of this thread lies inside the recording
   const int teq = ((L + RL - 1) / RL + 1) * LP_RMAX, teo = ((L - la) / RL) * LP_RMAX + NR - 1;
   auto prefetch = [&](long u0) {                                   // threads 0 .. 127: one sample and one weight per channel and thread
     const int e = tid;
     if (e >= 128) return;
     ehpf = te[(u0 / LP_WT) * teq + teo];                           // the tile's exponent trade, |eh| <= 64 (wpe_lp_scale_kernel)
+    // Every lane loads from a valid (clamped) address, raw, into its own register, and the staging step selects and scales: seventeen
+    // loads in flight.  (Guarded loads with the scale applied on arrival compiled to a branch around every load and a weight register
+    // shared by the eight channels -- eight global round trips in a row per tile, 40 % of the kernel's cycles: profiles/r06_wpe_lagprod_phases.txt)
     const long u = u0 + e;
     const long t = u0 + g.lowerN + la + e;
+    yok = e < YN && u < g.T;
+    wok = e < WN && t >= g.lowerN && t < g.T;
+    const long uc = u < g.T ? u : g.T - 1;
+    const long tc = t < 0 ? 0 : (t < g.T ? t : g.T - 1);
 #pragma unroll
     for (int c = 0; c < C; c++) {
-      ypf[c] = (e < YN && u < g.T) ? Xk[(long)c * g.T_stride + u] : make_float2(0.f, 0.f);
-      wpf[c] = (e < WN && t >= g.lowerN && t < g.T) ? Wk[(long)c * g.K * g.T_stride + t] * sa : 0.f;
+      ypf[c] = Xk[(long)c * g.T_stride + uc];
+      wpf[c] = Wk[(long)c * g.K * g.T_stride + tc];
     }
   };
   f32x16 acc[NR][NCW];
@@ -855,6 +871,10 @@ __device__ __forceinline__ void lagprod16_task(const float2* __restrict__ Xk, co
   const int boffx = ((pairl / C) * ys_ld) / 2 + 4 * lk;            // in float4 units (ys_ld is even)
   const int boffq = (pairl % C) * yq_ld + 8 * lk + d;
 #endif
+#ifdef BTK_LP_TIMING
+  long long lp_tm[5] = {0, 0, 0, 0, 0};
+  long long lp_last = __builtin_readcyclecounter();
+#endif
   prefetch(0);
   // Segments of LP16_SEG frames: the low-part products are 2^-11 of the high-part ones and, on the diagonal of R, of one sign; added to
   // an accumulator that has grown over very many frames they would fall under half an ulp and vanish (a bias, not noise).  So the
@@ -872,6 +892,7 @@ __device__ __forceinline__ void lagprod16_task(const float2* __restrict__ Xk, co
     // height (<= 2^14), the product -- hence the accumulators' scale -- is unchanged, and nothing is rounded by it.
     // (the exponent of the tile comes from wpe_lp_scale_kernel: one value per (stream, bin, tile), the same for every task)
     __syncthreads();                                               // the reads of the last tile are done
+    LP_MARK(0);
 #if defined(BTK_LP_ABLATE) && (BTK_LP_ABLATE & 16)             // ablation build: tiles after the first are neither staged nor copied
     if (tid < 128 && u0 == 0) {
 #else
@@ -880,18 +901,22 @@ __device__ __forceinline__ void lagprod16_task(const float2* __restrict__ Xk, co
       const int eh = ehpf;                                         // (loaded with the tile's samples, a tile ahead)
       const float fa = ldexpf(1.f, -eh), fb = sb * ldexpf(1.f, eh);
       const int e = tid;
+      if (e < YN) {                                                // (one branch per kind of row, not one per channel)
 #pragma unroll
-      for (int c = 0; c < C; c++) {
-        if (e < YN) {
-          const float2 v = ypf[c];
+        for (int c = 0; c < C; c++) {
+          const float2 v = yok ? ypf[c] : make_float2(0.f, 0.f);
           ys[c * ys_ld + e] = v;
           ysq[c * yq_ld + e] = make_float2(v.x * fb, v.y * fb);
         }
-        if (e < WN) ws[c * ws_ld + e] = wpf[c] * fa;
-        else if (e < ws_ld) ws[c * ws_ld + e] = 0.f;               // (the shifted copies read up to 14 values past a block's start)
+      }
+      if (e < ws_ld) {                                             // (the shifted copies read up to 11 values past a block's start: zeros behind the span)
+        const bool wl = e < WN && wok;
+#pragma unroll
+        for (int c = 0; c < C; c++) ws[c * ws_ld + e] = wl ? (wpf[c] * sa) * fa : 0.f;
       }
     }
     __syncthreads();
+    LP_MARK(1);
 #if defined(BTK_LP_ABLATE) && (BTK_LP_ABLATE & 64)             // ablation build: no global loads after the first tile
     if (false) prefetch(u0 + LP_WT);
 #else
@@ -907,7 +932,7 @@ __device__ __forceinline__ void lagprod16_task(const float2* __restrict__ Xk, co
       const int c = tid / LP16_NB, b = tid % LP16_NB;
       float wv16[12];
 #pragma unroll
-      for (int i = 0; i < 12; i++) { const int e = 8 * b + i; wv16[i] = (e < ws_ld) ? ws[c * ws_ld + e] : 0.f; }
+      for (int i = 0; i < 12; i++) wv16[i] = ws[c * ws_ld + 8 * b + i];   // (ws_ld >= 8 LP16_NB + 4: the launch)
       unsigned he[6], le[6], ho[5], lo_[5];                         // pairs (2 i, 2 i + 1) and (2 i + 1, 2 i + 2)
 #pragma unroll
       for (int i = 0; i < 6; i++) { he[i] = pk_hi(wv16[2 * i], wv16[2 * i + 1]); le[i] = pk_hi(sub_h_lo(wv16[2 * i], he[i]), sub_h_hi(wv16[2 * i + 1], he[i])); }
@@ -927,6 +952,7 @@ __device__ __forceinline__ void lagprod16_task(const float2* __restrict__ Xk, co
       }
     }
     __syncthreads();
+    LP_MARK(2);
 #pragma unroll 1
     for (int kk = 0; kk < LP_WT; kk += 16) {
       f16x8 ah[NR], al[NR];
@@ -974,6 +1000,7 @@ __device__ __forceinline__ void lagprod16_task(const float2* __restrict__ Xk, co
       }
     }
   }
+  LP_MARK(3);
   // ---- store the segment (as lagprod_task), with the two scales undone
   // (the lane indices pass through an opaque move: the addresses below are then computed here, per flush, instead of being hoisted
   // out of the segment loop and held in ~80 registers across the tile loop, which spilled the accumulators)
@@ -1019,7 +1046,14 @@ __device__ __forceinline__ void lagprod16_task(const float2* __restrict__ Xk, co
       __builtin_amdgcn_sched_barrier(0);
     }
   }
+  LP_MARK(4);
   }
+#ifdef BTK_LP_TIMING
+  if (tid == 0) {
+    for (int i = 0; i < 5; i++) atomicAdd(lp_phase_cycles + i, (unsigned long long)lp_tm[i]);
+    atomicAdd(lp_phase_cycles + 5, 1ull);
+  }
+#endif
 }
 
 template <int C, int NCW>
@@ -1391,6 +1425,19 @@ int btk_wpe_estimate(const void* X, int S, int K, int C, long T_stride, long T, 
                          R, rvec_from_R ? static_cast<const float2*>(nullptr) : rvec, g, load_factor, (float)diagonal_bias, Gp, fail_count, phase);
     BTK_HIP_CHECK(hipGetLastError());
   }
+#ifdef BTK_LP_TIMING
+  {
+    unsigned long long h[8];
+    BTK_HIP_CHECK(hipStreamSynchronize(st));
+    BTK_HIP_CHECK(hipMemcpyFromSymbol(h, HIP_SYMBOL(lp_phase_cycles), sizeof(h)));
+    static const char* nm[5] = {"partner_wait", "staging", "copies", "products", "epilogue"};
+    unsigned long long tot = 0;
+    for (int i = 0; i < 5; i++) tot += h[i];
+    fprintf(stderr, "[BTK_LP_TIMING] %llu tasks (cumulative), %.0f cycles per task:", h[5], h[5] ? (double)tot / h[5] : 0.0);
+    for (int i = 0; i < 5; i++) fprintf(stderr, " %s %.1f%%", nm[i], tot ? 100.0 * h[i] / tot : 0.0);
+    fprintf(stderr, "\n");
+  }
+#endif
   if (phase) {
     unsigned long long h[8];
     BTK_HIP_CHECK(hipMemcpyAsync(h, phase, sizeof(h), hipMemcpyDeviceToHost, st));
