@@ -89,26 +89,47 @@ __device__ __forceinline__ const float2* solve(const float2* __restrict__ mat, i
   f32x4 re[NS], im[NS];
   // ---- load: register v of lane (mg, mi) of a tile = row 4 mg + v, column mi.  Every lane loads from a valid address and selects
   //      afterwards (no divergent branches around the loads), eight tiles' loads in flight.
+  //      A branch per slot ends the basic block and the loads of slot s + 1 then wait for those of slot s (one global round trip per slot,
+  //      20 per system): slots are taken four at a time, and a group whose last slot holds a tile -- all but the last group of a wavefront
+  //      -- runs without branches, sixteen loads in flight.
+  auto load_slot = [&](int s, int ti, int tj) {
+    const int q = 16 * tj + mi;
 #pragma unroll
-  for (int s = 0; s < NS; s++) {
-    re[s] = f32x4{0.f, 0.f, 0.f, 0.f}; im[s] = f32x4{0.f, 0.f, 0.f, 0.f};
-    int ti, tj;
-    tile_of(s, ti, tj);
-    if (ti >= 0) {
-      const int q = 16 * tj + mi;
+    for (int v = 0; v < 4; v++) {
+      const int r = 16 * ti + 4 * mg + v;
+      const bool low = r < P && q < r;
+      int idx = low ? r * P + q : 0;                              // (P <= 271: 32 bits)
+      asm volatile("" : "+v"(idx));                               // (opaque: keeps the load unconditional)
+      const float2 a = mat[idx];
+      const float dg = (r < P) ? diag(r) : ((r < RH) ? 1.f : 0.f);
+      re[s][v] = low ? a.x : ((q == r) ? dg : 0.f);
+      im[s][v] = low ? a.y : 0.f;
+    }
+  };
+  constexpr int LG = 4;
 #pragma unroll
-      for (int v = 0; v < 4; v++) {
-        const int r = 16 * ti + 4 * mg + v;
-        const bool low = r < P && q < r;
-        int idx = low ? r * P + q : 0;                              // (P <= 271: 32 bits)
-        asm volatile("" : "+v"(idx));                               // (opaque: keeps the load unconditional)
-        const float2 a = mat[idx];
-        const float dg = (r < P) ? diag(r) : ((r < RH) ? 1.f : 0.f);
-        re[s][v] = low ? a.x : ((q == r) ? dg : 0.f);
-        im[s][v] = low ? a.y : 0.f;
+  for (int s0 = 0; s0 < NS; s0 += LG) {
+#pragma unroll
+    for (int s = s0; s < s0 + LG && s < NS; s++) { re[s] = f32x4{0.f, 0.f, 0.f, 0.f}; im[s] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    const int slast = (s0 + LG - 1 < NS) ? s0 + LG - 1 : NS - 1;
+    int tl_i, tl_j;
+    tile_of(slast, tl_i, tl_j);
+    if (tl_i >= 0) {                                                // tiles are dealt in order: every slot of the group holds one
+#pragma unroll
+      for (int s = s0; s < s0 + LG && s < NS; s++) {
+        int ti, tj;
+        tile_of(s, ti, tj);
+        load_slot(s, ti, tj);
+      }
+    } else {
+#pragma unroll
+      for (int s = s0; s < s0 + LG && s < NS; s++) {
+        int ti, tj;
+        tile_of(s, ti, tj);
+        if (ti >= 0) load_slot(s, ti, tj);
       }
     }
-    if ((s & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_sched_barrier(0);
   }
   // the right-hand-side row: row 15 of the tiles of the last tile row
 #pragma unroll
