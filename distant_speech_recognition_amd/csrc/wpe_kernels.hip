@@ -763,6 +763,7 @@ __device__ unsigned long long lp_phase_cycles[8];
 #else
 #define LP_MARK(i) do { } while (0)
 #endif
+constexpr int LP16_ROWH = 8 * (lp16_nb(8) + 1);                        // halfs per row of a shifted copy: [8 pad][8 LP16_NB values] (8 channels)
 constexpr int LP16_NCP = 4;                                        // shifted copies of the weight span kept in LDS
 typedef unsigned u32x12 __attribute__((ext_vector_type(12)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -804,7 +805,7 @@ __device__ __forceinline__ f16x8 lp16_block(const u32x12& w)
 // resident every LDS wait and every dependent vector instruction is exposed, ~22 cycles per instruction.)
 template <int C, int NR, int NCW>
 __device__ __forceinline__ void lagprod16_task(const float2* __restrict__ Xk, const float* __restrict__ Wk, const WpeGeom& g, float2* __restrict__ R,
-                                               int ys_ld, int ws_ld, int d, int la, int s, int k, float2* ys, float* ws, uint4* wcp,
+                                               int ys_ld, int d, int la, int s, int k, float2* ys, uint4* wcp,
                                                float sa, float sb, const int* __restrict__ te)
 {
   // Columns (round 6): the 2 C^2 = 128 columns are (re | im) x 64 channel pairs; a wavefront's column blocks are the REAL and the
@@ -855,12 +856,12 @@ __device__ __forceinline__ void lagprod16_task(const float2* __restrict__ Xk, co
   // lane are the windows 4 j .. 4 j + 7 of ONE stream -- copy m / C (a shift of 0 .. 3 frames) from the aligned offset kk + 8 lk on --,
   // so the lane reads 4 + 2 (NR - 1) consecutive registers' worth once (two 16-byte words and an 8-byte one at NR = 4) and block j's
   // operand is registers 2 j .. 2 j + 3 of that tuple: 5 LDS reads per 16 frames instead of 8, and only FOUR shifted copies to build.
-  // wcp[((hl LP16_NCP + copy) C + c) LP16_NB + block] (uint4 = 8 float16)
+  // wcp: row (hl LP16_NCP + copy) C + c of [8 pad][8 LP16_NB] float16 (LP16_ROWH / 8 uint4; the lane's stream starts one uint4 in)
   static_assert(RL == 4, "row blocks as windows of one shifted copy");
 #if defined(BTK_LP_ABLATE) && (BTK_LP_ABLATE & 4)              // ablation build: every lane of a half reads the same words
-  const int abase = lk;
+  const int abase = 1 + lk;
 #else
-  const int abase = m * LP16_NB + lk;                              // (copy C + c = m)
+  const int abase = m * (LP16_ROWH / 8) + 1 + lk;                  // (copy C + c = m; uint4 units, behind the row's pad)
 #endif
   // B: x = y_c1(u), q = fb y_c2(u + d) of the lane's pair c1 C + c2
   const int pairl = 32 * (NCW == 2 ? wv : (wv >> 1)) + m;
@@ -909,49 +910,33 @@ __device__ __forceinline__ void lagprod16_task(const float2* __restrict__ Xk, co
           ysq[c * yq_ld + e] = make_float2(v.x * fb, v.y * fb);
         }
       }
-      if (e < ws_ld) {                                             // (the shifted copies read up to 11 values past a block's start: zeros behind the span)
+      // The weight span as its four one-frame shifts, split into float16 high / low parts, written by the thread that holds the value:
+      // copy_s[p] = w[p + s], so thread e writes position e - s of copy s (16-bit stores; two channels share the conversions).  A row
+      // is [8 pad][8 LP16_NB values]: positions -3 .. -1 fall into the row's own pad, positions past the end into the next row's.
+      // (Until here the span went through a float row in LDS and a second step -- 80 threads, twelve dependent LDS reads each, a
+      //  barrier of its own -- rebuilt it as shifted copies.)
+      if (e < 8 * LP16_NB + 8) {
         const bool wl = e < WN && wok;
+        unsigned short* wch = reinterpret_cast<unsigned short*>(wcp);
 #pragma unroll
-        for (int c = 0; c < C; c++) ws[c * ws_ld + e] = wl ? (wpf[c] * sa) * fa : 0.f;
+        for (int c = 0; c < C; c += 2) {
+          const float w0 = wl ? (wpf[c] * sa) * fa : 0.f, w1 = wl ? (wpf[c + 1] * sa) * fa : 0.f;
+          const unsigned hi = pk_hi(w0, w1);
+          const unsigned lo = pk_hi(sub_h_lo(w0, hi), sub_h_hi(w1, hi));
+#pragma unroll
+          for (int sft = 0; sft < LP16_NCP; sft++) {
+            const int pos = 8 + e - sft;                           // halfs from the row's start
+            wch[((0 * LP16_NCP + sft) * C + c) * LP16_ROWH + pos] = (unsigned short)(hi & 0xffffu);
+            wch[((0 * LP16_NCP + sft) * C + c + 1) * LP16_ROWH + pos] = (unsigned short)(hi >> 16);
+            wch[((1 * LP16_NCP + sft) * C + c) * LP16_ROWH + pos] = (unsigned short)(lo & 0xffffu);
+            wch[((1 * LP16_NCP + sft) * C + c + 1) * LP16_ROWH + pos] = (unsigned short)(lo >> 16);
+          }
+        }
       }
     }
-    __syncthreads();
     LP_MARK(1);
-#if defined(BTK_LP_ABLATE) && (BTK_LP_ABLATE & 64)             // ablation build: no global loads after the first tile
-    if (false) prefetch(u0 + LP_WT);
-#else
-    if (u0 + LP_WT < g.T) prefetch(u0 + LP_WT);
-#endif
-    // the weight span of every channel as its four one-frame shifts, each split into float16 high / low parts: unit (c, block b)
-    // reads w[8 b .. 8 b + 11] and writes copy_s[8 b .. 8 b + 7] = w[8 b + s ..] for s = 0 .. 3
-#if defined(BTK_LP_ABLATE) && (BTK_LP_ABLATE & (2 | 16))       // ablation build: the shifted copies are built for the first tile only
-    if (tid < C * LP16_NB && u0 == 0) {
-#else
-    if (tid < C * LP16_NB) {
-#endif
-      const int c = tid / LP16_NB, b = tid % LP16_NB;
-      float wv16[12];
-#pragma unroll
-      for (int i = 0; i < 12; i++) wv16[i] = ws[c * ws_ld + 8 * b + i];   // (ws_ld >= 8 LP16_NB + 4: the launch)
-      unsigned he[6], le[6], ho[5], lo_[5];                         // pairs (2 i, 2 i + 1) and (2 i + 1, 2 i + 2)
-#pragma unroll
-      for (int i = 0; i < 6; i++) { he[i] = pk_hi(wv16[2 * i], wv16[2 * i + 1]); le[i] = pk_hi(sub_h_lo(wv16[2 * i], he[i]), sub_h_hi(wv16[2 * i + 1], he[i])); }
-#pragma unroll
-      for (int i = 0; i < 5; i++) {
-        ho[i] = pk_hi(wv16[2 * i + 1], wv16[2 * i + 2]);
-        lo_[i] = (le[i] >> 16) | (le[i + 1] << 16);                 // (the parts of a value do not depend on its partner in the pair)
-      }
-#pragma unroll
-      for (int sft = 0; sft < LP16_NCP; sft++) {
-        const int h = sft >> 1;
-        uint4 vh, vl;
-        if (sft & 1) { vh = make_uint4(ho[h], ho[h + 1], ho[h + 2], ho[h + 3]); vl = make_uint4(lo_[h], lo_[h + 1], lo_[h + 2], lo_[h + 3]); }
-        else         { vh = make_uint4(he[h], he[h + 1], he[h + 2], he[h + 3]); vl = make_uint4(le[h], le[h + 1], le[h + 2], le[h + 3]); }
-        wcp[((0 * LP16_NCP + sft) * C + c) * LP16_NB + b] = vh;
-        wcp[((1 * LP16_NCP + sft) * C + c) * LP16_NB + b] = vl;
-      }
-    }
     __syncthreads();
+    if (u0 + LP_WT < g.T) prefetch(u0 + LP_WT);
     LP_MARK(2);
 #pragma unroll 1
     for (int kk = 0; kk < LP_WT; kk += 16) {
@@ -959,7 +944,7 @@ __device__ __forceinline__ void lagprod16_task(const float2* __restrict__ Xk, co
       {
         u32x12 wh, wl;                                             // the lane's stream, 2 NR + 2 registers of it
         lp16_window<NR>(wcp + abase + kk / 8, wh);
-        lp16_window<NR>(wcp + LP16_NCP * C * LP16_NB + abase + kk / 8, wl);
+        lp16_window<NR>(wcp + LP16_NCP * C * (LP16_ROWH / 8) + abase + kk / 8, wl);
         if constexpr (NR > 1) asm volatile("" : "+v"(wh), "+v"(wl));   // (one register tuple each: the blocks' operands are sub-ranges of it, not copies)
         ah[0] = lp16_block<0>(wh); al[0] = lp16_block<0>(wl);
         if constexpr (NR > 1) { ah[1] = lp16_block<1>(wh); al[1] = lp16_block<1>(wl); }
@@ -1057,15 +1042,15 @@ __device__ __forceinline__ void lagprod16_task(const float2* __restrict__ Xk, co
 }
 
 template <int C, int NCW>
-__device__ __forceinline__ void wpe_lagprod16_body(const float2* __restrict__ X, const float* __restrict__ Winv, WpeGeom g, float2* __restrict__ R, int ys_ld, int ws_ld,
+__device__ __forceinline__ void wpe_lagprod16_body(const float2* __restrict__ X, const float* __restrict__ Winv, WpeGeom g, float2* __restrict__ R, int ys_ld,
                           const float* __restrict__ scales, const int* __restrict__ tile_exp, int nt_stride, int nstreams)
 {
   constexpr int RL = 32 / C;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int LP16_NB = lp16_nb(C);
-  uint4* wcp = reinterpret_cast<uint4*>(smem);                     // [2 (high | low)][LP16_NCP shifts][C][LP16_NB] x 8 float16
-  float2* ys = reinterpret_cast<float2*>(wcp + 2 * LP16_NCP * C * LP16_NB);   // [C][ys_ld]: sample u0 + e of channel c'
-  float* ws = reinterpret_cast<float*>(ys + C * ys_ld + C * (ys_ld - 1));   // (ys is followed by the scaled second factors, pitch ys_ld - 1) [C][ws_ld]: w_c(u0 + lowerN + la + e), scaled
+  static_assert(LP16_ROWH == 8 * (lp16_nb(C) + 1), "rows of the shifted copies");
+  uint4* wcp = reinterpret_cast<uint4*>(smem);                     // [2 (high | low)][LP16_NCP shifts][C] rows of [8 pad][8 LP16_NB] float16, + one pad behind the last row
+  float2* ys = reinterpret_cast<float2*>(wcp + 2 * LP16_NCP * C * (LP16_ROWH / 8) + 1);   // [C][ys_ld]: sample u0 + e of channel c'
+  // (ys is followed by the scaled second factors, pitch ys_ld - 1)
   // Launch order (round 6): the tasks of a (stream, bin) write the diagonals of the same eight matrices -- every 128-byte line of R takes
   // its sixteen entries from sixteen different tasks.  Workgroups go to the eight XCDs in turn, so with one grid row per bin a line was
   // assembled in eight L2s and left each of them partly written; here blockIdx.x = XCD + 8 task and blockIdx.y = a group of eight bins,
@@ -1088,25 +1073,25 @@ __device__ __forceinline__ void wpe_lagprod16_body(const float2* __restrict__ X,
   const float sa = scales[((long)s * g.K + k) * 2], sb = scales[((long)s * g.K + k) * 2 + 1];
   const int* te = tile_exp + ((long)s * g.K + k) * nt_stride;
   switch (nb) {
-    case 4: lagprod16_task<C, 4, NCW>(Xk, Wk, g, R, ys_ld, ws_ld, d, la, s, k, ys, ws, wcp, sa, sb, te); break;
-    case 3: lagprod16_task<C, 3, NCW>(Xk, Wk, g, R, ys_ld, ws_ld, d, la, s, k, ys, ws, wcp, sa, sb, te); break;
-    case 2: lagprod16_task<C, 2, NCW>(Xk, Wk, g, R, ys_ld, ws_ld, d, la, s, k, ys, ws, wcp, sa, sb, te); break;
-    default: lagprod16_task<C, 1, NCW>(Xk, Wk, g, R, ys_ld, ws_ld, d, la, s, k, ys, ws, wcp, sa, sb, te); break;
+    case 4: lagprod16_task<C, 4, NCW>(Xk, Wk, g, R, ys_ld, d, la, s, k, ys, wcp, sa, sb, te); break;
+    case 3: lagprod16_task<C, 3, NCW>(Xk, Wk, g, R, ys_ld, d, la, s, k, ys, wcp, sa, sb, te); break;
+    case 2: lagprod16_task<C, 2, NCW>(Xk, Wk, g, R, ys_ld, d, la, s, k, ys, wcp, sa, sb, te); break;
+    default: lagprod16_task<C, 1, NCW>(Xk, Wk, g, R, ys_ld, d, la, s, k, ys, wcp, sa, sb, te); break;
   }
 }
 
 // two wavefronts x two column blocks (256 registers per lane: two wavefronts per SIMD) / four x one (168: three per SIMD)
 __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2)))
-void wpe_lagprod16_w2_kernel(const float2* __restrict__ X, const float* __restrict__ Winv, WpeGeom g, float2* __restrict__ R, int ys_ld, int ws_ld,
+void wpe_lagprod16_w2_kernel(const float2* __restrict__ X, const float* __restrict__ Winv, WpeGeom g, float2* __restrict__ R, int ys_ld,
                              const float* __restrict__ scales, const int* __restrict__ tile_exp, int nt_stride, int nstreams)
 {
-  wpe_lagprod16_body<8, 2>(X, Winv, g, R, ys_ld, ws_ld, scales, tile_exp, nt_stride, nstreams);
+  wpe_lagprod16_body<8, 2>(X, Winv, g, R, ys_ld, scales, tile_exp, nt_stride, nstreams);
 }
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3)))
-void wpe_lagprod16_w4_kernel(const float2* __restrict__ X, const float* __restrict__ Winv, WpeGeom g, float2* __restrict__ R, int ys_ld, int ws_ld,
+void wpe_lagprod16_w4_kernel(const float2* __restrict__ X, const float* __restrict__ Winv, WpeGeom g, float2* __restrict__ R, int ys_ld,
                              const float* __restrict__ scales, const int* __restrict__ tile_exp, int nt_stride, int nstreams)
 {
-  wpe_lagprod16_body<8, 1>(X, Winv, g, R, ys_ld, ws_ld, scales, tile_exp, nt_stride, nstreams);
+  wpe_lagprod16_body<8, 1>(X, Winv, g, R, ys_ld, scales, tile_exp, nt_stride, nstreams);
 }
 
 template <int C>
@@ -1387,15 +1372,13 @@ int btk_wpe_estimate(const void* X, int S, int K, int C, long T_stride, long T, 
       const size_t lds_lp = sizeof(float2) * (size_t)C * ys_ld + sizeof(float) * (size_t)C * ws_ld;
       if (!btk_switches().wpe_lagprod_f32 && C == 8) {
         // round 5: float16-split operands on the 16 x faster matrix instruction (see lagprod16_task)
-        const int nb16 = lp16_nb(C);
-        const int ws16 = 8 * nb16 + 8;                                         // >= 8 (nb16 - 1) + 15 values (40 KB of LDS per task with this: four tasks per CU)
         int ys16 = LP_WT + g.L; while (ys16 % 32 != 2) ys16++;                 // float2 row pitch of the samples: the four rows x two lane halves of a 16-byte read on disjoint banks; the scaled second factors follow at pitch ys16 - 1
-        const size_t lds16p = sizeof(uint4) * 2 * LP16_NCP * (size_t)C * nb16 + sizeof(float2) * (size_t)C * (2 * ys16 - 1) + sizeof(float) * (size_t)C * ws16 + sizeof(float) * 8;
+        const size_t lds16p = sizeof(uint4) * (2 * LP16_NCP * (size_t)C * (LP16_ROWH / 8) + 1) + sizeof(float2) * (size_t)C * (2 * ys16 - 1);   // 23.8 KB at 33 lags
         hipLaunchKernelGGL(wpe_lp_scale_kernel, dim3((unsigned)K, (unsigned)S), dim3(256), 0, st, Xp, Winv, g, lp_scales, lp_tile_exp, nt_stride);
         if (btk_switches().wpe_lagprod_waves == 2)
-          hipLaunchKernelGGL(wpe_lagprod16_w2_kernel, dim3(8 * ntask, (unsigned)((K * S + 7) / 8)), dim3(128), lds16p, st, Xp, Winv, g, R, ys16, ws16, lp_scales, lp_tile_exp, nt_stride, S);
+          hipLaunchKernelGGL(wpe_lagprod16_w2_kernel, dim3(8 * ntask, (unsigned)((K * S + 7) / 8)), dim3(128), lds16p, st, Xp, Winv, g, R, ys16, lp_scales, lp_tile_exp, nt_stride, S);
         else
-          hipLaunchKernelGGL(wpe_lagprod16_w4_kernel, dim3(8 * ntask, (unsigned)((K * S + 7) / 8)), dim3(256), lds16p, st, Xp, Winv, g, R, ys16, ws16, lp_scales, lp_tile_exp, nt_stride, S);
+          hipLaunchKernelGGL(wpe_lagprod16_w4_kernel, dim3(8 * ntask, (unsigned)((K * S + 7) / 8)), dim3(256), lds16p, st, Xp, Winv, g, R, ys16, lp_scales, lp_tile_exp, nt_stride, S);
       }
       else if (C == 8) hipLaunchKernelGGL(wpe_lagprod_kernel<8>, dim3(ntask, (unsigned)K, (unsigned)S), dim3(64), lds_lp, st, Xp, Winv, g, R, ys_ld, ws_ld);
       else        hipLaunchKernelGGL(wpe_lagprod_kernel<4>, dim3(ntask, (unsigned)K, (unsigned)S), dim3(64), lds_lp, st, Xp, Winv, g, R, ys_ld, ws_ld);
